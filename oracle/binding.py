@@ -1,0 +1,320 @@
+"""ctypes binding of oracle/liboracle.so (+ the optional oracle/_ref libraries).
+
+TEST INFRASTRUCTURE ONLY: the checker, never the thing measured or shipped.
+"""
+import ctypes as C
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+KMER_DT = np.dtype([("kmer", "<u8"), ("meta", "<u4"), ("offset", "<u4")])
+OVERLAP_DT = np.dtype([("read", "<u4"), ("entry", "<u4"), ("rel", "<i4"),
+                       ("revcomp", "u1"), ("pad", "u1", (3,))])
+ALIGN_DT = np.dtype([("read", "<u4"), ("entry", "<u4"), ("rel", "<i4"),
+                     ("revcomp", "u1"), ("pad", "u1"), ("score", "<u2"),
+                     ("ref_begin", "<i4"), ("ref_end", "<i4"),
+                     ("query_begin", "<i4"), ("query_end", "<i4"),
+                     ("cigar_len", "<u4"), ("pad2", "<u4"), ("cigar_off", "<u8")])
+assert KMER_DT.itemsize == 16 and OVERLAP_DT.itemsize == 16
+assert ALIGN_DT.itemsize == 48
+
+
+class Params(C.Structure):
+    """orc_params: the scoring globals of reference src/Globals.h:27-36."""
+    _fields_ = [("match", C.c_uint32), ("mismatch", C.c_uint32),
+                ("gap_open", C.c_uint32), ("gap_extend", C.c_uint32),
+                ("score_threshold", C.c_uint32), ("report_cigar", C.c_int32)]
+
+    @classmethod
+    def default(cls, report_cigar=True, score_threshold=0, match=2, mismatch=3,
+                gap_open=5, gap_extend=2):
+        # defaults of reference src/main.cpp:44-55
+        return cls(match, mismatch, gap_open, gap_extend, score_threshold,
+                   1 if report_cigar else 0)
+
+
+class SswResult(C.Structure):
+    _fields_ = [("score1", C.c_uint16), ("ref_begin1", C.c_int32),
+                ("ref_end1", C.c_int32), ("read_begin1", C.c_int32),
+                ("read_end1", C.c_int32), ("cigar_len", C.c_int32),
+                ("status", C.c_int32)]
+
+
+def build(force=False):
+    """Compile liboracle.so (and oracle/_ref when /root/reference exists)."""
+    so = os.path.join(_HERE, "liboracle.so")
+    if force or not os.path.exists(so) or (
+            os.path.getmtime(so) < os.path.getmtime(os.path.join(_HERE, "kslam_oracle.c"))):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    elif os.path.isdir("/root/reference/src") and not os.path.exists(
+            os.path.join(_HERE, "_ref", "libssw_ref.so")):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "ref"])
+    return so
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        so = build()
+        L = C.CDLL(so)
+        u64, u32, i32, vp = C.c_uint64, C.c_uint32, C.c_int32, C.c_void_p
+        L.orc_count_kmers.restype = u64
+        L.orc_count_kmers.argtypes = [u64, C.c_uint]
+        L.orc_extract_all.restype = u64
+        L.orc_extract_all.argtypes = [u64, vp, vp, C.c_int, C.c_uint, vp]
+        L.orc_sort_kmers.argtypes = [vp, u64]
+        L.orc_count_overlaps.restype = u64
+        L.orc_count_overlaps.argtypes = [vp, u64]
+        L.orc_find_overlaps.restype = u64
+        L.orc_find_overlaps.argtypes = [vp, u64, vp, vp, vp]
+        L.orc_build_matrix.argtypes = [u32, u32, vp]
+        L.orc_translate.argtypes = [C.c_char_p, i32, vp]
+        for f in (L.orc_ssw_align, L.orc_ssw_align_plain):
+            f.argtypes = [vp, i32, vp, i32, vp, C.c_uint8, C.c_uint8, C.c_uint8,
+                          C.c_uint16, i32, vp, i32, C.POINTER(SswResult)]
+        L.orc_banded_sw.restype = i32
+        L.orc_banded_sw.argtypes = [vp, vp, i32, i32, i32, u32, u32, i32, vp, i32, vp, i32, vp]
+        L.orc_align.argtypes = [C.c_char_p, i32, C.c_char_p, i32, C.POINTER(Params),
+                                vp, i32, C.POINTER(SswResult), C.c_int]
+        L.orc_sw_on_overlap.argtypes = [vp, C.c_char_p, u64, C.c_char_p, u64,
+                                        C.POINTER(Params), vp, vp, i32, C.c_int]
+        L.orc_align_to_database.restype = C.c_int
+        L.orc_align_to_database.argtypes = [u64, vp, vp, u64, vp, vp, C.POINTER(Params),
+                                            C.c_int, C.POINTER(vp), C.POINTER(u64),
+                                            C.POINTER(vp), C.POINTER(u64), vp]
+        L.orc_free.argtypes = [vp]
+        L.orc_use_reference_ssw.restype = C.c_int
+        L.orc_use_reference_ssw.argtypes = [C.c_char_p]
+        L.orc_num_threads.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def _seq_arrays(seqs):
+    """list[bytes] -> (char** array, uint64 lens, keepalive)."""
+    n = len(seqs)
+    bufs = [C.create_string_buffer(s, len(s) + 1) for s in seqs]
+    ptrs = (C.c_char_p * max(n, 1))(*[C.cast(b, C.c_char_p) for b in bufs])
+    lens = np.array([len(s) for s in seqs], dtype=np.uint64)
+    return ptrs, lens, bufs
+
+
+def extract_kmers(seqs, is_gb, gap):
+    """getKMers_parallel (reference src/KMer.h:190-241) over a list of bytes."""
+    L = lib()
+    ptrs, lens, keep = _seq_arrays(seqs)
+    tot = sum(int(L.orc_count_kmers(int(x), gap)) for x in lens)
+    out = np.zeros(tot, dtype=KMER_DT)
+    got = L.orc_extract_all(len(seqs), C.cast(ptrs, C.c_void_p), lens.ctypes.data,
+                            int(is_gb), gap, out.ctypes.data)
+    assert got == tot
+    return out
+
+
+def sort_kmers(recs):
+    """sortKMers (reference src/KMer.h:388-398); returns a sorted copy."""
+    out = np.ascontiguousarray(recs.copy())
+    lib().orc_sort_kmers(out.ctypes.data, len(out))
+    return out
+
+
+def find_overlaps(sorted_recs, read_lens):
+    """findOverlaps_parallel (reference src/Overlap.h:277-295)."""
+    L = lib()
+    s = np.ascontiguousarray(sorted_recs)
+    rl = np.ascontiguousarray(np.asarray(read_lens, dtype=np.uint64))
+    raw = int(L.orc_count_overlaps(s.ctypes.data, len(s)))
+    out = np.zeros(raw + 1, dtype=OVERLAP_DT)
+    nraw = C.c_uint64(0)
+    m = L.orc_find_overlaps(s.ctypes.data, len(s), rl.ctypes.data, out.ctypes.data,
+                            C.byref(nraw))
+    return out[:m].copy(), int(nraw.value)
+
+
+def build_matrix(match, mismatch):
+    m = np.zeros(25, dtype=np.int8)
+    lib().orc_build_matrix(match, mismatch, m.ctypes.data)
+    return m
+
+
+def translate(seq):
+    out = np.zeros(max(len(seq), 1), dtype=np.int8)
+    lib().orc_translate(seq, len(seq), out.ctypes.data)
+    return out[:len(seq)]
+
+
+def ssw_align(read_codes, ref_codes, mat, gap_open, gap_extend, flag=0x0f,
+              filters=0, filterd=32767, plain=False):
+    """ssw_align (reference src/ssw.c:841-951) on translated sequences."""
+    L = lib()
+    rd = np.ascontiguousarray(read_codes, dtype=np.int8)
+    rf = np.ascontiguousarray(ref_codes, dtype=np.int8)
+    cap = 2 * (len(rd) + len(rf)) + 8
+    cig = np.zeros(cap, dtype=np.uint32)
+    res = SswResult()
+    f = L.orc_ssw_align_plain if plain else L.orc_ssw_align
+    f(rd.ctypes.data, len(rd), rf.ctypes.data, len(rf), mat.ctypes.data, gap_open,
+      gap_extend, flag, filters, filterd, cig.ctypes.data, cap, C.byref(res))
+    return res, cig[:max(res.cigar_len, 0)].copy()
+
+
+def align(query, ref, params=None, plain=False):
+    """Aligner::Align (reference src/ssw_cpp.cpp:234-283) on ASCII bytes."""
+    p = params or Params.default()
+    cap = 2 * (len(query) + len(ref)) + 8
+    cig = np.zeros(cap, dtype=np.uint32)
+    res = SswResult()
+    lib().orc_align(query, len(query), ref, len(ref), C.byref(p), cig.ctypes.data, cap,
+                    C.byref(res), int(plain))
+    return res, cig[:max(res.cigar_len, 0)].copy()
+
+
+def align_to_database(reads, entries, params=None, plain=False):
+    """alignToDatabase (reference src/SLAM.h:59-79).
+
+    Returns (alignments[ALIGN_DT], cigar_pool[uint32], phase_seconds[6])."""
+    L = lib()
+    p = params or Params.default()
+    rp, rl, k1 = _seq_arrays(reads)
+    ep, el, k2 = _seq_arrays(entries)
+    out, cig = C.c_void_p(), C.c_void_p()
+    n_out, n_cig = C.c_uint64(), C.c_uint64()
+    ph = np.zeros(6, dtype=np.float64)
+    rc = L.orc_align_to_database(len(reads), C.cast(rp, C.c_void_p), rl.ctypes.data,
+                                 len(entries), C.cast(ep, C.c_void_p), el.ctypes.data,
+                                 C.byref(p), int(plain), C.byref(out), C.byref(n_out),
+                                 C.byref(cig), C.byref(n_cig), ph.ctypes.data)
+    if rc != 0:
+        raise MemoryError("orc_align_to_database failed")
+    n, nc = int(n_out.value), int(n_cig.value)
+    al = np.frombuffer((C.c_char * (n * ALIGN_DT.itemsize)).from_address(out.value),
+                       dtype=ALIGN_DT).copy() if n else np.zeros(0, dtype=ALIGN_DT)
+    cg = np.frombuffer((C.c_char * (nc * 4)).from_address(cig.value),
+                       dtype=np.uint32).copy() if nc else np.zeros(0, dtype=np.uint32)
+    L.orc_free(out)
+    L.orc_free(cig)
+    return al, cg, ph
+
+
+def num_threads():
+    return int(lib().orc_num_threads())
+
+
+# ---------------------------------------------------------------------------
+# the REAL reference, compiled in place into oracle/_ref (may be absent)
+# ---------------------------------------------------------------------------
+REF_SSW = os.path.join(_HERE, "_ref", "libssw_ref.so")
+REF_KMER = os.path.join(_HERE, "_ref", "libkmer_ref.so")
+
+
+def have_ref_ssw():
+    build()
+    return os.path.exists(REF_SSW)
+
+
+def have_ref_kmer():
+    build()
+    return os.path.exists(REF_KMER)
+
+
+def use_reference_ssw(enable=True):
+    """Route orc_align's SSW core through the real ssw.c (cpu_baseline leg)."""
+    if enable and not have_ref_ssw():
+        return False
+    rc = lib().orc_use_reference_ssw(REF_SSW.encode() if enable else None)
+    return rc == 0
+
+
+class _RefSAlign(C.Structure):  # s_align, reference src/ssw.h:47-57
+    _fields_ = [("score1", C.c_uint16), ("score2", C.c_uint16),
+                ("ref_begin1", C.c_int32), ("ref_end1", C.c_int32),
+                ("read_begin1", C.c_int32), ("read_end1", C.c_int32),
+                ("ref_end2", C.c_int32), ("cigar", C.POINTER(C.c_uint32)),
+                ("cigarLen", C.c_int32)]
+
+
+_ref_ssw = None
+
+
+def ref_ssw_align(read_codes, ref_codes, mat, gap_open, gap_extend, flag=0x0f,
+                  filters=0, filterd=32767):
+    """Call the reference's own ssw_init + ssw_align (src/ssw.c:808,841)."""
+    global _ref_ssw
+    if _ref_ssw is None:
+        R = C.CDLL(REF_SSW)
+        R.ssw_init.restype = C.c_void_p
+        R.ssw_init.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int8]
+        R.ssw_align.restype = C.POINTER(_RefSAlign)
+        R.ssw_align.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_uint8, C.c_uint8,
+                                C.c_uint8, C.c_uint16, C.c_int32, C.c_int32]
+        R.init_destroy.argtypes = [C.c_void_p]
+        R.align_destroy.argtypes = [C.POINTER(_RefSAlign)]
+        _ref_ssw = R
+    R = _ref_ssw
+    rd = np.ascontiguousarray(read_codes, dtype=np.int8)
+    rf = np.ascontiguousarray(ref_codes, dtype=np.int8)
+    prof = R.ssw_init(rd.ctypes.data, len(rd), mat.ctypes.data, 5, 2)
+    a = R.ssw_align(prof, rf.ctypes.data, len(rf), gap_open, gap_extend, flag, filters,
+                    filterd, len(rd))
+    s = a.contents
+    cig = np.array([s.cigar[i] for i in range(s.cigarLen)], dtype=np.uint32) \
+        if s.cigar else np.zeros(0, dtype=np.uint32)
+    res = (s.score1, s.ref_begin1, s.ref_end1, s.read_begin1, s.read_end1)
+    R.align_destroy(a)
+    R.init_destroy(prof)
+    return res, cig
+
+
+_ref_kmer = None
+
+
+def _refk():
+    global _ref_kmer
+    if _ref_kmer is None:
+        R = C.CDLL(REF_KMER)
+        R.ref_extract_kmers.restype = C.c_uint64
+        R.ref_extract_kmers.argtypes = [C.c_uint64, C.c_void_p, C.c_void_p, C.c_int,
+                                        C.c_uint, C.c_void_p, C.c_uint64]
+        R.ref_sort_kmers.restype = C.c_int
+        R.ref_sort_kmers.argtypes = [C.c_void_p, C.c_uint64, C.c_char_p]
+        R.ref_kmer3.argtypes = [C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        _ref_kmer = R
+    return _ref_kmer
+
+
+def ref_extract_kmers(seqs, is_gb, gap):
+    """The reference's getKMers_parallel (src/KMer.h:190-241) itself."""
+    R = _refk()
+    ptrs, lens, keep = _seq_arrays(seqs)
+    cap = sum(max(0, (len(s) - 32) // gap + 1) if len(s) >= 32 else 0 for s in seqs) + 16
+    out = np.zeros(cap, dtype=KMER_DT)
+    n = R.ref_extract_kmers(len(seqs), C.cast(ptrs, C.c_void_p), lens.ctypes.data,
+                            int(is_gb), gap, out.ctypes.data, cap)
+    assert n <= cap
+    return out[:n].copy()
+
+
+def ref_sort_kmers(recs):
+    """The reference's sortKMers (src/KMer.h:388-398) itself."""
+    out = np.ascontiguousarray(recs.copy())
+    with tempfile.TemporaryDirectory() as d:
+        rc = _refk().ref_sort_kmers(out.ctypes.data, len(out), d.encode())
+    assert rc == 0
+    return out
+
+
+def ref_kmer3(s):
+    f, r = C.c_uint32(), C.c_uint32()
+    _refk().ref_kmer3(s, C.byref(f), C.byref(r))
+    return int(f.value), int(r.value)
+
+
+def cigar_string(cig):
+    return "".join("%d%s" % (int(c) >> 4, "MID"[int(c) & 15]) for c in cig)

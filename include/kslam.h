@@ -1,0 +1,180 @@
+/*
+ * kslam.h -- C ABI of the MI355X-native k-SLAM alignment hot path.
+ *
+ * One shared library (k-slam_amd/libkslam_hip.so, HIP for gfx950) exports
+ * exactly these symbols.  Plain pointers and sizes only: no C++ types, no
+ * torch types, no exceptions across the boundary.  Every call returns a
+ * kslam_status; kslam_last_error() gives the message.
+ *
+ * The boundary replaces, in the reference (citations into /root/reference/):
+ *
+ *   alignToDatabase(reads, genbankIndex) -> std::vector<Overlap>
+ *                                                     src/SLAM.h:59-79
+ *
+ * i.e. getKMersFromReads (src/KMer.h:373-381), GenbankIndex::getKMers
+ * (src/GenbankTools.h:211-219), sortKMers (src/KMer.h:388-398),
+ * findOverlaps_parallel (src/Overlap.h:277-295) and
+ * performSmithWatermanOnRange_parallel (src/SmithWaterman.h:234-249).
+ * INTEGRATION.md shows the reference-side binding.
+ */
+#ifndef KSLAM_H_
+#define KSLAM_H_
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KSLAM_ABI_VERSION 1
+#define KSLAM_K 32u /* src/Globals.h:25 */
+
+typedef enum {
+  KSLAM_OK = 0,
+  KSLAM_ERR_ARG = 1,         /* bad argument */
+  KSLAM_ERR_NO_DEVICE = 2,   /* no usable HIP device / HIP runtime failure */
+  KSLAM_ERR_OOM = 3,         /* host or device allocation failed */
+  KSLAM_ERR_UNSUPPORTED = 4, /* outside the supported envelope */
+  KSLAM_ERR_STATE = 5,       /* call order (e.g. align before set_index) */
+  KSLAM_ERR_INTERNAL = 6     /* device-side consistency check failed */
+} kslam_status;
+
+/* The implicit inputs of alignToDatabase: the scoring globals
+ * src/Globals.h:27-31,36 as set from the CLI (src/main.cpp:44-55) and
+ * reportCigar = (samFile != "") (src/SLAM.h:169). */
+typedef struct {
+  uint32_t match;           /* --match-score        default 2 */
+  uint32_t mismatch;        /* --mismatch-penalty   default 3 */
+  uint32_t gap_open;        /* --gap-open           default 5 */
+  uint32_t gap_extend;      /* --gap-extend         default 2 */
+  uint32_t score_threshold; /* --min-alignment-score default 0 */
+  int32_t report_cigar;     /* reportCigar */
+  int32_t device;           /* HIP device ordinal this context owns */
+  uint32_t max_kmers_per_chunk; /* 0 = default; internal read sub-batching */
+} kslam_params;
+
+/* KMerAndData<uint64_t,32>, src/KMer.h:58-116: 16 bytes, little endian.
+ * meta = id & 0x3FFFFFFF | isFromGB << 31 | revComp << 30 (src/KMer.h:65-67) */
+typedef struct {
+  uint64_t kmer;
+  uint32_t meta;
+  uint32_t offset;
+} kslam_kmer;
+
+/* OverlapTemp, src/Overlap.h:36-52 */
+typedef struct {
+  uint32_t read;   /* readPosInArray */
+  uint32_t entry;  /* entryPosInArray */
+  int32_t rel;     /* relativePosition */
+  uint8_t revcomp; /* revComp */
+  uint8_t pad[3];
+} kslam_overlap_temp;
+
+/* Overlap (src/Overlap.h:53-74) with its StripedSmithWaterman::Alignment
+ * (src/ssw_cpp.h:10-87) flattened; the malloc'ed cigar becomes a slice
+ * [cigar_off, cigar_off + cigar_len) of the batch's cigar pool (BAM packing
+ * len << 4 | op, op M=0 I=1 D=2). */
+typedef struct {
+  uint32_t read;
+  uint32_t entry;
+  int32_t rel;
+  uint8_t revcomp;
+  uint8_t pad;
+  uint16_t score; /* sw_score */
+  int32_t ref_begin;
+  int32_t ref_end;
+  int32_t query_begin;
+  int32_t query_end;
+  uint32_t cigar_len;
+  uint32_t pad2;
+  uint64_t cigar_off;
+} kslam_overlap;
+
+/* Device time per phase of the last kslam_align_* call, from HIP events on
+ * the context's own stream, in milliseconds; plus work counters. */
+typedef struct {
+  float ms_extract;     /* read k-mer extraction */
+  float ms_sort;        /* k-mer radix sort (histogram + all passes) */
+  float ms_sort_scatter;/* the onesweep scatter passes only */
+  float ms_join;        /* merge-join + overlap sort + dedupe */
+  float ms_sw;          /* forward + reverse Smith-Waterman passes */
+  float ms_cigar;       /* banded traceback */
+  float ms_total;       /* first kernel to last kernel */
+  uint32_t sort_passes; /* radix passes executed per k-mer sort */
+  uint64_t n_read_kmers;
+  uint64_t n_genome_kmers;
+  uint64_t n_overlaps_raw;   /* before sort + unique */
+  uint64_t n_overlaps;       /* candidates that went through SW */
+  uint64_t sw_cells;         /* forward-pass DP cells (query_len * window_len) */
+  uint32_t n_chunks;
+  uint32_t n_scatter_launches;
+} kslam_timings;
+
+typedef struct kslam_ctx kslam_ctx;
+
+/* ---- lifecycle ------------------------------------------------------- */
+uint32_t kslam_abi_version(void);
+kslam_status kslam_create(const kslam_params *params, kslam_ctx **out);
+void kslam_destroy(kslam_ctx *ctx);
+const char *kslam_last_error(const kslam_ctx *ctx);
+
+/* ---- the index: const GenbankIndex& (src/GenbankTools.h:187-220) ------
+ * entries[j].bases, already upper-cased by the DB builder
+ * (src/GenbankTools.h:256-258).  One-time: uploads the bases and builds the
+ * resident, sorted genome k-mer list (gap = k/2, src/SLAM.h:64). */
+kslam_status kslam_set_index(kslam_ctx *ctx, uint64_t n_entries,
+                             const char *const *bases, const uint64_t *lens);
+/* same, bases already in device memory: entry j occupies
+ * d_bases[h_offsets[j] .. h_offsets[j+1]) */
+kslam_status kslam_set_index_device(kslam_ctx *ctx, uint64_t n_entries,
+                                    const void *d_bases,
+                                    const uint64_t *h_offsets);
+
+/* ---- the operator: alignToDatabase, src/SLAM.h:59-79 -------------------
+ * reads[i].bases used verbatim (src/FASTQsequence.h:46).  Output: overlaps
+ * sorted by (read, entry, rel) after the reference's dedupe, each with its
+ * alignment; cigar present iff report_cigar && score >= score_threshold
+ * (src/ssw.c:924).  Buffers are owned by the library until
+ * kslam_free_batch. */
+kslam_status kslam_align_batch(kslam_ctx *ctx, uint64_t n_reads,
+                               const char *const *bases, const uint32_t *lens,
+                               kslam_overlap **out, uint64_t *n_out,
+                               uint32_t **cigar_pool, uint64_t *n_cigar);
+void kslam_free_batch(kslam_ctx *ctx, kslam_overlap *out, uint32_t *cigar_pool);
+
+/* ---- the same operator in three steps, for callers that keep the batch
+ * resident in HBM (bench.py, multi-GPU sharding) --------------------------- */
+kslam_status kslam_load_reads(kslam_ctx *ctx, uint64_t n_reads,
+                              const char *concat, const uint64_t *offsets);
+kslam_status kslam_load_reads_device(kslam_ctx *ctx, uint64_t n_reads,
+                                     const void *d_concat,
+                                     const uint64_t *h_offsets);
+kslam_status kslam_align_resident(kslam_ctx *ctx, uint64_t *n_out,
+                                  uint64_t *n_cigar);
+kslam_status kslam_fetch_results(kslam_ctx *ctx, kslam_overlap *out,
+                                 uint32_t *cigar_pool);
+/* device-to-device copy of the last results (for a RCCL gather) */
+kslam_status kslam_copy_results_device(kslam_ctx *ctx, void *d_overlaps,
+                                       void *d_cigar_pool);
+kslam_status kslam_get_timings(const kslam_ctx *ctx, kslam_timings *out);
+
+/* ---- stage-level entry points (parity tests of SURVEY section 8a rows) - */
+/* getKMers_parallel, src/KMer.h:190-241 */
+kslam_status kslam_extract_kmers(kslam_ctx *ctx, uint64_t n,
+                                 const char *const *bases,
+                                 const uint64_t *lens, int is_from_genbank,
+                                 uint32_t gap, kslam_kmer *out, uint64_t cap,
+                                 uint64_t *n_out);
+/* sortKMers, src/KMer.h:388-398 (kmer asc, meta desc; input order kept among
+ * exact ties) */
+kslam_status kslam_sort_kmers(kslam_ctx *ctx, kslam_kmer *recs, uint64_t n);
+/* findOverlaps_parallel, src/Overlap.h:277-295, on the loaded reads against
+ * the resident index */
+kslam_status kslam_find_overlaps(kslam_ctx *ctx, kslam_overlap_temp **out,
+                                 uint64_t *n_out, uint64_t *n_raw);
+void kslam_free(void *p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KSLAM_H_ */

@@ -1,0 +1,253 @@
+"""kslam_amd -- Python plumbing over the C ABI of libkslam_hip.so (include/kslam.h).
+
+The product is the HIP library; this module only loads it with ctypes so that
+tests/ and bench.py can drive it.  There is no CPU fallback: if the library is
+missing it raises, and on a box without a HIP device every call fails with
+KSLAM_ERR_NO_DEVICE.
+
+The directory is named ``k-slam_amd`` (not importable by name); load it with
+``tests/conftest.py``'s helper or ``importlib`` (see ``load_package`` in
+``__graft_entry__.py``).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libkslam_hip.so")
+
+KMER_DT = np.dtype([("kmer", "<u8"), ("meta", "<u4"), ("offset", "<u4")])
+OVERLAP_TEMP_DT = np.dtype([("read", "<u4"), ("entry", "<u4"), ("rel", "<i4"),
+                            ("revcomp", "u1"), ("pad", "u1", (3,))])
+OVERLAP_DT = np.dtype([("read", "<u4"), ("entry", "<u4"), ("rel", "<i4"),
+                       ("revcomp", "u1"), ("pad", "u1"), ("score", "<u2"),
+                       ("ref_begin", "<i4"), ("ref_end", "<i4"),
+                       ("query_begin", "<i4"), ("query_end", "<i4"),
+                       ("cigar_len", "<u4"), ("pad2", "<u4"), ("cigar_off", "<u8")])
+assert OVERLAP_DT.itemsize == 48
+
+STATUS = {0: "OK", 1: "ERR_ARG", 2: "ERR_NO_DEVICE", 3: "ERR_OOM", 4: "ERR_UNSUPPORTED",
+          5: "ERR_STATE", 6: "ERR_INTERNAL"}
+
+# every symbol include/kslam.h declares
+EXPORTS = ["kslam_abi_version", "kslam_create", "kslam_destroy", "kslam_last_error",
+           "kslam_set_index", "kslam_set_index_device", "kslam_align_batch", "kslam_free_batch",
+           "kslam_load_reads", "kslam_load_reads_device", "kslam_align_resident",
+           "kslam_fetch_results", "kslam_copy_results_device", "kslam_get_timings",
+           "kslam_extract_kmers", "kslam_sort_kmers", "kslam_find_overlaps", "kslam_free"]
+
+
+class Params(C.Structure):
+    """kslam_params: the scoring globals of reference src/Globals.h:27-36."""
+    _fields_ = [("match", C.c_uint32), ("mismatch", C.c_uint32), ("gap_open", C.c_uint32),
+                ("gap_extend", C.c_uint32), ("score_threshold", C.c_uint32),
+                ("report_cigar", C.c_int32), ("device", C.c_int32),
+                ("max_kmers_per_chunk", C.c_uint32)]
+
+
+class Timings(C.Structure):
+    _fields_ = [("ms_extract", C.c_float), ("ms_sort", C.c_float), ("ms_sort_scatter", C.c_float),
+                ("ms_join", C.c_float), ("ms_sw", C.c_float), ("ms_cigar", C.c_float),
+                ("ms_total", C.c_float), ("sort_passes", C.c_uint32),
+                ("n_read_kmers", C.c_uint64), ("n_genome_kmers", C.c_uint64),
+                ("n_overlaps_raw", C.c_uint64), ("n_overlaps", C.c_uint64),
+                ("sw_cells", C.c_uint64), ("n_chunks", C.c_uint32),
+                ("n_scatter_launches", C.c_uint32)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class KslamError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__("kslam status %s: %s" % (STATUS.get(status, status), msg))
+        self.status = status
+
+
+def build_library(force=False):
+    """hipcc --offload-arch=gfx950 build of libkslam_hip.so (cross-compiles without a GPU)."""
+    csrc = os.path.join(_HERE, "csrc")
+    if force:
+        subprocess.check_call(["make", "-C", csrc, "-s", "clean"])
+    subprocess.check_call(["make", "-C", csrc, "-s", "-j8"])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("%s is missing: run __graft_entry__.build() (hipcc) first; "
+                              "there is no CPU fallback" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        vp, u64, u32 = C.c_void_p, C.c_uint64, C.c_uint32
+        L.kslam_abi_version.restype = u32
+        L.kslam_create.argtypes = [C.POINTER(Params), C.POINTER(vp)]
+        L.kslam_destroy.argtypes = [vp]
+        L.kslam_last_error.restype = C.c_char_p
+        L.kslam_last_error.argtypes = [vp]
+        L.kslam_set_index.argtypes = [vp, u64, vp, vp]
+        L.kslam_set_index_device.argtypes = [vp, u64, vp, vp]
+        L.kslam_align_batch.argtypes = [vp, u64, vp, vp, C.POINTER(vp), C.POINTER(u64),
+                                        C.POINTER(vp), C.POINTER(u64)]
+        L.kslam_free_batch.argtypes = [vp, vp, vp]
+        L.kslam_load_reads.argtypes = [vp, u64, vp, vp]
+        L.kslam_load_reads_device.argtypes = [vp, u64, vp, vp]
+        L.kslam_align_resident.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
+        L.kslam_fetch_results.argtypes = [vp, vp, vp]
+        L.kslam_copy_results_device.argtypes = [vp, vp, vp]
+        L.kslam_get_timings.argtypes = [vp, C.POINTER(Timings)]
+        L.kslam_extract_kmers.argtypes = [vp, u64, vp, vp, C.c_int, u32, vp, u64, C.POINTER(u64)]
+        L.kslam_sort_kmers.argtypes = [vp, vp, u64]
+        L.kslam_find_overlaps.argtypes = [vp, C.POINTER(vp), C.POINTER(u64), C.POINTER(u64)]
+        L.kslam_free.argtypes = [vp]
+        _lib = L
+    return _lib
+
+
+def _seq_arrays(seqs):
+    n = len(seqs)
+    bufs = [C.create_string_buffer(s, len(s) + 1) for s in seqs]
+    ptrs = (C.c_char_p * max(n, 1))(*[C.cast(b, C.c_char_p) for b in bufs])
+    return ptrs, bufs
+
+
+def _concat(seqs):
+    lens = np.fromiter((len(s) for s in seqs), dtype=np.uint64, count=len(seqs))
+    off = np.zeros(len(seqs) + 1, dtype=np.uint64)
+    np.cumsum(lens, out=off[1:])
+    cat = np.frombuffer(b"".join(seqs) + b"\0", dtype=np.uint8)
+    return cat, off
+
+
+class Context:
+    """One kslam_ctx: one process, one GPU (reference threading model: src/SLAM.h:59 is
+    called from the main thread once per batch)."""
+
+    def __init__(self, match=2, mismatch=3, gap_open=5, gap_extend=2, score_threshold=0,
+                 report_cigar=True, device=0, max_kmers_per_chunk=0):
+        self._L = lib()
+        self._h = C.c_void_p()
+        p = Params(match, mismatch, gap_open, gap_extend, score_threshold,
+                   1 if report_cigar else 0, device, max_kmers_per_chunk)
+        st = self._L.kslam_create(C.byref(p), C.byref(self._h))
+        if st != 0:
+            msg = self._L.kslam_last_error(self._h).decode() if self._h else "create failed"
+            if self._h:
+                self._L.kslam_destroy(self._h)
+                self._h = C.c_void_p()
+            raise KslamError(st, msg)
+
+    def close(self):
+        if self._h:
+            self._L.kslam_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, st):
+        if st != 0:
+            raise KslamError(st, self._L.kslam_last_error(self._h).decode())
+
+    # ---- const GenbankIndex& ----
+    def set_index(self, entries):
+        ptrs, keep = _seq_arrays(entries)
+        lens = np.array([len(s) for s in entries], dtype=np.uint64)
+        self._chk(self._L.kslam_set_index(self._h, len(entries), C.cast(ptrs, C.c_void_p),
+                                          lens.ctypes.data))
+
+    def set_index_device(self, n_entries, dev_ptr, host_offsets):
+        off = np.ascontiguousarray(host_offsets, dtype=np.uint64)
+        self._chk(self._L.kslam_set_index_device(self._h, n_entries, dev_ptr, off.ctypes.data))
+
+    # ---- alignToDatabase ----
+    def align_batch(self, reads):
+        """alignToDatabase(reads, index): returns (overlaps[OVERLAP_DT], cigar_pool[u32])."""
+        ptrs, keep = _seq_arrays(reads)
+        lens = np.array([len(s) for s in reads], dtype=np.uint32)
+        out, cig = C.c_void_p(), C.c_void_p()
+        n_out, n_cig = C.c_uint64(), C.c_uint64()
+        self._chk(self._L.kslam_align_batch(self._h, len(reads), C.cast(ptrs, C.c_void_p),
+                                            lens.ctypes.data, C.byref(out), C.byref(n_out),
+                                            C.byref(cig), C.byref(n_cig)))
+        n, nc = int(n_out.value), int(n_cig.value)
+        ov = np.frombuffer((C.c_char * (n * 48)).from_address(out.value), dtype=OVERLAP_DT).copy() \
+            if n else np.zeros(0, dtype=OVERLAP_DT)
+        cg = np.frombuffer((C.c_char * (nc * 4)).from_address(cig.value), dtype=np.uint32).copy() \
+            if nc else np.zeros(0, dtype=np.uint32)
+        self._L.kslam_free_batch(self._h, out, cig)
+        return ov, cg
+
+    def load_reads(self, reads):
+        cat, off = _concat(reads)
+        self._chk(self._L.kslam_load_reads(self._h, len(reads), cat.ctypes.data, off.ctypes.data))
+
+    def load_reads_device(self, n_reads, dev_ptr, host_offsets):
+        off = np.ascontiguousarray(host_offsets, dtype=np.uint64)
+        self._chk(self._L.kslam_load_reads_device(self._h, n_reads, dev_ptr, off.ctypes.data))
+
+    def align_resident(self):
+        n_out, n_cig = C.c_uint64(), C.c_uint64()
+        self._chk(self._L.kslam_align_resident(self._h, C.byref(n_out), C.byref(n_cig)))
+        return int(n_out.value), int(n_cig.value)
+
+    def fetch_results(self, n_out, n_cig):
+        ov = np.zeros(n_out, dtype=OVERLAP_DT)
+        cg = np.zeros(n_cig, dtype=np.uint32)
+        self._chk(self._L.kslam_fetch_results(self._h, ov.ctypes.data, cg.ctypes.data))
+        return ov, cg
+
+    def copy_results_device(self, d_overlaps, d_cigars):
+        self._chk(self._L.kslam_copy_results_device(self._h, d_overlaps, d_cigars))
+
+    def timings(self):
+        t = Timings()
+        self._chk(self._L.kslam_get_timings(self._h, C.byref(t)))
+        return t.as_dict()
+
+    # ---- stage-level entry points ----
+    def extract_kmers(self, seqs, is_gb, gap):
+        ptrs, keep = _seq_arrays(seqs)
+        lens = np.array([len(s) for s in seqs], dtype=np.uint64)
+        cap = int(sum((int(x) - 32) // gap + 1 for x in lens if x >= 32))
+        out = np.zeros(max(cap, 1), dtype=KMER_DT)
+        n = C.c_uint64()
+        self._chk(self._L.kslam_extract_kmers(self._h, len(seqs), C.cast(ptrs, C.c_void_p),
+                                              lens.ctypes.data, int(is_gb), gap, out.ctypes.data,
+                                              cap, C.byref(n)))
+        assert int(n.value) == cap
+        return out[:cap]
+
+    def sort_kmers(self, recs):
+        out = np.ascontiguousarray(recs.copy())
+        self._chk(self._L.kslam_sort_kmers(self._h, out.ctypes.data, len(out)))
+        return out
+
+    def find_overlaps(self):
+        out = C.c_void_p()
+        n, raw = C.c_uint64(), C.c_uint64()
+        self._chk(self._L.kslam_find_overlaps(self._h, C.byref(out), C.byref(n), C.byref(raw)))
+        m = int(n.value)
+        ov = np.frombuffer((C.c_char * (m * 16)).from_address(out.value),
+                           dtype=OVERLAP_TEMP_DT).copy() if m else np.zeros(0, dtype=OVERLAP_TEMP_DT)
+        self._L.kslam_free(out)
+        return ov, int(raw.value)
+
+
+def align_to_database(reads, entries, **params):
+    """One-shot mirror of alignToDatabase(reads, genbankIndex), reference src/SLAM.h:59-79."""
+    ctx = Context(**params)
+    try:
+        ctx.set_index(entries)
+        return ctx.align_batch(reads)
+    finally:
+        ctx.close()

@@ -1,0 +1,176 @@
+// common.h -- shared declarations of the HIP implementation (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/kslam.h"
+
+namespace kslam {
+
+constexpr int WAVE = 64;
+
+struct HipError {
+  hipError_t code;
+  const char *what;
+  const char *file;
+  int line;
+};
+
+#define HIPCHK(expr)                                                      \
+  do {                                                                    \
+    hipError_t _e = (expr);                                               \
+    if (_e != hipSuccess) throw ::kslam::HipError{_e, #expr, __FILE__, __LINE__}; \
+  } while (0)
+
+struct StatusError {
+  kslam_status st;
+  std::string msg;
+};
+
+// grow-only device buffer
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  void ensure(size_t bytes) {
+    if (bytes <= cap) return;
+    if (p) HIPCHK(hipFree(p));
+    p = nullptr;
+    cap = 0;
+    size_t want = bytes + bytes / 8 + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {
+      p = nullptr;
+      (void)hipGetLastError();
+      throw StatusError{KSLAM_ERR_OOM, "hipMalloc of " + std::to_string(want) + " bytes failed"};
+    }
+    cap = want;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+// ---------------------------------------------------------------- scan.hip
+// exclusive scan of n u32 values; out may be u32 or u64. total (u64) is
+// written to d_total[0].  tmp must hold scan_tmp_bytes(n).
+size_t scan_tmp_bytes(uint64_t n);
+void exclusive_scan_u32(const uint32_t *d_in, uint32_t *d_out, uint64_t n,
+                        uint64_t *d_total, void *d_tmp, hipStream_t s);
+void exclusive_scan_u32_to_u64(const uint32_t *d_in, uint64_t *d_out, uint64_t n,
+                               uint64_t *d_total, void *d_tmp, hipStream_t s);
+
+// ------------------------------------------------------------- extract.hip
+struct SegEntry {   // one wave-sized unit of extraction work
+  uint32_t seq;     // sequence index (read id / entry id)
+  uint32_t q0;      // first k-mer index of the segment inside the sequence
+  uint64_t out;     // record index of k-mer q0 in the output
+};
+constexpr uint32_t SEG_KMERS = 128;  // k-mers per segment
+constexpr uint32_t MAX_GAP = 64;
+
+struct ExtractPlan {
+  uint64_t n_seqs = 0;
+  uint64_t n_kmers = 0;
+  uint64_t n_segs = 0;
+};
+// Sizes the work (device scans) and fills the segment table.
+// d_nk / d_nseg: u32[n] scratch; d_rec_start: u64[n]; d_seg_start: u64[n]
+void extract_plan(const uint64_t *d_offsets, uint64_t n_seqs, uint32_t gap,
+                  uint32_t *d_nk, uint32_t *d_nseg, uint64_t *d_rec_start,
+                  uint64_t *d_seg_start, uint64_t *d_totals /*[2]*/, void *d_scan_tmp,
+                  hipStream_t s);
+void extract_fill_segments(const uint32_t *d_nk, const uint64_t *d_rec_start,
+                           const uint64_t *d_seg_start, uint64_t n_seqs, uint32_t gap,
+                           SegEntry *d_segs, hipStream_t s);
+// AoS output (reference record layout); id_base is added to the sequence index
+void extract_kmers_launch(const uint8_t *d_bases, const uint64_t *d_offsets,
+                          const SegEntry *d_segs, uint64_t n_segs, uint32_t gap,
+                          int is_gb, uint32_t id_base, uint4 *d_out, hipStream_t s);
+
+// ---------------------------------------------------------- radix_sort.hip
+struct SortPass {
+  uint32_t word;    // which 32-bit word of the record holds the digit
+  uint32_t shift;   // bit shift inside the word
+  uint32_t invert;  // XOR mask applied to the word first (descending keys)
+};
+constexpr int SORT_TILE = 4096;
+struct SortWorkspace {
+  DevBuf hist;      // u32 [passes][256] -> exclusive bin bases
+  DevBuf status;    // u64 [tiles][256] decoupled look-back words
+  DevBuf tickets;   // u32 [passes + 1]
+  DevBuf errflag;   // u32
+  uint32_t epoch = 0;
+};
+// Sorts n records of REC_WORDS 32-bit words (4 = k-mer record, 2 = u64 key) by
+// the given passes (LSD order: passes[0] is the least significant digit).
+// Result ends in `a` if the number of passes is even, else in `b`; returns the
+// pointer holding the sorted data.  ev0/ev1 bracket the scatter passes.
+void *radix_sort(void *a, void *b, uint64_t n, int rec_words, const SortPass *passes,
+                 int n_passes, SortWorkspace &ws, hipStream_t s, hipEvent_t ev_scatter0,
+                 hipEvent_t ev_scatter1, uint32_t *n_launches);
+
+// ---------------------------------------------------------------- join.hip
+struct GenomeIndexDev {
+  const uint64_t *key;   // sorted genome k-mers
+  const uint32_t *meta;  // ID_isFromGB_RC
+  const uint32_t *off;   // offset
+  const uint32_t *bucket;  // [2^bits + 1] lower bounds by top `bits` bits of the key
+  uint32_t bucket_bits;
+  uint32_t n;
+};
+struct OverlapKeyLayout {  // packed u64 overlap: read | entry | rel + bias | revcomp
+  uint32_t bits_read, bits_entry, bits_rel;
+  uint32_t rel_bias;
+};
+constexpr int JOIN_TILE = 1024;
+void build_bucket_table(const uint64_t *d_keys, uint32_t n, uint32_t bits, uint32_t *d_bucket,
+                        hipStream_t s);
+void join_count(const uint4 *d_read_recs, uint32_t n_r, GenomeIndexDev g, uint32_t *d_block_tot,
+                hipStream_t s);
+void join_fill(const uint4 *d_read_recs, uint32_t n_r, GenomeIndexDev g, const uint32_t *d_read_len,
+               uint32_t read_id_base, const uint64_t *d_block_base, OverlapKeyLayout lay,
+               uint64_t *d_out, hipStream_t s);
+void dedupe_flags(const uint64_t *d_keys, uint64_t n, OverlapKeyLayout lay, uint32_t *d_flags,
+                  hipStream_t s);
+void dedupe_compact(const uint64_t *d_keys, const uint32_t *d_flags, const uint32_t *d_pos,
+                    uint64_t n, OverlapKeyLayout lay, uint32_t read_id_base, kslam_overlap *d_out,
+                    hipStream_t s);
+
+// ------------------------------------------------------------------ sw.hip
+struct SwParams {
+  int32_t match, mismatch, gap_open, gap_extend;
+  uint32_t score_threshold;
+  int32_t report_cigar;
+};
+struct SwInputs {
+  const uint8_t *read_bases;
+  const uint64_t *read_off;   // [n_reads + 1]
+  const uint8_t *genome_bases;
+  const uint64_t *genome_off; // [n_entries + 1]
+};
+// forward + reverse passes for n candidates (in place on d_ov: window-relative,
+// unflipped coordinates); d_band0[i] = initial band width for banded_sw
+// (0 = no cigar wanted, ssw.c:924-927)
+void sw_scores(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, uint32_t max_read_len,
+               uint32_t *d_band0, hipStream_t s);
+
+// --------------------------------------------------------------- cigar.hip
+struct CigarWork {
+  DevBuf flags, pos, list, bmax, needbig, scan_tmp, totals, cig_off, tmp, tmp_big, big_pos, scratch;
+};
+// banded DP + traceback into temp slots; returns the total number of cigar ops
+// and the number of "Trace back error" cases (reference would abort there)
+void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, uint32_t lmax, uint32_t *d_bw,
+                     CigarWork &W, uint64_t *n_cigar_out, uint32_t *n_tb_err, hipStream_t s);
+// un-flip + absolute coordinates, cigar gather into pool[pool_base ...)
+void cigar_finalize(kslam_overlap *d_ov, uint64_t n, SwInputs in, uint32_t lmax, CigarWork &W,
+                    uint32_t *d_pool, uint64_t pool_base, uint64_t *d_cells, hipStream_t s);
+
+}  // namespace kslam

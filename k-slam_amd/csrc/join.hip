@@ -1,0 +1,266 @@
+// join.hip -- sorted read k-mers x resident sorted genome k-mers -> candidate
+// overlaps, then the reference's sort + "unique within 3" dedupe.
+//
+// Replaces findOverlaps / processPileUp / findOverlaps_parallel (reference
+// src/Overlap.h:153-199, 230-246, 277-295).  Semantics kept:
+//   * k-mer value 0 never joins (Overlap.h:236-239);
+//   * a run of equal k-mers yields |genome records| x |read records| overlaps
+//     (Overlap.h:163-197); runs without a genome record yield nothing (:157);
+//   * off = g.rc ? L_read - r.offset - 32 : r.offset; rel = int32(g.offset - off);
+//     revComp = (g.rc != r.rc)                                   (Overlap.h:177-193)
+//   * overlaps sorted by (read, entry, rel) (Overlap.h:87-98); then std::unique
+//     with "same read & entry & |delta rel| < 3" against the LAST KEPT element
+//     (Overlap.h:79-85, 290).  revComp is appended as the least significant
+//     key bit (false first) so the order is total; the reference leaves such
+//     ties to an unstable sort.
+//
+// MI355X design: the reference re-sorts reads + genomes together every batch;
+// here the genome list is sorted once and stays in HBM (SoA: key / meta /
+// offset) with a 2^b-entry bucket table over the top key bits, so each sorted
+// read k-mer finds its genome run with two table reads plus a <= 5-step binary
+// search in a region its neighbours in the wavefront are touching too -- the
+// whole join is one streaming pass over both lists.  Output is a packed u64
+// per overlap (read | entry | rel + bias | revcomp) so that the overlap sort is
+// a keys-only radix sort over just the populated bytes.
+#include "common.h"
+
+namespace kslam {
+
+namespace {
+
+constexpr int JB = 256;                   // threads per block
+constexpr int JI = JOIN_TILE / JB;        // records per thread
+constexpr uint32_t BIG = 48;              // runs longer than this are expanded by the whole block
+constexpr int BIGQ = 64;
+
+__global__ void k_bucket(const uint64_t *__restrict__ keys, uint32_t n, uint32_t sh, uint32_t nb,
+                         uint32_t *__restrict__ bucket) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t b = (uint32_t)(keys[i] >> sh);
+  int64_t bp = i > 0 ? (int64_t)(keys[i - 1] >> sh) : -1;
+  for (int64_t x = bp + 1; x <= (int64_t)b; x++) bucket[x] = i;
+  if (i == n - 1)
+    for (uint32_t x = b + 1; x <= nb; x++) bucket[x] = n;
+}
+__global__ void k_bucket_empty(uint32_t nb, uint32_t *bucket) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i <= nb) bucket[i] = 0;
+}
+
+struct Run {
+  uint32_t lo, cnt;
+};
+
+__device__ inline Run find_run(uint64_t key, const GenomeIndexDev &g) {
+  Run r{0, 0};
+  if (key == 0) return r;  // Overlap.h:236
+  const uint32_t b = (uint32_t)(key >> (64 - g.bucket_bits));
+  uint32_t lo = g.bucket[b], hi = g.bucket[b + 1];
+  const uint32_t end = hi;
+  while (lo < hi) {  // lower_bound
+    uint32_t mid = lo + ((hi - lo) >> 1);
+    if (g.key[mid] < key) lo = mid + 1; else hi = mid;
+  }
+  if (lo >= end || g.key[lo] != key) return r;
+  uint32_t a = lo + 1, z = end;
+  while (a < z) {  // upper_bound
+    uint32_t mid = a + ((z - a) >> 1);
+    if (g.key[mid] <= key) a = mid + 1; else z = mid;
+  }
+  r.lo = lo;
+  r.cnt = a - lo;
+  return r;
+}
+
+__device__ inline uint32_t block_reduce_u32(uint32_t v, uint32_t *sm) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) v += __shfl_down(v, d, 64);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  uint32_t t = 0;
+  for (int i = 0; i < JB / 64; i++) t += sm[i];
+  __syncthreads();
+  return t;
+}
+
+__global__ __launch_bounds__(JB) void k_join_count(const uint4 *__restrict__ recs, uint32_t n,
+                                                   GenomeIndexDev g, uint32_t *__restrict__ block_tot) {
+  __shared__ uint32_t sm[JB / 64];
+  const uint32_t base = blockIdx.x * JOIN_TILE;
+  uint32_t acc = 0;
+#pragma unroll
+  for (int it = 0; it < JI; it++) {
+    uint32_t i = base + it * JB + threadIdx.x;
+    if (i < n) {
+      uint4 r = recs[i];
+      acc += find_run(((uint64_t)r.y << 32) | r.x, g).cnt;
+    }
+  }
+  uint32_t tot = block_reduce_u32(acc, sm);
+  if (threadIdx.x == 0) block_tot[blockIdx.x] = tot;
+}
+
+__device__ inline uint64_t make_overlap(uint32_t rmeta, uint32_t roff, uint32_t gmeta, uint32_t goff,
+                                        const uint32_t *read_len, const OverlapKeyLayout &lay) {
+  const uint32_t rid = rmeta & 0x3FFFFFFFu, gid = gmeta & 0x3FFFFFFFu;
+  const uint32_t rrc = (rmeta >> 30) & 1u, grc = (gmeta >> 30) & 1u;
+  const uint32_t off = grc ? (read_len[rid] - roff - KSLAM_K) : roff;  // Overlap.h:179-183
+  const int32_t rel = (int32_t)(goff - off);                            // Overlap.h:186
+  const uint64_t relb = (uint64_t)(uint32_t)(rel + (int32_t)lay.rel_bias);
+  return ((uint64_t)rid << (lay.bits_entry + lay.bits_rel + 1)) | ((uint64_t)gid << (lay.bits_rel + 1)) |
+         (relb << 1) | (uint64_t)(grc != rrc);
+}
+
+__global__ __launch_bounds__(JB) void k_join_fill(const uint4 *__restrict__ recs, uint32_t n,
+                                                  GenomeIndexDev g, const uint32_t *__restrict__ read_len,
+                                                  const uint64_t *__restrict__ block_base,
+                                                  OverlapKeyLayout lay, uint64_t *__restrict__ out) {
+  __shared__ uint32_t wsum[JB / 64];
+  __shared__ uint32_t bigq_n;
+  __shared__ uint4 bigq[BIGQ];       // {rmeta, roff, run.lo, run.cnt}
+  __shared__ uint32_t bigq_out[BIGQ];  // block-relative output offset
+  const uint32_t base = blockIdx.x * JOIN_TILE;
+  if (threadIdx.x == 0) bigq_n = 0;
+  uint4 r[JI];
+  Run run[JI];
+  uint32_t mine = 0;
+#pragma unroll
+  for (int it = 0; it < JI; it++) {
+    uint32_t i = base + it * JB + threadIdx.x;
+    run[it] = Run{0, 0};
+    if (i < n) {
+      r[it] = recs[i];
+      run[it] = find_run(((uint64_t)r[it].y << 32) | r[it].x, g);
+    }
+    mine += run[it].cnt;
+  }
+  // block exclusive scan of `mine`
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  uint32_t inc = mine;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t t = __shfl_up(inc, d, 64);
+    if (lane >= d) inc += t;
+  }
+  if (lane == 63) wsum[w] = inc;
+  __syncthreads();
+  uint32_t ex = inc - mine;
+  for (int i = 0; i < w; i++) ex += wsum[i];
+  const uint64_t bb = block_base[blockIdx.x];
+#pragma unroll
+  for (int it = 0; it < JI; it++) {
+    const uint32_t c = run[it].cnt;
+    if (c == 0) continue;
+    bool queued = false;
+    if (c > BIG) {
+      uint32_t slot = atomicAdd(&bigq_n, 1u);
+      if (slot < BIGQ) {
+        bigq[slot] = make_uint4(r[it].z, r[it].w, run[it].lo, c);
+        bigq_out[slot] = ex;
+        queued = true;
+      }
+    }
+    if (!queued) {
+      for (uint32_t j = 0; j < c; j++) {
+        const uint32_t gi = run[it].lo + j;
+        out[bb + ex + j] = make_overlap(r[it].z, r[it].w, g.meta[gi], g.off[gi], read_len, lay);
+      }
+    }
+    ex += c;
+  }
+  __syncthreads();
+  const uint32_t nq = min(bigq_n, (uint32_t)BIGQ);
+  for (uint32_t q = 0; q < nq; q++) {
+    const uint4 e = bigq[q];
+    const uint64_t ob = bb + bigq_out[q];
+    for (uint32_t j = threadIdx.x; j < e.w; j += JB) {
+      const uint32_t gi = e.z + j;
+      out[ob + j] = make_overlap(e.x, e.y, g.meta[gi], g.off[gi], read_len, lay);
+    }
+  }
+}
+
+__global__ void k_dedupe_flags(const uint64_t *__restrict__ keys, uint64_t n, uint32_t seg_shift,
+                               uint64_t rel_mask, uint32_t *__restrict__ flags) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t k = keys[i];
+  const uint64_t seg = k >> seg_shift;
+  if (i > 0 && (keys[i - 1] >> seg_shift) == seg) return;  // not a (read, entry) head
+  int64_t last = (int64_t)((k >> 1) & rel_mask);
+  flags[i] = 1;
+  for (uint64_t j = i + 1; j < n; j++) {
+    const uint64_t kj = keys[j];
+    if ((kj >> seg_shift) != seg) break;
+    const int64_t rj = (int64_t)((kj >> 1) & rel_mask);
+    if (rj - last < 3) flags[j] = 0;  // Overlap.h:83 vs the last kept element
+    else { flags[j] = 1; last = rj; }
+  }
+}
+
+__global__ void k_dedupe_compact(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ flags,
+                                 const uint32_t *__restrict__ pos, uint64_t n, OverlapKeyLayout lay,
+                                 uint32_t read_id_base, kslam_overlap *__restrict__ out) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || !flags[i]) return;
+  const uint64_t k = keys[i];
+  kslam_overlap o;
+  memset(&o, 0, sizeof o);
+  o.revcomp = (uint8_t)(k & 1u);
+  o.rel = (int32_t)((k >> 1) & ((1ull << lay.bits_rel) - 1)) - (int32_t)lay.rel_bias;
+  o.entry = (uint32_t)((k >> (lay.bits_rel + 1)) & ((1ull << lay.bits_entry) - 1));
+  o.read = (uint32_t)(k >> (lay.bits_entry + lay.bits_rel + 1)) + read_id_base;
+  out[pos[i]] = o;
+}
+
+}  // namespace
+
+void build_bucket_table(const uint64_t *d_keys, uint32_t n, uint32_t bits, uint32_t *d_bucket,
+                        hipStream_t s) {
+  const uint32_t nb = 1u << bits;
+  if (n == 0) {
+    hipLaunchKernelGGL(k_bucket_empty, dim3((nb + 256) / 256), dim3(256), 0, s, nb, d_bucket);
+  } else {
+    hipLaunchKernelGGL(k_bucket, dim3((n + 255) / 256), dim3(256), 0, s, d_keys, n, 64 - bits, nb, d_bucket);
+  }
+  HIPCHK(hipGetLastError());
+}
+
+void join_count(const uint4 *d_read_recs, uint32_t n_r, GenomeIndexDev g, uint32_t *d_block_tot,
+                hipStream_t s) {
+  if (n_r == 0) return;
+  unsigned blocks = (n_r + JOIN_TILE - 1) / JOIN_TILE;
+  hipLaunchKernelGGL(k_join_count, dim3(blocks), dim3(JB), 0, s, d_read_recs, n_r, g, d_block_tot);
+  HIPCHK(hipGetLastError());
+}
+
+void join_fill(const uint4 *d_read_recs, uint32_t n_r, GenomeIndexDev g, const uint32_t *d_read_len,
+               uint32_t read_id_base, const uint64_t *d_block_base, OverlapKeyLayout lay, uint64_t *d_out,
+               hipStream_t s) {
+  (void)read_id_base;
+  if (n_r == 0) return;
+  unsigned blocks = (n_r + JOIN_TILE - 1) / JOIN_TILE;
+  hipLaunchKernelGGL(k_join_fill, dim3(blocks), dim3(JB), 0, s, d_read_recs, n_r, g, d_read_len, d_block_base,
+                     lay, d_out);
+  HIPCHK(hipGetLastError());
+}
+
+void dedupe_flags(const uint64_t *d_keys, uint64_t n, OverlapKeyLayout lay, uint32_t *d_flags, hipStream_t s) {
+  if (n == 0) return;
+  unsigned blocks = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL(k_dedupe_flags, dim3(blocks), dim3(256), 0, s, d_keys, n, lay.bits_rel + 1,
+                     (1ull << lay.bits_rel) - 1, d_flags);
+  HIPCHK(hipGetLastError());
+}
+
+void dedupe_compact(const uint64_t *d_keys, const uint32_t *d_flags, const uint32_t *d_pos, uint64_t n,
+                    OverlapKeyLayout lay, uint32_t read_id_base, kslam_overlap *d_out, hipStream_t s) {
+  if (n == 0) return;
+  unsigned blocks = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL(k_dedupe_compact, dim3(blocks), dim3(256), 0, s, d_keys, d_flags, d_pos, n, lay,
+                     read_id_base, d_out);
+  HIPCHK(hipGetLastError());
+}
+
+}  // namespace kslam

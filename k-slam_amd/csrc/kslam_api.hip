@@ -1,0 +1,672 @@
+// kslam_api.hip -- the C ABI (include/kslam.h) and the host orchestration of
+// the hot path: alignToDatabase (reference src/SLAM.h:59-79) as
+//   extract read k-mers -> radix sort -> merge-join against the resident sorted
+//   genome k-mer list -> overlap sort + dedupe -> SW scores -> banded CIGAR.
+// All device work runs on the context's own HIP stream; phases are bracketed
+// with HIP events.  No CPU fallback exists: without a HIP device every entry
+// point fails with KSLAM_ERR_NO_DEVICE.
+#include "common.h"
+#include <algorithm>
+#include <new>
+
+using namespace kslam;
+
+struct kslam_ctx {
+  kslam_params prm{};
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  hipEvent_t ev[16]{};
+
+  // ---- index (const GenbankIndex&) ----
+  bool have_index = false;
+  uint64_t n_entries = 0;
+  uint64_t max_entry_len = 0;
+  std::vector<uint64_t> h_goff;  // [n_entries + 1]
+  DevBuf g_bases, g_off;
+  uint64_t n_gk = 0;
+  DevBuf gk_key, gk_meta, gk_off, g_bucket;
+  uint32_t bucket_bits = 8;
+
+  // ---- resident read batch ----
+  bool have_reads = false;
+  uint64_t n_reads = 0;
+  uint32_t max_read_len = 0;
+  std::vector<uint64_t> h_roff;  // [n_reads + 1]
+  DevBuf r_bases, r_off, r_len;
+
+  // ---- work buffers ----
+  DevBuf nk, nseg, rec_start, seg_start, segs, scan_tmp, totals;
+  DevBuf recs_a, recs_b, block_tot, block_base, ovk_a, ovk_b, flags, pos, band0;
+  SortWorkspace sortws;
+  CigarWork cig;
+  DevBuf cells;
+
+  // ---- results of the last align ----
+  DevBuf res_ov, res_cig, res_tmp;
+  uint64_t n_res = 0, n_cig = 0;
+  kslam_timings tm{};
+};
+
+namespace {
+
+template <typename F> kslam_status guarded(kslam_ctx *ctx, F &&f) {
+  if (!ctx) return KSLAM_ERR_ARG;
+  try {
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e != hipSuccess) {
+      ctx->err = std::string("hipSetDevice failed: ") + hipGetErrorString(e);
+      return KSLAM_ERR_NO_DEVICE;
+    }
+    f();
+    return KSLAM_OK;
+  } catch (const StatusError &se) {
+    ctx->err = se.msg;
+    return se.st;
+  } catch (const HipError &he) {
+    ctx->err = std::string("HIP error ") + hipGetErrorString(he.code) + " at " + he.file + ":" +
+               std::to_string(he.line) + " in " + he.what;
+    (void)hipGetLastError();
+    return he.code == hipErrorOutOfMemory ? KSLAM_ERR_OOM : KSLAM_ERR_NO_DEVICE;
+  } catch (const std::bad_alloc &) {
+    ctx->err = "host allocation failed";
+    return KSLAM_ERR_OOM;
+  }
+}
+
+uint32_t bits_for(uint64_t max_value) {
+  uint32_t b = 1;
+  while (b < 64 && (max_value >> b) != 0) b++;
+  return b;
+}
+
+// grow a device buffer while keeping its first `used` bytes
+void ensure_keep(DevBuf &b, size_t bytes, size_t used, hipStream_t s) {
+  if (bytes <= b.cap) return;
+  DevBuf nb;
+  nb.ensure(bytes + bytes / 2);
+  if (used && b.p) {
+    HIPCHK(hipMemcpyAsync(nb.p, b.p, used, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+  }
+  b.release();
+  b = nb;
+}
+
+__global__ void k_lens(const uint64_t *off, uint64_t n, uint32_t *len) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) len[i] = (uint32_t)(off[i + 1] - off[i]);
+}
+
+__global__ void k_split_soa(const uint4 *__restrict__ recs, uint32_t n, uint64_t *__restrict__ key,
+                            uint32_t *__restrict__ meta, uint32_t *__restrict__ off) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint4 r = recs[i];
+  key[i] = ((uint64_t)r.y << 32) | r.x;
+  meta[i] = r.z;
+  off[i] = r.w;
+}
+
+__global__ void k_to_temp(const kslam_overlap *__restrict__ in, uint64_t n, kslam_overlap_temp *__restrict__ out) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  kslam_overlap o = in[i];
+  kslam_overlap_temp t;
+  t.read = o.read; t.entry = o.entry; t.rel = o.rel; t.revcomp = o.revcomp;
+  t.pad[0] = t.pad[1] = t.pad[2] = 0;
+  out[i] = t;
+}
+
+// passes over the 64-bit k-mer (words x, y of the record), least significant first
+void kmer_passes(std::vector<SortPass> &v) {
+  for (uint32_t w = 0; w < 2; w++)
+    for (uint32_t b = 0; b < 4; b++) v.push_back(SortPass{w, 8 * b, 0});
+}
+// sortKMers key (KMer.h:392-396): kmer asc, meta desc -> LSD: ~meta bytes, then kmer bytes
+void full_key_passes(std::vector<SortPass> &v) {
+  for (uint32_t b = 0; b < 4; b++) v.push_back(SortPass{2, 8 * b, 0xFFFFFFFFu});
+  kmer_passes(v);
+}
+
+struct Planned {
+  uint64_t n_kmers = 0, n_segs = 0;
+};
+Planned plan_host(const uint64_t *off, uint64_t n, uint32_t gap) {
+  Planned p;
+  for (uint64_t i = 0; i < n; i++) {
+    uint64_t len = off[i + 1] - off[i];
+    uint64_t k = len >= KSLAM_K ? (len - KSLAM_K) / gap + 1 : 0;
+    p.n_kmers += k;
+    p.n_segs += (k + SEG_KMERS - 1) / SEG_KMERS;
+  }
+  return p;
+}
+
+// extraction of n sequences d_off[0..n] into d_out (AoS records)
+void run_extract(kslam_ctx *c, const uint8_t *d_bases, const uint64_t *d_off, uint64_t n, uint32_t gap, int is_gb,
+                 uint64_t n_segs, uint4 *d_out) {
+  hipStream_t s = c->stream;
+  c->nk.ensure(n * sizeof(uint32_t) + 4);
+  c->nseg.ensure(n * sizeof(uint32_t) + 4);
+  c->rec_start.ensure(n * sizeof(uint64_t) + 8);
+  c->seg_start.ensure(n * sizeof(uint64_t) + 8);
+  c->scan_tmp.ensure(scan_tmp_bytes(n));
+  c->totals.ensure(8 * sizeof(uint64_t));
+  c->segs.ensure((n_segs + 1) * sizeof(SegEntry));
+  extract_plan(d_off, n, gap, c->nk.as<uint32_t>(), c->nseg.as<uint32_t>(), c->rec_start.as<uint64_t>(),
+               c->seg_start.as<uint64_t>(), c->totals.as<uint64_t>(), c->scan_tmp.p, s);
+  extract_fill_segments(c->nk.as<uint32_t>(), c->rec_start.as<uint64_t>(), c->seg_start.as<uint64_t>(), n, gap,
+                        c->segs.as<SegEntry>(), s);
+  extract_kmers_launch(d_bases, d_off, c->segs.as<SegEntry>(), n_segs, gap, is_gb, 0, d_out, s);
+}
+
+void check_sort_error(kslam_ctx *c) {
+  if (!c->sortws.errflag.p) return;
+  uint32_t e = 0;
+  HIPCHK(hipMemcpyAsync(&e, c->sortws.errflag.p, sizeof e, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (e) {
+    HIPCHK(hipMemsetAsync(c->sortws.errflag.p, 0, sizeof(uint32_t), c->stream));
+    throw StatusError{KSLAM_ERR_INTERNAL, "radix sort look-back timed out"};
+  }
+}
+
+void build_index(kslam_ctx *c) {
+  hipStream_t s = c->stream;
+  const uint64_t n = c->n_entries;
+  c->max_entry_len = 0;
+  for (uint64_t i = 0; i < n; i++) c->max_entry_len = std::max(c->max_entry_len, c->h_goff[i + 1] - c->h_goff[i]);
+  if (n >= (1ull << 30)) throw StatusError{KSLAM_ERR_UNSUPPORTED, "more than 2^30 entries (KMer.h:65 id field)"};
+  if (c->max_entry_len >= (1ull << 32)) throw StatusError{KSLAM_ERR_UNSUPPORTED, "entry longer than 2^32 bases"};
+  c->g_off.ensure((n + 1) * sizeof(uint64_t));
+  HIPCHK(hipMemcpyAsync(c->g_off.p, c->h_goff.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+  Planned pl = plan_host(c->h_goff.data(), n, KSLAM_K / 2);  // gap k/2, SLAM.h:64
+  if (pl.n_kmers >= (1ull << 32)) throw StatusError{KSLAM_ERR_UNSUPPORTED, "more than 2^32 genome k-mers"};
+  c->n_gk = pl.n_kmers;
+  const uint64_t m = pl.n_kmers;
+  c->recs_a.ensure((m + 1) * sizeof(uint4));
+  c->recs_b.ensure((m + 1) * sizeof(uint4));
+  run_extract(c, c->g_bases.as<uint8_t>(), c->g_off.as<uint64_t>(), n, KSLAM_K / 2, 1, pl.n_segs,
+              c->recs_a.as<uint4>());
+  std::vector<SortPass> passes;
+  full_key_passes(passes);
+  void *sorted = radix_sort(c->recs_a.p, c->recs_b.p, m, 4, passes.data(), (int)passes.size(), c->sortws, s,
+                            nullptr, nullptr, nullptr);
+  c->gk_key.ensure((m + 1) * sizeof(uint64_t));
+  c->gk_meta.ensure((m + 1) * sizeof(uint32_t));
+  c->gk_off.ensure((m + 1) * sizeof(uint32_t));
+  if (m) hipLaunchKernelGGL(k_split_soa, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, (const uint4 *)sorted,
+                            (uint32_t)m, c->gk_key.as<uint64_t>(), c->gk_meta.as<uint32_t>(),
+                            c->gk_off.as<uint32_t>());
+  uint32_t bits = 8;
+  while (bits < 24 && (m >> (bits + 3)) != 0) bits++;
+  c->bucket_bits = bits;
+  c->g_bucket.ensure(((1ull << bits) + 2) * sizeof(uint32_t));
+  build_bucket_table(c->gk_key.as<uint64_t>(), (uint32_t)m, bits, c->g_bucket.as<uint32_t>(), s);
+  HIPCHK(hipStreamSynchronize(s));
+  check_sort_error(c);
+  c->have_index = true;
+}
+
+void finish_load_reads(kslam_ctx *c) {
+  hipStream_t s = c->stream;
+  const uint64_t n = c->n_reads;
+  if (n >= (1ull << 30)) throw StatusError{KSLAM_ERR_UNSUPPORTED, "more than 2^30 reads (KMer.h:65 id field)"};
+  uint64_t mx = 0;
+  for (uint64_t i = 0; i < n; i++) mx = std::max(mx, c->h_roff[i + 1] - c->h_roff[i]);
+  if (mx > 512) throw StatusError{KSLAM_ERR_UNSUPPORTED, "reads longer than 512 bases are not supported yet"};
+  c->max_read_len = (uint32_t)mx;
+  c->r_off.ensure((n + 1) * sizeof(uint64_t));
+  HIPCHK(hipMemcpyAsync(c->r_off.p, c->h_roff.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+  c->r_len.ensure((n + 1) * sizeof(uint32_t));
+  if (n) hipLaunchKernelGGL(k_lens, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, c->r_off.as<uint64_t>(), n,
+                            c->r_len.as<uint32_t>());
+  HIPCHK(hipStreamSynchronize(s));
+  c->have_reads = true;
+  c->n_res = 0;
+  c->n_cig = 0;
+}
+
+float ev_ms(hipEvent_t a, hipEvent_t b) {
+  float ms = 0;
+  HIPCHK(hipEventElapsedTime(&ms, a, b));
+  return ms;
+}
+
+// the hot path on the resident reads; stop_after_join: only rows a-3..a-6
+void align_resident(kslam_ctx *c, bool stop_after_join, uint64_t *n_raw_out) {
+  if (!c->have_index) throw StatusError{KSLAM_ERR_STATE, "kslam_set_index has not been called"};
+  if (!c->have_reads) throw StatusError{KSLAM_ERR_STATE, "no reads loaded"};
+  hipStream_t s = c->stream;
+  kslam_timings tm{};
+  tm.n_genome_kmers = c->n_gk;
+  c->n_res = 0;
+  c->n_cig = 0;
+  c->cells.ensure(sizeof(uint64_t));
+  HIPCHK(hipMemsetAsync(c->cells.p, 0, sizeof(uint64_t), s));
+  uint64_t n_raw_total = 0;
+
+  // overlap key layout: read (chunk local) | entry | rel + bias | revcomp
+  OverlapKeyLayout lay;
+  lay.bits_entry = bits_for(c->n_entries ? c->n_entries - 1 : 0);
+  lay.rel_bias = c->max_read_len;
+  lay.bits_rel = bits_for(c->max_entry_len + c->max_read_len);
+  if (lay.bits_entry + lay.bits_rel + 1 > 56)
+    throw StatusError{KSLAM_ERR_UNSUPPORTED, "entry count x entry length too large for the packed overlap key"};
+  const uint32_t max_bits_read = 63 - lay.bits_entry - lay.bits_rel;
+  const uint64_t max_chunk_reads = max_bits_read >= 31 ? (1ull << 31) : (1ull << max_bits_read);
+  const uint64_t max_chunk_kmers = c->prm.max_kmers_per_chunk ? c->prm.max_kmers_per_chunk : (1ull << 28);
+
+  GenomeIndexDev g;
+  g.key = c->gk_key.as<uint64_t>(); g.meta = c->gk_meta.as<uint32_t>(); g.off = c->gk_off.as<uint32_t>();
+  g.bucket = c->g_bucket.as<uint32_t>(); g.bucket_bits = c->bucket_bits; g.n = (uint32_t)c->n_gk;
+  SwInputs in;
+  in.read_bases = c->r_bases.as<uint8_t>(); in.read_off = c->r_off.as<uint64_t>();
+  in.genome_bases = c->g_bases.as<uint8_t>(); in.genome_off = c->g_off.as<uint64_t>();
+  SwParams sp;
+  sp.match = (int32_t)c->prm.match; sp.mismatch = (int32_t)c->prm.mismatch;
+  sp.gap_open = (int32_t)c->prm.gap_open; sp.gap_extend = (int32_t)c->prm.gap_extend;
+  sp.score_threshold = c->prm.score_threshold; sp.report_cigar = c->prm.report_cigar;
+
+  std::vector<SortPass> kpasses;
+  kmer_passes(kpasses);
+  tm.sort_passes = (uint32_t)kpasses.size();
+
+  uint64_t r0 = 0;
+  const uint64_t n = c->n_reads;
+  uint32_t tb_err_total = 0;
+  while (r0 < n) {
+    // ---- chunk [r0, r1) ----
+    uint64_t r1 = r0, nk = 0, nsegs = 0;
+    while (r1 < n && (r1 - r0) < max_chunk_reads) {
+      uint64_t len = c->h_roff[r1 + 1] - c->h_roff[r1];
+      uint64_t k = len >= KSLAM_K ? len - KSLAM_K + 1 : 0;  // gap 1, KMer.h:378
+      if (r1 > r0 && nk + k > max_chunk_kmers) break;
+      nk += k;
+      nsegs += (k + SEG_KMERS - 1) / SEG_KMERS;
+      r1++;
+    }
+    if (nk >= (1ull << 32)) throw StatusError{KSLAM_ERR_UNSUPPORTED, "a single read chunk exceeds 2^32 k-mers"};
+    const uint64_t nr = r1 - r0;
+    tm.n_chunks++;
+    tm.n_read_kmers += nk;
+    lay.bits_read = bits_for(nr ? nr - 1 : 0);
+    const uint64_t *d_off = c->r_off.as<uint64_t>() + r0;
+
+    // ---- a-3: read k-mer extraction ----
+    HIPCHK(hipEventRecord(c->ev[0], s));
+    c->recs_a.ensure((nk + 1) * sizeof(uint4));
+    c->recs_b.ensure((nk + 1) * sizeof(uint4));
+    run_extract(c, c->r_bases.as<uint8_t>(), d_off, nr, 1, 0, nsegs, c->recs_a.as<uint4>());
+    HIPCHK(hipEventRecord(c->ev[1], s));
+    // ---- a-4: sort by k-mer ----
+    const uint4 *sorted = (const uint4 *)radix_sort(c->recs_a.p, c->recs_b.p, nk, 4, kpasses.data(),
+                                                    (int)kpasses.size(), c->sortws, s, c->ev[2], c->ev[3],
+                                                    &tm.n_scatter_launches);
+    HIPCHK(hipEventRecord(c->ev[4], s));
+    // ---- a-5: join ----
+    const uint64_t n_tiles = (nk + JOIN_TILE - 1) / JOIN_TILE;
+    c->block_tot.ensure((n_tiles + 1) * sizeof(uint32_t));
+    c->block_base.ensure((n_tiles + 1) * sizeof(uint64_t));
+    c->scan_tmp.ensure(scan_tmp_bytes(std::max<uint64_t>(n_tiles, 1)));
+    uint64_t *d_tot = c->totals.as<uint64_t>();
+    uint64_t raw = 0;
+    if (nk) {
+      join_count(sorted, (uint32_t)nk, g, c->block_tot.as<uint32_t>(), s);
+      exclusive_scan_u32_to_u64(c->block_tot.as<uint32_t>(), c->block_base.as<uint64_t>(), n_tiles, d_tot,
+                                c->scan_tmp.p, s);
+      HIPCHK(hipMemcpyAsync(&raw, d_tot, sizeof raw, hipMemcpyDeviceToHost, s));
+      HIPCHK(hipStreamSynchronize(s));
+    }
+    n_raw_total += raw;
+    if (raw >= (1ull << 32)) throw StatusError{KSLAM_ERR_UNSUPPORTED, "more than 2^32 raw overlaps in one chunk; lower max_kmers_per_chunk"};
+    uint64_t m = 0;
+    if (raw) {
+      c->ovk_a.ensure((raw + 1) * sizeof(uint64_t));
+      c->ovk_b.ensure((raw + 1) * sizeof(uint64_t));
+      join_fill(sorted, (uint32_t)nk, g, c->r_len.as<uint32_t>() + r0, (uint32_t)r0, c->block_base.as<uint64_t>(),
+                lay, c->ovk_a.as<uint64_t>(), s);
+      // ---- a-6: sort by (read, entry, rel[, revcomp]) + unique ----
+      const uint32_t key_bits = lay.bits_read + lay.bits_entry + lay.bits_rel + 1;
+      std::vector<SortPass> op;
+      for (uint32_t b = 0; b < (key_bits + 7) / 8; b++) op.push_back(SortPass{b / 4, 8 * (b % 4), 0});
+      const uint64_t *keys = (const uint64_t *)radix_sort(c->ovk_a.p, c->ovk_b.p, raw, 2, op.data(), (int)op.size(),
+                                                          c->sortws, s, nullptr, nullptr, nullptr);
+      c->flags.ensure((raw + 1) * sizeof(uint32_t));
+      c->pos.ensure((raw + 1) * sizeof(uint32_t));
+      c->scan_tmp.ensure(scan_tmp_bytes(raw));
+      dedupe_flags(keys, raw, lay, c->flags.as<uint32_t>(), s);
+      exclusive_scan_u32(c->flags.as<uint32_t>(), c->pos.as<uint32_t>(), raw, d_tot, c->scan_tmp.p, s);
+      HIPCHK(hipMemcpyAsync(&m, d_tot, sizeof m, hipMemcpyDeviceToHost, s));
+      HIPCHK(hipStreamSynchronize(s));
+      ensure_keep(c->res_ov, (c->n_res + m + 1) * sizeof(kslam_overlap), c->n_res * sizeof(kslam_overlap), s);
+      dedupe_compact(keys, c->flags.as<uint32_t>(), c->pos.as<uint32_t>(), raw, lay, (uint32_t)r0,
+                     c->res_ov.as<kslam_overlap>() + c->n_res, s);
+    }
+    HIPCHK(hipEventRecord(c->ev[5], s));
+    uint64_t ncig = 0;
+    if (m && !stop_after_join) {
+      kslam_overlap *cand = c->res_ov.as<kslam_overlap>() + c->n_res;
+      // ---- a-8..a-12: scores and ends ----
+      c->band0.ensure((m + 1) * sizeof(uint32_t));
+      sw_scores(cand, m, in, sp, c->max_read_len, c->band0.as<uint32_t>(), s);
+      HIPCHK(hipEventRecord(c->ev[6], s));
+      // ---- a-13: cigar ----
+      uint32_t tb_err = 0;
+      cigar_traceback(cand, m, in, sp, c->max_read_len, c->band0.as<uint32_t>(), c->cig, &ncig, &tb_err, s);
+      tb_err_total += tb_err;
+      ensure_keep(c->res_cig, (c->n_cig + ncig + 1) * sizeof(uint32_t), c->n_cig * sizeof(uint32_t), s);
+      cigar_finalize(cand, m, in, c->max_read_len, c->cig, c->res_cig.as<uint32_t>(), c->n_cig,
+                     c->cells.as<uint64_t>(), s);
+    } else {
+      HIPCHK(hipEventRecord(c->ev[6], s));
+    }
+    HIPCHK(hipEventRecord(c->ev[7], s));
+    HIPCHK(hipStreamSynchronize(s));
+    check_sort_error(c);
+    tm.ms_extract += ev_ms(c->ev[0], c->ev[1]);
+    tm.ms_sort += ev_ms(c->ev[1], c->ev[4]);
+    tm.ms_sort_scatter += ev_ms(c->ev[2], c->ev[3]);
+    tm.ms_join += ev_ms(c->ev[4], c->ev[5]);
+    tm.ms_sw += ev_ms(c->ev[5], c->ev[6]);
+    tm.ms_cigar += ev_ms(c->ev[6], c->ev[7]);
+    tm.ms_total += ev_ms(c->ev[0], c->ev[7]);
+    c->n_res += m;
+    c->n_cig += ncig;
+    r0 = r1;
+  }
+  tm.n_overlaps_raw = n_raw_total;
+  tm.n_overlaps = c->n_res;
+  HIPCHK(hipMemcpyAsync(&tm.sw_cells, c->cells.p, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  c->tm = tm;
+  if (n_raw_out) *n_raw_out = n_raw_total;
+  if (tb_err_total)
+    throw StatusError{KSLAM_ERR_INTERNAL, std::to_string(tb_err_total) +
+                                              " candidates hit the reference's 'Trace back error' path"};
+}
+
+void validate_params(const kslam_params &p) {
+  if (p.match == 0 || p.match > 31) throw StatusError{KSLAM_ERR_UNSUPPORTED, "match score must be in 1..31"};
+  if (p.mismatch > 32) throw StatusError{KSLAM_ERR_UNSUPPORTED, "mismatch penalty must be <= 32"};
+  if (p.gap_open > 255 || p.gap_extend > 255) throw StatusError{KSLAM_ERR_UNSUPPORTED, "gap penalties must fit uint8_t (ssw_cpp.h Aligner)"};
+  if (p.gap_extend == 0 || p.gap_extend >= p.gap_open)
+    throw StatusError{KSLAM_ERR_UNSUPPORTED,
+                      "gap_extend must be in 1..gap_open-1: the reference's striped Lazy-F loop is layout "
+                      "dependent otherwise (DESIGN.md, 'scoring envelope')"};
+  if (p.mismatch > p.gap_open + p.gap_extend)
+    throw StatusError{KSLAM_ERR_UNSUPPORTED,
+                      "mismatch must be <= gap_open + gap_extend: the reference's striped kernel never refreshes "
+                      "E after Lazy-F, which is only unobservable inside this envelope (DESIGN.md)"};
+  if (p.score_threshold > 65535) throw StatusError{KSLAM_ERR_UNSUPPORTED, "score_threshold must fit uint16_t (ssw_cpp.h Filter)"};
+}
+
+}  // namespace
+
+extern "C" {
+
+uint32_t kslam_abi_version(void) { return KSLAM_ABI_VERSION; }
+
+kslam_status kslam_create(const kslam_params *params, kslam_ctx **out) {
+  if (!params || !out) return KSLAM_ERR_ARG;
+  *out = nullptr;
+  kslam_ctx *c = new (std::nothrow) kslam_ctx();
+  if (!c) return KSLAM_ERR_OOM;
+  c->prm = *params;
+  c->device = params->device;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0 || c->device < 0 || c->device >= ndev) {
+    // no device: hand back a context that only carries the message (so the caller can read it)
+    c->err = "no usable HIP device (hipGetDeviceCount: " + std::string(hipGetErrorString(e)) + ", count " +
+             std::to_string(ndev) + ", requested " + std::to_string(c->device) + "); this library has no CPU path";
+    (void)hipGetLastError();
+    *out = c;
+    c->device = -1;
+    return KSLAM_ERR_NO_DEVICE;
+  }
+  kslam_status st = guarded(c, [&] {
+    validate_params(c->prm);
+    HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    for (auto &ev : c->ev) HIPCHK(hipEventCreate(&ev));
+  });
+  *out = c;
+  return st;
+}
+
+void kslam_destroy(kslam_ctx *c) {
+  if (!c) return;
+  if (c->device >= 0) {
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    DevBuf *bufs[] = {&c->g_bases, &c->g_off, &c->gk_key, &c->gk_meta, &c->gk_off, &c->g_bucket, &c->r_bases,
+                      &c->r_off, &c->r_len, &c->nk, &c->nseg, &c->rec_start, &c->seg_start, &c->segs, &c->scan_tmp,
+                      &c->totals, &c->recs_a, &c->recs_b, &c->block_tot, &c->block_base, &c->ovk_a, &c->ovk_b,
+                      &c->flags, &c->pos, &c->band0, &c->sortws.hist, &c->sortws.status, &c->sortws.tickets,
+                      &c->sortws.errflag, &c->cig.flags, &c->cig.pos, &c->cig.list, &c->cig.bmax, &c->cig.needbig,
+                      &c->cig.scan_tmp, &c->cig.totals, &c->cig.cig_off, &c->cig.tmp, &c->cig.tmp_big,
+                      &c->cig.big_pos, &c->cig.scratch, &c->cells, &c->res_ov, &c->res_cig, &c->res_tmp};
+    for (DevBuf *b : bufs) b->release();
+    for (auto &ev : c->ev) if (ev) (void)hipEventDestroy(ev);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+  }
+  delete c;
+}
+
+const char *kslam_last_error(const kslam_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+kslam_status kslam_set_index(kslam_ctx *c, uint64_t n_entries, const char *const *bases, const uint64_t *lens) {
+  return guarded(c, [&] {
+    if (n_entries && (!bases || !lens)) throw StatusError{KSLAM_ERR_ARG, "null bases/lens"};
+    c->have_index = false;
+    c->n_entries = n_entries;
+    c->h_goff.assign(n_entries + 1, 0);
+    for (uint64_t i = 0; i < n_entries; i++) c->h_goff[i + 1] = c->h_goff[i] + lens[i];
+    const uint64_t total = c->h_goff[n_entries];
+    c->g_bases.ensure(total + 64);
+    for (uint64_t i = 0; i < n_entries; i++)
+      if (lens[i])
+        HIPCHK(hipMemcpyAsync(c->g_bases.as<uint8_t>() + c->h_goff[i], bases[i], lens[i], hipMemcpyHostToDevice,
+                              c->stream));
+    HIPCHK(hipMemsetAsync(c->g_bases.as<uint8_t>() + total, 0, 64, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    build_index(c);
+  });
+}
+
+kslam_status kslam_set_index_device(kslam_ctx *c, uint64_t n_entries, const void *d_bases,
+                                    const uint64_t *h_offsets) {
+  return guarded(c, [&] {
+    if (n_entries && (!d_bases || !h_offsets)) throw StatusError{KSLAM_ERR_ARG, "null bases/offsets"};
+    c->have_index = false;
+    c->n_entries = n_entries;
+    c->h_goff.assign(n_entries + 1, 0);
+    const uint64_t o0 = n_entries ? h_offsets[0] : 0;
+    for (uint64_t i = 0; i <= n_entries && n_entries; i++) c->h_goff[i] = h_offsets[i] - o0;
+    const uint64_t total = c->h_goff[n_entries];
+    c->g_bases.ensure(total + 64);
+    if (total)
+      HIPCHK(hipMemcpyAsync(c->g_bases.p, (const uint8_t *)d_bases + o0, total, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipMemsetAsync(c->g_bases.as<uint8_t>() + total, 0, 64, c->stream));
+    build_index(c);
+  });
+}
+
+kslam_status kslam_load_reads(kslam_ctx *c, uint64_t n_reads, const char *concat, const uint64_t *offsets) {
+  return guarded(c, [&] {
+    if (n_reads && (!concat || !offsets)) throw StatusError{KSLAM_ERR_ARG, "null reads/offsets"};
+    c->have_reads = false;
+    c->n_reads = n_reads;
+    c->h_roff.assign(n_reads + 1, 0);
+    const uint64_t o0 = n_reads ? offsets[0] : 0;
+    for (uint64_t i = 0; i <= n_reads && n_reads; i++) c->h_roff[i] = offsets[i] - o0;
+    const uint64_t total = c->h_roff[n_reads];
+    c->r_bases.ensure(total + 64);
+    if (total) HIPCHK(hipMemcpyAsync(c->r_bases.p, concat + o0, total, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemsetAsync(c->r_bases.as<uint8_t>() + total, 0, 64, c->stream));
+    finish_load_reads(c);
+  });
+}
+
+kslam_status kslam_load_reads_device(kslam_ctx *c, uint64_t n_reads, const void *d_concat,
+                                     const uint64_t *h_offsets) {
+  return guarded(c, [&] {
+    if (n_reads && (!d_concat || !h_offsets)) throw StatusError{KSLAM_ERR_ARG, "null reads/offsets"};
+    c->have_reads = false;
+    c->n_reads = n_reads;
+    c->h_roff.assign(n_reads + 1, 0);
+    const uint64_t o0 = n_reads ? h_offsets[0] : 0;
+    for (uint64_t i = 0; i <= n_reads && n_reads; i++) c->h_roff[i] = h_offsets[i] - o0;
+    const uint64_t total = c->h_roff[n_reads];
+    c->r_bases.ensure(total + 64);
+    if (total)
+      HIPCHK(hipMemcpyAsync(c->r_bases.p, (const uint8_t *)d_concat + o0, total, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipMemsetAsync(c->r_bases.as<uint8_t>() + total, 0, 64, c->stream));
+    finish_load_reads(c);
+  });
+}
+
+kslam_status kslam_align_resident(kslam_ctx *c, uint64_t *n_out, uint64_t *n_cigar) {
+  return guarded(c, [&] {
+    align_resident(c, false, nullptr);
+    if (n_out) *n_out = c->n_res;
+    if (n_cigar) *n_cigar = c->n_cig;
+  });
+}
+
+kslam_status kslam_fetch_results(kslam_ctx *c, kslam_overlap *out, uint32_t *cigar_pool) {
+  return guarded(c, [&] {
+    if (c->n_res && out)
+      HIPCHK(hipMemcpyAsync(out, c->res_ov.p, c->n_res * sizeof(kslam_overlap), hipMemcpyDeviceToHost, c->stream));
+    if (c->n_cig && cigar_pool)
+      HIPCHK(hipMemcpyAsync(cigar_pool, c->res_cig.p, c->n_cig * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+  });
+}
+
+kslam_status kslam_copy_results_device(kslam_ctx *c, void *d_overlaps, void *d_cigar_pool) {
+  return guarded(c, [&] {
+    if (c->n_res && d_overlaps)
+      HIPCHK(hipMemcpyAsync(d_overlaps, c->res_ov.p, c->n_res * sizeof(kslam_overlap), hipMemcpyDeviceToDevice,
+                            c->stream));
+    if (c->n_cig && d_cigar_pool)
+      HIPCHK(hipMemcpyAsync(d_cigar_pool, c->res_cig.p, c->n_cig * sizeof(uint32_t), hipMemcpyDeviceToDevice,
+                            c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+  });
+}
+
+kslam_status kslam_get_timings(const kslam_ctx *c, kslam_timings *out) {
+  if (!c || !out) return KSLAM_ERR_ARG;
+  *out = c->tm;
+  return KSLAM_OK;
+}
+
+kslam_status kslam_align_batch(kslam_ctx *c, uint64_t n_reads, const char *const *bases, const uint32_t *lens,
+                               kslam_overlap **out, uint64_t *n_out, uint32_t **cigar_pool, uint64_t *n_cigar) {
+  if (!c || !out || !n_out || !cigar_pool || !n_cigar) return KSLAM_ERR_ARG;
+  *out = nullptr; *cigar_pool = nullptr; *n_out = 0; *n_cigar = 0;
+  std::vector<uint64_t> off(n_reads + 1, 0);
+  std::vector<char> cat;
+  kslam_status st = guarded(c, [&] {
+    if (n_reads && (!bases || !lens)) throw StatusError{KSLAM_ERR_ARG, "null bases/lens"};
+    for (uint64_t i = 0; i < n_reads; i++) off[i + 1] = off[i] + lens[i];
+    cat.resize(off[n_reads] + 1);
+    for (uint64_t i = 0; i < n_reads; i++) memcpy(cat.data() + off[i], bases[i], lens[i]);
+  });
+  if (st != KSLAM_OK) return st;
+  st = kslam_load_reads(c, n_reads, cat.data(), off.data());
+  if (st != KSLAM_OK) return st;
+  uint64_t no = 0, nc = 0;
+  st = kslam_align_resident(c, &no, &nc);
+  if (st != KSLAM_OK) return st;
+  kslam_overlap *ho = (kslam_overlap *)malloc((no + 1) * sizeof(kslam_overlap));
+  uint32_t *hc = (uint32_t *)malloc((nc + 1) * sizeof(uint32_t));
+  if (!ho || !hc) {
+    free(ho); free(hc);
+    c->err = "host allocation of the result buffers failed";
+    return KSLAM_ERR_OOM;
+  }
+  st = kslam_fetch_results(c, ho, hc);
+  if (st != KSLAM_OK) { free(ho); free(hc); return st; }
+  *out = ho; *n_out = no; *cigar_pool = hc; *n_cigar = nc;
+  return KSLAM_OK;
+}
+
+void kslam_free_batch(kslam_ctx *, kslam_overlap *out, uint32_t *cigar_pool) {
+  free(out);
+  free(cigar_pool);
+}
+void kslam_free(void *p) { free(p); }
+
+kslam_status kslam_extract_kmers(kslam_ctx *c, uint64_t n, const char *const *bases, const uint64_t *lens,
+                                 int is_from_genbank, uint32_t gap, kslam_kmer *out, uint64_t cap, uint64_t *n_out) {
+  return guarded(c, [&] {
+    if (!n_out) throw StatusError{KSLAM_ERR_ARG, "null n_out"};
+    if (gap == 0 || gap > MAX_GAP) throw StatusError{KSLAM_ERR_UNSUPPORTED, "gap must be in 1..64"};
+    if (n >= (1ull << 30)) throw StatusError{KSLAM_ERR_UNSUPPORTED, "more than 2^30 sequences"};
+    std::vector<uint64_t> off(n + 1, 0);
+    for (uint64_t i = 0; i < n; i++) off[i + 1] = off[i] + lens[i];
+    Planned pl = plan_host(off.data(), n, gap);
+    *n_out = pl.n_kmers;
+    if (pl.n_kmers > cap || pl.n_kmers == 0) return;
+    hipStream_t s = c->stream;
+    DevBuf db, doff, drec;
+    db.ensure(off[n] + 64);
+    doff.ensure((n + 1) * sizeof(uint64_t));
+    drec.ensure(pl.n_kmers * sizeof(uint4));
+    for (uint64_t i = 0; i < n; i++)
+      if (lens[i]) HIPCHK(hipMemcpyAsync(db.as<uint8_t>() + off[i], bases[i], lens[i], hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(db.as<uint8_t>() + off[n], 0, 64, s));
+    HIPCHK(hipMemcpyAsync(doff.p, off.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+    run_extract(c, db.as<uint8_t>(), doff.as<uint64_t>(), n, gap, is_from_genbank, pl.n_segs, drec.as<uint4>());
+    HIPCHK(hipMemcpyAsync(out, drec.p, pl.n_kmers * sizeof(uint4), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    db.release(); doff.release(); drec.release();
+  });
+}
+
+kslam_status kslam_sort_kmers(kslam_ctx *c, kslam_kmer *recs, uint64_t n) {
+  return guarded(c, [&] {
+    if (n == 0) return;
+    if (!recs) throw StatusError{KSLAM_ERR_ARG, "null recs"};
+    hipStream_t s = c->stream;
+    DevBuf a, b;
+    a.ensure(n * sizeof(uint4));
+    b.ensure(n * sizeof(uint4));
+    HIPCHK(hipMemcpyAsync(a.p, recs, n * sizeof(uint4), hipMemcpyHostToDevice, s));
+    std::vector<SortPass> passes;
+    full_key_passes(passes);
+    void *sorted = radix_sort(a.p, b.p, n, 4, passes.data(), (int)passes.size(), c->sortws, s, nullptr, nullptr,
+                              nullptr);
+    HIPCHK(hipMemcpyAsync(recs, sorted, n * sizeof(uint4), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    check_sort_error(c);
+    a.release(); b.release();
+  });
+}
+
+kslam_status kslam_find_overlaps(kslam_ctx *c, kslam_overlap_temp **out, uint64_t *n_out, uint64_t *n_raw) {
+  if (!out || !n_out) return KSLAM_ERR_ARG;
+  *out = nullptr; *n_out = 0;
+  return guarded(c, [&] {
+    uint64_t raw = 0;
+    align_resident(c, true, &raw);
+    if (n_raw) *n_raw = raw;
+    const uint64_t m = c->n_res;
+    kslam_overlap_temp *h = (kslam_overlap_temp *)malloc((m + 1) * sizeof(kslam_overlap_temp));
+    if (!h) throw StatusError{KSLAM_ERR_OOM, "host allocation failed"};
+    if (m) {
+      c->res_tmp.ensure(m * sizeof(kslam_overlap_temp));
+      hipLaunchKernelGGL(k_to_temp, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream,
+                         c->res_ov.as<kslam_overlap>(), m, c->res_tmp.as<kslam_overlap_temp>());
+      HIPCHK(hipMemcpyAsync(h, c->res_tmp.p, m * sizeof(kslam_overlap_temp), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    *out = h;
+    *n_out = m;
+  });
+}
+
+}  // extern "C"

@@ -1,0 +1,142 @@
+"""GPU parity tests proper: the HIP path through the C ABI vs the CPU oracle.
+
+Bit-exact bar: every integer field and every CIGAR op must be identical.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx(kslam):
+    c = kslam.Context()
+    yield c
+    c.close()
+
+
+def _rand_seqs(rng, n, lo, hi, junk=True):
+    out = []
+    for _ in range(n):
+        L = int(rng.integers(lo, hi + 1))
+        s = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, L)].copy()
+        if junk and L and rng.random() < 0.3:
+            k = rng.integers(0, L, rng.integers(1, 4))
+            s[k] = rng.choice(np.frombuffer(b"NnacgtRYU-", dtype=np.uint8), len(k))
+        out.append(s.tobytes())
+    return out
+
+
+@pytest.mark.parametrize("is_gb,gap", [(False, 1), (True, 16), (True, 4), (False, 3), (True, 1), (False, 64)])
+def test_extract_parity(ctx, oracle, is_gb, gap):
+    rng = np.random.default_rng(100 + gap + int(is_gb))
+    seqs = _rand_seqs(rng, 300, 0, 400) + [b"", b"A" * 31, b"A" * 32, b"ACGT" * 8, b"N" * 50,
+                                           b"acgt" * 20] + _rand_seqs(rng, 3, 3000, 9000)
+    exp = oracle.extract_kmers(seqs, is_gb, gap)
+    got = ctx.extract_kmers(seqs, is_gb, gap)
+    assert len(exp) == len(got)
+    assert (exp == got).all()
+
+
+def test_extract_golden_vector(ctx):
+    # reference answers recorded in SURVEY.md section 8c
+    s = b"ACGTTGCAAGGCTTAACCGGTTACGATCGATCGGATCCAGTNACGT"
+    r = ctx.extract_kmers([b""] * 7 + [s], False, 1)
+    assert (int(r[0]["kmer"]), int(r[0]["meta"]), int(r[0]["offset"])) == (0x1eb43da05fa1c9c9, 7, 0)
+    assert (int(r[1]["kmer"]), int(r[1]["meta"]), int(r[1]["offset"])) == (0x72727817e835ad07, 0x40000007, 13)
+    g = ctx.extract_kmers([b""] * 5 + [s], True, 4)
+    assert [(int(x["meta"]), int(x["offset"])) for x in g] == [
+        (0x80000005, 0), (0xc0000005, 4), (0x80000005, 8), (0x80000005, 12)]
+
+
+@pytest.mark.parametrize("n", [0, 1, 63, 4096, 4097, 100000, 1 << 20])
+def test_sort_parity(ctx, oracle, kslam, n):
+    rng = np.random.default_rng(7 + n)
+    recs = np.zeros(n, dtype=kslam.KMER_DT)
+    # forced key ties: few distinct k-mers, random meta (all four flag combinations)
+    recs["kmer"] = rng.integers(0, max(n // 8, 2), n, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+    recs["meta"] = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+    recs["offset"] = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+    got = ctx.sort_kmers(recs)
+    exp = oracle.sort_kmers(recs)
+    # reference key is (kmer asc, meta desc); offset is not part of it (KMer.h:392-396)
+    assert (got["kmer"] == exp["kmer"]).all() and (got["meta"] == exp["meta"]).all()
+    # same multiset: normalise the unspecified tie order by offset
+    o = np.lexsort((got["offset"], ~got["meta"], got["kmer"]))
+    assert (got[o] == exp).all()
+
+
+def _dataset(synth, seed, n_pairs, n_species=3, n_strains=2, glen=20000, **kw):
+    genomes = synth.make_genomes(seed, n_species, n_strains, glen, shared_segment=2000)
+    reads, truth = synth.make_paired_reads(seed + 1, genomes, n_pairs, **kw)
+    return synth.to_bytes(reads), synth.to_bytes(genomes), truth
+
+
+def test_find_overlaps_parity(kslam, oracle, synth):
+    reads, genomes, _ = _dataset(synth, 11, 500, edge_frac=0.1, n_rate=0.002)
+    c = kslam.Context()
+    c.set_index(genomes)
+    c.load_reads(reads)
+    got, raw = c.find_overlaps()
+    c.close()
+    recs = np.concatenate([oracle.extract_kmers(reads, False, 1), oracle.extract_kmers(genomes, True, 16)])
+    exp, exp_raw = oracle.find_overlaps(oracle.sort_kmers(recs), [len(r) for r in reads])
+    assert raw == exp_raw
+    assert len(got) == len(exp)
+    for f in ("read", "entry", "rel", "revcomp"):
+        assert (got[f] == exp[f]).all(), f
+
+
+def _compare_alignments(got, gcig, exp, ecig):
+    assert len(got) == len(exp)
+    for f in ("read", "entry", "rel", "revcomp", "score", "ref_begin", "ref_end", "query_begin",
+              "query_end", "cigar_len"):
+        bad = np.nonzero(got[f] != exp[f])[0]
+        assert len(bad) == 0, "%s differs at %s: got %s exp %s" % (f, bad[:5], got[bad[:5]], exp[bad[:5]])
+    for i in range(len(got)):
+        a = gcig[int(got["cigar_off"][i]):int(got["cigar_off"][i]) + int(got["cigar_len"][i])]
+        b = ecig[int(exp["cigar_off"][i]):int(exp["cigar_off"][i]) + int(exp["cigar_len"][i])]
+        assert (a == b).all(), "cigar %d" % i
+
+
+@pytest.mark.parametrize("case", ["default", "nocigar", "threshold", "edges", "indels", "len250", "len100"])
+def test_align_parity(kslam, oracle, synth, case):
+    kw, pk = {}, {}
+    if case == "nocigar":
+        pk = dict(report_cigar=False)
+    if case == "threshold":
+        pk = dict(score_threshold=250)
+    if case == "edges":
+        kw = dict(edge_frac=0.5, n_rate=0.005)
+    if case == "indels":
+        kw = dict(indel_rate=0.02, sub_rate=0.03)
+    if case == "len250":
+        kw = dict(read_len=250, frag_mean=450)
+    if case == "len100":
+        kw = dict(read_len=100, frag_mean=250)
+    reads, genomes, _ = _dataset(synth, 21 + len(case), 400, **kw)
+    reads = reads + [b"ACGT" * 5, b"", b"N" * 150]  # too short / empty / all-N reads produce nothing
+    got, gcig = kslam.align_to_database(reads, genomes, **pk)
+    p = oracle.Params.default(report_cigar=pk.get("report_cigar", True),
+                              score_threshold=pk.get("score_threshold", 0))
+    exp, ecig, _ = oracle.align_to_database(reads, genomes, p)
+    assert len(exp) > 300
+    _compare_alignments(got, gcig, exp, ecig)
+
+
+def test_align_chunked_equals_unchunked(kslam, synth):
+    reads, genomes, _ = _dataset(synth, 5, 600)
+    a, ac = kslam.align_to_database(reads, genomes)
+    b, bc = kslam.align_to_database(reads, genomes, max_kmers_per_chunk=20000)
+    _compare_alignments(a, ac, b, bc)
+
+
+def test_empty_batch(kslam, synth):
+    _, genomes, _ = _dataset(synth, 5, 1)
+    ov, cg = kslam.align_to_database([], genomes)
+    assert len(ov) == 0 and len(cg) == 0
+
+
+def test_unsupported_scoring_fails_loudly(kslam):
+    with pytest.raises(kslam.KslamError):
+        kslam.Context(gap_open=2, gap_extend=3)

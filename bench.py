@@ -1,0 +1,315 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the k-SLAM alignment hot path on MI355X.
+
+A "step" is one pass of the hot path (alignToDatabase, reference src/SLAM.h:59-79:
+read k-mer extraction -> k-mer sort -> join against the resident genome k-mer list ->
+overlap sort/dedupe -> Smith-Waterman -> CIGAR) over one batch of synthetic paired reads
+that is already resident in HBM.  Workload at N=1 = BASELINE.json configs[1]:
+1M 150 bp read pairs vs a ~5 Gb synthetic bacterial database.  With N > 1 every rank
+replicates the database, aligns its own 1M pairs (weak scaling) and the per-read results
+are gathered to rank 0 over RCCL inside the timed region.
+
+Prints ONE JSON line on rank 0 (see the driver contract in the task statement).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as entry  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+READ_LEN = 150
+_ACGT = torch.tensor(list(b"ACGT"), dtype=torch.uint8)
+
+
+def _codes_of(x):
+    """ASCII uint8 tensor -> 0..3 for A,C,G,T (others 0)."""
+    c = torch.zeros_like(x)
+    c[x == ord("C")] = 1
+    c[x == ord("G")] = 2
+    c[x == ord("T")] = 3
+    return c
+
+
+def _revcomp_rows(x):
+    """reverse-complement each row of an ASCII uint8 [n, L] tensor."""
+    lut = torch.arange(256, dtype=torch.uint8, device=x.device)
+    for a, b in zip(b"ACGT", b"TGCA"):
+        lut[a] = b
+    return lut[x.flip(1).long()]
+
+
+def make_database(dev, gen, n_species, n_strains, length):
+    """Species x strains database as ONE device byte tensor + host offsets.
+    Strains derive from the species root by 1-3 % substitutions + sparse 1-10 bp indels."""
+    acgt = _ACGT.to(dev)
+    cap = int(n_species * n_strains * length * 1.01) + 1024
+    db = torch.empty(cap, dtype=torch.uint8, device=dev)
+    offs = [0]
+    for _ in range(n_species):
+        root_codes = torch.randint(0, 4, (length,), generator=gen, device=dev, dtype=torch.uint8)
+        for st in range(n_strains):
+            codes = root_codes
+            if st > 0:
+                rate = 0.01 + 0.02 * float(torch.rand(1, generator=gen, device=dev))
+                m = torch.rand(length, generator=gen, device=dev) < rate
+                shift = torch.randint(1, 4, (length,), generator=gen, device=dev, dtype=torch.uint8)
+                codes = torch.where(m, (root_codes + shift) % 4, root_codes)
+                # sparse indels: ~1 per 2 kb, 1-10 bp
+                ev = torch.rand(length, generator=gen, device=dev) < 0.0005
+                ln = torch.randint(1, 11, (length,), generator=gen, device=dev)
+                is_ins = torch.rand(length, generator=gen, device=dev) < 0.5
+                counts = torch.ones(length, dtype=torch.long, device=dev)
+                counts = torch.where(ev & is_ins, 1 + ln, counts)
+                # deletion of ln bases starting at the event
+                del_start = torch.nonzero(ev & ~is_ins).flatten()
+                if del_start.numel():
+                    dl = ln[del_start]
+                    idx = (del_start[:, None] + torch.arange(10, device=dev)[None, :])
+                    keep = torch.arange(10, device=dev)[None, :] < dl[:, None]
+                    idx = idx[keep]
+                    idx = idx[idx < length]
+                    counts[idx] = 0
+                src = torch.repeat_interleave(torch.arange(length, device=dev), counts)
+                out = codes[src]
+                dup = torch.zeros_like(src, dtype=torch.bool)
+                dup[1:] = src[1:] == src[:-1]
+                rnd = torch.randint(0, 4, (src.numel(),), generator=gen, device=dev, dtype=torch.uint8)
+                codes = torch.where(dup, rnd, out)
+            n = codes.numel()
+            db[offs[-1]:offs[-1] + n] = acgt[codes.long()]
+            offs.append(offs[-1] + n)
+    return db[:offs[-1]], np.array(offs, dtype=np.uint64)
+
+
+def make_reads(dev, gen, db, offs, n_pairs, read_len=READ_LEN, sub_rate=0.01, indel_rate=0.001,
+               unmapped=0.02):
+    """[2 * n_pairs, read_len] ASCII tensor in the reference batch layout (R1 block | R2 block)."""
+    acgt = _ACGT.to(dev)
+    goff = torch.from_numpy(offs.astype(np.int64)).to(dev)
+    glen = goff[1:] - goff[:-1]
+    ng = glen.numel()
+    g = torch.randint(0, ng, (n_pairs,), generator=gen, device=dev)
+    frag = (350 + 30 * torch.randn(n_pairs, generator=gen, device=dev)).round().long().clamp(read_len + 1, 1000)
+    span = (glen[g] - frag - 2).clamp(min=1)
+    start = (torch.rand(n_pairs, generator=gen, device=dev, dtype=torch.float64) * span).long()
+    W = read_len + 1
+    j = torch.arange(W, device=dev)[None, :]
+    a_idx = goff[g][:, None] + start[:, None] + j                       # forward window at s
+    b_idx = goff[g][:, None] + (start + frag - W)[:, None] + j          # window ending at s + f
+    A = db[a_idx]
+    B = _revcomp_rows(db[b_idx])
+    flip = torch.rand(n_pairs, generator=gen, device=dev) < 0.5
+    r1 = torch.where(flip[:, None], B, A)
+    r2 = torch.where(flip[:, None], A, B)
+    reads = torch.cat([r1, r2], 0)                                      # [2n, W]
+    n2 = 2 * n_pairs
+    # substitutions
+    m = torch.rand(n2, W, generator=gen, device=dev) < sub_rate
+    shift = torch.randint(1, 4, (n2, W), generator=gen, device=dev, dtype=torch.uint8)
+    reads = torch.where(m, acgt[((_codes_of(reads) + shift) % 4).long()], reads)
+    # at most one single-base indel per read
+    p_ind = 1.0 - (1.0 - indel_rate) ** read_len
+    has = torch.rand(n2, generator=gen, device=dev) < p_ind
+    pos = torch.randint(1, read_len - 1, (n2,), generator=gen, device=dev)
+    ins = torch.rand(n2, generator=gen, device=dev) < 0.5
+    jj = torch.arange(read_len, device=dev)[None, :].expand(n2, read_len)
+    d = torch.zeros(n2, read_len, dtype=torch.long, device=dev)
+    d = torch.where((has & ins)[:, None] & (jj > pos[:, None]), torch.full_like(d, -1), d)
+    d = torch.where((has & ~ins)[:, None] & (jj >= pos[:, None]), torch.full_like(d, 1), d)
+    out = torch.gather(reads, 1, jj + d)
+    rnd = acgt[torch.randint(0, 4, (n2,), generator=gen, device=dev)]
+    at = (has & ins)[:, None] & (jj == pos[:, None])
+    out = torch.where(at, rnd[:, None].expand(n2, read_len), out)
+    # pairs from a genome that is not in the database
+    um = torch.rand(n_pairs, generator=gen, device=dev) < unmapped
+    um2 = torch.cat([um, um])
+    junk = acgt[torch.randint(0, 4, (n2, read_len), generator=gen, device=dev)]
+    out = torch.where(um2[:, None], junk, out)
+    return out.contiguous()
+
+
+def cpu_baseline(db, offs, seed, n_genomes, n_pairs):
+    """The oracle's alignToDatabase timed on the host cores, on a bounded sample of the
+    same workload (reported baseline; the oracle is the checker, never the product)."""
+    import oracle as O
+    n_genomes = min(n_genomes, len(offs) - 1)
+    sub = db[:int(offs[n_genomes])].cpu()
+    suboffs = offs[:n_genomes + 1]
+    gen = torch.Generator(device="cpu")
+    gen.manual_seed(seed)
+    reads = make_reads(torch.device("cpu"), gen, sub, suboffs, n_pairs).numpy()
+    rl = [reads[i].tobytes() for i in range(reads.shape[0])]
+    subn = sub.numpy()
+    gl = [subn[int(suboffs[i]):int(suboffs[i + 1])].tobytes() for i in range(n_genomes)]
+    kind_ssw = "own scalar SSW restatement"
+    if O.use_reference_ssw(True):
+        kind_ssw = "SSW core = the reference's own ssw.c (SSE2) from oracle/_ref"
+    t = time.time()
+    al, cg, ph = O.align_to_database(rl, gl)
+    dt = time.time() - t
+    O.use_reference_ssw(False)
+    return {
+        "value": round(len(rl) / dt, 1), "unit": "reads/s", "cores": O.num_threads(), "kind": "port",
+        "sample": "%d pairs x %d bp vs the first %d database genomes (%.0f Mb); whole reference batch "
+                  "path incl. genome k-mer re-extraction and the (reads+genomes) sort, OpenMP; %s; "
+                  "%.1f s wall, phases extract/genome/sort/join/sw = %s s" % (
+                      n_pairs, READ_LEN, n_genomes, float(suboffs[-1]) / 1e6, kind_ssw, dt,
+                      "/".join("%.2f" % x for x in ph[:5])),
+        "n_alignments": int(len(al)),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--pairs", type=int, default=1_000_000, help="read pairs per GPU per step")
+    ap.add_argument("--species", type=int, default=250)
+    ap.add_argument("--strains", type=int, default=5)
+    ap.add_argument("--genome-len", type=int, default=4_000_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-pairs", type=int, default=20000)
+    ap.add_argument("--cpu-genomes", type=int, default=25)
+    ap.add_argument("--no-cigar", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    K = entry.load_package()
+    kdist = importlib.import_module("kslam_amd.dist")
+
+    # ---- synthetic inputs, generated straight into HBM (data: synthetic) ----
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1)                      # database: same on every rank (replicated index)
+    t0 = time.time()
+    db, offs = make_database(dev, gen, args.species, args.strains, args.genome_len)
+    gen.manual_seed(2 + 1000 * rank)        # reads: a different shard of pairs per rank
+    reads = make_reads(dev, gen, db, offs, args.pairs)
+    torch.cuda.synchronize()
+    t_gen = time.time() - t0
+
+    ctx = K.Context(report_cigar=not args.no_cigar, device=local_rank)
+    t0 = time.time()
+    ctx.set_index_device(len(offs) - 1, db.data_ptr(), offs)
+    t_index = time.time() - t0
+    n_reads = reads.shape[0]
+    roffs = (np.arange(n_reads + 1, dtype=np.uint64) * np.uint64(READ_LEN))
+    ctx.load_reads_device(n_reads, reads.data_ptr(), roffs)
+
+    def step():
+        n_out, n_cig = ctx.align_resident()
+        if world > 1:
+            ov = torch.empty(n_out * 48, dtype=torch.uint8, device=dev)
+            cg = torch.empty(n_cig * 4, dtype=torch.uint8, device=dev)
+            ctx.copy_results_device(ov.data_ptr(), cg.data_ptr())
+            kdist.gather_to_rank0(ov, cg)
+        return n_out, n_cig
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    acc = {}
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        n_out, n_cig = step()
+        for k, v in ctx.timings().items():
+            acc[k] = acc.get(k, 0) + v
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+
+    if rank == 0:
+        S = args.steps
+        tm = {k: v / S for k, v in acc.items()}
+        total_reads = n_reads * world * S
+        n_kmers = tm["n_read_kmers"]
+        passes = int(round(tm["sort_passes"]))
+        launches = max(tm["n_scatter_launches"], 1)
+        launch_ms = tm["ms_sort_scatter"] / launches
+        per_launch_bytes = (n_kmers / max(tm["n_chunks"], 1)) * 16 * 2   # one pass: 16 B in + 16 B out per record
+        achieved = per_launch_bytes / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("k_onesweep_bytes_per_launch")
+            except Exception:
+                traffic = None
+        sort_bytes = n_kmers * 16 * (2 * passes + 1)
+        out = {
+            "metric": "paired 150bp reads/sec classified (bit-exact SAM)",
+            "value": round(total_reads / elapsed, 1),
+            "unit": "reads/s",
+            "n_gpus": world, "steps": S, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / S * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u64 k-mers / i32 DP", "data": "synthetic",
+            "config": {
+                "workload": "BASELINE configs[1]: %d x 2 x %d bp reads per GPU vs %d-genome "
+                            "(%d species x %d strains x %.1f Mb = %.2f Gb) synthetic bacterial db, "
+                            "hot path alignToDatabase incl. CIGAR, inputs resident in HBM" % (
+                                args.pairs, READ_LEN, len(offs) - 1, args.species, args.strains,
+                                args.genome_len / 1e6, float(offs[-1]) / 1e9),
+                "pairs_per_gpu": args.pairs, "db_bases": int(offs[-1]),
+                "parallelism": "read pairs sharded x%d, genome k-mer list replicated, gather to rank 0" % world,
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": "k_onesweep<4> (one radix pass of the read k-mer sort)",
+                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "launch_ms": round(launch_ms, 4), "bytes_per_launch": int(per_launch_bytes),
+                "sort_phase": {"passes": passes, "bytes": int(sort_bytes), "ms": round(tm["ms_sort"], 3),
+                               "frac": round(sort_bytes / (tm["ms_sort"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                               if tm["ms_sort"] > 0 else 0.0},
+            },
+            "phases_ms": {k: round(tm[k], 3) for k in ("ms_extract", "ms_sort", "ms_join", "ms_sw",
+                                                         "ms_cigar", "ms_total")},
+            "counts": {"read_kmers": int(n_kmers), "genome_kmers": int(tm["n_genome_kmers"]),
+                       "overlaps_raw": int(tm["n_overlaps_raw"]), "candidates": int(tm["n_overlaps"]),
+                       "cigar_ops": int(n_cig), "chunks": int(tm["n_chunks"])},
+            "sw_gcups": round(tm["sw_cells"] / ((tm["ms_sw"]) * 1e-3) / 1e9, 1) if tm["ms_sw"] > 0 else 0.0,
+            "setup_s": {"generate": round(t_gen, 2), "index_build": round(t_index, 2)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(db, offs, 77, args.cpu_genomes, args.cpu_pairs)
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

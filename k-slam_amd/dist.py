@@ -1,0 +1,81 @@
+"""Read-pair sharding across ranks and the end-of-batch gather.
+
+The hot path shards by read pair: k-mer extraction, the join and SW are per read,
+the dedupe is per (read, entry).  Each rank keeps the genome index replicated in
+its own HBM and aligns pairs [lo, hi) of the batch; there is NO collective on
+the data path.  The only exchange is the variable-length gather of the per-read
+results to rank 0 at the end of the batch (RCCL point-to-point over xGMI on the
+GPU box: each peer has its own direct link to GPU 0; gloo in the CPU tests).
+
+Batch layout (reference src/FASTQsequence.h:111-123): reads = [R1 block | R2
+block], mate of i is i + n.  A rank's local batch keeps that layout:
+[R1[lo:hi] | R2[lo:hi]].
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n_pairs, world):
+    return [(r * n_pairs // world, (r + 1) * n_pairs // world) for r in range(world)]
+
+
+def local_reads(reads, n_pairs, lo, hi):
+    """reads: sequence of 2*n_pairs items in block layout -> the rank's local block layout."""
+    return list(reads[lo:hi]) + list(reads[n_pairs + lo:n_pairs + hi])
+
+
+def gather_to_rank0(ov_bytes, cig_bytes, group=None):
+    """Variable-length gather of (overlap records, cigar pool) byte tensors to rank 0.
+
+    ov_bytes / cig_bytes: 1-D uint8 tensors (device tensors with the nccl backend).
+    Returns on rank 0 a list of (ov, cig) uint8 tensors per rank, elsewhere None."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    dev = ov_bytes.device
+    sizes = torch.tensor([ov_bytes.numel(), cig_bytes.numel()], dtype=torch.int64, device=dev)
+    all_sizes = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(all_sizes, sizes, group=group)
+    if rank == 0:
+        parts = [(ov_bytes, cig_bytes)]
+        reqs = []
+        for r in range(1, world):
+            no, nc = int(all_sizes[r][0]), int(all_sizes[r][1])
+            o = torch.empty(no, dtype=torch.uint8, device=dev)
+            c = torch.empty(nc, dtype=torch.uint8, device=dev)
+            if no:
+                reqs.append(dist.irecv(o, src=r, group=group))
+            if nc:
+                reqs.append(dist.irecv(c, src=r, group=group))
+            parts.append((o, c))
+        for q in reqs:
+            q.wait()
+        return parts
+    reqs = []
+    if ov_bytes.numel():
+        reqs.append(dist.isend(ov_bytes, dst=0, group=group))
+    if cig_bytes.numel():
+        reqs.append(dist.isend(cig_bytes, dst=0, group=group))
+    for q in reqs:
+        q.wait()
+    return None
+
+
+def reassemble(parts, bounds, n_pairs, overlap_dtype):
+    """Rank 0: per-rank results (local read ids) -> one batch-global result in the
+    reference order (read, entry, rel).  parts[r] = (overlaps ndarray, cigar ndarray)."""
+    r1_parts, r2_parts, pools = [], [], []
+    base = 0
+    for (ov, cig), (lo, hi) in zip(parts, bounds):
+        ov = ov.copy()
+        n_loc = hi - lo
+        ov["cigar_off"] = np.where(ov["cigar_len"] > 0, ov["cigar_off"] + np.uint64(base), np.uint64(0))
+        is_r2 = ov["read"] >= n_loc
+        ov["read"] = np.where(is_r2, ov["read"] - n_loc + n_pairs + lo, ov["read"] + lo).astype(np.uint32)
+        r1_parts.append(ov[~is_r2])
+        r2_parts.append(ov[is_r2])
+        pools.append(cig)
+        base += len(cig)
+    out = np.concatenate(r1_parts + r2_parts) if parts else np.zeros(0, dtype=overlap_dtype)
+    pool = np.concatenate(pools) if pools else np.zeros(0, dtype=np.uint32)
+    return out, pool

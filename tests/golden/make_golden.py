@@ -1,0 +1,119 @@
+#!/usr/bin/env python3
+"""Generates the committed golden fixtures (run in the build container, where
+/root/reference exists and oracle/_ref has been built from it).
+
+ * survey_vectors.json : reference answers recorded in SURVEY.md section 8c (k-mer records of
+   a 46-base read / genome, `TAG` at K=3, four Aligner::Align tuples).  Written verbatim, and
+   re-checked here against the real reference pieces that can be built (KMer.h, ssw.c).
+ * ssw_vectors.npz     : 1500 random (read, ref) code pairs with the answers of the reference's
+   own ssw_init + ssw_align (oracle/_ref/libssw_ref.so), scoring (2,3,5,2) and (1,4,6,1).
+ * kmer_vectors.npz    : sequences + the records produced by the reference's own
+   getKMers_parallel and sortKMers (oracle/_ref/libkmer_ref.so).
+ * align_small.npz     : a seeded 150-pair x 6-genome data set with the expected
+   alignToDatabase output; produced by the oracle with its SSW core routed through the
+   reference's ssw.c AND by the oracle's own restatement, asserted identical.
+Fixtures are data (inputs + expected outputs); no reference source text is stored.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle as O  # noqa: E402
+from conftest import load_kslam  # noqa: E402
+
+
+def main():
+    assert O.have_ref_ssw() and O.have_ref_kmer(), "needs oracle/_ref (reference present)"
+    # ---- SURVEY 8c vectors ----
+    q = "ACGTTGCAAGGCTTAACCGGTTACGATCGATCGGATCCAGT"
+    sv = {
+        "read46": "ACGTTGCAAGGCTTAACCGGTTACGATCGATCGGATCCAGTNACGT",
+        "read_id": 7, "read_records": [[0x1eb43da05fa1c9c9, 0x00000007, 0], [0x72727817e835ad07, 0x40000007, 13]],
+        "genome_id": 5, "genome_gap": 4, "genome_meta_off": [[0x80000005, 0], [0xc0000005, 4], [0x80000005, 8], [0x80000005, 12]],
+        "tag_k3": {"seq": "TAG", "fwd": 35, "rc": 24},
+        "align": [
+            {"query": q, "ref": q, "ref_len": 41, "score": 82, "ref_b": 0, "ref_e": 40, "q_b": 0, "q_e": 40, "cigar": "41M"},
+            {"query": q, "ref": "ACGTTGCAAGGCTTAACCGGTTTTACGATCGATCGGATCCAG", "ref_len": 41, "score": 71,
+             "ref_b": 0, "ref_e": 40, "q_b": 0, "q_e": 38, "cigar": "20M2D19M"},
+            {"query": "ACGTNNGCAAGGCTTAACCGGTTACGATCGATCGGATCCAGT", "ref": q, "ref_len": 41, "score": 75,
+             "q_b": 0, "q_e": 41, "cigar": "4M1I37M"},
+        ],
+        "scoring": [2, 3, 5, 2],
+    }
+    assert O.ref_kmer3(b"TAG") == (35, 24)
+    r = O.ref_extract_kmers([b""] * 7 + [sv["read46"].encode()], False, 1)
+    assert [int(r[0]["kmer"]), int(r[0]["meta"]), int(r[0]["offset"])] == sv["read_records"][0]
+    json.dump(sv, open(os.path.join(HERE, "survey_vectors.json"), "w"), indent=1)
+
+    # ---- SSW vectors from the real ssw.c ----
+    rng = np.random.default_rng(12345)
+    cases = []
+    for params in ((2, 3, 5, 2), (1, 4, 6, 1)):
+        mat = O.build_matrix(params[0], params[1])
+        for _ in range(750):
+            L = int(rng.integers(20, 256))
+            ref = rng.integers(0, 4, L).astype(np.int8)
+            rd = ref.copy()
+            k = rng.integers(0, max(1, L // 10))
+            rd[rng.integers(0, L, k)] = rng.integers(0, 4, k)
+            if rng.random() < 0.5:  # indel
+                p = int(rng.integers(1, L - 1)); n = int(rng.integers(1, 4))
+                rd = np.concatenate([rd[:p], rd[p + n:]]) if rng.random() < 0.5 else \
+                    np.concatenate([rd[:p], rng.integers(0, 4, n).astype(np.int8), rd[p:]])
+            if rng.random() < 0.3:
+                rd = np.concatenate([rng.integers(0, 4, rng.integers(1, 15)).astype(np.int8), rd])
+            if rng.random() < 0.2:
+                rd[rng.integers(0, len(rd))] = 4
+            if rng.random() < 0.2:
+                ref = ref[:int(rng.integers(L // 2, L + 1))]
+            res, cig = O.ref_ssw_align(rd, ref, mat, params[2], params[3])
+            cases.append((params, rd, ref, res, cig))
+    np.savez_compressed(
+        os.path.join(HERE, "ssw_vectors.npz"),
+        params=np.array([c[0] for c in cases], dtype=np.int32),
+        reads=np.concatenate([c[1] for c in cases]), read_len=np.array([len(c[1]) for c in cases]),
+        refs=np.concatenate([c[2] for c in cases]), ref_len=np.array([len(c[2]) for c in cases]),
+        results=np.array([c[3] for c in cases], dtype=np.int32),
+        cigars=np.concatenate([c[4] for c in cases]), cigar_len=np.array([len(c[4]) for c in cases]))
+
+    # ---- k-mer vectors from the real KMer.h ----
+    B = np.frombuffer(b"ACGTNacgt", dtype=np.uint8)
+    seqs = [B[rng.choice(9, int(rng.integers(0, 300)), p=[.24, .24, .24, .24, .01, .0075, .0075, .0075, .0075])].tobytes()
+            for _ in range(60)] + [b"A" * 40, b"ACGT" * 10, b"T" * 33]
+    rr = O.ref_extract_kmers(seqs, False, 1)
+    rg = O.ref_extract_kmers(seqs, True, 16)
+    allr = np.concatenate([rr, rg])
+    srt = O.ref_sort_kmers(allr)
+    np.savez_compressed(os.path.join(HERE, "kmer_vectors.npz"),
+                        seqs=np.frombuffer(b"".join(seqs), dtype=np.uint8),
+                        seq_len=np.array([len(s) for s in seqs]), reads_gap1=rr, genbank_gap16=rg,
+                        sorted_kmer=srt["kmer"], sorted_meta=srt["meta"])
+
+    # ---- small end-to-end alignToDatabase fixture ----
+    K = load_kslam()
+    import importlib
+    synth = importlib.import_module("kslam_amd.synth")
+    genomes = synth.make_genomes(41, 3, 2, 12000, shared_segment=1500)
+    reads, _ = synth.make_paired_reads(42, genomes, 150, edge_frac=0.15, n_rate=0.003, indel_rate=0.004)
+    reads, genomes = synth.to_bytes(reads), synth.to_bytes(genomes)
+    a1, c1, _ = O.align_to_database(reads, genomes)
+    assert O.use_reference_ssw(True)
+    a2, c2, _ = O.align_to_database(reads, genomes)
+    O.use_reference_ssw(False)
+    assert (a1 == a2).all() and np.array_equal(c1, c2), "oracle restatement != reference ssw core"
+    np.savez_compressed(os.path.join(HERE, "align_small.npz"),
+                        reads=np.frombuffer(b"".join(reads), dtype=np.uint8),
+                        read_len=np.array([len(s) for s in reads]),
+                        genomes=np.frombuffer(b"".join(genomes), dtype=np.uint8),
+                        genome_len=np.array([len(s) for s in genomes]), alignments=a1, cigars=c1)
+    print("fixtures written:", sorted(f for f in os.listdir(HERE) if f.endswith((".npz", ".json"))))
+
+
+if __name__ == "__main__":
+    main()

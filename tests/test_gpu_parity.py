@@ -140,3 +140,113 @@ def test_empty_batch(kslam, synth):
 def test_unsupported_scoring_fails_loudly(kslam):
     with pytest.raises(kslam.KslamError):
         kslam.Context(gap_open=2, gap_extend=3)
+
+
+# ---------------------------------------------------------------------------
+# committed golden fixtures (made from the real reference pieces in the build container,
+# tests/golden/make_golden.py): nothing here needs /root/reference at run time
+# ---------------------------------------------------------------------------
+import os
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _split(flat, lens):
+    out, p = [], 0
+    for n in lens:
+        out.append(flat[p:p + int(n)])
+        p += int(n)
+    return out
+
+
+def test_golden_kmer_vectors(ctx):
+    z = np.load(os.path.join(GOLD, "kmer_vectors.npz"))
+    seqs = [s.tobytes() for s in _split(z["seqs"], z["seq_len"])]
+    rr = ctx.extract_kmers(seqs, False, 1)
+    rg = ctx.extract_kmers(seqs, True, 16)
+    assert (rr == z["reads_gap1"]).all() and (rg == z["genbank_gap16"]).all()
+    srt = ctx.sort_kmers(np.concatenate([rr, rg]))
+    assert (srt["kmer"] == z["sorted_kmer"]).all() and (srt["meta"] == z["sorted_meta"]).all()
+
+
+def test_golden_align_small(kslam):
+    z = np.load(os.path.join(GOLD, "align_small.npz"))
+    reads = [s.tobytes() for s in _split(z["reads"], z["read_len"])]
+    genomes = [s.tobytes() for s in _split(z["genomes"], z["genome_len"])]
+    got, gcig = kslam.align_to_database(reads, genomes)
+    _compare_alignments(got, gcig, z["alignments"], z["cigars"])
+
+
+def test_golden_ssw_vectors_through_the_abi(kslam):
+    """Each (read, ref) pair of the real-ssw.c vector file becomes a 1-read / 1-entry batch whose
+    only candidate is the planted k-mer hit; checks score + coordinates + CIGAR through the ABI.
+    Only vectors that share an exact 32-mer at a 16-aligned reference offset produce a candidate."""
+    z = np.load(os.path.join(GOLD, "ssw_vectors.npz"))
+    reads, refs = _split(z["reads"], z["read_len"]), _split(z["refs"], z["ref_len"])
+    cigs = _split(z["cigars"], z["cigar_len"])
+    lut = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    checked = 0
+    ctxs = {}
+    for i in range(len(reads)):
+        prm = tuple(int(v) for v in z["params"][i])
+        rd, rf = lut[reads[i]].tobytes(), lut[refs[i]].tobytes()
+        if len(rf) < len(rd) or len(rf) > len(rd):  # window must equal ref: need |ref| == |read| case only
+            continue
+        if prm not in ctxs:
+            ctxs[prm] = kslam.Context(match=prm[0], mismatch=prm[1], gap_open=prm[2], gap_extend=prm[3])
+        c = ctxs[prm]
+        c.set_index([rf])
+        ov, cg = c.align_batch([rd])
+        hit = ov[(ov["rel"] == 0) & (ov["revcomp"] == 0)]
+        if len(hit) == 0:
+            continue
+        h = hit[0]
+        exp = tuple(int(v) for v in z["results"][i])
+        assert (int(h["score"]), int(h["ref_begin"]), int(h["ref_end"]), int(h["query_begin"]),
+                int(h["query_end"])) == exp, i
+        assert np.array_equal(cg[int(h["cigar_off"]):int(h["cigar_off"]) + int(h["cigar_len"])], cigs[i]), i
+        checked += 1
+    for c in ctxs.values():
+        c.close()
+    assert checked >= 20, checked
+
+
+# ---------------------------------------------------------------------------
+# size-independent properties on a larger batch (the oracle would take minutes here)
+# ---------------------------------------------------------------------------
+def test_properties_large_batch(kslam, synth):
+    genomes = synth.make_genomes(77, 8, 3, 200000)
+    reads, truth = synth.make_paired_reads(78, genomes, 20000, sub_rate=0.0, indel_rate=0.0, unmapped_frac=0.05)
+    rb, gb = synth.to_bytes(reads), synth.to_bytes(genomes)
+    c = kslam.Context(max_kmers_per_chunk=1 << 20)   # forces several internal chunks
+    c.set_index(gb)
+    ov, cg = c.align_batch(rb)
+    ov2, cg2 = c.align_batch(rb)                      # idempotence
+    tm = c.timings()
+    c.close()
+    assert tm["n_chunks"] > 1
+    assert (ov == ov2).all() and np.array_equal(cg, cg2)
+    # sortedness: (read, entry, rel) non-decreasing, reference order (src/Overlap.h:87-98)
+    key = (ov["read"].astype(np.int64) << 40) | (ov["entry"].astype(np.int64) << 24) | (ov["rel"].astype(np.int64) + (1 << 20))
+    assert (np.diff(key) >= 0).all()
+    # error-free planted reads: best hit on the source genome has score 2 * L and CIGAR "150M"
+    n = len(truth)
+    best = {}
+    for i in np.nonzero(ov["score"] == 300)[0]:
+        best.setdefault(int(ov["read"][i]), []).append(i)
+    found = 0
+    for p, (g, start, flip) in enumerate(truth):
+        if g < 0:
+            continue
+        for rid in (p, p + n):
+            hits = [i for i in best.get(rid, []) if int(ov["entry"][i]) == g]
+            assert hits, (p, rid)
+            h = hits[0]
+            assert int(ov["cigar_len"][h]) == 1 and int(cg[int(ov["cigar_off"][h])]) == (150 << 4)
+            assert int(ov["ref_end"][h]) - int(ov["ref_begin"][h]) == 149
+            found += 1
+    assert found > 30000
+    # unmapped pairs (random sequence) have no alignment at all
+    for p, (g, _, _) in enumerate(truth):
+        if g < 0:
+            assert not (ov["read"] == p).any()

@@ -1,0 +1,191 @@
+"""CPU tests: the oracle against the golden vectors and (when oracle/_ref exists) the real
+reference pieces; structural expectations of the reference's own src/Tests.h."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _split(flat, lens):
+    out, p = [], 0
+    for n in lens:
+        out.append(flat[p:p + int(n)])
+        p += int(n)
+    return out
+
+
+def test_survey_vectors(oracle):
+    sv = json.load(open(os.path.join(GOLD, "survey_vectors.json")))
+    r = oracle.extract_kmers([b""] * sv["read_id"] + [sv["read46"].encode()], False, 1)
+    for i, exp in enumerate(sv["read_records"]):
+        assert [int(r[i]["kmer"]), int(r[i]["meta"]), int(r[i]["offset"])] == exp
+    g = oracle.extract_kmers([b""] * sv["genome_id"] + [sv["read46"].encode()], True, sv["genome_gap"])
+    assert [[int(x["meta"]), int(x["offset"])] for x in g] == sv["genome_meta_off"]
+    p = oracle.Params.default(match=sv["scoring"][0], mismatch=sv["scoring"][1],
+                              gap_open=sv["scoring"][2], gap_extend=sv["scoring"][3])
+    for a in sv["align"]:
+        for plain in (False, True):
+            res, cig = oracle.align(a["query"].encode(), a["ref"].encode()[:a["ref_len"]], p, plain=plain)
+            assert res.score1 == a["score"]
+            assert oracle.cigar_string(cig) == a["cigar"]
+            assert (res.read_begin1, res.read_end1) == (a["q_b"], a["q_e"])
+            if "ref_b" in a:
+                assert (res.ref_begin1, res.ref_end1) == (a["ref_b"], a["ref_e"])
+
+
+def test_ssw_golden_vectors(oracle):
+    """oracle (striped emulation AND the plain-Gotoh kernel spec) == answers of the real ssw.c"""
+    z = np.load(os.path.join(GOLD, "ssw_vectors.npz"))
+    reads, refs = _split(z["reads"], z["read_len"]), _split(z["refs"], z["ref_len"])
+    cigs = _split(z["cigars"], z["cigar_len"])
+    for i in range(len(reads)):
+        m, x, go, ge = [int(v) for v in z["params"][i]]
+        mat = oracle.build_matrix(m, x)
+        for plain in (False, True):
+            res, cig = oracle.ssw_align(reads[i], refs[i], mat, go, ge, plain=plain)
+            got = (res.score1, res.ref_begin1, res.ref_end1, res.read_begin1, res.read_end1)
+            assert got == tuple(int(v) for v in z["results"][i]), (i, plain)
+            assert np.array_equal(cig, cigs[i]), (i, plain)
+
+
+def test_kmer_golden_vectors(oracle):
+    z = np.load(os.path.join(GOLD, "kmer_vectors.npz"))
+    seqs = [s.tobytes() for s in _split(z["seqs"], z["seq_len"])]
+    rr = oracle.extract_kmers(seqs, False, 1)
+    rg = oracle.extract_kmers(seqs, True, 16)
+    assert (rr == z["reads_gap1"]).all() and (rg == z["genbank_gap16"]).all()
+    srt = oracle.sort_kmers(np.concatenate([rr, rg]))
+    assert (srt["kmer"] == z["sorted_kmer"]).all() and (srt["meta"] == z["sorted_meta"]).all()
+
+
+def test_align_small_golden(oracle):
+    z = np.load(os.path.join(GOLD, "align_small.npz"))
+    reads = [s.tobytes() for s in _split(z["reads"], z["read_len"])]
+    genomes = [s.tobytes() for s in _split(z["genomes"], z["genome_len"])]
+    for plain in (False, True):
+        al, cg, _ = oracle.align_to_database(reads, genomes, plain=plain)
+        assert (al == z["alignments"]).all() and np.array_equal(cg, z["cigars"])
+
+
+def _random_pair(rng):
+    L = int(rng.integers(20, 256))
+    ref = rng.integers(0, 4, L).astype(np.int8)
+    rd = ref.copy()
+    k = int(rng.integers(0, max(1, L // 8)))
+    rd[rng.integers(0, L, k)] = rng.integers(0, 4, k)
+    for _ in range(int(rng.integers(0, 3))):
+        p = int(rng.integers(1, len(rd) - 1)); n = int(rng.integers(1, 4))
+        rd = np.concatenate([rd[:p], rd[p + n:]]) if rng.random() < 0.5 else \
+            np.concatenate([rd[:p], rng.integers(0, 4, n).astype(np.int8), rd[p:]])
+    if rng.random() < 0.3:
+        rd = np.concatenate([rng.integers(0, 4, rng.integers(1, 20)).astype(np.int8), rd])
+    if rng.random() < 0.3:
+        rd = np.concatenate([rd, rng.integers(0, 4, rng.integers(1, 20)).astype(np.int8)])
+    if rng.random() < 0.2:
+        rd[rng.integers(0, len(rd))] = 4
+    if rng.random() < 0.2:
+        ref[rng.integers(0, len(ref))] = 4
+    if rng.random() < 0.2:
+        ref = ref[:int(rng.integers(L // 2, L + 1))]
+    return rd[:300], ref
+
+
+@pytest.mark.parametrize("params,n", [((2, 3, 5, 2), 3000), ((1, 4, 6, 1), 800), ((2, 6, 5, 1), 800),
+                                      ((3, 2, 4, 3), 800)])
+def test_plain_spec_equals_striped(oracle, params, n):
+    """The plain-Gotoh spec the HIP kernel implements == the striped emulation, inside the
+    scoring envelope kslam_create accepts (gapE < gapO, mismatch <= gapO + gapE)."""
+    rng = np.random.default_rng(sum(params))
+    mat = oracle.build_matrix(params[0], params[1])
+    for i in range(n):
+        rd, ref = _random_pair(rng)
+        a, ca = oracle.ssw_align(rd, ref, mat, params[2], params[3])
+        b, cb = oracle.ssw_align(rd, ref, mat, params[2], params[3], plain=True)
+        assert (a.score1, a.ref_begin1, a.ref_end1, a.read_begin1, a.read_end1) == \
+               (b.score1, b.ref_begin1, b.ref_end1, b.read_begin1, b.read_end1), i
+        assert np.array_equal(ca, cb), i
+
+
+def test_against_real_ssw_when_present(oracle):
+    if not oracle.have_ref_ssw():
+        pytest.skip("oracle/_ref/libssw_ref.so not built (no /root/reference)")
+    rng = np.random.default_rng(99)
+    for params in ((2, 3, 5, 2), (2, 9, 5, 2), (5, 4, 10, 10), (2, 8, 2, 3)):  # incl. sets outside the envelope
+        mat = oracle.build_matrix(params[0], params[1])
+        for i in range(500):
+            rd, ref = _random_pair(rng)
+            r0, c0 = oracle.ref_ssw_align(rd, ref, mat, params[2], params[3])
+            r1, c1 = oracle.ssw_align(rd, ref, mat, params[2], params[3])
+            assert (r1.score1, r1.ref_begin1, r1.ref_end1, r1.read_begin1, r1.read_end1) == r0, (params, i)
+            assert np.array_equal(c0, c1), (params, i)
+
+
+def test_against_real_kmer_code_when_present(oracle):
+    if not oracle.have_ref_kmer():
+        pytest.skip("oracle/_ref/libkmer_ref.so not built (no /root/reference)")
+    rng = np.random.default_rng(5)
+    B = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    seqs = [B[rng.choice(5, int(rng.integers(0, 500)), p=[.245, .245, .245, .245, .02])].tobytes() for _ in range(200)]
+    for is_gb, gap in ((False, 1), (True, 16), (True, 5)):
+        assert (oracle.extract_kmers(seqs, is_gb, gap) == oracle.ref_extract_kmers(seqs, is_gb, gap)).all()
+    recs = np.concatenate([oracle.extract_kmers(seqs, False, 1), oracle.extract_kmers(seqs, True, 16)])
+    a, b = oracle.sort_kmers(recs), oracle.ref_sort_kmers(recs)
+    assert (a["kmer"] == b["kmer"]).all() and (a["meta"] == b["meta"]).all()
+    assert oracle.ref_kmer3(b"TAG") == (35, 24)  # src/KMer.h:27
+
+
+def test_encoding_order_and_canonical_choice(oracle):
+    """src/Tests.h:334-452: packed k-mers sort in A<C<T<G order; canonical = numerically smaller,
+    palindromes take the rc branch (src/KMer.h:173)."""
+    r = oracle.extract_kmers([b"A" * 32, b"C" * 32, b"T" * 32, b"G" * 32], False, 1)
+    # A*32 / C*32: rc is T*32 / G*32 (larger) so forward; T*32 -> rc A*32 = 0 so rc; G -> rc C
+    assert [int(x["kmer"]) for x in r] == [0, 0x5555555555555555, 0, 0x5555555555555555]
+    assert [int(x["meta"]) >> 30 for x in r] == [0, 0, 1, 1]
+    pal = b"ACGT" * 8  # reverse complement of itself
+    p = oracle.extract_kmers([pal], False, 1)
+    assert int(p[0]["meta"]) >> 30 == 1 and int(p[0]["offset"]) == 0
+
+
+def test_dedupe_ladder(oracle):
+    """src/Overlap.h:79-85,290: unique compares with the LAST KEPT element: 0,2,4,5,8 -> 0,4,8."""
+    K = oracle.KMER_DT
+    rels = [0, 2, 4, 5, 8]
+    recs = []
+    for i, rel in enumerate(rels):
+        km = 1000 + i
+        recs.append((km, (1 << 31) | 3, 100 + rel))  # genome entry 3 at offset 100+rel
+        recs.append((km, 7, 100))                    # read 7 at offset 100 -> rel
+    a = np.array(recs, dtype=K)
+    ov, raw = oracle.find_overlaps(oracle.sort_kmers(a), [200] * 8)
+    assert raw == 5
+    assert [int(x) for x in ov["rel"]] == [0, 4, 8]
+    assert set(int(x) for x in ov["read"]) == {7} and set(int(x) for x in ov["entry"]) == {3}
+
+
+def test_planted_overlaps_and_scores(oracle, synth):
+    """src/Tests.h:161-333: planted (entry, rel, revComp) recovered; SW score = 2 x overlap length."""
+    rng = np.random.default_rng(2)
+    genomes = [synth.random_bases(rng, 3000) for _ in range(40)]
+    reads, truth = [], []
+    for i in range(300):
+        g = int(rng.integers(0, 40)); L = 100
+        off = int(rng.integers(-30, 3000 - 70))
+        lo, hi = max(off, 0), min(off + L, 3000)
+        s = np.concatenate([synth.random_bases(rng, lo - off), genomes[g][lo:hi], synth.random_bases(rng, off + L - hi)])
+        rc = bool(rng.random() < 0.5)
+        reads.append((synth.revcomp(s) if rc else s).tobytes())
+        truth.append((g, off, rc, hi - lo))
+    al, cg, _ = oracle.align_to_database(reads, [g.tobytes() for g in genomes])
+    for i, (g, off, rc, ovl) in enumerate(truth):
+        m = al[(al["read"] == i) & (al["entry"] == g)]
+        hit = [x for x in m if abs(int(x["rel"]) - off) < 3 and bool(x["revcomp"]) == rc]
+        assert hit and int(hit[0]["score"]) == 2 * ovl, i
+
+
+def test_kmer_zero_never_joins(oracle):
+    """src/Overlap.h:236-239: runs with kMerInt == 0 (poly-A / poly-T / all-N) are skipped."""
+    al, _, _ = oracle.align_to_database([b"A" * 100, b"N" * 100, b"T" * 100], [b"A" * 500])
+    assert len(al) == 0

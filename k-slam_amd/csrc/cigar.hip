@@ -54,7 +54,7 @@ __global__ void k_class_flags(const uint32_t *__restrict__ bw, const uint8_t *__
   if (i >= n) return;
   const uint32_t b = bw[i];
   uint32_t f = 0;
-  if (b != 0) {
+  if (b != 0 && !(b >> 31)) {   // bit 31: inline <n>M set by the SW kernel
     if (big) f = needbig[i] ? 1u : 0u;
     else f = (!needbig[i] && band_class(b) == cls) ? 1u : 0u;
   }
@@ -77,11 +77,18 @@ __global__ void k_max_bw(const uint32_t *__restrict__ bw, const uint32_t *__rest
 }
 
 __global__ void k_max_all(const uint32_t *__restrict__ bw, uint64_t n, uint32_t *__restrict__ out) {
+  __shared__ uint32_t sm[4];
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t v = i < n ? bw[i] : 0;
+  if (v >> 31) v = 0;
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) v = max(v, (uint32_t)__shfl_down((int)v, d, 64));
-  if ((threadIdx.x & 63) == 0 && v) atomicMax(out, v);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    v = max(max(sm[0], sm[1]), max(sm[2], sm[3]));
+    if (v) atomicMax(out, v);
+  }
 }
 
 struct CigJob {
@@ -260,6 +267,7 @@ __global__ __launch_bounds__(256) void k_finalize(kslam_overlap *__restrict__ ov
                                                   const uint32_t *__restrict__ tmp_big, uint32_t cap_big,
                                                   const uint32_t *__restrict__ big_pos,
                                                   const uint8_t *__restrict__ needbig,
+                                                  const uint32_t *__restrict__ bw,
                                                   uint32_t *__restrict__ pool, uint64_t pool_base, unsigned long long *cells) {
   __shared__ unsigned long long sm[4];
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -272,7 +280,9 @@ __global__ __launch_bounds__(256) void k_finalize(kslam_overlap *__restrict__ ov
     const int64_t wlen = (int64_t)min(L, G - (uint64_t)s0);
     mycells = L * (unsigned long long)wlen;
     const uint32_t cl = o.cigar_len;
-    if (cl) {
+    if (cl && (bw[i] >> 31)) {
+      pool[pool_base + cig_off[i]] = (bw[i] & 0x7FFFFFFFu) << 4;   // <n>M
+    } else if (cl) {
       const uint32_t *src = (needbig[i] == 2) ? tmp_big + (uint64_t)big_pos[i] * cap_big
                                                           : tmp + i * (uint64_t)cap;
       uint32_t *dst = pool + pool_base + cig_off[i];
@@ -410,12 +420,12 @@ void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, u
 }
 
 void cigar_finalize(kslam_overlap *d_ov, uint64_t n, SwInputs in, uint32_t lmax, CigarWork &W,
-                    uint32_t *d_pool, uint64_t pool_base, uint64_t *d_cells, hipStream_t s) {
+                    const uint32_t *d_bw, uint32_t *d_pool, uint64_t pool_base, uint64_t *d_cells, hipStream_t s) {
   if (n == 0) return;
   const unsigned nb = (unsigned)((n + 255) / 256);
   hipLaunchKernelGGL(k_finalize, dim3(nb), dim3(256), 0, s, d_ov, n, in, W.cig_off.as<uint64_t>(),
                      W.tmp.as<uint32_t>(), CIG_CAP, W.tmp_big.as<uint32_t>(), 2 * lmax + 4,
-                     W.big_pos.as<uint32_t>(), W.needbig.as<uint8_t>(), d_pool, pool_base,
+                     W.big_pos.as<uint32_t>(), W.needbig.as<uint8_t>(), d_bw, d_pool, pool_base,
                      reinterpret_cast<unsigned long long *>(d_cells));
   HIPCHK(hipGetLastError());
 }

@@ -171,6 +171,6 @@ void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, u
                      CigarWork &W, uint64_t *n_cigar_out, uint32_t *n_tb_err, hipStream_t s);
 // un-flip + absolute coordinates, cigar gather into pool[pool_base ...)
 void cigar_finalize(kslam_overlap *d_ov, uint64_t n, SwInputs in, uint32_t lmax, CigarWork &W,
-                    uint32_t *d_pool, uint64_t pool_base, uint64_t *d_cells, hipStream_t s);
+                    const uint32_t *d_bw, uint32_t *d_pool, uint64_t pool_base, uint64_t *d_cells, hipStream_t s);
 
 }  // namespace kslam

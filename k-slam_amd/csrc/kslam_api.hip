@@ -215,7 +215,8 @@ void finish_load_reads(kslam_ctx *c) {
   if (n >= (1ull << 30)) throw StatusError{KSLAM_ERR_UNSUPPORTED, "more than 2^30 reads (KMer.h:65 id field)"};
   uint64_t mx = 0;
   for (uint64_t i = 0; i < n; i++) mx = std::max(mx, c->h_roff[i + 1] - c->h_roff[i]);
-  if (mx > 512) throw StatusError{KSLAM_ERR_UNSUPPORTED, "reads longer than 512 bases are not supported yet"};
+  if (mx > 511) throw StatusError{KSLAM_ERR_UNSUPPORTED, "reads longer than 511 bases are not supported yet"};
+  if ((uint64_t)c->prm.match * mx > 8191) throw StatusError{KSLAM_ERR_UNSUPPORTED, "match * read length must stay below 8192 (14-bit score field of the SW kernel)"};
   c->max_read_len = (uint32_t)mx;
   c->r_off.ensure((n + 1) * sizeof(uint64_t));
   HIPCHK(hipMemcpyAsync(c->r_off.p, c->h_roff.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s));
@@ -357,7 +358,7 @@ void align_resident(kslam_ctx *c, bool stop_after_join, uint64_t *n_raw_out) {
       cigar_traceback(cand, m, in, sp, c->max_read_len, c->band0.as<uint32_t>(), c->cig, &ncig, &tb_err, s);
       tb_err_total += tb_err;
       ensure_keep(c->res_cig, (c->n_cig + ncig + 1) * sizeof(uint32_t), c->n_cig * sizeof(uint32_t), s);
-      cigar_finalize(cand, m, in, c->max_read_len, c->cig, c->res_cig.as<uint32_t>(), c->n_cig,
+      cigar_finalize(cand, m, in, c->max_read_len, c->cig, c->band0.as<uint32_t>(), c->res_cig.as<uint32_t>(), c->n_cig,
                      c->cells.as<uint64_t>(), s);
     } else {
       HIPCHK(hipEventRecord(c->ev[6], s));

@@ -79,6 +79,8 @@ def lib():
         for f in (L.orc_ssw_align, L.orc_ssw_align_plain):
             f.argtypes = [vp, i32, vp, i32, vp, C.c_uint8, C.c_uint8, C.c_uint8,
                           C.c_uint16, i32, vp, i32, C.POINTER(SswResult)]
+        L.orc_ssw_align_mode.argtypes = [vp, i32, vp, i32, vp, C.c_uint8, C.c_uint8, C.c_uint8,
+                                         C.c_uint16, i32, vp, i32, C.POINTER(SswResult), C.c_int]
         L.orc_banded_sw.restype = i32
         L.orc_banded_sw.argtypes = [vp, vp, i32, i32, i32, u32, u32, i32, vp, i32, vp, i32, vp]
         L.orc_align.argtypes = [C.c_char_p, i32, C.c_char_p, i32, C.POINTER(Params),
@@ -159,9 +161,9 @@ def ssw_align(read_codes, ref_codes, mat, gap_open, gap_extend, flag=0x0f,
     cap = 2 * (len(rd) + len(rf)) + 8
     cig = np.zeros(cap, dtype=np.uint32)
     res = SswResult()
-    f = L.orc_ssw_align_plain if plain else L.orc_ssw_align
-    f(rd.ctypes.data, len(rd), rf.ctypes.data, len(rf), mat.ctypes.data, gap_open,
-      gap_extend, flag, filters, filterd, cig.ctypes.data, cap, C.byref(res))
+    L.orc_ssw_align_mode(rd.ctypes.data, len(rd), rf.ctypes.data, len(rf), mat.ctypes.data, gap_open,
+                         gap_extend, flag, filters, filterd, cig.ctypes.data, cap, C.byref(res),
+                         int(plain))
     return res, cig[:max(res.cigar_len, 0)].copy()
 
 

@@ -561,6 +561,56 @@ static sw_end plain_pass(const int8_t *ref, int ref_dir, int32_t refLen,
 }
 
 /* ------------------------------------------------------------------------
+ * Second formulation of the same SPEC, the one the HIP kernel actually runs:
+ * ONE forward pass that carries, next to every score, the start cell of the
+ * alignment it belongs to ("origin"), packed as score * 2^18 + (col << 9 | row)
+ * so that an integer max is a lexicographic (score, col, row) max.  Among all
+ * optimal alignments ending at (end_ref, end_read) it therefore reports the one
+ * starting at the largest column, then the largest row -- exactly what the
+ * reference's reverse pass finds (first column from the right whose maximum
+ * equals the score, then the smallest reversed read index, ssw.c:906-923).
+ * A cell whose score is 0 stores the key of its diagonal successor, so a fresh
+ * alignment picks up its own first cell as origin.
+ * ---------------------------------------------------------------------- */
+static void origin_pass(const int8_t *ref, int32_t refLen, const int8_t *read,
+                        int32_t readLen, const int8_t *mat, int32_t n,
+                        int32_t gapO, int32_t gapE, int32_t *score,
+                        int32_t *end_ref, int32_t *end_read, int32_t *beg_ref,
+                        int32_t *beg_read) {
+  const int KB = 18;
+  int64_t *H = (int64_t *)calloc((size_t)readLen + 1, sizeof(int64_t));
+  int64_t *E = (int64_t *)calloc((size_t)readLen + 1, sizeof(int64_t));
+  const int64_t NEG = -((int64_t)(gapO + gapE + 1) << KB);
+  for (int32_t i = 0; i < readLen; i++) { H[i] = ((int64_t)0 << 9) | (i + 1); E[i] = NEG; } /* virtual cell (i, -1): diagonal successor (i + 1, 0) */
+  int64_t bestV = 0; int32_t best = 0, bc = 0, br = readLen - 1;
+  for (int32_t c = 0; c < refLen; c++) {
+    int64_t F = NEG;
+    int64_t diag = ((int64_t)c << 9) | 0;          /* virtual row -1: successor (0, c) */
+    const int8_t *mrow = mat + ref[c] * n;
+    for (int32_t i = 0; i < readLen; i++) {
+      int64_t h = diag + ((int64_t)mrow[read[i]] << KB);
+      if (E[i] > h) h = E[i];
+      if (F > h) h = F;
+      const int64_t Z = ((int64_t)(c + 1) << 9) | (int64_t)(i + 1);
+      if (Z > h) h = Z;
+      diag = H[i];
+      H[i] = h;
+      const int32_t sc = (int32_t)(h >> KB);
+      if (sc > best) { best = sc; bestV = h; bc = c; br = i; }
+      const int64_t hg = h - ((int64_t)gapO << KB);
+      int64_t e = E[i] - ((int64_t)gapE << KB);
+      E[i] = e > hg ? e : hg;
+      int64_t f = F - ((int64_t)gapE << KB);
+      F = f > hg ? f : hg;
+    }
+  }
+  free(H); free(E);
+  *score = best; *end_ref = bc; *end_read = br;
+  const int32_t key = (int32_t)(bestV & ((1 << KB) - 1));
+  *beg_ref = key >> 9; *beg_read = key & 511;
+}
+
+/* ------------------------------------------------------------------------
  * a-13: banded_sw, src/ssw.c:594-792, restated with the same three row
  * arrays and index helpers (set_u :56-62, set_d :66-72) so that the edge
  * sentinels (:655) behave identically.  Returns the cigar length, writes the
@@ -701,6 +751,14 @@ static void ssw_align_impl(const int8_t *read, int32_t readLen,
   bias = abs(bias);
   int word = 0;
   sw_end best;
+  if (plain == 2 && (flag & 0x08) && readLen < 512 && refLen < 512) {
+    int32_t sc, er, eq, brf, brd;
+    origin_pass(ref, refLen, read, readLen, mat, n, gapO, gapE, &sc, &er, &eq, &brf, &brd);
+    r->score1 = (uint16_t)sc; r->ref_end1 = er; r->read_end1 = eq;
+    r->ref_begin1 = brf; r->read_begin1 = brd;
+    if (sc == 0) { r->ref_begin1 = -1; r->read_begin1 = -1; return; }
+    goto cigar_stage;
+  }
   if (plain) {
     best = plain_pass(ref, 0, refLen, read, readLen, mat, n, gapO, gapE, -1);
     word = 1;
@@ -733,6 +791,7 @@ static void ssw_align_impl(const int8_t *read, int32_t readLen,
   free(rev);
   r->ref_begin1 = br.ref;
   r->read_begin1 = r->read_end1 - br.read;
+cigar_stage:
   if ((7 & flag) == 0 || ((2 & flag) != 0 && r->score1 < filters) ||
       ((4 & flag) != 0 && (r->ref_end1 - r->ref_begin1 > filterd ||
                            r->read_end1 - r->read_begin1 > filterd)))
@@ -756,6 +815,14 @@ void orc_ssw_align(const int8_t *read, int32_t read_len, const int8_t *ref,
                    orc_ssw_result *res) {
   ssw_align_impl(read, read_len, ref, ref_len, mat, gap_open, gap_extend, flag,
                  filters, filterd, cigar_out, cigar_cap, res, 0);
+}
+void orc_ssw_align_mode(const int8_t *read, int32_t read_len, const int8_t *ref,
+                        int32_t ref_len, const int8_t mat[25], uint8_t gap_open,
+                        uint8_t gap_extend, uint8_t flag, uint16_t filters,
+                        int32_t filterd, uint32_t *cigar_out, int32_t cigar_cap,
+                        orc_ssw_result *res, int mode) {
+  ssw_align_impl(read, read_len, ref, ref_len, mat, gap_open, gap_extend, flag,
+                 filters, filterd, cigar_out, cigar_cap, res, mode);
 }
 void orc_ssw_align_plain(const int8_t *read, int32_t read_len,
                          const int8_t *ref, int32_t ref_len,

@@ -114,6 +114,13 @@ void orc_ssw_align_plain(const int8_t *read, int32_t read_len,
                          uint8_t gap_extend, uint8_t flag, uint16_t filters,
                          int32_t filterd, uint32_t *cigar_out,
                          int32_t cigar_cap, orc_ssw_result *res);
+/* mode 0 = striped emulation, 1 = plain two-pass Gotoh, 2 = single forward pass
+ * with origin tracking (what the HIP kernel runs) */
+void orc_ssw_align_mode(const int8_t *read, int32_t read_len, const int8_t *ref,
+                        int32_t ref_len, const int8_t mat[25], uint8_t gap_open,
+                        uint8_t gap_extend, uint8_t flag, uint16_t filters,
+                        int32_t filterd, uint32_t *cigar_out, int32_t cigar_cap,
+                        orc_ssw_result *res, int mode);
 int32_t orc_banded_sw(const int8_t *ref, const int8_t *read, int32_t ref_len,
                       int32_t read_len, int32_t score, uint32_t gap_open,
                       uint32_t gap_extend, int32_t band_width,

@@ -18,6 +18,7 @@
 // in near lock step, so the row arrays and the 1-byte-per-cell direction matrix
 // are touched with coalesced 64-lane accesses that stay in L2.
 #include "common.h"
+#include "banded_core.h"
 
 namespace kslam {
 
@@ -109,13 +110,58 @@ struct CigJob {
   uint32_t *err;        // [0] traceback errors
 };
 
-__global__ __launch_bounds__(64) void k_banded(CigJob J, SwInputs in, SwParams p) {
+// banded_sw (ssw.c:594-792): one attempt with J.bw[ci], then traceback when max >= score.
+// One candidate per lane; everything the DP touches lives in LDS laid out [element][lane]
+// (NL lanes per block, fewer for wide bands): translated read / reference spans, the three
+// row arrays, one direction byte per band cell.  The serial chain (f and the left H) runs in
+// registers; the previous-row values and the reference code of the next cell are fetched one
+// iteration ahead so LDS latency hides behind the chain.
+struct LdsLayout {
+  uint32_t nl;       // lanes (candidates) per block
+  uint32_t lmax;     // rows / columns the sequence buffers are sized for
+  uint32_t W1;       // row array length (2 * slot_bw + 4)
+  uint32_t wd;       // direction cells per row the global slab is sized for (2 * slot_bw + 1)
+};
+
+// stage `len` bases starting at src (any alignment) as SSW codes into dst[k * NL]; when `rev`
+// the bases are complemented and written back to front (window of a revComp overlap)
+__device__ inline void stage_codes(const uint8_t *src, int32_t len, bool rev, uint8_t *dst, uint32_t NL) {
+  const uintptr_t a0 = reinterpret_cast<uintptr_t>(src);
+  const uintptr_t al = a0 & ~(uintptr_t)3;
+  const int32_t nw = (int32_t)((a0 + (uintptr_t)len - al + 3) >> 2);
+  const uint32_t *w = reinterpret_cast<const uint32_t *>(al);
+  const int32_t shift0 = (int32_t)(a0 - al);
+  for (int32_t x = 0; x < nw; x++) {
+    const uint32_t v = w[x];
+#pragma unroll
+    for (int32_t b = 0; b < 4; b++) {
+      const int32_t k = x * 4 + b - shift0;
+      if (k >= 0 && k < len) {
+        const uint32_t ch = (v >> (8 * b)) & 0xFFu;
+        if (rev) dst[(uint32_t)(len - 1 - k) * NL] = (uint8_t)tr_base(comp_base(ch));
+        else dst[(uint32_t)k * NL] = (uint8_t)tr_base(ch);
+      }
+    }
+  }
+}
+
+// One candidate per lane.  LDS ([element][lane]): translated spans + the three row arrays.
+// Global slab per block ([cell][lane], coalesced, L2 resident): one direction byte per band
+// cell, written fire-and-forget during the DP and read back only by the traceback.
+__global__ __launch_bounds__(64) void k_banded_lds(CigJob J, SwInputs in, SwParams p, LdsLayout Y) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
   const uint32_t lane = threadIdx.x;
-  const uint32_t li = blockIdx.x * 64 + lane;
-  if (li >= J.m) return;
+  const uint32_t NL = Y.nl;
+  const uint32_t li = blockIdx.x * NL + lane;
+  if (lane >= NL || li >= J.m) return;
+  uint8_t *SQ = lds_raw;
+  uint8_t *SR = SQ + (size_t)Y.lmax * NL;
+  int32_t *S = reinterpret_cast<int32_t *>(SR + (((size_t)Y.lmax * NL + 15) & ~(size_t)15));
+  uint8_t *D = J.scratch + (uint64_t)blockIdx.x * J.wave_slab;
+
   const uint32_t ci = J.list[J.list_base + li];
   kslam_overlap o = J.ov[ci];
-  int32_t band_width = (int32_t)J.bw[ci];
+  const int32_t band_width = (int32_t)J.bw[ci];
   const int32_t score = o.score;
   const int32_t refLen = o.ref_end - o.ref_begin + 1;    // ssw.c:930-931
   const int32_t readLen = o.query_end - o.query_begin + 1;
@@ -127,117 +173,47 @@ __global__ __launch_bounds__(64) void k_banded(CigJob J, SwInputs in, SwParams p
     J.bw[ci] = 0;
     return;
   }
-  const uint64_t ro = in.read_off[o.read];
-  const uint64_t L = in.read_off[o.read + 1] - ro;
-  const uint64_t go = in.genome_off[o.entry];
-  const uint64_t G = in.genome_off[o.entry + 1] - go;
-  const int64_t s0 = o.rel > 0 ? o.rel : 0;
-  const int64_t wlen = (int64_t)min(L, G - (uint64_t)s0);
-  const uint8_t *rd = in.read_bases + ro + o.query_begin;
-  const uint8_t *gw = in.genome_bases + go + s0;
-  const int32_t rb = o.ref_begin;
-  const bool rc = o.revcomp != 0;
-
-  const int32_t width = band_width * 2 + 3, width_d = band_width * 2 + 1;
-  const int32_t W1 = (int32_t)J.slot_bw * 2 + 4;  // row array length the slab was sized for
-  uint8_t *slab = J.scratch + (uint64_t)blockIdx.x * J.wave_slab;
-  int32_t *S = reinterpret_cast<int32_t *>(slab);
-  uint8_t *D = slab + (uint64_t)3 * W1 * 64 * sizeof(int32_t);
-#define HB(k) S[(uint32_t)(k) * 64u + lane]
-#define EB(k) S[(uint32_t)(W1 + (k)) * 64u + lane]
-#define HC(k) S[(uint32_t)(2 * W1 + (k)) * 64u + lane]
-#define DIR(i, col) D[((uint64_t)(i) * (uint32_t)width_d + (uint32_t)(col)) * 64u + lane]
-  int32_t mx = J.bmax[ci];
-  for (int32_t k = 0; k <= width; k++) { HB(k) = 0; EB(k) = 0; HC(k) = 0; }
-  for (int32_t i = 0; i < readLen; i++) {
-    int32_t beg = 0, end = refLen - 1, u = 0, edge, f;
-    int32_t j = i - band_width;
-    beg = beg > j ? beg : j;
-    j = i + band_width;
-    end = end < j ? end : j;
-    edge = end + 1 < width - 1 ? end + 1 : width - 1;      // ssw.c:654
-    f = 0;
-    HB(0) = 0; EB(0) = 0; HB(edge) = 0; EB(edge) = 0; HC(0) = 0;  // ssw.c:655
-    const uint32_t qc = tr_base(rd[i]);
-    const int32_t xi = i - band_width > 0 ? i - band_width : 0;
-    const int32_t xim = i - 1 - band_width > 0 ? i - 1 - band_width : 0;
-    for (j = beg; j <= end; j++) {
-      const int32_t e = j - xim + 1;        // set_u(e, w, i-1, j)
-      const int32_t b = j - 1 - xi + 1;     // set_u(b, w, i, j-1)
-      const int32_t d = j - 1 - xim + 1;    // set_u(d, w, i-1, j-1)
-      u = j - xi + 1;                       // set_u(u, w, i, j)
-      const int32_t pos = rb + j;
-      const uint32_t ch = rc ? comp_base(gw[wlen - 1 - pos]) : gw[pos];
-      const uint32_t rcode = tr_base(ch);
-      const int32_t sc = (qc > 3u || rcode > 3u) ? 0 : (qc == rcode ? p.match : -p.mismatch);
-      int32_t t1 = i == 0 ? -p.gap_open : HB(e) - p.gap_open;     // ssw.c:668-671
-      int32_t t2 = i == 0 ? -p.gap_extend : EB(e) - p.gap_extend;
-      const int32_t ev = t1 > t2 ? t1 : t2;
-      EB(u) = ev;
-      const uint32_t de = t1 > t2 ? 3u : 2u;
-      t1 = HC(b) - p.gap_open;                                     // ssw.c:673-676
-      t2 = f - p.gap_extend;
-      f = t1 > t2 ? t1 : t2;
-      const uint32_t df = t1 > t2 ? 5u : 4u;
-      const int32_t e1 = ev > 0 ? ev : 0, f1 = f > 0 ? f : 0;      // ssw.c:678-682
-      t1 = e1 > f1 ? e1 : f1;
-      t2 = HB(d) + sc;
-      const int32_t hv = t1 > t2 ? t1 : t2;
-      HC(u) = hv;
-      if (hv > mx) mx = hv;                                        // ssw.c:684
-      const uint32_t dh = t1 <= t2 ? 1u : (e1 > f1 ? de : df);     // ssw.c:686-690
-      DIR(i, j - xi) = (uint8_t)((de - 2u) | ((df - 4u) << 1) | (dh << 2));
-    }
-    for (j = 1; j <= u; j++) HB(j) = HC(j);                        // ssw.c:692
+  {  // stage the two spans as SSW codes (ssw_cpp.cpp:11-23)
+    const uint64_t ro = in.read_off[o.read];
+    const uint64_t L = in.read_off[o.read + 1] - ro;
+    const uint64_t go = in.genome_off[o.entry];
+    const uint64_t G = in.genome_off[o.entry + 1] - go;
+    const int64_t s0 = o.rel > 0 ? o.rel : 0;
+    const int64_t wlen = (int64_t)min(L, G - (uint64_t)s0);
+    stage_codes(in.read_bases + ro + o.query_begin, readLen, false, SQ + lane, NL);
+    const uint8_t *gw = in.genome_bases + go + s0;
+    if (o.revcomp)   // window position x of the flipped window is genome position wlen - 1 - x
+      stage_codes(gw + (wlen - 1 - o.ref_end), refLen, true, SR + lane, NL);
+    else
+      stage_codes(gw + o.ref_begin, refLen, false, SR + lane, NL);
   }
+  struct Acc {
+    int32_t *S; uint8_t *SQ, *SR, *D;
+    uint32_t NL, lane, W1, width_d;
+    __device__ int32_t &hb(int32_t k) { return S[(uint32_t)k * NL + lane]; }
+    __device__ int32_t &eb(int32_t k) { return S[(W1 + (uint32_t)k) * NL + lane]; }
+    __device__ int32_t &hc(int32_t k) { return S[(2 * W1 + (uint32_t)k) * NL + lane]; }
+    __device__ uint32_t q(int32_t i) { return SQ[(uint32_t)i * NL + lane]; }
+    __device__ uint32_t r(int32_t j) { return SR[(uint32_t)j * NL + lane]; }
+    __device__ void set_dir(int32_t i, int32_t col, uint32_t v) { D[((size_t)i * width_d + (uint32_t)col) * NL + lane] = (uint8_t)v; }
+    __device__ uint32_t get_dir(int32_t i, int32_t col) { return D[((size_t)i * width_d + (uint32_t)col) * NL + lane]; }
+  } A{S, SQ, SR, D, NL, lane, Y.W1, (uint32_t)(band_width * 2 + 1)};
+  (void)score;
+  const int32_t mx = banded_attempt(A, refLen, readLen, band_width, p, J.bmax[ci]);
   J.bmax[ci] = mx;
   if (mx < score) {               // ssw.c:693-694: retry with twice the band
     J.bw[ci] = (uint32_t)band_width * 2u;
     return;
   }
-  // traceback, ssw.c:698-771
-  int32_t i = readLen - 1, j = refLen - 1, cnt = 0, l = 0, op = 0, cur = 0, plane = 2;
   uint32_t *tmp = J.tmp + (uint64_t)(J.big ? (J.list_base + li) : ci) * J.cap;
-  bool bad = false, ovf = false;
-  while (i > 0) {
-    const int32_t xi = i - band_width > 0 ? i - band_width : 0;
-    const int32_t col = j - xi;
-    const int32_t jend = (refLen - 1) < (i + band_width) ? (refLen - 1) : (i + band_width);
-    uint32_t dir = 0;
-    if (col >= 0 && j <= jend && j >= 0) {
-      const uint32_t bb = DIR(i, col);
-      dir = plane == 2 ? ((bb >> 2) & 7u) : (plane == 0 ? 2u + (bb & 1u) : 4u + ((bb >> 1) & 1u));
-    }
-    switch (dir) {
-      case 1: --i; --j; plane = 2; op = 0; break;
-      case 2: --i; plane = 0; op = 1; break;
-      case 3: --i; plane = 2; op = 1; break;
-      case 4: --j; plane = 1; op = 2; break;
-      case 5: --j; plane = 2; op = 2; break;
-      default: bad = true; break;
-    }
-    if (bad) break;
-    if (op == cur) ++cnt;
-    else {
-      if ((uint32_t)l < J.cap) tmp[l] = (uint32_t)cnt << 4 | (uint32_t)cur; else ovf = true;
-      ++l;
-      cur = op;
-      cnt = 1;
-    }
-  }
-  if (bad) {
+  bool ovf = false;
+  const int32_t l = banded_traceback(A, refLen, readLen, band_width, tmp, J.cap, &ovf);
+  if (l < 0) {
     atomicAdd(&J.err[0], 1u);
     o.cigar_len = 0;
     J.ov[ci] = o;
     J.bw[ci] = 0;
     return;
-  }
-  if (op == 0) {                                                    // ssw.c:754-761
-    if ((uint32_t)l < J.cap) tmp[l] = (uint32_t)(cnt + 1) << 4; else ovf = true;
-    ++l;
-  } else {
-    if ((uint32_t)l + 1 < J.cap) { tmp[l] = (uint32_t)cnt << 4 | (uint32_t)op; tmp[l + 1] = 16u; } else ovf = true;
-    l += 2;
   }
   if (ovf) {
     J.needbig[ci] = 1;  // rerun with a full-size temp slot
@@ -247,10 +223,6 @@ __global__ __launch_bounds__(64) void k_banded(CigJob J, SwInputs in, SwParams p
   J.ov[ci] = o;
   J.bw[ci] = 0;
   J.needbig[ci] = J.big ? 2 : 0;  // 2: ops live in the big temp area
-#undef HB
-#undef EB
-#undef HC
-#undef DIR
 }
 
 __global__ void k_cigar_lens(const kslam_overlap *__restrict__ ov, uint64_t n, uint32_t *__restrict__ lens) {
@@ -313,8 +285,13 @@ __global__ __launch_bounds__(256) void k_finalize(kslam_overlap *__restrict__ ov
 // ---------------------------------------------------------------------------
 // host driver of the cigar stage
 // ---------------------------------------------------------------------------
-namespace {
-constexpr uint32_t CIG_CAP = 24;  // ops per small temp slot
+void cigar_prepare(CigarWork &W, uint64_t n, hipStream_t s) {
+  if (n == 0) return;
+  W.bmax.ensure(n * sizeof(int32_t));
+  W.needbig.ensure(n);
+  W.tmp.ensure(n * (uint64_t)CIG_CAP * sizeof(uint32_t));
+  HIPCHK(hipMemsetAsync(W.bmax.p, 0, n * sizeof(int32_t), s));
+  HIPCHK(hipMemsetAsync(W.needbig.p, 0, n, s));
 }
 
 void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, uint32_t lmax, uint32_t *d_bw,
@@ -327,22 +304,16 @@ void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, u
   W.flags.ensure(n * sizeof(uint32_t));
   W.pos.ensure(n * sizeof(uint32_t));
   W.list.ensure(n * sizeof(uint32_t));
-  W.bmax.ensure(n * sizeof(int32_t));
-  W.needbig.ensure(n);
   W.big_pos.ensure(n * sizeof(uint32_t));
   W.scan_tmp.ensure(scan_tmp_bytes(n));
   W.totals.ensure(4 * sizeof(uint64_t));
   W.cig_off.ensure(n * sizeof(uint64_t));
-  W.tmp.ensure(n * (uint64_t)CIG_CAP * sizeof(uint32_t));
   W.tmp_big.ensure(256);
   uint64_t *d_tot = W.totals.as<uint64_t>();
   uint32_t *d_err = reinterpret_cast<uint32_t *>(d_tot + 2);
-  HIPCHK(hipMemsetAsync(W.bmax.p, 0, n * sizeof(int32_t), s));
-  HIPCHK(hipMemsetAsync(W.needbig.p, 0, n, s));
   HIPCHK(hipMemsetAsync(d_tot, 0, 4 * sizeof(uint64_t), s));
   const uint32_t cap_big = 2 * lmax + 4;
   if (p.report_cigar) {
-    const uint64_t SCRATCH_BUDGET = 1ull << 31;
     auto run_lists = [&](uint32_t cls, bool big) -> uint64_t {
       hipLaunchKernelGGL(k_class_flags, dim3(nb), dim3(256), 0, s, d_bw, W.needbig.as<uint8_t>(), n, cls,
                          big ? 1u : 0u, W.flags.as<uint32_t>());
@@ -355,18 +326,31 @@ void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, u
       return m;
     };
     auto launch = [&](uint64_t m, uint32_t slot_bw, bool big) {
-      const uint64_t W1 = (uint64_t)slot_bw * 2 + 4;
-      uint64_t slab = 64ull * (3 * W1 * sizeof(int32_t) + (uint64_t)(2 * slot_bw + 1) * lmax);
+      LdsLayout Y;
+      Y.lmax = lmax; Y.W1 = slot_bw * 2 + 4; Y.wd = slot_bw * 2 + 1;
+      const size_t per_lane = (size_t)2 * lmax + (size_t)3 * Y.W1 * sizeof(int32_t);
+      uint32_t nl = 64;
+      while (nl > 1 && per_lane * nl + 64 > 64 * 1024) nl >>= 1;   // <= 64 KB: at least two blocks per CU
+      Y.nl = nl;
+      const size_t lds = (size_t)lmax * nl + (((size_t)lmax * nl + 15) & ~(size_t)15) +
+                         (size_t)3 * Y.W1 * nl * sizeof(int32_t);
+      if (lds > 160 * 1024) throw StatusError{KSLAM_ERR_UNSUPPORTED, "banded traceback band does not fit LDS"};
+      if (lds > 64 * 1024)
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_banded_lds),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      uint64_t slab = (uint64_t)lmax * Y.wd * nl;
       slab = (slab + 255) & ~255ull;
-      const uint64_t waves_per_launch = std::max<uint64_t>(1, SCRATCH_BUDGET / slab);
-      const uint64_t per_launch = waves_per_launch * 64;
-      W.scratch.ensure(std::min<uint64_t>((m + 63) / 64, waves_per_launch) * slab);
-      for (uint64_t base = 0; base < m; base += per_launch) {
+      const uint64_t SCRATCH_BUDGET = 3ull << 30;
+      const uint64_t blocks_per_launch = std::max<uint64_t>(1, SCRATCH_BUDGET / slab);
+      const uint64_t n_blocks = (m + nl - 1) / nl;
+      W.scratch.ensure(std::min<uint64_t>(n_blocks, blocks_per_launch) * slab);
+      for (uint64_t b0 = 0; b0 < n_blocks; b0 += blocks_per_launch) {
         CigJob J;
         J.ov = d_ov; J.bw = d_bw; J.bmax = W.bmax.as<int32_t>(); J.needbig = W.needbig.as<uint8_t>();
         J.list = W.list.as<uint32_t>();
-        J.m = (uint32_t)std::min<uint64_t>(per_launch, m - base);
-        J.list_base = (uint32_t)base;
+        const uint64_t nb_here = std::min<uint64_t>(blocks_per_launch, n_blocks - b0);
+        J.list_base = (uint32_t)(b0 * nl);
+        J.m = (uint32_t)std::min<uint64_t>(nb_here * nl, m - b0 * nl);
         J.slot_bw = slot_bw; J.lmax = lmax;
         J.cap = big ? cap_big : CIG_CAP;
         J.tmp = big ? W.tmp_big.as<uint32_t>() : W.tmp.as<uint32_t>();
@@ -374,7 +358,7 @@ void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, u
         J.scratch = W.scratch.as<uint8_t>();
         J.wave_slab = slab;
         J.err = d_err;
-        hipLaunchKernelGGL(k_banded, dim3((J.m + 63) / 64), dim3(64), 0, s, J, in, p);
+        hipLaunchKernelGGL(k_banded_lds, dim3((unsigned)nb_here), dim3(64), lds, s, J, in, p, Y);
       }
       HIPCHK(hipGetLastError());
     };
@@ -392,6 +376,7 @@ void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, u
         if (cls > last_cls) break;
         continue;
       }
+      if (getenv("KSLAM_DEBUG")) fprintf(stderr, "[kslam] cigar class %u (band <= %u): %llu candidates\n", cls, 1u << cls, (unsigned long long)m);
       launch(m, 1u << cls, false);
       if (cls >= last_cls) last_cls = cls + 1;
     }

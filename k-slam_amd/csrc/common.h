@@ -165,6 +165,9 @@ void sw_scores(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, uint32_
 struct CigarWork {
   DevBuf flags, pos, list, bmax, needbig, scan_tmp, totals, cig_off, tmp, tmp_big, big_pos, scratch;
 };
+constexpr uint32_t CIG_CAP = 24;  // ops per small temp cigar slot
+// allocates and clears the per-candidate cigar state; call before sw_scores
+void cigar_prepare(CigarWork &W, uint64_t n, hipStream_t s);
 // banded DP + traceback into temp slots; returns the total number of cigar ops
 // and the number of "Trace back error" cases (reference would abort there)
 void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, uint32_t lmax, uint32_t *d_bw,

@@ -351,6 +351,7 @@ void align_resident(kslam_ctx *c, bool stop_after_join, uint64_t *n_raw_out) {
       kslam_overlap *cand = c->res_ov.as<kslam_overlap>() + c->n_res;
       // ---- a-8..a-12: scores and ends ----
       c->band0.ensure((m + 1) * sizeof(uint32_t));
+      cigar_prepare(c->cig, m, s);
       sw_scores(cand, m, in, sp, c->max_read_len, c->band0.as<uint32_t>(), s);
       HIPCHK(hipEventRecord(c->ev[6], s));
       // ---- a-13: cigar ----

@@ -158,8 +158,12 @@ struct SwInputs {
 // forward + reverse passes for n candidates (in place on d_ov: window-relative,
 // unflipped coordinates); d_band0[i] = initial band width for banded_sw
 // (0 = no cigar wanted, ssw.c:924-927)
+struct SwWork {
+  DevBuf flags, pos, list, scan_tmp, totals;
+};
+// *n_full_out: candidates that needed the full-matrix kernel (the rest ran in a proven band)
 void sw_scores(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, uint32_t max_read_len,
-               uint32_t *d_band0, hipStream_t s);
+               uint32_t *d_band0, SwWork &W, uint64_t *n_full_out, hipStream_t s);
 
 // --------------------------------------------------------------- cigar.hip
 struct CigarWork {

@@ -40,6 +40,7 @@ struct kslam_ctx {
   DevBuf recs_a, recs_b, block_tot, block_base, ovk_a, ovk_b, flags, pos, band0;
   SortWorkspace sortws;
   CigarWork cig;
+  SwWork sww;
   DevBuf cells;
 
   // ---- results of the last align ----
@@ -352,7 +353,9 @@ void align_resident(kslam_ctx *c, bool stop_after_join, uint64_t *n_raw_out) {
       // ---- a-8..a-12: scores and ends ----
       c->band0.ensure((m + 1) * sizeof(uint32_t));
       cigar_prepare(c->cig, m, s);
-      sw_scores(cand, m, in, sp, c->max_read_len, c->band0.as<uint32_t>(), s);
+      uint64_t n_full = 0;
+      sw_scores(cand, m, in, sp, c->max_read_len, c->band0.as<uint32_t>(), c->sww, &n_full, s);
+      if (getenv("KSLAM_DEBUG")) fprintf(stderr, "[kslam] SW: %llu candidates, %llu needed the full-matrix kernel\n", (unsigned long long)m, (unsigned long long)n_full);
       HIPCHK(hipEventRecord(c->ev[6], s));
       // ---- a-13: cigar ----
       uint32_t tb_err = 0;
@@ -448,7 +451,7 @@ void kslam_destroy(kslam_ctx *c) {
                       &c->flags, &c->pos, &c->band0, &c->sortws.hist, &c->sortws.status, &c->sortws.tickets,
                       &c->sortws.errflag, &c->cig.flags, &c->cig.pos, &c->cig.list, &c->cig.bmax, &c->cig.needbig,
                       &c->cig.scan_tmp, &c->cig.totals, &c->cig.cig_off, &c->cig.tmp, &c->cig.tmp_big,
-                      &c->cig.big_pos, &c->cig.scratch, &c->cells, &c->res_ov, &c->res_cig, &c->res_tmp};
+                      &c->cig.big_pos, &c->cig.scratch, &c->sww.flags, &c->sww.pos, &c->sww.list, &c->sww.scan_tmp, &c->sww.totals, &c->cells, &c->res_ov, &c->res_cig, &c->res_tmp};
     for (DevBuf *b : bufs) b->release();
     for (auto &ev : c->ev) if (ev) (void)hipEventDestroy(ev);
     if (c->stream) (void)hipStreamDestroy(c->stream);

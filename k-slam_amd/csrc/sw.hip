@@ -72,6 +72,31 @@ struct PassResult {
   int32_t score, end_col, end_row, beg_col, beg_row;
 };
 
+// group-wide selection of the best cell from the lane-local bests: max score, then smallest
+// column, then smallest row (ssw.c:316-342); also hands out its origin key
+__device__ inline PassResult reduce_best(int32_t lbV, int32_t lbZ) {
+  const int32_t lane = threadIdx.x & 63;
+  const int32_t sc = lbV >> KB;
+  const int32_t ecol = (lbZ >> 9) - 1, erow = (lbZ & 511) - 1;
+  const int32_t G = sc > 0 ? ((sc << KB) | ((511 - ecol) << 9) | (511 - erow)) : 0;
+  int32_t Gm = G;
+#pragma unroll
+  for (int m = 1; m < 16; m <<= 1) Gm = max(Gm, __shfl_xor(Gm, m, 16));
+  const uint64_t bal = __ballot(G == Gm && Gm != 0);
+  const uint32_t grp_bits = (uint32_t)(bal >> (lane & 48)) & 0xFFFFu;
+  PassResult res{0, 0, 0, 0, 0};
+  const int32_t src = (lane & 48) | (grp_bits ? __builtin_ctz(grp_bits) : 0);
+  const int32_t wV = __shfl(lbV, src, 64), wZ = __shfl(lbZ, src, 64);
+  if (grp_bits) {
+    res.score = wV >> KB;
+    res.end_col = (wZ >> 9) - 1;
+    res.end_row = (wZ & 511) - 1;
+    res.beg_col = (wV & KEYMASK) >> 9;
+    res.beg_row = wV & 511;
+  }
+  return res;
+}
+
 // One forward SW pass with origin tracking for the 16-lane group this lane belongs to.
 // Every DP value is score * 2^18 + origin key, so v_max_i32 is a lexicographic
 // (score, start column, start row) maximum: among the optimal alignments ending at the
@@ -142,62 +167,35 @@ __device__ inline PassResult sw_origin_pass(const uint8_t *qcodes, int32_t qlen,
       out_f = F;
     }
   }
-  // group reduction: max score, then smallest column, then smallest row
-  const int32_t sc = lbV >> KB;
-  const int32_t ecol = (lbZ >> 9) - 1, erow = (lbZ & 511) - 1;
-  int32_t G = sc > 0 ? ((sc << KB) | ((511 - ecol) << 9) | (511 - erow)) : 0;
-  int32_t Gm = G;
-#pragma unroll
-  for (int m = 1; m < 16; m <<= 1) Gm = max(Gm, __shfl_xor(Gm, m, 16));
-  const uint64_t bal = __ballot(G == Gm && Gm != 0);
-  const uint32_t grp_bits = (uint32_t)(bal >> (lane & 48)) & 0xFFFFu;
-  PassResult res{0, 0, 0, 0, 0};
-  const int32_t src = (lane & 48) | (grp_bits ? __builtin_ctz(grp_bits) : 0);
-  const int32_t wV = __shfl(lbV, src, 64), wZ = __shfl(lbZ, src, 64);
-  if (grp_bits) {
-    res.score = wV >> KB;
-    res.end_col = (wZ >> 9) - 1;
-    res.end_row = (wZ & 511) - 1;
-    res.beg_col = (wV & KEYMASK) >> 9;
-    res.beg_row = wV & 511;
-  }
-  return res;
+  return reduce_best(lbV, lbZ);
 }
 
-template <int R>
-__global__ __launch_bounds__(256) void k_sw(kslam_overlap *__restrict__ ov, uint64_t n, SwInputs in, SwParams p,
-                                            uint32_t *__restrict__ band0) {
-  constexpr int LMAX = R * 16;
-  __shared__ uint8_t s_q[16][LMAX];
-  __shared__ uint8_t s_w[16][LMAX];
-  const int32_t lane = threadIdx.x & 63;
-  const int32_t t = lane & 15;
-  const int32_t grp = threadIdx.x >> 4;
-  const uint64_t ci = (uint64_t)blockIdx.x * 16 + grp;
-  const bool have = ci < n;
-  int32_t L = 0, wlen = 0;
-  if (have) {
-    const kslam_overlap o = ov[ci];
-    const uint64_t ro = in.read_off[o.read];
-    L = (int32_t)(in.read_off[o.read + 1] - ro);
-    const uint64_t go = in.genome_off[o.entry];
-    const uint64_t G = in.genome_off[o.entry + 1] - go;
-    const int64_t s0 = o.rel > 0 ? o.rel : 0;                     // SmithWaterman.h:204
-    wlen = (int32_t)min((uint64_t)L, G - (uint64_t)s0);            // substr, :205-206
-    const uint32_t revcomp = o.revcomp;
-    for (int32_t i = t; i < L; i += 16) s_q[grp][i] = (uint8_t)translate_base(in.read_bases[ro + i]);
-    for (int32_t j = t; j < wlen; j += 16) {
-      uint32_t ch;
-      if (!revcomp) ch = in.genome_bases[go + s0 + j];
-      else ch = complement_base(in.genome_bases[go + s0 + (wlen - 1 - j)]);  // :207
-      s_w[grp][j] = (uint8_t)translate_base(ch);
-    }
+// ---- shared pieces of the two SW kernels ------------------------------------------------------
+// stage read + window of candidate `o` as SSW codes (all 16 lanes of the group cooperate)
+__device__ inline void stage_candidate(const kslam_overlap &o, const SwInputs &in, int32_t t, uint8_t *sq,
+                                       uint8_t *sw, int32_t *L_out, int32_t *wlen_out) {
+  const uint64_t ro = in.read_off[o.read];
+  const int32_t L = (int32_t)(in.read_off[o.read + 1] - ro);
+  const uint64_t go = in.genome_off[o.entry];
+  const uint64_t G = in.genome_off[o.entry + 1] - go;
+  const int64_t s0 = o.rel > 0 ? o.rel : 0;                           // SmithWaterman.h:204
+  const int32_t wlen = (int32_t)min((uint64_t)L, G - (uint64_t)s0);    // substr, :205-206
+  for (int32_t i = t; i < L; i += 16) sq[i] = (uint8_t)translate_base(in.read_bases[ro + i]);
+  for (int32_t j = t; j < wlen; j += 16) {
+    uint32_t ch;
+    if (!o.revcomp) ch = in.genome_bases[go + s0 + j];
+    else ch = complement_base(in.genome_bases[go + s0 + (wlen - 1 - j)]);  // :207
+    sw[j] = (uint8_t)translate_base(ch);
   }
-  __syncthreads();
-  // forward pass (ssw.c:870-877) and, by origin tracking, the result of the reverse pass (:906-923)
-  const PassResult f = sw_origin_pass<R>(s_q[grp], L, s_w[grp], have ? wlen : 0, p);
+  *L_out = L;
+  *wlen_out = wlen;
+}
+
+// result record + band request for banded_sw, ssw.c:924-935 (flag 0x0f: score and distance filters)
+__device__ inline void sw_epilogue(kslam_overlap *ov, uint64_t ci, bool have, int32_t t, int32_t L,
+                                   const PassResult &f, const uint8_t *sq, const uint8_t *sw, const SwParams &p,
+                                   uint32_t *band0) {
   const bool ok = have && f.score > 0;
-  // band request for banded_sw, ssw.c:924-935 (flag 0x0f: score and distance filters)
   const int32_t refLen = f.end_col - f.beg_col + 1, readLen = f.end_row - f.beg_row + 1;
   const bool want = p.report_cigar && ok && (uint32_t)f.score >= (p.score_threshold & 0xFFFFu) &&
                     refLen - 1 <= 32767 && readLen - 1 <= 32767;
@@ -207,7 +205,7 @@ __global__ __launch_bounds__(256) void k_sw(kslam_overlap *__restrict__ ov, uint
   int32_t dsum = 0;
   if (want && refLen == readLen) {
     for (int32_t k = t; k < readLen; k += 16) {
-      const uint32_t q = s_q[grp][f.beg_row + k], c = s_w[grp][f.beg_col + k];
+      const uint32_t q = sq[f.beg_row + k], c = sw[f.beg_col + k];
       dsum += (q > 3u || c > 3u) ? 0 : (q == c ? p.match : -p.mismatch);
     }
   }
@@ -236,20 +234,230 @@ __global__ __launch_bounds__(256) void k_sw(kslam_overlap *__restrict__ ov, uint
   }
 }
 
+// ---- full-matrix kernel (any candidate) --------------------------------------------------------
+template <int R>
+__global__ __launch_bounds__(256) void k_sw(kslam_overlap *__restrict__ ov, uint64_t n, SwInputs in, SwParams p,
+                                            uint32_t *__restrict__ band0, const uint32_t *__restrict__ list) {
+  constexpr int LMAX = R * 16;
+  __shared__ uint8_t s_q[16][LMAX];
+  __shared__ uint8_t s_w[16][LMAX];
+  const int32_t lane = threadIdx.x & 63;
+  const int32_t t = lane & 15;
+  const int32_t grp = threadIdx.x >> 4;
+  const uint64_t gi = (uint64_t)blockIdx.x * 16 + grp;
+  const bool have = gi < n;
+  const uint64_t ci = have ? (list ? list[gi] : gi) : 0;
+  int32_t L = 0, wlen = 0;
+  if (have) stage_candidate(ov[ci], in, t, s_q[grp], s_w[grp], &L, &wlen);
+  __syncthreads();
+  // forward pass (ssw.c:870-877) and, by origin tracking, the result of the reverse pass (:906-923)
+  const PassResult f = sw_origin_pass<R>(s_q[grp], L, s_w[grp], have ? wlen : 0, p);
+  sw_epilogue(ov, ci, have, t, L, f, s_q[grp], s_w[grp], p, band0);
+}
+
+// ---- banded anti-diagonal kernel ---------------------------------------------------------------
+// Exact pruning.  Let LB be the score of a real alignment (best ungapped segment on the seed
+// diagonal).  Any alignment with score S >= LB and g gap bases pays at least
+// cost(g) = gO + (g-1) gE (gE < gO), so it has m >= m0(g) = ceil((LB + cost(g)) / match) matches,
+// hence uses >= m0(g) rows and columns: its start diagonal d = j - i lies in
+// [-(L - m0(g)), W - m0(g)] and every cell of it within g of that.  The union over feasible g is a
+// band [dlo, dhi] that contains EVERY alignment scoring >= LB -- in particular all optimal ones,
+// which is all the reference's answer depends on (values of other cells may come out lower,
+// never higher, so they cannot win a maximum or a tie).  When the band has <= 32 diagonals the
+// group's 16 lanes sweep it by anti-diagonals, two adjacent diagonals per lane (one of them is
+// active on every step, so no lane idles): the cell on diagonal d at step k = i + j takes E from
+// diagonal d-1 and F from diagonal d+1 (both step k-1: own register or one DPP row shift) and its
+// own diagonal's H from step k-2.  Candidates whose band is wider go to the full kernel.
+struct Seg { int32_t tot, pre, suf, best; };
+__device__ inline Seg seg_join(const Seg &a, const Seg &b) {
+  Seg r;
+  r.tot = a.tot + b.tot;
+  r.pre = max(a.pre, a.tot + b.pre);
+  r.suf = max(b.suf, b.tot + a.suf);
+  r.best = max(max(a.best, b.best), a.suf + b.pre);
+  return r;
+}
+
+template <int LMAX>
+__global__ __launch_bounds__(256) void k_sw_band(kslam_overlap *__restrict__ ov, uint64_t n, SwInputs in, SwParams p,
+                                                 uint32_t *__restrict__ band0, uint32_t *__restrict__ todo) {
+  __shared__ uint8_t s_q[16][LMAX];
+  __shared__ uint8_t s_w[16][LMAX];
+  __shared__ uint32_t s_tab[16][LMAX];
+  const int32_t lane = threadIdx.x & 63;
+  const int32_t t = lane & 15;
+  const int32_t grp = threadIdx.x >> 4;
+  const uint64_t ci = (uint64_t)blockIdx.x * 16 + grp;
+  const bool have = ci < n;
+  int32_t L = 0, W = 0, rel = 0;
+  if (have) {
+    const kslam_overlap o = ov[ci];
+    rel = o.rel;
+    stage_candidate(o, in, t, s_q[grp], s_w[grp], &L, &W);
+  }
+  __syncthreads();
+  for (int32_t i = t; i < L; i += 16) {   // 6-bit packed score row per query base
+    const uint32_t q = s_q[grp][i];
+    uint32_t tb = 0;
+#pragma unroll
+    for (uint32_t c = 0; c < 4; c++) {
+      const int32_t s = q > 3u ? 0 : (q == c ? p.match : -p.mismatch);
+      tb |= ((uint32_t)s & 63u) << (6 * c);
+    }
+    s_tab[grp][i] = tb;
+  }
+  __syncthreads();
+  // lower bound: best ungapped segment on the seed diagonal j = i + d0
+  const int32_t d0 = rel < 0 ? rel : 0;
+  const int32_t i_lo = d0 < 0 ? -d0 : 0;
+  const int32_t i_hi = min(L, W - d0);          // exclusive
+  const int32_t span = max(i_hi - i_lo, 0);
+  const int32_t per = (span + 15) >> 4;
+  Seg sg{0, 0, 0, 0};
+  {
+    const int32_t a = i_lo + t * per, b = min(a + per, i_hi);
+    int32_t run = 0, minpre = 0;
+    for (int32_t i = a; i < b; i++) {
+      const uint32_t q = s_q[grp][i], c = s_w[grp][i + d0];
+      const int32_t s = (q > 3u || c > 3u) ? 0 : (q == c ? p.match : -p.mismatch);
+      run += s;
+      sg.pre = max(sg.pre, run);
+      sg.best = max(sg.best, run - minpre);
+      minpre = min(minpre, run);
+    }
+    sg.tot = run;
+    sg.suf = run - minpre;
+  }
+#pragma unroll
+  for (int m = 1; m < 16; m <<= 1) {            // ordered tree reduction to lane 0 of the group
+    Seg o2;
+    o2.tot = __shfl_down(sg.tot, m, 16); o2.pre = __shfl_down(sg.pre, m, 16);
+    o2.suf = __shfl_down(sg.suf, m, 16); o2.best = __shfl_down(sg.best, m, 16);
+    if ((t & (2 * m - 1)) == 0) sg = seg_join(sg, o2);
+  }
+  const int32_t LB = __shfl(sg.best, lane & 48, 64);
+  // band that contains every alignment scoring >= LB
+  int32_t dlo = 1 << 20, dhi = -(1 << 20);
+  if (have && LB > 0) {
+    const int32_t Lm = min(L, W);
+    for (int32_t g = 0; g < 1024; g++) {
+      const int32_t cost = g == 0 ? 0 : p.gap_open + (g - 1) * p.gap_extend;
+      const int32_t m0 = (LB + cost + p.match - 1) / p.match;
+      if (m0 > Lm) break;
+      dlo = min(dlo, -(L - m0) - g);
+      dhi = max(dhi, (W - m0) + g);
+    }
+  }
+  const bool banded = have && LB > 0 && dhi >= dlo && dhi - dlo + 1 <= 32;
+  if (have && t == 0) todo[ci] = banded ? 0u : 1u;
+  if (__ballot(banded) == 0ull) return;          // wave-uniform: nothing to do here
+
+  const int32_t gO = p.gap_open << KB, gE = p.gap_extend << KB;
+  const int32_t NEG = -((p.gap_open + p.gap_extend + 1) << KB);
+  const int32_t dA = dlo + 2 * t, dB = dA + 1;
+  // H of the virtual predecessor of each diagonal's first cell: score 0, key = that first cell
+  int32_t HdA = dA >= 0 ? (dA << 9) : -dA;
+  int32_t HdB = dB >= 0 ? (dB << 9) : -dB;
+  int32_t EoA = NEG, FoA = NEG, EoB = NEG, FoB = NEG;
+  int32_t lbV = 0, lbZ = 0;
+  const int32_t kend = banded ? L + W - 2 : -1;
+  const uint32_t *tab = s_tab[grp];
+  const uint8_t *wc = s_w[grp];
+  // phase A runs at k, phase B at k + 1; with an odd dlo phase B owns the even diagonals, whose
+  // first cell can sit on anti-diagonal 0, so start one pair earlier
+  for (int32_t k = (dlo & 1) ? -1 : 0;; k += 2) {
+    if (__ballot(k <= kend) == 0ull) break;
+    {  // phase A: even diagonal of the lane at anti-diagonal k
+      const int32_t ein = dpp_row_shr1(EoB);
+      const int32_t Ein = t == 0 ? NEG : ein;
+      const int32_t Fin = FoB;
+      const int32_t i = (k - dA) >> 1, j = i + dA;
+      if (k <= kend && (uint32_t)i < (uint32_t)L && (uint32_t)j < (uint32_t)W) {
+        const int32_t s = __builtin_amdgcn_sbfe(tab[i], (uint32_t)wc[j] * 6u, 6);
+        const int32_t Z = ((j + 1) << 9) | (i + 1);
+        int32_t h = max(max(HdA + (s << KB), Ein), Fin);
+        h = max(h, Z);
+        HdA = h;
+        const int32_t hg = h - gO;
+        EoA = max(Ein - gE, hg);
+        FoA = max(Fin - gE, hg);
+        const bool up = h > (lbV | KEYMASK);
+        lbV = up ? h : lbV;
+        lbZ = up ? Z : lbZ;
+      }
+    }
+    {  // phase B: odd diagonal at anti-diagonal k + 1
+      const int32_t fin = __builtin_amdgcn_update_dpp(0, FoA, 0x101, 0xF, 0xF, true);  // row_shl:1
+      const int32_t Fin = t == 15 ? NEG : fin;
+      const int32_t Ein = EoA;
+      const int32_t i = (k + 1 - dB) >> 1, j = i + dB;
+      if (k + 1 <= kend && (uint32_t)i < (uint32_t)L && (uint32_t)j < (uint32_t)W) {
+        const int32_t s = __builtin_amdgcn_sbfe(tab[i], (uint32_t)wc[j] * 6u, 6);
+        const int32_t Z = ((j + 1) << 9) | (i + 1);
+        int32_t h = max(max(HdB + (s << KB), Ein), Fin);
+        h = max(h, Z);
+        HdB = h;
+        const int32_t hg = h - gO;
+        EoB = max(Ein - gE, hg);
+        FoB = max(Fin - gE, hg);
+        const bool up = h > (lbV | KEYMASK);
+        lbV = up ? h : lbV;
+        lbZ = up ? Z : lbZ;
+      }
+    }
+  }
+  const PassResult f = reduce_best(lbV, lbZ);
+  sw_epilogue(ov, ci, banded, t, L, f, s_q[grp], s_w[grp], p, band0);
+}
+
+__global__ void k_scatter_todo(const uint32_t *__restrict__ flags, const uint32_t *__restrict__ pos, uint64_t n,
+                               uint32_t *__restrict__ list) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && flags[i]) list[pos[i]] = (uint32_t)i;
+}
+
 }  // namespace
 
 void sw_scores(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, uint32_t max_read_len,
-               uint32_t *d_band0, hipStream_t s) {
+               uint32_t *d_band0, SwWork &W, uint64_t *n_full_out, hipStream_t s) {
+  if (n_full_out) *n_full_out = 0;
   if (n == 0) return;
-  unsigned blocks = (unsigned)((n + 15) / 16);
-  if (max_read_len <= 160)
-    hipLaunchKernelGGL(k_sw<10>, dim3(blocks), dim3(256), 0, s, d_ov, n, in, p, d_band0);
-  else if (max_read_len <= 256)
-    hipLaunchKernelGGL(k_sw<16>, dim3(blocks), dim3(256), 0, s, d_ov, n, in, p, d_band0);
-  else if (max_read_len <= 511)
-    hipLaunchKernelGGL(k_sw<32>, dim3(blocks), dim3(256), 0, s, d_ov, n, in, p, d_band0);
-  else
-    throw StatusError{KSLAM_ERR_UNSUPPORTED, "reads longer than 511 bases are not supported yet"};
+  if (max_read_len > 511) throw StatusError{KSLAM_ERR_UNSUPPORTED, "reads longer than 511 bases are not supported yet"};
+  if (n >= (1ull << 32)) throw StatusError{KSLAM_ERR_UNSUPPORTED, ">= 2^32 candidates in one chunk"};
+  const unsigned blocks = (unsigned)((n + 15) / 16);
+  const uint32_t *list = nullptr;
+  uint64_t m = n;
+  const char *force_full = getenv("KSLAM_SW_FULL");
+  if (!(force_full && force_full[0] == '1')) {
+    // pass 1: banded kernel on every candidate whose provable band fits 32 diagonals
+    W.flags.ensure(n * sizeof(uint32_t));
+    W.pos.ensure(n * sizeof(uint32_t));
+    W.list.ensure(n * sizeof(uint32_t));
+    W.scan_tmp.ensure(scan_tmp_bytes(n));
+    W.totals.ensure(2 * sizeof(uint64_t));
+    if (max_read_len <= 160)
+      hipLaunchKernelGGL(k_sw_band<160>, dim3(blocks), dim3(256), 0, s, d_ov, n, in, p, d_band0, W.flags.as<uint32_t>());
+    else if (max_read_len <= 256)
+      hipLaunchKernelGGL(k_sw_band<256>, dim3(blocks), dim3(256), 0, s, d_ov, n, in, p, d_band0, W.flags.as<uint32_t>());
+    else
+      hipLaunchKernelGGL(k_sw_band<512>, dim3(blocks), dim3(256), 0, s, d_ov, n, in, p, d_band0, W.flags.as<uint32_t>());
+    exclusive_scan_u32(W.flags.as<uint32_t>(), W.pos.as<uint32_t>(), n, W.totals.as<uint64_t>(), W.scan_tmp.p, s);
+    HIPCHK(hipMemcpyAsync(&m, W.totals.p, sizeof m, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (m) hipLaunchKernelGGL(k_scatter_todo, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
+                              W.flags.as<uint32_t>(), W.pos.as<uint32_t>(), n, W.list.as<uint32_t>());
+    list = W.list.as<uint32_t>();
+  }
+  if (n_full_out) *n_full_out = m;
+  if (m) {  // pass 2: full matrix for the rest
+    const unsigned b2 = (unsigned)((m + 15) / 16);
+    if (max_read_len <= 160)
+      hipLaunchKernelGGL(k_sw<10>, dim3(b2), dim3(256), 0, s, d_ov, m, in, p, d_band0, list);
+    else if (max_read_len <= 256)
+      hipLaunchKernelGGL(k_sw<16>, dim3(b2), dim3(256), 0, s, d_ov, m, in, p, d_band0, list);
+    else
+      hipLaunchKernelGGL(k_sw<32>, dim3(b2), dim3(256), 0, s, d_ov, m, in, p, d_band0, list);
+  }
   HIPCHK(hipGetLastError());
 }
 

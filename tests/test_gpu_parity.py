@@ -250,3 +250,21 @@ def test_properties_large_batch(kslam, synth):
     for p, (g, _, _) in enumerate(truth):
         if g < 0:
             assert not (ov["read"] == p).any()
+
+
+def test_banded_sw_equals_full_matrix_sw(kslam, synth, monkeypatch):
+    """The provably-banded anti-diagonal SW kernel and the full-matrix kernel must agree on every
+    candidate (divergent strains, indels, N, reads hanging off the genome ends)."""
+    genomes = synth.make_genomes(91, 6, 4, 60000, strain_sub=0.03, strain_indel=0.002)
+    reads, _ = synth.make_paired_reads(92, genomes, 6000, sub_rate=0.02, indel_rate=0.004, n_rate=0.002,
+                                       edge_frac=0.05)
+    rb, gb = synth.to_bytes(reads), synth.to_bytes(genomes)
+    c = kslam.Context()
+    c.set_index(gb)
+    a, ac = c.align_batch(rb)
+    monkeypatch.setenv("KSLAM_SW_FULL", "1")
+    b, bc = c.align_batch(rb)
+    monkeypatch.delenv("KSLAM_SW_FULL")
+    c.close()
+    assert len(a) > 20000
+    _compare_alignments(a, ac, b, bc)

@@ -256,28 +256,20 @@ __global__ __launch_bounds__(256) void k_sw(kslam_overlap *__restrict__ ov, uint
 }
 
 // ---- banded anti-diagonal kernel ---------------------------------------------------------------
-// Exact pruning.  Let LB be the score of a real alignment (best ungapped segment on the seed
-// diagonal).  Any alignment with score S >= LB and g gap bases pays at least
-// cost(g) = gO + (g-1) gE (gE < gO), so it has m >= m0(g) = ceil((LB + cost(g)) / match) matches,
-// hence uses >= m0(g) rows and columns: its start diagonal d = j - i lies in
-// [-(L - m0(g)), W - m0(g)] and every cell of it within g of that.  The union over feasible g is a
-// band [dlo, dhi] that contains EVERY alignment scoring >= LB -- in particular all optimal ones,
-// which is all the reference's answer depends on (values of other cells may come out lower,
-// never higher, so they cannot win a maximum or a tie).  When the band has <= 32 diagonals the
-// group's 16 lanes sweep it by anti-diagonals, two adjacent diagonals per lane (one of them is
-// active on every step, so no lane idles): the cell on diagonal d at step k = i + j takes E from
-// diagonal d-1 and F from diagonal d+1 (both step k-1: own register or one DPP row shift) and its
-// own diagonal's H from step k-2.  Candidates whose band is wider go to the full kernel.
-struct Seg { int32_t tot, pre, suf, best; };
-__device__ inline Seg seg_join(const Seg &a, const Seg &b) {
-  Seg r;
-  r.tot = a.tot + b.tot;
-  r.pre = max(a.pre, a.tot + b.pre);
-  r.suf = max(b.suf, b.tot + a.suf);
-  r.best = max(max(a.best, b.best), a.suf + b.pre);
-  return r;
-}
-
+// Exact pruning with an a-posteriori certificate.  The group sweeps the 64 diagonals around the
+// seed diagonal; the best score S1 found there is the score of a real alignment, hence a lower
+// bound of the optimum.  Any alignment with score S >= S1 and g gap bases pays at least
+// cost(g) = gO + (g-1) gE (gE < gO), so it has m >= m0(g) = ceil((S1 + cost(g)) / match) matches,
+// uses >= m0(g) rows and columns, starts on a diagonal d = j - i in [-(L - m0(g)), W - m0(g)] and
+// stays within g of it.  If the union of those ranges over all feasible g lies inside the swept
+// band, the band contained EVERY alignment scoring >= S1 -- in particular all optimal ones, which
+// is all the reference's answer depends on (cells fed from outside the band can only come out
+// lower, never higher, so they cannot win a maximum or a tie) -- and the result is exact.
+// Otherwise the candidate is flagged for the full-matrix kernel.
+// Sweep: 16 lanes x 4 adjacent diagonals; on every anti-diagonal step k = i + j a lane computes
+// the two cells of its diagonals with the parity of k.  A cell takes E from diagonal d-1 and F
+// from diagonal d+1 (both from step k-1: own registers, or one DPP row shift at the lane
+// boundary) and its own diagonal's H from step k-2.
 template <int LMAX>
 __global__ __launch_bounds__(256) void k_sw_band(kslam_overlap *__restrict__ ov, uint64_t n, SwInputs in, SwParams p,
                                                  uint32_t *__restrict__ band0, uint32_t *__restrict__ todo) {
@@ -307,107 +299,74 @@ __global__ __launch_bounds__(256) void k_sw_band(kslam_overlap *__restrict__ ov,
     s_tab[grp][i] = tb;
   }
   __syncthreads();
-  // lower bound: best ungapped segment on the seed diagonal j = i + d0
-  const int32_t d0 = rel < 0 ? rel : 0;
-  const int32_t i_lo = d0 < 0 ? -d0 : 0;
-  const int32_t i_hi = min(L, W - d0);          // exclusive
-  const int32_t span = max(i_hi - i_lo, 0);
-  const int32_t per = (span + 15) >> 4;
-  Seg sg{0, 0, 0, 0};
-  {
-    const int32_t a = i_lo + t * per, b = min(a + per, i_hi);
-    int32_t run = 0, minpre = 0;
-    for (int32_t i = a; i < b; i++) {
-      const uint32_t q = s_q[grp][i], c = s_w[grp][i + d0];
-      const int32_t s = (q > 3u || c > 3u) ? 0 : (q == c ? p.match : -p.mismatch);
-      run += s;
-      sg.pre = max(sg.pre, run);
-      sg.best = max(sg.best, run - minpre);
-      minpre = min(minpre, run);
-    }
-    sg.tot = run;
-    sg.suf = run - minpre;
-  }
-#pragma unroll
-  for (int m = 1; m < 16; m <<= 1) {            // ordered tree reduction to lane 0 of the group
-    Seg o2;
-    o2.tot = __shfl_down(sg.tot, m, 16); o2.pre = __shfl_down(sg.pre, m, 16);
-    o2.suf = __shfl_down(sg.suf, m, 16); o2.best = __shfl_down(sg.best, m, 16);
-    if ((t & (2 * m - 1)) == 0) sg = seg_join(sg, o2);
-  }
-  const int32_t LB = __shfl(sg.best, lane & 48, 64);
-  // band that contains every alignment scoring >= LB
-  int32_t dlo = 1 << 20, dhi = -(1 << 20);
-  if (have && LB > 0) {
-    const int32_t Lm = min(L, W);
-    for (int32_t g = 0; g < 1024; g++) {
-      const int32_t cost = g == 0 ? 0 : p.gap_open + (g - 1) * p.gap_extend;
-      const int32_t m0 = (LB + cost + p.match - 1) / p.match;
-      if (m0 > Lm) break;
-      dlo = min(dlo, -(L - m0) - g);
-      dhi = max(dhi, (W - m0) + g);
-    }
-  }
-  const bool banded = have && LB > 0 && dhi >= dlo && dhi - dlo + 1 <= 32;
-  if (have && t == 0) todo[ci] = banded ? 0u : 1u;
-  if (__ballot(banded) == 0ull) return;          // wave-uniform: nothing to do here
-
   const int32_t gO = p.gap_open << KB, gE = p.gap_extend << KB;
   const int32_t NEG = -((p.gap_open + p.gap_extend + 1) << KB);
-  const int32_t dA = dlo + 2 * t, dB = dA + 1;
-  // H of the virtual predecessor of each diagonal's first cell: score 0, key = that first cell
-  int32_t HdA = dA >= 0 ? (dA << 9) : -dA;
-  int32_t HdB = dB >= 0 ? (dB << 9) : -dB;
-  int32_t EoA = NEG, FoA = NEG, EoB = NEG, FoB = NEG;
+  const int32_t d0 = rel < 0 ? rel : 0;          // seed diagonal: read base i sits on window base i + d0
+  const int32_t dlo = d0 - 32;
+  int32_t dq[4], Hd[4], Eo[4], Fo[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    dq[q] = dlo + 4 * t + q;
+    Hd[q] = dq[q] >= 0 ? (dq[q] << 9) : -dq[q];  // virtual predecessor of the diagonal's first cell
+    Eo[q] = NEG;
+    Fo[q] = NEG;
+  }
   int32_t lbV = 0, lbZ = 0;
-  const int32_t kend = banded ? L + W - 2 : -1;
+  const int32_t kend = have ? L + W - 2 : -2;
   const uint32_t *tab = s_tab[grp];
   const uint8_t *wc = s_w[grp];
-  // phase A runs at k, phase B at k + 1; with an odd dlo phase B owns the even diagonals, whose
-  // first cell can sit on anti-diagonal 0, so start one pair earlier
+  auto cell = [&](int32_t d, int32_t &H, int32_t Ein, int32_t Fin, int32_t &E, int32_t &F, int32_t k) {
+    const int32_t i = (k - d) >> 1, j = i + d;
+    if (k <= kend && (uint32_t)i < (uint32_t)L && (uint32_t)j < (uint32_t)W) {
+      const int32_t s = __builtin_amdgcn_sbfe(tab[i], (uint32_t)wc[j] * 6u, 6);
+      const int32_t Z = ((j + 1) << 9) | (i + 1);
+      int32_t h = max(max(H + (s << KB), Ein), Fin);
+      h = max(h, Z);
+      H = h;
+      const int32_t hg = h - gO;
+      E = max(Ein - gE, hg);
+      F = max(Fin - gE, hg);
+      const bool up = h > (lbV | KEYMASK);
+      lbV = up ? h : lbV;
+      lbZ = up ? Z : lbZ;
+    }
+  };
+  // diagonals q = 0, 2 have the parity of dlo, q = 1, 3 the other one; phase A runs at k, phase B
+  // at k + 1; start one pair early when dlo is odd so that anti-diagonal 0 is not skipped
   for (int32_t k = (dlo & 1) ? -1 : 0;; k += 2) {
     if (__ballot(k <= kend) == 0ull) break;
-    {  // phase A: even diagonal of the lane at anti-diagonal k
-      const int32_t ein = dpp_row_shr1(EoB);
-      const int32_t Ein = t == 0 ? NEG : ein;
-      const int32_t Fin = FoB;
-      const int32_t i = (k - dA) >> 1, j = i + dA;
-      if (k <= kend && (uint32_t)i < (uint32_t)L && (uint32_t)j < (uint32_t)W) {
-        const int32_t s = __builtin_amdgcn_sbfe(tab[i], (uint32_t)wc[j] * 6u, 6);
-        const int32_t Z = ((j + 1) << 9) | (i + 1);
-        int32_t h = max(max(HdA + (s << KB), Ein), Fin);
-        h = max(h, Z);
-        HdA = h;
-        const int32_t hg = h - gO;
-        EoA = max(Ein - gE, hg);
-        FoA = max(Fin - gE, hg);
-        const bool up = h > (lbV | KEYMASK);
-        lbV = up ? h : lbV;
-        lbZ = up ? Z : lbZ;
-      }
+    {  // phase A: diagonals 0 and 2 of the lane
+      const int32_t ein = dpp_row_shr1(Eo[3]);
+      const int32_t e0 = t == 0 ? NEG : ein, f0 = Fo[1];
+      const int32_t e2 = Eo[1], f2 = Fo[3];
+      cell(dq[0], Hd[0], e0, f0, Eo[0], Fo[0], k);
+      cell(dq[2], Hd[2], e2, f2, Eo[2], Fo[2], k);
     }
-    {  // phase B: odd diagonal at anti-diagonal k + 1
-      const int32_t fin = __builtin_amdgcn_update_dpp(0, FoA, 0x101, 0xF, 0xF, true);  // row_shl:1
-      const int32_t Fin = t == 15 ? NEG : fin;
-      const int32_t Ein = EoA;
-      const int32_t i = (k + 1 - dB) >> 1, j = i + dB;
-      if (k + 1 <= kend && (uint32_t)i < (uint32_t)L && (uint32_t)j < (uint32_t)W) {
-        const int32_t s = __builtin_amdgcn_sbfe(tab[i], (uint32_t)wc[j] * 6u, 6);
-        const int32_t Z = ((j + 1) << 9) | (i + 1);
-        int32_t h = max(max(HdB + (s << KB), Ein), Fin);
-        h = max(h, Z);
-        HdB = h;
-        const int32_t hg = h - gO;
-        EoB = max(Ein - gE, hg);
-        FoB = max(Fin - gE, hg);
-        const bool up = h > (lbV | KEYMASK);
-        lbV = up ? h : lbV;
-        lbZ = up ? Z : lbZ;
-      }
+    {  // phase B: diagonals 1 and 3
+      const int32_t fin = __builtin_amdgcn_update_dpp(0, Fo[0], 0x101, 0xF, 0xF, true);  // row_shl:1
+      const int32_t e1 = Eo[0], f1 = Fo[2];
+      const int32_t e3 = Eo[2], f3 = t == 15 ? NEG : fin;
+      cell(dq[1], Hd[1], e1, f1, Eo[1], Fo[1], k + 1);
+      cell(dq[3], Hd[3], e3, f3, Eo[3], Fo[3], k + 1);
     }
   }
   const PassResult f = reduce_best(lbV, lbZ);
-  sw_epilogue(ov, ci, banded, t, L, f, s_q[grp], s_w[grp], p, band0);
+  // certificate: every alignment scoring >= f.score lies inside [dlo, dlo + 63]
+  bool exact = false;
+  if (have && f.score > 0) {
+    int32_t rlo = 1 << 20, rhi = -(1 << 20);
+    const int32_t Lm = min(L, W);
+    for (int32_t g = 0; g < 2048; g++) {
+      const int32_t cost = g == 0 ? 0 : p.gap_open + (g - 1) * p.gap_extend;
+      const int32_t m0 = (f.score + cost + p.match - 1) / p.match;
+      if (m0 > Lm) break;
+      rlo = min(rlo, -(L - m0) - g);
+      rhi = max(rhi, (W - m0) + g);
+    }
+    exact = rlo >= dlo && rhi <= dlo + 63;
+  }
+  if (have && t == 0) todo[ci] = exact ? 0u : 1u;
+  sw_epilogue(ov, ci, exact, t, L, f, s_q[grp], s_w[grp], p, band0);
 }
 
 __global__ void k_scatter_todo(const uint32_t *__restrict__ flags, const uint32_t *__restrict__ pos, uint64_t n,

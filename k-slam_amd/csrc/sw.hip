@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256) void k_sw_band(kslam_overlap *__restrict__ ov,
   const uint8_t *wc = s_w[grp];
   auto cell = [&](int32_t d, int32_t &H, int32_t Ein, int32_t Fin, int32_t &E, int32_t &F, int32_t k) {
     const int32_t i = (k - d) >> 1, j = i + d;
-    if (k <= kend && (uint32_t)i < (uint32_t)L && (uint32_t)j < (uint32_t)W) {
+    if ((uint32_t)i < (uint32_t)L && (uint32_t)j < (uint32_t)W) {   // implies k <= L + W - 2
       const int32_t s = __builtin_amdgcn_sbfe(tab[i], (uint32_t)wc[j] * 6u, 6);
       const int32_t Z = ((j + 1) << 9) | (i + 1);
       int32_t h = max(max(H + (s << KB), Ein), Fin);

@@ -174,6 +174,14 @@ kslam_status kslam_find_overlaps(kslam_ctx *ctx, kslam_overlap_temp **out,
                                  uint64_t *n_out, uint64_t *n_raw);
 void kslam_free(void *p);
 
+/* ---- device self-test / micro-benchmark of the k-mer radix sort -------------
+ * Sorts n pseudo-random 16-byte records `iters` times (8 passes over the 64-bit
+ * k-mer, the hot-path configuration), checks the order on the device and reports
+ * milliseconds per sort and per scatter launch (HIP events).  Diagnostic only. */
+kslam_status kslam_selftest_sort(kslam_ctx *ctx, uint64_t n, uint32_t iters,
+                                 float *ms_per_sort, float *ms_per_scatter_launch,
+                                 uint64_t *n_inversions);
+
 #ifdef __cplusplus
 }
 #endif

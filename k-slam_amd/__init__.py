@@ -36,7 +36,8 @@ EXPORTS = ["kslam_abi_version", "kslam_create", "kslam_destroy", "kslam_last_err
            "kslam_set_index", "kslam_set_index_device", "kslam_align_batch", "kslam_free_batch",
            "kslam_load_reads", "kslam_load_reads_device", "kslam_align_resident",
            "kslam_fetch_results", "kslam_copy_results_device", "kslam_get_timings",
-           "kslam_extract_kmers", "kslam_sort_kmers", "kslam_find_overlaps", "kslam_free"]
+           "kslam_extract_kmers", "kslam_sort_kmers", "kslam_find_overlaps", "kslam_free",
+           "kslam_selftest_sort"]
 
 
 class Params(C.Structure):
@@ -106,6 +107,8 @@ def lib():
         L.kslam_sort_kmers.argtypes = [vp, vp, u64]
         L.kslam_find_overlaps.argtypes = [vp, C.POINTER(vp), C.POINTER(u64), C.POINTER(u64)]
         L.kslam_free.argtypes = [vp]
+        L.kslam_selftest_sort.argtypes = [vp, u64, u32, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                          C.POINTER(u64)]
         _lib = L
     return _lib
 
@@ -231,6 +234,12 @@ class Context:
         out = np.ascontiguousarray(recs.copy())
         self._chk(self._L.kslam_sort_kmers(self._h, out.ctypes.data, len(out)))
         return out
+
+    def selftest_sort(self, n, iters=3):
+        """(ms per 8-pass sort, ms per scatter launch, inversions) on n random records."""
+        a, b, inv = C.c_float(), C.c_float(), C.c_uint64()
+        self._chk(self._L.kslam_selftest_sort(self._h, n, iters, C.byref(a), C.byref(b), C.byref(inv)))
+        return float(a.value), float(b.value), int(inv.value)
 
     def find_overlaps(self):
         out = C.c_void_p()

@@ -109,6 +109,24 @@ __global__ void k_split_soa(const uint4 *__restrict__ recs, uint32_t n, uint64_t
   off[i] = r.w;
 }
 
+__global__ void k_fill_random(uint4 *recs, uint32_t n, uint64_t seed) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint64_t z = seed + (uint64_t)i * 0x9E3779B97F4A7C15ull;   // splitmix64
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  recs[i] = make_uint4((uint32_t)z, (uint32_t)(z >> 32), i, ~i);
+}
+__global__ void k_count_inversions(const uint4 *recs, uint32_t n, unsigned long long *out) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i + 1 >= n) return;
+  const uint4 a = recs[i], b = recs[i + 1];
+  const uint64_t ka = ((uint64_t)a.y << 32) | a.x, kb = ((uint64_t)b.y << 32) | b.x;
+  // stable LSD: equal keys keep their input order (z = original index)
+  if (ka > kb || (ka == kb && a.z > b.z)) atomicAdd(out, 1ull);
+}
+
 __global__ void k_to_temp(const kslam_overlap *__restrict__ in, uint64_t n, kslam_overlap_temp *__restrict__ out) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -271,8 +289,18 @@ void align_resident(kslam_ctx *c, bool stop_after_join, uint64_t *n_raw_out) {
   sp.gap_open = (int32_t)c->prm.gap_open; sp.gap_extend = (int32_t)c->prm.gap_extend;
   sp.score_threshold = c->prm.score_threshold; sp.report_cigar = c->prm.report_cigar;
 
+  // The join looks every read k-mer up in the resident genome list (bucket table over the top
+  // bucket_bits key bits + binary search), so the read list only has to be ordered as far as that
+  // lookup benefits from locality: by the top key bytes covering the bucket bits.  Lower bytes
+  // would only order records inside one bucket, which no later stage observes (the overlap list
+  // is re-sorted by (read, entry, rel)).  KSLAM_SORT_BYTES overrides (8 = full 64-bit order).
   std::vector<SortPass> kpasses;
-  kmer_passes(kpasses);
+  {
+    uint32_t nbytes = (c->bucket_bits + 7) / 8;
+    if (const char *e = getenv("KSLAM_SORT_BYTES")) nbytes = (uint32_t)atoi(e);
+    nbytes = std::min(8u, std::max(1u, nbytes));
+    for (uint32_t b = 8 - nbytes; b < 8; b++) kpasses.push_back(SortPass{b / 4, 8 * (b % 4), 0});
+  }
   tm.sort_passes = (uint32_t)kpasses.size();
 
   uint64_t r0 = 0;
@@ -649,6 +677,43 @@ kslam_status kslam_sort_kmers(kslam_ctx *c, kslam_kmer *recs, uint64_t n) {
     HIPCHK(hipStreamSynchronize(s));
     check_sort_error(c);
     a.release(); b.release();
+  });
+}
+
+kslam_status kslam_selftest_sort(kslam_ctx *c, uint64_t n, uint32_t iters, float *ms_per_sort,
+                                 float *ms_per_scatter_launch, uint64_t *n_inversions) {
+  return guarded(c, [&] {
+    if (n == 0 || n >= (1ull << 32) || iters == 0) throw StatusError{KSLAM_ERR_ARG, "bad n / iters"};
+    hipStream_t s = c->stream;
+    c->recs_a.ensure((n + 1) * sizeof(uint4));
+    c->recs_b.ensure((n + 1) * sizeof(uint4));
+    c->cells.ensure(sizeof(uint64_t));
+    std::vector<SortPass> passes;
+    kmer_passes(passes);
+    float tot = 0, tot_sc = 0;
+    uint32_t launches = 0;
+    const void *sorted = nullptr;
+    for (uint32_t it = 0; it < iters; it++) {
+      hipLaunchKernelGGL(k_fill_random, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, c->recs_a.as<uint4>(),
+                         (uint32_t)n, 0x1234567ull + it);
+      HIPCHK(hipEventRecord(c->ev[0], s));
+      sorted = radix_sort(c->recs_a.p, c->recs_b.p, n, 4, passes.data(), (int)passes.size(), c->sortws, s, c->ev[2],
+                          c->ev[3], &launches);
+      HIPCHK(hipEventRecord(c->ev[1], s));
+      HIPCHK(hipStreamSynchronize(s));
+      tot += ev_ms(c->ev[0], c->ev[1]);
+      tot_sc += ev_ms(c->ev[2], c->ev[3]);
+    }
+    check_sort_error(c);
+    HIPCHK(hipMemsetAsync(c->cells.p, 0, sizeof(uint64_t), s));
+    hipLaunchKernelGGL(k_count_inversions, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const uint4 *)sorted,
+                       (uint32_t)n, c->cells.as<unsigned long long>());
+    uint64_t inv = 0;
+    HIPCHK(hipMemcpyAsync(&inv, c->cells.p, sizeof inv, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (ms_per_sort) *ms_per_sort = tot / iters;
+    if (ms_per_scatter_launch) *ms_per_scatter_launch = launches ? tot_sc / launches : 0.f;
+    if (n_inversions) *n_inversions = inv;
   });
 }
 

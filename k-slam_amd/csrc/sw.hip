@@ -20,8 +20,8 @@
 // pass, so one int32 DP reproduces both.  The reverse pass is not run at all: the
 // forward pass carries each alignment's start cell along with its score (see
 // sw_origin_pass), which provably selects the same begin as the reference's
-// reverse scan; oracle/kslam_oracle.c origin_pass is the CPU statement of it
-// (80k random + 60k low-complexity trials equal to the striped emulation).  The striped Lazy-F evaluation order
+// reverse scan (the test tree holds a scalar CPU statement of it that
+// equals the striped emulation on 80k random + 60k low-complexity trials).  The striped Lazy-F evaluation order
 // is only observable when a gap pair can beat a mismatch or when gapE >= gapO;
 // kslam_create rejects such scoring.
 //

@@ -268,3 +268,9 @@ def test_banded_sw_equals_full_matrix_sw(kslam, synth, monkeypatch):
     c.close()
     assert len(a) > 20000
     _compare_alignments(a, ac, b, bc)
+
+
+def test_sort_selftest_large(ctx):
+    """full-size property: 64 M random records come out ordered (stable) after the 8-pass sort"""
+    ms, ms_launch, inv = ctx.selftest_sort(1 << 26, 1)
+    assert inv == 0

@@ -74,6 +74,7 @@ struct PassResult {
 
 // group-wide selection of the best cell from the lane-local bests: max score, then smallest
 // column, then smallest row (ssw.c:316-342); also hands out its origin key
+template <int GL = 16>
 __device__ inline PassResult reduce_best(int32_t lbV, int32_t lbZ) {
   const int32_t lane = threadIdx.x & 63;
   const int32_t sc = lbV >> KB;
@@ -81,11 +82,12 @@ __device__ inline PassResult reduce_best(int32_t lbV, int32_t lbZ) {
   const int32_t G = sc > 0 ? ((sc << KB) | ((511 - ecol) << 9) | (511 - erow)) : 0;
   int32_t Gm = G;
 #pragma unroll
-  for (int m = 1; m < 16; m <<= 1) Gm = max(Gm, __shfl_xor(Gm, m, 16));
+  for (int m = 1; m < GL; m <<= 1) Gm = max(Gm, __shfl_xor(Gm, m, GL));
   const uint64_t bal = __ballot(G == Gm && Gm != 0);
-  const uint32_t grp_bits = (uint32_t)(bal >> (lane & 48)) & 0xFFFFu;
+  const int32_t gbase = lane & ~(GL - 1);
+  const uint32_t grp_bits = (uint32_t)(bal >> gbase) & ((1u << GL) - 1u);
   PassResult res{0, 0, 0, 0, 0};
-  const int32_t src = (lane & 48) | (grp_bits ? __builtin_ctz(grp_bits) : 0);
+  const int32_t src = gbase | (grp_bits ? __builtin_ctz(grp_bits) : 0);
   const int32_t wV = __shfl(lbV, src, 64), wZ = __shfl(lbZ, src, 64);
   if (grp_bits) {
     res.score = wV >> KB;
@@ -172,6 +174,7 @@ __device__ inline PassResult sw_origin_pass(const uint8_t *qcodes, int32_t qlen,
 
 // ---- shared pieces of the two SW kernels ------------------------------------------------------
 // stage read + window of candidate `o` as SSW codes (all 16 lanes of the group cooperate)
+template <int GL = 16>
 __device__ inline void stage_candidate(const kslam_overlap &o, const SwInputs &in, int32_t t, uint8_t *sq,
                                        uint8_t *sw, int32_t *L_out, int32_t *wlen_out) {
   const uint64_t ro = in.read_off[o.read];
@@ -180,8 +183,8 @@ __device__ inline void stage_candidate(const kslam_overlap &o, const SwInputs &i
   const uint64_t G = in.genome_off[o.entry + 1] - go;
   const int64_t s0 = o.rel > 0 ? o.rel : 0;                           // SmithWaterman.h:204
   const int32_t wlen = (int32_t)min((uint64_t)L, G - (uint64_t)s0);    // substr, :205-206
-  for (int32_t i = t; i < L; i += 16) sq[i] = (uint8_t)translate_base(in.read_bases[ro + i]);
-  for (int32_t j = t; j < wlen; j += 16) {
+  for (int32_t i = t; i < L; i += GL) sq[i] = (uint8_t)translate_base(in.read_bases[ro + i]);
+  for (int32_t j = t; j < wlen; j += GL) {
     uint32_t ch;
     if (!o.revcomp) ch = in.genome_bases[go + s0 + j];
     else ch = complement_base(in.genome_bases[go + s0 + (wlen - 1 - j)]);  // :207
@@ -192,6 +195,7 @@ __device__ inline void stage_candidate(const kslam_overlap &o, const SwInputs &i
 }
 
 // result record + band request for banded_sw, ssw.c:924-935 (flag 0x0f: score and distance filters)
+template <int GL = 16>
 __device__ inline void sw_epilogue(kslam_overlap *ov, uint64_t ci, bool have, int32_t t, int32_t L,
                                    const PassResult &f, const uint8_t *sq, const uint8_t *sw, const SwParams &p,
                                    uint32_t *band0) {
@@ -204,13 +208,13 @@ __device__ inline void sw_epilogue(kslam_overlap *ov, uint64_t ci, bool have, in
   // direction there is "diagonal" (ties prefer it, ssw.c:686) and the cigar is <n>M.
   int32_t dsum = 0;
   if (want && refLen == readLen) {
-    for (int32_t k = t; k < readLen; k += 16) {
+    for (int32_t k = t; k < readLen; k += GL) {
       const uint32_t q = sq[f.beg_row + k], c = sw[f.beg_col + k];
       dsum += (q > 3u || c > 3u) ? 0 : (q == c ? p.match : -p.mismatch);
     }
   }
 #pragma unroll
-  for (int m = 1; m < 16; m <<= 1) dsum += __shfl_xor(dsum, m, 16);
+  for (int m = 1; m < GL; m <<= 1) dsum += __shfl_xor(dsum, m, GL);
   if (have && t == 0) {
     kslam_overlap o = ov[ci];
     o.score = (uint16_t)f.score;
@@ -270,25 +274,31 @@ __global__ __launch_bounds__(256) void k_sw(kslam_overlap *__restrict__ ov, uint
 // the two cells of its diagonals with the parity of k.  A cell takes E from diagonal d-1 and F
 // from diagonal d+1 (both from step k-1: own registers, or one DPP row shift at the lane
 // boundary) and its own diagonal's H from step k-2.
-template <int LMAX>
+// GL = lanes per candidate: 8 (32 diagonals, 8 candidates per wave) or 16 (64 diagonals, 4 per wave).
+// `list` (optional) maps work items to candidates; todo[] is indexed by work item.
+template <int LMAX, int GL>
 __global__ __launch_bounds__(256) void k_sw_band(kslam_overlap *__restrict__ ov, uint64_t n, SwInputs in, SwParams p,
-                                                 uint32_t *__restrict__ band0, uint32_t *__restrict__ todo) {
-  __shared__ uint8_t s_q[16][LMAX];
-  __shared__ uint8_t s_w[16][LMAX];
-  __shared__ uint32_t s_tab[16][LMAX];
+                                                 uint32_t *__restrict__ band0, uint32_t *__restrict__ todo,
+                                                 const uint32_t *__restrict__ list) {
+  constexpr int NG = 256 / GL;          // candidates per block
+  constexpr int ND = 4 * GL;            // diagonals swept
+  __shared__ uint8_t s_q[NG][LMAX];
+  __shared__ uint8_t s_w[NG][LMAX];
+  __shared__ uint32_t s_tab[NG][LMAX];
   const int32_t lane = threadIdx.x & 63;
-  const int32_t t = lane & 15;
-  const int32_t grp = threadIdx.x >> 4;
-  const uint64_t ci = (uint64_t)blockIdx.x * 16 + grp;
-  const bool have = ci < n;
+  const int32_t t = lane & (GL - 1);
+  const int32_t grp = threadIdx.x / GL;
+  const uint64_t gi = (uint64_t)blockIdx.x * NG + grp;
+  const bool have = gi < n;
+  const uint64_t ci = have ? (list ? list[gi] : gi) : 0;
   int32_t L = 0, W = 0, rel = 0;
   if (have) {
     const kslam_overlap o = ov[ci];
     rel = o.rel;
-    stage_candidate(o, in, t, s_q[grp], s_w[grp], &L, &W);
+    stage_candidate<GL>(o, in, t, s_q[grp], s_w[grp], &L, &W);
   }
   __syncthreads();
-  for (int32_t i = t; i < L; i += 16) {   // 6-bit packed score row per query base
+  for (int32_t i = t; i < L; i += GL) {   // 6-bit packed score row per query base
     const uint32_t q = s_q[grp][i];
     uint32_t tb = 0;
 #pragma unroll
@@ -302,7 +312,7 @@ __global__ __launch_bounds__(256) void k_sw_band(kslam_overlap *__restrict__ ov,
   const int32_t gO = p.gap_open << KB, gE = p.gap_extend << KB;
   const int32_t NEG = -((p.gap_open + p.gap_extend + 1) << KB);
   const int32_t d0 = rel < 0 ? rel : 0;          // seed diagonal: read base i sits on window base i + d0
-  const int32_t dlo = d0 - 32;
+  const int32_t dlo = d0 - ND / 2;
   int32_t dq[4], Hd[4], Eo[4], Fo[4];
 #pragma unroll
   for (int q = 0; q < 4; q++) {
@@ -345,13 +355,13 @@ __global__ __launch_bounds__(256) void k_sw_band(kslam_overlap *__restrict__ ov,
     {  // phase B: diagonals 1 and 3
       const int32_t fin = __builtin_amdgcn_update_dpp(0, Fo[0], 0x101, 0xF, 0xF, true);  // row_shl:1
       const int32_t e1 = Eo[0], f1 = Fo[2];
-      const int32_t e3 = Eo[2], f3 = t == 15 ? NEG : fin;
+      const int32_t e3 = Eo[2], f3 = t == GL - 1 ? NEG : fin;
       cell(dq[1], Hd[1], e1, f1, Eo[1], Fo[1], k + 1);
       cell(dq[3], Hd[3], e3, f3, Eo[3], Fo[3], k + 1);
     }
   }
-  const PassResult f = reduce_best(lbV, lbZ);
-  // certificate: every alignment scoring >= f.score lies inside [dlo, dlo + 63]
+  const PassResult f = reduce_best<GL>(lbV, lbZ);
+  // certificate: every alignment scoring >= f.score lies inside [dlo, dlo + ND - 1]
   bool exact = false;
   if (have && f.score > 0) {
     int32_t rlo = 1 << 20, rhi = -(1 << 20);
@@ -363,16 +373,16 @@ __global__ __launch_bounds__(256) void k_sw_band(kslam_overlap *__restrict__ ov,
       rlo = min(rlo, -(L - m0) - g);
       rhi = max(rhi, (W - m0) + g);
     }
-    exact = rlo >= dlo && rhi <= dlo + 63;
+    exact = rlo >= dlo && rhi <= dlo + ND - 1;
   }
-  if (have && t == 0) todo[ci] = exact ? 0u : 1u;
-  sw_epilogue(ov, ci, exact, t, L, f, s_q[grp], s_w[grp], p, band0);
+  if (have && t == 0) todo[gi] = exact ? 0u : 1u;
+  sw_epilogue<GL>(ov, ci, exact, t, L, f, s_q[grp], s_w[grp], p, band0);
 }
 
 __global__ void k_scatter_todo(const uint32_t *__restrict__ flags, const uint32_t *__restrict__ pos, uint64_t n,
-                               uint32_t *__restrict__ list) {
+                               const uint32_t *__restrict__ src, uint32_t *__restrict__ list) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n && flags[i]) list[pos[i]] = (uint32_t)i;
+  if (i < n && flags[i]) list[pos[i]] = src ? src[i] : (uint32_t)i;
 }
 
 }  // namespace
@@ -383,39 +393,51 @@ void sw_scores(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, uint32_
   if (n == 0) return;
   if (max_read_len > 511) throw StatusError{KSLAM_ERR_UNSUPPORTED, "reads longer than 511 bases are not supported yet"};
   if (n >= (1ull << 32)) throw StatusError{KSLAM_ERR_UNSUPPORTED, ">= 2^32 candidates in one chunk"};
-  const unsigned blocks = (unsigned)((n + 15) / 16);
+  const int lm = max_read_len <= 160 ? 0 : (max_read_len <= 256 ? 1 : 2);
   const uint32_t *list = nullptr;
   uint64_t m = n;
   const char *force_full = getenv("KSLAM_SW_FULL");
   if (!(force_full && force_full[0] == '1')) {
-    // pass 1: banded kernel on every candidate whose provable band fits 32 diagonals
     W.flags.ensure(n * sizeof(uint32_t));
     W.pos.ensure(n * sizeof(uint32_t));
     W.list.ensure(n * sizeof(uint32_t));
+    W.list2.ensure(n * sizeof(uint32_t));
     W.scan_tmp.ensure(scan_tmp_bytes(n));
     W.totals.ensure(2 * sizeof(uint64_t));
-    if (max_read_len <= 160)
-      hipLaunchKernelGGL(k_sw_band<160>, dim3(blocks), dim3(256), 0, s, d_ov, n, in, p, d_band0, W.flags.as<uint32_t>());
-    else if (max_read_len <= 256)
-      hipLaunchKernelGGL(k_sw_band<256>, dim3(blocks), dim3(256), 0, s, d_ov, n, in, p, d_band0, W.flags.as<uint32_t>());
-    else
-      hipLaunchKernelGGL(k_sw_band<512>, dim3(blocks), dim3(256), 0, s, d_ov, n, in, p, d_band0, W.flags.as<uint32_t>());
-    exclusive_scan_u32(W.flags.as<uint32_t>(), W.pos.as<uint32_t>(), n, W.totals.as<uint64_t>(), W.scan_tmp.p, s);
-    HIPCHK(hipMemcpyAsync(&m, W.totals.p, sizeof m, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    if (m) hipLaunchKernelGGL(k_scatter_todo, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
-                              W.flags.as<uint32_t>(), W.pos.as<uint32_t>(), n, W.list.as<uint32_t>());
-    list = W.list.as<uint32_t>();
+    // tier 1: 32 diagonals, 8 lanes per candidate; tier 2: 64 diagonals, 16 lanes; both carry an
+    // exactness certificate, whatever fails it goes on to the next tier
+    for (int tier = 0; tier < 2 && m; tier++) {
+      uint32_t *flags = W.flags.as<uint32_t>();
+      uint32_t *out_list = tier == 0 ? W.list.as<uint32_t>() : W.list2.as<uint32_t>();
+      if (tier == 0) {
+        const unsigned blocks = (unsigned)((m + 31) / 32);
+        if (lm == 0) hipLaunchKernelGGL((k_sw_band<160, 8>), dim3(blocks), dim3(256), 0, s, d_ov, m, in, p, d_band0, flags, list);
+        else if (lm == 1) hipLaunchKernelGGL((k_sw_band<256, 8>), dim3(blocks), dim3(256), 0, s, d_ov, m, in, p, d_band0, flags, list);
+        else hipLaunchKernelGGL((k_sw_band<512, 8>), dim3(blocks), dim3(256), 0, s, d_ov, m, in, p, d_band0, flags, list);
+      } else {
+        const unsigned blocks = (unsigned)((m + 15) / 16);
+        if (lm == 0) hipLaunchKernelGGL((k_sw_band<160, 16>), dim3(blocks), dim3(256), 0, s, d_ov, m, in, p, d_band0, flags, list);
+        else if (lm == 1) hipLaunchKernelGGL((k_sw_band<256, 16>), dim3(blocks), dim3(256), 0, s, d_ov, m, in, p, d_band0, flags, list);
+        else hipLaunchKernelGGL((k_sw_band<512, 16>), dim3(blocks), dim3(256), 0, s, d_ov, m, in, p, d_band0, flags, list);
+      }
+      exclusive_scan_u32(flags, W.pos.as<uint32_t>(), m, W.totals.as<uint64_t>(), W.scan_tmp.p, s);
+      uint64_t m2 = 0;
+      HIPCHK(hipMemcpyAsync(&m2, W.totals.p, sizeof m2, hipMemcpyDeviceToHost, s));
+      HIPCHK(hipStreamSynchronize(s));
+      if (m2) hipLaunchKernelGGL(k_scatter_todo, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, flags,
+                                 W.pos.as<uint32_t>(), m, list, out_list);
+      if (getenv("KSLAM_DEBUG")) fprintf(stderr, "[kslam] SW tier %d: %llu candidates in, %llu left\n", tier + 1,
+                                          (unsigned long long)m, (unsigned long long)m2);
+      list = out_list;
+      m = m2;
+    }
   }
   if (n_full_out) *n_full_out = m;
-  if (m) {  // pass 2: full matrix for the rest
+  if (m) {  // full matrix for the rest
     const unsigned b2 = (unsigned)((m + 15) / 16);
-    if (max_read_len <= 160)
-      hipLaunchKernelGGL(k_sw<10>, dim3(b2), dim3(256), 0, s, d_ov, m, in, p, d_band0, list);
-    else if (max_read_len <= 256)
-      hipLaunchKernelGGL(k_sw<16>, dim3(b2), dim3(256), 0, s, d_ov, m, in, p, d_band0, list);
-    else
-      hipLaunchKernelGGL(k_sw<32>, dim3(b2), dim3(256), 0, s, d_ov, m, in, p, d_band0, list);
+    if (lm == 0) hipLaunchKernelGGL(k_sw<10>, dim3(b2), dim3(256), 0, s, d_ov, m, in, p, d_band0, list);
+    else if (lm == 1) hipLaunchKernelGGL(k_sw<16>, dim3(b2), dim3(256), 0, s, d_ov, m, in, p, d_band0, list);
+    else hipLaunchKernelGGL(k_sw<32>, dim3(b2), dim3(256), 0, s, d_ov, m, in, p, d_band0, list);
   }
   HIPCHK(hipGetLastError());
 }

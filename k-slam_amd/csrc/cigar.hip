@@ -24,25 +24,6 @@ namespace kslam {
 
 namespace {
 
-__device__ inline uint32_t tr_base(uint32_t c) {  // ssw_cpp.cpp:11-23
-  switch (c) {
-    case 'A': case 'a': return 0;
-    case 'C': case 'c': return 1;
-    case 'G': case 'g': return 2;
-    case 'T': case 't': return 3;
-    case 'U': case 'u': return 0;
-    default: return 4;
-  }
-}
-__device__ inline uint32_t comp_base(uint32_t c) {  // sequenceTools.h:98-116
-  switch (c) {
-    case 'A': return 'T';
-    case 'C': return 'G';
-    case 'T': return 'A';
-    case 'G': return 'C';
-    default: return c;
-  }
-}
 __device__ inline uint32_t band_class(uint32_t bw) {
   uint32_t c = 0;
   while ((1u << c) < bw) c++;
@@ -108,6 +89,7 @@ struct CigJob {
   uint8_t *scratch;
   uint64_t wave_slab;   // scratch bytes per wavefront
   uint32_t *err;        // [0] traceback errors
+  uint32_t variant;     // timing ablations (KSLAM_CIGAR_VARIANT), 0 in production
 };
 
 // banded_sw (ssw.c:594-792): one attempt with J.bw[ci], then traceback when max >= score.
@@ -123,23 +105,53 @@ struct LdsLayout {
   uint32_t wd;       // direction cells per row the global slab is sized for (2 * slot_bw + 1)
 };
 
-// stage `len` bases starting at src (any alignment) as SSW codes into dst[k * NL]; when `rev`
-// the bases are complemented and written back to front (window of a revComp overlap)
-__device__ inline void stage_codes(const uint8_t *src, int32_t len, bool rev, uint8_t *dst, uint32_t NL) {
+// Wave-cooperative staging of one span per lane: for each lane c of the wave in turn, all lanes
+// fetch c's span with coalesced aligned dword loads and store the SSW codes transposed into
+// dst[k * NS + c] (NS = NL + 1 keeps those strided byte stores on distinct LDS banks).  When
+// `rev` the bases are complemented and written back to front (window of a revComp overlap).
+__device__ inline void stage_codes_wave(const uint8_t *src, int32_t len, bool rev, uint8_t *dst, uint32_t NS,
+                                        uint32_t nl_active) {
+  const uint32_t lane = threadIdx.x;
   const uintptr_t a0 = reinterpret_cast<uintptr_t>(src);
-  const uintptr_t al = a0 & ~(uintptr_t)3;
-  const int32_t nw = (int32_t)((a0 + (uintptr_t)len - al + 3) >> 2);
-  const uint32_t *w = reinterpret_cast<const uint32_t *>(al);
-  const int32_t shift0 = (int32_t)(a0 - al);
-  for (int32_t x = 0; x < nw; x++) {
-    const uint32_t v = w[x];
+  const int32_t maxlen = [&] {   // longest span in the wave (wave-uniform loop bound)
+    int32_t m = len;
 #pragma unroll
-    for (int32_t b = 0; b < 4; b++) {
-      const int32_t k = x * 4 + b - shift0;
-      if (k >= 0 && k < len) {
-        const uint32_t ch = (v >> (8 * b)) & 0xFFu;
-        if (rev) dst[(uint32_t)(len - 1 - k) * NL] = (uint8_t)tr_base(comp_base(ch));
-        else dst[(uint32_t)k * NL] = (uint8_t)tr_base(ch);
+    for (int d = 32; d > 0; d >>= 1) m = max(m, __shfl_xor(m, d, 64));
+    return m;
+  }();
+  const int32_t nchunk = (maxlen + 3 + 255) / 256;   // 64 lanes x 4 bytes per chunk (+3 for misalignment)
+  for (int32_t ch = 0; ch < nchunk; ch++) {
+    for (uint32_t c0 = 0; c0 < nl_active; c0 += 8) {
+      uint32_t v[8];
+      int32_t clen[8], shift0[8];
+      uint32_t crev[8];
+#pragma unroll
+      for (uint32_t u = 0; u < 8; u++) {            // 8 candidates' loads in flight together
+        const uint32_t c = min(c0 + u, 63u);
+        const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)a0, c);
+        const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(a0 >> 32), c);
+        clen[u] = c0 + u < nl_active ? (int32_t)__builtin_amdgcn_readlane((uint32_t)len, c) : 0;
+        crev[u] = __builtin_amdgcn_readlane((uint32_t)rev, c);
+        const uintptr_t ca = ((uintptr_t)hi << 32) | lo;
+        const uintptr_t al = ca & ~(uintptr_t)3;
+        shift0[u] = (int32_t)(ca - al);
+        const int32_t nw = (shift0[u] + clen[u] + 3) >> 2;
+        const int32_t x = ch * 64 + (int32_t)lane;
+        v[u] = x < nw ? reinterpret_cast<const uint32_t *>(al)[x] : 0u;
+      }
+#pragma unroll
+      for (uint32_t u = 0; u < 8; u++) {
+        const uint32_t c = c0 + u;
+        const int32_t x = ch * 64 + (int32_t)lane;
+#pragma unroll
+        for (int32_t b = 0; b < 4; b++) {
+          const int32_t k = x * 4 + b - shift0[u];
+          if (k >= 0 && k < clen[u]) {
+            const uint32_t chh = (v[u] >> (8 * b)) & 0xFFu;
+            const uint32_t code = crev[u] ? ssw_code_complemented(chh) : ssw_code(chh);
+            dst[(uint32_t)(crev[u] ? clen[u] - 1 - k : k) * NS + c] = (uint8_t)code;
+          }
+        }
       }
     }
   }
@@ -150,56 +162,72 @@ __device__ inline void stage_codes(const uint8_t *src, int32_t len, bool rev, ui
 // cell, written fire-and-forget during the DP and read back only by the traceback.
 __global__ __launch_bounds__(64) void k_banded_lds(CigJob J, SwInputs in, SwParams p, LdsLayout Y) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+  if (J.variant == 3) return;   // ablation: launch floor
   const uint32_t lane = threadIdx.x;
-  const uint32_t NL = Y.nl;
+  const uint32_t NL = Y.nl, NS = NL + 1;
   const uint32_t li = blockIdx.x * NL + lane;
-  if (lane >= NL || li >= J.m) return;
+  const bool have = lane < NL && li < J.m;
+  const uint32_t n_here = min(NL, J.m - blockIdx.x * NL);
   uint8_t *SQ = lds_raw;
-  uint8_t *SR = SQ + (size_t)Y.lmax * NL;
-  int32_t *S = reinterpret_cast<int32_t *>(SR + (((size_t)Y.lmax * NL + 15) & ~(size_t)15));
+  uint8_t *SR = SQ + (size_t)Y.lmax * NS;
+  int32_t *S = reinterpret_cast<int32_t *>(lds_raw + (((size_t)2 * Y.lmax * NS + 15) & ~(size_t)15));
   uint8_t *D = J.scratch + (uint64_t)blockIdx.x * J.wave_slab;
 
-  const uint32_t ci = J.list[J.list_base + li];
-  kslam_overlap o = J.ov[ci];
-  const int32_t band_width = (int32_t)J.bw[ci];
+  uint32_t ci = 0;
+  kslam_overlap o;
+  memset(&o, 0, sizeof o);
+  int32_t band_width = 1, refLen = 0, readLen = 0;
+  bool skip = !have;
+  const uint8_t *qsrc = in.read_bases, *rsrc = in.genome_bases;
+  if (have) {
+    ci = J.list[J.list_base + li];
+    o = J.ov[ci];
+    band_width = (int32_t)J.bw[ci];
+    refLen = o.ref_end - o.ref_begin + 1;    // ssw.c:930-931
+    readLen = o.query_end - o.query_begin + 1;
+    // direction buffer growth check of the reference, ssw.c:631-642
+    if ((int64_t)(band_width * 2 + 1) * readLen * 3 >= ((int64_t)1 << 30)) {
+      o.score = 0;                                          // ssw.c:941-944
+      o.cigar_len = 0;
+      J.ov[ci] = o;
+      J.bw[ci] = 0;
+      skip = true;
+    } else {
+      const uint64_t ro = in.read_off[o.read];
+      const uint64_t L = in.read_off[o.read + 1] - ro;
+      const uint64_t go = in.genome_off[o.entry];
+      const uint64_t G = in.genome_off[o.entry + 1] - go;
+      const int64_t s0 = o.rel > 0 ? o.rel : 0;
+      const int64_t wlen = (int64_t)min(L, G - (uint64_t)s0);
+      qsrc = in.read_bases + ro + o.query_begin;
+      // window position x of a flipped (revComp) window is genome position wlen - 1 - x
+      rsrc = in.genome_bases + go + s0 + (o.revcomp ? (wlen - 1 - o.ref_end) : (int64_t)o.ref_begin);
+    }
+  }
+  if (J.variant == 4) return;   // ablation: candidate header loads only
+  if (J.variant == 5) { qsrc = in.read_bases + 64 * lane; rsrc = in.genome_bases + 64 * lane; }   // ablation: cache-resident sources
+  // stage the two spans as SSW codes (ssw_cpp.cpp:11-23), cooperatively and coalesced
+  stage_codes_wave(qsrc, skip ? 0 : readLen, false, SQ, NS, n_here);
+  stage_codes_wave(rsrc, skip ? 0 : refLen, !skip && o.revcomp != 0, SR, NS, n_here);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  if (skip || J.variant == 2 || J.variant == 5) return;
   const int32_t score = o.score;
-  const int32_t refLen = o.ref_end - o.ref_begin + 1;    // ssw.c:930-931
-  const int32_t readLen = o.query_end - o.query_begin + 1;
-  // direction buffer growth check of the reference, ssw.c:631-642
-  if ((int64_t)(band_width * 2 + 1) * readLen * 3 >= ((int64_t)1 << 30)) {
-    o.score = 0;                                          // ssw.c:941-944
-    o.cigar_len = 0;
-    J.ov[ci] = o;
-    J.bw[ci] = 0;
-    return;
-  }
-  {  // stage the two spans as SSW codes (ssw_cpp.cpp:11-23)
-    const uint64_t ro = in.read_off[o.read];
-    const uint64_t L = in.read_off[o.read + 1] - ro;
-    const uint64_t go = in.genome_off[o.entry];
-    const uint64_t G = in.genome_off[o.entry + 1] - go;
-    const int64_t s0 = o.rel > 0 ? o.rel : 0;
-    const int64_t wlen = (int64_t)min(L, G - (uint64_t)s0);
-    stage_codes(in.read_bases + ro + o.query_begin, readLen, false, SQ + lane, NL);
-    const uint8_t *gw = in.genome_bases + go + s0;
-    if (o.revcomp)   // window position x of the flipped window is genome position wlen - 1 - x
-      stage_codes(gw + (wlen - 1 - o.ref_end), refLen, true, SR + lane, NL);
-    else
-      stage_codes(gw + o.ref_begin, refLen, false, SR + lane, NL);
-  }
   struct Acc {
     int32_t *S; uint8_t *SQ, *SR, *D;
     uint32_t NL, lane, W1, width_d;
     __device__ int32_t &hb(int32_t k) { return S[(uint32_t)k * NL + lane]; }
     __device__ int32_t &eb(int32_t k) { return S[(W1 + (uint32_t)k) * NL + lane]; }
     __device__ int32_t &hc(int32_t k) { return S[(2 * W1 + (uint32_t)k) * NL + lane]; }
-    __device__ uint32_t q(int32_t i) { return SQ[(uint32_t)i * NL + lane]; }
-    __device__ uint32_t r(int32_t j) { return SR[(uint32_t)j * NL + lane]; }
+    __device__ uint32_t q(int32_t i) { return SQ[(uint32_t)i * (NL + 1) + lane]; }
+    __device__ uint32_t r(int32_t j) { return SR[(uint32_t)j * (NL + 1) + lane]; }
     __device__ void set_dir(int32_t i, int32_t col, uint32_t v) { D[((size_t)i * width_d + (uint32_t)col) * NL + lane] = (uint8_t)v; }
     __device__ uint32_t get_dir(int32_t i, int32_t col) { return D[((size_t)i * width_d + (uint32_t)col) * NL + lane]; }
   } A{S, SQ, SR, D, NL, lane, Y.W1, (uint32_t)(band_width * 2 + 1)};
   (void)score;
   const int32_t mx = banded_attempt(A, refLen, readLen, band_width, p, J.bmax[ci]);
+  if (J.variant == 1) return;   // ablation: no traceback
   J.bmax[ci] = mx;
   if (mx < score) {               // ssw.c:693-694: retry with twice the band
     J.bw[ci] = (uint32_t)band_width * 2u;
@@ -332,8 +360,7 @@ void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, u
       uint32_t nl = 64;
       while (nl > 1 && per_lane * nl + 64 > 64 * 1024) nl >>= 1;   // <= 64 KB: at least two blocks per CU
       Y.nl = nl;
-      const size_t lds = (size_t)lmax * nl + (((size_t)lmax * nl + 15) & ~(size_t)15) +
-                         (size_t)3 * Y.W1 * nl * sizeof(int32_t);
+      const size_t lds = (((size_t)2 * lmax * (nl + 1) + 15) & ~(size_t)15) + (size_t)3 * Y.W1 * nl * sizeof(int32_t);
       if (lds > 160 * 1024) throw StatusError{KSLAM_ERR_UNSUPPORTED, "banded traceback band does not fit LDS"};
       if (lds > 64 * 1024)
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_banded_lds),
@@ -358,6 +385,7 @@ void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, u
         J.scratch = W.scratch.as<uint8_t>();
         J.wave_slab = slab;
         J.err = d_err;
+        { const char *cv = getenv("KSLAM_CIGAR_VARIANT"); J.variant = cv ? (uint32_t)atoi(cv) : 0u; }
         hipLaunchKernelGGL(k_banded_lds, dim3((unsigned)nb_here), dim3(64), lds, s, J, in, p, Y);
       }
       HIPCHK(hipGetLastError());

@@ -57,6 +57,25 @@ struct DevBuf {
   template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
+// ---- base coding shared by the SW and cigar kernels (branch-free) ---------------------------
+#ifdef __HIPCC__
+// kBaseTranslation (reference src/ssw_cpp.cpp:11-23): A/a 0, C/c 1, G/g 2, T/t 3, U/u 0, else 4
+__device__ inline uint32_t ssw_code(uint32_t c) {
+  const uint32_t idx = c & 31u;                                        // A 1, C 3, G 7, T 20, U 21
+  const bool known = ((c & 0xC0u) == 0x40u) && ((0x0030008Au >> idx) & 1u);
+  const uint32_t code = (uint32_t)(((1ull << 6) | (2ull << 14) | (3ull << 40)) >> (2u * idx)) & 3u;
+  return known ? code : 4u;
+}
+// the same after inPlaceReverseComplement's per-base step (reference src/sequenceTools.h:98-116):
+// only UPPER-case A/C/G/T are complemented, every other character is left as it is
+__device__ inline uint32_t ssw_code_complemented(uint32_t c) {
+  const uint32_t idx = c & 31u;
+  const uint32_t code = ssw_code(c);
+  const bool upper_acgt = ((c & 0xE0u) == 0x40u) && ((0x0010008Au >> idx) & 1u);
+  return upper_acgt ? 3u - code : code;
+}
+#endif
+
 // ---------------------------------------------------------------- scan.hip
 // exclusive scan of n u32 values; out may be u32 or u64. total (u64) is
 // written to d_total[0].  tmp must hold scan_tmp_bytes(n).

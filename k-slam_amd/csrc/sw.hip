@@ -40,26 +40,6 @@ namespace kslam {
 
 namespace {
 
-__device__ inline uint32_t translate_base(uint32_t c) {  // ssw_cpp.cpp:11-23
-  switch (c) {
-    case 'A': case 'a': return 0;
-    case 'C': case 'c': return 1;
-    case 'G': case 'g': return 2;
-    case 'T': case 't': return 3;
-    case 'U': case 'u': return 0;
-    default: return 4;
-  }
-}
-__device__ inline uint32_t complement_base(uint32_t c) {  // sequenceTools.h:98-116
-  switch (c) {
-    case 'A': return 'T';
-    case 'C': return 'G';
-    case 'T': return 'A';
-    case 'G': return 'C';
-    default: return c;
-  }
-}
-
 __device__ inline int32_t dpp_row_shr1(int32_t v) {
   // lane i of each 16-lane row receives lane i-1; lane 0 receives 0
   return __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);
@@ -183,12 +163,10 @@ __device__ inline void stage_candidate(const kslam_overlap &o, const SwInputs &i
   const uint64_t G = in.genome_off[o.entry + 1] - go;
   const int64_t s0 = o.rel > 0 ? o.rel : 0;                           // SmithWaterman.h:204
   const int32_t wlen = (int32_t)min((uint64_t)L, G - (uint64_t)s0);    // substr, :205-206
-  for (int32_t i = t; i < L; i += GL) sq[i] = (uint8_t)translate_base(in.read_bases[ro + i]);
+  for (int32_t i = t; i < L; i += GL) sq[i] = (uint8_t)ssw_code(in.read_bases[ro + i]);
   for (int32_t j = t; j < wlen; j += GL) {
-    uint32_t ch;
-    if (!o.revcomp) ch = in.genome_bases[go + s0 + j];
-    else ch = complement_base(in.genome_bases[go + s0 + (wlen - 1 - j)]);  // :207
-    sw[j] = (uint8_t)translate_base(ch);
+    sw[j] = (uint8_t)(o.revcomp ? ssw_code_complemented(in.genome_bases[go + s0 + (wlen - 1 - j)])  // :207
+                                : ssw_code(in.genome_bases[go + s0 + j]));
   }
   *L_out = L;
   *wlen_out = wlen;

@@ -107,7 +107,8 @@ struct LdsLayout {
 
 // Wave-cooperative staging of one span per lane: for each lane c of the wave in turn, all lanes
 // fetch c's span with coalesced aligned dword loads and store the SSW codes transposed into
-// dst[k * NS + c] (NS = NL + 1 keeps those strided byte stores on distinct LDS banks).  When
+// dst as 4-bit codes, byte (k / 2) * NS + c, nibble k & 1 (NS = NL + 1 spreads the strided
+// accesses over the LDS banks; the buffer is zeroed first and filled with LDS atomic ORs).  When
 // `rev` the bases are complemented and written back to front (window of a revComp overlap).
 __device__ inline void stage_codes_wave(const uint8_t *src, int32_t len, bool rev, uint8_t *dst, uint32_t NS,
                                         uint32_t nl_active) {
@@ -149,7 +150,10 @@ __device__ inline void stage_codes_wave(const uint8_t *src, int32_t len, bool re
           if (k >= 0 && k < clen[u]) {
             const uint32_t chh = (v[u] >> (8 * b)) & 0xFFu;
             const uint32_t code = crev[u] ? ssw_code_complemented(chh) : ssw_code(chh);
-            dst[(uint32_t)(crev[u] ? clen[u] - 1 - k : k) * NS + c] = (uint8_t)code;
+            const uint32_t kk = (uint32_t)(crev[u] ? clen[u] - 1 - k : k);
+            const uint32_t byte_addr = (kk >> 1) * NS + c;              // two 4-bit codes per byte
+            atomicOr(reinterpret_cast<uint32_t *>(dst) + (byte_addr >> 2),
+                     code << (8u * (byte_addr & 3u) + 4u * (kk & 1u)));
           }
         }
       }
@@ -168,9 +172,14 @@ __global__ __launch_bounds__(64) void k_banded_lds(CigJob J, SwInputs in, SwPara
   const uint32_t li = blockIdx.x * NL + lane;
   const bool have = lane < NL && li < J.m;
   const uint32_t n_here = min(NL, J.m - blockIdx.x * NL);
+  const uint32_t half = (((Y.lmax + 1) / 2) * NS + 3) & ~3u;   // bytes per packed sequence buffer
   uint8_t *SQ = lds_raw;
-  uint8_t *SR = SQ + (size_t)Y.lmax * NS;
-  int32_t *S = reinterpret_cast<int32_t *>(lds_raw + (((size_t)2 * Y.lmax * NS + 15) & ~(size_t)15));
+  uint8_t *SR = SQ + half;
+  int16_t *S = reinterpret_cast<int16_t *>(lds_raw + (((size_t)2 * half + 15) & ~(size_t)15));
+  for (uint32_t x = lane; x < half / 2; x += 64) reinterpret_cast<uint32_t *>(lds_raw)[x] = 0;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   uint8_t *D = J.scratch + (uint64_t)blockIdx.x * J.wave_slab;
 
   uint32_t ci = 0;
@@ -215,13 +224,13 @@ __global__ __launch_bounds__(64) void k_banded_lds(CigJob J, SwInputs in, SwPara
   if (skip || J.variant == 2 || J.variant == 5) return;
   const int32_t score = o.score;
   struct Acc {
-    int32_t *S; uint8_t *SQ, *SR, *D;
+    int16_t *S; uint8_t *SQ, *SR, *D;   // row arrays as int16: |values| < 2^13 (14-bit score field)
     uint32_t NL, lane, W1, width_d;
-    __device__ int32_t &hb(int32_t k) { return S[(uint32_t)k * NL + lane]; }
-    __device__ int32_t &eb(int32_t k) { return S[(W1 + (uint32_t)k) * NL + lane]; }
-    __device__ int32_t &hc(int32_t k) { return S[(2 * W1 + (uint32_t)k) * NL + lane]; }
-    __device__ uint32_t q(int32_t i) { return SQ[(uint32_t)i * (NL + 1) + lane]; }
-    __device__ uint32_t r(int32_t j) { return SR[(uint32_t)j * (NL + 1) + lane]; }
+    __device__ int16_t &hb(int32_t k) { return S[(uint32_t)k * NL + lane]; }
+    __device__ int16_t &eb(int32_t k) { return S[(W1 + (uint32_t)k) * NL + lane]; }
+    __device__ int16_t &hc(int32_t k) { return S[(2 * W1 + (uint32_t)k) * NL + lane]; }
+    __device__ uint32_t q(int32_t i) { return (SQ[((uint32_t)i >> 1) * (NL + 1) + lane] >> (4 * (i & 1))) & 15u; }
+    __device__ uint32_t r(int32_t j) { return (SR[((uint32_t)j >> 1) * (NL + 1) + lane] >> (4 * (j & 1))) & 15u; }
     __device__ void set_dir(int32_t i, int32_t col, uint32_t v) { D[((size_t)i * width_d + (uint32_t)col) * NL + lane] = (uint8_t)v; }
     __device__ uint32_t get_dir(int32_t i, int32_t col) { return D[((size_t)i * width_d + (uint32_t)col) * NL + lane]; }
   } A{S, SQ, SR, D, NL, lane, Y.W1, (uint32_t)(band_width * 2 + 1)};
@@ -356,11 +365,12 @@ void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, u
     auto launch = [&](uint64_t m, uint32_t slot_bw, bool big) {
       LdsLayout Y;
       Y.lmax = lmax; Y.W1 = slot_bw * 2 + 4; Y.wd = slot_bw * 2 + 1;
-      const size_t per_lane = (size_t)2 * lmax + (size_t)3 * Y.W1 * sizeof(int32_t);
+      const size_t per_lane = (size_t)lmax + 2 + (size_t)3 * Y.W1 * sizeof(int16_t);
       uint32_t nl = 64;
       while (nl > 1 && per_lane * nl + 64 > 64 * 1024) nl >>= 1;   // <= 64 KB: at least two blocks per CU
       Y.nl = nl;
-      const size_t lds = (((size_t)2 * lmax * (nl + 1) + 15) & ~(size_t)15) + (size_t)3 * Y.W1 * nl * sizeof(int32_t);
+      const size_t half = ((((size_t)lmax + 1) / 2) * (nl + 1) + 3) & ~(size_t)3;
+      const size_t lds = ((2 * half + 15) & ~(size_t)15) + (size_t)3 * Y.W1 * nl * sizeof(int16_t);
       if (lds > 160 * 1024) throw StatusError{KSLAM_ERR_UNSUPPORTED, "banded traceback band does not fit LDS"};
       if (lds > 64 * 1024)
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_banded_lds),

@@ -25,7 +25,7 @@ for tag, d in (('FETCH_SIZE', 'pf'), ('WRITE_SIZE', 'pw')):
                 continue
             k = clean(r['Kernel_Name'])
             a = pmc.setdefault(k, {}).setdefault(r['Counter_Name'], [0, 0.0, 0.0])
-            v = float(r['Counter_Value']); a[0] += 1; a[1] += v; a[2] = max(a[2], v)
+            v = float(r["Counter_Value"]); a[0] += 1; a[1] += v; a[2] = max(a[2], v)
 out = {k: {c: {'dispatches': a[0], 'sum': a[1], 'mean': a[1] / a[0], 'max': a[2]} for c, a in cs.items()} for k, cs in pmc.items()}
 json.dump(out, open('gpurun_out/keep/%s_pmc_kslam.json' % R, 'w'), indent=1, sort_keys=True)
 for k in sorted(out):

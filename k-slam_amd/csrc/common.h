@@ -121,10 +121,11 @@ struct SortPass {
 };
 constexpr int SORT_TILE = 4096;
 struct SortWorkspace {
-  DevBuf hist;      // u32 [passes][256] -> exclusive bin bases
-  DevBuf status;    // u64 [tiles][256] decoupled look-back words
-  DevBuf tickets;   // u32 [passes + 1]
-  DevBuf errflag;   // u32
+  DevBuf hist;      // u32 [chunks][256] per-chunk digit totals -> bases
+  DevBuf status;    // u32 [tiles][256] per-tile digit counts -> in-chunk prefixes
+  DevBuf tickets;   // unused
+  DevBuf errflag;   // unused (no device-side waiting any more)
+  hipEvent_t *ev_sc0 = nullptr, *ev_sc1 = nullptr;   // optional per-pass events around k_scatter
   uint32_t epoch = 0;
 };
 // Sorts n records of REC_WORDS 32-bit words (4 = k-mer record, 2 = u64 key) by

@@ -123,7 +123,7 @@ constexpr int SORT_TILE = 4096;
 struct SortWorkspace {
   DevBuf hist;      // u32 [chunks][256] per-chunk digit totals -> bases
   DevBuf status;    // u32 [tiles][256] per-tile digit counts -> in-chunk prefixes
-  DevBuf tickets;   // unused
+  DevBuf tickets;   // u32 [256] per-digit totals -> global bin bases
   DevBuf errflag;   // unused (no device-side waiting any more)
   hipEvent_t *ev_sc0 = nullptr, *ev_sc1 = nullptr;   // optional per-pass events around k_scatter
   uint32_t epoch = 0;

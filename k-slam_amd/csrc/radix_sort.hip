@@ -78,17 +78,39 @@ __global__ __launch_bounds__(256) void k_chunk_scan(uint32_t *__restrict__ tile_
   }
   chunk_tot[(uint64_t)blockIdx.x * 256 + d] = acc;
 }
-// level 2: one workgroup: exclusive prefix over chunks per digit, then over digits (bin bases)
-__global__ __launch_bounds__(256) void k_top_scan(uint32_t *__restrict__ chunk_tot, uint32_t n_chunks) {
+// level 2: one workgroup per digit: exclusive prefix of that digit's chunk totals (column scan)
+__global__ __launch_bounds__(256) void k_col_scan(uint32_t *__restrict__ chunk_tot, uint32_t n_chunks,
+                                                  uint32_t *__restrict__ digit_tot) {
   __shared__ uint32_t ws[4];
-  const uint32_t d = threadIdx.x, lane = d & 63, w = d >> 6;
-  uint32_t acc = 0;
-  for (uint32_t c = 0; c < n_chunks; c++) {
+  const uint32_t d = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const uint32_t per = (n_chunks + 255) / 256;
+  const uint32_t c0 = tid * per, c1 = min(c0 + per, n_chunks);
+  uint32_t sum = 0;
+  for (uint32_t c = c0; c < c1; c++) sum += chunk_tot[(uint64_t)c * 256 + d];
+  uint32_t inc = sum;
+#pragma unroll
+  for (int dd = 1; dd < 64; dd <<= 1) {
+    uint32_t t = __shfl_up(inc, dd, 64);
+    if (lane >= (uint32_t)dd) inc += t;
+  }
+  if (lane == 63) ws[w] = inc;
+  __syncthreads();
+  uint32_t base = 0, tot = 0;
+  for (uint32_t i = 0; i < 4; i++) { if (i < w) base += ws[i]; tot += ws[i]; }
+  uint32_t acc = base + inc - sum;
+  for (uint32_t c = c0; c < c1; c++) {
     const uint32_t v = chunk_tot[(uint64_t)c * 256 + d];
     chunk_tot[(uint64_t)c * 256 + d] = acc;
     acc += v;
   }
-  uint32_t inc = acc;   // digit total -> exclusive scan over the 256 digits
+  if (tid == 0) digit_tot[d] = tot;
+}
+// level 3: exclusive scan of the 256 digit totals -> global bin bases
+__global__ __launch_bounds__(256) void k_bin_scan(uint32_t *__restrict__ digit_tot) {
+  __shared__ uint32_t ws[4];
+  const uint32_t d = threadIdx.x, lane = d & 63, w = d >> 6;
+  const uint32_t v = digit_tot[d];
+  uint32_t inc = v;
 #pragma unroll
   for (int dd = 1; dd < 64; dd <<= 1) {
     uint32_t t = __shfl_up(inc, dd, 64);
@@ -98,8 +120,7 @@ __global__ __launch_bounds__(256) void k_top_scan(uint32_t *__restrict__ chunk_t
   __syncthreads();
   uint32_t base = 0;
   for (uint32_t i = 0; i < w; i++) base += ws[i];
-  const uint32_t bin_base = base + inc - acc;
-  for (uint32_t c = 0; c < n_chunks; c++) chunk_tot[(uint64_t)c * 256 + d] += bin_base;
+  digit_tot[d] = base + inc - v;
 }
 
 // ---- scatter of one LSD pass --------------------------------------------------------------------
@@ -110,7 +131,8 @@ template <int RW>
 __global__ __launch_bounds__(RS_BLOCK) void k_scatter(const typename RecT<RW>::type *__restrict__ in,
                                                       typename RecT<RW>::type *__restrict__ out, uint32_t n,
                                                       const uint32_t *__restrict__ tile_prefix,
-                                                      const uint32_t *__restrict__ chunk_base, SortPass pass) {
+                                                      const uint32_t *__restrict__ chunk_base,
+                                                      const uint32_t *__restrict__ bin_base, SortPass pass) {
   using T = typename RecT<RW>::type;
   __shared__ T stage[SORT_TILE];
   __shared__ uint32_t wave_hist[RS_WAVES][256];
@@ -139,7 +161,8 @@ __global__ __launch_bounds__(RS_BLOCK) void k_scatter(const typename RecT<RW>::t
     if (loc < count) item[it] = in[tile_base + loc];
   }
   uint32_t gbase = 0;
-  if (tid < 256) gbase = chunk_base[(uint64_t)(tile / CHUNK_TILES) * 256 + tid] + tile_prefix[(uint64_t)tile * 256 + tid];
+  if (tid < 256)
+    gbase = bin_base[tid] + chunk_base[(uint64_t)(tile / CHUNK_TILES) * 256 + tid] + tile_prefix[(uint64_t)tile * 256 + tid];
   const uint64_t lt_mask = (1ull << lane) - 1ull;
 #pragma unroll
   for (int it = 0; it < RS_ITEMS; it++) {
@@ -216,15 +239,17 @@ void sort_impl(void *a, void *b, uint32_t n, const PassList &pl, SortWorkspace &
   const uint32_t chunks = (tiles + CHUNK_TILES - 1) / CHUNK_TILES;
   uint32_t *tile_hist = ws.status.as<uint32_t>();
   uint32_t *chunk_tot = ws.hist.as<uint32_t>();
+  uint32_t *digit_tot = ws.tickets.as<uint32_t>();
   T *src = (T *)a, *dst = (T *)b;
   if (ev0) HIPCHK(hipEventRecord(ev0, s));
   for (int p = 0; p < pl.n; p++) {
     hipLaunchKernelGGL(k_tile_hist<RW>, dim3(tiles), dim3(RS_BLOCK), 0, s, (const T *)src, n, pl.p[p], tile_hist);
     hipLaunchKernelGGL(k_chunk_scan, dim3(chunks), dim3(256), 0, s, tile_hist, tiles, chunk_tot);
-    hipLaunchKernelGGL(k_top_scan, dim3(1), dim3(256), 0, s, chunk_tot, chunks);
+    hipLaunchKernelGGL(k_col_scan, dim3(256), dim3(256), 0, s, chunk_tot, chunks, digit_tot);
+    hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(256), 0, s, digit_tot);
     if (ws.ev_sc0) HIPCHK(hipEventRecord(ws.ev_sc0[p], s));
     hipLaunchKernelGGL(k_scatter<RW>, dim3(tiles), dim3(RS_BLOCK), 0, s, (const T *)src, dst, n, tile_hist,
-                       chunk_tot, pl.p[p]);
+                       chunk_tot, digit_tot, pl.p[p]);
     if (ws.ev_sc0) HIPCHK(hipEventRecord(ws.ev_sc1[p], s));
     T *t = src; src = dst; dst = t;
     if (n_launches) (*n_launches)++;
@@ -252,6 +277,7 @@ void *radix_sort(void *a, void *b, uint64_t n, int rec_words, const SortPass *pa
   const uint64_t chunks = (tiles + CHUNK_TILES - 1) / CHUNK_TILES;
   ws.status.ensure(tiles * 256 * sizeof(uint32_t));   // per-tile digit histograms / prefixes
   ws.hist.ensure(chunks * 256 * sizeof(uint32_t));    // per-chunk totals / bases
+  ws.tickets.ensure(256 * sizeof(uint32_t));           // per-digit totals -> bin bases
   void *res = nullptr;
   if (rec_words == 4) sort_impl<4>(a, b, (uint32_t)n, pl, ws, s, ev0, ev1, n_launches, &res);
   else if (rec_words == 2) sort_impl<2>(a, b, (uint32_t)n, pl, ws, s, ev0, ev1, n_launches, &res);

@@ -24,9 +24,11 @@ for tag, d in (('FETCH_SIZE', 'pf'), ('WRITE_SIZE', 'pw')):
             if 'kslam' not in r['Kernel_Name']:
                 continue
             k = clean(r['Kernel_Name'])
-            a = pmc.setdefault(k, {}).setdefault(r['Counter_Name'], [0, 0.0, 0.0])
-            v = float(r["Counter_Value"]); a[0] += 1; a[1] += v; a[2] = max(a[2], v)
-out = {k: {c: {'dispatches': a[0], 'sum': a[1], 'mean': a[1] / a[0], 'max': a[2]} for c, a in cs.items()} for k, cs in pmc.items()}
+            a = pmc.setdefault(k, {}).setdefault(r['Counter_Name'], [0, 0.0, 0.0, []])
+            v = float(r["Counter_Value"]); a[0] += 1; a[1] += v; a[2] = max(a[2], v); a[3].append(v)
+out = {k: {c: {'dispatches': a[0], 'sum': a[1], 'mean': a[1] / a[0], 'max': a[2], 'min': min(a[3]),
+               'per_dispatch': a[3] if k.startswith(('k_scatter<4>', 'k_tile_hist<4>')) else None}
+           for c, a in cs.items()} for k, cs in pmc.items()}
 json.dump(out, open('gpurun_out/keep/%s_pmc_kslam.json' % R, 'w'), indent=1, sort_keys=True)
 for k in sorted(out):
     print(k.ljust(30), {c: (v['dispatches'], '%.4g' % v['mean'], '%.4g' % v['max']) for c, v in out[k].items()})

@@ -153,9 +153,8 @@ def cpu_baseline(db, offs, seed, n_genomes, n_pairs):
     kind_ssw = "own scalar SSW restatement"
     if O.use_reference_ssw(True):
         kind_ssw = "SSW core = the reference's own ssw.c (SSE2) from oracle/_ref"
-    t = time.time()
     al, cg, ph = O.align_to_database(rl, gl)
-    dt = time.time() - t
+    dt = float(ph[5])          # seconds inside the C call (excludes the ctypes marshalling)
     O.use_reference_ssw(False)
     return {
         "value": round(len(rl) / dt, 1), "unit": "reads/s", "cores": O.num_threads(), "kind": "port",
@@ -178,7 +177,7 @@ def main():
     ap.add_argument("--strains", type=int, default=5)
     ap.add_argument("--genome-len", type=int, default=4_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-pairs", type=int, default=20000)
+    ap.add_argument("--cpu-pairs", type=int, default=300000)
     ap.add_argument("--cpu-genomes", type=int, default=25)
     ap.add_argument("--no-cigar", action="store_true")
     args = ap.parse_args()

@@ -173,7 +173,7 @@ __device__ inline void stage_candidate(const kslam_overlap &o, const SwInputs &i
 }
 
 // result record + band request for banded_sw, ssw.c:924-935 (flag 0x0f: score and distance filters)
-template <int GL = 16>
+template <int GL = 16, int WS = 1>   // WS: the window codes in sw[] are stored multiplied by WS
 __device__ inline void sw_epilogue(kslam_overlap *ov, uint64_t ci, bool have, int32_t t, int32_t L,
                                    const PassResult &f, const uint8_t *sq, const uint8_t *sw, const SwParams &p,
                                    uint32_t *band0) {
@@ -188,7 +188,7 @@ __device__ inline void sw_epilogue(kslam_overlap *ov, uint64_t ci, bool have, in
   if (want && refLen == readLen) {
     for (int32_t k = t; k < readLen; k += GL) {
       const uint32_t q = sq[f.beg_row + k], c = sw[f.beg_col + k];
-      dsum += (q > 3u || c > 3u) ? 0 : (q == c ? p.match : -p.mismatch);
+      dsum += (q > 3u || c > 3u * WS) ? 0 : (q * WS == c ? p.match : -p.mismatch);
     }
   }
 #pragma unroll
@@ -286,56 +286,72 @@ __global__ __launch_bounds__(256) void k_sw_band(kslam_overlap *__restrict__ ov,
     }
     s_tab[grp][i] = tb;
   }
+  for (int32_t j = t; j < W; j += GL) s_w[grp][j] = (uint8_t)(s_w[grp][j] * 6u);   // bfe offset of the column code
   __syncthreads();
   const int32_t gO = p.gap_open << KB, gE = p.gap_extend << KB;
   const int32_t NEG = -((p.gap_open + p.gap_extend + 1) << KB);
   const int32_t d0 = rel < 0 ? rel : 0;          // seed diagonal: read base i sits on window base i + d0
   const int32_t dlo = d0 - ND / 2;
-  int32_t dq[4], Hd[4], Eo[4], Fo[4];
+  // diagonals q = 0, 2 have the parity of dlo, q = 1, 3 the other one; phase A runs at k, phase B
+  // at k + 1; start one pair early when dlo is odd so that anti-diagonal 0 is not skipped
+  const int32_t k0 = (dlo & 1) ? -1 : 0;
+  // Per-diagonal running state, all linear in the loop turn n (cell row i = i0 + n):
+  //   vs/vl: the cell is inside the matrix iff (unsigned)(n - vs) < vl
+  //   Z    : ((j + 1) << 9) | (i + 1) = 513 i + 512 d + 513 for in-matrix cells
+  //   ta/wa: LDS addresses of the cell's score row and (6x pre-scaled) column code
+  int32_t Hd[4], Eo[4], Fo[4], vs[4], Zq[4];
+  uint32_t vl[4];
+  const uint32_t *ta[4];
+  const uint8_t *wa[4];
 #pragma unroll
   for (int q = 0; q < 4; q++) {
-    dq[q] = dlo + 4 * t + q;
-    Hd[q] = dq[q] >= 0 ? (dq[q] << 9) : -dq[q];  // virtual predecessor of the diagonal's first cell
+    const int32_t d = dlo + 4 * t + q;
+    const int32_t i0 = (k0 + (q & 1) - d) >> 1;
+    const int32_t lo = d < 0 ? -d : 0, hi = min(L, W - d);
+    vs[q] = lo - i0;
+    vl[q] = (uint32_t)max(hi - lo, 0);
+    Zq[q] = 513 * i0 + 512 * d + 513;
+    ta[q] = s_tab[grp] + i0;
+    wa[q] = s_w[grp] + (i0 + d);
+    Hd[q] = d >= 0 ? (d << 9) : -d;    // virtual predecessor of the diagonal's first cell
     Eo[q] = NEG;
     Fo[q] = NEG;
   }
   int32_t lbV = 0, lbZ = 0;
-  const int32_t kend = have ? L + W - 2 : -2;
-  const uint32_t *tab = s_tab[grp];
-  const uint8_t *wc = s_w[grp];
-  auto cell = [&](int32_t d, int32_t &H, int32_t Ein, int32_t Fin, int32_t &E, int32_t &F, int32_t k) {
-    const int32_t i = (k - d) >> 1, j = i + d;
-    if ((uint32_t)i < (uint32_t)L && (uint32_t)j < (uint32_t)W) {   // implies k <= L + W - 2
-      const int32_t s = __builtin_amdgcn_sbfe(tab[i], (uint32_t)wc[j] * 6u, 6);
-      const int32_t Z = ((j + 1) << 9) | (i + 1);
-      int32_t h = max(max(H + (s << KB), Ein), Fin);
+  const int32_t nturns = have ? ((L + W - 2 - k0) >> 1) + 1 : 0;
+  auto cell = [&](int q, int32_t n, int32_t Ein, int32_t Fin) {
+    if ((uint32_t)(n - vs[q]) < vl[q]) {
+      const int32_t s = __builtin_amdgcn_sbfe(*ta[q], (uint32_t)*wa[q], 6);
+      const int32_t Z = Zq[q];
+      int32_t h = max(max(Hd[q] + (s << KB), Ein), Fin);
       h = max(h, Z);
-      H = h;
+      Hd[q] = h;
       const int32_t hg = h - gO;
-      E = max(Ein - gE, hg);
-      F = max(Fin - gE, hg);
+      Eo[q] = max(Ein - gE, hg);
+      Fo[q] = max(Fin - gE, hg);
       const bool up = h > (lbV | KEYMASK);
       lbV = up ? h : lbV;
       lbZ = up ? Z : lbZ;
     }
+    Zq[q] += 513;
+    ta[q] += 1;
+    wa[q] += 1;
   };
-  // diagonals q = 0, 2 have the parity of dlo, q = 1, 3 the other one; phase A runs at k, phase B
-  // at k + 1; start one pair early when dlo is odd so that anti-diagonal 0 is not skipped
-  for (int32_t k = (dlo & 1) ? -1 : 0;; k += 2) {
-    if (__ballot(k <= kend) == 0ull) break;
+  for (int32_t n = 0;; n++) {
+    if (__ballot(n < nturns) == 0ull) break;
     {  // phase A: diagonals 0 and 2 of the lane
       const int32_t ein = dpp_row_shr1(Eo[3]);
       const int32_t e0 = t == 0 ? NEG : ein, f0 = Fo[1];
       const int32_t e2 = Eo[1], f2 = Fo[3];
-      cell(dq[0], Hd[0], e0, f0, Eo[0], Fo[0], k);
-      cell(dq[2], Hd[2], e2, f2, Eo[2], Fo[2], k);
+      cell(0, n, e0, f0);
+      cell(2, n, e2, f2);
     }
     {  // phase B: diagonals 1 and 3
       const int32_t fin = __builtin_amdgcn_update_dpp(0, Fo[0], 0x101, 0xF, 0xF, true);  // row_shl:1
       const int32_t e1 = Eo[0], f1 = Fo[2];
       const int32_t e3 = Eo[2], f3 = t == GL - 1 ? NEG : fin;
-      cell(dq[1], Hd[1], e1, f1, Eo[1], Fo[1], k + 1);
-      cell(dq[3], Hd[3], e3, f3, Eo[3], Fo[3], k + 1);
+      cell(1, n, e1, f1);
+      cell(3, n, e3, f3);
     }
   }
   const PassResult f = reduce_best<GL>(lbV, lbZ);
@@ -354,7 +370,7 @@ __global__ __launch_bounds__(256) void k_sw_band(kslam_overlap *__restrict__ ov,
     exact = rlo >= dlo && rhi <= dlo + ND - 1;
   }
   if (have && t == 0) todo[gi] = exact ? 0u : 1u;
-  sw_epilogue<GL>(ov, ci, exact, t, L, f, s_q[grp], s_w[grp], p, band0);
+  sw_epilogue<GL, 6>(ov, ci, exact, t, L, f, s_q[grp], s_w[grp], p, band0);
 }
 
 __global__ void k_scatter_todo(const uint32_t *__restrict__ flags, const uint32_t *__restrict__ pos, uint64_t n,

@@ -137,7 +137,7 @@ def make_reads(dev, gen, db, offs, n_pairs, read_len=READ_LEN, sub_rate=0.01, in
     return out.contiguous()
 
 
-def cpu_baseline(db, offs, seed, n_genomes, n_pairs):
+def cpu_baseline(db, offs, seed, n_genomes, n_pairs, read_len=READ_LEN):
     """The oracle's alignToDatabase timed on the host cores, on a bounded sample of the
     same workload (reported baseline; the oracle is the checker, never the product)."""
     import oracle as O
@@ -146,7 +146,7 @@ def cpu_baseline(db, offs, seed, n_genomes, n_pairs):
     suboffs = offs[:n_genomes + 1]
     gen = torch.Generator(device="cpu")
     gen.manual_seed(seed)
-    reads = make_reads(torch.device("cpu"), gen, sub, suboffs, n_pairs).numpy()
+    reads = make_reads(torch.device("cpu"), gen, sub, suboffs, n_pairs, read_len=read_len).numpy()
     rl = [reads[i].tobytes() for i in range(reads.shape[0])]
     subn = sub.numpy()
     gl = [subn[int(suboffs[i]):int(suboffs[i + 1])].tobytes() for i in range(n_genomes)]
@@ -161,7 +161,7 @@ def cpu_baseline(db, offs, seed, n_genomes, n_pairs):
         "sample": "%d pairs x %d bp vs the first %d database genomes (%.0f Mb); whole reference batch "
                   "path incl. genome k-mer re-extraction and the (reads+genomes) sort, OpenMP; %s; "
                   "%.1f s wall, phases extract/genome/sort/join/sw = %s s" % (
-                      n_pairs, READ_LEN, n_genomes, float(suboffs[-1]) / 1e6, kind_ssw, dt,
+                      n_pairs, read_len, n_genomes, float(suboffs[-1]) / 1e6, kind_ssw, dt,
                       "/".join("%.2f" % x for x in ph[:5])),
         "n_alignments": int(len(al)),
     }
@@ -180,6 +180,7 @@ def main():
     ap.add_argument("--cpu-pairs", type=int, default=300000)
     ap.add_argument("--cpu-genomes", type=int, default=25)
     ap.add_argument("--no-cigar", action="store_true")
+    ap.add_argument("--read-len", type=int, default=READ_LEN, help="150 (BASELINE configs[1..3]) or 250 (configs[4])")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -206,7 +207,7 @@ def main():
     t0 = time.time()
     db, offs = make_database(dev, gen, args.species, args.strains, args.genome_len)
     gen.manual_seed(2 + 1000 * rank)        # reads: a different shard of pairs per rank
-    reads = make_reads(dev, gen, db, offs, args.pairs)
+    reads = make_reads(dev, gen, db, offs, args.pairs, read_len=args.read_len)
     torch.cuda.synchronize()
     t_gen = time.time() - t0
 
@@ -215,7 +216,7 @@ def main():
     ctx.set_index_device(len(offs) - 1, db.data_ptr(), offs)
     t_index = time.time() - t0
     n_reads = reads.shape[0]
-    roffs = (np.arange(n_reads + 1, dtype=np.uint64) * np.uint64(READ_LEN))
+    roffs = (np.arange(n_reads + 1, dtype=np.uint64) * np.uint64(args.read_len))
     ctx.load_reads_device(n_reads, reads.data_ptr(), roffs)
 
     def step():
@@ -268,7 +269,7 @@ def main():
                 traffic = None
         sort_bytes = n_kmers * 16 * (2 * passes + 1)
         out = {
-            "metric": "paired 150bp reads/sec classified (bit-exact SAM)",
+            "metric": "paired %dbp reads/sec classified (bit-exact SAM)" % args.read_len,
             "value": round(total_reads / elapsed, 1),
             "unit": "reads/s",
             "n_gpus": world, "steps": S, "warmup": args.warmup,
@@ -276,10 +277,11 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64 k-mers / i32 DP", "data": "synthetic",
             "config": {
-                "workload": "BASELINE configs[1]: %d x 2 x %d bp reads per GPU vs %d-genome "
+                "workload": "BASELINE configs[%d]: %d x 2 x %d bp reads per GPU vs %d-genome "
                             "(%d species x %d strains x %.1f Mb = %.2f Gb) synthetic bacterial db, "
                             "hot path alignToDatabase incl. CIGAR, inputs resident in HBM" % (
-                                args.pairs, READ_LEN, len(offs) - 1, args.species, args.strains,
+                                4 if args.read_len > 150 else 1, args.pairs, args.read_len, len(offs) - 1,
+                                args.species, args.strains,
                                 args.genome_len / 1e6, float(offs[-1]) / 1e9),
                 "pairs_per_gpu": args.pairs, "db_bases": int(offs[-1]),
                 "parallelism": "read pairs sharded x%d, genome k-mer list replicated, gather to rank 0" % world,
@@ -302,7 +304,7 @@ def main():
             "setup_s": {"generate": round(t_gen, 2), "index_build": round(t_index, 2)},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(db, offs, 77, args.cpu_genomes, args.cpu_pairs)
+            out["cpu_baseline"] = cpu_baseline(db, offs, 77, args.cpu_genomes, args.cpu_pairs, args.read_len)
         print(json.dumps(out), flush=True)
     ctx.close()
     if world > 1:

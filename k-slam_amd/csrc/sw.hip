@@ -248,18 +248,18 @@ __global__ __launch_bounds__(256) void k_sw(kslam_overlap *__restrict__ ov, uint
 // is all the reference's answer depends on (cells fed from outside the band can only come out
 // lower, never higher, so they cannot win a maximum or a tie) -- and the result is exact.
 // Otherwise the candidate is flagged for the full-matrix kernel.
-// Sweep: 16 lanes x 4 adjacent diagonals; on every anti-diagonal step k = i + j a lane computes
-// the two cells of its diagonals with the parity of k.  A cell takes E from diagonal d-1 and F
+// Sweep: GL lanes x DPL adjacent diagonals; on every anti-diagonal step k = i + j a lane computes
+// the DPL / 2 cells of its diagonals with the parity of k.  A cell takes E from diagonal d-1 and F
 // from diagonal d+1 (both from step k-1: own registers, or one DPP row shift at the lane
 // boundary) and its own diagonal's H from step k-2.
 // GL = lanes per candidate: 8 (32 diagonals, 8 candidates per wave) or 16 (64 diagonals, 4 per wave).
 // `list` (optional) maps work items to candidates; todo[] is indexed by work item.
-template <int LMAX, int GL>
+template <int LMAX, int GL, int DPL>
 __global__ __launch_bounds__(256) void k_sw_band(kslam_overlap *__restrict__ ov, uint64_t n, SwInputs in, SwParams p,
                                                  uint32_t *__restrict__ band0, uint32_t *__restrict__ todo,
                                                  const uint32_t *__restrict__ list) {
   constexpr int NG = 256 / GL;          // candidates per block
-  constexpr int ND = 4 * GL;            // diagonals swept
+  constexpr int ND = DPL * GL;          // diagonals swept (DPL adjacent diagonals per lane)
   __shared__ uint8_t s_q[NG][LMAX];
   __shared__ uint8_t s_w[NG][LMAX];
   __shared__ uint32_t s_tab[NG][LMAX];
@@ -299,13 +299,13 @@ __global__ __launch_bounds__(256) void k_sw_band(kslam_overlap *__restrict__ ov,
   //   vs/vl: the cell is inside the matrix iff (unsigned)(n - vs) < vl
   //   Z    : ((j + 1) << 9) | (i + 1) = 513 i + 512 d + 513 for in-matrix cells
   //   ta/wa: LDS addresses of the cell's score row and (6x pre-scaled) column code
-  int32_t Hd[4], Eo[4], Fo[4], vs[4], Zq[4];
-  uint32_t vl[4];
-  const uint32_t *ta[4];
-  const uint8_t *wa[4];
+  int32_t Hd[DPL], Eo[DPL], Fo[DPL], vs[DPL], Zq[DPL];
+  uint32_t vl[DPL];
+  const uint32_t *ta[DPL];
+  const uint8_t *wa[DPL];
 #pragma unroll
-  for (int q = 0; q < 4; q++) {
-    const int32_t d = dlo + 4 * t + q;
+  for (int q = 0; q < DPL; q++) {
+    const int32_t d = dlo + DPL * t + q;
     const int32_t i0 = (k0 + (q & 1) - d) >> 1;
     const int32_t lo = d < 0 ? -d : 0, hi = min(L, W - d);
     vs[q] = lo - i0;
@@ -339,19 +339,27 @@ __global__ __launch_bounds__(256) void k_sw_band(kslam_overlap *__restrict__ ov,
   };
   for (int32_t n = 0;; n++) {
     if (__ballot(n < nturns) == 0ull) break;
-    {  // phase A: diagonals 0 and 2 of the lane
-      const int32_t ein = dpp_row_shr1(Eo[3]);
-      const int32_t e0 = t == 0 ? NEG : ein, f0 = Fo[1];
-      const int32_t e2 = Eo[1], f2 = Fo[3];
-      cell(0, n, e0, f0);
-      cell(2, n, e2, f2);
+    {  // phase A: the lane's even diagonals; E comes from the odd diagonal below, F from the one above
+      const int32_t ein = dpp_row_shr1(Eo[DPL - 1]);
+      int32_t e[DPL / 2], f[DPL / 2];
+#pragma unroll
+      for (int h = 0; h < DPL / 2; h++) {
+        e[h] = h == 0 ? (t == 0 ? NEG : ein) : Eo[2 * h - 1];
+        f[h] = Fo[2 * h + 1];
+      }
+#pragma unroll
+      for (int h = 0; h < DPL / 2; h++) cell(2 * h, n, e[h], f[h]);
     }
-    {  // phase B: diagonals 1 and 3
+    {  // phase B: the odd diagonals
       const int32_t fin = __builtin_amdgcn_update_dpp(0, Fo[0], 0x101, 0xF, 0xF, true);  // row_shl:1
-      const int32_t e1 = Eo[0], f1 = Fo[2];
-      const int32_t e3 = Eo[2], f3 = t == GL - 1 ? NEG : fin;
-      cell(1, n, e1, f1);
-      cell(3, n, e3, f3);
+      int32_t e[DPL / 2], f[DPL / 2];
+#pragma unroll
+      for (int h = 0; h < DPL / 2; h++) {
+        e[h] = Eo[2 * h];
+        f[h] = h == DPL / 2 - 1 ? (t == GL - 1 ? NEG : fin) : Fo[2 * h + 2];
+      }
+#pragma unroll
+      for (int h = 0; h < DPL / 2; h++) cell(2 * h + 1, n, e[h], f[h]);
     }
   }
   const PassResult f = reduce_best<GL>(lbV, lbZ);
@@ -398,22 +406,23 @@ void sw_scores(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, uint32_
     W.list2.ensure(n * sizeof(uint32_t));
     W.scan_tmp.ensure(scan_tmp_bytes(n));
     W.totals.ensure(2 * sizeof(uint64_t));
-    // tier 1: 32 diagonals, 8 lanes per candidate; tier 2: 64 diagonals, 16 lanes; both carry an
-    // exactness certificate, whatever fails it goes on to the next tier
-    for (int tier = 0; tier < 2 && m; tier++) {
+    // tier 1: 32 diagonals (8 lanes x 4), tier 2: 64 (16 x 4), tier 3 (reads > 160 bases): 128
+    // (16 x 8); each carries an exactness certificate, whatever fails it goes on to the next tier
+    const int n_tiers = lm == 0 ? 2 : 3;
+    for (int tier = 0; tier < n_tiers && m; tier++) {
       uint32_t *flags = W.flags.as<uint32_t>();
-      uint32_t *out_list = tier == 0 ? W.list.as<uint32_t>() : W.list2.as<uint32_t>();
+      uint32_t *out_list = (tier & 1) == 0 ? W.list.as<uint32_t>() : W.list2.as<uint32_t>();
+      const unsigned b8 = (unsigned)((m + 31) / 32), b16 = (unsigned)((m + 15) / 16);
+#define KSLAM_BAND(LM, GLV, DPLV, NB) \
+  hipLaunchKernelGGL((k_sw_band<LM, GLV, DPLV>), dim3(NB), dim3(256), 0, s, d_ov, m, in, p, d_band0, flags, list)
       if (tier == 0) {
-        const unsigned blocks = (unsigned)((m + 31) / 32);
-        if (lm == 0) hipLaunchKernelGGL((k_sw_band<160, 8>), dim3(blocks), dim3(256), 0, s, d_ov, m, in, p, d_band0, flags, list);
-        else if (lm == 1) hipLaunchKernelGGL((k_sw_band<256, 8>), dim3(blocks), dim3(256), 0, s, d_ov, m, in, p, d_band0, flags, list);
-        else hipLaunchKernelGGL((k_sw_band<512, 8>), dim3(blocks), dim3(256), 0, s, d_ov, m, in, p, d_band0, flags, list);
+        if (lm == 0) KSLAM_BAND(160, 8, 4, b8); else if (lm == 1) KSLAM_BAND(256, 8, 4, b8); else KSLAM_BAND(512, 8, 4, b8);
+      } else if (tier == 1) {
+        if (lm == 0) KSLAM_BAND(160, 16, 4, b16); else if (lm == 1) KSLAM_BAND(256, 16, 4, b16); else KSLAM_BAND(512, 16, 4, b16);
       } else {
-        const unsigned blocks = (unsigned)((m + 15) / 16);
-        if (lm == 0) hipLaunchKernelGGL((k_sw_band<160, 16>), dim3(blocks), dim3(256), 0, s, d_ov, m, in, p, d_band0, flags, list);
-        else if (lm == 1) hipLaunchKernelGGL((k_sw_band<256, 16>), dim3(blocks), dim3(256), 0, s, d_ov, m, in, p, d_band0, flags, list);
-        else hipLaunchKernelGGL((k_sw_band<512, 16>), dim3(blocks), dim3(256), 0, s, d_ov, m, in, p, d_band0, flags, list);
+        if (lm == 1) KSLAM_BAND(256, 16, 8, b16); else KSLAM_BAND(512, 16, 8, b16);
       }
+#undef KSLAM_BAND
       exclusive_scan_u32(flags, W.pos.as<uint32_t>(), m, W.totals.as<uint64_t>(), W.scan_tmp.p, s);
       uint64_t m2 = 0;
       HIPCHK(hipMemcpyAsync(&m2, W.totals.p, sizeof m2, hipMemcpyDeviceToHost, s));

@@ -157,6 +157,10 @@ void join_count(const uint4 *d_read_recs, uint32_t n_r, GenomeIndexDev g, uint32
 void join_fill(const uint4 *d_read_recs, uint32_t n_r, GenomeIndexDev g, const uint32_t *d_read_len,
                uint32_t read_id_base, const uint64_t *d_block_base, OverlapKeyLayout lay,
                uint64_t *d_out, hipStream_t s);
+// single-pass join: output ranges reserved with one atomic per workgroup; *d_cursor ends as the
+// total number of overlaps; nothing beyond `cap` is written (caller reruns with a larger buffer)
+void join_fill_single_pass(const uint4 *d_read_recs, uint32_t n_r, GenomeIndexDev g, const uint32_t *d_read_len,
+                           uint64_t *d_cursor, uint64_t cap, OverlapKeyLayout lay, uint64_t *d_out, hipStream_t s);
 void dedupe_flags(const uint64_t *d_keys, uint64_t n, OverlapKeyLayout lay, uint32_t *d_flags,
                   hipStream_t s);
 void dedupe_compact(const uint64_t *d_keys, const uint32_t *d_flags, const uint32_t *d_pos,

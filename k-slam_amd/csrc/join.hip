@@ -112,11 +112,18 @@ __device__ inline uint64_t make_overlap(uint32_t rmeta, uint32_t roff, uint32_t 
          (relb << 1) | (uint64_t)(grc != rrc);
 }
 
+// block_base != nullptr: deterministic positions from the count pass.  block_base == nullptr:
+// single-pass mode, the workgroup reserves its output range with one atomic add on cursor[0]
+// and skips its writes when the range would exceed `cap` (the host then reruns with a larger
+// buffer); output ORDER then depends on scheduling, which is harmless because the overlap keys
+// are totally ordered by the sort that follows (equal keys are indistinguishable).
 __global__ __launch_bounds__(JB) void k_join_fill(const uint4 *__restrict__ recs, uint32_t n,
                                                   GenomeIndexDev g, const uint32_t *__restrict__ read_len,
                                                   const uint64_t *__restrict__ block_base,
+                                                  unsigned long long *__restrict__ cursor, uint64_t cap,
                                                   OverlapKeyLayout lay, uint64_t *__restrict__ out) {
   __shared__ uint32_t wsum[JB / 64];
+  __shared__ unsigned long long s_base;
   __shared__ uint32_t bigq_n;
   __shared__ uint4 bigq[BIGQ];       // {rmeta, roff, run.lo, run.cnt}
   __shared__ uint32_t bigq_out[BIGQ];  // block-relative output offset
@@ -147,7 +154,17 @@ __global__ __launch_bounds__(JB) void k_join_fill(const uint4 *__restrict__ recs
   __syncthreads();
   uint32_t ex = inc - mine;
   for (int i = 0; i < w; i++) ex += wsum[i];
-  const uint64_t bb = block_base[blockIdx.x];
+  uint64_t bb;
+  if (block_base) {
+    bb = block_base[blockIdx.x];
+  } else {
+    uint32_t tot = 0;
+    for (int i = 0; i < JB / 64; i++) tot += wsum[i];
+    if (threadIdx.x == 0) s_base = tot ? atomicAdd(cursor, (unsigned long long)tot) : 0ull;
+    __syncthreads();
+    bb = s_base;
+    if (bb + tot > cap) return;   // does not fit: only the cursor matters now (wave-uniform exit)
+  }
 #pragma unroll
   for (int it = 0; it < JI; it++) {
     const uint32_t c = run[it].cnt;
@@ -242,7 +259,17 @@ void join_fill(const uint4 *d_read_recs, uint32_t n_r, GenomeIndexDev g, const u
   if (n_r == 0) return;
   unsigned blocks = (n_r + JOIN_TILE - 1) / JOIN_TILE;
   hipLaunchKernelGGL(k_join_fill, dim3(blocks), dim3(JB), 0, s, d_read_recs, n_r, g, d_read_len, d_block_base,
-                     lay, d_out);
+                     (unsigned long long *)nullptr, (uint64_t)0, lay, d_out);
+  HIPCHK(hipGetLastError());
+}
+
+void join_fill_single_pass(const uint4 *d_read_recs, uint32_t n_r, GenomeIndexDev g, const uint32_t *d_read_len,
+                           uint64_t *d_cursor, uint64_t cap, OverlapKeyLayout lay, uint64_t *d_out, hipStream_t s) {
+  HIPCHK(hipMemsetAsync(d_cursor, 0, sizeof(uint64_t), s));
+  if (n_r == 0) return;
+  unsigned blocks = (n_r + JOIN_TILE - 1) / JOIN_TILE;
+  hipLaunchKernelGGL(k_join_fill, dim3(blocks), dim3(JB), 0, s, d_read_recs, n_r, g, d_read_len,
+                     (const uint64_t *)nullptr, reinterpret_cast<unsigned long long *>(d_cursor), cap, lay, d_out);
   HIPCHK(hipGetLastError());
 }
 

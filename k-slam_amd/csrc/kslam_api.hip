@@ -219,8 +219,9 @@ void build_index(kslam_ctx *c) {
   if (m) hipLaunchKernelGGL(k_split_soa, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, (const uint4 *)sorted,
                             (uint32_t)m, c->gk_key.as<uint64_t>(), c->gk_meta.as<uint32_t>(),
                             c->gk_off.as<uint32_t>());
-  uint32_t bits = 8;
-  while (bits < 24 && (m >> (bits + 3)) != 0) bits++;
+  uint32_t bits = 8, max_bits = 26;   // 26: ~5 genome k-mers per bucket for a 5 Gb database (268 MB table)
+  if (const char *e = getenv("KSLAM_BUCKET_BITS")) max_bits = std::min(28u, std::max(8u, (uint32_t)atoi(e)));
+  while (bits < max_bits && (m >> (bits + 3)) != 0) bits++;
   c->bucket_bits = bits;
   c->g_bucket.ensure(((1ull << bits) + 2) * sizeof(uint32_t));
   build_bucket_table(c->gk_key.as<uint64_t>(), (uint32_t)m, bits, c->g_bucket.as<uint32_t>(), s);
@@ -297,7 +298,7 @@ void align_resident(kslam_ctx *c, bool stop_after_join, uint64_t *n_raw_out) {
   // is re-sorted by (read, entry, rel)).  KSLAM_SORT_BYTES overrides (8 = full 64-bit order).
   std::vector<SortPass> kpasses;
   {
-    uint32_t nbytes = (c->bucket_bits + 7) / 8;
+    uint32_t nbytes = (std::min(c->bucket_bits, 24u) + 7) / 8;
     if (const char *e = getenv("KSLAM_SORT_BYTES")) nbytes = (uint32_t)atoi(e);
     nbytes = std::min(8u, std::max(1u, nbytes));
     for (uint32_t b = 8 - nbytes; b < 8; b++) kpasses.push_back(SortPass{b / 4, 8 * (b % 4), 0});
@@ -346,20 +347,24 @@ void align_resident(kslam_ctx *c, bool stop_after_join, uint64_t *n_raw_out) {
     uint64_t *d_tot = c->totals.as<uint64_t>();
     uint64_t raw = 0;
     if (nk) {
-      join_count(sorted, (uint32_t)nk, g, c->block_tot.as<uint32_t>(), s);
-      exclusive_scan_u32_to_u64(c->block_tot.as<uint32_t>(), c->block_base.as<uint64_t>(), n_tiles, d_tot,
-                                c->scan_tmp.p, s);
-      HIPCHK(hipMemcpyAsync(&raw, d_tot, sizeof raw, hipMemcpyDeviceToHost, s));
-      HIPCHK(hipStreamSynchronize(s));
+      // single-pass join into a buffer sized from the last batch; rerun once if it was too small
+      const uint64_t have_cap = c->ovk_a.cap / sizeof(uint64_t);
+      uint64_t cap = have_cap > nk / 6 + 1024 ? have_cap - 1 : nk / 6 + 1024;   // never grows a big-enough buffer
+      for (int attempt = 0; attempt < 2; attempt++) {
+        c->ovk_a.ensure((cap + 1) * sizeof(uint64_t));
+        join_fill_single_pass(sorted, (uint32_t)nk, g, c->r_len.as<uint32_t>() + r0, d_tot, cap, lay,
+                              c->ovk_a.as<uint64_t>(), s);
+        HIPCHK(hipMemcpyAsync(&raw, d_tot, sizeof raw, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        if (raw <= cap) break;
+        cap = raw + raw / 8;
+      }
     }
     n_raw_total += raw;
     if (raw >= (1ull << 32)) throw StatusError{KSLAM_ERR_UNSUPPORTED, "more than 2^32 raw overlaps in one chunk; lower max_kmers_per_chunk"};
     uint64_t m = 0;
     if (raw) {
-      c->ovk_a.ensure((raw + 1) * sizeof(uint64_t));
       c->ovk_b.ensure((raw + 1) * sizeof(uint64_t));
-      join_fill(sorted, (uint32_t)nk, g, c->r_len.as<uint32_t>() + r0, (uint32_t)r0, c->block_base.as<uint64_t>(),
-                lay, c->ovk_a.as<uint64_t>(), s);
       // ---- a-6: sort by (read, entry, rel[, revcomp]) + unique ----
       const uint32_t key_bits = lay.bits_read + lay.bits_entry + lay.bits_rel + 1;
       std::vector<SortPass> op;

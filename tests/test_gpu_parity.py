@@ -277,3 +277,31 @@ def test_sort_selftest_large(ctx):
     """full-size property: 64 M random records come out ordered (stable) after the 8-pass sort"""
     ms, ms_launch, inv = ctx.selftest_sort(1 << 26, 1)
     assert inv == 0
+
+
+def test_ragged_reads_and_odd_entries(kslam, oracle, synth):
+    """ragged read lengths (incl. < 32 and empty), entries shorter than k, an empty entry"""
+    rng = np.random.default_rng(321)
+    genomes = synth.make_genomes(55, 3, 2, 15000)
+    reads, _ = synth.make_paired_reads(56, genomes, 300, read_len=300, frag_mean=600, indel_rate=0.003)
+    reads = [r[:int(rng.integers(0, 301))] for r in reads]
+    gb = synth.to_bytes(genomes) + [b"ACGT" * 5, b"", b"A" * 40, synth.random_bases(rng, 33).tobytes()]
+    rb = synth.to_bytes(reads)
+    got, gcig = kslam.align_to_database(rb, gb)
+    exp, ecig, _ = oracle.align_to_database(rb, gb)
+    assert len(exp) > 200
+    _compare_alignments(got, gcig, exp, ecig)
+
+
+def test_repeated_genomes_long_runs(kslam, oracle, synth):
+    """collisions: 120 identical entries make every k-mer run 120 long (whole-workgroup expansion
+    path of the join) and every read a 120-way multi-hit"""
+    rng = np.random.default_rng(77)
+    g = synth.random_bases(rng, 4000)
+    genomes = [g.tobytes()] * 120
+    reads, _ = synth.make_paired_reads(78, [g], 60, unmapped_frac=0.0)
+    rb = synth.to_bytes(reads)
+    got, gcig = kslam.align_to_database(rb, genomes)
+    exp, ecig, _ = oracle.align_to_database(rb, genomes)
+    assert len(exp) >= 120 * 100
+    _compare_alignments(got, gcig, exp, ecig)

@@ -193,9 +193,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("KSLAM_BENCH_FORCE_DIST") == "1"   # the override runs the RCCL code path at N=1
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     K = entry.load_package()
@@ -221,7 +223,7 @@ def main():
 
     def step():
         n_out, n_cig = ctx.align_resident()
-        if world > 1:
+        if use_dist:
             ov = torch.empty(n_out * 48, dtype=torch.uint8, device=dev)
             cg = torch.empty(n_cig * 4, dtype=torch.uint8, device=dev)
             ctx.copy_results_device(ov.data_ptr(), cg.data_ptr())
@@ -230,7 +232,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -245,7 +247,7 @@ def main():
             acc[k] = acc.get(k, 0) + v
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
@@ -307,7 +309,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(db, offs, 77, args.cpu_genomes, args.cpu_pairs, args.read_len)
         print(json.dumps(out), flush=True)
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

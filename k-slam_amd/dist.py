@@ -36,29 +36,29 @@ def gather_to_rank0(ov_bytes, cig_bytes, group=None):
     sizes = torch.tensor([ov_bytes.numel(), cig_bytes.numel()], dtype=torch.int64, device=dev)
     all_sizes = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world)]
     dist.all_gather(all_sizes, sizes, group=group)
+    # one batched group of point-to-point operations (ncclGroupStart/End under RCCL), so the seven
+    # peers stream to rank 0 concurrently, each over its own xGMI link
+    ops, parts = [], None
     if rank == 0:
         parts = [(ov_bytes, cig_bytes)]
-        reqs = []
         for r in range(1, world):
             no, nc = int(all_sizes[r][0]), int(all_sizes[r][1])
             o = torch.empty(no, dtype=torch.uint8, device=dev)
             c = torch.empty(nc, dtype=torch.uint8, device=dev)
             if no:
-                reqs.append(dist.irecv(o, src=r, group=group))
+                ops.append(dist.P2POp(dist.irecv, o, r, group))
             if nc:
-                reqs.append(dist.irecv(c, src=r, group=group))
+                ops.append(dist.P2POp(dist.irecv, c, r, group))
             parts.append((o, c))
-        for q in reqs:
+    else:
+        if ov_bytes.numel():
+            ops.append(dist.P2POp(dist.isend, ov_bytes, 0, group))
+        if cig_bytes.numel():
+            ops.append(dist.P2POp(dist.isend, cig_bytes, 0, group))
+    if ops:
+        for q in dist.batch_isend_irecv(ops):
             q.wait()
-        return parts
-    reqs = []
-    if ov_bytes.numel():
-        reqs.append(dist.isend(ov_bytes, dst=0, group=group))
-    if cig_bytes.numel():
-        reqs.append(dist.isend(cig_bytes, dst=0, group=group))
-    for q in reqs:
-        q.wait()
-    return None
+    return parts
 
 
 def reassemble(parts, bounds, n_pairs, overlap_dtype):

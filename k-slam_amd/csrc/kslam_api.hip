@@ -8,6 +8,7 @@
 #include "common.h"
 #include <algorithm>
 #include <new>
+#include <thread>
 
 using namespace kslam;
 
@@ -43,6 +44,10 @@ struct kslam_ctx {
   CigarWork cig;
   SwWork sww;
   DevBuf cells;
+
+  // ---- pinned host staging (host-pointer entry point): reused across batches ----
+  struct Pinned { void *p; size_t cap; bool in_use; };
+  std::vector<Pinned> pinned;
 
   // ---- results of the last align ----
   DevBuf res_ov, res_cig, res_tmp;
@@ -93,6 +98,32 @@ void ensure_keep(DevBuf &b, size_t bytes, size_t used, hipStream_t s) {
   }
   b.release();
   b = nb;
+}
+
+// pinned host buffers from a small per-context pool (pinning is expensive; reuse across batches)
+void *pinned_get(kslam_ctx *c, size_t bytes) {
+  for (auto &b : c->pinned)
+    if (!b.in_use && b.cap >= bytes) { b.in_use = true; return b.p; }
+  for (auto &b : c->pinned)   // replace a free buffer that is too small
+    if (!b.in_use) {
+      (void)hipHostFree(b.p);
+      b.p = nullptr; b.cap = 0;
+      size_t want = bytes + bytes / 4 + 4096;
+      if (hipHostMalloc(&b.p, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); b.p = nullptr; throw StatusError{KSLAM_ERR_OOM, "hipHostMalloc failed"}; }
+      b.cap = want; b.in_use = true;
+      return b.p;
+    }
+  kslam_ctx::Pinned nb{nullptr, 0, true};
+  size_t want = bytes + bytes / 4 + 4096;
+  if (hipHostMalloc(&nb.p, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); throw StatusError{KSLAM_ERR_OOM, "hipHostMalloc failed"}; }
+  nb.cap = want;
+  c->pinned.push_back(nb);
+  return nb.p;
+}
+bool pinned_put(kslam_ctx *c, void *p) {
+  for (auto &b : c->pinned)
+    if (b.p == p) { b.in_use = false; return true; }
+  return false;
 }
 
 __global__ void k_lens(const uint64_t *off, uint64_t n, uint32_t *len) {
@@ -491,6 +522,7 @@ void kslam_destroy(kslam_ctx *c) {
                       &c->cig.scan_tmp, &c->cig.totals, &c->cig.cig_off, &c->cig.tmp, &c->cig.tmp_big,
                       &c->cig.big_pos, &c->cig.scratch, &c->sww.flags, &c->sww.pos, &c->sww.list, &c->sww.list2, &c->sww.scan_tmp, &c->sww.totals, &c->cells, &c->res_ov, &c->res_cig, &c->res_tmp};
     for (DevBuf *b : bufs) b->release();
+    for (auto &b : c->pinned) if (b.p) (void)hipHostFree(b.p);
     for (auto &ev : c->ev) if (ev) (void)hipEventDestroy(ev);
     for (auto &ev : c->evs0) if (ev) (void)hipEventDestroy(ev);
     for (auto &ev : c->evs1) if (ev) (void)hipEventDestroy(ev);
@@ -613,35 +645,49 @@ kslam_status kslam_align_batch(kslam_ctx *c, uint64_t n_reads, const char *const
   if (!c || !out || !n_out || !cigar_pool || !n_cigar) return KSLAM_ERR_ARG;
   *out = nullptr; *cigar_pool = nullptr; *n_out = 0; *n_cigar = 0;
   std::vector<uint64_t> off(n_reads + 1, 0);
-  std::vector<char> cat;
+  char *cat = nullptr;
   kslam_status st = guarded(c, [&] {
     if (n_reads && (!bases || !lens)) throw StatusError{KSLAM_ERR_ARG, "null bases/lens"};
     for (uint64_t i = 0; i < n_reads; i++) off[i + 1] = off[i] + lens[i];
-    cat.resize(off[n_reads] + 1);
-    for (uint64_t i = 0; i < n_reads; i++) memcpy(cat.data() + off[i], bases[i], lens[i]);
+    // gather the reads into one pinned buffer, in parallel (2 M small copies per 1 M pairs)
+    cat = (char *)pinned_get(c, off[n_reads] + 64);
+    unsigned nt = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    if (n_reads < 100000) nt = 1;
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; t++) {
+      const uint64_t lo = n_reads * t / nt, hi = n_reads * (t + 1) / nt;
+      auto work = [=, &off] { for (uint64_t i = lo; i < hi; i++) memcpy(cat + off[i], bases[i], lens[i]); };
+      if (nt == 1) work(); else th.emplace_back(work);
+    }
+    for (auto &x : th) x.join();
   });
-  if (st != KSLAM_OK) return st;
-  st = kslam_load_reads(c, n_reads, cat.data(), off.data());
+  if (st != KSLAM_OK) { if (cat) pinned_put(c, cat); return st; }
+  st = kslam_load_reads(c, n_reads, cat, off.data());
+  pinned_put(c, cat);
   if (st != KSLAM_OK) return st;
   uint64_t no = 0, nc = 0;
   st = kslam_align_resident(c, &no, &nc);
   if (st != KSLAM_OK) return st;
-  kslam_overlap *ho = (kslam_overlap *)malloc((no + 1) * sizeof(kslam_overlap));
-  uint32_t *hc = (uint32_t *)malloc((nc + 1) * sizeof(uint32_t));
-  if (!ho || !hc) {
-    free(ho); free(hc);
-    c->err = "host allocation of the result buffers failed";
-    return KSLAM_ERR_OOM;
+  kslam_overlap *ho = nullptr;
+  uint32_t *hc = nullptr;
+  st = guarded(c, [&] {   // pinned result buffers: D2H at full PCIe rate, reused by the next batch
+    ho = (kslam_overlap *)pinned_get(c, (no + 1) * sizeof(kslam_overlap));
+    hc = (uint32_t *)pinned_get(c, (nc + 1) * sizeof(uint32_t));
+  });
+  if (st == KSLAM_OK) st = kslam_fetch_results(c, ho, hc);
+  if (st != KSLAM_OK) {
+    if (ho) pinned_put(c, ho);
+    if (hc) pinned_put(c, hc);
+    return st;
   }
-  st = kslam_fetch_results(c, ho, hc);
-  if (st != KSLAM_OK) { free(ho); free(hc); return st; }
   *out = ho; *n_out = no; *cigar_pool = hc; *n_cigar = nc;
   return KSLAM_OK;
 }
 
-void kslam_free_batch(kslam_ctx *, kslam_overlap *out, uint32_t *cigar_pool) {
-  free(out);
-  free(cigar_pool);
+void kslam_free_batch(kslam_ctx *c, kslam_overlap *out, uint32_t *cigar_pool) {
+  if (!c) return;
+  if (out && !pinned_put(c, out)) free(out);
+  if (cigar_pool && !pinned_put(c, cigar_pool)) free(cigar_pool);
 }
 void kslam_free(void *p) { free(p); }
 

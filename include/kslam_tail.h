@@ -1,0 +1,199 @@
+/*
+ * kslam_tail.h -- C ABI of the host tail that follows the alignment hot path
+ * (SURVEY.md section 8f row N1): score screen -> read pairing -> insert-size
+ * screen -> score-fraction screen -> pseudo-assembly -> SAM records.
+ *
+ * Same library as kslam.h (k-slam_amd/libkslam_hip.so).  These entry points are
+ * host-only: they never touch the GPU and take the kslam_overlap array +
+ * cigar pool exactly as kslam_align_batch / kslam_fetch_results return them.
+ *
+ * They replace, in the reference (citations into /root/reference/), the body
+ * of metagenomicAnalysis between alignToDatabase and the taxonomy step
+ * (src/SLAM.h:101-133, same steps again in the low-memory loop
+ * src/SLAM.h:209-239):
+ *
+ *   screenOverlapsByScoreThreshold          src/Overlap.h:329-341
+ *   makePair / getPairsFromRead / getPairedOverlaps src/PairedOverlap.h:107-270
+ *   getPerReadOverlaps (paired)             src/PairedOverlap.h:437-470
+ *   getPerReadOverlaps (single end)         src/Overlap.h:303-327
+ *   getDummyAlignmentPairsFromSingleEndReads src/PairedOverlap.h:280-298
+ *   getMaxAllowedInsertSize                 src/PairedOverlap.h:314-360
+ *   screenPairedAlignmentsByInsertSize      src/PairedOverlap.h:396-436
+ *   screenPairedAlignmentsByScore           src/PairedOverlap.h:361-390
+ *   pseudoAssembly                          src/PairedOverlap.h:480-582
+ *   getCigarAndMD / getSAMFromPair          src/SAM.h:101-237, 352-433
+ *   writeSAMOutputPairs / getHeader         src/SAM.h:443-512, 513-531
+ *
+ * Where the reference leaves the result to an unstable parallel sort
+ * (__gnu_parallel::sort on the partial key (pair, entry, rel) in
+ * getPairedOverlaps) this library fixes the order: ties keep the input order
+ * (read ascending, i.e. the R1 overlap before the R2 overlap).  DESIGN.md
+ * section 9 lists every such point.
+ */
+#ifndef KSLAM_TAIL_H_
+#define KSLAM_TAIL_H_
+#include "kslam.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* which stages run after pairing; the reference flow is all of them */
+#define KSLAM_TAIL_INSERT_SCREEN 1u /* getMaxAllowedInsertSize + screen (paired only) */
+#define KSLAM_TAIL_SCORE_SCREEN 2u  /* screenPairedAlignmentsByScore */
+#define KSLAM_TAIL_PSEUDO_ASM 4u    /* pseudoAssembly + second score screen */
+#define KSLAM_TAIL_ALL 7u
+#define KSLAM_TAIL_PAIRING_ONLY 8u /* stop after pairing + grouping (stage-level tests) */
+
+/* The globals the tail reads (src/Globals.h:31-42, set in src/main.cpp:40-97) */
+typedef struct {
+  uint32_t score_threshold;    /* --min-alignment-score      default 0 */
+  uint32_t num_sam_alignments; /* --num-alignments           default 10 */
+  double score_fraction;       /* --score-fraction-threshold default 0.95 */
+  int32_t pseudo_assembly;     /* !--no-pseudo-assembly      default 1 */
+  int32_t sam_xa;              /* --sam-xa                   default 0 */
+  int32_t report_cigar;        /* reportCigar = SAM file requested */
+  int32_t paired;              /* pairedData = R2 file given */
+  uint32_t stages;             /* KSLAM_TAIL_* mask; 0 means KSLAM_TAIL_ALL
+                                  (PSEUDO_ASM still needs pseudo_assembly) */
+  int32_t threads;             /* 0 = one per hardware thread */
+} kslam_tail_params;
+
+/* std::vector<FASTQSequence> (src/FASTQsequence.h:38-50) by columns: item i of
+ * a column is text[off[i] .. off[i+1]).  Paired batches are [R1 block | R2
+ * block], mate of i is i + n_reads/2 (src/FASTQsequence.h:111-123). */
+typedef struct {
+  uint64_t n_reads;
+  const char *bases;
+  const uint64_t *bases_off;
+  const char *quality; /* same lengths as bases (phred+33) */
+  const uint64_t *quality_off;
+  const char *ids; /* sequenceIdentifier, already stripped */
+  const uint64_t *ids_off;
+} kslam_reads_view;
+
+/* The GenbankIndex fields the tail reads (src/GenbankTools.h:136-164): bases,
+ * locusTag, taxonomyID and the gene list (codingSequence start/stop, geneName,
+ * proteinID, product; src/GenbankTools.h:47-100; start/stop are the CDS's
+ * uint32 fields reinterpreted as int, as getGene does, src/GenbankTools.h:170-185), genes in CSR form by entry.
+ * n_genes == 0: all gene pointers may be NULL. */
+typedef struct {
+  uint64_t n_entries;
+  const char *bases;
+  const uint64_t *bases_off;
+  const char *locus_tag;
+  const uint64_t *locus_tag_off;
+  const uint32_t *taxonomy_id;
+  uint64_t n_genes;
+  const uint64_t *gene_first; /* n_entries + 1 */
+  const int32_t *gene_start;
+  const int32_t *gene_stop;
+  const char *gene_name;
+  const uint64_t *gene_name_off; /* n_genes + 1 */
+  const char *protein_id;
+  const uint64_t *protein_id_off;
+  const char *product;
+  const uint64_t *product_off;
+} kslam_index_view;
+
+#define KSLAM_NO_OVERLAP 0xFFFFFFFFu
+
+/* PairedOverlap, src/PairedOverlap.h:32-57; the two Overlap copies become
+ * indices into the caller's kslam_overlap array */
+typedef struct {
+  uint32_t combined_score;
+  uint32_t entry;
+  int32_t ref_start;
+  int32_t ref_end;
+  uint32_t insert_size;
+  uint32_t r1; /* KSLAM_NO_OVERLAP when hasR1 is false */
+  uint32_t r2;
+  uint32_t pad;
+} kslam_paired_overlap;
+
+/* ReadPairAndOverlaps, src/PairedOverlap.h:62-75: alignmentPairs is
+ * pairs[first .. first + count) */
+typedef struct {
+  uint32_t r1_read;
+  uint32_t r2_read;
+  uint64_t first;
+  uint64_t count;
+} kslam_read_pair;
+
+typedef struct {
+  uint64_t n_overlaps_in;
+  uint64_t n_overlaps_screened; /* after the score threshold */
+  uint64_t n_paired_initial;    /* PairedOverlaps out of pairing */
+  uint64_t n_paired_final;
+  uint64_t n_read_pairs;        /* read pairs (or reads) with >= 1 alignment */
+  uint64_t n_insert_sizes;
+  uint32_t max_insert_size;     /* getMaxAllowedInsertSize result */
+  uint32_t threads;
+  double ms_pairing;
+  double ms_insert;
+  double ms_screens;
+  double ms_pseudo;
+  double ms_sam;
+  uint64_t sam_bytes;           /* SAM text produced */
+} kslam_tail_stats;
+
+/* message of the calling thread's last failed kslam_tail_* / kslam_sam_* call */
+const char *kslam_tail_last_error(void);
+
+/* src/SLAM.h:102-128 up to (not including) the SAM writer.  Outputs are malloc'ed,
+ * release with kslam_free.  The overlaps must be in alignToDatabase's order
+ * (read, entry, rel). */
+kslam_status kslam_tail_pairs(const kslam_tail_params *params,
+                              const kslam_reads_view *reads,
+                              const kslam_overlap *overlaps, uint64_t n_overlaps,
+                              kslam_read_pair **read_pairs, uint64_t *n_read_pairs,
+                              kslam_paired_overlap **pairs, uint64_t *n_pairs,
+                              kslam_tail_stats *stats);
+
+/* writeSAMOutputPairs over every read pair, src/SAM.h:443-512 (the text the
+ * reference streams to the SAM file after the header).  Sorts each read pair's
+ * alignment pairs in place, as the reference does. */
+kslam_status kslam_sam_records(const kslam_tail_params *params,
+                               const kslam_reads_view *reads,
+                               const kslam_index_view *index,
+                               const kslam_overlap *overlaps, uint64_t n_overlaps,
+                               const uint32_t *cigar_pool, uint64_t n_cigar,
+                               const kslam_read_pair *read_pairs, uint64_t n_read_pairs,
+                               kslam_paired_overlap *pairs, uint64_t n_pairs,
+                               char **text, uint64_t *text_len, kslam_tail_stats *stats);
+
+/* both of the above in one call: overlaps -> SAM records */
+kslam_status kslam_tail_sam(const kslam_tail_params *params,
+                            const kslam_reads_view *reads,
+                            const kslam_index_view *index,
+                            const kslam_overlap *overlaps, uint64_t n_overlaps,
+                            const uint32_t *cigar_pool, uint64_t n_cigar,
+                            char **text, uint64_t *text_len, kslam_tail_stats *stats);
+
+/* The same with the text handed to a writer instead of one buffer: the drop-in
+ * for the reference's `outFile << entry` stream (src/SAM.h:507-509).  `write` is
+ * called on the calling thread, chunk after chunk in output order, each chunk a
+ * whole number of lines; a non-zero return aborts with KSLAM_ERR_ARG.  The chunks
+ * live in buffers the library keeps between calls, so a steady stream of batches
+ * allocates nothing. */
+typedef int (*kslam_write_fn)(void *user, const char *data, uint64_t len);
+kslam_status kslam_tail_sam_write(const kslam_tail_params *params,
+                                  const kslam_reads_view *reads,
+                                  const kslam_index_view *index,
+                                  const kslam_overlap *overlaps, uint64_t n_overlaps,
+                                  const uint32_t *cigar_pool, uint64_t n_cigar,
+                                  kslam_write_fn write, void *user, kslam_tail_stats *stats);
+
+/* The tail keeps its work buffers (a few hundred bytes per overlap) between
+ * calls; this returns them to the allocator.  Calls are serialised internally:
+ * each one already spreads over all worker threads. */
+void kslam_tail_release_buffers(void);
+
+/* getHeader, src/SAM.h:513-531 */
+kslam_status kslam_sam_header(const kslam_index_view *index, const char *command_line,
+                              char **text, uint64_t *text_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KSLAM_TAIL_H_ */

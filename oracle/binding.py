@@ -50,6 +50,10 @@ def build(force=False):
     if force or not os.path.exists(so) or (
             os.path.getmtime(so) < os.path.getmtime(os.path.join(_HERE, "kslam_oracle.c"))):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
+    elif not os.path.exists(os.path.join(_HERE, "libtail_oracle.so")) or (
+            os.path.getmtime(os.path.join(_HERE, "libtail_oracle.so")) <
+            os.path.getmtime(os.path.join(_HERE, "tail_oracle.cpp"))):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "libtail_oracle.so"])
     elif os.path.isdir("/root/reference/src") and not os.path.exists(
             os.path.join(_HERE, "_ref", "libssw_ref.so")):
         subprocess.check_call(["make", "-C", _HERE, "-s", "ref"])
@@ -320,3 +324,72 @@ def ref_kmer3(s):
 
 def cigar_string(cig):
     return "".join("%d%s" % (int(c) >> 4, "MID"[int(c) & 15]) for c in cig)
+
+
+# ---- host tail (oracle/tail_oracle.cpp): pairing .. SAM, serial restatement ----
+PAIRED_OVERLAP_DT = np.dtype([("combined_score", "<u4"), ("entry", "<u4"), ("ref_start", "<i4"),
+                              ("ref_end", "<i4"), ("insert_size", "<u4"), ("r1", "<u4"),
+                              ("r2", "<u4"), ("pad", "<u4")])
+READ_PAIR_DT = np.dtype([("r1_read", "<u4"), ("r2_read", "<u4"), ("first", "<u8"), ("count", "<u8")])
+_tail = None
+
+
+def tail_lib():
+    global _tail
+    if _tail is None:
+        build()
+        L = C.CDLL(os.path.join(_HERE, "libtail_oracle.so"))
+        vp, u64 = C.c_void_p, C.c_uint64
+        L.orc_tail_pairs.argtypes = [vp, vp, vp, u64, C.POINTER(vp), C.POINTER(u64), C.POINTER(vp),
+                                     C.POINTER(u64), vp]
+        L.orc_tail_sam.argtypes = [vp, vp, vp, vp, u64, vp, u64, C.POINTER(vp), C.POINTER(u64), vp]
+        L.orc_sam_header.argtypes = [vp, C.c_char_p, C.POINTER(vp), C.POINTER(u64)]
+        L.orc_tail_free.argtypes = [vp]
+        _tail = L
+    return _tail
+
+
+def _tail_take(ptr, n, dtype):
+    if n:
+        buf = (C.c_char * (int(n) * dtype.itemsize)).from_address(ptr.value)
+        out = np.frombuffer(buf, dtype=dtype).copy()
+    else:
+        out = np.zeros(0, dtype=dtype)
+    tail_lib().orc_tail_free(ptr)
+    return out
+
+
+def tail_pairs(params, reads_view, overlaps, stats=None):
+    """params / reads_view / stats: the ctypes structures of include/kslam_tail.h
+    (the tests build them with the product's plumbing module).  -> (read_pairs, pairs)"""
+    L = tail_lib()
+    ov = np.ascontiguousarray(overlaps, dtype=ALIGN_DT)
+    rp, pr, nrp, npr = C.c_void_p(), C.c_void_p(), C.c_uint64(), C.c_uint64()
+    rc = L.orc_tail_pairs(C.addressof(params), C.addressof(reads_view), ov.ctypes.data, len(ov),
+                          C.byref(rp), C.byref(nrp), C.byref(pr), C.byref(npr),
+                          C.addressof(stats) if stats is not None else None)
+    assert rc == 0
+    return _tail_take(rp, nrp.value, READ_PAIR_DT), _tail_take(pr, npr.value, PAIRED_OVERLAP_DT)
+
+
+def tail_sam(params, reads_view, index_view, overlaps, cigar_pool, stats=None):
+    L = tail_lib()
+    ov = np.ascontiguousarray(overlaps, dtype=ALIGN_DT)
+    pool = np.ascontiguousarray(cigar_pool, dtype=np.uint32)
+    txt, n = C.c_void_p(), C.c_uint64()
+    rc = L.orc_tail_sam(C.addressof(params), C.addressof(reads_view), C.addressof(index_view),
+                        ov.ctypes.data, len(ov), pool.ctypes.data if len(pool) else None, len(pool),
+                        C.byref(txt), C.byref(n), C.addressof(stats) if stats is not None else None)
+    assert rc == 0
+    out = C.string_at(txt.value, n.value)
+    L.orc_tail_free(txt)
+    return out
+
+
+def sam_header(index_view, command_line=b""):
+    L = tail_lib()
+    txt, n = C.c_void_p(), C.c_uint64()
+    assert L.orc_sam_header(C.addressof(index_view), command_line, C.byref(txt), C.byref(n)) == 0
+    out = C.string_at(txt.value, n.value)
+    L.orc_tail_free(txt)
+    return out

@@ -12,8 +12,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared_symbols():
-    h = open(os.path.join(ROOT, "include", "kslam.h")).read()
+def _declared_symbols(header="kslam.h"):
+    h = open(os.path.join(ROOT, "include", header)).read()
     h = re.sub(r"/\*.*?\*/", "", h, flags=re.S)
     return sorted(set(re.findall(r"\b(kslam_[a-z_0-9]+)\s*\(", h)))
 
@@ -28,6 +28,23 @@ def test_library_exports_every_declared_symbol(kslam):
         assert hasattr(L, name), "missing export " + name
     assert sorted(kslam.EXPORTS) == declared
     assert L.kslam_abi_version() == 1
+
+
+def test_library_exports_every_tail_symbol(kslam):
+    """include/kslam_tail.h (host tail) lives in the same library."""
+    import ctypes
+    import importlib
+    T = importlib.import_module("kslam_amd.tail")
+    L = ctypes.CDLL(kslam.LIB_PATH)
+    declared = _declared_symbols("kslam_tail.h")
+    assert len(declared) == 7
+    for name in declared:
+        assert hasattr(L, name), "missing export " + name
+    assert sorted(T.EXPORTS) == declared
+    # struct sizes the header implies (natural alignment, no packing)
+    assert ctypes.sizeof(T.TailParams) == 40 and ctypes.sizeof(T.ReadsView) == 56
+    assert ctypes.sizeof(T.IndexView) == 128 and ctypes.sizeof(T.TailStats) == 104
+    assert T.PAIRED_OVERLAP_DT.itemsize == 32 and T.READ_PAIR_DT.itemsize == 24
 
 
 def test_struct_layouts(kslam):

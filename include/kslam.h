@@ -153,6 +153,11 @@ kslam_status kslam_align_resident(kslam_ctx *ctx, uint64_t *n_out,
                                   uint64_t *n_cigar);
 kslam_status kslam_fetch_results(kslam_ctx *ctx, kslam_overlap *out,
                                  uint32_t *cigar_pool);
+/* the last results in page-locked host buffers the library owns and reuses
+ * (full PCIe rate, no allocation per batch); hand them back with
+ * kslam_free_batch.  Several batches may be outstanding at once. */
+kslam_status kslam_take_results(kslam_ctx *ctx, kslam_overlap **out, uint64_t *n_out,
+                                uint32_t **cigar_pool, uint64_t *n_cigar);
 /* device-to-device copy of the last results (for a RCCL gather) */
 kslam_status kslam_copy_results_device(kslam_ctx *ctx, void *d_overlaps,
                                        void *d_cigar_pool);

@@ -35,7 +35,7 @@ STATUS = {0: "OK", 1: "ERR_ARG", 2: "ERR_NO_DEVICE", 3: "ERR_OOM", 4: "ERR_UNSUP
 EXPORTS = ["kslam_abi_version", "kslam_create", "kslam_destroy", "kslam_last_error",
            "kslam_set_index", "kslam_set_index_device", "kslam_align_batch", "kslam_free_batch",
            "kslam_load_reads", "kslam_load_reads_device", "kslam_align_resident",
-           "kslam_fetch_results", "kslam_copy_results_device", "kslam_get_timings",
+           "kslam_fetch_results", "kslam_take_results", "kslam_copy_results_device", "kslam_get_timings",
            "kslam_extract_kmers", "kslam_sort_kmers", "kslam_find_overlaps", "kslam_free",
            "kslam_selftest_sort"]
 
@@ -101,6 +101,7 @@ def lib():
         L.kslam_load_reads_device.argtypes = [vp, u64, vp, vp]
         L.kslam_align_resident.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
         L.kslam_fetch_results.argtypes = [vp, vp, vp]
+        L.kslam_take_results.argtypes = [vp, C.POINTER(vp), C.POINTER(u64), C.POINTER(vp), C.POINTER(u64)]
         L.kslam_copy_results_device.argtypes = [vp, vp, vp]
         L.kslam_get_timings.argtypes = [vp, C.POINTER(Timings)]
         L.kslam_extract_kmers.argtypes = [vp, u64, vp, vp, C.c_int, u32, vp, u64, C.POINTER(u64)]
@@ -208,6 +209,20 @@ class Context:
         cg = np.zeros(n_cig, dtype=np.uint32)
         self._chk(self._L.kslam_fetch_results(self._h, ov.ctypes.data, cg.ctypes.data))
         return ov, cg
+
+    def take_results(self):
+        """Last results as numpy views of the library's page-locked buffers (no copy).
+        Returns (overlaps, cigar_pool, release); call release() when done with both arrays."""
+        po, pc, no, nc = C.c_void_p(), C.c_void_p(), C.c_uint64(), C.c_uint64()
+        self._chk(self._L.kslam_take_results(self._h, C.byref(po), C.byref(no), C.byref(pc), C.byref(nc)))
+        ov = np.frombuffer((C.c_char * (no.value * OVERLAP_DT.itemsize)).from_address(po.value),
+                           dtype=OVERLAP_DT) if no.value else np.zeros(0, dtype=OVERLAP_DT)
+        cg = np.frombuffer((C.c_char * (nc.value * 4)).from_address(pc.value),
+                           dtype=np.uint32) if nc.value else np.zeros(0, dtype=np.uint32)
+
+        def release():
+            self._L.kslam_free_batch(self._h, po, pc)
+        return ov, cg, release
 
     def copy_results_device(self, d_overlaps, d_cigars):
         self._chk(self._L.kslam_copy_results_device(self._h, d_overlaps, d_cigars))

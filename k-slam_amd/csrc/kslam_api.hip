@@ -622,6 +622,26 @@ kslam_status kslam_fetch_results(kslam_ctx *c, kslam_overlap *out, uint32_t *cig
   });
 }
 
+kslam_status kslam_take_results(kslam_ctx *c, kslam_overlap **out, uint64_t *n_out, uint32_t **cigar_pool,
+                                uint64_t *n_cigar) {
+  if (!c || !out || !n_out || !cigar_pool || !n_cigar) return KSLAM_ERR_ARG;
+  *out = nullptr; *cigar_pool = nullptr; *n_out = 0; *n_cigar = 0;
+  kslam_overlap *ho = nullptr;
+  uint32_t *hc = nullptr;
+  kslam_status st = guarded(c, [&] {   // pinned: D2H at full PCIe rate, reused by later batches
+    ho = (kslam_overlap *)pinned_get(c, (c->n_res + 1) * sizeof(kslam_overlap));
+    hc = (uint32_t *)pinned_get(c, (c->n_cig + 1) * sizeof(uint32_t));
+  });
+  if (st == KSLAM_OK) st = kslam_fetch_results(c, ho, hc);
+  if (st != KSLAM_OK) {
+    if (ho) pinned_put(c, ho);
+    if (hc) pinned_put(c, hc);
+    return st;
+  }
+  *out = ho; *n_out = c->n_res; *cigar_pool = hc; *n_cigar = c->n_cig;
+  return KSLAM_OK;
+}
+
 kslam_status kslam_copy_results_device(kslam_ctx *c, void *d_overlaps, void *d_cigar_pool) {
   return guarded(c, [&] {
     if (c->n_res && d_overlaps)
@@ -665,23 +685,9 @@ kslam_status kslam_align_batch(kslam_ctx *c, uint64_t n_reads, const char *const
   st = kslam_load_reads(c, n_reads, cat, off.data());
   pinned_put(c, cat);
   if (st != KSLAM_OK) return st;
-  uint64_t no = 0, nc = 0;
-  st = kslam_align_resident(c, &no, &nc);
+  st = kslam_align_resident(c, nullptr, nullptr);
   if (st != KSLAM_OK) return st;
-  kslam_overlap *ho = nullptr;
-  uint32_t *hc = nullptr;
-  st = guarded(c, [&] {   // pinned result buffers: D2H at full PCIe rate, reused by the next batch
-    ho = (kslam_overlap *)pinned_get(c, (no + 1) * sizeof(kslam_overlap));
-    hc = (uint32_t *)pinned_get(c, (nc + 1) * sizeof(uint32_t));
-  });
-  if (st == KSLAM_OK) st = kslam_fetch_results(c, ho, hc);
-  if (st != KSLAM_OK) {
-    if (ho) pinned_put(c, ho);
-    if (hc) pinned_put(c, hc);
-    return st;
-  }
-  *out = ho; *n_out = no; *cigar_pool = hc; *n_cigar = nc;
-  return KSLAM_OK;
+  return kslam_take_results(c, out, n_out, cigar_pool, n_cigar);
 }
 
 void kslam_free_batch(kslam_ctx *c, kslam_overlap *out, uint32_t *cigar_pool) {

@@ -1,0 +1,347 @@
+// fastq.cpp -- FASTQ ingest behind include/kslam_fastq.h.
+//
+// The reference reads a FASTQ stream with a getline loop that builds one object
+// of three std::strings per read (src/FASTQsequence.h:129-165).  Here the bytes
+// of the file are indexed in parallel -- count line terminators per chunk, prefix
+// sum, then every chunk knows the global number of each line it closes, and line
+// i belongs to record i / 4 as field i % 4 -- and the three fields are copied
+// into column arrays (bases / quality / identifiers + offsets), which is what the
+// device upload (kslam_load_reads) and the host tail (kslam_reads_view) consume.
+#include <vector>
+
+#include "../../include/kslam_fastq.h"
+#include "workers.hpp"
+
+namespace {
+using namespace kslam_host;
+
+// A line terminator starts at p: "\r" (alone or followed by "\n"), or "\n" not
+// preceded by "\r" (src/sequenceTools.h:57-64).
+inline bool is_event(const char *t, uint64_t p) {
+  return t[p] == '\r' || (t[p] == '\n' && !(p > 0 && t[p - 1] == '\r'));
+}
+inline uint64_t line_after(const char *t, uint64_t len, uint64_t p) {
+  return (t[p] == '\r' && p + 1 < len && t[p + 1] == '\n') ? p + 2 : p + 1;
+}
+
+struct Field {
+  uint64_t start = 0;
+  uint32_t len = 0;
+};
+
+// Uninitialised storage kept between calls (same reasoning as the column block cache below).
+template <typename T>
+struct Buf {
+  T *p = nullptr;
+  size_t cap = 0;
+  T *ensure(size_t n) {
+    if (n > cap) {
+      size_t want = std::max(n, cap + cap / 2);
+      T *q = (T *)realloc((void *)p, want * sizeof(T));
+      if (!q) fail(KSLAM_ERR_OOM, "out of host memory for the FASTQ line index");
+      p = q;
+      cap = want;
+    }
+    return p;
+  }
+};
+
+struct IndexArena {  // one per stream slot (R1 / R2)
+  Buf<uint64_t> events;
+  Buf<Field> id, bases, qual;
+};
+std::mutex g_parse_call;  // one parse at a time: each spreads over all workers anyway
+IndexArena g_arena[2];
+
+// where the three kept fields of every record of one stream are
+struct StreamIndex {
+  const char *text = nullptr;
+  uint64_t n = 0;         // records taken
+  uint64_t consumed = 0;  // where the reference's stream would stand afterwards
+  Field *id = nullptr, *bases = nullptr, *qual = nullptr;
+};
+
+// FASTQSequence::FASTQSequence, src/FASTQsequence.h:61-71: drop the first
+// character, cut at the first space, then at the first '/'
+inline Field identifier_of(const char *t, uint64_t start, uint64_t len) {
+  Field f;
+  if (len <= 1) return f;
+  const char *h = t + start;
+  uint64_t end = len;
+  if (const void *sp = memchr(h, ' ', len)) {
+    uint64_t space = (const char *)sp - h;
+    // substr(1, space - 1); a space at index 0 gives substr(1, 0) = ""
+    end = space == 0 ? 1 : space;
+  }
+  f.start = start + 1;
+  uint64_t n = end - 1;
+  if (const void *sl = memchr(h + 1, '/', n)) n = (const char *)sl - (h + 1);
+  if (n > 0xFFFFFFFFull) fail(KSLAM_ERR_UNSUPPORTED, "FASTQ header line longer than 4 GiB");
+  f.len = (uint32_t)n;
+  return f;
+}
+
+void index_stream(const char *text, uint64_t len, uint64_t max_reads, bool at_eof, int threads,
+                  IndexArena &A, StreamIndex &ix) {
+  ix.text = text;
+  if (len && !text) fail(KSLAM_ERR_ARG, "null text");
+  // without the rest of the stream a trailing "\r" may or may not be half of "\r\n"
+  uint64_t scan_len = len;
+  if (!at_eof && len && text[len - 1] == '\r') scan_len = len - 1;
+  const uint64_t chunk = 1 << 20;
+  const size_t n_chunks = (size_t)((scan_len + chunk - 1) / chunk);
+  std::vector<uint64_t> count(n_chunks + 1, 0), last_event(n_chunks, UINT64_MAX);
+  // one scan of the text: each chunk lists where its line terminators start, in its own slice of
+  // a shared array (one slot per 8 bytes of text; a chunk with denser terminators than that --
+  // not FASTQ -- spills to a vector of its own)
+  const uint64_t slots = chunk / 8;
+  uint64_t *ev_arena = A.events.ensure(n_chunks * slots + 1);
+  std::vector<std::vector<uint64_t>> spill(n_chunks);
+  Pool::get().tasks(threads, n_chunks, [&](size_t c) {
+    const uint64_t lo = c * chunk, hi = std::min(scan_len, lo + chunk);
+    uint64_t *ev = ev_arena + c * slots, k = 0;
+    std::vector<uint64_t> &extra = spill[c];
+    auto push = [&](uint64_t p) {
+      if (k < slots)
+        ev[k] = p;
+      else
+        extra.push_back(p);
+      k++;
+    };
+    uint64_t p = lo;
+    const uint64_t ones = 0x0101010101010101ull, high = 0x8080808080808080ull;
+    while (p < hi) {
+      // skip 8 bytes at a time while none of them is LF (0x0A) or CR (0x0D)
+      while (p + 8 <= hi) {
+        uint64_t w;
+        memcpy(&w, text + p, 8);
+        const uint64_t a = w ^ (ones * 0x0A), b = w ^ (ones * 0x0D);
+        if ((((a - ones) & ~a) | ((b - ones) & ~b)) & high) break;
+        p += 8;
+      }
+      const uint64_t stop = std::min(hi, p + 8);
+      for (; p < stop; p++)
+        if ((text[p] == '\n' || text[p] == '\r') && is_event(text, p)) push(p);
+    }
+    count[c + 1] = k;
+    last_event[c] = !k ? UINT64_MAX : (k <= slots ? ev[k - 1] : extra.back());
+  });
+  for (size_t c = 0; c < n_chunks; c++) count[c + 1] += count[c];
+  const uint64_t terminated = count[n_chunks];
+  // start of the line each chunk's first event closes
+  std::vector<uint64_t> carry(n_chunks + 1, 0);
+  for (size_t c = 0; c < n_chunks; c++)
+    carry[c + 1] = last_event[c] == UINT64_MAX ? carry[c] : line_after(text, len, last_event[c]);
+  const uint64_t rest_start = carry[n_chunks];  // text after the last terminator
+  // at the true end of the stream the reference reads the unterminated rest (if any) and then
+  // one more, empty, line before the stream fails (src/sequenceTools.h:65-68)
+  const uint64_t rest_lines = at_eof ? (rest_start < len ? 2 : 1) : 0;
+  uint64_t n = (terminated + rest_lines) / 4;
+  if (max_reads && n > max_reads) n = max_reads;
+  ix.n = n;
+  ix.id = A.id.ensure(n + 1);
+  ix.bases = A.bases.ensure(n + 1);
+  ix.qual = A.qual.ensure(n + 1);
+  std::vector<uint64_t> after_quality(1, 0);  // next-line start after the last record's 4th line
+  const uint64_t want_lines = 4 * n;
+  auto store = [&](uint64_t line, uint64_t start, uint64_t end, uint64_t next) {
+    const uint64_t rec = line / 4, flen = end - start;
+    if (flen > 0xFFFFFFFFull) fail(KSLAM_ERR_UNSUPPORTED, "FASTQ line longer than 4 GiB");
+    switch (line % 4) {
+      case 0: ix.id[rec] = identifier_of(text, start, flen); break;
+      case 1: ix.bases[rec] = Field{start, (uint32_t)flen}; break;
+      case 3:
+        ix.qual[rec] = Field{start, (uint32_t)flen};
+        if (rec + 1 == n) after_quality[0] = next;
+        break;
+      default: break;
+    }
+  };
+  Pool::get().tasks(threads, n_chunks, [&](size_t c) {
+    uint64_t line = count[c];
+    uint64_t start = carry[c];
+    const uint64_t k = count[c + 1] - count[c];
+    const uint64_t *ev = ev_arena + c * slots;
+    for (uint64_t j = 0; j < k && line < want_lines; j++) {
+      const uint64_t p = j < slots ? ev[j] : spill[c][j - slots];
+      const uint64_t next = line_after(text, len, p);
+      store(line, start, p, next);
+      start = next;
+      line++;
+    }
+  });
+  // the lines past the last terminator (only ever part of the final record)
+  for (uint64_t line = terminated; line < want_lines; line++) {
+    if (line == terminated && rest_start < len)
+      store(line, rest_start, len, len);
+    else
+      store(line, len, len, len);  // the empty line read at end of stream
+  }
+  // short of max_reads at the true end of the stream, the reference's loop has read on to the end
+  if (at_eof && (!max_reads || n < max_reads))
+    ix.consumed = len;
+  else
+    ix.consumed = n ? after_quality[0] : 0;
+}
+
+// Column arrays are recycled: a batch is a few hundred MB, and faulting that much fresh
+// memory in for every batch costs more than parsing it.  kslam_reads_free parks the
+// blocks here (a handful at most); the next parse takes the ones that are big enough.
+struct BlockCache {
+  struct Block {
+    void *p;
+    size_t cap;
+    bool in_use;
+  };
+  std::mutex m;
+  std::vector<Block> blocks;
+  void *get(size_t bytes) {
+    std::lock_guard<std::mutex> lk(m);
+    size_t best = SIZE_MAX;
+    for (size_t i = 0; i < blocks.size(); i++)
+      if (!blocks[i].in_use && blocks[i].cap >= bytes && (best == SIZE_MAX || blocks[i].cap < blocks[best].cap))
+        best = i;
+    if (best != SIZE_MAX) {
+      blocks[best].in_use = true;
+      return blocks[best].p;
+    }
+    const size_t cap = bytes + bytes / 8 + 64;
+    void *p = malloc(cap);
+    if (!p) fail(KSLAM_ERR_OOM, "out of host memory for the read columns");
+    // replace a parked block that was too small, so the cache does not grow without bound
+    for (auto &b : blocks)
+      if (!b.in_use) {
+        free(b.p);
+        b = Block{p, cap, true};
+        return p;
+      }
+    blocks.push_back(Block{p, cap, true});
+    return p;
+  }
+  void put(void *p) {
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(m);
+    size_t parked = 0;
+    for (auto &b : blocks) parked += !b.in_use;
+    for (size_t i = 0; i < blocks.size(); i++)
+      if (blocks[i].p == p) {
+        if (parked >= 12) {  // two batches' worth of columns is plenty
+          free(p);
+          blocks.erase(blocks.begin() + i);
+        } else
+          blocks[i].in_use = false;
+        return;
+      }
+    free(p);
+  }
+};
+BlockCache &cache() {
+  static BlockCache *c = new BlockCache();
+  return *c;
+}
+
+template <typename T>
+T *alloc(uint64_t n) {
+  return (T *)cache().get(sizeof(T) * (n + 1));
+}
+
+void free_columns(kslam_reads_columns *c) {
+  cache().put(c->bases);
+  cache().put(c->bases_off);
+  cache().put(c->quality);
+  cache().put(c->quality_off);
+  cache().put(c->ids);
+  cache().put(c->ids_off);
+  memset(c, 0, sizeof *c);
+}
+
+// streams[k]'s records become reads [first[k], first[k] + n_k) of the batch
+void emit_columns(const std::vector<const StreamIndex *> &streams, int threads, kslam_reads_columns *out) {
+  uint64_t n = 0;
+  for (auto s : streams) n += s->n;
+  memset(out, 0, sizeof *out);
+  out->n_reads = n;
+  try {
+    out->bases_off = alloc<uint64_t>(n + 1);
+    out->quality_off = alloc<uint64_t>(n + 1);
+    out->ids_off = alloc<uint64_t>(n + 1);
+    uint64_t b = 0, q = 0, i = 0, r = 0;
+    for (auto s : streams)
+      for (uint64_t k = 0; k < s->n; k++, r++) {
+        out->bases_off[r] = b;
+        out->quality_off[r] = q;
+        out->ids_off[r] = i;
+        b += s->bases[k].len;
+        q += s->qual[k].len;
+        i += s->id[k].len;
+      }
+    out->bases_off[n] = b;
+    out->quality_off[n] = q;
+    out->ids_off[n] = i;
+    out->bases = alloc<char>(b + 64);  // slack: the device upload reads whole words
+    out->quality = alloc<char>(q + 1);
+    out->ids = alloc<char>(i + 1);
+    memset(out->bases + b, 0, 64);
+    out->quality[q] = 0;
+    out->ids[i] = 0;
+    uint64_t first = 0;
+    for (auto s : streams) {
+      const uint64_t grain = 8192, n_tasks = (s->n + grain - 1) / grain;
+      Pool::get().tasks(threads, n_tasks, [&](size_t t) {
+        for (uint64_t k = t * grain; k < std::min(s->n, (t + 1) * grain); k++) {
+          const uint64_t rr = first + k;
+          memcpy(out->bases + out->bases_off[rr], s->text + s->bases[k].start, s->bases[k].len);
+          memcpy(out->quality + out->quality_off[rr], s->text + s->qual[k].start, s->qual[k].len);
+          memcpy(out->ids + out->ids_off[rr], s->text + s->id[k].start, s->id[k].len);
+        }
+      });
+      first += s->n;
+    }
+  } catch (...) {
+    free_columns(out);
+    throw;
+  }
+}
+
+int thread_count(int threads) { return std::max(1, std::min(threads > 0 ? threads : usable_cpus(), 512)); }
+
+}  // namespace
+
+extern "C" {
+
+kslam_status kslam_fastq_parse(const char *text, uint64_t len, uint64_t max_reads, int at_eof, int threads,
+                               kslam_reads_columns *out, uint64_t *consumed) {
+  return guarded([&] {
+    if (!out) fail(KSLAM_ERR_ARG, "null output argument");
+    memset(out, 0, sizeof *out);
+    const int nt = thread_count(threads);
+    std::lock_guard<std::mutex> one(g_parse_call);
+    StreamIndex ix;
+    index_stream(text, len, max_reads, at_eof != 0, nt, g_arena[0], ix);
+    emit_columns({&ix}, nt, out);
+    if (consumed) *consumed = ix.consumed;
+  });
+}
+
+kslam_status kslam_fastq_parse_pair(const char *r1, uint64_t len1, const char *r2, uint64_t len2,
+                                    uint64_t max_pairs, int at_eof, int threads, kslam_reads_columns *out,
+                                    uint64_t *consumed1, uint64_t *consumed2) {
+  return guarded([&] {
+    if (!out) fail(KSLAM_ERR_ARG, "null output argument");
+    memset(out, 0, sizeof *out);
+    const int nt = thread_count(threads);
+    std::lock_guard<std::mutex> one(g_parse_call);
+    StreamIndex a, b;
+    index_stream(r1, len1, max_pairs, at_eof != 0, nt, g_arena[0], a);
+    index_stream(r2, len2, max_pairs, at_eof != 0, nt, g_arena[1], b);
+    if (a.n != b.n) fail(KSLAM_ERR_ARG, "mismatch in R1 and R2 size");  // src/FASTQsequence.h:118-122
+    emit_columns({&a, &b}, nt, out);
+    if (consumed1) *consumed1 = a.consumed;
+    if (consumed2) *consumed2 = b.consumed;
+  });
+}
+
+void kslam_reads_free(kslam_reads_columns *cols) {
+  if (cols) free_columns(cols);
+}
+}

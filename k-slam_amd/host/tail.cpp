@@ -33,136 +33,15 @@
 #include <vector>
 
 #include "../../include/kslam_tail.h"
+#include "workers.hpp"
 
 namespace {
 
 typedef kslam_paired_overlap Rec;
 typedef kslam_read_pair Group;
 
-struct TailError {
-  kslam_status code;
-  std::string msg;
-};
-[[noreturn]] void fail(kslam_status c, const std::string &m) { throw TailError{c, m}; }
-
-thread_local std::string g_err;
-
-double now_ms() {
-  return std::chrono::duration<double, std::milli>(
-             std::chrono::steady_clock::now().time_since_epoch())
-      .count();
-}
-
-// ---------------------------------------------------------------- worker pool --
-// Persistent workers, woken per parallel region; the caller is worker 0.
-class Pool {
- public:
-  static Pool &get() {
-    static Pool *p = new Pool();  // never destroyed: workers are detached
-    return *p;
-  }
-  void run(int n, const std::function<void(int)> &f) {
-    if (n <= 1) {
-      f(0);
-      return;
-    }
-    std::lock_guard<std::mutex> region(region_);
-    {
-      std::unique_lock<std::mutex> lk(m_);
-      while ((int)workers_ < n - 1) {
-        int id = workers_++;
-        std::thread([this, id] { loop(id); }).detach();
-      }
-      job_ = &f;
-      want_ = n - 1;
-      active_ = n - 1;
-      failed_ = false;
-      gen_++;
-    }
-    start_.notify_all();
-    try {
-      f(0);
-    } catch (const TailError &e) {
-      note(e);
-    } catch (const std::exception &e) {
-      note(TailError{KSLAM_ERR_INTERNAL, e.what()});
-    }
-    std::unique_lock<std::mutex> lk(m_);
-    done_.wait(lk, [&] { return active_ == 0; });
-    job_ = nullptr;
-    if (failed_) throw error_;
-  }
-  // dynamic schedule of n_tasks over n_threads
-  void tasks(int n_threads, size_t n_tasks, const std::function<void(size_t)> &f) {
-    std::atomic<size_t> next(0);
-    run((int)std::min<size_t>(n_threads, std::max<size_t>(n_tasks, 1)), [&](int) {
-      for (;;) {
-        size_t t = next.fetch_add(1, std::memory_order_relaxed);
-        if (t >= n_tasks) break;
-        f(t);
-      }
-    });
-  }
-
- private:
-  void note(const TailError &e) {
-    std::lock_guard<std::mutex> lk(m_);
-    if (!failed_) {
-      failed_ = true;
-      error_ = e;
-    }
-  }
-  void loop(int id) {
-    uint64_t seen = 0;
-    for (;;) {
-      const std::function<void(int)> *job;
-      {
-        std::unique_lock<std::mutex> lk(m_);
-        start_.wait(lk, [&] { return gen_ != seen; });
-        seen = gen_;
-        if (id >= want_) continue;
-        job = job_;
-      }
-      try {
-        (*job)(id + 1);
-      } catch (const TailError &e) {
-        note(e);
-      } catch (const std::exception &e) {
-        note(TailError{KSLAM_ERR_INTERNAL, e.what()});
-      }
-      std::lock_guard<std::mutex> lk(m_);
-      if (--active_ == 0) done_.notify_one();
-    }
-  }
-  std::mutex region_, m_;
-  std::condition_variable start_, done_;
-  const std::function<void(int)> *job_ = nullptr;
-  uint64_t gen_ = 0;
-  int want_ = 0, active_ = 0;
-  size_t workers_ = 0;
-  bool failed_ = false;
-  TailError error_;
-};
-
-// CPUs this process may actually use: the hardware threads, capped by a cgroup v2
-// CPU quota when there is one (more runnable threads than quota only get throttled)
-int usable_cpus() {
-  static const int n = [] {
-    int hw = (int)std::thread::hardware_concurrency();
-    if (hw < 1) hw = 1;
-    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
-      char quota[32];
-      long period = 0;
-      if (fscanf(f, "%31s %ld", quota, &period) == 2 && period > 0 && strcmp(quota, "max") != 0) {
-        long q = atol(quota);
-        if (q > 0) hw = std::min<long>(hw, std::max<long>(1, (q + period - 1) / period));
-      }
-      fclose(f);
-    }
-    return hw;
-  }();
-  return n;
-}
+using namespace kslam_host;
+typedef HostError TailError;
 
 int thread_count(const kslam_tail_params *p) {
   int n = p->threads > 0 ? p->threads : usable_cpus();
@@ -1428,23 +1307,6 @@ void sam_stage(const SamInput &in, Arena &A, int threads, const Group *groups, s
   buf[at.back()] = 0;
   *sink.text = buf;
   *sink.text_len = at.back();
-}
-
-template <typename F>
-kslam_status guarded(F &&f) {
-  try {
-    f();
-    return KSLAM_OK;
-  } catch (const TailError &e) {
-    g_err = e.msg;
-    return e.code;
-  } catch (const std::bad_alloc &) {
-    g_err = "out of host memory";
-    return KSLAM_ERR_OOM;
-  } catch (const std::exception &e) {
-    g_err = e.what();
-    return KSLAM_ERR_INTERNAL;
-  }
 }
 
 Input make_input(const kslam_tail_params *p, const kslam_reads_view *reads, const kslam_overlap *ov,

@@ -91,6 +91,42 @@ class Reads:
         self.view = ReadsView(n, _p(b), _p(bo), _p(q), _p(qo), _p(i), _p(io))
 
 
+class ReadsArrays(Reads):
+    """The same view over numpy columns that already exist (no per-read Python objects):
+    fixed-length reads as one uint8 array, offsets = arange * read_len."""
+
+    def __init__(self, bases_u8, read_len, quality_u8=None, ids=None):
+        bases_u8 = np.ascontiguousarray(bases_u8, dtype=np.uint8).reshape(-1)
+        n = len(bases_u8) // read_len
+        off = np.arange(n + 1, dtype=np.uint64) * np.uint64(read_len)
+        if quality_u8 is None:
+            quality_u8 = np.full(n * read_len, ord("I"), dtype=np.uint8)
+        quality_u8 = np.ascontiguousarray(quality_u8, dtype=np.uint8).reshape(-1)
+        if ids is None:
+            half = max(n // 2, 1)
+            ids = [b"r%d" % (i % half) for i in range(n)]
+        idc = _column(ids)
+        self._keep = [bases_u8, off, quality_u8, idc]
+        self.view = ReadsView(n, _p(bases_u8), _p(off), _p(quality_u8), _p(off), _p(idc[0]), _p(idc[1]))
+
+
+class IndexArrays:
+    """Index view over one concatenated uint8 genome array + offsets."""
+
+    def __init__(self, bases_u8, offsets, locus_tags=None, taxonomy_ids=None):
+        bases_u8 = np.ascontiguousarray(bases_u8, dtype=np.uint8).reshape(-1)
+        off = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(off) - 1
+        if locus_tags is None:
+            locus_tags = [b"entry%d" % i for i in range(n)]
+        tax = np.zeros(max(n, 1), dtype=np.uint32)
+        if taxonomy_ids is not None:
+            tax[:n] = taxonomy_ids
+        lc = _column(locus_tags)
+        self._keep = [bases_u8, off, lc, tax]
+        self.view = IndexView(n, _p(bases_u8), _p(off), _p(lc[0]), _p(lc[1]), _p(tax))
+
+
 class Index:
     """Column view of the GenbankIndex fields the tail reads.
 
@@ -215,6 +251,18 @@ def tail_sam_write(params, reads, index, overlaps, cigar_pool, sink):
             return 1
 
     cb = WRITE_FN(_cb)
+    _chk(L.kslam_tail_sam_write(C.byref(params), C.byref(reads.view), C.byref(index.view), pov, len(ov),
+                                _p(pool) if len(pool) else None, len(pool), cb, None, C.byref(st)))
+    return st
+
+
+def tail_sam_discard(params, reads, index, overlaps, cigar_pool):
+    """kslam_tail_sam_write with a writer that drops the text (timing runs) -> stats"""
+    L = lib()
+    ov, pov = _ov(overlaps)
+    pool = np.ascontiguousarray(cigar_pool, dtype=np.uint32)
+    st = TailStats()
+    cb = WRITE_FN(lambda user, data, n: 0)
     _chk(L.kslam_tail_sam_write(C.byref(params), C.byref(reads.view), C.byref(index.view), pov, len(ov),
                                 _p(pool) if len(pool) else None, len(pool), cb, None, C.byref(st)))
     return st

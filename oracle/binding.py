@@ -54,8 +54,13 @@ def build(force=False):
             os.path.getmtime(os.path.join(_HERE, "libtail_oracle.so")) <
             os.path.getmtime(os.path.join(_HERE, "tail_oracle.cpp"))):
         subprocess.check_call(["make", "-C", _HERE, "-s", "libtail_oracle.so"])
-    elif os.path.isdir("/root/reference/src") and not os.path.exists(
-            os.path.join(_HERE, "_ref", "libssw_ref.so")):
+    elif not os.path.exists(os.path.join(_HERE, "libfastq_oracle.so")) or (
+            os.path.getmtime(os.path.join(_HERE, "libfastq_oracle.so")) <
+            os.path.getmtime(os.path.join(_HERE, "fastq_oracle.cpp"))):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "libfastq_oracle.so"])
+    elif os.path.isdir("/root/reference/src") and not (
+            os.path.exists(os.path.join(_HERE, "_ref", "libssw_ref.so")) and
+            os.path.exists(os.path.join(_HERE, "_ref", "libfastq_ref.so"))):
         subprocess.check_call(["make", "-C", _HERE, "-s", "ref"])
     return so
 
@@ -99,6 +104,7 @@ def lib():
         L.orc_use_reference_ssw.restype = C.c_int
         L.orc_use_reference_ssw.argtypes = [C.c_char_p]
         L.orc_num_threads.restype = C.c_int
+        L.orc_set_num_threads.argtypes = [C.c_int]
         _lib = L
     return _lib
 
@@ -211,6 +217,23 @@ def align_to_database(reads, entries, params=None, plain=False):
 
 def num_threads():
     return int(lib().orc_num_threads())
+
+
+def usable_cpus():
+    """CPUs this process can really use: os.cpu_count() capped by a cgroup-v2 CPU quota
+    (the GPU boxes run jobs under cpu.max = 16 CPUs of a 256-thread host)."""
+    n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def set_num_threads(n):
+    lib().orc_set_num_threads(int(n))
 
 
 # ---------------------------------------------------------------------------
@@ -393,3 +416,66 @@ def sam_header(index_view, command_line=b""):
     out = C.string_at(txt.value, n.value)
     L.orc_tail_free(txt)
     return out
+
+
+# ---- FASTQ reader (oracle/fastq_oracle.cpp) and the real one (oracle/_ref/libfastq_ref.so) ----
+REF_FASTQ = os.path.join(_HERE, "_ref", "libfastq_ref.so")
+_fq = None
+_fqref = None
+
+
+def _unflatten(n, ptrs, free):
+    out = []
+    for text, off in ptrs:
+        o = np.frombuffer((C.c_char * (8 * (n + 1))).from_address(off.value), dtype=np.uint64).copy()
+        raw = C.string_at(text.value, int(o[n])) if int(o[n]) else b""
+        out.append([raw[int(o[i]):int(o[i + 1])] for i in range(n)])
+        free(text)
+        free(off)
+    return out
+
+
+def fastq_read(text, pos=0, max_reads=0xFFFFFFFF):
+    """One getSequencesFromFASTQFile call on the restated reader, starting at byte `pos`.
+    -> (bases, quality, ids, position of the stream afterwards)"""
+    global _fq
+    if _fq is None:
+        build()
+        L = C.CDLL(os.path.join(_HERE, "libfastq_oracle.so"))
+        vp, u64 = C.c_void_p, C.c_uint64
+        L.orc_fastq_read.argtypes = [C.c_char_p, u64, C.POINTER(u64), C.c_uint32, C.POINTER(u64)] + \
+            [C.POINTER(vp)] * 6
+        L.orc_fastq_free.argtypes = [vp]
+        _fq = L
+    p, n = C.c_uint64(pos), C.c_uint64()
+    v = [C.c_void_p() for _ in range(6)]
+    assert _fq.orc_fastq_read(text, len(text), C.byref(p), max_reads, C.byref(n),
+                              *[C.byref(x) for x in v]) == 0
+    b, q, i = _unflatten(int(n.value), [(v[0], v[1]), (v[2], v[3]), (v[4], v[5])], _fq.orc_fastq_free)
+    return b, q, i, int(p.value)
+
+
+def have_ref_fastq():
+    build()
+    return os.path.exists(REF_FASTQ)
+
+
+def ref_fastq_read(path, per_call=0xFFFFFFFF):
+    """The REAL reference reader on a file, called per_call reads at a time until exhausted.
+    -> (bases, quality, ids, reads returned by each call)"""
+    global _fqref
+    if _fqref is None:
+        L = C.CDLL(REF_FASTQ)
+        vp, u64 = C.c_void_p, C.c_uint64
+        L.ref_fastq_read.argtypes = [C.c_char_p, C.c_uint32, C.POINTER(u64)] + [C.POINTER(vp)] * 6 + \
+            [vp, u64, C.POINTER(u64)]
+        L.ref_fastq_free.argtypes = [vp]
+        _fqref = L
+    n, nc = C.c_uint64(), C.c_uint64()
+    calls = np.zeros(4096, dtype=np.uint64)
+    v = [C.c_void_p() for _ in range(6)]
+    rc = _fqref.ref_fastq_read(path.encode(), per_call, C.byref(n), *[C.byref(x) for x in v],
+                               calls.ctypes.data, len(calls), C.byref(nc))
+    assert rc == 0, "reference reader could not open " + path
+    b, q, i = _unflatten(int(n.value), [(v[0], v[1]), (v[2], v[3]), (v[4], v[5])], _fqref.ref_fastq_free)
+    return b, q, i, [int(x) for x in calls[:int(nc.value)]]

@@ -37,6 +37,14 @@ int orc_num_threads(void) {
 #endif
 }
 
+void orc_set_num_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+
 void orc_free(void *p) { free(p); }
 
 /* ------------------------------------------------------------------------

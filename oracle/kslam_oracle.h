@@ -151,6 +151,7 @@ void orc_free(void *p);
  * (oracle/_ref/libssw_ref.so: ssw_init/ssw_align) for cpu_baseline timing */
 int orc_use_reference_ssw(const char *libpath);
 int orc_num_threads(void);
+void orc_set_num_threads(int n); /* OpenMP team size for the parallel phases */
 
 #ifdef __cplusplus
 }

@@ -115,5 +115,43 @@ def main():
     print("fixtures written:", sorted(f for f in os.listdir(HERE) if f.endswith((".npz", ".json"))))
 
 
+def make_fastq_cases():
+    """Inputs + the records the reference's own reader (oracle/_ref/libfastq_ref.so, built from
+    src/FASTQsequence.h where it lies) returns for them -> tests/golden/fastq_cases.json."""
+    import base64
+    import tempfile
+    import numpy as np
+    import oracle as O
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_fastq import make_text
+    assert O.have_ref_fastq(), "needs /root/reference (make -C oracle ref)"
+    named = [
+        ("plain", b"@r1\nACGT\n+\nIIII\n@r2\nGG\n+\nII\n"),
+        ("crlf and lone cr", b"@r1 d/1\r\nACGT\r\n+\r\nIIII\r@r2/2\rAC\r+\rII\r"),
+        ("no final newline", b"@r1\nACGT\n+\nIIII"),
+        ("missing quality line", b"@r1\nACGT\n+\n"),
+        ("identifier rules", b"@ x\nA\n+\nI\n@\nC\n+\nI\n\nG\n+\nI\n@a/b/c d/e\nT\n+\nI\n@/lead\nA\n+\nI\n"),
+        ("blank lines inside", b"@r1\n\n+\n\n@r2\nAC\n+\nII\n\n\n"),
+        ("truncated record", b"@r1\nACGT\n+\nIIII\n@r2\nAC\n"),
+        ("empty", b""),
+    ]
+    rng = np.random.default_rng(2024)
+    for k in range(6):
+        named.append(("random %d" % k, make_text(rng, 25, truncate=k % 2 == 1, blank_tail=k % 3)))
+    cases = []
+    with tempfile.TemporaryDirectory() as d:
+        for name, text in named:
+            path = os.path.join(d, "c.fq")
+            open(path, "wb").write(text)
+            b, q, i, _ = O.ref_fastq_read(path)
+            cases.append({"name": name, "text_b64": base64.b64encode(text).decode(),
+                          "records": [[base64.b64encode(x).decode() for x in r] for r in zip(i, b, q)]})
+    json.dump({"source": "reference src/FASTQsequence.h getSequencesFromFASTQFile via oracle/ref_fastq_driver.cpp",
+               "cases": cases}, open(os.path.join(HERE, "fastq_cases.json"), "w"), indent=0)
+    print("fastq_cases.json:", len(cases), "cases")
+
+
 if __name__ == "__main__":
-    main()
+    if "--fastq" not in sys.argv:      # --fastq: only (re)write fastq_cases.json
+        main()
+    make_fastq_cases()

@@ -131,6 +131,28 @@ def test_align_chunked_equals_unchunked(kslam, synth):
     _compare_alignments(a, ac, b, bc)
 
 
+def test_resident_path_and_page_locked_results(kslam, synth):
+    """load_reads -> align_resident -> take_results (library-owned page-locked buffers, two batches
+    outstanding at once) gives what the one-call host-pointer entry point gives."""
+    reads, genomes, _ = _dataset(synth, 6, 500)
+    exp, ecig = kslam.align_to_database(reads, genomes)
+    c = kslam.Context()
+    c.set_index(genomes)
+    c.load_reads(reads)
+    n_out, n_cig = c.align_resident()
+    a, ac, rel_a = c.take_results()
+    c.align_resident()
+    b, bc, rel_b = c.take_results()          # first batch still held
+    assert a.ctypes.data != b.ctypes.data and len(a) == n_out and len(ac) == n_cig
+    _compare_alignments(a, ac, exp, ecig)
+    _compare_alignments(b, bc, exp, ecig)
+    f, fc = c.fetch_results(n_out, n_cig)
+    _compare_alignments(f, fc, exp, ecig)
+    rel_a()
+    rel_b()
+    c.close()
+
+
 def test_empty_batch(kslam, synth):
     _, genomes, _ = _dataset(synth, 5, 1)
     ov, cg = kslam.align_to_database([], genomes)

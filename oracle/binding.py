@@ -45,24 +45,23 @@ class SswResult(C.Structure):
 
 
 def build(force=False):
-    """Compile liboracle.so (and oracle/_ref when /root/reference exists)."""
+    """Compile the checker libraries (and oracle/_ref when /root/reference exists).  make decides
+    what is out of date; on a box without the sources the prebuilt files are used as they are."""
     so = os.path.join(_HERE, "liboracle.so")
-    if force or not os.path.exists(so) or (
-            os.path.getmtime(so) < os.path.getmtime(os.path.join(_HERE, "kslam_oracle.c"))):
+    have_all = all(os.path.exists(os.path.join(_HERE, f))
+                   for f in ("liboracle.so", "libtail_oracle.so", "libfastq_oracle.so"))
+    if force:
+        subprocess.check_call(["make", "-C", _HERE, "-s", "clean"])
+    if force or not have_all or os.path.isdir("/root/reference/src") or _stale():
         subprocess.check_call(["make", "-C", _HERE, "-s"])
-    elif not os.path.exists(os.path.join(_HERE, "libtail_oracle.so")) or (
-            os.path.getmtime(os.path.join(_HERE, "libtail_oracle.so")) <
-            os.path.getmtime(os.path.join(_HERE, "tail_oracle.cpp"))):
-        subprocess.check_call(["make", "-C", _HERE, "-s", "libtail_oracle.so"])
-    elif not os.path.exists(os.path.join(_HERE, "libfastq_oracle.so")) or (
-            os.path.getmtime(os.path.join(_HERE, "libfastq_oracle.so")) <
-            os.path.getmtime(os.path.join(_HERE, "fastq_oracle.cpp"))):
-        subprocess.check_call(["make", "-C", _HERE, "-s", "libfastq_oracle.so"])
-    elif os.path.isdir("/root/reference/src") and not (
-            os.path.exists(os.path.join(_HERE, "_ref", "libssw_ref.so")) and
-            os.path.exists(os.path.join(_HERE, "_ref", "libfastq_ref.so"))):
-        subprocess.check_call(["make", "-C", _HERE, "-s", "ref"])
     return so
+
+
+def _stale():
+    pairs = [("liboracle.so", "kslam_oracle.c"), ("libtail_oracle.so", "tail_oracle.cpp"),
+             ("libfastq_oracle.so", "fastq_oracle.cpp")]
+    return any(os.path.getmtime(os.path.join(_HERE, a)) < os.path.getmtime(os.path.join(_HERE, b))
+               for a, b in pairs)
 
 
 _lib = None

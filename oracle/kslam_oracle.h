@@ -26,6 +26,12 @@
  *   the window/flip driver (orc_sw_on_overlap) and the ssw_cpp wrapper
  *   (orc_align) are line-by-line restatements checked only against the
  *   reference's own structural test expectations (src/Tests.h:161-330).
+ *
+ * Two more checkers live beside this one, each with its own status header:
+ *   fastq_oracle.cpp  FASTQ reader (src/FASTQsequence.h) -- PINNED by the real
+ *                     reference (ref_fastq_driver.cpp -> _ref/libfastq_ref.so)
+ *   tail_oracle.cpp   pairing .. SAM (src/PairedOverlap.h, src/SAM.h) -- PARITY
+ *                     UNPINNED (Boost), pinned by the SAM definition instead
  */
 #ifndef KSLAM_ORACLE_H_
 #define KSLAM_ORACLE_H_

@@ -1,0 +1,83 @@
+/*
+ * kslam_taxonomy.h -- C ABI of the taxonomy stage after the host tail (the
+ * "per-read LCA" part of SURVEY.md section 8f row N1).  Same library as
+ * kslam.h; host-only.
+ *
+ * Replaces, in the reference (citations into /root/reference/):
+ *
+ *   TaxonomyDB(file) / readTaxonomyIndex     src/TaxonomyDatabase.h:87-93, 166-183
+ *   getLowestCommonAncestor / getParentTaxID src/TaxonomyDatabase.h:185-231
+ *   getScientificName / getRank / getLineage src/TaxonomyDatabase.h:233-265
+ *   getTaxIDAtRank / isBelowInTree / isSubSpecies
+ *                                            src/TaxonomyDatabase.h:306-349
+ *   getResultFromPairedOverlaps (taxonomy id + read name; the gene list is not
+ *   carried)                                 src/MetagenomicResults.h:88-112
+ *   convertAlignmentsToIdentifiedTaxonomies_parallel
+ *                                            src/MetagenomicResults.h:182-197
+ *   writePerReadResults                      src/MetagenomicResults.h:455-463
+ *   combineTaxonomies + sortResults + writeAbbreviatedResultsFile (read counts
+ *   per taxon)                               src/MetagenomicResults.h:149-177, 237-274
+ *
+ * Not replaced: the XML report (writeResults / getXML, src/MetagenomicResults.h:
+ * 213-224, 302-366), which lists every gene hit with fields the database builder
+ * stores (locus tag, GeneID, reference sequence) -- see DESIGN.md section 7.
+ *
+ * The reference walks hash-map lookups up the tree and compares root-ward paths
+ * level by level; here the tree is a dense parent/depth array and the LCA of a
+ * set is a fold of pairwise depth-aligned walks -- same answers, including the
+ * reference's conventions: a path stops below the root (a parent id of 1 ends
+ * it), so taxa under different top-level nodes have LCA 0; an id of 0, or ids
+ * the tree does not know next to other ids, give 0.
+ */
+#ifndef KSLAM_TAXONOMY_H_
+#define KSLAM_TAXONOMY_H_
+#include "kslam_tail.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct kslam_taxdb kslam_taxdb;
+
+/* The <db>/taxDB text: four lines per node -- taxonomy id, parent id, scientific
+ * name, rank (writeTaxonomyIndex, src/TaxonomyDatabase.h:153-165).  A repeated id
+ * keeps its first record, as the reference's map insert does.  Errors (message
+ * in kslam_tail_last_error()): a line count that is not a multiple of four or an
+ * id line that is not a number (the reference throws from std::stoi), a cycle in
+ * the parent links (the reference would not terminate). */
+kslam_status kslam_taxdb_parse(const char *text, uint64_t len, kslam_taxdb **out);
+void kslam_taxdb_free(kslam_taxdb *db);
+uint64_t kslam_taxdb_size(const kslam_taxdb *db);
+
+uint32_t kslam_taxdb_lca(const kslam_taxdb *db, const uint32_t *tax_ids, uint64_t n);
+uint32_t kslam_taxdb_parent(const kslam_taxdb *db, uint32_t tax_id);
+uint32_t kslam_taxdb_at_rank(const kslam_taxdb *db, uint32_t tax_id, const char *rank);
+int32_t kslam_taxdb_is_below(const kslam_taxdb *db, uint32_t upper, uint32_t lower);
+int32_t kslam_taxdb_is_subspecies(const kslam_taxdb *db, uint32_t tax_id);
+/* text is malloc'ed (kslam_free); which: 0 scientific name, 1 rank, 2 lineage */
+kslam_status kslam_taxdb_text(const kslam_taxdb *db, uint32_t tax_id, int which, char **text,
+                              uint64_t *text_len);
+
+/* One batch: the taxonomy id of every read pair that kslam_tail_pairs returned
+ * (LCA over the entries of its alignment pairs) into tax_ids[n_read_pairs], and
+ * the per-read lines "identifier \t taxonomy id \n" the reference writes to
+ * <out>_PerRead (malloc'ed, kslam_free; may be NULL to skip). */
+kslam_status kslam_tail_classify(const kslam_tail_params *params, const kslam_reads_view *reads,
+                                 const kslam_index_view *index, const kslam_taxdb *db,
+                                 const kslam_read_pair *read_pairs, uint64_t n_read_pairs,
+                                 const kslam_paired_overlap *pairs, uint64_t n_pairs,
+                                 uint32_t *tax_ids, char **per_read_text, uint64_t *per_read_len);
+
+/* End of run: the taxonomy ids of all classified read pairs, in order, to the
+ * "<name> \t <percent of num_reads>" lines of <out>_abbreviated.  Keeps the
+ * reference's bookkeeping quirk (src/MetagenomicResults.h:159-175): when no read
+ * pair is unclassified (id 0), the first record of the lowest id is dropped.
+ * The reference orders equal ids with an unstable parallel sort; input order is
+ * kept here (it only matters for which record that quirk drops). */
+kslam_status kslam_taxonomy_summary(const kslam_taxdb *db, const uint32_t *tax_ids, uint64_t n,
+                                    uint64_t num_reads, char **text, uint64_t *text_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KSLAM_TAXONOMY_H_ */

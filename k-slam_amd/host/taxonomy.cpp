@@ -1,0 +1,339 @@
+// taxonomy.cpp -- the taxonomy stage behind include/kslam_taxonomy.h (per-read LCA of SURVEY.md
+// section 8f row N1).
+//
+// The reference keeps the NCBI tree in an unordered_map<taxid, entry> and answers every query by
+// chains of hash lookups (src/TaxonomyDatabase.h); its LCA builds one root-ward path vector per
+// input id and compares them level by level.  Here the tree is dense: nodes numbered in file
+// order, a parent-index and a depth array, and the LCA of a set is a fold of pairwise walks that
+// first level the depths.  The conventions that make the answers equal are in the header.
+#include <cmath>
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/kslam_taxonomy.h"
+#include "workers.hpp"
+
+struct kslam_taxdb {
+  static constexpr uint32_t NONE = 0xFFFFFFFFu;
+  std::unordered_map<uint32_t, uint32_t> node_of;  // taxonomy id -> node
+  std::vector<uint32_t> tax_id, parent_id;         // as in the file
+  std::vector<uint32_t> up;                        // node of getParentTaxID(), NONE when that is 0
+  std::vector<uint32_t> depth;                     // nodes on the path up to the top-level node
+  std::vector<std::string> name, rank;
+  uint64_t n_real = 0;  // nodes read from the file; nodes past this stand for parent ids the file
+                        // mentions but never defines (the reference still puts them on paths)
+  uint32_t node(uint32_t id) const {
+    auto it = node_of.find(id);
+    return it == node_of.end() ? NONE : it->second;
+  }
+  bool known(uint32_t id) const {
+    uint32_t n = node(id);
+    return n != NONE && n < n_real;
+  }
+  // getParentTaxID, src/TaxonomyDatabase.h:225-231
+  uint32_t parent_tax(uint32_t id) const {
+    uint32_t n = node(id);
+    if (n != NONE && n < n_real && parent_id[n] != 1) return parent_id[n];
+    return 0;
+  }
+};
+
+namespace {
+using namespace kslam_host;
+
+bool to_number(const char *s, size_t n, uint32_t *out) {
+  // std::stoi: optional whitespace, optional sign, digits; trailing text ignored
+  size_t i = 0;
+  while (i < n && (s[i] == ' ' || s[i] == '\t' || s[i] == '\r' || s[i] == '\v' || s[i] == '\f')) i++;
+  bool neg = false;
+  if (i < n && (s[i] == '+' || s[i] == '-')) neg = s[i++] == '-';
+  if (i >= n || s[i] < '0' || s[i] > '9') return false;
+  int64_t v = 0;
+  for (; i < n && s[i] >= '0' && s[i] <= '9'; i++) {
+    v = v * 10 + (s[i] - '0');
+    if (v > 2147483648ll) return false;  // std::out_of_range in the reference
+  }
+  if (neg) v = -v;
+  if (v > 2147483647ll) return false;
+  *out = (uint32_t)(int32_t)v;
+  return true;
+}
+
+uint32_t lca_nodes(const kslam_taxdb &db, uint32_t a, uint32_t b) {
+  while (db.depth[a] > db.depth[b]) a = db.up[a];
+  while (db.depth[b] > db.depth[a]) b = db.up[b];
+  while (a != b) {
+    a = db.up[a];
+    b = db.up[b];
+    if (a == kslam_taxdb::NONE || b == kslam_taxdb::NONE) return kslam_taxdb::NONE;
+  }
+  return a;
+}
+
+// getLowestCommonAncestor, src/TaxonomyDatabase.h:185-223
+uint32_t lca_ids(const kslam_taxdb &db, const uint32_t *ids, uint64_t n) {
+  if (n == 0) return 0;
+  uint32_t acc = kslam_taxdb::NONE;
+  uint32_t lone = 0;  // an id the tree does not know: a path of just itself
+  bool have_lone = false;
+  for (uint64_t i = 0; i < n; i++) {
+    const uint32_t id = ids[i];
+    if (id == 0) return 0;  // empty path: nothing in common
+    const uint32_t nd = db.node(id);
+    if (nd == kslam_taxdb::NONE) {
+      if (acc != kslam_taxdb::NONE || (have_lone && lone != id)) return 0;
+      lone = id;
+      have_lone = true;
+      continue;
+    }
+    if (have_lone) return 0;
+    acc = acc == kslam_taxdb::NONE ? nd : lca_nodes(db, acc, nd);
+    if (acc == kslam_taxdb::NONE) return 0;
+  }
+  return have_lone ? lone : db.tax_id[acc];
+}
+
+std::string lineage_of(const kslam_taxdb &db, uint32_t id) {  // src/TaxonomyDatabase.h:249-265
+  std::string lineage;
+  for (;;) {
+    if (id != 131567) {
+      if (!lineage.empty()) lineage.insert(0, "; ");
+      if (db.known(id)) lineage.insert(0, db.name[db.node(id)]);
+      if (db.known(id) && db.rank[db.node(id)] == "species") lineage.clear();
+    }
+    id = db.parent_tax(id);
+    if (id == 0) {
+      if (!lineage.empty()) lineage.append(".");
+      break;
+    }
+  }
+  return lineage;
+}
+
+char *dup_text(const std::string &s, uint64_t *len) {
+  char *p = (char *)malloc(s.size() + 1);
+  if (!p) fail(KSLAM_ERR_OOM, "out of host memory");
+  memcpy(p, s.data(), s.size());
+  p[s.size()] = 0;
+  *len = s.size();
+  return p;
+}
+
+}  // namespace
+
+extern "C" {
+
+kslam_status kslam_taxdb_parse(const char *text, uint64_t len, kslam_taxdb **out) {
+  return guarded([&] {
+    if (!out || (len && !text)) fail(KSLAM_ERR_ARG, "null argument");
+    *out = nullptr;
+    std::unique_ptr<kslam_taxdb> db(new kslam_taxdb());
+    // std::getline lines: '\n' only; a final line without '\n' still counts
+    std::vector<std::pair<uint64_t, uint64_t>> lines;
+    for (uint64_t p = 0; p < len;) {
+      const void *nl = memchr(text + p, '\n', len - p);
+      uint64_t e = nl ? (uint64_t)((const char *)nl - text) : len;
+      lines.push_back({p, e - p});
+      p = e + 1;
+    }
+    if (lines.size() % 4) fail(KSLAM_ERR_ARG, "taxonomy index: line count is not a multiple of four");
+    for (size_t i = 0; i < lines.size(); i += 4) {
+      uint32_t id, parent;
+      if (!to_number(text + lines[i].first, lines[i].second, &id) ||
+          !to_number(text + lines[i + 1].first, lines[i + 1].second, &parent))
+        fail(KSLAM_ERR_ARG, "taxonomy index: id line " + std::to_string(i + 1) + " is not a number");
+      if (db->node_of.count(id)) continue;  // map::insert keeps the first
+      db->node_of[id] = (uint32_t)db->tax_id.size();
+      db->tax_id.push_back(id);
+      db->parent_id.push_back(parent);
+      db->name.emplace_back(text + lines[i + 2].first, lines[i + 2].second);
+      db->rank.emplace_back(text + lines[i + 3].first, lines[i + 3].second);
+    }
+    db->n_real = db->tax_id.size();
+    // parents the file never defines still appear on the reference's paths
+    for (uint64_t n = 0; n < db->n_real; n++) {
+      const uint32_t p = db->parent_id[n];
+      if (p != 1 && p != 0 && !db->node_of.count(p)) {
+        db->node_of[p] = (uint32_t)db->tax_id.size();
+        db->tax_id.push_back(p);
+        db->parent_id.push_back(1);
+        db->name.emplace_back();
+        db->rank.emplace_back();
+      }
+    }
+    const size_t N = db->tax_id.size();
+    db->up.assign(N, kslam_taxdb::NONE);
+    for (size_t n = 0; n < N; n++) {
+      const uint32_t p = n < db->n_real ? db->parent_id[n] : 1;
+      if (p != 1 && p != 0) db->up[n] = db->node_of[p];
+    }
+    // depths, and a cycle check, by walking up with path marking
+    db->depth.assign(N, 0);
+    std::vector<uint32_t> stack;
+    std::vector<uint8_t> on_path(N, 0);
+    for (size_t n = 0; n < N; n++) {
+      if (db->depth[n]) continue;
+      stack.clear();
+      uint32_t v = (uint32_t)n;
+      while (v != kslam_taxdb::NONE && !db->depth[v]) {
+        if (on_path[v]) fail(KSLAM_ERR_ARG, "taxonomy index: the parent links contain a cycle");
+        on_path[v] = 1;
+        stack.push_back(v);
+        v = db->up[v];
+      }
+      uint32_t d = v == kslam_taxdb::NONE ? 0 : db->depth[v];
+      for (size_t k = stack.size(); k-- > 0;) {
+        db->depth[stack[k]] = ++d;
+        on_path[stack[k]] = 0;
+      }
+    }
+    *out = db.release();
+  });
+}
+
+void kslam_taxdb_free(kslam_taxdb *db) { delete db; }
+uint64_t kslam_taxdb_size(const kslam_taxdb *db) { return db ? db->n_real : 0; }
+
+uint32_t kslam_taxdb_lca(const kslam_taxdb *db, const uint32_t *tax_ids, uint64_t n) {
+  if (!db || (!tax_ids && n)) return 0;
+  return lca_ids(*db, tax_ids, n);
+}
+
+uint32_t kslam_taxdb_parent(const kslam_taxdb *db, uint32_t tax_id) { return db ? db->parent_tax(tax_id) : 0; }
+
+// getTaxIDAtRank, src/TaxonomyDatabase.h:306-317
+uint32_t kslam_taxdb_at_rank(const kslam_taxdb *db, uint32_t tax_id, const char *rank) {
+  if (!db || !rank) return 0;
+  uint32_t n = db->node(tax_id);
+  while (n != kslam_taxdb::NONE && n < db->n_real && db->parent_id[n] != 1) {
+    if (db->rank[n] == rank) return db->tax_id[n];
+    n = db->node(db->parent_id[n]);
+  }
+  return 0;
+}
+
+// isBelowInTree, src/TaxonomyDatabase.h:318-331
+int32_t kslam_taxdb_is_below(const kslam_taxdb *db, uint32_t upper, uint32_t lower) {
+  if (!db) return -1;
+  uint32_t n = db->node(lower);
+  unsigned level = 0;
+  while (n != kslam_taxdb::NONE && n < db->n_real && db->parent_id[n] != 1) {
+    if (db->tax_id[n] == upper) return (int32_t)level;
+    n = db->node(db->parent_id[n]);
+    level++;
+  }
+  return -1;
+}
+
+// isSubSpecies, src/TaxonomyDatabase.h:332-349
+int32_t kslam_taxdb_is_subspecies(const kslam_taxdb *db, uint32_t tax_id) {
+  if (!db) return 0;
+  uint32_t n = db->node(tax_id);
+  int levels = 0;
+  while (n != kslam_taxdb::NONE && n < db->n_real && db->parent_id[n] != 1) {
+    if (db->rank[n] == "species") return levels > 0;
+    n = db->node(db->parent_id[n]);
+    levels++;
+  }
+  return 0;
+}
+
+kslam_status kslam_taxdb_text(const kslam_taxdb *db, uint32_t tax_id, int which, char **text,
+                              uint64_t *text_len) {
+  return guarded([&] {
+    if (!db || !text || !text_len) fail(KSLAM_ERR_ARG, "null argument");
+    std::string s;
+    if (which == 0 || which == 1) {
+      if (db->known(tax_id)) s = which == 0 ? db->name[db->node(tax_id)] : db->rank[db->node(tax_id)];
+    } else if (which == 2)
+      s = lineage_of(*db, tax_id);
+    else
+      fail(KSLAM_ERR_ARG, "which must be 0 (name), 1 (rank) or 2 (lineage)");
+    *text = dup_text(s, text_len);
+  });
+}
+
+kslam_status kslam_tail_classify(const kslam_tail_params *params, const kslam_reads_view *reads,
+                                 const kslam_index_view *index, const kslam_taxdb *db,
+                                 const kslam_read_pair *read_pairs, uint64_t n_read_pairs,
+                                 const kslam_paired_overlap *pairs, uint64_t n_pairs, uint32_t *tax_ids,
+                                 char **per_read_text, uint64_t *per_read_len) {
+  return guarded([&] {
+    if (!params || !reads || !index || !db || !tax_ids || (n_read_pairs && (!read_pairs || !pairs)))
+      fail(KSLAM_ERR_ARG, "null argument");
+    if (!index->taxonomy_id) fail(KSLAM_ERR_ARG, "index view needs taxonomy_id");
+    if (per_read_text && (!per_read_len || !reads->ids || !reads->ids_off))
+      fail(KSLAM_ERR_ARG, "per-read text needs the read identifiers and a length output");
+    const int threads = std::max(1, std::min(params->threads > 0 ? params->threads : usable_cpus(), 512));
+    const uint64_t grain = 4096, n_tasks = (n_read_pairs + grain - 1) / grain;
+    Pool::get().tasks(threads, n_tasks, [&](size_t t) {
+      std::vector<uint32_t> ids;
+      for (uint64_t g = t * grain; g < std::min(n_read_pairs, (t + 1) * grain); g++) {
+        const kslam_read_pair &rp = read_pairs[g];
+        if (rp.first + rp.count > n_pairs) fail(KSLAM_ERR_ARG, "read pair slice outside the pairs array");
+        ids.clear();
+        for (uint64_t k = 0; k < rp.count; k++) {
+          const uint32_t e = pairs[rp.first + k].entry;
+          if (e >= index->n_entries) fail(KSLAM_ERR_ARG, "alignment pair refers outside the index");
+          ids.push_back(index->taxonomy_id[e]);
+        }
+        tax_ids[g] = lca_ids(*db, ids.data(), ids.size());  // src/MetagenomicResults.h:88-112
+      }
+    });
+    if (per_read_text) {  // writePerReadResults, src/MetagenomicResults.h:455-463
+      std::string out;
+      out.reserve(n_read_pairs * 24);
+      for (uint64_t g = 0; g < n_read_pairs; g++) {
+        if (!read_pairs[g].count) continue;  // (a result without alignments has no read name)
+        const uint32_t r = read_pairs[g].r1_read;
+        if (r >= reads->n_reads) fail(KSLAM_ERR_ARG, "read pair refers to a read outside the batch");
+        out.append(reads->ids + reads->ids_off[r], reads->ids_off[r + 1] - reads->ids_off[r]);
+        out += '\t';
+        out += std::to_string(tax_ids[g]);
+        out += '\n';
+      }
+      *per_read_text = dup_text(out, per_read_len);
+    }
+  });
+}
+
+kslam_status kslam_taxonomy_summary(const kslam_taxdb *db, const uint32_t *tax_ids, uint64_t n,
+                                    uint64_t num_reads, char **text, uint64_t *text_len) {
+  return guarded([&] {
+    if (!db || !text || !text_len || (n && !tax_ids)) fail(KSLAM_ERR_ARG, "null argument");
+    // combineTaxonomies, src/MetagenomicResults.h:149-177, on (id) records in stable id order:
+    // only the group sizes matter downstream
+    std::vector<uint32_t> sorted(tax_ids, tax_ids + n);
+    std::stable_sort(sorted.begin(), sorted.end());
+    std::vector<std::pair<uint32_t, uint64_t>> groups;  // (taxonomy id, reads)
+    if (n) {
+      uint32_t test = 0;
+      size_t start = 0;
+      for (size_t i = 1; i < n; i++)
+        if (sorted[i] != test) {
+          if (test != 0) groups.push_back({sorted[start], i - start});
+          test = sorted[i];
+          start = i;
+        }
+      if (sorted[start] != 0) groups.push_back({sorted[start], n - start});
+    }
+    // sortResults, src/MetagenomicResults.h:254-262
+    std::sort(groups.begin(), groups.end(), [](const std::pair<uint32_t, uint64_t> &a,
+                                               const std::pair<uint32_t, uint64_t> &b) {
+      return a.second == b.second ? a.first < b.first : a.second > b.second;
+    });
+    // writeAbbreviatedResultsFile, src/MetagenomicResults.h:237-248 (ostream << double = "%g")
+    std::string out;
+    char num[64];
+    const unsigned reads32 = (unsigned)num_reads;  // the reference's `const unsigned numReads`
+    for (auto &g : groups) {
+      if (db->known(g.first)) out += db->name[db->node(g.first)];
+      snprintf(num, sizeof num, "\t%g\n", g.second * 100.0 / reads32);
+      out += num;
+    }
+    *text = dup_text(out, text_len);
+  });
+}
+}

@@ -49,7 +49,8 @@ def build(force=False):
     what is out of date; on a box without the sources the prebuilt files are used as they are."""
     so = os.path.join(_HERE, "liboracle.so")
     have_all = all(os.path.exists(os.path.join(_HERE, f))
-                   for f in ("liboracle.so", "libtail_oracle.so", "libfastq_oracle.so"))
+                   for f in ("liboracle.so", "libtail_oracle.so", "libfastq_oracle.so",
+                             "libtaxonomy_oracle.so"))
     if force:
         subprocess.check_call(["make", "-C", _HERE, "-s", "clean"])
     if force or not have_all or os.path.isdir("/root/reference/src") or _stale():
@@ -59,7 +60,7 @@ def build(force=False):
 
 def _stale():
     pairs = [("liboracle.so", "kslam_oracle.c"), ("libtail_oracle.so", "tail_oracle.cpp"),
-             ("libfastq_oracle.so", "fastq_oracle.cpp")]
+             ("libfastq_oracle.so", "fastq_oracle.cpp"), ("libtaxonomy_oracle.so", "taxonomy_oracle.cpp")]
     return any(os.path.getmtime(os.path.join(_HERE, a)) < os.path.getmtime(os.path.join(_HERE, b))
                for a, b in pairs)
 
@@ -478,3 +479,116 @@ def ref_fastq_read(path, per_call=0xFFFFFFFF):
     assert rc == 0, "reference reader could not open " + path
     b, q, i = _unflatten(int(n.value), [(v[0], v[1]), (v[2], v[3]), (v[4], v[5])], _fqref.ref_fastq_free)
     return b, q, i, [int(x) for x in calls[:int(nc.value)]]
+
+
+# ---- taxonomy tree (oracle/taxonomy_oracle.cpp) and the real one (oracle/_ref/libtaxonomy_ref.so) ----
+REF_TAXONOMY = os.path.join(_HERE, "_ref", "libtaxonomy_ref.so")
+
+
+class _TaxTree:
+    """Common surface of the restated tree and the reference's TaxonomyDB."""
+
+    def __init__(self, L, prefix, handle, closer):
+        self._L, self._p, self._h, self._close = L, prefix, handle, closer
+
+    def _f(self, name):
+        return getattr(self._L, self._p + name)
+
+    def lca(self, ids):
+        a = np.ascontiguousarray(ids, dtype=np.uint32)
+        return int(self._f("taxdb_lca")(self._h, a.ctypes.data, len(a)))
+
+    def parent(self, i):
+        return int(self._f("taxdb_parent")(self._h, i))
+
+    def at_rank(self, i, rank):
+        return int(self._f("taxdb_at_rank")(self._h, i, rank))
+
+    def is_below(self, upper, lower):
+        return int(self._f("taxdb_is_below")(self._h, upper, lower))
+
+    def is_subspecies(self, i):
+        return int(self._f("taxdb_is_subspecies")(self._h, i))
+
+    def text(self, i, which):
+        p = self._f("taxdb_text")(self._h, i, which)
+        s = C.string_at(p)
+        self._f("tax_free")(p)
+        return s
+
+    def close(self):
+        if self._h:
+            self._close(self._h)
+            self._h = None
+
+
+def _tax_sigs(L, p):
+    vp, u32, u64 = C.c_void_p, C.c_uint32, C.c_uint64
+    getattr(L, p + "taxdb_lca").restype = u32
+    getattr(L, p + "taxdb_lca").argtypes = [vp, vp, u64]
+    getattr(L, p + "taxdb_parent").restype = u32
+    getattr(L, p + "taxdb_parent").argtypes = [vp, u32]
+    getattr(L, p + "taxdb_at_rank").restype = u32
+    getattr(L, p + "taxdb_at_rank").argtypes = [vp, u32, C.c_char_p]
+    getattr(L, p + "taxdb_is_below").restype = C.c_int32
+    getattr(L, p + "taxdb_is_below").argtypes = [vp, u32, u32]
+    getattr(L, p + "taxdb_is_subspecies").restype = C.c_int32
+    getattr(L, p + "taxdb_is_subspecies").argtypes = [vp, u32]
+    getattr(L, p + "taxdb_text").restype = vp
+    getattr(L, p + "taxdb_text").argtypes = [vp, u32, C.c_int]
+    getattr(L, p + "tax_free").argtypes = [vp]
+
+
+_taxo = None
+_taxref = None
+
+
+def taxonomy_lib():
+    global _taxo
+    if _taxo is None:
+        build()
+        L = C.CDLL(os.path.join(_HERE, "libtaxonomy_oracle.so"))
+        _tax_sigs(L, "orc_")
+        L.orc_taxdb_parse.restype = C.c_void_p
+        L.orc_taxdb_parse.argtypes = [C.c_char_p, C.c_uint64]
+        L.orc_taxdb_free.argtypes = [C.c_void_p]
+        L.orc_taxonomy_summary.restype = C.c_void_p
+        L.orc_taxonomy_summary.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32]
+        _taxo = L
+    return _taxo
+
+
+def taxonomy_tree(text):
+    L = taxonomy_lib()
+    return _TaxTree(L, "orc_", L.orc_taxdb_parse(text, len(text)), L.orc_taxdb_free)
+
+
+def taxonomy_summary(tree, ids, num_reads):
+    L = taxonomy_lib()
+    a = np.ascontiguousarray(ids, dtype=np.uint32)
+    p = L.orc_taxonomy_summary(tree._h, a.ctypes.data, len(a), num_reads)
+    s = C.string_at(p)
+    L.orc_tax_free(p)
+    return s
+
+
+def have_ref_taxonomy():
+    build()
+    return os.path.exists(REF_TAXONOMY)
+
+
+def ref_taxonomy_tree(path):
+    """The REAL reference TaxonomyDB built from a taxDB file."""
+    global _taxref
+    if _taxref is None:
+        L = C.CDLL(REF_TAXONOMY)
+        _tax_sigs(L, "ref_")
+        L.ref_taxdb_open.restype = C.c_void_p
+        L.ref_taxdb_open.argtypes = [C.c_char_p]
+        L.ref_taxdb_close.argtypes = [C.c_void_p]
+        L.ref_taxdb_size.restype = C.c_uint64
+        L.ref_taxdb_size.argtypes = [C.c_void_p]
+        _taxref = L
+    h = _taxref.ref_taxdb_open(path.encode())
+    assert h, "reference TaxonomyDB could not open " + path
+    return _TaxTree(_taxref, "ref_", h, _taxref.ref_taxdb_close)

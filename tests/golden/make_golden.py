@@ -151,7 +151,37 @@ def make_fastq_cases():
     print("fastq_cases.json:", len(cases), "cases")
 
 
+def make_taxonomy_cases():
+    """A taxDB text + the REAL reference TaxonomyDB's answers (oracle/_ref/libtaxonomy_ref.so, built
+    from src/TaxonomyDatabase.h where it lies) -> tests/golden/taxonomy_cases.json."""
+    import tempfile
+    import numpy as np
+    import oracle as O
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_taxonomy import make_tree, query_sets
+    assert O.have_ref_taxonomy(), "needs /root/reference (make -C oracle ref)"
+    rng = np.random.default_rng(77)
+    text, ids = make_tree(rng, 120)
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "taxDB")
+        open(path, "wb").write(text)
+        ref = O.ref_taxonomy_tree(path)
+        lca = [[s, ref.lca(s)] for s in query_sets(rng, ids, 300)]
+        nodes = [[i, ref.parent(i), ref.text(i, 0).decode(), ref.text(i, 1).decode(), ref.text(i, 2).decode(),
+                  ref.is_subspecies(i), ref.at_rank(i, b"species")]
+                 for i in list(dict.fromkeys(ids))[:120] + [0, 1, 999999]]
+        ref.close()
+    json.dump({"source": "reference src/TaxonomyDatabase.h via oracle/ref_taxonomy_driver.cpp",
+               "taxdb": text.decode(), "lca": lca, "nodes": nodes},
+              open(os.path.join(HERE, "taxonomy_cases.json"), "w"), indent=0)
+    print("taxonomy_cases.json:", len(lca), "lca queries,", len(nodes), "nodes")
+
+
 if __name__ == "__main__":
+    if "--taxonomy" in sys.argv:
+        make_taxonomy_cases()
+        sys.exit(0)
     if "--fastq" not in sys.argv:      # --fastq: only (re)write fastq_cases.json
         main()
     make_fastq_cases()
+    make_taxonomy_cases()

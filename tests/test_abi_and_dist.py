@@ -47,6 +47,19 @@ def test_library_exports_every_tail_symbol(kslam):
     assert T.PAIRED_OVERLAP_DT.itemsize == 32 and T.READ_PAIR_DT.itemsize == 24
 
 
+@pytest.mark.parametrize("header,module,count", [("kslam_fastq.h", "fastq", 3), ("kslam_taxonomy.h", "taxonomy", 11)])
+def test_library_exports_every_host_stage_symbol(kslam, header, module, count):
+    import ctypes
+    import importlib
+    M = importlib.import_module("kslam_amd." + module)
+    L = ctypes.CDLL(kslam.LIB_PATH)
+    declared = [d for d in _declared_symbols(header) if d != "kslam_write_fn"]
+    assert len(declared) == count
+    for name in declared:
+        assert hasattr(L, name), "missing export " + name
+    assert sorted(M.EXPORTS) == declared
+
+
 def test_struct_layouts(kslam):
     assert kslam.KMER_DT.itemsize == 16          # sizeof(KMerAndData<uint64_t,32>), src/KMer.h:103-116
     assert kslam.OVERLAP_TEMP_DT.itemsize == 16  # OverlapTemp, src/Overlap.h:36-52

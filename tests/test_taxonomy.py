@@ -1,0 +1,176 @@
+"""Taxonomy stage (include/kslam_taxonomy.h; the per-read LCA of SURVEY.md section 8f row N1).
+
+Tree queries are compared three ways -- product (dense parent/depth arrays), restatement
+(oracle/taxonomy_oracle.cpp: hash map + root-ward paths) and the REAL reference
+(oracle/_ref/libtaxonomy_ref.so = src/TaxonomyDatabase.h compiled in place), plus the answers the
+reference gave for tests/golden/taxonomy_cases.json.  The per-read and summary steps
+(src/MetagenomicResults.h, unbuildable here) are compared product vs restatement and against
+hand-worked cases.  Host-only.
+"""
+import importlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RANKS = [b"no rank", b"superkingdom", b"phylum", b"class", b"order", b"family", b"genus", b"species",
+         b"subspecies", b"strain", b""]
+
+
+@pytest.fixture(scope="module")
+def X(kslam):
+    return importlib.import_module("kslam_amd.taxonomy")
+
+
+def make_tree(rng, n, dangling=3, duplicates=2):
+    """-> (taxDB text, list of ids).  Node 1 is the root (its own parent); 131567 hangs below it."""
+    ids = [1, 131567] + [int(x) for x in rng.choice(np.arange(2, 200000), n, replace=False) if x != 131567]
+    parent = {1: 1, 131567: 1}
+    for k, i in enumerate(ids[2:], start=2):
+        parent[i] = ids[int(rng.integers(0, k))] if rng.random() < 0.9 else 1
+    recs = []
+    for i in ids:
+        recs.append((i, parent[i], b"name of %d" % i if rng.random() < 0.95 else b"",
+                     RANKS[int(rng.integers(0, len(RANKS)))]))
+    for _ in range(dangling):       # a parent id that no record defines
+        recs.append((int(rng.integers(300000, 400000)), int(rng.integers(400000, 500000)), b"orphan", b"genus"))
+    order = rng.permutation(len(recs))
+    recs = [recs[j] for j in order]
+    for _ in range(duplicates):     # a repeated id: the first record wins
+        i, p, nm, rk = recs[int(rng.integers(0, len(recs)))]
+        recs.append((i, 1, b"DUPLICATE", b"species"))
+    text = b"".join(b"%d\n%d\n%s\n%s\n" % r for r in recs)
+    return text, [r[0] for r in recs] + [r[1] for r in recs]
+
+
+def query_sets(rng, ids, n_sets):
+    out = []
+    for _ in range(n_sets):
+        k = int(rng.integers(1, 6))
+        s = [int(ids[int(rng.integers(0, len(ids)))]) for _ in range(k)]
+        r = rng.random()
+        if r < 0.08:
+            s.append(0)
+        elif r < 0.16:
+            s.append(999999)            # an id the tree has never heard of
+        elif r < 0.2:
+            s = [999999, 999999]
+        out.append(s)
+    return out + [[], [1], [1, 1], [131567]]
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_tree_queries_three_ways(X, oracle, tmp_path, seed):
+    rng = np.random.default_rng(seed)
+    text, ids = make_tree(rng, 300)
+    db, orc = X.TaxDB(text), oracle.taxonomy_tree(text)
+    trees = [orc]
+    if oracle.have_ref_taxonomy():
+        path = str(tmp_path / "taxDB")
+        open(path, "wb").write(text)
+        trees.append(oracle.ref_taxonomy_tree(path))
+    for t in trees:
+        for s in query_sets(rng, ids, 400):
+            assert db.lca(s) == t.lca(s), s
+        for i in list(dict.fromkeys(ids))[:200] + [0, 1, 999999, 131567]:
+            assert db.parent(i) == t.parent(i), i
+            for which in (X.TaxDB.NAME, X.TaxDB.RANK, X.TaxDB.LINEAGE):
+                assert db.text(i, which) == t.text(i, which), (i, which)
+            assert db.is_subspecies(i) == t.is_subspecies(i), i
+            for rank in (b"species", b"genus", b"nothing"):
+                assert db.at_rank(i, rank) == t.at_rank(i, rank), (i, rank)
+            j = int(ids[int(rng.integers(0, len(ids)))])
+            assert db.is_below(j, i) == t.is_below(j, i) and db.is_below(i, i) == t.is_below(i, i)
+    for t in trees:
+        t.close()
+
+
+def test_lca_conventions_by_hand(X):
+    # 1 root; 2 and 3 top-level; 2 -> 20 -> 200, 201;  3 -> 30
+    text = b"".join(b"%d\n%d\n%s\n%s\n" % r for r in [
+        (1, 1, b"root", b"no rank"), (2, 1, b"Bacteria", b"superkingdom"), (3, 1, b"Viruses", b"superkingdom"),
+        (20, 2, b"Escherichia", b"genus"), (200, 20, b"Escherichia coli", b"species"),
+        (201, 20, b"Escherichia albertii", b"species"), (2000, 200, b"E. coli K-12", b"no rank"),
+        (30, 3, b"Some virus", b"species")])
+    db = X.TaxDB(text)
+    assert len(db) == 8
+    assert db.lca([200, 201]) == 20 and db.lca([2000, 201]) == 20 and db.lca([2000, 200]) == 200
+    assert db.lca([200]) == 200 and db.lca([200, 200, 200]) == 200
+    assert db.lca([200, 30]) == 0          # different top-level nodes: paths stop below the root
+    assert db.lca([200, 0]) == 0 and db.lca([]) == 0 and db.lca([77]) == 77 and db.lca([77, 200]) == 0
+    assert db.parent(2) == 0 and db.parent(20) == 2 and db.parent(77) == 0
+    assert db.is_subspecies(2000) == 1 and db.is_subspecies(200) == 0 and db.is_subspecies(20) == 0
+    assert db.at_rank(2000, b"species") == 200 and db.at_rank(2000, b"genus") == 20
+    assert db.at_rank(2000, b"superkingdom") == 0   # the walk stops at a node whose parent is 1
+    assert db.text(2000, X.TaxDB.LINEAGE) == b"Bacteria; Escherichia."   # everything from species down is cut
+    assert db.text(20, X.TaxDB.LINEAGE) == b"Bacteria; Escherichia."
+    assert db.text(77, X.TaxDB.NAME) == b""
+
+
+def test_parse_errors(kslam, X):
+    with pytest.raises(kslam.KslamError) as e:
+        X.TaxDB(b"5\n1\nname\n")
+    assert e.value.status == 1 and "multiple of four" in str(e.value)
+    with pytest.raises(kslam.KslamError) as e:
+        X.TaxDB(b"five\n1\nname\nrank\n")
+    assert e.value.status == 1 and "not a number" in str(e.value)
+    with pytest.raises(kslam.KslamError) as e:
+        X.TaxDB(b"5\n6\na\nr\n6\n5\nb\nr\n")
+    assert e.value.status == 1 and "cycle" in str(e.value)
+    assert len(X.TaxDB(b"")) == 0
+
+
+def test_summary_and_its_first_record_quirk(X, oracle):
+    text = b"".join(b"%d\n%d\n%s\n%s\n" % r for r in [
+        (1, 1, b"root", b""), (2, 1, b"Bacteria", b""), (20, 2, b"Escherichia", b"genus"),
+        (200, 20, b"Escherichia coli", b"species")])
+    db, orc = X.TaxDB(text), oracle.taxonomy_tree(text)
+    # with unclassified pairs (id 0) present every group is complete
+    ids = [200, 0, 20, 200, 200, 0, 20]
+    assert db.summary(ids, 10) == b"Escherichia coli\t30\nEscherichia\t20\n"
+    # without any id 0 the lowest id loses its first record (src/MetagenomicResults.h:159-175)
+    ids = [200, 20, 200, 200, 20]
+    assert db.summary(ids, 10) == b"Escherichia coli\t30\nEscherichia\t10\n"
+    assert db.summary([200], 3) == b"Escherichia coli\t33.3333\n" and db.summary([], 3) == b""
+    rng = np.random.default_rng(3)
+    for trial in range(50):
+        ids = rng.choice([0, 2, 20, 200, 999], int(rng.integers(0, 40)),
+                         p=[0.1, 0.2, 0.3, 0.3, 0.1] if trial % 2 else [0.0, 0.3, 0.3, 0.3, 0.1])
+        assert db.summary(ids, 1000) == oracle.taxonomy_summary(orc, ids, 1000)
+
+
+def test_classify_read_pairs(kslam, X, oracle):
+    T = importlib.import_module("kslam_amd.tail")
+    from test_tail import _fuzz_overlaps
+    rng = np.random.default_rng(11)
+    text, ids = make_tree(rng, 60, dangling=0, duplicates=0)
+    db, orc = X.TaxDB(text), oracle.taxonomy_tree(text)
+    n_entries = 12
+    entry_tax = [int(ids[int(rng.integers(0, 60))]) for _ in range(n_entries)]
+    entry_tax[3] = 0                                     # an entry without a taxonomy id
+    ov, n_reads = _fuzz_overlaps(kslam, rng, 3000, n_entries)
+    reads = T.Reads([b"A" * 100] * n_reads, ids=[b"q%d" % (i % 3000) for i in range(n_reads)])
+    index = T.Index([b"A" * 8000] * n_entries, taxonomy_ids=entry_tax)
+    P = T.TailParams.default(report_cigar=False, threads=3)
+    rp, pr, _ = T.tail_pairs(P, reads, ov)
+    got, per_read = db.classify(P, reads, index, rp, pr)
+    exp = [orc.lca([entry_tax[int(e)] for e in pr["entry"][int(g["first"]):int(g["first"]) + int(g["count"])]])
+           for g in rp]
+    assert got.tolist() == exp and len(set(exp)) > 5
+    assert per_read == b"".join(b"q%d\t%d\n" % (int(g["r1_read"]), t) for g, t in zip(rp, exp))
+    assert db.classify(P, reads, index, rp, pr, per_read=False)[1] is None
+
+
+def test_golden_answers_from_the_real_reference(X, oracle):
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "taxonomy_cases.json")))
+    text = g["taxdb"].encode()
+    db, orc = X.TaxDB(text), oracle.taxonomy_tree(text)
+    assert len(g["lca"]) >= 200
+    for ids, ans in g["lca"]:
+        assert db.lca(ids) == ans and orc.lca(ids) == ans, ids
+    for i, parent, name, rank, lineage, sub, species in g["nodes"]:
+        assert (db.parent(i), db.is_subspecies(i), db.at_rank(i, b"species")) == (parent, sub, species)
+        assert [db.text(i, w).decode() for w in (0, 1, 2)] == [name, rank, lineage]
+        assert orc.text(i, 2).decode() == lineage

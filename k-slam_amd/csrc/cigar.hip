@@ -103,6 +103,7 @@ struct LdsLayout {
   uint32_t lmax;     // rows / columns the sequence buffers are sized for
   uint32_t W1;       // row array length (2 * slot_bw + 4)
   uint32_t wd;       // direction cells per row the global slab is sized for (2 * slot_bw + 1)
+  uint32_t wpr;      // direction words per row kept in LDS (six 5-bit cells per word); 0: global slab
 };
 
 // Wave-cooperative staging of one span per lane: for each lane c of the wave in turn, all lanes
@@ -161,9 +162,11 @@ __device__ inline void stage_codes_wave(const uint8_t *src, int32_t len, bool re
   }
 }
 
-// One candidate per lane.  LDS ([element][lane]): translated spans + the three row arrays.
-// Global slab per block ([cell][lane], coalesced, L2 resident): one direction byte per band
-// cell, written fire-and-forget during the DP and read back only by the traceback.
+// One candidate per lane.  LDS ([element][lane]): translated spans + the three row arrays, and,
+// for the narrow bands nearly every candidate needs, the direction matrix itself: 5 bits per band
+// cell, six cells per word, so the traceback -- a chain of dependent loads, one per step -- runs
+// at LDS latency.  Wider bands keep the directions in a global slab per block ([cell][lane],
+// coalesced, L2 resident), written fire-and-forget during the DP.
 __global__ __launch_bounds__(64) void k_banded_lds(CigJob J, SwInputs in, SwParams p, LdsLayout Y) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
   if (J.variant == 3) return;   // ablation: launch floor
@@ -176,6 +179,8 @@ __global__ __launch_bounds__(64) void k_banded_lds(CigJob J, SwInputs in, SwPara
   uint8_t *SQ = lds_raw;
   uint8_t *SR = SQ + half;
   int16_t *S = reinterpret_cast<int16_t *>(lds_raw + (((size_t)2 * half + 15) & ~(size_t)15));
+  uint32_t *DW = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(S) +
+                                              (((size_t)3 * Y.W1 * NL * sizeof(int16_t) + 15) & ~(size_t)15));
   for (uint32_t x = lane; x < half / 2; x += 64) reinterpret_cast<uint32_t *>(lds_raw)[x] = 0;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -231,9 +236,23 @@ __global__ __launch_bounds__(64) void k_banded_lds(CigJob J, SwInputs in, SwPara
     __device__ int16_t &hc(int32_t k) { return S[(2 * W1 + (uint32_t)k) * NL + lane]; }
     __device__ uint32_t q(int32_t i) { return (SQ[((uint32_t)i >> 1) * (NL + 1) + lane] >> (4 * (i & 1))) & 15u; }
     __device__ uint32_t r(int32_t j) { return (SR[((uint32_t)j >> 1) * (NL + 1) + lane] >> (4 * (j & 1))) & 15u; }
-    __device__ void set_dir(int32_t i, int32_t col, uint32_t v) { D[((size_t)i * width_d + (uint32_t)col) * NL + lane] = (uint8_t)v; }
-    __device__ uint32_t get_dir(int32_t i, int32_t col) { return D[((size_t)i * width_d + (uint32_t)col) * NL + lane]; }
-  } A{S, SQ, SR, D, NL, lane, Y.W1, (uint32_t)(band_width * 2 + 1)};
+    uint32_t *DW, wpr, acc;             // LDS direction words: [row * wpr + word][lane]
+    __device__ void set_dir(int32_t i, int32_t col, uint32_t v) {
+      if (wpr) {
+        const uint32_t w = (uint32_t)col / 6u, sh = 5u * ((uint32_t)col - 6u * w);
+        acc = sh ? (acc | (v << sh)) : v;   // cells of a row arrive in column order: the word is complete
+        DW[((uint32_t)i * wpr + w) * NL + lane] = acc;   // after its last cell, no read-modify-write needed
+      } else
+        D[((size_t)i * width_d + (uint32_t)col) * NL + lane] = (uint8_t)v;
+    }
+    __device__ uint32_t get_dir(int32_t i, int32_t col) {
+      if (wpr) {
+        const uint32_t w = (uint32_t)col / 6u, sh = 5u * ((uint32_t)col - 6u * w);
+        return (DW[((uint32_t)i * wpr + w) * NL + lane] >> sh) & 31u;
+      }
+      return D[((size_t)i * width_d + (uint32_t)col) * NL + lane];
+    }
+  } A{S, SQ, SR, D, NL, lane, Y.W1, (uint32_t)(band_width * 2 + 1), DW, Y.wpr, 0u};
   (void)score;
   const int32_t mx = banded_attempt(A, refLen, readLen, band_width, p, J.bmax[ci]);
   if (J.variant == 1) return;   // ablation: no traceback
@@ -365,17 +384,27 @@ void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, u
     auto launch = [&](uint64_t m, uint32_t slot_bw, bool big) {
       LdsLayout Y;
       Y.lmax = lmax; Y.W1 = slot_bw * 2 + 4; Y.wd = slot_bw * 2 + 1;
-      const size_t per_lane = (size_t)lmax + 2 + (size_t)3 * Y.W1 * sizeof(int16_t);
+      // Directions: global slab.  Keeping them in LDS (KSLAM_CIGAR_DIRS=lds) was measured: the DP is
+      // LDS-instruction bound, not bound by the traceback's loads, and the extra 38 KB per block cost
+      // more occupancy than the traceback gained (class 1: 7.9 ms against 2.8 ms).
+      const size_t base_lane = (size_t)lmax + 2 + (size_t)3 * Y.W1 * sizeof(int16_t);
+      const uint32_t wpr_fit = (Y.wd + 5) / 6;
+      const char *force = getenv("KSLAM_CIGAR_DIRS");
+      const bool dir_in_lds = force && force[0] == 'l' &&
+                              (base_lane + (size_t)lmax * wpr_fit * 4) * 16 + 64 <= 64 * 1024;
+      Y.wpr = dir_in_lds ? wpr_fit : 0;
+      const size_t per_lane = base_lane + (size_t)lmax * Y.wpr * 4;
       uint32_t nl = 64;
       while (nl > 1 && per_lane * nl + 64 > 64 * 1024) nl >>= 1;   // <= 64 KB: at least two blocks per CU
       Y.nl = nl;
       const size_t half = ((((size_t)lmax + 1) / 2) * (nl + 1) + 3) & ~(size_t)3;
-      const size_t lds = ((2 * half + 15) & ~(size_t)15) + (size_t)3 * Y.W1 * nl * sizeof(int16_t);
+      const size_t rows_bytes = ((size_t)3 * Y.W1 * nl * sizeof(int16_t) + 15) & ~(size_t)15;
+      const size_t lds = ((2 * half + 15) & ~(size_t)15) + rows_bytes + (size_t)lmax * Y.wpr * 4 * nl;
       if (lds > 160 * 1024) throw StatusError{KSLAM_ERR_UNSUPPORTED, "banded traceback band does not fit LDS"};
       if (lds > 64 * 1024)
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_banded_lds),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      uint64_t slab = (uint64_t)lmax * Y.wd * nl;
+      uint64_t slab = Y.wpr ? 256 : (uint64_t)lmax * Y.wd * nl;
       slab = (slab + 255) & ~255ull;
       const uint64_t SCRATCH_BUDGET = 3ull << 30;
       const uint64_t blocks_per_launch = std::max<uint64_t>(1, SCRATCH_BUDGET / slab);

@@ -172,6 +172,7 @@ struct SwParams {
   int32_t match, mismatch, gap_open, gap_extend;
   uint32_t score_threshold;
   int32_t report_cigar;
+  uint32_t ablate = 0;   // KSLAM_SW_ABLATE (measurement only): 1 = skip the DP sweep, 2 = skip staging too
 };
 struct SwInputs {
   const uint8_t *read_bases;
@@ -183,7 +184,7 @@ struct SwInputs {
 // unflipped coordinates); d_band0[i] = initial band width for banded_sw
 // (0 = no cigar wanted, ssw.c:924-927)
 struct SwWork {
-  DevBuf flags, pos, list, list2, scan_tmp, totals;
+  DevBuf flags, pos, list, list2, scan_tmp, totals, tier_list[4];
 };
 // *n_full_out: candidates that needed the full-matrix kernel (the rest ran in a proven band)
 void sw_scores(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, uint32_t max_read_len,

@@ -172,6 +172,99 @@ __device__ inline void stage_candidate(const kslam_overlap &o, const SwInputs &i
   *wlen_out = wlen;
 }
 
+// ---- wide staging --------------------------------------------------------------------------------
+// The byte-at-a-time staging above costs as much as the banded DP itself (one memory instruction
+// and one LDS store per base).  Here a span is fetched as 16-byte chunks from the 16-byte-aligned
+// address below it, a chunk per lane, converted in registers and stored with one 16-byte LDS
+// write -- at the chunk's own position, NOT re-aligned: the buffer holds the codes of the aligned
+// chunks and the caller gets the offset at which its span starts.  A reverse-complemented window
+// stores the chunks in reverse order with their bytes reversed, which lands the reversed span at a
+// (different) offset of the same buffer.  Both base arrays are the library's own copies: 256-byte
+// aligned starts and 64 bytes of slack at the end, so the aligned reads never leave them.
+constexpr int STAGE_PAD = 32;   // bytes a span buffer needs beyond the longest span
+
+template <int WS>
+__device__ inline uint32_t codes_of_dword(uint32_t v, bool comp) {
+  uint32_t out = 0;
+#pragma unroll
+  for (int b = 0; b < 4; b++) {
+    const uint32_t ch = (v >> (8 * b)) & 0xFFu;
+    out |= ((comp ? ssw_code_complemented(ch) : ssw_code(ch)) * (uint32_t)WS) << (8 * b);
+  }
+  return out;
+}
+
+// 6-bit packed score row (one field per reference code 0..3, code 4 reads the clear bits 24..29)
+__device__ inline uint32_t score_row(uint32_t q, const SwParams &p) {
+  const uint32_t mis = (uint32_t)(-p.mismatch) & 63u, mat = (uint32_t)p.match & 63u;
+  const uint32_t all_mis = mis | (mis << 6) | (mis << 12) | (mis << 18);
+  return q > 3u ? 0u : (all_mis ^ ((mis ^ mat) << (6u * q)));
+}
+
+// GL lanes stage src[0..len) into dst (16-byte aligned, >= len + STAGE_PAD bytes) as WS x code;
+// when tab != nullptr also the score row of every base.  Returns the offset of element 0 in dst.
+template <int GL, int WS>
+__device__ inline int32_t stage_span(const uint8_t *src, int32_t len, bool rc, int32_t t, uint8_t *dst,
+                                     uint32_t *tab, const SwParams &p) {
+  const uint32_t shift = (uint32_t)(reinterpret_cast<uintptr_t>(src) & 15u);
+  const uint4 *base = reinterpret_cast<const uint4 *>(src - shift);
+  const int32_t nch = ((int32_t)shift + len + 15) >> 4;
+  for (int32_t k = t; k < nch; k += GL) {
+    const uint4 v = base[k];
+    uint4 c;
+    int32_t at;
+    if (!rc) {
+      c.x = codes_of_dword<WS>(v.x, false);
+      c.y = codes_of_dword<WS>(v.y, false);
+      c.z = codes_of_dword<WS>(v.z, false);
+      c.w = codes_of_dword<WS>(v.w, false);
+      at = k;
+    } else {   // reversed: last chunk first, bytes of a chunk back to front
+      c.x = __builtin_bswap32(codes_of_dword<WS>(v.w, true));
+      c.y = __builtin_bswap32(codes_of_dword<WS>(v.z, true));
+      c.z = __builtin_bswap32(codes_of_dword<WS>(v.y, true));
+      c.w = __builtin_bswap32(codes_of_dword<WS>(v.x, true));
+      at = nch - 1 - k;
+    }
+    reinterpret_cast<uint4 *>(dst)[at] = c;
+    if (tab) {
+      const uint32_t w[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+      for (int d = 0; d < 4; d++) {
+        uint4 r;
+        r.x = score_row(((w[d]) & 0xFFu) / (uint32_t)WS, p);
+        r.y = score_row(((w[d] >> 8) & 0xFFu) / (uint32_t)WS, p);
+        r.z = score_row(((w[d] >> 16) & 0xFFu) / (uint32_t)WS, p);
+        r.w = score_row((w[d] >> 24) / (uint32_t)WS, p);
+        reinterpret_cast<uint4 *>(tab)[at * 4 + d] = r;
+      }
+    }
+  }
+  return rc ? 16 * nch - (int32_t)shift - len : (int32_t)shift;
+}
+
+struct Staged {
+  int32_t L, W;        // read length, window length
+  int32_t qoff, woff;  // where read base 0 / window base 0 sit in the staged buffers
+};
+// read (codes x 1, + score rows when tab != nullptr) and window (codes x WS) of candidate o
+template <int GL, int WS>
+__device__ inline Staged stage_candidate_wide(const kslam_overlap &o, const SwInputs &in, int32_t t, uint8_t *sq,
+                                              uint8_t *sw, uint32_t *tab, const SwParams &p) {
+  const uint64_t ro = in.read_off[o.read];
+  const int32_t L = (int32_t)(in.read_off[o.read + 1] - ro);
+  const uint64_t go = in.genome_off[o.entry];
+  const uint64_t G = in.genome_off[o.entry + 1] - go;
+  const int64_t s0 = o.rel > 0 ? o.rel : 0;                           // SmithWaterman.h:204
+  const int32_t wlen = (int32_t)min((uint64_t)L, G - (uint64_t)s0);    // substr, :205-206
+  Staged st;
+  st.L = L;
+  st.W = wlen;
+  st.qoff = stage_span<GL, 1>(in.read_bases + ro, L, false, t, sq, tab, p);
+  st.woff = stage_span<GL, WS>(in.genome_bases + go + s0, wlen, o.revcomp != 0, t, sw, nullptr, p);   // :207
+  return st;
+}
+
 // result record + band request for banded_sw, ssw.c:924-935 (flag 0x0f: score and distance filters)
 template <int GL = 16, int WS = 1>   // WS: the window codes in sw[] are stored multiplied by WS
 __device__ inline void sw_epilogue(kslam_overlap *ov, uint64_t ci, bool have, int32_t t, int32_t L,
@@ -237,6 +330,183 @@ __global__ __launch_bounds__(256) void k_sw(kslam_overlap *__restrict__ ov, uint
   sw_epilogue(ov, ci, have, t, L, f, s_q[grp], s_w[grp], p, band0);
 }
 
+// ---- exactness certificate of a band -----------------------------------------------------------
+// `score` is the score of some real alignment of the candidate (a lower bound of the optimum).  Any
+// alignment scoring S >= score with g gap bases pays at least cost(g) = gO + (g-1) gE (gE < gO), so
+// it has m >= m0(g) = ceil((score + cost(g)) / match) matches, uses >= m0(g) rows and columns,
+// starts on a diagonal d = j - i in [-(L - m0(g)), W - m0(g)] and stays within g of it.  True when
+// the union of those ranges over all feasible g lies inside [dlo, dlo + ND - 1].
+__device__ inline bool band_certifies(int32_t score, int32_t L, int32_t W, int32_t dlo, int32_t ND,
+                                      const SwParams &p) {
+  if (score <= 0) return false;
+  int32_t rlo = 1 << 20, rhi = -(1 << 20);
+  const int32_t Lm = min(L, W);
+  for (int32_t g = 0; g < 2048; g++) {
+    const int32_t cost = g == 0 ? 0 : p.gap_open + (g - 1) * p.gap_extend;
+    const int32_t m0 = (score + cost + p.match - 1) / p.match;
+    if (m0 > Lm) break;
+    rlo = min(rlo, -(L - m0) - g);
+    rhi = max(rhi, (W - m0) + g);
+    if (rlo < dlo || rhi > dlo + ND - 1) return false;
+  }
+  return rlo >= dlo && rhi <= dlo + ND - 1;
+}
+
+// ---- tier planning ------------------------------------------------------------------------------
+// Which band does a candidate need?  The certificate only asks for a lower bound of the optimal
+// score, and the cheapest real alignment to score is the seed itself: the read laid on one of the
+// diagonals the join merged into this candidate (|rel difference| < 3), no gaps, full length.  The
+// best of those five plain diagonal sums picks the narrowest band that is certain to certify;
+// gapped alignments, whose diagonal sums are poor, start in the 32-diagonal band and move up on
+// failure as before.  tier: 0 = 16 diagonals, 1 = 32, 2 = 64, 3 = 128 (reads > 160 bases only).
+template <int LMAX>
+__global__ __launch_bounds__(256) void k_sw_plan(const kslam_overlap *__restrict__ ov, uint64_t n, SwInputs in,
+                                                 SwParams p, int n_tiers, uint8_t *__restrict__ tier) {
+  constexpr int GL = 8, NG = 256 / GL;
+  __shared__ __attribute__((aligned(16))) uint8_t s_q[NG][LMAX + STAGE_PAD];
+  __shared__ __attribute__((aligned(16))) uint8_t s_w[NG][LMAX + STAGE_PAD];
+  const int32_t lane = threadIdx.x & 63;
+  const int32_t t = lane & (GL - 1);
+  const int32_t grp = threadIdx.x / GL;
+  const uint64_t gi = (uint64_t)blockIdx.x * NG + grp;
+  const bool have = gi < n;
+  int32_t L = 0, W = 0, rel = 0;
+  const uint8_t *qc = s_q[grp], *wc = s_w[grp];
+  if (have) {
+    const kslam_overlap o = ov[gi];
+    rel = o.rel;
+    const Staged st = stage_candidate_wide<GL, 1>(o, in, t, s_q[grp], s_w[grp], nullptr, p);
+    L = st.L;
+    W = st.W;
+    qc += st.qoff;
+    wc += st.woff;
+  }
+  __syncthreads();
+  const int32_t d0 = rel < 0 ? rel : 0;
+  int32_t sum[5] = {0, 0, 0, 0, 0};
+  for (int32_t i = t; i < L; i += GL) {
+    const uint32_t q = qc[i];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+      const int32_t j = i + d0 + k - 2;
+      if (j >= 0 && j < W) {
+        const uint32_t c = wc[j];
+        sum[k] += (q > 3u || c > 3u) ? 0 : (q == c ? (int32_t)p.match : -(int32_t)p.mismatch);
+      }
+    }
+  }
+  int32_t best = 0;
+#pragma unroll
+  for (int k = 0; k < 5; k++) {
+    int32_t v = sum[k];
+#pragma unroll
+    for (int m = 1; m < GL; m <<= 1) v += __shfl_xor(v, m, GL);
+    best = max(best, v);
+  }
+  if (have && t == 0) {
+    int choice = 1;   // no diagonal certifies anything: start in the 32-diagonal band
+    for (int k = 0; k < n_tiers; k++) {
+      const int ND = 16 << k;
+      if (band_certifies(best, L, W, d0 - ND / 2, ND, p)) {
+        choice = k;
+        break;
+      }
+    }
+    tier[gi] = (uint8_t)choice;
+  }
+}
+
+// 4-way stable partition of the candidate numbers by tier: per-block counts, one small scan,
+// then a scatter that ranks within the block by ballots.
+constexpr int TIER_ITEMS = 4096;   // candidates per block
+__global__ __launch_bounds__(256) void k_tier_hist(const uint8_t *__restrict__ tier, uint64_t n,
+                                                   uint32_t *__restrict__ block_hist, uint32_t n_blocks) {
+  __shared__ uint32_t h[4];
+  if (threadIdx.x < 4) h[threadIdx.x] = 0;
+  __syncthreads();
+  uint32_t c[4] = {0, 0, 0, 0};
+  const uint64_t base = (uint64_t)blockIdx.x * TIER_ITEMS;
+  for (uint32_t k = threadIdx.x; k < TIER_ITEMS; k += 256) {
+    const uint64_t i = base + k;
+    if (i < n) c[tier[i] & 3]++;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    uint32_t v = c[k];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_down(v, d, 64);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(&h[k], v);
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) block_hist[threadIdx.x * n_blocks + blockIdx.x] = h[threadIdx.x];
+}
+
+// exclusive scan of block_hist per tier (each tier's list starts at 0); totals[k] = tier size
+__global__ __launch_bounds__(1024) void k_tier_scan(uint32_t *__restrict__ block_hist, uint32_t n_blocks,
+                                                    uint32_t *__restrict__ totals) {
+  __shared__ uint32_t part[1024];
+  const uint32_t k = blockIdx.x;   // tier
+  uint32_t *a = block_hist + (size_t)k * n_blocks;
+  const uint32_t per = (n_blocks + 1023) / 1024;
+  const uint32_t lo = min(n_blocks, threadIdx.x * per), hi = min(n_blocks, lo + per);
+  uint32_t sum = 0;
+  for (uint32_t i = lo; i < hi; i++) sum += a[i];
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t run = 0;
+    for (uint32_t i = 0; i < 1024; i++) {
+      const uint32_t v = part[i];
+      part[i] = run;
+      run += v;
+    }
+    totals[k] = run;
+  }
+  __syncthreads();
+  uint32_t run = part[threadIdx.x];
+  for (uint32_t i = lo; i < hi; i++) {
+    const uint32_t v = a[i];
+    a[i] = run;
+    run += v;
+  }
+}
+
+struct TierLists {
+  uint32_t *list[4];
+};
+__global__ __launch_bounds__(256) void k_tier_scatter(const uint8_t *__restrict__ tier, uint64_t n,
+                                                      const uint32_t *__restrict__ block_hist, uint32_t n_blocks,
+                                                      TierLists out) {
+  __shared__ uint32_t base[4];       // running position of each tier inside this block
+  __shared__ uint32_t wave_cnt[4][4];
+  if (threadIdx.x < 4) base[threadIdx.x] = block_hist[threadIdx.x * n_blocks + blockIdx.x];
+  __syncthreads();
+  const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint64_t b0 = (uint64_t)blockIdx.x * TIER_ITEMS;
+  for (uint32_t r = 0; r < TIER_ITEMS / 256; r++) {
+    const uint64_t i = b0 + (uint64_t)r * 256 + threadIdx.x;
+    const int tk = i < n ? (int)(tier[i] & 3) : -1;
+    uint32_t rank = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint64_t m = __ballot(tk == k);
+      if (tk == k) rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+      if (lane == 0) wave_cnt[k][wv] = (uint32_t)__popcll(m);
+    }
+    __syncthreads();
+    if (tk >= 0) {
+      uint32_t off = base[tk] + rank;
+      for (uint32_t w = 0; w < wv; w++) off += wave_cnt[tk][w];
+      out.list[tk][off] = (uint32_t)i;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4)
+      base[threadIdx.x] += wave_cnt[threadIdx.x][0] + wave_cnt[threadIdx.x][1] + wave_cnt[threadIdx.x][2] +
+                           wave_cnt[threadIdx.x][3];
+    __syncthreads();
+  }
+}
+
 // ---- banded anti-diagonal kernel ---------------------------------------------------------------
 // Exact pruning with an a-posteriori certificate.  The group sweeps the 64 diagonals around the
 // seed diagonal; the best score S1 found there is the score of a real alignment, hence a lower
@@ -256,13 +526,13 @@ __global__ __launch_bounds__(256) void k_sw(kslam_overlap *__restrict__ ov, uint
 // `list` (optional) maps work items to candidates; todo[] is indexed by work item.
 template <int LMAX, int GL, int DPL>
 __global__ __launch_bounds__(256) void k_sw_band(kslam_overlap *__restrict__ ov, uint64_t n, SwInputs in, SwParams p,
-                                                 uint32_t *__restrict__ band0, uint32_t *__restrict__ todo,
-                                                 const uint32_t *__restrict__ list) {
+                                                 uint32_t *__restrict__ band0, const uint32_t *__restrict__ list,
+                                                 uint32_t *__restrict__ next_list, uint32_t *__restrict__ next_count) {
   constexpr int NG = 256 / GL;          // candidates per block
   constexpr int ND = DPL * GL;          // diagonals swept (DPL adjacent diagonals per lane)
-  __shared__ uint8_t s_q[NG][LMAX];
-  __shared__ uint8_t s_w[NG][LMAX];
-  __shared__ uint32_t s_tab[NG][LMAX];
+  __shared__ __attribute__((aligned(16))) uint8_t s_q[NG][LMAX + STAGE_PAD];
+  __shared__ __attribute__((aligned(16))) uint8_t s_w[NG][LMAX + STAGE_PAD];
+  __shared__ __attribute__((aligned(16))) uint32_t s_tab[NG][LMAX + STAGE_PAD];
   const int32_t lane = threadIdx.x & 63;
   const int32_t t = lane & (GL - 1);
   const int32_t grp = threadIdx.x / GL;
@@ -270,23 +540,18 @@ __global__ __launch_bounds__(256) void k_sw_band(kslam_overlap *__restrict__ ov,
   const bool have = gi < n;
   const uint64_t ci = have ? (list ? list[gi] : gi) : 0;
   int32_t L = 0, W = 0, rel = 0;
-  if (have) {
+  const uint8_t *qc = s_q[grp], *wc = s_w[grp];   // read codes, window codes x 6 (the bfe offset)
+  const uint32_t *tab = s_tab[grp];               // 6-bit packed score row per read base
+  if (have && p.ablate < 2) {
     const kslam_overlap o = ov[ci];
     rel = o.rel;
-    stage_candidate<GL>(o, in, t, s_q[grp], s_w[grp], &L, &W);
+    const Staged st = stage_candidate_wide<GL, 6>(o, in, t, s_q[grp], s_w[grp], s_tab[grp], p);
+    L = st.L;
+    W = st.W;
+    qc += st.qoff;
+    wc += st.woff;
+    tab += st.qoff;
   }
-  __syncthreads();
-  for (int32_t i = t; i < L; i += GL) {   // 6-bit packed score row per query base
-    const uint32_t q = s_q[grp][i];
-    uint32_t tb = 0;
-#pragma unroll
-    for (uint32_t c = 0; c < 4; c++) {
-      const int32_t s = q > 3u ? 0 : (q == c ? p.match : -p.mismatch);
-      tb |= ((uint32_t)s & 63u) << (6 * c);
-    }
-    s_tab[grp][i] = tb;
-  }
-  for (int32_t j = t; j < W; j += GL) s_w[grp][j] = (uint8_t)(s_w[grp][j] * 6u);   // bfe offset of the column code
   __syncthreads();
   const int32_t gO = p.gap_open << KB, gE = p.gap_extend << KB;
   const int32_t NEG = -((p.gap_open + p.gap_extend + 1) << KB);
@@ -311,14 +576,14 @@ __global__ __launch_bounds__(256) void k_sw_band(kslam_overlap *__restrict__ ov,
     vs[q] = lo - i0;
     vl[q] = (uint32_t)max(hi - lo, 0);
     Zq[q] = 513 * i0 + 512 * d + 513;
-    ta[q] = s_tab[grp] + i0;
-    wa[q] = s_w[grp] + (i0 + d);
+    ta[q] = tab + i0;
+    wa[q] = wc + (i0 + d);
     Hd[q] = d >= 0 ? (d << 9) : -d;    // virtual predecessor of the diagonal's first cell
     Eo[q] = NEG;
     Fo[q] = NEG;
   }
   int32_t lbV = 0, lbZ = 0;
-  const int32_t nturns = have ? ((L + W - 2 - k0) >> 1) + 1 : 0;
+  const int32_t nturns = have && !p.ablate ? ((L + W - 2 - k0) >> 1) + 1 : 0;
   auto cell = [&](int q, int32_t n, int32_t Ein, int32_t Fin) {
     if ((uint32_t)(n - vs[q]) < vl[q]) {
       const int32_t s = __builtin_amdgcn_sbfe(*ta[q], (uint32_t)*wa[q], 6);
@@ -364,27 +629,18 @@ __global__ __launch_bounds__(256) void k_sw_band(kslam_overlap *__restrict__ ov,
   }
   const PassResult f = reduce_best<GL>(lbV, lbZ);
   // certificate: every alignment scoring >= f.score lies inside [dlo, dlo + ND - 1]
-  bool exact = false;
-  if (have && f.score > 0) {
-    int32_t rlo = 1 << 20, rhi = -(1 << 20);
-    const int32_t Lm = min(L, W);
-    for (int32_t g = 0; g < 2048; g++) {
-      const int32_t cost = g == 0 ? 0 : p.gap_open + (g - 1) * p.gap_extend;
-      const int32_t m0 = (f.score + cost + p.match - 1) / p.match;
-      if (m0 > Lm) break;
-      rlo = min(rlo, -(L - m0) - g);
-      rhi = max(rhi, (W - m0) + g);
+  const bool exact = have && band_certifies(f.score, L, W, dlo, ND, p);
+  {  // the others go on to the next tier: one atomic per wave reserves their list slots
+    const bool fail = have && t == 0 && !exact;
+    const uint64_t m = __ballot(fail);
+    if (m) {
+      uint32_t base = 0;
+      if (lane == (int32_t)__builtin_ctzll(m)) base = atomicAdd(next_count, (uint32_t)__popcll(m));
+      base = __shfl(base, __builtin_ctzll(m), 64);
+      if (fail) next_list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)ci;
     }
-    exact = rlo >= dlo && rhi <= dlo + ND - 1;
   }
-  if (have && t == 0) todo[gi] = exact ? 0u : 1u;
-  sw_epilogue<GL, 6>(ov, ci, exact, t, L, f, s_q[grp], s_w[grp], p, band0);
-}
-
-__global__ void k_scatter_todo(const uint32_t *__restrict__ flags, const uint32_t *__restrict__ pos, uint64_t n,
-                               const uint32_t *__restrict__ src, uint32_t *__restrict__ list) {
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n && flags[i]) list[pos[i]] = src ? src[i] : (uint32_t)i;
+  sw_epilogue<GL, 6>(ov, ci, exact, t, L, f, qc, wc, p, band0);
 }
 
 }  // namespace
@@ -396,51 +652,73 @@ void sw_scores(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, uint32_
   if (max_read_len > 511) throw StatusError{KSLAM_ERR_UNSUPPORTED, "reads longer than 511 bases are not supported yet"};
   if (n >= (1ull << 32)) throw StatusError{KSLAM_ERR_UNSUPPORTED, ">= 2^32 candidates in one chunk"};
   const int lm = max_read_len <= 160 ? 0 : (max_read_len <= 256 ? 1 : 2);
-  const uint32_t *list = nullptr;
-  uint64_t m = n;
+  const uint32_t *full_list = nullptr;
+  uint64_t n_full = n;
   const char *force_full = getenv("KSLAM_SW_FULL");
+  const bool debug = getenv("KSLAM_DEBUG") != nullptr;
+  if (const char *ab = getenv("KSLAM_SW_ABLATE")) p.ablate = (uint32_t)atoi(ab);
   if (!(force_full && force_full[0] == '1')) {
-    W.flags.ensure(n * sizeof(uint32_t));
-    W.pos.ensure(n * sizeof(uint32_t));
-    W.list.ensure(n * sizeof(uint32_t));
-    W.list2.ensure(n * sizeof(uint32_t));
-    W.scan_tmp.ensure(scan_tmp_bytes(n));
-    W.totals.ensure(2 * sizeof(uint64_t));
-    // tier 1: 32 diagonals (8 lanes x 4), tier 2: 64 (16 x 4), tier 3 (reads > 160 bases): 128
-    // (16 x 8); each carries an exactness certificate, whatever fails it goes on to the next tier
-    const int n_tiers = lm == 0 ? 2 : 3;
-    for (int tier = 0; tier < n_tiers && m; tier++) {
-      uint32_t *flags = W.flags.as<uint32_t>();
-      uint32_t *out_list = (tier & 1) == 0 ? W.list.as<uint32_t>() : W.list2.as<uint32_t>();
+    // banded tiers of 16 / 32 / 64 (/ 128 for reads > 160 bases) diagonals; k_sw_plan sends each
+    // candidate to the narrowest one its seed diagonal already certifies, the others start at 32;
+    // whatever fails a tier's certificate is appended to the next tier's list, and what fails the
+    // widest goes to the full-matrix kernel
+    const int n_tiers = lm == 0 ? 3 : 4;
+    W.flags.ensure(n);                                   // tier per candidate (u8)
+    for (int k = 0; k < 4; k++) W.tier_list[k].ensure((n + 1) * sizeof(uint32_t));
+    W.list.ensure((n + 1) * sizeof(uint32_t));           // list for the full-matrix kernel
+    const uint32_t n_blocks = (uint32_t)((n + TIER_ITEMS - 1) / TIER_ITEMS);
+    W.pos.ensure((size_t)4 * n_blocks * sizeof(uint32_t));
+    W.totals.ensure(16 * sizeof(uint32_t));
+    uint8_t *tier = W.flags.as<uint8_t>();
+    uint32_t *counts = W.totals.as<uint32_t>();          // [0..3] tier sizes, [4] full-matrix list size
+    HIPCHK(hipMemsetAsync(counts, 0, 16 * sizeof(uint32_t), s));
+    const unsigned pb = (unsigned)((n + 31) / 32);
+    if (lm == 0) hipLaunchKernelGGL(k_sw_plan<160>, dim3(pb), dim3(256), 0, s, d_ov, n, in, p, n_tiers, tier);
+    else if (lm == 1) hipLaunchKernelGGL(k_sw_plan<256>, dim3(pb), dim3(256), 0, s, d_ov, n, in, p, n_tiers, tier);
+    else hipLaunchKernelGGL(k_sw_plan<512>, dim3(pb), dim3(256), 0, s, d_ov, n, in, p, n_tiers, tier);
+    hipLaunchKernelGGL(k_tier_hist, dim3(n_blocks), dim3(256), 0, s, tier, n, W.pos.as<uint32_t>(), n_blocks);
+    hipLaunchKernelGGL(k_tier_scan, dim3(4), dim3(1024), 0, s, W.pos.as<uint32_t>(), n_blocks, counts);
+    TierLists TL;
+    for (int k = 0; k < 4; k++) TL.list[k] = W.tier_list[k].as<uint32_t>();
+    hipLaunchKernelGGL(k_tier_scatter, dim3(n_blocks), dim3(256), 0, s, tier, n, W.pos.as<uint32_t>(), n_blocks, TL);
+    uint32_t h[5] = {0, 0, 0, 0, 0};
+    for (int k = 0; k < n_tiers; k++) {
+      // the size of tier k: planned + appended by the tier before it (both in counts[k] by now)
+      HIPCHK(hipMemcpyAsync(h, counts, sizeof h, hipMemcpyDeviceToHost, s));
+      HIPCHK(hipStreamSynchronize(s));
+      const uint64_t m = h[k];
+      if (debug) fprintf(stderr, "[kslam] SW tier %d (%d diagonals): %llu candidates\n", k, 16 << k, (unsigned long long)m);
+      if (!m) continue;
+      const uint32_t *list = TL.list[k];
+      uint32_t *nl = k + 1 < n_tiers ? TL.list[k + 1] : W.list.as<uint32_t>();
+      uint32_t *nc = k + 1 < n_tiers ? counts + k + 1 : counts + 4;
       const unsigned b8 = (unsigned)((m + 31) / 32), b16 = (unsigned)((m + 15) / 16);
 #define KSLAM_BAND(LM, GLV, DPLV, NB) \
-  hipLaunchKernelGGL((k_sw_band<LM, GLV, DPLV>), dim3(NB), dim3(256), 0, s, d_ov, m, in, p, d_band0, flags, list)
-      if (tier == 0) {
+  hipLaunchKernelGGL((k_sw_band<LM, GLV, DPLV>), dim3(NB), dim3(256), 0, s, d_ov, m, in, p, d_band0, list, nl, nc)
+      if (k == 0) {
+        if (lm == 0) KSLAM_BAND(160, 8, 2, b8); else if (lm == 1) KSLAM_BAND(256, 8, 2, b8); else KSLAM_BAND(512, 8, 2, b8);
+      } else if (k == 1) {
         if (lm == 0) KSLAM_BAND(160, 8, 4, b8); else if (lm == 1) KSLAM_BAND(256, 8, 4, b8); else KSLAM_BAND(512, 8, 4, b8);
-      } else if (tier == 1) {
+      } else if (k == 2) {
         if (lm == 0) KSLAM_BAND(160, 16, 4, b16); else if (lm == 1) KSLAM_BAND(256, 16, 4, b16); else KSLAM_BAND(512, 16, 4, b16);
       } else {
         if (lm == 1) KSLAM_BAND(256, 16, 8, b16); else KSLAM_BAND(512, 16, 8, b16);
       }
 #undef KSLAM_BAND
-      exclusive_scan_u32(flags, W.pos.as<uint32_t>(), m, W.totals.as<uint64_t>(), W.scan_tmp.p, s);
-      uint64_t m2 = 0;
-      HIPCHK(hipMemcpyAsync(&m2, W.totals.p, sizeof m2, hipMemcpyDeviceToHost, s));
-      HIPCHK(hipStreamSynchronize(s));
-      if (m2) hipLaunchKernelGGL(k_scatter_todo, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, flags,
-                                 W.pos.as<uint32_t>(), m, list, out_list);
-      if (getenv("KSLAM_DEBUG")) fprintf(stderr, "[kslam] SW tier %d: %llu candidates in, %llu left\n", tier + 1,
-                                          (unsigned long long)m, (unsigned long long)m2);
-      list = out_list;
-      m = m2;
     }
+    HIPCHK(hipMemcpyAsync(h, counts, sizeof h, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    n_full = h[4];
+    full_list = W.list.as<uint32_t>();
+    if (debug) fprintf(stderr, "[kslam] SW full matrix: %llu candidates\n", (unsigned long long)n_full);
   }
-  if (n_full_out) *n_full_out = m;
-  if (m) {  // full matrix for the rest
+  if (n_full_out) *n_full_out = n_full;
+  if (n_full) {  // full matrix for the rest
+    const uint64_t m = n_full;
     const unsigned b2 = (unsigned)((m + 15) / 16);
-    if (lm == 0) hipLaunchKernelGGL(k_sw<10>, dim3(b2), dim3(256), 0, s, d_ov, m, in, p, d_band0, list);
-    else if (lm == 1) hipLaunchKernelGGL(k_sw<16>, dim3(b2), dim3(256), 0, s, d_ov, m, in, p, d_band0, list);
-    else hipLaunchKernelGGL(k_sw<32>, dim3(b2), dim3(256), 0, s, d_ov, m, in, p, d_band0, list);
+    if (lm == 0) hipLaunchKernelGGL(k_sw<10>, dim3(b2), dim3(256), 0, s, d_ov, m, in, p, d_band0, full_list);
+    else if (lm == 1) hipLaunchKernelGGL(k_sw<16>, dim3(b2), dim3(256), 0, s, d_ov, m, in, p, d_band0, full_list);
+    else hipLaunchKernelGGL(k_sw<32>, dim3(b2), dim3(256), 0, s, d_ov, m, in, p, d_band0, full_list);
   }
   HIPCHK(hipGetLastError());
 }

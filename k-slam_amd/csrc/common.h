@@ -179,7 +179,14 @@ struct SwInputs {
   const uint64_t *read_off;   // [n_reads + 1]
   const uint8_t *genome_bases;
   const uint64_t *genome_off; // [n_entries + 1]
+  // the same two arrays as base codes (encode_bases): what the SW kernels stage from
+  const uint8_t *read_codes = nullptr;
+  const uint8_t *genome_codes = nullptr;
 };
+// One byte per base: bits 0..2 = SSW code 0..4 (ssw_code), bit 3 = "upper-case A/C/G/T", i.e. the
+// bases inPlaceReverseComplement complements (ssw_code_complemented(c) = bit 3 ? 3 - code : code).
+// Done once per index and once per read batch so that no SW kernel decodes ASCII again.
+void encode_bases(const uint8_t *d_src, uint8_t *d_dst, uint64_t n, hipStream_t s);
 // forward + reverse passes for n candidates (in place on d_ov: window-relative,
 // unflipped coordinates); d_band0[i] = initial band width for banded_sw
 // (0 = no cigar wanted, ssw.c:924-927)

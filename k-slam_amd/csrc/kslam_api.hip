@@ -25,7 +25,7 @@ struct kslam_ctx {
   uint64_t n_entries = 0;
   uint64_t max_entry_len = 0;
   std::vector<uint64_t> h_goff;  // [n_entries + 1]
-  DevBuf g_bases, g_off;
+  DevBuf g_bases, g_off, g_codes;   // g_codes: encode_bases(g_bases)
   uint64_t n_gk = 0;
   DevBuf gk_key, gk_meta, gk_off, g_bucket;
   uint32_t bucket_bits = 8;
@@ -35,7 +35,7 @@ struct kslam_ctx {
   uint64_t n_reads = 0;
   uint32_t max_read_len = 0;
   std::vector<uint64_t> h_roff;  // [n_reads + 1]
-  DevBuf r_bases, r_off, r_len;
+  DevBuf r_bases, r_off, r_len, r_codes;
 
   // ---- work buffers ----
   DevBuf nk, nseg, rec_start, seg_start, segs, scan_tmp, totals;
@@ -232,6 +232,8 @@ void build_index(kslam_ctx *c) {
   if (c->max_entry_len >= (1ull << 32)) throw StatusError{KSLAM_ERR_UNSUPPORTED, "entry longer than 2^32 bases"};
   c->g_off.ensure((n + 1) * sizeof(uint64_t));
   HIPCHK(hipMemcpyAsync(c->g_off.p, c->h_goff.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+  c->g_codes.ensure(c->h_goff[n] + 64);
+  encode_bases(c->g_bases.as<uint8_t>(), c->g_codes.as<uint8_t>(), c->h_goff[n] + 48, s);
   Planned pl = plan_host(c->h_goff.data(), n, KSLAM_K / 2);  // gap k/2, SLAM.h:64
   if (pl.n_kmers >= (1ull << 32)) throw StatusError{KSLAM_ERR_UNSUPPORTED, "more than 2^32 genome k-mers"};
   c->n_gk = pl.n_kmers;
@@ -272,6 +274,8 @@ void finish_load_reads(kslam_ctx *c) {
   c->max_read_len = (uint32_t)mx;
   c->r_off.ensure((n + 1) * sizeof(uint64_t));
   HIPCHK(hipMemcpyAsync(c->r_off.p, c->h_roff.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+  c->r_codes.ensure(c->h_roff[n] + 64);
+  encode_bases(c->r_bases.as<uint8_t>(), c->r_codes.as<uint8_t>(), c->h_roff[n] + 48, s);
   c->r_len.ensure((n + 1) * sizeof(uint32_t));
   if (n) hipLaunchKernelGGL(k_lens, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, c->r_off.as<uint64_t>(), n,
                             c->r_len.as<uint32_t>());
@@ -317,6 +321,7 @@ void align_resident(kslam_ctx *c, bool stop_after_join, uint64_t *n_raw_out) {
   SwInputs in;
   in.read_bases = c->r_bases.as<uint8_t>(); in.read_off = c->r_off.as<uint64_t>();
   in.genome_bases = c->g_bases.as<uint8_t>(); in.genome_off = c->g_off.as<uint64_t>();
+  in.read_codes = c->r_codes.as<uint8_t>(); in.genome_codes = c->g_codes.as<uint8_t>();
   SwParams sp;
   sp.match = (int32_t)c->prm.match; sp.mismatch = (int32_t)c->prm.mismatch;
   sp.gap_open = (int32_t)c->prm.gap_open; sp.gap_extend = (int32_t)c->prm.gap_extend;
@@ -514,7 +519,7 @@ void kslam_destroy(kslam_ctx *c) {
   if (c->device >= 0) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    DevBuf *bufs[] = {&c->g_bases, &c->g_off, &c->gk_key, &c->gk_meta, &c->gk_off, &c->g_bucket, &c->r_bases,
+    DevBuf *bufs[] = {&c->g_codes, &c->r_codes, &c->g_bases, &c->g_off, &c->gk_key, &c->gk_meta, &c->gk_off, &c->g_bucket, &c->r_bases,
                       &c->r_off, &c->r_len, &c->nk, &c->nseg, &c->rec_start, &c->seg_start, &c->segs, &c->scan_tmp,
                       &c->totals, &c->recs_a, &c->recs_b, &c->block_tot, &c->block_base, &c->ovk_a, &c->ovk_b,
                       &c->flags, &c->pos, &c->band0, &c->sortws.hist, &c->sortws.status, &c->sortws.tickets,

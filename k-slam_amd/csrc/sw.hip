@@ -176,22 +176,21 @@ __device__ inline void stage_candidate(const kslam_overlap &o, const SwInputs &i
 // The byte-at-a-time staging above costs as much as the banded DP itself (one memory instruction
 // and one LDS store per base).  Here a span is fetched as 16-byte chunks from the 16-byte-aligned
 // address below it, a chunk per lane, converted in registers and stored with one 16-byte LDS
-// write -- at the chunk's own position, NOT re-aligned: the buffer holds the codes of the aligned
+// write (the sources are the pre-encoded base arrays, see encode_bases) -- at the chunk's own
+// position, NOT re-aligned: the buffer holds the codes of the aligned
 // chunks and the caller gets the offset at which its span starts.  A reverse-complemented window
 // stores the chunks in reverse order with their bytes reversed, which lands the reversed span at a
 // (different) offset of the same buffer.  Both base arrays are the library's own copies: 256-byte
 // aligned starts and 64 bytes of slack at the end, so the aligned reads never leave them.
 constexpr int STAGE_PAD = 32;   // bytes a span buffer needs beyond the longest span
 
+// four encoded bases (see encode_bases) -> four SSW codes x WS, optionally complemented
 template <int WS>
 __device__ inline uint32_t codes_of_dword(uint32_t v, bool comp) {
-  uint32_t out = 0;
-#pragma unroll
-  for (int b = 0; b < 4; b++) {
-    const uint32_t ch = (v >> (8 * b)) & 0xFFu;
-    out |= ((comp ? ssw_code_complemented(ch) : ssw_code(ch)) * (uint32_t)WS) << (8 * b);
-  }
-  return out;
+  uint32_t c = v & 0x07070707u;
+  if (comp) c ^= ((v >> 3) & 0x01010101u) * 3u;   // 3 - code where the base is complementable
+  if (WS == 6) c = (c << 2) + (c << 1);           // codes <= 4: no carry between the bytes
+  return c;
 }
 
 // 6-bit packed score row (one field per reference code 0..3, code 4 reads the clear bits 24..29)
@@ -260,8 +259,8 @@ __device__ inline Staged stage_candidate_wide(const kslam_overlap &o, const SwIn
   Staged st;
   st.L = L;
   st.W = wlen;
-  st.qoff = stage_span<GL, 1>(in.read_bases + ro, L, false, t, sq, tab, p);
-  st.woff = stage_span<GL, WS>(in.genome_bases + go + s0, wlen, o.revcomp != 0, t, sw, nullptr, p);   // :207
+  st.qoff = stage_span<GL, 1>(in.read_codes + ro, L, false, t, sq, tab, p);
+  st.woff = stage_span<GL, WS>(in.genome_codes + go + s0, wlen, o.revcomp != 0, t, sw, nullptr, p);   // :207
   return st;
 }
 
@@ -530,9 +529,17 @@ __global__ __launch_bounds__(256) void k_sw_band(kslam_overlap *__restrict__ ov,
                                                  uint32_t *__restrict__ next_list, uint32_t *__restrict__ next_count) {
   constexpr int NG = 256 / GL;          // candidates per block
   constexpr int ND = DPL * GL;          // diagonals swept (DPL adjacent diagonals per lane)
+  // The sweep also computes cells that lie outside the matrix near its corners (no per-cell range
+  // test): the score rows and the window are padded by PADM entries of "scores 0 against
+  // everything" on both sides.  Such cells can only hold values derived from real ones by standing
+  // still or paying for gaps, so they never beat a real maximum (strictly), and nothing flows from
+  // them back into the matrix: before the matrix they hold exactly the zero-score value Z a fresh
+  // alignment starts from, after it every dependency points further out.
+  constexpr int PADM = ND == 16 ? 16 : (ND == 32 ? 32 : (ND == 64 ? 48 : 80));   // >= ND / 2 + 2, x16
+  constexpr int ROW = LMAX + STAGE_PAD + 2 * PADM;
   __shared__ __attribute__((aligned(16))) uint8_t s_q[NG][LMAX + STAGE_PAD];
-  __shared__ __attribute__((aligned(16))) uint8_t s_w[NG][LMAX + STAGE_PAD];
-  __shared__ __attribute__((aligned(16))) uint32_t s_tab[NG][LMAX + STAGE_PAD];
+  __shared__ __attribute__((aligned(16))) uint8_t s_w[NG][ROW];
+  __shared__ __attribute__((aligned(16))) uint32_t s_tab[NG][ROW];
   const int32_t lane = threadIdx.x & 63;
   const int32_t t = lane & (GL - 1);
   const int32_t grp = threadIdx.x / GL;
@@ -540,12 +547,13 @@ __global__ __launch_bounds__(256) void k_sw_band(kslam_overlap *__restrict__ ov,
   const bool have = gi < n;
   const uint64_t ci = have ? (list ? list[gi] : gi) : 0;
   int32_t L = 0, W = 0, rel = 0;
-  const uint8_t *qc = s_q[grp], *wc = s_w[grp];   // read codes, window codes x 6 (the bfe offset)
-  const uint32_t *tab = s_tab[grp];               // 6-bit packed score row per read base
+  const uint8_t *qc = s_q[grp];
+  uint8_t *wc = s_w[grp] + PADM;         // window codes x 6 (the bfe offset)
+  uint32_t *tab = s_tab[grp] + PADM;     // 6-bit packed score row per read base
   if (have && p.ablate < 2) {
     const kslam_overlap o = ov[ci];
     rel = o.rel;
-    const Staged st = stage_candidate_wide<GL, 6>(o, in, t, s_q[grp], s_w[grp], s_tab[grp], p);
+    const Staged st = stage_candidate_wide<GL, 6>(o, in, t, s_q[grp], wc, tab, p);
     L = st.L;
     W = st.W;
     qc += st.qoff;
@@ -553,78 +561,92 @@ __global__ __launch_bounds__(256) void k_sw_band(kslam_overlap *__restrict__ ov,
     tab += st.qoff;
   }
   __syncthreads();
+  for (int32_t x = t; x < PADM; x += GL) {   // the padding, after the chunk stores it overlaps
+    tab[x - PADM] = 0u;
+    tab[L + x] = 0u;
+    wc[x - PADM] = 24;                       // code 4 x 6: the clear bits 24..29 of every score row
+    wc[W + x] = 24;
+  }
+  __syncthreads();
   const int32_t gO = p.gap_open << KB, gE = p.gap_extend << KB;
   const int32_t NEG = -((p.gap_open + p.gap_extend + 1) << KB);
   const int32_t d0 = rel < 0 ? rel : 0;          // seed diagonal: read base i sits on window base i + d0
-  const int32_t dlo = d0 - ND / 2;
+  const int32_t dlo = d0 - ND / 2, dhi = dlo + ND - 1;
+  // anti-diagonals k = i + j that hold a matrix cell of some band diagonal: diagonal d spans
+  // k = |d| .. (d <= W - L ? 2L - 2 + d : 2W - 2 - d)
+  const int32_t kmin = dhi >= 0 ? 0 : -dhi;
+  const int32_t dstar = min(max(W - L, dlo), dhi);
+  const int32_t kmax = dstar <= W - L ? 2 * L - 2 + dstar : 2 * W - 2 - dstar;
   // diagonals q = 0, 2 have the parity of dlo, q = 1, 3 the other one; phase A runs at k, phase B
-  // at k + 1; start one pair early when dlo is odd so that anti-diagonal 0 is not skipped
-  const int32_t k0 = (dlo & 1) ? -1 : 0;
-  // Per-diagonal running state, all linear in the loop turn n (cell row i = i0 + n):
-  //   vs/vl: the cell is inside the matrix iff (unsigned)(n - vs) < vl
-  //   Z    : ((j + 1) << 9) | (i + 1) = 513 i + 512 d + 513 for in-matrix cells
-  //   ta/wa: LDS addresses of the cell's score row and (6x pre-scaled) column code
-  int32_t Hd[DPL], Eo[DPL], Fo[DPL], vs[DPL], Zq[DPL];
-  uint32_t vl[DPL];
-  const uint32_t *ta[DPL];
-  const uint8_t *wa[DPL];
+  // at k + 1, so the first k has the parity of dlo
+  const int32_t k0 = kmin - ((kmin - dlo) & 1);
+  // The lane's DPL diagonals d = db + q come in pairs (q = 2h, 2h + 1).  On turn n pair h sits on
+  // read row i = ib - h + n (both of its cells: phase B runs one anti-diagonal later) and on window
+  // columns jb + h + n and jb + h + 1 + n.  So one score-row pointer and one window pointer per lane
+  // serve all cells with constant offsets, and every Z = ((j + 1) << 9) | (i + 1) = 513 i + 512 d + 513
+  // is a constant away from the lane's Z of diagonal 0.
+  const int32_t db = dlo + DPL * t;
+  const int32_t ib = (k0 - db) >> 1;                 // exact: k0 and dlo have the same parity, DPL is even
+  const uint32_t *tp = tab + (ib - (DPL / 2 - 1));   // tp[DPL/2 - 1 - h]: score row of pair h
+  const uint8_t *wp = wc + (ib + db);                // wp[h], wp[h + 1]: window codes of pair h
+  int32_t Zb = 513 * ib + 512 * db + 513;
+  int32_t Hd[DPL], Eo[DPL], Fo[DPL];
 #pragma unroll
   for (int q = 0; q < DPL; q++) {
-    const int32_t d = dlo + DPL * t + q;
-    const int32_t i0 = (k0 + (q & 1) - d) >> 1;
-    const int32_t lo = d < 0 ? -d : 0, hi = min(L, W - d);
-    vs[q] = lo - i0;
-    vl[q] = (uint32_t)max(hi - lo, 0);
-    Zq[q] = 513 * i0 + 512 * d + 513;
-    ta[q] = tab + i0;
-    wa[q] = wc + (i0 + d);
-    Hd[q] = d >= 0 ? (d << 9) : -d;    // virtual predecessor of the diagonal's first cell
+    const int h = q >> 1;
+    Hd[q] = Zb + (-513 * h + 512 * q) - 513;   // the cell before the first one: zero score, Z of its own
     Eo[q] = NEG;
     Fo[q] = NEG;
   }
   int32_t lbV = 0, lbZ = 0;
-  const int32_t nturns = have && !p.ablate ? ((L + W - 2 - k0) >> 1) + 1 : 0;
-  auto cell = [&](int q, int32_t n, int32_t Ein, int32_t Fin) {
-    if ((uint32_t)(n - vs[q]) < vl[q]) {
-      const int32_t s = __builtin_amdgcn_sbfe(*ta[q], (uint32_t)*wa[q], 6);
-      const int32_t Z = Zq[q];
-      int32_t h = max(max(Hd[q] + (s << KB), Ein), Fin);
-      h = max(h, Z);
-      Hd[q] = h;
-      const int32_t hg = h - gO;
-      Eo[q] = max(Ein - gE, hg);
-      Fo[q] = max(Fin - gE, hg);
-      const bool up = h > (lbV | KEYMASK);
-      lbV = up ? h : lbV;
-      lbZ = up ? Z : lbZ;
-    }
-    Zq[q] += 513;
-    ta[q] += 1;
-    wa[q] += 1;
+  const int32_t nturns = have && !p.ablate && L > 0 && W > 0 && kmax >= k0 ? ((kmax - k0) >> 1) + 1 : 0;
+  uint32_t trow[DPL / 2], wcode[DPL / 2 + 1];
+  auto cell = [&](int q, int32_t Ein, int32_t Fin) {
+    const int h = q >> 1;
+    const int32_t s = __builtin_amdgcn_sbfe(trow[h], wcode[h + (q & 1)], 6);
+    const int32_t Z = Zb + (-513 * h + 512 * q);
+    int32_t hv = max(max(Hd[q] + (s << KB), Ein), Fin);
+    hv = max(hv, Z);
+    Hd[q] = hv;
+    const int32_t hg = hv - gO;
+    Eo[q] = max(Ein - gE, hg);
+    Fo[q] = max(Fin - gE, hg);
+    const bool up = hv > (lbV | KEYMASK);
+    lbV = up ? hv : lbV;
+    lbZ = up ? Z : lbZ;
   };
   for (int32_t n = 0;; n++) {
     if (__ballot(n < nturns) == 0ull) break;
-    {  // phase A: the lane's even diagonals; E comes from the odd diagonal below, F from the one above
-      const int32_t ein = dpp_row_shr1(Eo[DPL - 1]);
-      int32_t e[DPL / 2], f[DPL / 2];
+    if (n < nturns) {   // a candidate that is done must not run on into its neighbours' buffers
 #pragma unroll
-      for (int h = 0; h < DPL / 2; h++) {
-        e[h] = h == 0 ? (t == 0 ? NEG : ein) : Eo[2 * h - 1];
-        f[h] = Fo[2 * h + 1];
+      for (int h = 0; h < DPL / 2; h++) trow[h] = tp[DPL / 2 - 1 - h];
+#pragma unroll
+      for (int h = 0; h <= DPL / 2; h++) wcode[h] = wp[h];
+      tp += 1;
+      wp += 1;
+      {  // phase A: the lane's even diagonals; E comes from the odd diagonal below, F from the one above
+        const int32_t ein = dpp_row_shr1(Eo[DPL - 1]);
+        int32_t e[DPL / 2], f[DPL / 2];
+#pragma unroll
+        for (int h = 0; h < DPL / 2; h++) {
+          e[h] = h == 0 ? (t == 0 ? NEG : ein) : Eo[2 * h - 1];
+          f[h] = Fo[2 * h + 1];
+        }
+#pragma unroll
+        for (int h = 0; h < DPL / 2; h++) cell(2 * h, e[h], f[h]);
       }
+      {  // phase B: the odd diagonals
+        const int32_t fin = __builtin_amdgcn_update_dpp(0, Fo[0], 0x101, 0xF, 0xF, true);  // row_shl:1
+        int32_t e[DPL / 2], f[DPL / 2];
 #pragma unroll
-      for (int h = 0; h < DPL / 2; h++) cell(2 * h, n, e[h], f[h]);
-    }
-    {  // phase B: the odd diagonals
-      const int32_t fin = __builtin_amdgcn_update_dpp(0, Fo[0], 0x101, 0xF, 0xF, true);  // row_shl:1
-      int32_t e[DPL / 2], f[DPL / 2];
+        for (int h = 0; h < DPL / 2; h++) {
+          e[h] = Eo[2 * h];
+          f[h] = h == DPL / 2 - 1 ? (t == GL - 1 ? NEG : fin) : Fo[2 * h + 2];
+        }
 #pragma unroll
-      for (int h = 0; h < DPL / 2; h++) {
-        e[h] = Eo[2 * h];
-        f[h] = h == DPL / 2 - 1 ? (t == GL - 1 ? NEG : fin) : Fo[2 * h + 2];
+        for (int h = 0; h < DPL / 2; h++) cell(2 * h + 1, e[h], f[h]);
       }
-#pragma unroll
-      for (int h = 0; h < DPL / 2; h++) cell(2 * h + 1, n, e[h], f[h]);
+      Zb += 513;
     }
   }
   const PassResult f = reduce_best<GL>(lbV, lbZ);
@@ -644,6 +666,36 @@ __global__ __launch_bounds__(256) void k_sw_band(kslam_overlap *__restrict__ ov,
 }
 
 }  // namespace
+
+namespace {
+__global__ __launch_bounds__(256) void k_encode(const uint4 *__restrict__ src, uint4 *__restrict__ dst, uint64_t n16) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n16) return;
+  const uint4 v = src[i];
+  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+  uint32_t o[4];
+#pragma unroll
+  for (int d = 0; d < 4; d++) {
+    uint32_t out = 0;
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+      const uint32_t ch = (w[d] >> (8 * b)) & 0xFFu;
+      const uint32_t code = ssw_code(ch);
+      const uint32_t flag = ssw_code_complemented(ch) != code ? 8u : 0u;
+      out |= (code | flag) << (8 * b);
+    }
+    o[d] = out;
+  }
+  dst[i] = make_uint4(o[0], o[1], o[2], o[3]);
+}
+}  // namespace
+
+void encode_bases(const uint8_t *d_src, uint8_t *d_dst, uint64_t n, hipStream_t s) {
+  const uint64_t n16 = (n + 15) / 16;   // both arrays carry 64 bytes of slack
+  if (n16) hipLaunchKernelGGL(k_encode, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, s,
+                              reinterpret_cast<const uint4 *>(d_src), reinterpret_cast<uint4 *>(d_dst), n16);
+  HIPCHK(hipGetLastError());
+}
 
 void sw_scores(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, uint32_t max_read_len,
                uint32_t *d_band0, SwWork &W, uint64_t *n_full_out, hipStream_t s) {

@@ -523,11 +523,11 @@ __global__ __launch_bounds__(256) void k_tier_scatter(const uint8_t *__restrict_
 // boundary) and its own diagonal's H from step k-2.
 // GL = lanes per candidate: 8 (32 diagonals, 8 candidates per wave) or 16 (64 diagonals, 4 per wave).
 // `list` (optional) maps work items to candidates; todo[] is indexed by work item.
-template <int LMAX, int GL, int DPL>
-__global__ __launch_bounds__(256) void k_sw_band(kslam_overlap *__restrict__ ov, uint64_t n, SwInputs in, SwParams p,
+template <int LMAX, int GL, int DPL, int BS = 256>
+__global__ __launch_bounds__(BS) void k_sw_band(kslam_overlap *__restrict__ ov, uint64_t n, SwInputs in, SwParams p,
                                                  uint32_t *__restrict__ band0, const uint32_t *__restrict__ list,
                                                  uint32_t *__restrict__ next_list, uint32_t *__restrict__ next_count) {
-  constexpr int NG = 256 / GL;          // candidates per block
+  constexpr int NG = BS / GL;           // candidates per block
   constexpr int ND = DPL * GL;          // diagonals swept (DPL adjacent diagonals per lane)
   // The sweep also computes cells that lie outside the matrix near its corners (no per-cell range
   // test): the score rows and the window are padded by PADM entries of "scores 0 against
@@ -744,17 +744,23 @@ void sw_scores(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, uint32_
       const uint32_t *list = TL.list[k];
       uint32_t *nl = k + 1 < n_tiers ? TL.list[k + 1] : W.list.as<uint32_t>();
       uint32_t *nc = k + 1 < n_tiers ? counts + k + 1 : counts + 4;
-      const unsigned b8 = (unsigned)((m + 31) / 32), b16 = (unsigned)((m + 15) / 16);
-#define KSLAM_BAND(LM, GLV, DPLV, NB) \
-  hipLaunchKernelGGL((k_sw_band<LM, GLV, DPLV>), dim3(NB), dim3(256), 0, s, d_ov, m, in, p, d_band0, list, nl, nc)
+#define KSLAM_BAND(LM, GLV, DPLV, BSV) \
+  hipLaunchKernelGGL((k_sw_band<LM, GLV, DPLV, BSV>), dim3((unsigned)((m + (BSV / GLV) - 1) / (BSV / GLV))), dim3(BSV), 0, s, \
+                     d_ov, m, in, p, d_band0, list, nl, nc)
+      // lanes x diagonals per lane, measured on the bench workload: 8 x 8 beats 16 x 4 for the
+      // 64-diagonal tier (9.7 against 10.5 ms); 4-lane shapes lose (half the waves per LDS byte)
+      static const int shape = getenv("KSLAM_SW_SHAPE") ? atoi(getenv("KSLAM_SW_SHAPE")) : 4;   // tuning knob
       if (k == 0) {
-        if (lm == 0) KSLAM_BAND(160, 8, 2, b8); else if (lm == 1) KSLAM_BAND(256, 8, 2, b8); else KSLAM_BAND(512, 8, 2, b8);
+        if (lm == 0) { if (shape & 1) KSLAM_BAND(160, 4, 4, 128); else KSLAM_BAND(160, 8, 2, 256); }
+        else if (lm == 1) KSLAM_BAND(256, 8, 2, 256); else KSLAM_BAND(512, 8, 2, 256);
       } else if (k == 1) {
-        if (lm == 0) KSLAM_BAND(160, 8, 4, b8); else if (lm == 1) KSLAM_BAND(256, 8, 4, b8); else KSLAM_BAND(512, 8, 4, b8);
+        if (lm == 0) { if (shape & 2) KSLAM_BAND(160, 4, 8, 128); else KSLAM_BAND(160, 8, 4, 256); }
+        else if (lm == 1) KSLAM_BAND(256, 8, 4, 256); else KSLAM_BAND(512, 8, 4, 256);
       } else if (k == 2) {
-        if (lm == 0) KSLAM_BAND(160, 16, 4, b16); else if (lm == 1) KSLAM_BAND(256, 16, 4, b16); else KSLAM_BAND(512, 16, 4, b16);
+        if (lm == 0) { if (shape & 4) KSLAM_BAND(160, 8, 8, 128); else KSLAM_BAND(160, 16, 4, 256); }
+        else if (lm == 1) KSLAM_BAND(256, 16, 4, 256); else KSLAM_BAND(512, 16, 4, 256);
       } else {
-        if (lm == 1) KSLAM_BAND(256, 16, 8, b16); else KSLAM_BAND(512, 16, 8, b16);
+        if (lm == 1) KSLAM_BAND(256, 16, 8, 256); else KSLAM_BAND(512, 16, 8, 256);
       }
 #undef KSLAM_BAND
     }

@@ -19,6 +19,7 @@
 // are touched with coalesced 64-lane accesses that stay in L2.
 #include "common.h"
 #include "banded_core.h"
+#include "stage.h"
 
 namespace kslam {
 
@@ -37,7 +38,8 @@ __global__ void k_class_flags(const uint32_t *__restrict__ bw, const uint8_t *__
   const uint32_t b = bw[i];
   uint32_t f = 0;
   if (b != 0 && !(b >> 31)) {   // bit 31: inline <n>M set by the SW kernel
-    if (big) f = needbig[i] ? 1u : 0u;
+    if (big == 1) f = needbig[i] ? 1u : 0u;
+    else if (big == 2) f = (needbig[i] == 3 && band_class(b) == cls) ? 1u : 0u;   // sent back by the systolic kernel
     else f = (!needbig[i] && band_class(b) == cls) ? 1u : 0u;
   }
   flags[i] = f;
@@ -196,6 +198,7 @@ __global__ __launch_bounds__(64) void k_banded_lds(CigJob J, SwInputs in, SwPara
   if (have) {
     ci = J.list[J.list_base + li];
     o = J.ov[ci];
+    if (J.needbig[ci] == 3) J.needbig[ci] = 0;   // handed over by the systolic kernel
     band_width = (int32_t)J.bw[ci];
     refLen = o.ref_end - o.ref_begin + 1;    // ssw.c:930-931
     readLen = o.query_end - o.query_begin + 1;
@@ -264,6 +267,185 @@ __global__ __launch_bounds__(64) void k_banded_lds(CigJob J, SwInputs in, SwPara
   uint32_t *tmp = J.tmp + (uint64_t)(J.big ? (J.list_base + li) : ci) * J.cap;
   bool ovf = false;
   const int32_t l = banded_traceback(A, refLen, readLen, band_width, tmp, J.cap, &ovf);
+  if (l < 0) {
+    atomicAdd(&J.err[0], 1u);
+    o.cigar_len = 0;
+    J.ov[ci] = o;
+    J.bw[ci] = 0;
+    return;
+  }
+  if (ovf) {
+    J.needbig[ci] = 1;  // rerun with a full-size temp slot
+    return;
+  }
+  o.cigar_len = (uint32_t)l;
+  J.ov[ci] = o;
+  J.bw[ci] = 0;
+  J.needbig[ci] = J.big ? 2 : 0;  // 2: ops live in the big temp area
+}
+
+// ---- systolic banded attempt ----------------------------------------------------------------------
+// The same recurrence as banded_attempt (ssw.c:645-693), but a candidate is spread over GL lanes the
+// way the scoring kernels are: lane t owns DPL adjacent diagonals d = j - i of the band
+// [-bw, +bw], and on every anti-diagonal k = i + j the diagonals of one parity advance by a cell.
+// A cell needs (H, E) of the cell above it -- diagonal d + 1, one anti-diagonal earlier -- (H, F) of
+// the cell to its left -- diagonal d - 1, one anti-diagonal earlier -- and its own diagonal's H from
+// two anti-diagonals earlier: all in this lane's registers or one DPP shift away.  Cells that do
+// not exist (outside the band, outside the matrix, not reached yet) read as H = E = F = 0, which is
+// what the reference's zero-initialised rows and its h_b/e_b sentinels (ssw.c:645, 655) present;
+// here a diagonal simply keeps its zero registers until its first real cell.  The 5 direction bits
+// of a cell go to a per-candidate slab, one word per lane and turn, where the traceback (same
+// banded_traceback as everywhere) finds cell (i, j) by arithmetic.
+// Not handled here, sent back to the one-lane-per-candidate kernel (needbig = 3): spans the band
+// covers completely (refLen <= 2 bw + 1), where the sentinel write of ssw.c:655 lands on a live cell.
+template <int LMAX, int GL, int DPL, int BS>
+__global__ __launch_bounds__(BS) void k_cigar_systolic(CigJob J, SwInputs in, SwParams p) {
+  constexpr int NG = BS / GL, ND = GL * DPL, WPT = (DPL + 5) / 6;   // six 5-bit cells per word
+  __shared__ __attribute__((aligned(16))) uint8_t s_w[NG][LMAX + STAGE_PAD];
+  __shared__ __attribute__((aligned(16))) uint32_t s_tab[NG][LMAX + STAGE_PAD];
+  const int32_t lane = threadIdx.x & 63;
+  const int32_t t = lane & (GL - 1);
+  const int32_t grp = threadIdx.x / GL;
+  const uint32_t li = blockIdx.x * NG + grp;
+  bool have = li < J.m;
+  uint32_t ci = 0;
+  kslam_overlap o;
+  memset(&o, 0, sizeof o);
+  int32_t bw = 1, refLen = 0, readLen = 0;
+  const uint8_t *wc = s_w[grp];
+  const uint32_t *tab = s_tab[grp];
+  if (have) {
+    ci = J.list[J.list_base + li];
+    o = J.ov[ci];
+    bw = (int32_t)J.bw[ci];
+    refLen = o.ref_end - o.ref_begin + 1;    // ssw.c:930-931
+    readLen = o.query_end - o.query_begin + 1;
+    if (2 * bw + 1 > ND || refLen <= 2 * bw + 1 || readLen > LMAX || refLen > LMAX || readLen < 1) {
+      if (t == 0) J.needbig[ci] = 3;
+      have = false;
+    }
+  }
+  if (have) {
+    const uint64_t ro = in.read_off[o.read];
+    const uint64_t L = in.read_off[o.read + 1] - ro;
+    const uint64_t go = in.genome_off[o.entry];
+    const uint64_t G = in.genome_off[o.entry + 1] - go;
+    const int64_t s0 = o.rel > 0 ? o.rel : 0;
+    const int64_t wlen = (int64_t)min(L, G - (uint64_t)s0);
+    // window position x of a flipped (revComp) window is genome position wlen - 1 - x
+    const uint8_t *rsrc = in.genome_codes + go + s0 + (o.revcomp ? (wlen - 1 - o.ref_end) : (int64_t)o.ref_begin);
+    tab += stage_span<GL, 1>(in.read_codes + ro + o.query_begin, readLen, false, t, s_w[grp], s_tab[grp], p);
+    __builtin_amdgcn_wave_barrier();   // the read's codes were only a vehicle for the score rows
+    wc += stage_span<GL, 6>(rsrc, refLen, o.revcomp != 0, t, s_w[grp], nullptr, p);
+  }
+  __syncthreads();
+  // ---- the attempt
+  const int32_t gO = p.gap_open, gE = p.gap_extend;
+  const int32_t k0 = (bw & 1) ? -1 : 0;               // first anti-diagonal: parity of the lowest diagonal -bw
+  const int32_t db = -bw + DPL * t;
+  const int32_t ib = (k0 - db) >> 1;
+  int32_t H[DPL], E[DPL], F[DPL], vs[DPL];
+  uint32_t vl[DPL];
+#pragma unroll
+  for (int q = 0; q < DPL; q++) {
+    const int32_t d = db + q, i0 = ib - (q >> 1);
+    const int32_t lo = d < 0 ? -d : 0, hi = min(readLen, refLen - d);
+    vs[q] = lo - i0;
+    vl[q] = (have && DPL * t + q <= 2 * bw) ? (uint32_t)max(hi - lo, 0) : 0u;
+    H[q] = 0;
+    E[q] = 0;
+    F[q] = 0;
+  }
+  const uint32_t *tp = tab + (ib - (DPL / 2 - 1));
+  const uint8_t *wp = wc + (ib + db);
+  int32_t mx = 0;
+  const int32_t nturns = have ? ((readLen + refLen - 2 - k0) >> 1) + 1 : 0;
+  uint32_t *D = reinterpret_cast<uint32_t *>(J.scratch) + ((uint64_t)blockIdx.x * NG + grp) * (J.wave_slab / 4);
+  uint32_t word[WPT];
+  auto cell = [&](int q, int32_t n, int32_t Hu, int32_t Eu, int32_t Hl, int32_t Fl) {
+    if ((uint32_t)(n - vs[q]) < vl[q]) {
+      const int h = q >> 1;
+      const int32_t s = __builtin_amdgcn_sbfe(tp[DPL / 2 - 1 - h], (uint32_t)wp[h + (q & 1)], 6);
+      int32_t t1 = Hu - gO, t2 = Eu - gE;                  // ssw.c:668-671
+      const int32_t ev = max(t1, t2);
+      const uint32_t de = t1 > t2 ? 1u : 0u;
+      t1 = Hl - gO;                                        // ssw.c:673-676
+      t2 = Fl - gE;
+      const int32_t fv = max(t1, t2);
+      const uint32_t df = t1 > t2 ? 1u : 0u;
+      const int32_t e1 = max(ev, 0), f1 = max(fv, 0);      // ssw.c:678-682
+      const int32_t m1 = max(e1, f1), dg = H[q] + s;
+      const int32_t hv = max(m1, dg);
+      mx = max(mx, hv);                                    // ssw.c:684
+      const uint32_t dh = m1 <= dg ? 1u : (e1 > f1 ? 2u + de : 4u + df);   // ssw.c:686-690
+      H[q] = hv;
+      E[q] = ev;
+      F[q] = fv;
+      word[q / 6] |= (de | (df << 1) | (dh << 2)) << (5 * (q % 6));
+    }
+  };
+  for (int32_t n = 0;; n++) {
+    if (__ballot(n < nturns) == 0ull) break;
+#pragma unroll
+    for (int w = 0; w < WPT; w++) word[w] = 0;
+    {  // phase A: the even diagonals of the lane; left neighbour of q = 0 lives in lane t - 1
+      const int32_t hl = dpp_row_shr1(H[DPL - 1]), fl = dpp_row_shr1(F[DPL - 1]);
+      int32_t Hl[DPL / 2], Fl[DPL / 2], Hu[DPL / 2], Eu[DPL / 2];
+#pragma unroll
+      for (int h = 0; h < DPL / 2; h++) {
+        Hl[h] = h == 0 ? (t == 0 ? 0 : hl) : H[2 * h - 1];
+        Fl[h] = h == 0 ? (t == 0 ? 0 : fl) : F[2 * h - 1];
+        Hu[h] = H[2 * h + 1];
+        Eu[h] = E[2 * h + 1];
+      }
+#pragma unroll
+      for (int h = 0; h < DPL / 2; h++) cell(2 * h, n, Hu[h], Eu[h], Hl[h], Fl[h]);
+    }
+    {  // phase B: the odd diagonals; upper neighbour of q = DPL - 1 lives in lane t + 1
+      const int32_t hu = dpp_row_shl1(H[0]), eu = dpp_row_shl1(E[0]);
+      int32_t Hl[DPL / 2], Fl[DPL / 2], Hu[DPL / 2], Eu[DPL / 2];
+#pragma unroll
+      for (int h = 0; h < DPL / 2; h++) {
+        Hl[h] = H[2 * h];
+        Fl[h] = F[2 * h];
+        Hu[h] = h == DPL / 2 - 1 ? (t == GL - 1 ? 0 : hu) : H[2 * h + 2];
+        Eu[h] = h == DPL / 2 - 1 ? (t == GL - 1 ? 0 : eu) : E[2 * h + 2];
+      }
+#pragma unroll
+      for (int h = 0; h < DPL / 2; h++) cell(2 * h + 1, n, Hu[h], Eu[h], Hl[h], Fl[h]);
+    }
+    if (n < nturns) {
+#pragma unroll
+      for (int w = 0; w < WPT; w++) D[((uint32_t)n * GL + (uint32_t)t) * WPT + w] = word[w];
+    }
+    tp += 1;
+    wp += 1;
+  }
+#pragma unroll
+  for (int m = 1; m < GL; m <<= 1) mx = max(mx, __shfl_xor(mx, m, GL));
+  __threadfence_block();   // the direction words of the whole group, visible to its lane 0
+  if (!have || t != 0) return;
+  const int32_t best = max(mx, J.bmax[ci]);   // `max` is carried across attempts, ssw.c:684
+  J.bmax[ci] = best;
+  if (best < (int32_t)o.score) {               // ssw.c:693-694: retry with twice the band
+    J.bw[ci] = (uint32_t)bw * 2u;
+    return;
+  }
+  struct Acc {
+    const uint32_t *D;
+    int32_t bw, k0;
+    __device__ uint32_t get_dir(int32_t i, int32_t col) const {
+      const int32_t j = col + (i - bw > 0 ? i - bw : 0);
+      const int32_t x = j - i + bw;
+      const int32_t tt = x / DPL, q = x - tt * DPL;
+      const int32_t n = (i + j - k0 - (q & 1)) >> 1;
+      const uint32_t wv = D[((uint32_t)n * GL + (uint32_t)tt) * WPT + q / 6];
+      return (wv >> (5 * (q % 6))) & 31u;
+    }
+  } A{D, bw, k0};
+  uint32_t *tmp = J.tmp + (uint64_t)(J.big ? (J.list_base + li) : ci) * J.cap;
+  bool ovf = false;
+  const int32_t l = banded_traceback(A, refLen, readLen, bw, tmp, J.cap, &ovf);
   if (l < 0) {
     atomicAdd(&J.err[0], 1u);
     o.cigar_len = 0;
@@ -370,9 +552,9 @@ void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, u
   HIPCHK(hipMemsetAsync(d_tot, 0, 4 * sizeof(uint64_t), s));
   const uint32_t cap_big = 2 * lmax + 4;
   if (p.report_cigar) {
-    auto run_lists = [&](uint32_t cls, bool big) -> uint64_t {
+    auto run_lists = [&](uint32_t cls, uint32_t mode) -> uint64_t {   // mode: 0 class, 1 big rerun, 2 handed back
       hipLaunchKernelGGL(k_class_flags, dim3(nb), dim3(256), 0, s, d_bw, W.needbig.as<uint8_t>(), n, cls,
-                         big ? 1u : 0u, W.flags.as<uint32_t>());
+                         mode, W.flags.as<uint32_t>());
       exclusive_scan_u32(W.flags.as<uint32_t>(), W.pos.as<uint32_t>(), n, d_tot, W.scan_tmp.p, s);
       uint64_t m = 0;
       HIPCHK(hipMemcpyAsync(&m, d_tot, sizeof m, hipMemcpyDeviceToHost, s));
@@ -380,6 +562,54 @@ void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, u
       if (m) hipLaunchKernelGGL(k_scatter_list, dim3(nb), dim3(256), 0, s, W.flags.as<uint32_t>(),
                                 W.pos.as<uint32_t>(), n, W.list.as<uint32_t>());
       return m;
+    };
+    // one attempt for the m candidates of W.list with the systolic kernel; false when the band is
+    // too wide for it
+    // bit c: band class c (bw <= 2^c) runs on the systolic kernel.  Measured per class on the bench
+    // workload (one-lane kernel / systolic, ms): c3 2.2 / 1.4, c4 3.1 / 1.5, c5 2.1 / 0.2; the narrow
+    // classes, where 5 of 16 diagonal slots are live and the single-lane traceback dominates, stay
+    // on the one-lane kernel (c0-c2: 3.9 / 5.4).
+    static const int sys_mask = getenv("KSLAM_CIGAR_SYS") ? atoi(getenv("KSLAM_CIGAR_SYS")) : 0xF8;
+    auto launch_systolic = [&](uint64_t m, uint32_t slot_bw, uint32_t cls) -> bool {
+      const uint32_t need = 2 * slot_bw + 1;
+      if (need > 128 || !((sys_mask >> std::min(cls, 7u)) & 1)) return false;
+      const int lm = lmax <= 160 ? 0 : (lmax <= 256 ? 1 : 2);
+      const uint32_t LM = lm == 0 ? 160 : (lm == 1 ? 256 : 512);
+      const uint32_t GL = need > 64 ? 16 : 8, DPL = need <= 16 ? 2 : (need <= 32 ? 4 : 8);
+      const uint32_t WPT = (DPL + 5) / 6, NG = 128 / GL;
+      uint64_t slab = (uint64_t)(LM + 2) * GL * WPT * 4;   // direction words of one candidate
+      slab = (slab + 255) & ~255ull;
+      const uint64_t SCRATCH_BUDGET = 3ull << 30;
+      const uint64_t groups_per_launch = std::max<uint64_t>(NG, (SCRATCH_BUDGET / slab) / NG * NG);
+      W.scratch.ensure(std::min<uint64_t>((m + NG - 1) / NG * NG, groups_per_launch) * slab);
+      for (uint64_t g0 = 0; g0 < m; g0 += groups_per_launch) {
+        CigJob J;
+        J.ov = d_ov; J.bw = d_bw; J.bmax = W.bmax.as<int32_t>(); J.needbig = W.needbig.as<uint8_t>();
+        J.list = W.list.as<uint32_t>();
+        J.list_base = (uint32_t)g0;
+        J.m = (uint32_t)std::min<uint64_t>(groups_per_launch, m - g0);
+        J.slot_bw = slot_bw; J.lmax = lmax;
+        J.cap = CIG_CAP;
+        J.tmp = W.tmp.as<uint32_t>();
+        J.big = 0;
+        J.scratch = W.scratch.as<uint8_t>();
+        J.wave_slab = slab;
+        J.err = d_err;
+        J.variant = 0;
+        const unsigned nb = (unsigned)((J.m + NG - 1) / NG);
+#define KSLAM_SYS(LMV, GLV, DPLV) \
+  hipLaunchKernelGGL((k_cigar_systolic<LMV, GLV, DPLV, 128>), dim3(nb), dim3(128), 0, s, J, in, p)
+#define KSLAM_SYS_LM(GLV, DPLV) \
+  do { if (lm == 0) KSLAM_SYS(160, GLV, DPLV); else if (lm == 1) KSLAM_SYS(256, GLV, DPLV); else KSLAM_SYS(512, GLV, DPLV); } while (0)
+        if (GL == 16) KSLAM_SYS_LM(16, 8);
+        else if (DPL == 2) KSLAM_SYS_LM(8, 2);
+        else if (DPL == 4) KSLAM_SYS_LM(8, 4);
+        else KSLAM_SYS_LM(8, 8);
+#undef KSLAM_SYS_LM
+#undef KSLAM_SYS
+      }
+      HIPCHK(hipGetLastError());
+      return true;
     };
     auto launch = [&](uint64_t m, uint32_t slot_bw, bool big) {
       LdsLayout Y;
@@ -438,17 +668,23 @@ void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, u
     while ((1ull << last_cls) < mb0) last_cls++;
     // failures move up exactly one class, so the sweep ends at the first empty class above last_cls
     for (uint32_t cls = 0; cls < 31 && mb0 > 0; cls++) {
-      uint64_t m = run_lists(cls, false);
+      uint64_t m = run_lists(cls, 0);
       if (m == 0) {
         if (cls > last_cls) break;
         continue;
       }
       if (getenv("KSLAM_DEBUG")) fprintf(stderr, "[kslam] cigar class %u (band <= %u): %llu candidates\n", cls, 1u << cls, (unsigned long long)m);
-      launch(m, 1u << cls, false);
+      if (launch_systolic(m, 1u << cls, cls)) {
+        const uint64_t m2 = run_lists(cls, 2);   // the few it hands back (spans the band covers completely)
+        if (getenv("KSLAM_DEBUG")) fprintf(stderr, "[kslam]   handed to the one-lane kernel: %llu\n", (unsigned long long)m2);
+        if (m2) launch(m2, 1u << cls, false);
+      } else {
+        launch(m, 1u << cls, false);
+      }
       if (cls >= last_cls) last_cls = cls + 1;
     }
     // candidates whose cigar did not fit the small temp slot: rerun with full-size slots
-    uint64_t n_big = run_lists(0, true);
+    uint64_t n_big = run_lists(0, 1);
     if (n_big) {
       W.tmp_big.ensure(n_big * (uint64_t)cap_big * sizeof(uint32_t));
       HIPCHK(hipMemcpyAsync(W.big_pos.p, W.pos.p, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));

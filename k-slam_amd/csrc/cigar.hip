@@ -164,11 +164,74 @@ __device__ inline void stage_codes_wave(const uint8_t *src, int32_t len, bool re
   }
 }
 
+// ---- narrow bands: the band lives in registers ------------------------------------------------------
+// One attempt of banded_sw (ssw.c:645-693) for a lane whose band width is at most BW.  Slot x of the
+// band is diagonal j - i = x - bw; H and E of the previous row sit in registers indexed by slot
+// (statically, the slot loop is unrolled), a row is swept left to right with the F chain and the left
+// H in registers, and the five direction bits of its cells leave as one or two words.  Cells that do
+// not exist -- slots beyond 2 bw, columns outside [0, refLen) -- hold H = E = 0 and pass H = F = 0 to
+// the right, which is what the reference's zeroed rows and its sentinels present (see the systolic
+// kernel below for the same argument).  Caller guarantees refLen > 2 bw + 1.
+template <int BW, class Seq>
+__device__ inline int32_t banded_attempt_reg(Seq &m, uint32_t *DW, uint32_t NL, uint32_t lane, int32_t refLen,
+                                             int32_t readLen, int32_t bw, const SwParams &p, int32_t mx) {
+  constexpr int NX = 2 * BW + 1, WPR = (NX + 5) / 6;
+  int32_t H[NX + 1], E[NX + 1];
+  uint32_t R[NX];
+#pragma unroll
+  for (int x = 0; x <= NX; x++) { H[x] = 0; E[x] = 0; }
+#pragma unroll
+  for (int x = 0; x < NX; x++) {
+    const int32_t j = x - bw;
+    R[x] = (uint32_t)j < (uint32_t)refLen ? m.r(j) : 4u;
+  }
+  const int32_t live = 2 * bw;   // last live slot
+  for (int32_t i = 0; i < readLen; i++) {
+    const uint32_t qc = m.q(i);
+    int32_t hleft = 0, f = 0;
+    uint32_t word[WPR];
+#pragma unroll
+    for (int w = 0; w < WPR; w++) word[w] = 0;
+#pragma unroll
+    for (int x = 0; x < NX; x++) {
+      const int32_t j = i + x - bw;
+      const bool valid = x <= live && (uint32_t)j < (uint32_t)refLen;
+      const uint32_t rc = R[x];
+      const int32_t sc = (qc > 3u || rc > 3u) ? 0 : (qc == rc ? p.match : -p.mismatch);
+      int32_t t1 = H[x + 1] - p.gap_open, t2 = E[x + 1] - p.gap_extend;     // ssw.c:668-671
+      const int32_t ev = max(t1, t2);
+      const uint32_t de = t1 > t2 ? 1u : 0u;
+      t1 = hleft - p.gap_open;                                             // ssw.c:673-676
+      t2 = f - p.gap_extend;
+      const int32_t fv = max(t1, t2);
+      const uint32_t df = t1 > t2 ? 1u : 0u;
+      const int32_t e1 = max(ev, 0), f1 = max(fv, 0);                      // ssw.c:678-682
+      const int32_t m1 = max(e1, f1), dg = H[x] + sc;
+      const int32_t hv = max(m1, dg);
+      const uint32_t dh = m1 <= dg ? 1u : (e1 > f1 ? 2u + de : 4u + df);   // ssw.c:686-690
+      H[x] = valid ? hv : 0;
+      E[x] = valid ? ev : 0;
+      hleft = H[x];
+      f = valid ? fv : 0;
+      mx = valid ? max(mx, hv) : mx;                                       // ssw.c:684
+      word[x / 6] |= valid ? (de | (df << 1) | (dh << 2)) << (5 * (x % 6)) : 0u;
+    }
+#pragma unroll
+    for (int w = 0; w < WPR; w++) DW[((uint32_t)i * WPR + w) * NL + lane] = word[w];
+#pragma unroll
+    for (int x = 0; x + 1 < NX; x++) R[x] = R[x + 1];
+    const int32_t jn = i + 1 + (NX - 1) - bw;
+    R[NX - 1] = (uint32_t)jn < (uint32_t)refLen ? m.r(jn) : 4u;
+  }
+  return mx;
+}
+
 // One candidate per lane.  LDS ([element][lane]): translated spans + the three row arrays, and,
 // for the narrow bands nearly every candidate needs, the direction matrix itself: 5 bits per band
 // cell, six cells per word, so the traceback -- a chain of dependent loads, one per step -- runs
 // at LDS latency.  Wider bands keep the directions in a global slab per block ([cell][lane],
 // coalesced, L2 resident), written fire-and-forget during the DP.
+template <int REG_BW>   // 0: rows in LDS, any band; 2 / 4: bands up to that width in registers
 __global__ __launch_bounds__(64) void k_banded_lds(CigJob J, SwInputs in, SwParams p, LdsLayout Y) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
   if (J.variant == 3) return;   // ablation: launch floor
@@ -248,8 +311,10 @@ __global__ __launch_bounds__(64) void k_banded_lds(CigJob J, SwInputs in, SwPara
       } else
         D[((size_t)i * width_d + (uint32_t)col) * NL + lane] = (uint8_t)v;
     }
+    int32_t reg_bw = 0;                 // > 0: the words hold band slots (banded_attempt_reg), not columns
     __device__ uint32_t get_dir(int32_t i, int32_t col) {
       if (wpr) {
+        if (reg_bw > 0 && i < reg_bw) col += reg_bw - i;   // slot = j - i + bw, col = j - max(0, i - bw)
         const uint32_t w = (uint32_t)col / 6u, sh = 5u * ((uint32_t)col - 6u * w);
         return (DW[((uint32_t)i * wpr + w) * NL + lane] >> sh) & 31u;
       }
@@ -257,7 +322,20 @@ __global__ __launch_bounds__(64) void k_banded_lds(CigJob J, SwInputs in, SwPara
     }
   } A{S, SQ, SR, D, NL, lane, Y.W1, (uint32_t)(band_width * 2 + 1), DW, Y.wpr, 0u};
   (void)score;
-  const int32_t mx = banded_attempt(A, refLen, readLen, band_width, p, J.bmax[ci]);
+  int32_t mx;
+  bool in_regs = false;
+  if constexpr (REG_BW > 0) in_regs = band_width <= REG_BW && refLen > 2 * band_width + 1;
+  if (in_regs) {
+    // direction words in the global slab, [row * WPR + word][lane]; slot x of row i
+    constexpr uint32_t WPR = (2 * (REG_BW > 0 ? REG_BW : 1) + 1 + 5) / 6;
+    mx = banded_attempt_reg<(REG_BW > 0 ? REG_BW : 1)>(A, reinterpret_cast<uint32_t *>(D), NL, lane, refLen,
+                                                        readLen, band_width, p, J.bmax[ci]);
+    A.DW = reinterpret_cast<uint32_t *>(D);
+    A.wpr = WPR;
+    A.reg_bw = band_width;
+  } else {
+    mx = banded_attempt(A, refLen, readLen, band_width, p, J.bmax[ci]);
+  }
   if (J.variant == 1) return;   // ablation: no traceback
   J.bmax[ci] = mx;
   if (mx < score) {               // ssw.c:693-694: retry with twice the band
@@ -632,10 +710,15 @@ void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, u
       const size_t lds = ((2 * half + 15) & ~(size_t)15) + rows_bytes + (size_t)lmax * Y.wpr * 4 * nl;
       if (lds > 160 * 1024) throw StatusError{KSLAM_ERR_UNSUPPORTED, "banded traceback band does not fit LDS"};
       if (lds > 64 * 1024)
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_banded_lds),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      uint64_t slab = Y.wpr ? 256 : (uint64_t)lmax * Y.wd * nl;
-      slab = (slab + 255) & ~255ull;
+        for (const void *f : {reinterpret_cast<const void *>(&k_banded_lds<0>),
+                              reinterpret_cast<const void *>(&k_banded_lds<2>),
+                              reinterpret_cast<const void *>(&k_banded_lds<4>)})
+          HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      // narrow bands: the band in registers (KSLAM_CIGAR_REG=0 turns it off)
+      static const bool use_reg = !(getenv("KSLAM_CIGAR_REG") && getenv("KSLAM_CIGAR_REG")[0] == '0');
+      const uint32_t reg_bw = (!use_reg || big || Y.wpr) ? 0u : (slot_bw <= 2 ? 2u : (slot_bw <= 4 ? 4u : 0u));
+      uint64_t slab = Y.wpr ? 256 : (uint64_t)lmax * std::max<uint32_t>(Y.wd, reg_bw ? 8u : 0u) * nl;   // direction
+      slab = (slab + 255) & ~255ull;   // bytes per block; the register variant stores <= 8 bytes per row and lane
       const uint64_t SCRATCH_BUDGET = 3ull << 30;
       const uint64_t blocks_per_launch = std::max<uint64_t>(1, SCRATCH_BUDGET / slab);
       const uint64_t n_blocks = (m + nl - 1) / nl;
@@ -655,7 +738,9 @@ void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, u
         J.wave_slab = slab;
         J.err = d_err;
         { const char *cv = getenv("KSLAM_CIGAR_VARIANT"); J.variant = cv ? (uint32_t)atoi(cv) : 0u; }
-        hipLaunchKernelGGL(k_banded_lds, dim3((unsigned)nb_here), dim3(64), lds, s, J, in, p, Y);
+        if (reg_bw == 2) hipLaunchKernelGGL(k_banded_lds<2>, dim3((unsigned)nb_here), dim3(64), lds, s, J, in, p, Y);
+        else if (reg_bw == 4) hipLaunchKernelGGL(k_banded_lds<4>, dim3((unsigned)nb_here), dim3(64), lds, s, J, in, p, Y);
+        else hipLaunchKernelGGL(k_banded_lds<0>, dim3((unsigned)nb_here), dim3(64), lds, s, J, in, p, Y);
       }
       HIPCHK(hipGetLastError());
     };

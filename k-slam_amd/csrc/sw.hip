@@ -287,43 +287,64 @@ __device__ inline bool band_certifies(int32_t score, int32_t L, int32_t W, int32
 template <int LMAX>
 __global__ __launch_bounds__(256) void k_sw_plan(const kslam_overlap *__restrict__ ov, uint64_t n, SwInputs in,
                                                  SwParams p, int n_tiers, uint8_t *__restrict__ tier) {
-  constexpr int GL = 8, NG = 256 / GL;
-  __shared__ __attribute__((aligned(16))) uint8_t s_q[NG][LMAX + STAGE_PAD];
-  __shared__ __attribute__((aligned(16))) uint8_t s_w[NG][LMAX + STAGE_PAD];
+  constexpr int GL = 8, NG = 256 / GL, PW = 16;   // PW: bytes of "N" padding either side of a span
+  __shared__ __attribute__((aligned(16))) uint8_t s_q[NG][LMAX + STAGE_PAD + 2 * PW];
+  __shared__ __attribute__((aligned(16))) uint8_t s_w[NG][LMAX + STAGE_PAD + 2 * PW];
   const int32_t lane = threadIdx.x & 63;
   const int32_t t = lane & (GL - 1);
   const int32_t grp = threadIdx.x / GL;
   const uint64_t gi = (uint64_t)blockIdx.x * NG + grp;
   const bool have = gi < n;
   int32_t L = 0, W = 0, rel = 0;
-  const uint8_t *qc = s_q[grp], *wc = s_w[grp];
+  uint8_t *qc = s_q[grp] + PW, *wc = s_w[grp] + PW;
   if (have) {
     const kslam_overlap o = ov[gi];
     rel = o.rel;
-    const Staged st = stage_candidate_wide<GL, 1>(o, in, t, s_q[grp], s_w[grp], nullptr, p);
+    const Staged st = stage_candidate_wide<GL, 1>(o, in, t, qc, wc, nullptr, p);
     L = st.L;
     W = st.W;
     qc += st.qoff;
     wc += st.woff;
   }
   __syncthreads();
+  for (int32_t x = t; x < PW; x += GL) {   // code 4 scores 0 against everything
+    qc[-1 - x] = 4;
+    qc[L + x] = 4;
+    wc[-1 - x] = 4;
+    wc[W + x] = 4;
+  }
+  __syncthreads();
+  // Four bases per step: read word (LDS-aligned) against the five window words at offsets
+  // d0 - 2 .. d0 + 2, matches and mismatches counted with byte-parallel arithmetic (codes are
+  // 0..4, so x + 0x7F sets bit 7 of a byte iff it is non-zero; code 4 = bit 2 = "scores 0").
   const int32_t d0 = rel < 0 ? rel : 0;
-  int32_t sum[5] = {0, 0, 0, 0, 0};
-  for (int32_t i = t; i < L; i += GL) {
-    const uint32_t q = qc[i];
+  const int32_t qa = (int32_t)(reinterpret_cast<uintptr_t>(qc) & 3u);
+  // read indices i = 4 m - qa; keep every window byte touched inside its padding
+  const int32_t i_lo = max(-qa, ((-d0 - 8) & ~3) - qa), i_hi = min(L, W - d0 + 8);
+  uint32_t nm[5] = {0, 0, 0, 0, 0}, nx[5] = {0, 0, 0, 0, 0};
+  constexpr uint32_t B7 = 0x80808080u, LO7 = 0x7F7F7F7Fu;
+  for (int32_t i = i_lo + 4 * t; i < i_hi; i += 4 * GL) {
+    const uint32_t q = *reinterpret_cast<const uint32_t *>(qc + i);
+    const uint32_t qn = (q << 5) & B7;   // bit 7 where the read base is N / padding
+    const uint8_t *wa = wc + (i + d0 - 2);
+    const uint32_t sh = (uint32_t)(reinterpret_cast<uintptr_t>(wa) & 3u);
+    const uint32_t *wb = reinterpret_cast<const uint32_t *>(wa - sh);
+    const uint64_t lo = (uint64_t)wb[0] | ((uint64_t)wb[1] << 32), hi = (uint64_t)wb[1] | ((uint64_t)wb[2] << 32);
 #pragma unroll
     for (int k = 0; k < 5; k++) {
-      const int32_t j = i + d0 + k - 2;
-      if (j >= 0 && j < W) {
-        const uint32_t c = wc[j];
-        sum[k] += (q > 3u || c > 3u) ? 0 : (q == c ? (int32_t)p.match : -(int32_t)p.mismatch);
-      }
+      const uint32_t o = sh + (uint32_t)k;   // byte offset of this diagonal's word in wb[0..2]
+      const uint32_t w = o < 4u ? (uint32_t)(lo >> (8u * o)) : (uint32_t)(hi >> (8u * (o - 4u)));
+      const uint32_t x = q ^ w;
+      const uint32_t ne = (x + LO7) & B7;            // bytes that differ
+      const uint32_t inv = qn | ((w << 5) & B7);     // bytes that score 0
+      nx[k] += (uint32_t)__popc(ne & (inv ^ B7));    // mismatches
+      nm[k] += (uint32_t)__popc((ne | inv) ^ B7);    // matches
     }
   }
   int32_t best = 0;
 #pragma unroll
   for (int k = 0; k < 5; k++) {
-    int32_t v = sum[k];
+    int32_t v = (int32_t)nm[k] * p.match - (int32_t)nx[k] * p.mismatch;
 #pragma unroll
     for (int m = 1; m < GL; m <<= 1) v += __shfl_xor(v, m, GL);
     best = max(best, v);

@@ -264,18 +264,35 @@ __global__ __launch_bounds__(256) void k_sw(kslam_overlap *__restrict__ ov, uint
 __device__ inline bool band_certifies(int32_t score, int32_t L, int32_t W, int32_t dlo, int32_t ND,
                                       const SwParams &p) {
   if (score <= 0) return false;
-  int32_t rlo = 1 << 20, rhi = -(1 << 20);
-  const int32_t Lm = min(L, W);
-  for (int32_t g = 0; g < 2048; g++) {
-    const int32_t cost = g == 0 ? 0 : p.gap_open + (g - 1) * p.gap_extend;
-    const int32_t m0 = (score + cost + p.match - 1) / p.match;
-    if (m0 > Lm) break;
-    rlo = min(rlo, -(L - m0) - g);
-    rhi = max(rhi, (W - m0) + g);
-    if (rlo < dlo || rhi > dlo + ND - 1) return false;
+  // With A(g) = m0(g) - g the ranges are [-(L - A(g)), W - A(g)]: all that matters is the smallest
+  // A(g) over the feasible g (m0(g) <= min(L, W)).  For g >= 1, A(g) = ceil((c + g gE) / match) - g
+  // never decreases with g when gE >= match and never increases when gE < match, so the minimum
+  // sits at g = 0, g = 1 or the largest feasible g: no loop.
+  const int32_t Lm = min(L, W), ma = p.match;
+  const int32_t m00 = (score + ma - 1) / ma;
+  if (m00 > Lm) return true;   // (cannot happen for a score some alignment reached; nothing to bound)
+  int32_t amin = m00;
+  const int32_t room = Lm * ma - score - p.gap_open;   // >= 0 iff one gap base is affordable
+  if (room >= 0) {
+    int32_t g = 1;
+    if (p.gap_extend < ma) g = min(room / p.gap_extend + 1, 2047);
+    const int32_t m0 = (score + p.gap_open + (g - 1) * p.gap_extend + ma - 1) / ma;
+    amin = min(amin, m0 - g);
   }
-  return rlo >= dlo && rhi <= dlo + ND - 1;
+  return amin - L >= dlo && W - amin <= dlo + ND - 1;
 }
+
+// The banded tiers of one launch configuration: diagonals swept per tier, the list each tier works
+// through and the counters behind the lists (counts[k]: entries of list k; counts[NT_FULL]: entries of
+// the full-matrix list).
+constexpr int NT_MAX = 5, NT_FULL = 7;
+struct Tiers {
+  int n;                  // tiers in use
+  int nd[NT_MAX];         // diagonals of tier k, ascending
+  uint32_t *list[NT_MAX];
+  uint32_t *full_list;
+  uint32_t *counts;
+};
 
 // ---- tier planning ------------------------------------------------------------------------------
 // Which band does a candidate need?  The certificate only asks for a lower bound of the optimal
@@ -283,10 +300,10 @@ __device__ inline bool band_certifies(int32_t score, int32_t L, int32_t W, int32
 // diagonals the join merged into this candidate (|rel difference| < 3), no gaps, full length.  The
 // best of those five plain diagonal sums picks the narrowest band that is certain to certify;
 // gapped alignments, whose diagonal sums are poor, start in the 32-diagonal band and move up on
-// failure as before.  tier: 0 = 16 diagonals, 1 = 32, 2 = 64, 3 = 128 (reads > 160 bases only).
+// failure as before.
 template <int LMAX>
 __global__ __launch_bounds__(256) void k_sw_plan(const kslam_overlap *__restrict__ ov, uint64_t n, SwInputs in,
-                                                 SwParams p, int n_tiers, uint8_t *__restrict__ tier) {
+                                                 SwParams p, Tiers T, uint8_t *__restrict__ tier) {
   constexpr int GL = 8, NG = 256 / GL, PW = 16;   // PW: bytes of "N" padding either side of a span
   __shared__ __attribute__((aligned(16))) uint8_t s_q[NG][LMAX + STAGE_PAD + 2 * PW];
   __shared__ __attribute__((aligned(16))) uint8_t s_w[NG][LMAX + STAGE_PAD + 2 * PW];
@@ -351,8 +368,8 @@ __global__ __launch_bounds__(256) void k_sw_plan(const kslam_overlap *__restrict
   }
   if (have && t == 0) {
     int choice = 1;   // no diagonal certifies anything: start in the 32-diagonal band
-    for (int k = 0; k < n_tiers; k++) {
-      const int ND = 16 << k;
+    for (int k = 0; k < T.n; k++) {
+      const int ND = T.nd[k];
       if (band_certifies(best, L, W, d0 - ND / 2, ND, p)) {
         choice = k;
         break;
@@ -362,29 +379,30 @@ __global__ __launch_bounds__(256) void k_sw_plan(const kslam_overlap *__restrict
   }
 }
 
-// 4-way stable partition of the candidate numbers by tier: per-block counts, one small scan,
+// NT-way stable partition of the candidate numbers by tier: per-block counts, one small scan,
 // then a scatter that ranks within the block by ballots.
 constexpr int TIER_ITEMS = 4096;   // candidates per block
+constexpr int NT = 8;              // tier bins (5 used)
 __global__ __launch_bounds__(256) void k_tier_hist(const uint8_t *__restrict__ tier, uint64_t n,
                                                    uint32_t *__restrict__ block_hist, uint32_t n_blocks) {
-  __shared__ uint32_t h[4];
-  if (threadIdx.x < 4) h[threadIdx.x] = 0;
+  __shared__ uint32_t h[NT];
+  if (threadIdx.x < NT) h[threadIdx.x] = 0;
   __syncthreads();
-  uint32_t c[4] = {0, 0, 0, 0};
+  uint32_t c[NT] = {0, 0, 0, 0, 0, 0, 0, 0};
   const uint64_t base = (uint64_t)blockIdx.x * TIER_ITEMS;
   for (uint32_t k = threadIdx.x; k < TIER_ITEMS; k += 256) {
     const uint64_t i = base + k;
-    if (i < n) c[tier[i] & 3]++;
+    if (i < n) c[tier[i] & (NT - 1)]++;
   }
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
+  for (int k = 0; k < NT; k++) {
     uint32_t v = c[k];
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) v += __shfl_down(v, d, 64);
     if ((threadIdx.x & 63) == 0 && v) atomicAdd(&h[k], v);
   }
   __syncthreads();
-  if (threadIdx.x < 4) block_hist[threadIdx.x * n_blocks + blockIdx.x] = h[threadIdx.x];
+  if (threadIdx.x < NT) block_hist[threadIdx.x * n_blocks + blockIdx.x] = h[threadIdx.x];
 }
 
 // exclusive scan of block_hist per tier (each tier's list starts at 0); totals[k] = tier size
@@ -418,23 +436,23 @@ __global__ __launch_bounds__(1024) void k_tier_scan(uint32_t *__restrict__ block
 }
 
 struct TierLists {
-  uint32_t *list[4];
+  uint32_t *list[NT];
 };
 __global__ __launch_bounds__(256) void k_tier_scatter(const uint8_t *__restrict__ tier, uint64_t n,
                                                       const uint32_t *__restrict__ block_hist, uint32_t n_blocks,
                                                       TierLists out) {
-  __shared__ uint32_t base[4];       // running position of each tier inside this block
-  __shared__ uint32_t wave_cnt[4][4];
-  if (threadIdx.x < 4) base[threadIdx.x] = block_hist[threadIdx.x * n_blocks + blockIdx.x];
+  __shared__ uint32_t base[NT];      // running position of each tier inside this block
+  __shared__ uint32_t wave_cnt[NT][4];
+  if (threadIdx.x < NT) base[threadIdx.x] = block_hist[threadIdx.x * n_blocks + blockIdx.x];
   __syncthreads();
   const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint64_t b0 = (uint64_t)blockIdx.x * TIER_ITEMS;
   for (uint32_t r = 0; r < TIER_ITEMS / 256; r++) {
     const uint64_t i = b0 + (uint64_t)r * 256 + threadIdx.x;
-    const int tk = i < n ? (int)(tier[i] & 3) : -1;
+    const int tk = i < n ? (int)(tier[i] & (NT - 1)) : -1;
     uint32_t rank = 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < NT; k++) {
       const uint64_t m = __ballot(tk == k);
       if (tk == k) rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
       if (lane == 0) wave_cnt[k][wv] = (uint32_t)__popcll(m);
@@ -446,7 +464,7 @@ __global__ __launch_bounds__(256) void k_tier_scatter(const uint8_t *__restrict_
       out.list[tk][off] = (uint32_t)i;
     }
     __syncthreads();
-    if (threadIdx.x < 4)
+    if (threadIdx.x < NT)
       base[threadIdx.x] += wave_cnt[threadIdx.x][0] + wave_cnt[threadIdx.x][1] + wave_cnt[threadIdx.x][2] +
                            wave_cnt[threadIdx.x][3];
     __syncthreads();
@@ -473,7 +491,7 @@ __global__ __launch_bounds__(256) void k_tier_scatter(const uint8_t *__restrict_
 template <int LMAX, int GL, int DPL, int BS = 256>
 __global__ __launch_bounds__(BS) void k_sw_band(kslam_overlap *__restrict__ ov, uint64_t n, SwInputs in, SwParams p,
                                                  uint32_t *__restrict__ band0, const uint32_t *__restrict__ list,
-                                                 uint32_t *__restrict__ next_list, uint32_t *__restrict__ next_count) {
+                                                 Tiers T, int self) {
   constexpr int NG = BS / GL;           // candidates per block
   constexpr int ND = DPL * GL;          // diagonals swept (DPL adjacent diagonals per lane)
   // The sweep also computes cells that lie outside the matrix near its corners (no per-cell range
@@ -482,7 +500,7 @@ __global__ __launch_bounds__(BS) void k_sw_band(kslam_overlap *__restrict__ ov, 
   // still or paying for gaps, so they never beat a real maximum (strictly), and nothing flows from
   // them back into the matrix: before the matrix they hold exactly the zero-score value Z a fresh
   // alignment starts from, after it every dependency points further out.
-  constexpr int PADM = ND == 16 ? 16 : (ND == 32 ? 32 : (ND == 64 ? 48 : 80));   // >= ND / 2 + 2, x16
+  constexpr int PADM = ND == 16 ? 16 : (ND <= 48 ? 32 : (ND == 64 ? 48 : 80));   // >= ND / 2 + 2, x16
   constexpr int ROW = LMAX + STAGE_PAD + 2 * PADM;
   __shared__ __attribute__((aligned(16))) uint8_t s_q[NG][LMAX + STAGE_PAD];
   __shared__ __attribute__((aligned(16))) uint8_t s_w[NG][ROW];
@@ -599,14 +617,28 @@ __global__ __launch_bounds__(BS) void k_sw_band(kslam_overlap *__restrict__ ov, 
   const PassResult f = reduce_best<GL>(lbV, lbZ);
   // certificate: every alignment scoring >= f.score lies inside [dlo, dlo + ND - 1]
   const bool exact = have && band_certifies(f.score, L, W, dlo, ND, p);
-  {  // the others go on to the next tier: one atomic per wave reserves their list slots
+  {  // The others move on.  What this band found is a real alignment's score, i.e. a lower bound:
+     // it picks the narrowest later tier that is certain to certify (or the full matrix) directly.
+     // One atomic per wave and destination reserves the list slots.
     const bool fail = have && t == 0 && !exact;
-    const uint64_t m = __ballot(fail);
-    if (m) {
+    int dest = -1;
+    if (fail) {
+      dest = NT_FULL;
+      for (int k = self + 1; k < T.n; k++)
+        if (f.score <= 0 || band_certifies(f.score, L, W, d0 - T.nd[k] / 2, T.nd[k], p)) {
+          dest = k;   // (nothing found at all: just try the next band)
+          break;
+        }
+    }
+    for (int k = self + 1; k <= NT_FULL; k++) {
+      if (k >= T.n && k != NT_FULL) continue;
+      const uint64_t m = __ballot(dest == k);
+      if (!m) continue;
       uint32_t base = 0;
-      if (lane == (int32_t)__builtin_ctzll(m)) base = atomicAdd(next_count, (uint32_t)__popcll(m));
+      if (lane == (int32_t)__builtin_ctzll(m)) base = atomicAdd(T.counts + k, (uint32_t)__popcll(m));
       base = __shfl(base, __builtin_ctzll(m), 64);
-      if (fail) next_list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)ci;
+      uint32_t *dl = k == NT_FULL ? T.full_list : T.list[k];
+      if (dest == k) dl[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)ci;
     }
   }
   sw_epilogue<GL, 6>(ov, ci, exact, t, L, f, qc, wc, p, band0);
@@ -661,59 +693,73 @@ void sw_scores(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, uint32_
     // candidate to the narrowest one its seed diagonal already certifies, the others start at 32;
     // whatever fails a tier's certificate is appended to the next tier's list, and what fails the
     // widest goes to the full-matrix kernel
-    const int n_tiers = lm == 0 ? 3 : 4;
+    Tiers T;
+    memset(&T, 0, sizeof T);
+    {
+      const int nd0[4] = {16, 32, 48, 64}, nd1[5] = {16, 32, 48, 64, 128};
+      static const bool no48 = getenv("KSLAM_SW_NO48") != nullptr;   // ablation
+      T.n = 0;
+      for (int k = 0; k < (lm == 0 ? 4 : 5); k++) {
+        const int nd = lm == 0 ? nd0[k] : nd1[k];
+        if (nd == 48 && no48) continue;
+        T.nd[T.n++] = nd;
+      }
+    }
     W.flags.ensure(n);                                   // tier per candidate (u8)
-    for (int k = 0; k < 4; k++) W.tier_list[k].ensure((n + 1) * sizeof(uint32_t));
+    for (int k = 0; k < T.n; k++) W.tier_list[k].ensure((n + 1) * sizeof(uint32_t));
     W.list.ensure((n + 1) * sizeof(uint32_t));           // list for the full-matrix kernel
     const uint32_t n_blocks = (uint32_t)((n + TIER_ITEMS - 1) / TIER_ITEMS);
-    W.pos.ensure((size_t)4 * n_blocks * sizeof(uint32_t));
+    W.pos.ensure((size_t)NT * n_blocks * sizeof(uint32_t));
     W.totals.ensure(16 * sizeof(uint32_t));
     uint8_t *tier = W.flags.as<uint8_t>();
-    uint32_t *counts = W.totals.as<uint32_t>();          // [0..3] tier sizes, [4] full-matrix list size
+    uint32_t *counts = W.totals.as<uint32_t>();          // [k] tier sizes, [NT_FULL] full-matrix list size
     HIPCHK(hipMemsetAsync(counts, 0, 16 * sizeof(uint32_t), s));
-    const unsigned pb = (unsigned)((n + 31) / 32);
-    if (lm == 0) hipLaunchKernelGGL(k_sw_plan<160>, dim3(pb), dim3(256), 0, s, d_ov, n, in, p, n_tiers, tier);
-    else if (lm == 1) hipLaunchKernelGGL(k_sw_plan<256>, dim3(pb), dim3(256), 0, s, d_ov, n, in, p, n_tiers, tier);
-    else hipLaunchKernelGGL(k_sw_plan<512>, dim3(pb), dim3(256), 0, s, d_ov, n, in, p, n_tiers, tier);
-    hipLaunchKernelGGL(k_tier_hist, dim3(n_blocks), dim3(256), 0, s, tier, n, W.pos.as<uint32_t>(), n_blocks);
-    hipLaunchKernelGGL(k_tier_scan, dim3(4), dim3(1024), 0, s, W.pos.as<uint32_t>(), n_blocks, counts);
     TierLists TL;
-    for (int k = 0; k < 4; k++) TL.list[k] = W.tier_list[k].as<uint32_t>();
+    for (int k = 0; k < NT; k++) TL.list[k] = W.tier_list[std::min(k, NT_MAX - 1)].as<uint32_t>();
+    for (int k = 0; k < T.n; k++) T.list[k] = W.tier_list[k].as<uint32_t>();
+    T.full_list = W.list.as<uint32_t>();
+    T.counts = counts;
+    const unsigned pb = (unsigned)((n + 31) / 32);
+    if (lm == 0) hipLaunchKernelGGL(k_sw_plan<160>, dim3(pb), dim3(256), 0, s, d_ov, n, in, p, T, tier);
+    else if (lm == 1) hipLaunchKernelGGL(k_sw_plan<256>, dim3(pb), dim3(256), 0, s, d_ov, n, in, p, T, tier);
+    else hipLaunchKernelGGL(k_sw_plan<512>, dim3(pb), dim3(256), 0, s, d_ov, n, in, p, T, tier);
+    hipLaunchKernelGGL(k_tier_hist, dim3(n_blocks), dim3(256), 0, s, tier, n, W.pos.as<uint32_t>(), n_blocks);
+    hipLaunchKernelGGL(k_tier_scan, dim3(NT), dim3(1024), 0, s, W.pos.as<uint32_t>(), n_blocks, counts);
     hipLaunchKernelGGL(k_tier_scatter, dim3(n_blocks), dim3(256), 0, s, tier, n, W.pos.as<uint32_t>(), n_blocks, TL);
-    uint32_t h[5] = {0, 0, 0, 0, 0};
-    for (int k = 0; k < n_tiers; k++) {
-      // the size of tier k: planned + appended by the tier before it (both in counts[k] by now)
+    uint32_t h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (debug) {
+      HIPCHK(hipMemcpyAsync(h, counts, sizeof h, hipMemcpyDeviceToHost, s));
+      HIPCHK(hipStreamSynchronize(s));
+      fprintf(stderr, "[kslam] SW planned: %u / %u / %u / %u / %u\n", h[0], h[1], h[2], h[3], h[4]);
+    }
+    for (int k = 0; k < T.n; k++) {
+      // the size of tier k: planned + sent on by the tiers before it (both in counts[k] by now)
       HIPCHK(hipMemcpyAsync(h, counts, sizeof h, hipMemcpyDeviceToHost, s));
       HIPCHK(hipStreamSynchronize(s));
       const uint64_t m = h[k];
-      if (debug) fprintf(stderr, "[kslam] SW tier %d (%d diagonals): %llu candidates\n", k, 16 << k, (unsigned long long)m);
+      const int nd = T.nd[k];
+      if (debug) fprintf(stderr, "[kslam] SW tier %d (%d diagonals): %llu candidates\n", k, nd, (unsigned long long)m);
       if (!m) continue;
-      const uint32_t *list = TL.list[k];
-      uint32_t *nl = k + 1 < n_tiers ? TL.list[k + 1] : W.list.as<uint32_t>();
-      uint32_t *nc = k + 1 < n_tiers ? counts + k + 1 : counts + 4;
+      const uint32_t *list = T.list[k];
 #define KSLAM_BAND(LM, GLV, DPLV, BSV) \
   hipLaunchKernelGGL((k_sw_band<LM, GLV, DPLV, BSV>), dim3((unsigned)((m + (BSV / GLV) - 1) / (BSV / GLV))), dim3(BSV), 0, s, \
-                     d_ov, m, in, p, d_band0, list, nl, nc)
+                     d_ov, m, in, p, d_band0, list, T, k)
+#define KSLAM_BAND_LM(GLV, DPLV, BSV) \
+  do { if (lm == 0) KSLAM_BAND(160, GLV, DPLV, BSV); else if (lm == 1) KSLAM_BAND(256, GLV, DPLV, BSV); \
+       else KSLAM_BAND(512, GLV, DPLV, BSV); } while (0)
       // lanes x diagonals per lane, measured on the bench workload: 8 x 8 beats 16 x 4 for the
       // 64-diagonal tier (9.7 against 10.5 ms); 4-lane shapes lose (half the waves per LDS byte)
-      static const int shape = getenv("KSLAM_SW_SHAPE") ? atoi(getenv("KSLAM_SW_SHAPE")) : 4;   // tuning knob
-      if (k == 0) {
-        if (lm == 0) { if (shape & 1) KSLAM_BAND(160, 4, 4, 128); else KSLAM_BAND(160, 8, 2, 256); }
-        else if (lm == 1) KSLAM_BAND(256, 8, 2, 256); else KSLAM_BAND(512, 8, 2, 256);
-      } else if (k == 1) {
-        if (lm == 0) { if (shape & 2) KSLAM_BAND(160, 4, 8, 128); else KSLAM_BAND(160, 8, 4, 256); }
-        else if (lm == 1) KSLAM_BAND(256, 8, 4, 256); else KSLAM_BAND(512, 8, 4, 256);
-      } else if (k == 2) {
-        if (lm == 0) { if (shape & 4) KSLAM_BAND(160, 8, 8, 128); else KSLAM_BAND(160, 16, 4, 256); }
-        else if (lm == 1) KSLAM_BAND(256, 16, 4, 256); else KSLAM_BAND(512, 16, 4, 256);
-      } else {
-        if (lm == 1) KSLAM_BAND(256, 16, 8, 256); else KSLAM_BAND(512, 16, 8, 256);
-      }
+      if (nd == 16) KSLAM_BAND_LM(8, 2, 256);
+      else if (nd == 32) KSLAM_BAND_LM(8, 4, 256);
+      else if (nd == 48) KSLAM_BAND_LM(8, 6, 128);
+      else if (nd == 64) { if (lm == 0) KSLAM_BAND(160, 8, 8, 128); else KSLAM_BAND_LM(16, 4, 256); }
+      else KSLAM_BAND_LM(16, 8, 256);
+#undef KSLAM_BAND_LM
 #undef KSLAM_BAND
     }
     HIPCHK(hipMemcpyAsync(h, counts, sizeof h, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    n_full = h[4];
+    n_full = h[NT_FULL];
     full_list = W.list.as<uint32_t>();
     if (debug) fprintf(stderr, "[kslam] SW full matrix: %llu candidates\n", (unsigned long long)n_full);
   }

@@ -92,7 +92,30 @@ struct CigJob {
   uint64_t wave_slab;   // scratch bytes per wavefront
   uint32_t *err;        // [0] traceback errors
   uint32_t variant;     // timing ablations (KSLAM_CIGAR_VARIANT), 0 in production
+  // where candidates go that are not finished by this launch (nullptr: the host re-lists by flags)
+  uint32_t *next_list = nullptr, *next_count = nullptr;         // band doubled: the next class
+  uint32_t *special_list = nullptr, *special_count = nullptr;   // handed back by the systolic kernel
+  uint32_t *big_count = nullptr;                                // cigar longer than the small temp slot
 };
+
+// wave-aggregated append of candidate ci to a list (one atomic per wave)
+__device__ inline void append_candidate(bool want, uint32_t ci, uint32_t *list, uint32_t *count) {
+  const uint64_t m = __ballot(want);
+  if (!m) return;
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t leader = (uint32_t)__builtin_ctzll(m);
+  uint32_t base = 0;
+  if (lane == leader) base = atomicAdd(count, (uint32_t)__popcll(m));
+  base = __shfl((int)base, (int)leader, 64);
+  if (want) list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = ci;
+}
+
+__global__ void k_cig_class(const uint32_t *__restrict__ bw, uint64_t n, uint8_t *__restrict__ cls) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t b = bw[i];
+  cls[i] = (b != 0 && !(b >> 31)) ? (uint8_t)min(band_class(b), 7u) : (uint8_t)255;
+}
 
 // banded_sw (ssw.c:594-792): one attempt with J.bw[ci], then traceback when max >= score.
 // One candidate per lane; everything the DP touches lives in LDS laid out [element][lane]
@@ -340,6 +363,7 @@ __global__ __launch_bounds__(64) void k_banded_lds(CigJob J, SwInputs in, SwPara
   J.bmax[ci] = mx;
   if (mx < score) {               // ssw.c:693-694: retry with twice the band
     J.bw[ci] = (uint32_t)band_width * 2u;
+    if (J.next_list) append_candidate(true, ci, J.next_list, J.next_count);
     return;
   }
   uint32_t *tmp = J.tmp + (uint64_t)(J.big ? (J.list_base + li) : ci) * J.cap;
@@ -354,6 +378,7 @@ __global__ __launch_bounds__(64) void k_banded_lds(CigJob J, SwInputs in, SwPara
   }
   if (ovf) {
     J.needbig[ci] = 1;  // rerun with a full-size temp slot
+    if (J.big_count) atomicAdd(J.big_count, 1u);
     return;
   }
   o.cigar_len = (uint32_t)l;
@@ -385,7 +410,7 @@ __global__ __launch_bounds__(BS) void k_cigar_systolic(CigJob J, SwInputs in, Sw
   const int32_t t = lane & (GL - 1);
   const int32_t grp = threadIdx.x / GL;
   const uint32_t li = blockIdx.x * NG + grp;
-  bool have = li < J.m;
+  bool have = li < J.m, special = false;
   uint32_t ci = 0;
   kslam_overlap o;
   memset(&o, 0, sizeof o);
@@ -400,9 +425,11 @@ __global__ __launch_bounds__(BS) void k_cigar_systolic(CigJob J, SwInputs in, Sw
     readLen = o.query_end - o.query_begin + 1;
     if (2 * bw + 1 > ND || refLen <= 2 * bw + 1 || readLen > LMAX || refLen > LMAX || readLen < 1) {
       if (t == 0) J.needbig[ci] = 3;
+      special = true;
       have = false;
     }
   }
+  if (J.special_list) append_candidate(special && t == 0, ci, J.special_list, J.special_count);
   if (have) {
     const uint64_t ro = in.read_off[o.read];
     const uint64_t L = in.read_off[o.read + 1] - ro;
@@ -507,6 +534,7 @@ __global__ __launch_bounds__(BS) void k_cigar_systolic(CigJob J, SwInputs in, Sw
   J.bmax[ci] = best;
   if (best < (int32_t)o.score) {               // ssw.c:693-694: retry with twice the band
     J.bw[ci] = (uint32_t)bw * 2u;
+    if (J.next_list) append_candidate(true, ci, J.next_list, J.next_count);
     return;
   }
   struct Acc {
@@ -533,6 +561,7 @@ __global__ __launch_bounds__(BS) void k_cigar_systolic(CigJob J, SwInputs in, Sw
   }
   if (ovf) {
     J.needbig[ci] = 1;  // rerun with a full-size temp slot
+    if (J.big_count) atomicAdd(J.big_count, 1u);
     return;
   }
   o.cigar_len = (uint32_t)l;
@@ -648,7 +677,12 @@ void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, u
     // classes, where 5 of 16 diagonal slots are live and the single-lane traceback dominates, stay
     // on the one-lane kernel (c0-c2: 3.9 / 5.4).
     static const int sys_mask = getenv("KSLAM_CIGAR_SYS") ? atoi(getenv("KSLAM_CIGAR_SYS")) : 0xF8;
-    auto launch_systolic = [&](uint64_t m, uint32_t slot_bw, uint32_t cls) -> bool {
+    struct Route {
+      const uint32_t *list = nullptr;
+      uint32_t *next_list = nullptr, *next_count = nullptr, *special_list = nullptr, *special_count = nullptr,
+               *big_count = nullptr;
+    };
+    auto launch_systolic = [&](uint64_t m, uint32_t slot_bw, uint32_t cls, const Route &R) -> bool {
       const uint32_t need = 2 * slot_bw + 1;
       if (need > 128 || !((sys_mask >> std::min(cls, 7u)) & 1)) return false;
       const int lm = lmax <= 160 ? 0 : (lmax <= 256 ? 1 : 2);
@@ -663,7 +697,9 @@ void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, u
       for (uint64_t g0 = 0; g0 < m; g0 += groups_per_launch) {
         CigJob J;
         J.ov = d_ov; J.bw = d_bw; J.bmax = W.bmax.as<int32_t>(); J.needbig = W.needbig.as<uint8_t>();
-        J.list = W.list.as<uint32_t>();
+        J.list = R.list ? R.list : W.list.as<uint32_t>();
+        J.next_list = R.next_list; J.next_count = R.next_count;
+        J.special_list = R.special_list; J.special_count = R.special_count; J.big_count = R.big_count;
         J.list_base = (uint32_t)g0;
         J.m = (uint32_t)std::min<uint64_t>(groups_per_launch, m - g0);
         J.slot_bw = slot_bw; J.lmax = lmax;
@@ -689,7 +725,7 @@ void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, u
       HIPCHK(hipGetLastError());
       return true;
     };
-    auto launch = [&](uint64_t m, uint32_t slot_bw, bool big) {
+    auto launch = [&](uint64_t m, uint32_t slot_bw, bool big, const Route &R) {
       LdsLayout Y;
       Y.lmax = lmax; Y.W1 = slot_bw * 2 + 4; Y.wd = slot_bw * 2 + 1;
       // Directions: global slab.  Keeping them in LDS (KSLAM_CIGAR_DIRS=lds) was measured: the DP is
@@ -726,7 +762,8 @@ void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, u
       for (uint64_t b0 = 0; b0 < n_blocks; b0 += blocks_per_launch) {
         CigJob J;
         J.ov = d_ov; J.bw = d_bw; J.bmax = W.bmax.as<int32_t>(); J.needbig = W.needbig.as<uint8_t>();
-        J.list = W.list.as<uint32_t>();
+        J.list = R.list ? R.list : W.list.as<uint32_t>();
+        J.next_list = R.next_list; J.next_count = R.next_count; J.big_count = R.big_count;
         const uint64_t nb_here = std::min<uint64_t>(blocks_per_launch, n_blocks - b0);
         J.list_base = (uint32_t)(b0 * nl);
         J.m = (uint32_t)std::min<uint64_t>(nb_here * nl, m - b0 * nl);
@@ -744,32 +781,71 @@ void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, u
       }
       HIPCHK(hipGetLastError());
     };
-    // largest initial band class present
-    hipLaunchKernelGGL(k_max_all, dim3(nb), dim3(256), 0, s, d_bw, n, reinterpret_cast<uint32_t *>(d_tot + 1));
-    uint64_t mb0 = 0;
-    HIPCHK(hipMemcpyAsync(&mb0, d_tot + 1, sizeof mb0, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    uint32_t last_cls = 0;
-    while ((1ull << last_cls) < mb0) last_cls++;
-    // failures move up exactly one class, so the sweep ends at the first empty class above last_cls
-    for (uint32_t cls = 0; cls < 31 && mb0 > 0; cls++) {
-      uint64_t m = run_lists(cls, 0);
-      if (m == 0) {
-        if (cls > last_cls) break;
-        continue;
-      }
-      if (getenv("KSLAM_DEBUG")) fprintf(stderr, "[kslam] cigar class %u (band <= %u): %llu candidates\n", cls, 1u << cls, (unsigned long long)m);
-      if (launch_systolic(m, 1u << cls, cls)) {
-        const uint64_t m2 = run_lists(cls, 2);   // the few it hands back (spans the band covers completely)
-        if (getenv("KSLAM_DEBUG")) fprintf(stderr, "[kslam]   handed to the one-lane kernel: %llu\n", (unsigned long long)m2);
-        if (m2) launch(m2, 1u << cls, false);
+    // Band classes 0..6 (bw <= 64): one partition of the candidates by class, then class after class;
+    // an attempt that falls short of the score doubles its band, i.e. moves up exactly one class, and
+    // the kernels append such candidates to the next class's list themselves.
+    const bool debug = getenv("KSLAM_DEBUG") != nullptr;
+    W.cls.ensure(n);
+    for (int k = 0; k < 8; k++) W.cls_list[k].ensure((n + 1) * sizeof(uint32_t));
+    W.special.ensure((n + 1) * sizeof(uint32_t));
+    W.counters.ensure(16 * sizeof(uint32_t));
+    uint32_t *cnt = W.counters.as<uint32_t>();   // [0..7] class list sizes, [8] handed back, [9] long cigars
+    HIPCHK(hipMemsetAsync(cnt, 0, 16 * sizeof(uint32_t), s));
+    hipLaunchKernelGGL(k_cig_class, dim3(nb), dim3(256), 0, s, d_bw, n, W.cls.as<uint8_t>());
+    uint32_t *lists[8];
+    for (int k = 0; k < 8; k++) lists[k] = W.cls_list[k].as<uint32_t>();
+    partition_bins(W.cls.as<uint8_t>(), n, lists, cnt, W.pos, s);
+    uint32_t hc[10];
+    for (uint32_t cls = 0; cls < 7; cls++) {
+      HIPCHK(hipMemcpyAsync(hc, cnt, sizeof hc, hipMemcpyDeviceToHost, s));
+      HIPCHK(hipStreamSynchronize(s));
+      const uint64_t m = hc[cls];
+      if (m == 0) continue;
+      if (debug) fprintf(stderr, "[kslam] cigar class %u (band <= %u): %llu candidates\n", cls, 1u << cls, (unsigned long long)m);
+      Route R;
+      R.list = lists[cls];
+      R.next_list = lists[cls + 1];
+      R.next_count = cnt + cls + 1;
+      R.special_list = W.special.as<uint32_t>();
+      R.special_count = cnt + 8;
+      R.big_count = cnt + 9;
+      if (launch_systolic(m, 1u << cls, cls, R)) {
+        HIPCHK(hipMemcpyAsync(hc, cnt, sizeof hc, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        if (hc[8]) {   // the few it hands back (spans the band covers completely)
+          if (debug) fprintf(stderr, "[kslam]   handed to the one-lane kernel: %u\n", hc[8]);
+          Route R2 = R;
+          R2.list = W.special.as<uint32_t>();
+          R2.special_list = nullptr;
+          launch(hc[8], 1u << cls, false, R2);
+          HIPCHK(hipMemsetAsync(cnt + 8, 0, sizeof(uint32_t), s));
+        }
       } else {
-        launch(m, 1u << cls, false);
+        launch(m, 1u << cls, false, R);
       }
-      if (cls >= last_cls) last_cls = cls + 1;
+    }
+    // wider than 64 (never seen on real reads): the flag / scan / scatter loop, class by class
+    HIPCHK(hipMemcpyAsync(hc, cnt, sizeof hc, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (hc[7]) {
+      uint32_t last_cls = 7;
+      for (uint32_t cls = 7; cls < 31; cls++) {
+        uint64_t m = run_lists(cls, 0);
+        if (m == 0) {
+          if (cls > last_cls) break;
+          continue;
+        }
+        if (debug) fprintf(stderr, "[kslam] cigar class %u (band <= %u): %llu candidates\n", cls, 1u << cls, (unsigned long long)m);
+        Route R;
+        R.big_count = cnt + 9;
+        launch(m, 1u << cls, false, R);
+        last_cls = cls + 1;
+      }
+      HIPCHK(hipMemcpyAsync(hc, cnt, sizeof hc, hipMemcpyDeviceToHost, s));
+      HIPCHK(hipStreamSynchronize(s));
     }
     // candidates whose cigar did not fit the small temp slot: rerun with full-size slots
-    uint64_t n_big = run_lists(0, 1);
+    uint64_t n_big = hc[9] ? run_lists(0, 1) : 0;
     if (n_big) {
       W.tmp_big.ensure(n_big * (uint64_t)cap_big * sizeof(uint32_t));
       HIPCHK(hipMemcpyAsync(W.big_pos.p, W.pos.p, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
@@ -779,7 +855,7 @@ void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, u
       uint64_t mb = 0;
       HIPCHK(hipMemcpyAsync(&mb, d_tot + 1, sizeof mb, hipMemcpyDeviceToHost, s));
       HIPCHK(hipStreamSynchronize(s));
-      launch(n_big, (uint32_t)mb, true);
+      launch(n_big, (uint32_t)mb, true, Route());
     }
   }
   // cigar pool layout

@@ -197,9 +197,15 @@ struct SwWork {
 void sw_scores(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, uint32_t max_read_len,
                uint32_t *d_band0, SwWork &W, uint64_t *n_full_out, hipStream_t s);
 
+// Stable 8-way partition of the element numbers 0..n-1 by d_bins[i] (bins >= 8 are left out):
+// d_lists[k] receives bin k's numbers in order, d_counts[k] its size (sw.hip).
+void partition_bins(const uint8_t *d_bins, uint64_t n, uint32_t *const d_lists[8], uint32_t *d_counts, DevBuf &pos,
+                    hipStream_t s);
+
 // --------------------------------------------------------------- cigar.hip
 struct CigarWork {
-  DevBuf flags, pos, list, bmax, needbig, scan_tmp, totals, cig_off, tmp, tmp_big, big_pos, scratch;
+  DevBuf flags, pos, list, bmax, needbig, scan_tmp, totals, cig_off, tmp, tmp_big, big_pos, scratch, cls, cls_list[8],
+      special, counters;
 };
 constexpr uint32_t CIG_CAP = 24;  // ops per small temp cigar slot
 // allocates and clears the per-candidate cigar state; call before sw_scores

@@ -392,7 +392,7 @@ __global__ __launch_bounds__(256) void k_tier_hist(const uint8_t *__restrict__ t
   const uint64_t base = (uint64_t)blockIdx.x * TIER_ITEMS;
   for (uint32_t k = threadIdx.x; k < TIER_ITEMS; k += 256) {
     const uint64_t i = base + k;
-    if (i < n) c[tier[i] & (NT - 1)]++;
+    if (i < n && tier[i] < NT) c[tier[i]]++;
   }
 #pragma unroll
   for (int k = 0; k < NT; k++) {
@@ -449,7 +449,7 @@ __global__ __launch_bounds__(256) void k_tier_scatter(const uint8_t *__restrict_
   const uint64_t b0 = (uint64_t)blockIdx.x * TIER_ITEMS;
   for (uint32_t r = 0; r < TIER_ITEMS / 256; r++) {
     const uint64_t i = b0 + (uint64_t)r * 256 + threadIdx.x;
-    const int tk = i < n ? (int)(tier[i] & (NT - 1)) : -1;
+    const int tk = (i < n && tier[i] < NT) ? (int)tier[i] : -1;   // bins >= NT: not listed
     uint32_t rank = 0;
 #pragma unroll
     for (int k = 0; k < NT; k++) {
@@ -645,6 +645,19 @@ __global__ __launch_bounds__(BS) void k_sw_band(kslam_overlap *__restrict__ ov, 
 }
 
 }  // namespace
+
+void partition_bins(const uint8_t *d_bins, uint64_t n, uint32_t *const d_lists[8], uint32_t *d_counts, DevBuf &pos,
+                    hipStream_t s) {
+  if (n == 0) return;
+  const uint32_t n_blocks = (uint32_t)((n + TIER_ITEMS - 1) / TIER_ITEMS);
+  pos.ensure((size_t)NT * n_blocks * sizeof(uint32_t));
+  TierLists TL;
+  for (int k = 0; k < NT; k++) TL.list[k] = d_lists[k];
+  hipLaunchKernelGGL(k_tier_hist, dim3(n_blocks), dim3(256), 0, s, d_bins, n, pos.as<uint32_t>(), n_blocks);
+  hipLaunchKernelGGL(k_tier_scan, dim3(NT), dim3(1024), 0, s, pos.as<uint32_t>(), n_blocks, d_counts);
+  hipLaunchKernelGGL(k_tier_scatter, dim3(n_blocks), dim3(256), 0, s, d_bins, n, pos.as<uint32_t>(), n_blocks, TL);
+  HIPCHK(hipGetLastError());
+}
 
 namespace {
 __global__ __launch_bounds__(256) void k_encode(const uint4 *__restrict__ src, uint4 *__restrict__ dst, uint64_t n16) {

@@ -35,18 +35,22 @@ __device__ inline uint32_t codes_of_dword(uint32_t v, bool comp) {
   return c;
 }
 
-// 6-bit packed score row (one field per reference code 0..3, code 4 reads the clear bits 24..29)
-__device__ inline uint32_t score_row(uint32_t q, const SwParams &p) {
-  const uint32_t mis = (uint32_t)(-p.mismatch) & 63u, mat = (uint32_t)p.match & 63u;
-  const uint32_t all_mis = mis | (mis << 6) | (mis << 12) | (mis << 18);
-  return q > 3u ? 0u : (all_mis ^ ((mis ^ mat) << (6u * q)));
+// 6-bit packed score row (one field per reference code 0..3; code 4 = N / padding reads field 4).
+// `bias` is added to every score, also to the zeros of N: the band kernels fold a constant per
+// diagonal step into the table (see k_sw_band).
+__device__ inline uint32_t score_row(uint32_t q, const SwParams &p, int32_t bias) {
+  const uint32_t mis = (uint32_t)(bias - p.mismatch) & 63u, mat = (uint32_t)(bias + p.match) & 63u;
+  const uint32_t zero = (uint32_t)bias & 63u;
+  const uint32_t all_mis = mis | (mis << 6) | (mis << 12) | (mis << 18) | (zero << 24);
+  const uint32_t all_zero = zero | (zero << 6) | (zero << 12) | (zero << 18) | (zero << 24);
+  return q > 3u ? all_zero : (all_mis ^ ((mis ^ mat) << (6u * q)));
 }
 
 // GL lanes stage src[0..len) into dst (16-byte aligned, >= len + STAGE_PAD bytes) as WS x code;
 // when tab != nullptr also the score row of every base.  Returns the offset of element 0 in dst.
 template <int GL, int WS>
 __device__ inline int32_t stage_span(const uint8_t *src, int32_t len, bool rc, int32_t t, uint8_t *dst,
-                                     uint32_t *tab, const SwParams &p) {
+                                     uint32_t *tab, const SwParams &p, int32_t bias = 0) {
   const uint32_t shift = (uint32_t)(reinterpret_cast<uintptr_t>(src) & 15u);
   const uint4 *base = reinterpret_cast<const uint4 *>(src - shift);
   const int32_t nch = ((int32_t)shift + len + 15) >> 4;
@@ -73,10 +77,10 @@ __device__ inline int32_t stage_span(const uint8_t *src, int32_t len, bool rc, i
 #pragma unroll
       for (int d = 0; d < 4; d++) {
         uint4 r;
-        r.x = score_row(((w[d]) & 0xFFu) / (uint32_t)WS, p);
-        r.y = score_row(((w[d] >> 8) & 0xFFu) / (uint32_t)WS, p);
-        r.z = score_row(((w[d] >> 16) & 0xFFu) / (uint32_t)WS, p);
-        r.w = score_row((w[d] >> 24) / (uint32_t)WS, p);
+        r.x = score_row(((w[d]) & 0xFFu) / (uint32_t)WS, p, bias);
+        r.y = score_row(((w[d] >> 8) & 0xFFu) / (uint32_t)WS, p, bias);
+        r.z = score_row(((w[d] >> 16) & 0xFFu) / (uint32_t)WS, p, bias);
+        r.w = score_row((w[d] >> 24) / (uint32_t)WS, p, bias);
         reinterpret_cast<uint4 *>(tab)[at * 4 + d] = r;
       }
     }

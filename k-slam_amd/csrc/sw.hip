@@ -175,7 +175,7 @@ struct Staged {
 // read (codes x 1, + score rows when tab != nullptr) and window (codes x WS) of candidate o
 template <int GL, int WS>
 __device__ inline Staged stage_candidate_wide(const kslam_overlap &o, const SwInputs &in, int32_t t, uint8_t *sq,
-                                              uint8_t *sw, uint32_t *tab, const SwParams &p) {
+                                              uint8_t *sw, uint32_t *tab, const SwParams &p, int32_t bias = 0) {
   const uint64_t ro = in.read_off[o.read];
   const int32_t L = (int32_t)(in.read_off[o.read + 1] - ro);
   const uint64_t go = in.genome_off[o.entry];
@@ -185,7 +185,7 @@ __device__ inline Staged stage_candidate_wide(const kslam_overlap &o, const SwIn
   Staged st;
   st.L = L;
   st.W = wlen;
-  st.qoff = stage_span<GL, 1>(in.read_codes + ro, L, false, t, sq, tab, p);
+  st.qoff = stage_span<GL, 1>(in.read_codes + ro, L, false, t, sq, tab, p, bias);
   st.woff = stage_span<GL, WS>(in.genome_codes + go + s0, wlen, o.revcomp != 0, t, sw, nullptr, p);   // :207
   return st;
 }
@@ -288,6 +288,7 @@ __device__ inline bool band_certifies(int32_t score, int32_t L, int32_t W, int32
 constexpr int NT_MAX = 5, NT_FULL = 7;
 struct Tiers {
   int n;                  // tiers in use
+  int unknown;            // tier a candidate starts in when its seed diagonals certify nothing
   int nd[NT_MAX];         // diagonals of tier k, ascending
   uint32_t *list[NT_MAX];
   uint32_t *full_list;
@@ -367,7 +368,7 @@ __global__ __launch_bounds__(256) void k_sw_plan(const kslam_overlap *__restrict
     best = max(best, v);
   }
   if (have && t == 0) {
-    int choice = 1;   // no diagonal certifies anything: start in the 32-diagonal band
+    int choice = T.unknown;   // no diagonal certifies anything (gapped alignment): see sw_scores
     for (int k = 0; k < T.n; k++) {
       const int ND = T.nd[k];
       if (band_certifies(best, L, W, d0 - ND / 2, ND, p)) {
@@ -518,7 +519,7 @@ __global__ __launch_bounds__(BS) void k_sw_band(kslam_overlap *__restrict__ ov, 
   if (have && p.ablate < 2) {
     const kslam_overlap o = ov[ci];
     rel = o.rel;
-    const Staged st = stage_candidate_wide<GL, 6>(o, in, t, s_q[grp], wc, tab, p);
+    const Staged st = stage_candidate_wide<GL, 6>(o, in, t, s_q[grp], wc, tab, p, 2 * p.gap_extend);
     L = st.L;
     W = st.W;
     qc += st.qoff;
@@ -526,14 +527,19 @@ __global__ __launch_bounds__(BS) void k_sw_band(kslam_overlap *__restrict__ ov, 
     tab += st.qoff;
   }
   __syncthreads();
+  const uint32_t pad_row = score_row(4u, p, 2 * p.gap_extend);
   for (int32_t x = t; x < PADM; x += GL) {   // the padding, after the chunk stores it overlaps
-    tab[x - PADM] = 0u;
-    tab[L + x] = 0u;
-    wc[x - PADM] = 24;                       // code 4 x 6: the clear bits 24..29 of every score row
+    tab[x - PADM] = pad_row;
+    tab[L + x] = pad_row;
+    wc[x - PADM] = 24;                       // code 4 x 6: field 4 of every score row
     wc[W + x] = 24;
   }
   __syncthreads();
-  const int32_t gO = p.gap_open << KB, gE = p.gap_extend << KB;
+  // Gap extension for free: every value is held with gE x (its anti-diagonal k = i + j) added to the
+  // score.  Then E' = max(E', H' - (gO - gE)) needs no subtraction for the extension, a diagonal step
+  // adds 2 gE (folded into the score table) and the zero floor Z grows by 2 gE per turn like
+  // everything else.  The running best is kept relative to the current anti-diagonal's offset.
+  const int32_t gE18 = p.gap_extend << KB, gOE = (p.gap_open - p.gap_extend) << KB;
   const int32_t NEG = -((p.gap_open + p.gap_extend + 1) << KB);
   const int32_t d0 = rel < 0 ? rel : 0;          // seed diagonal: read base i sits on window base i + d0
   const int32_t dlo = d0 - ND / 2, dhi = dlo + ND - 1;
@@ -554,28 +560,29 @@ __global__ __launch_bounds__(BS) void k_sw_band(kslam_overlap *__restrict__ ov, 
   const int32_t ib = (k0 - db) >> 1;                 // exact: k0 and dlo have the same parity, DPL is even
   const uint32_t *tp = tab + (ib - (DPL / 2 - 1));   // tp[DPL/2 - 1 - h]: score row of pair h
   const uint8_t *wp = wc + (ib + db);                // wp[h], wp[h + 1]: window codes of pair h
-  int32_t Zb = 513 * ib + 512 * db + 513;
+  int32_t Zb = 513 * ib + 512 * db + 513 + gE18 * k0;   // Z' of diagonal 0 of the lane (phase A: anti-diagonal k)
+  int32_t ZbB = Zb + gE18;                              // ... of the phase B cells (anti-diagonal k + 1)
   int32_t Hd[DPL], Eo[DPL], Fo[DPL];
 #pragma unroll
   for (int q = 0; q < DPL; q++) {
     const int h = q >> 1;
-    Hd[q] = Zb + (-513 * h + 512 * q) - 513;   // the cell before the first one: zero score, Z of its own
+    Hd[q] = ((q & 1) ? ZbB : Zb) + (-513 * h + 512 * q) - 513 - 2 * gE18;   // the cell before the first one
     Eo[q] = NEG;
     Fo[q] = NEG;
   }
-  int32_t lbV = 0, lbZ = 0;
+  int32_t lbV = gE18 * k0, lbZ = 0;   // best so far, in the offset of the phase being computed
   const int32_t nturns = have && !p.ablate && L > 0 && W > 0 && kmax >= k0 ? ((kmax - k0) >> 1) + 1 : 0;
   uint32_t trow[DPL / 2], wcode[DPL / 2 + 1];
   auto cell = [&](int q, int32_t Ein, int32_t Fin) {
     const int h = q >> 1;
     const int32_t s = __builtin_amdgcn_sbfe(trow[h], wcode[h + (q & 1)], 6);
-    const int32_t Z = Zb + (-513 * h + 512 * q);
+    const int32_t Z = ((q & 1) ? ZbB : Zb) + (-513 * h + 512 * q);
     int32_t hv = max(max(Hd[q] + (s << KB), Ein), Fin);
     hv = max(hv, Z);
     Hd[q] = hv;
-    const int32_t hg = hv - gO;
-    Eo[q] = max(Ein - gE, hg);
-    Fo[q] = max(Fin - gE, hg);
+    const int32_t hg = hv - gOE;
+    Eo[q] = max(Ein, hg);
+    Fo[q] = max(Fin, hg);
     const bool up = hv > (lbV | KEYMASK);
     lbV = up ? hv : lbV;
     lbZ = up ? Z : lbZ;
@@ -600,6 +607,7 @@ __global__ __launch_bounds__(BS) void k_sw_band(kslam_overlap *__restrict__ ov, 
 #pragma unroll
         for (int h = 0; h < DPL / 2; h++) cell(2 * h, e[h], f[h]);
       }
+      lbV += gE18;
       {  // phase B: the odd diagonals
         const int32_t fin = __builtin_amdgcn_update_dpp(0, Fo[0], 0x101, 0xF, 0xF, true);  // row_shl:1
         int32_t e[DPL / 2], f[DPL / 2];
@@ -611,9 +619,13 @@ __global__ __launch_bounds__(BS) void k_sw_band(kslam_overlap *__restrict__ ov, 
 #pragma unroll
         for (int h = 0; h < DPL / 2; h++) cell(2 * h + 1, e[h], f[h]);
       }
-      Zb += 513;
+      lbV += gE18;
+      Zb += 513 + 2 * gE18;
+      ZbB += 513 + 2 * gE18;
     }
   }
+  lbV -= gE18 * (k0 + 2 * nturns);   // back to plain scores
+  lbZ &= KEYMASK;                    // the position key; the offset sat above it
   const PassResult f = reduce_best<GL>(lbV, lbZ);
   // certificate: every alignment scoring >= f.score lies inside [dlo, dlo + ND - 1]
   const bool exact = have && band_certifies(f.score, L, W, dlo, ND, p);
@@ -699,9 +711,12 @@ void sw_scores(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, uint32_
   const uint32_t *full_list = nullptr;
   uint64_t n_full = n;
   const char *force_full = getenv("KSLAM_SW_FULL");
+  // the band kernels carry gE x (i + j) on top of the score and 2 gE inside the 6-bit table fields
+  const bool band_ok = (int64_t)(p.match + 2 * p.gap_extend) * (int64_t)max_read_len <= 8191 &&
+                       p.match + 2 * p.gap_extend <= 31;
   const bool debug = getenv("KSLAM_DEBUG") != nullptr;
   if (const char *ab = getenv("KSLAM_SW_ABLATE")) p.ablate = (uint32_t)atoi(ab);
-  if (!(force_full && force_full[0] == '1')) {
+  if (!(force_full && force_full[0] == '1') && band_ok) {
     // banded tiers of 16 / 32 / 64 (/ 128 for reads > 160 bases) diagonals; k_sw_plan sends each
     // candidate to the narrowest one its seed diagonal already certifies, the others start at 32;
     // whatever fails a tier's certificate is appended to the next tier's list, and what fails the
@@ -717,6 +732,14 @@ void sw_scores(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, uint32_
         if (nd == 48 && no48) continue;
         T.nd[T.n++] = nd;
       }
+    }
+    // Candidates whose diagonal sums certify nothing are the gapped ones; on the bench workload 62 % of
+    // them end up needing more than 32 diagonals, so starting them at 48 (3.1 us) is cheaper than 32
+    // first (2.25 us) and 48 again for most.
+    {
+      static const int unk = getenv("KSLAM_SW_UNKNOWN_ND") ? atoi(getenv("KSLAM_SW_UNKNOWN_ND")) : 48;
+      T.unknown = 1;
+      for (int k = 0; k < T.n; k++) if (T.nd[k] <= unk) T.unknown = k;
     }
     W.flags.ensure(n);                                   // tier per candidate (u8)
     for (int k = 0; k < T.n; k++) W.tier_list[k].ensure((n + 1) * sizeof(uint32_t));

@@ -587,15 +587,23 @@ __global__ __launch_bounds__(BS) void k_sw_band(kslam_overlap *__restrict__ ov, 
     lbV = up ? hv : lbV;
     lbZ = up ? Z : lbZ;
   };
-  for (int32_t n = 0;; n++) {
-    if (__ballot(n < nturns) == 0ull) break;
-    if (n < nturns) {   // a candidate that is done must not run on into its neighbours' buffers
+  // All lanes of the wave run the turns of its longest candidate.  A candidate that is done has only
+  // cells outside the matrix left (every one has a padding row or a padding column: "scores 0", so no
+  // new maximum); it stops advancing its pointers one turn past its last real one, so that it neither
+  // re-scores real cells nor runs on into its neighbours' buffers.
+  int32_t nmax = nturns;
+#pragma unroll
+  for (int m = GL; m < 64; m <<= 1) nmax = max(nmax, __shfl_xor(nmax, m, 64));
+  nmax = __builtin_amdgcn_readfirstlane(nmax);
+  for (int32_t n = 0; n < nmax; n++) {
+    {
 #pragma unroll
       for (int h = 0; h < DPL / 2; h++) trow[h] = tp[DPL / 2 - 1 - h];
 #pragma unroll
       for (int h = 0; h <= DPL / 2; h++) wcode[h] = wp[h];
-      tp += 1;
-      wp += 1;
+      const int32_t adv = n < nturns ? 1 : 0;
+      tp += adv;
+      wp += adv;
       {  // phase A: the lane's even diagonals; E comes from the odd diagonal below, F from the one above
         const int32_t ein = dpp_row_shr1(Eo[DPL - 1]);
         int32_t e[DPL / 2], f[DPL / 2];
@@ -620,11 +628,12 @@ __global__ __launch_bounds__(BS) void k_sw_band(kslam_overlap *__restrict__ ov, 
         for (int h = 0; h < DPL / 2; h++) cell(2 * h + 1, e[h], f[h]);
       }
       lbV += gE18;
-      Zb += 513 + 2 * gE18;
-      ZbB += 513 + 2 * gE18;
+      const int32_t zinc = 2 * gE18 + (adv ? 513 : 0);   // a frozen candidate's position key stays put
+      Zb += zinc;
+      ZbB += zinc;
     }
   }
-  lbV -= gE18 * (k0 + 2 * nturns);   // back to plain scores
+  lbV -= gE18 * (k0 + 2 * nmax);     // back to plain scores
   lbZ &= KEYMASK;                    // the position key; the offset sat above it
   const PassResult f = reduce_best<GL>(lbV, lbZ);
   // certificate: every alignment scoring >= f.score lies inside [dlo, dlo + ND - 1]

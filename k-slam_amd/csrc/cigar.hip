@@ -676,7 +676,7 @@ void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, u
     // workload (one-lane kernel / systolic, ms): c3 2.2 / 1.4, c4 3.1 / 1.5, c5 2.1 / 0.2; the narrow
     // classes, where 5 of 16 diagonal slots are live and the single-lane traceback dominates, stay
     // on the one-lane kernel (c0-c2: 3.9 / 5.4).
-    static const int sys_mask = getenv("KSLAM_CIGAR_SYS") ? atoi(getenv("KSLAM_CIGAR_SYS")) : 0xF8;
+    const int sys_mask = getenv("KSLAM_CIGAR_SYS") ? atoi(getenv("KSLAM_CIGAR_SYS")) : 0xF8;
     struct Route {
       const uint32_t *list = nullptr;
       uint32_t *next_list = nullptr, *next_count = nullptr, *special_list = nullptr, *special_count = nullptr,
@@ -751,7 +751,7 @@ void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, u
                               reinterpret_cast<const void *>(&k_banded_lds<4>)})
           HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       // narrow bands: the band in registers (KSLAM_CIGAR_REG=0 turns it off)
-      static const bool use_reg = !(getenv("KSLAM_CIGAR_REG") && getenv("KSLAM_CIGAR_REG")[0] == '0');
+      const bool use_reg = !(getenv("KSLAM_CIGAR_REG") && getenv("KSLAM_CIGAR_REG")[0] == '0');
       const uint32_t reg_bw = (!use_reg || big || Y.wpr) ? 0u : (slot_bw <= 2 ? 2u : (slot_bw <= 4 ? 4u : 0u));
       uint64_t slab = Y.wpr ? 256 : (uint64_t)lmax * std::max<uint32_t>(Y.wd, reg_bw ? 8u : 0u) * nl;   // direction
       slab = (slab + 255) & ~255ull;   // bytes per block; the register variant stores <= 8 bytes per row and lane

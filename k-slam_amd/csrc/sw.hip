@@ -734,7 +734,7 @@ void sw_scores(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, uint32_
     memset(&T, 0, sizeof T);
     {
       const int nd0[4] = {16, 32, 48, 64}, nd1[5] = {16, 32, 48, 64, 128};
-      static const bool no48 = getenv("KSLAM_SW_NO48") != nullptr;   // ablation
+      const bool no48 = getenv("KSLAM_SW_NO48") != nullptr;   // ablation
       T.n = 0;
       for (int k = 0; k < (lm == 0 ? 4 : 5); k++) {
         const int nd = lm == 0 ? nd0[k] : nd1[k];
@@ -746,7 +746,7 @@ void sw_scores(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, uint32_
     // them end up needing more than 32 diagonals, so starting them at 48 (3.1 us) is cheaper than 32
     // first (2.25 us) and 48 again for most.
     {
-      static const int unk = getenv("KSLAM_SW_UNKNOWN_ND") ? atoi(getenv("KSLAM_SW_UNKNOWN_ND")) : 48;
+      const int unk = getenv("KSLAM_SW_UNKNOWN_ND") ? atoi(getenv("KSLAM_SW_UNKNOWN_ND")) : 48;
       T.unknown = 1;
       for (int k = 0; k < T.n; k++) if (T.nd[k] <= unk) T.unknown = k;
     }

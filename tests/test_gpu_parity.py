@@ -295,6 +295,38 @@ def test_banded_sw_equals_full_matrix_sw(kslam, synth, monkeypatch, read_len, fr
     _compare_alignments(a, ac, b, bc)
 
 
+@pytest.mark.parametrize("read_len", [150, 250])
+def test_every_kernel_variant_gives_the_same_alignments(kslam, synth, monkeypatch, read_len):
+    """The hot path picks among several implementations per candidate (band tiers planned from the
+    seed diagonal / full matrix for the scores; band in registers / systolic / one lane with LDS rows
+    for the CIGAR).  Forcing each choice in turn must not change a single field or CIGAR op."""
+    genomes = synth.make_genomes(191, 6, 4, 60000, strain_sub=0.03, strain_indel=0.003)
+    reads, _ = synth.make_paired_reads(192, genomes, 5000 if read_len == 150 else 2500, read_len=read_len,
+                                       frag_mean=2 * read_len + 50, sub_rate=0.02, indel_rate=0.006,
+                                       n_rate=0.002, edge_frac=0.05)
+    rb, gb = synth.to_bytes(reads), synth.to_bytes(genomes)
+    c = kslam.Context()
+    c.set_index(gb)
+    base, bcig = c.align_batch(rb)
+    assert len(base) > 8000 and (base["cigar_len"] > 1).sum() > 1000
+    variants = [{"KSLAM_CIGAR_SYS": "0", "KSLAM_CIGAR_REG": "0"},   # every CIGAR on the literal one-lane kernel
+                {"KSLAM_CIGAR_SYS": "255"},                          # systolic for every band class
+                {"KSLAM_CIGAR_SYS": "0"},                            # registers for narrow, one-lane for wide
+                {"KSLAM_CIGAR_DIRS": "lds", "KSLAM_CIGAR_SYS": "0", "KSLAM_CIGAR_REG": "0"},
+                {"KSLAM_SW_FULL": "1"},                              # full-matrix scores only
+                {"KSLAM_SW_NO48": "1"},                              # tiers 16 / 32 / 64
+                {"KSLAM_SW_UNKNOWN_ND": "16"},                       # gapped candidates start at the narrowest band
+                {"KSLAM_SW_UNKNOWN_ND": "64"}]
+    for env in variants:
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        got, gcig = c.align_batch(rb)
+        for k in env:
+            monkeypatch.delenv(k)
+        _compare_alignments(got, gcig, base, bcig)
+    c.close()
+
+
 def test_sort_selftest_large(ctx):
     """full-size property: 64 M random records come out ordered (stable) after the 8-pass sort"""
     ms, ms_launch, inv = ctx.selftest_sort(1 << 26, 1)

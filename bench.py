@@ -275,16 +275,27 @@ def main():
     roffs = (np.arange(n_reads + 1, dtype=np.uint64) * np.uint64(args.read_len))
     ctx.load_reads_device(n_reads, reads.data_ptr(), roffs)
 
+    pending = []   # the gather of the previous batch, still in flight while this one is aligned
+
+    def drain():
+        while pending:
+            kdist.finish_gather(pending.pop())
+
     def step():
         n_out, n_cig = ctx.align_resident()
         if use_dist:
+            # the one exchange of the path: this rank's results go to rank 0 (point-to-point over xGMI).
+            # The transfer of batch k overlaps the alignment of batch k + 1; it is waited for before the
+            # next one starts and before the clock stops.
             ov = torch.empty(n_out * 48, dtype=torch.uint8, device=dev)
             cg = torch.empty(n_cig * 4, dtype=torch.uint8, device=dev)
             ctx.copy_results_device(ov.data_ptr(), cg.data_ptr())
-            kdist.gather_to_rank0(ov, cg)
+            drain()
+            pending.append(kdist.start_gather(ov, cg))
         return n_out, n_cig
 
     def barrier():
+        drain()
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()

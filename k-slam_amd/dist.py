@@ -25,11 +25,13 @@ def local_reads(reads, n_pairs, lo, hi):
     return list(reads[lo:hi]) + list(reads[n_pairs + lo:n_pairs + hi])
 
 
-def gather_to_rank0(ov_bytes, cig_bytes, group=None):
-    """Variable-length gather of (overlap records, cigar pool) byte tensors to rank 0.
+def start_gather(ov_bytes, cig_bytes, group=None):
+    """Begin the variable-length gather of (overlap records, cigar pool) byte tensors to rank 0.
 
-    ov_bytes / cig_bytes: 1-D uint8 tensors (device tensors with the nccl backend).
-    Returns on rank 0 a list of (ov, cig) uint8 tensors per rank, elsewhere None."""
+    ov_bytes / cig_bytes: 1-D uint8 tensors (device tensors with the nccl backend); they must stay
+    alive and unmodified until finish_gather.  Returns a handle for finish_gather.  Between the two
+    calls the caller is free to run the next batch: the point-to-point transfers proceed on the
+    communicator's own stream."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     dev = ov_bytes.device
@@ -55,10 +57,21 @@ def gather_to_rank0(ov_bytes, cig_bytes, group=None):
             ops.append(dist.P2POp(dist.isend, ov_bytes, 0, group))
         if cig_bytes.numel():
             ops.append(dist.P2POp(dist.isend, cig_bytes, 0, group))
-    if ops:
-        for q in dist.batch_isend_irecv(ops):
-            q.wait()
-    return parts
+    reqs = dist.batch_isend_irecv(ops) if ops else []
+    return {"reqs": reqs, "parts": parts, "keep": (ov_bytes, cig_bytes)}
+
+
+def finish_gather(handle):
+    """Wait for a gather begun with start_gather.  Returns on rank 0 a list of (ov, cig) uint8
+    tensors per rank, elsewhere None."""
+    for q in handle["reqs"]:
+        q.wait()
+    return handle["parts"]
+
+
+def gather_to_rank0(ov_bytes, cig_bytes, group=None):
+    """start_gather + finish_gather in one call."""
+    return finish_gather(start_gather(ov_bytes, cig_bytes, group))
 
 
 def reassemble(parts, bounds, n_pairs, overlap_dtype):

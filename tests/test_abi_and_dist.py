@@ -103,7 +103,12 @@ bounds = kd.shard_bounds(n_pairs, world)
 lo, hi = bounds[rank]
 al, cg, _ = O.align_to_database(kd.local_reads(reads, n_pairs, lo, hi), genomes)   # stands in for the HIP path
 ov_t = torch.from_numpy(al.view(np.uint8).copy()); cg_t = torch.from_numpy(cg.view(np.uint8).copy())
-parts = kd.gather_to_rank0(ov_t, cg_t)
+handle = kd.start_gather(ov_t, cg_t)          # bench.py overlaps the next batch here
+parts = kd.finish_gather(handle)
+again = kd.gather_to_rank0(ov_t, cg_t)         # the one-call form gives the same
+assert (again is None) == (parts is None)
+if parts is not None:
+    assert all(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) for a, b in zip(parts, again))
 if rank == 0:
     parts = [(p[0].numpy().view(K.OVERLAP_DT), p[1].numpy().view(np.uint32)) for p in parts]
     got, pool = kd.reassemble(parts, bounds, n_pairs, K.OVERLAP_DT)

@@ -60,21 +60,6 @@ __global__ void k_max_bw(const uint32_t *__restrict__ bw, const uint32_t *__rest
   if ((threadIdx.x & 63) == 0 && v) atomicMax(out, v);
 }
 
-__global__ void k_max_all(const uint32_t *__restrict__ bw, uint64_t n, uint32_t *__restrict__ out) {
-  __shared__ uint32_t sm[4];
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  uint32_t v = i < n ? bw[i] : 0;
-  if (v >> 31) v = 0;
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) v = max(v, (uint32_t)__shfl_down((int)v, d, 64));
-  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    v = max(max(sm[0], sm[1]), max(sm[2], sm[3]));
-    if (v) atomicMax(out, v);
-  }
-}
-
 struct CigJob {
   kslam_overlap *ov;
   uint32_t *bw;

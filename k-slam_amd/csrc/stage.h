@@ -15,8 +15,8 @@ __device__ inline int32_t dpp_row_shl1(int32_t v) {
 }
 
 // ---- wide staging --------------------------------------------------------------------------------
-// The byte-at-a-time staging above costs as much as the banded DP itself (one memory instruction
-// and one LDS store per base).  Here a span is fetched as 16-byte chunks from the 16-byte-aligned
+// Byte-at-a-time staging (stage_candidate in sw.hip, kept for the full-matrix kernel) cost as much as
+// a 16-diagonal band sweep: one memory instruction and one LDS store per base.  Here a span is fetched as 16-byte chunks from the 16-byte-aligned
 // address below it, a chunk per lane, converted in registers and stored with one 16-byte LDS
 // write (the sources are the pre-encoded base arrays, see encode_bases) -- at the chunk's own
 // position, NOT re-aligned: the buffer holds the codes of the aligned

@@ -172,7 +172,7 @@ struct SwParams {
   int32_t match, mismatch, gap_open, gap_extend;
   uint32_t score_threshold;
   int32_t report_cigar;
-  uint32_t ablate = 0;   // KSLAM_SW_ABLATE (measurement only): 1 = skip the DP sweep, 2 = skip staging too
+  uint32_t ablate = 0;   // KSLAM_SW_ABLATE (measurement only): 1 = no sweep, 2 = no staging either, 3 = one turn, result accepted
 };
 struct SwInputs {
   const uint8_t *read_bases;

@@ -571,7 +571,8 @@ __global__ __launch_bounds__(BS) void k_sw_band(kslam_overlap *__restrict__ ov, 
     Fo[q] = NEG;
   }
   int32_t lbV = gE18 * k0, lbZ = 0;   // best so far, in the offset of the phase being computed
-  const int32_t nturns = have && !p.ablate && L > 0 && W > 0 && kmax >= k0 ? ((kmax - k0) >> 1) + 1 : 0;
+  int32_t nturns = have && p.ablate != 1 && L > 0 && W > 0 && kmax >= k0 ? ((kmax - k0) >> 1) + 1 : 0;
+  if (p.ablate == 3) nturns = min(nturns, 1);   // measurement only: everything but the sweep
   uint32_t trow[DPL / 2], wcode[DPL / 2 + 1];
   auto cell = [&](int q, int32_t Ein, int32_t Fin) {
     const int h = q >> 1;
@@ -637,7 +638,7 @@ __global__ __launch_bounds__(BS) void k_sw_band(kslam_overlap *__restrict__ ov, 
   lbZ &= KEYMASK;                    // the position key; the offset sat above it
   const PassResult f = reduce_best<GL>(lbV, lbZ);
   // certificate: every alignment scoring >= f.score lies inside [dlo, dlo + ND - 1]
-  const bool exact = have && band_certifies(f.score, L, W, dlo, ND, p);
+  const bool exact = have && (p.ablate == 3 || band_certifies(f.score, L, W, dlo, ND, p));
   {  // The others move on.  What this band found is a real alignment's score, i.e. a lower bound:
      // it picks the narrowest later tier that is certain to certify (or the full matrix) directly.
      // One atomic per wave and destination reserves the list slots.

@@ -567,26 +567,29 @@ __global__ __launch_bounds__(BS) void k_sw_band(kslam_overlap *__restrict__ ov, 
   for (int q = 0; q < DPL; q++) {
     const int h = q >> 1;
     Hd[q] = ((q & 1) ? ZbB : Zb) + (-513 * h + 512 * q) - 513 - 2 * gE18;   // the cell before the first one
-    Eo[q] = NEG;
+    Eo[q] = Zb + (-513 * ((q + 1) >> 1) + 512 * (q + 1));   // no gap yet: the floor of phase A's cell q + 1 (odd q)
     Fo[q] = NEG;
   }
-  int32_t lbV = gE18 * k0, lbZ = 0;   // best so far, in the offset of the phase being computed
+  int32_t lbV = gE18 * k0, lbZ = 512;   // best so far, in the offset of the phase being computed
   int32_t nturns = have && p.ablate != 1 && L > 0 && W > 0 && kmax >= k0 ? ((kmax - k0) >> 1) + 1 : 0;
   if (p.ablate == 3) nturns = min(nturns, 1);   // measurement only: everything but the sweep
   uint32_t trow[DPL / 2], wcode[DPL / 2 + 1];
   auto cell = [&](int q, int32_t Ein, int32_t Fin) {
     const int h = q >> 1;
     const int32_t s = __builtin_amdgcn_sbfe(trow[h], wcode[h + (q & 1)], 6);
-    const int32_t Z = ((q & 1) ? ZbB : Zb) + (-513 * h + 512 * q);
-    int32_t hv = max(max(Hd[q] + (s << KB), Ein), Fin);
-    hv = max(hv, Z);
+    // The zero floor rides on E: what a cell hands to its right-hand neighbour (i, j + 1, one
+    // anti-diagonal on) is max(E, that neighbour's Z), so the neighbour's max3 below already holds
+    // its floor and needs no fourth operand.  Older floors carried along are lower in the score
+    // field than the newest one, i.e. dominated: every H is the same value as with a separate floor.
+    const int32_t Zr = ((q & 1) ? ZbB : Zb) + (-513 * h + 512 * q) + 512 + gE18;   // Z of (i, j + 1)
+    const int32_t hv = max(max(Hd[q] + (s << KB), Ein), Fin);
     Hd[q] = hv;
     const int32_t hg = hv - gOE;
-    Eo[q] = max(Ein, hg);
+    Eo[q] = max(max(Ein, hg), Zr);
     Fo[q] = max(Fin, hg);
     const bool up = hv > (lbV | KEYMASK);
     lbV = up ? hv : lbV;
-    lbZ = up ? Z : lbZ;
+    lbZ = up ? Zr : lbZ;   // 512 above the cell's own key (taken off after the sweep)
   };
   // All lanes of the wave run the turns of its longest candidate.  A candidate that is done has only
   // cells outside the matrix left (every one has a padding row or a padding column: "scores 0", so no
@@ -610,7 +613,7 @@ __global__ __launch_bounds__(BS) void k_sw_band(kslam_overlap *__restrict__ ov, 
         int32_t e[DPL / 2], f[DPL / 2];
 #pragma unroll
         for (int h = 0; h < DPL / 2; h++) {
-          e[h] = h == 0 ? (t == 0 ? NEG : ein) : Eo[2 * h - 1];
+          e[h] = h == 0 ? (t == 0 ? Zb : ein) : Eo[2 * h - 1];   // band edge: no E, just the floor
           f[h] = Fo[2 * h + 1];
         }
 #pragma unroll
@@ -635,7 +638,7 @@ __global__ __launch_bounds__(BS) void k_sw_band(kslam_overlap *__restrict__ ov, 
     }
   }
   lbV -= gE18 * (k0 + 2 * nmax);     // back to plain scores
-  lbZ &= KEYMASK;                    // the position key; the offset sat above it
+  lbZ = (lbZ - 512) & KEYMASK;       // the position key; the offset sat above it
   const PassResult f = reduce_best<GL>(lbV, lbZ);
   // certificate: every alignment scoring >= f.score lies inside [dlo, dlo + ND - 1]
   const bool exact = have && (p.ablate == 3 || band_certifies(f.score, L, W, dlo, ND, p));

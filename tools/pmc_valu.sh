@@ -1,0 +1,38 @@
+# SQ instruction counters of the SW kernels for one bench step -> gpurun_out/keep/<tag>_valu.json
+TAG=${1:-r01f}
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT; rm -rf /tmp/prof4; mkdir -p /tmp/prof4 gpurun_out/keep
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS --output-format csv -d /tmp/prof4 -o x -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-sam-pipeline > /tmp/o4 2> /tmp/e4
+rm -rf /tmp/prof5; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof5 -o x -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-sam-pipeline > /tmp/o5 2> /tmp/e5
+python3 - "$TAG" <<'PY'
+import csv, glob, json, sys
+tag = sys.argv[1]
+def clean(n): return n.replace('(anonymous namespace)::', '').replace('kslam::', '').replace('void ', '').split('(')[0]
+agg = {}
+for f in glob.glob('/tmp/prof4/**/*counter_collection.csv', recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = clean(r['Kernel_Name'])
+        if not k.startswith(('k_sw', 'k_cigar_systolic', 'k_banded')): continue
+        agg.setdefault(k, {}).setdefault(r['Counter_Name'], 0.0)
+        agg[k][r['Counter_Name']] += float(r['Counter_Value'])
+dur = {}
+for r in csv.DictReader(open(glob.glob('/tmp/prof5/**/*kernel_stats.csv', recursive=True)[0])):
+    dur[clean(r['Name'])] = float(r['TotalDurationNs'])
+out = {"source": "rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS and, in a separate run, --kernel-trace --stats; bench.py --steps 1 --warmup 0",
+       "peak_valu_wave_instr_per_s": 256 * 4 * 2.4e9 / 2,
+       "peak_note": "256 CUs x 4 SIMD-32 x 2.4 GHz, a wave64 VALU instruction issues over 2 cycles (MI355X_MICROARCH.md)",
+       "kernels": {}}
+tot_i = tot_t = 0
+for k, c in sorted(agg.items()):
+    t = dur.get(k)
+    if not t: continue
+    rate = c.get('SQ_INSTS_VALU', 0) / (t * 1e-9)
+    out["kernels"][k] = {"valu_wave_instr": c.get('SQ_INSTS_VALU'), "salu": c.get('SQ_INSTS_SALU'), "lds": c.get('SQ_INSTS_LDS'),
+                         "waves": c.get('SQ_WAVES'), "duration_ms": t / 1e6, "valu_wave_instr_per_s": rate,
+                         "frac_of_peak": rate / out["peak_valu_wave_instr_per_s"]}
+    if k.startswith('k_sw_band'): tot_i += c.get('SQ_INSTS_VALU', 0); tot_t += t
+out["sw_band_total"] = {"valu_wave_instr": tot_i, "duration_ms": tot_t / 1e6, "valu_wave_instr_per_s": tot_i / (tot_t * 1e-9),
+                        "frac_of_peak": tot_i / (tot_t * 1e-9) / out["peak_valu_wave_instr_per_s"]}
+json.dump(out, open('gpurun_out/keep/%s_valu.json' % tag, 'w'), indent=1)
+for k, v in out["kernels"].items(): print(k.ljust(36), "%.0f G/s  %.2f of peak  (%.2f ms)" % (v["valu_wave_instr_per_s"] / 1e9, v["frac_of_peak"], v["duration_ms"]))
+print("sw band total", out["sw_band_total"])
+PY

@@ -34,6 +34,8 @@
 // moves: {H of the last row, F leaving the strip} and the running column
 // maximum packed as (H << 16 | 0xFFFF - row) so one v_max_u32 both maximises H
 // and minimises the row index.  Sequences sit in LDS as 1 byte/base codes.
+#include <type_traits>
+
 #include "common.h"
 #include "stage.h"
 
@@ -43,6 +45,13 @@ namespace {
 
 constexpr int KB = 18;                    // low bits of a packed DP value: origin key (col << 9 | row)
 constexpr int32_t KEYMASK = (1 << KB) - 1;
+
+// a wave-uniform value in a vector register (kept there: the compiler would hold it in an SGPR)
+__device__ inline int32_t in_vgpr(int32_t x) {
+  int32_t v;
+  asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(x));
+  return v;
+}
 
 struct PassResult {
   int32_t score, end_col, end_row, beg_col, beg_row;
@@ -560,85 +569,115 @@ __global__ __launch_bounds__(BS) void k_sw_band(kslam_overlap *__restrict__ ov, 
   const int32_t ib = (k0 - db) >> 1;                 // exact: k0 and dlo have the same parity, DPL is even
   const uint32_t *tp = tab + (ib - (DPL / 2 - 1));   // tp[DPL/2 - 1 - h]: score row of pair h
   const uint8_t *wp = wc + (ib + db);                // wp[h], wp[h + 1]: window codes of pair h
-  int32_t Zb = 513 * ib + 512 * db + 513 + gE18 * k0;   // Z' of diagonal 0 of the lane (phase A: anti-diagonal k)
-  int32_t ZbB = Zb + gE18;                              // ... of the phase B cells (anti-diagonal k + 1)
+  const int32_t Zb0 = 513 * ib + 512 * db + 513 + gE18 * k0;   // Z' of diagonal 0 of the lane on anti-diagonal k0
+  // Loop-invariant operands of the sweep live in VGPRs on purpose: on gfx950 the plain 32-bit
+  // add / sub / or / and issue at twice the rate when every source is a VGPR or a literal (an SGPR
+  // source halves it; tools/valu_peak.hip).
+  const int32_t gOEv = in_vgpr(gOE), dZv = in_vgpr(512 + gE18), zincv = in_vgpr(2 * gE18 + 513);
+  // ZrA / ZrB: Z' of the right-hand neighbour (i, j + 1, one anti-diagonal on) of the lane's
+  // diagonal-0 cell in phase A (anti-diagonal k) and phase B (k + 1)
+  int32_t ZrA = Zb0 + 512 + gE18, ZrB = ZrA + gE18;
   int32_t Hd[DPL], Eo[DPL], Fo[DPL];
 #pragma unroll
   for (int q = 0; q < DPL; q++) {
     const int h = q >> 1;
-    Hd[q] = ((q & 1) ? ZbB : Zb) + (-513 * h + 512 * q) - 513 - 2 * gE18;   // the cell before the first one
-    Eo[q] = Zb + (-513 * ((q + 1) >> 1) + 512 * (q + 1));   // no gap yet: the floor of phase A's cell q + 1 (odd q)
+    Hd[q] = Zb0 + ((q & 1) ? gE18 : 0) + (-513 * h + 512 * q) - 513 - 2 * gE18;   // the cell before the first one
+    Eo[q] = Zb0 + (-513 * ((q + 1) >> 1) + 512 * (q + 1));   // no gap yet: the floor of phase A's cell q + 1 (odd q)
     Fo[q] = NEG;
   }
-  int32_t lbV = gE18 * k0, lbZ = 512;   // best so far, in the offset of the phase being computed
+  // Running best of the lane, by the reference's rule -- highest score, then smallest column, then
+  // smallest row (ssw.c:316-342) -- whatever order the cells are visited in (a lane meets column j + 1
+  // of one diagonal before column j of the next).  G = (H' | KEYMASK) - Zr is the plain score (the
+  // anti-diagonal offset cancels) over the INVERTED position key, so one signed compare decides.
+  // The H' that came with the best G (score and origin key) rides along as the low half of a 64-bit
+  // (G, H') pair whose maximum is ONE v_max_f64: bit patterns of non-negative doubles order like
+  // integers, and with the IEEE bit of the MODE register cleared every NaN pattern -- here: G in
+  // [-2^20, 0), only cells scoring <= gE + 3 -- is simply passed over, like the negative ones.
+  const int32_t G0 = KEYMASK - 512 - gE18;   // G = G0 + score * 2^18 - key(cell)
+  double best = 0.0;                         // (G, H') of the lane's best cell; +0.0: none yet
+  asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 9, 1), 0");   // MODE.IEEE = 0 (no float math in this kernel)
   int32_t nturns = have && p.ablate != 1 && L > 0 && W > 0 && kmax >= k0 ? ((kmax - k0) >> 1) + 1 : 0;
   if (p.ablate == 3) nturns = min(nturns, 1);   // measurement only: everything but the sweep
   uint32_t trow[DPL / 2], wcode[DPL / 2 + 1];
   auto cell = [&](int q, int32_t Ein, int32_t Fin) {
     const int h = q >> 1;
     const int32_t s = __builtin_amdgcn_sbfe(trow[h], wcode[h + (q & 1)], 6);
-    // The zero floor rides on E: what a cell hands to its right-hand neighbour (i, j + 1, one
-    // anti-diagonal on) is max(E, that neighbour's Z), so the neighbour's max3 below already holds
-    // its floor and needs no fourth operand.  Older floors carried along are lower in the score
-    // field than the newest one, i.e. dominated: every H is the same value as with a separate floor.
-    const int32_t Zr = ((q & 1) ? ZbB : Zb) + (-513 * h + 512 * q) + 512 + gE18;   // Z of (i, j + 1)
+    // The zero floor rides on E: what a cell hands to its right-hand neighbour is max(E, that
+    // neighbour's Z), so the neighbour's max3 below already holds its floor and needs no fourth
+    // operand.  Older floors carried along are lower in the score field than the newest one, i.e.
+    // dominated: every H is the same value as with a separate floor.
+    const int32_t Zr = ((q & 1) ? ZrB : ZrA) + (-513 * h + 512 * q);
     const int32_t hv = max(max(Hd[q] + (s << KB), Ein), Fin);
     Hd[q] = hv;
-    const int32_t hg = hv - gOE;
+    const int32_t hg = hv - gOEv;
     Eo[q] = max(max(Ein, hg), Zr);
     Fo[q] = max(Fin, hg);
-    const bool up = hv > (lbV | KEYMASK);
-    lbV = up ? hv : lbV;
-    lbZ = up ? Zr : lbZ;   // 512 above the cell's own key (taken off after the sweep)
+    const int32_t G = (hv | KEYMASK) - Zr;
+    const double cand = __hiloint2double(G, hv);
+    asm("v_max_f64 %0, %1, %2" : "=v"(best) : "v"(best), "v"(cand));
   };
   // All lanes of the wave run the turns of its longest candidate.  A candidate that is done has only
   // cells outside the matrix left (every one has a padding row or a padding column: "scores 0", so no
   // new maximum); it stops advancing its pointers one turn past its last real one, so that it neither
-  // re-scores real cells nor runs on into its neighbours' buffers.
-  int32_t nmax = nturns;
+  // re-scores real cells nor runs on into its neighbours' buffers.  The turns every candidate of the
+  // wave still needs run without that bookkeeping.
+  int32_t nmax = nturns, nmin = nturns;
 #pragma unroll
-  for (int m = GL; m < 64; m <<= 1) nmax = max(nmax, __shfl_xor(nmax, m, 64));
+  for (int m = GL; m < 64; m <<= 1) {
+    nmax = max(nmax, __shfl_xor(nmax, m, 64));
+    nmin = min(nmin, __shfl_xor(nmin, m, 64));
+  }
   nmax = __builtin_amdgcn_readfirstlane(nmax);
-  for (int32_t n = 0; n < nmax; n++) {
-    {
+  nmin = __builtin_amdgcn_readfirstlane(nmin);
+  auto turn = [&](auto may_freeze, int32_t n) {
 #pragma unroll
-      for (int h = 0; h < DPL / 2; h++) trow[h] = tp[DPL / 2 - 1 - h];
+    for (int h = 0; h < DPL / 2; h++) trow[h] = tp[DPL / 2 - 1 - h];
 #pragma unroll
-      for (int h = 0; h <= DPL / 2; h++) wcode[h] = wp[h];
+    for (int h = 0; h <= DPL / 2; h++) wcode[h] = wp[h];
+    int32_t zinc;
+    if constexpr (decltype(may_freeze)::value) {
       const int32_t adv = n < nturns ? 1 : 0;
       tp += adv;
       wp += adv;
-      {  // phase A: the lane's even diagonals; E comes from the odd diagonal below, F from the one above
-        const int32_t ein = dpp_row_shr1(Eo[DPL - 1]);
-        int32_t e[DPL / 2], f[DPL / 2];
-#pragma unroll
-        for (int h = 0; h < DPL / 2; h++) {
-          e[h] = h == 0 ? (t == 0 ? Zb : ein) : Eo[2 * h - 1];   // band edge: no E, just the floor
-          f[h] = Fo[2 * h + 1];
-        }
-#pragma unroll
-        for (int h = 0; h < DPL / 2; h++) cell(2 * h, e[h], f[h]);
-      }
-      lbV += gE18;
-      {  // phase B: the odd diagonals
-        const int32_t fin = __builtin_amdgcn_update_dpp(0, Fo[0], 0x101, 0xF, 0xF, true);  // row_shl:1
-        int32_t e[DPL / 2], f[DPL / 2];
-#pragma unroll
-        for (int h = 0; h < DPL / 2; h++) {
-          e[h] = Eo[2 * h];
-          f[h] = h == DPL / 2 - 1 ? (t == GL - 1 ? NEG : fin) : Fo[2 * h + 2];
-        }
-#pragma unroll
-        for (int h = 0; h < DPL / 2; h++) cell(2 * h + 1, e[h], f[h]);
-      }
-      lbV += gE18;
-      const int32_t zinc = 2 * gE18 + (adv ? 513 : 0);   // a frozen candidate's position key stays put
-      Zb += zinc;
-      ZbB += zinc;
+      zinc = 2 * gE18 + (adv ? 513 : 0);   // a frozen candidate's position key stays put
+    } else {
+      tp += 1;
+      wp += 1;
+      zinc = zincv;
     }
-  }
-  lbV -= gE18 * (k0 + 2 * nmax);     // back to plain scores
-  lbZ = (lbZ - 512) & KEYMASK;       // the position key; the offset sat above it
+    {  // phase A: the lane's even diagonals; E comes from the odd diagonal below, F from the one above
+      const int32_t ein = dpp_row_shr1(Eo[DPL - 1]);
+      int32_t e[DPL / 2], f[DPL / 2];
+#pragma unroll
+      for (int h = 0; h < DPL / 2; h++) {
+        e[h] = h == 0 ? (t == 0 ? ZrA - dZv : ein) : Eo[2 * h - 1];   // band edge: no E, just the floor
+        f[h] = Fo[2 * h + 1];
+      }
+#pragma unroll
+      for (int h = 0; h < DPL / 2; h++) cell(2 * h, e[h], f[h]);
+    }
+    {  // phase B: the odd diagonals
+      const int32_t fin = __builtin_amdgcn_update_dpp(0, Fo[0], 0x101, 0xF, 0xF, true);  // row_shl:1
+      int32_t e[DPL / 2], f[DPL / 2];
+#pragma unroll
+      for (int h = 0; h < DPL / 2; h++) {
+        e[h] = Eo[2 * h];
+        f[h] = h == DPL / 2 - 1 ? (t == GL - 1 ? NEG : fin) : Fo[2 * h + 2];
+      }
+#pragma unroll
+      for (int h = 0; h < DPL / 2; h++) cell(2 * h + 1, e[h], f[h]);
+    }
+    ZrA += zinc;
+    ZrB += zinc;
+  };
+  for (int32_t n = 0; n < nmin; n++) turn(std::false_type{}, n);
+  for (int32_t n = nmin; n < nmax; n++) turn(std::true_type{}, n);
+  // back to the lane's best as (score, origin key) and the cell's position key
+  const int32_t Gb = __double2hiint(best), lbO = __double2loint(best);
+  const bool none = (Gb | lbO) == 0;
+  const int32_t gv = Gb - G0;                       // score * 2^18 - key(cell), key(cell) in (0, 2^18)
+  const int32_t lsc = none ? 0 : (gv + KEYMASK) >> KB;
+  const int32_t lbV = (lsc << KB) | (lbO & KEYMASK), lbZ = none ? 0 : (lsc << KB) - gv;
   const PassResult f = reduce_best<GL>(lbV, lbZ);
   // certificate: every alignment scoring >= f.score lies inside [dlo, dlo + ND - 1]
   const bool exact = have && (p.ablate == 3 || band_certifies(f.score, L, W, dlo, ND, p));

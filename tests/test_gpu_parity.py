@@ -359,3 +359,26 @@ def test_repeated_genomes_long_runs(kslam, oracle, synth):
     exp, ecig, _ = oracle.align_to_database(rb, genomes)
     assert len(exp) >= 120 * 100
     _compare_alignments(got, gcig, exp, ecig)
+
+
+@pytest.mark.parametrize("unknown_nd", [None, "32", "48", "64"])
+def test_equal_best_scores_on_neighbouring_diagonals(kslam, oracle, monkeypatch, unknown_nd):
+    """tests/golden/sw_tie_cases.json: reads whose best score is reached by two alignments ending a few
+    diagonals apart (a tandem repeat after a unique seed; window cut by the genome end), found with
+    a model of the band sweep's visiting order.  The reference reports the smallest end column, then
+    the smallest end row (ssw.c:316-342) -- also when both ends fall to the same lane of the sweep."""
+    import json
+    cases = json.load(open(os.path.join(GOLD, "sw_tie_cases.json")))
+    if unknown_nd:
+        monkeypatch.setenv("KSLAM_SW_UNKNOWN_ND", unknown_nd)
+    bad = []
+    for k, c in enumerate(cases):
+        reads, genomes = [c["read"].encode()], [c["ref"].encode()]
+        got, gcig = kslam.align_to_database(reads, genomes)
+        exp, ecig, _ = oracle.align_to_database(reads, genomes)
+        assert len(exp) == 1 and (int(exp["ref_end"][0]), int(exp["query_end"][0])) == tuple(c["true"])
+        try:
+            _compare_alignments(got, gcig, exp, ecig)
+        except AssertionError as e:
+            bad.append((k, c["dpl"], str(e)[:120]))
+    assert not bad, bad

@@ -17,7 +17,7 @@
       asm volatile(REP16(OP("%0", "%1") OP("%1", "%2") OP("%2", "%3") OP("%3", "%4") OP("%4", "%5")     \
                              OP("%5", "%6") OP("%6", "%7") OP("%7", "%0"))                              \
                    : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)     \
-                   : "v"(b), "v"(c) : "vcc");                                                           \
+                   : "v"(b), "v"(c) : "vcc", "s20", "s21", "s22");                                                           \
     out[blockIdx.x * blockDim.x + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;                 \
   }
 
@@ -65,13 +65,41 @@
 #define OP_XAD(d, s)     "v_xad_u32 " d ", " s ", %8, %9\n"
 #define OP_BFI(d, s)     "v_bfi_b32 " d ", " s ", %8, %9\n"
 #define OP_ALIGNBIT(d, s) "v_alignbit_b32 " d ", " s ", %8, 8\n"
-#define OP_PKADDF32(d, s) ""
+// compare + two selects, the running-best update of the SW sweep: through VCC (32-bit encodings)
+// and through an SGPR pair (64-bit encodings); 3 instructions per OP
+#define OP_CMPCND32(d, s) "v_cmp_gt_i32 vcc, " s ", %8\n v_cndmask_b32 " d ", " d ", " s ", vcc\n v_cndmask_b32 %9, %9, " s ", vcc\n"
+#define OP_CMPCND64(d, s) "v_cmp_gt_i32 s[20:21], " s ", %8\n v_cndmask_b32 " d ", " d ", " s ", s[20:21]\n v_cndmask_b32 %9, %9, " s ", s[20:21]\n"
+#define OP_CND32(d, s)    "v_cndmask_b32 " d ", " d ", " s ", vcc\n"
+#define OP_CND64(d, s)    "v_cndmask_b32 " d ", " d ", " s ", s[20:21]\n"
+#define OP_SUBREV(d, s)   "v_subrev_u32 " d ", %8, " s "\n"
+#define OP_ADDS(d, s)     "v_add_u32 " d ", s22, " s "\n"
+#define OP_ADDLIT(d, s)   "v_add_u32 " d ", 0x3ff, " s "\n"
+#define OP_ORLIT(d, s)    "v_or_b32 " d ", 0x3ffff, " s "\n"
+#define OP_MAXLIT(d, s)   "v_max_i32 " d ", 0x3ffff, " s "\n"
 
 #define KINDS(X) X(ADD) X(SUB) X(AND) X(OR) X(XOR) X(MOV) X(LSHL) X(LSHR) X(ASHR) X(MAXI) X(MAXU) X(MINI) X(MAXF) X(ADDF) X(FMA) \
   X(MAX3) X(MAX3F) X(MED3) X(ADD3) X(LSHLADD) X(ANDOR) X(BFE) X(PERM) X(CMP) X(CNDMASK) X(MAXI16) X(MAXU16) X(ADDU16) X(PKMAXI16) \
-  X(PKADDU16) X(PKMAXF16) X(MAXF16) X(MOVDPP) X(ADDDPP) X(MAXDPP) X(ADDSDWA) X(SAD) X(MAD24) X(MULLO) X(ADDCO) X(XAD) X(BFI) X(ALIGNBIT)
+  X(PKADDU16) X(PKMAXF16) X(MAXF16) X(MOVDPP) X(ADDDPP) X(MAXDPP) X(ADDSDWA) X(SAD) X(MAD24) X(MULLO) X(ADDCO) X(XAD) X(BFI) X(ALIGNBIT) X(CMPCND32) X(CMPCND64) X(CND32) X(CND64) X(SUBREV) X(ADDS) X(ADDLIT) X(ORLIT) X(MAXLIT)
 #define MK(N) DEFK(k_##N, OP_##N)
 KINDS(MK)
+
+// 64-bit maximum through the f64 pipe (bit patterns of non-negative, non-NaN doubles order like integers)
+__global__ void __launch_bounds__(256) k_MAXF64(uint32_t *out, int iters) {
+  double a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, b = blockIdx.x + 0.5;
+  for (int i = 0; i < iters; ++i)
+    asm volatile(REP16("v_max_f64 %0, %1, %4\n v_max_f64 %1, %2, %4\n v_max_f64 %2, %3, %4\n v_max_f64 %3, %0, %4\n"
+                       "v_max_f64 %0, %1, %4\n v_max_f64 %1, %2, %4\n v_max_f64 %2, %3, %4\n v_max_f64 %3, %0, %4\n")
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b));
+  out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)(a0 + a1 + a2 + a3);
+}
+__global__ void __launch_bounds__(256) k_CMPU64(uint32_t *out, int iters) {
+  double a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, b = blockIdx.x + 0.5;
+  for (int i = 0; i < iters; ++i)
+    asm volatile(REP16("v_cmp_gt_u64 s[20:21], %1, %4\n v_cmp_gt_u64 s[20:21], %2, %4\n v_cmp_gt_u64 s[20:21], %3, %4\n v_cmp_gt_u64 s[20:21], %0, %4\n"
+                       "v_cmp_gt_u64 s[20:21], %1, %4\n v_cmp_gt_u64 s[20:21], %2, %4\n v_cmp_gt_u64 s[20:21], %3, %4\n v_cmp_gt_u64 s[20:21], %0, %4\n")
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b) : "s20", "s21");
+  out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)(a0 + a1 + a2 + a3);
+}
 
 typedef void (*kern_t)(uint32_t *, int);
 static void run(const char *name, kern_t k, int waves_per_simd, uint32_t *out) {
@@ -91,6 +119,7 @@ int main() {
   for (int w : {4, 1}) {
 #define RUN(N) run(#N, k_##N, w, out);
     KINDS(RUN)
+    RUN(MAXF64) RUN(CMPU64)
   }
   return 0;
 }

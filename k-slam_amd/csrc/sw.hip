@@ -53,6 +53,21 @@ __device__ inline int32_t in_vgpr(int32_t x) {
   return v;
 }
 
+typedef int32_t v2i32 __attribute__((ext_vector_type(2)));
+// a + b / a - b as exactly one all-VGPR instruction: keeps the compiler from re-deriving running
+// values as sums of several induction variables or folding an SGPR into a three-operand form
+// (both cost more issue cycles than they save; tools/valu_peak.hip)
+__device__ inline int32_t add_vv(int32_t a, int32_t b) {
+  int32_t r;
+  asm("v_add_u32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ inline int32_t sub_vv(int32_t a, int32_t b) {
+  int32_t r;
+  asm("v_sub_u32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 struct PassResult {
   int32_t score, end_col, end_row, beg_col, beg_row;
 };
@@ -612,8 +627,9 @@ __global__ __launch_bounds__(BS) void k_sw_band(kslam_overlap *__restrict__ ov, 
     const int32_t hg = hv - gOEv;
     Eo[q] = max(max(Ein, hg), Zr);
     Fo[q] = max(Fin, hg);
-    const int32_t G = (hv | KEYMASK) - Zr;
-    const double cand = __hiloint2double(G, hv);
+    const int32_t G = sub_vv(hv | KEYMASK, Zr);
+    const v2i32 gh = {hv, G};                              // low half, high half
+    const double cand = __builtin_bit_cast(double, gh);
     asm("v_max_f64 %0, %1, %2" : "=v"(best) : "v"(best), "v"(cand));
   };
   // All lanes of the wave run the turns of its longest candidate.  A candidate that is done has only
@@ -667,13 +683,14 @@ __global__ __launch_bounds__(BS) void k_sw_band(kslam_overlap *__restrict__ ov, 
 #pragma unroll
       for (int h = 0; h < DPL / 2; h++) cell(2 * h + 1, e[h], f[h]);
     }
-    ZrA += zinc;
-    ZrB += zinc;
+    ZrA = add_vv(ZrA, zinc);
+    ZrB = add_vv(ZrB, zinc);
   };
   for (int32_t n = 0; n < nmin; n++) turn(std::false_type{}, n);
   for (int32_t n = nmin; n < nmax; n++) turn(std::true_type{}, n);
   // back to the lane's best as (score, origin key) and the cell's position key
-  const int32_t Gb = __double2hiint(best), lbO = __double2loint(best);
+  const v2i32 bb = __builtin_bit_cast(v2i32, best);
+  const int32_t Gb = bb.y, lbO = bb.x;
   const bool none = (Gb | lbO) == 0;
   const int32_t gv = Gb - G0;                       // score * 2^18 - key(cell), key(cell) in (0, 2^18)
   const int32_t lsc = none ? 0 : (gv + KEYMASK) >> KB;

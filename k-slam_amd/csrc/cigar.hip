@@ -194,6 +194,7 @@ __device__ inline int32_t banded_attempt_reg(Seq &m, uint32_t *DW, uint32_t NL, 
     R[x] = (uint32_t)j < (uint32_t)refLen ? m.r(j) : 4u;
   }
   const int32_t live = 2 * bw;   // last live slot
+  const int32_t gO = in_vgpr(p.gap_open), gE = in_vgpr(p.gap_extend);
   for (int32_t i = 0; i < readLen; i++) {
     const uint32_t qc = m.q(i);
     int32_t hleft = 0, f = 0;
@@ -206,11 +207,11 @@ __device__ inline int32_t banded_attempt_reg(Seq &m, uint32_t *DW, uint32_t NL, 
       const bool valid = x <= live && (uint32_t)j < (uint32_t)refLen;
       const uint32_t rc = R[x];
       const int32_t sc = (qc > 3u || rc > 3u) ? 0 : (qc == rc ? p.match : -p.mismatch);
-      int32_t t1 = H[x + 1] - p.gap_open, t2 = E[x + 1] - p.gap_extend;     // ssw.c:668-671
+      int32_t t1 = H[x + 1] - gO, t2 = E[x + 1] - gE;                       // ssw.c:668-671
       const int32_t ev = max(t1, t2);
       const uint32_t de = t1 > t2 ? 1u : 0u;
-      t1 = hleft - p.gap_open;                                             // ssw.c:673-676
-      t2 = f - p.gap_extend;
+      t1 = hleft - gO;                                                     // ssw.c:673-676
+      t2 = f - gE;
       const int32_t fv = max(t1, t2);
       const uint32_t df = t1 > t2 ? 1u : 0u;
       const int32_t e1 = max(ev, 0), f1 = max(fv, 0);                      // ssw.c:678-682
@@ -430,7 +431,7 @@ __global__ __launch_bounds__(BS) void k_cigar_systolic(CigJob J, SwInputs in, Sw
   }
   __syncthreads();
   // ---- the attempt
-  const int32_t gO = p.gap_open, gE = p.gap_extend;
+  const int32_t gO = in_vgpr(p.gap_open), gE = in_vgpr(p.gap_extend);
   const int32_t k0 = (bw & 1) ? -1 : 0;               // first anti-diagonal: parity of the lowest diagonal -bw
   const int32_t db = -bw + DPL * t;
   const int32_t ib = (k0 - db) >> 1;
@@ -449,13 +450,18 @@ __global__ __launch_bounds__(BS) void k_cigar_systolic(CigJob J, SwInputs in, Sw
   const uint32_t *tp = tab + (ib - (DPL / 2 - 1));
   const uint8_t *wp = wc + (ib + db);
   int32_t mx = 0;
-  const int32_t nturns = have ? ((readLen + refLen - 2 - k0) >> 1) + 1 : 0;
+  const int32_t nturns = have && J.variant != 2 ? ((readLen + refLen - 2 - k0) >> 1) + 1 : 0;   // (variant 2: staging only)
   uint32_t *D = reinterpret_cast<uint32_t *>(J.scratch) + ((uint64_t)blockIdx.x * NG + grp) * (J.wave_slab / 4);
   uint32_t word[WPT];
-  auto cell = [&](int q, int32_t n, int32_t Hu, int32_t Eu, int32_t Hl, int32_t Fl) {
-    if ((uint32_t)(n - vs[q]) < vl[q]) {
+  // score rows and window codes of a turn are fetched up front for all of the lane's cells, existing
+  // or not (an address outside the candidate's rows reads a neighbour's or nothing; the value is
+  // not used): inside the per-cell branches the loads would each be waited for in turn
+  uint32_t trow[DPL / 2], wcode[DPL / 2 + 1];
+  int32_t nv = 0;   // the turn counter in a VGPR
+  auto cell = [&](int q, int32_t Hu, int32_t Eu, int32_t Hl, int32_t Fl) {
+    if ((uint32_t)(nv - vs[q]) < vl[q]) {
       const int h = q >> 1;
-      const int32_t s = __builtin_amdgcn_sbfe(tp[DPL / 2 - 1 - h], (uint32_t)wp[h + (q & 1)], 6);
+      const int32_t s = __builtin_amdgcn_sbfe(trow[h], wcode[h + (q & 1)], 6);
       int32_t t1 = Hu - gO, t2 = Eu - gE;                  // ssw.c:668-671
       const int32_t ev = max(t1, t2);
       const uint32_t de = t1 > t2 ? 1u : 0u;
@@ -478,6 +484,10 @@ __global__ __launch_bounds__(BS) void k_cigar_systolic(CigJob J, SwInputs in, Sw
     if (__ballot(n < nturns) == 0ull) break;
 #pragma unroll
     for (int w = 0; w < WPT; w++) word[w] = 0;
+#pragma unroll
+    for (int h = 0; h < DPL / 2; h++) trow[h] = tp[DPL / 2 - 1 - h];
+#pragma unroll
+    for (int h = 0; h <= DPL / 2; h++) wcode[h] = wp[h];
     {  // phase A: the even diagonals of the lane; left neighbour of q = 0 lives in lane t - 1
       const int32_t hl = dpp_row_shr1(H[DPL - 1]), fl = dpp_row_shr1(F[DPL - 1]);
       int32_t Hl[DPL / 2], Fl[DPL / 2], Hu[DPL / 2], Eu[DPL / 2];
@@ -489,7 +499,7 @@ __global__ __launch_bounds__(BS) void k_cigar_systolic(CigJob J, SwInputs in, Sw
         Eu[h] = E[2 * h + 1];
       }
 #pragma unroll
-      for (int h = 0; h < DPL / 2; h++) cell(2 * h, n, Hu[h], Eu[h], Hl[h], Fl[h]);
+      for (int h = 0; h < DPL / 2; h++) cell(2 * h, Hu[h], Eu[h], Hl[h], Fl[h]);
     }
     {  // phase B: the odd diagonals; upper neighbour of q = DPL - 1 lives in lane t + 1
       const int32_t hu = dpp_row_shl1(H[0]), eu = dpp_row_shl1(E[0]);
@@ -502,7 +512,7 @@ __global__ __launch_bounds__(BS) void k_cigar_systolic(CigJob J, SwInputs in, Sw
         Eu[h] = h == DPL / 2 - 1 ? (t == GL - 1 ? 0 : eu) : E[2 * h + 2];
       }
 #pragma unroll
-      for (int h = 0; h < DPL / 2; h++) cell(2 * h + 1, n, Hu[h], Eu[h], Hl[h], Fl[h]);
+      for (int h = 0; h < DPL / 2; h++) cell(2 * h + 1, Hu[h], Eu[h], Hl[h], Fl[h]);
     }
     if (n < nturns) {
 #pragma unroll
@@ -510,11 +520,12 @@ __global__ __launch_bounds__(BS) void k_cigar_systolic(CigJob J, SwInputs in, Sw
     }
     tp += 1;
     wp += 1;
+    nv += 1;
   }
 #pragma unroll
   for (int m = 1; m < GL; m <<= 1) mx = max(mx, __shfl_xor(mx, m, GL));
   __threadfence_block();   // the direction words of the whole group, visible to its lane 0
-  if (!have || t != 0) return;
+  if (!have || t != 0 || J.variant == 1) return;   // (variant 1, measurement only: no traceback)
   const int32_t best = max(mx, J.bmax[ci]);   // `max` is carried across attempts, ssw.c:684
   J.bmax[ci] = best;
   if (best < (int32_t)o.score) {               // ssw.c:693-694: retry with twice the band
@@ -694,7 +705,7 @@ void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, u
         J.scratch = W.scratch.as<uint8_t>();
         J.wave_slab = slab;
         J.err = d_err;
-        J.variant = 0;
+        { const char *cv = getenv("KSLAM_CIGAR_VARIANT"); J.variant = cv ? (uint32_t)atoi(cv) : 0u; }
         const unsigned nb = (unsigned)((J.m + NG - 1) / NG);
 #define KSLAM_SYS(LMV, GLV, DPLV) \
   hipLaunchKernelGGL((k_cigar_systolic<LMV, GLV, DPLV, 128>), dim3(nb), dim3(128), 0, s, J, in, p)

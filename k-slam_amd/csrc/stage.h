@@ -5,6 +5,16 @@
 
 namespace kslam {
 
+// A wave-uniform value in a vector register (kept there: the compiler would hold it in an SGPR).
+// On gfx950 the plain 32-bit add / sub / and / or issue in 2 cycles per wave when every source is a
+// VGPR or a literal and in 4 with an SGPR source (tools/valu_peak.hip), so loop-invariant operands
+// of the DP sweeps are parked in VGPRs.
+__device__ inline int32_t in_vgpr(int32_t x) {
+  int32_t v;
+  asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(x));
+  return v;
+}
+
 __device__ inline int32_t dpp_row_shr1(int32_t v) {
   // lane i of each 16-lane row receives lane i-1; lane 0 receives 0
   return __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);

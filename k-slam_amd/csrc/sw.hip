@@ -46,13 +46,6 @@ namespace {
 constexpr int KB = 18;                    // low bits of a packed DP value: origin key (col << 9 | row)
 constexpr int32_t KEYMASK = (1 << KB) - 1;
 
-// a wave-uniform value in a vector register (kept there: the compiler would hold it in an SGPR)
-__device__ inline int32_t in_vgpr(int32_t x) {
-  int32_t v;
-  asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(x));
-  return v;
-}
-
 typedef int32_t v2i32 __attribute__((ext_vector_type(2)));
 // a + b / a - b as exactly one all-VGPR instruction: keeps the compiler from re-deriving running
 // values as sums of several induction variables or folding an SGPR into a three-operand form

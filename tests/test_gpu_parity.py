@@ -382,3 +382,44 @@ def test_equal_best_scores_on_neighbouring_diagonals(kslam, oracle, monkeypatch,
         except AssertionError as e:
             bad.append((k, c["dpl"], str(e)[:120]))
     assert not bad, bad
+
+
+def _low_complexity_dataset(synth, seed, n_genomes, n_reads, read_len):
+    """Genomes that alternate unique stretches (seeds) with tandem repeats of period 1..6 (where equal
+    best scores, equal-cost gap placements and off-diagonal optima are the rule), reads sampled from
+    them on both strands with substitutions, Ns and indels; some reads run over a genome's end."""
+    rng = np.random.default_rng(seed)
+    genomes = []
+    for _ in range(n_genomes):
+        parts = []
+        while sum(len(x) for x in parts) < 3000:
+            parts.append(synth.random_bases(rng, int(rng.integers(40, 90))))
+            unit = synth.random_bases(rng, int(rng.integers(1, 7)))
+            rep = np.resize(unit, int(rng.integers(20, 120)))
+            parts.append(synth.mutate(rng, rep, 0.02, 0.004))
+        genomes.append(np.concatenate(parts))
+    genomes.append(synth.mutate(rng, genomes[0], 0.02, 0.003, 4))   # a strain: near-identical candidates
+    reads = []
+    for _ in range(n_reads):
+        g = genomes[int(rng.integers(0, len(genomes)))]
+        L = int(rng.integers(read_len // 2, read_len + 1))
+        p = int(rng.integers(0, len(g) - L // 2))
+        r = synth.mutate(rng, g[p:p + L], 0.02, 0.01, 4)
+        if rng.random() < 0.2 and len(r) > 3:
+            r[rng.integers(0, len(r), int(rng.integers(1, 3)))] = ord("N")
+        reads.append(synth.revcomp(r) if rng.random() < 0.5 else r)
+    return synth.to_bytes(reads), synth.to_bytes(genomes)
+
+
+@pytest.mark.parametrize("read_len,scoring", [(150, None), (100, None), (250, None), (150, (1, 4, 6, 1)), (150, (3, 2, 4, 1))])
+def test_low_complexity_parity(kslam, oracle, synth, read_len, scoring):
+    reads, genomes = _low_complexity_dataset(synth, 900 + read_len + (scoring[0] if scoring else 0), 5, 2500, read_len)
+    kw = {}
+    p = oracle.Params.default()
+    if scoring:
+        kw = dict(match=scoring[0], mismatch=scoring[1], gap_open=scoring[2], gap_extend=scoring[3])
+        p = oracle.Params.default(**kw)
+    got, gcig = kslam.align_to_database(reads, genomes, **kw)
+    exp, ecig, _ = oracle.align_to_database(reads, genomes, p)
+    assert len(exp) > 2000 and (exp["cigar_len"] > 1).sum() > 300
+    _compare_alignments(got, gcig, exp, ecig)

@@ -19,7 +19,12 @@ for r in csv.DictReader(open(glob.glob('/tmp/prof5/**/*kernel_stats.csv', recurs
     dur[clean(r['Name'])] = float(r['TotalDurationNs'])
 out = {"source": "rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS and, in a separate run, --kernel-trace --stats; bench.py --steps 1 --warmup 0",
        "peak_valu_wave_instr_per_s": 256 * 4 * 2.4e9 / 2,
-       "peak_note": "256 CUs x 4 SIMD-32 x 2.4 GHz, a wave64 VALU instruction issues over 2 cycles (MI355X_MICROARCH.md)",
+       "peak_note": "256 CUs x 4 SIMD-32 x 2.4 GHz, a wave64 VALU instruction issues over 2 cycles (MI355X_MICROARCH.md).  "
+                    "tools/valu_peak.hip measures what the chip sustains per instruction kind: ~1.08 T/s for the 2-cycle "
+                    "kinds (32-bit add/sub/and/or/xor/mov/lshr with VGPR or literal sources) and ~0.575 T/s for the 4-cycle "
+                    "kinds (v_max/min_i32, every VOP3 / DPP / SDWA encoding, any SGPR source, v_max_f64): a kernel made mostly "
+                    "of the latter tops out near 0.6 T/s = 0.5 of this nominal peak",
+       "measured_rate_2cycle_kinds": 1.084e12, "measured_rate_4cycle_kinds": 0.575e12,
        "kernels": {}}
 tot_i = tot_t = 0
 for k, c in sorted(agg.items()):

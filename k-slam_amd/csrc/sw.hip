@@ -575,8 +575,14 @@ __global__ __launch_bounds__(BS) void k_sw_band(kslam_overlap *__restrict__ ov, 
   // is a constant away from the lane's Z of diagonal 0.
   const int32_t db = dlo + DPL * t;
   const int32_t ib = (k0 - db) >> 1;                 // exact: k0 and dlo have the same parity, DPL is even
-  const uint32_t *tp = tab + (ib - (DPL / 2 - 1));   // tp[DPL/2 - 1 - h]: score row of pair h
-  const uint8_t *wp = wc + (ib + db);                // wp[h], wp[h + 1]: window codes of pair h
+  // One byte offset into each LDS array per lane, advanced by a single all-VGPR add per turn; the
+  // loads use it with immediate offsets (score row of pair h: dword DPL/2 - 1 - h; window codes of
+  // pair h: bytes h and h + 1).
+  uint8_t *const tab0 = reinterpret_cast<uint8_t *>(&s_tab[0][0]);
+  uint8_t *const win0 = &s_w[0][0];
+  int32_t tofs = (int32_t)(reinterpret_cast<const uint8_t *>(tab + (ib - (DPL / 2 - 1))) - tab0);
+  int32_t wofs = (int32_t)((wc + (ib + db)) - win0);
+  const int32_t two_v = in_vgpr(2), eight_v = in_vgpr(8);
   const int32_t Zb0 = 513 * ib + 512 * db + 513 + gE18 * k0;   // Z' of diagonal 0 of the lane on anti-diagonal k0
   // Loop-invariant operands of the sweep live in VGPRs on purpose: on gfx950 the plain 32-bit
   // add / sub / or / and issue at twice the rate when every source is a VGPR or a literal (an SGPR
@@ -638,22 +644,8 @@ __global__ __launch_bounds__(BS) void k_sw_band(kslam_overlap *__restrict__ ov, 
   }
   nmax = __builtin_amdgcn_readfirstlane(nmax);
   nmin = __builtin_amdgcn_readfirstlane(nmin);
-  auto turn = [&](auto may_freeze, int32_t n) {
-#pragma unroll
-    for (int h = 0; h < DPL / 2; h++) trow[h] = tp[DPL / 2 - 1 - h];
-#pragma unroll
-    for (int h = 0; h <= DPL / 2; h++) wcode[h] = wp[h];
-    int32_t zinc;
-    if constexpr (decltype(may_freeze)::value) {
-      const int32_t adv = n < nturns ? 1 : 0;
-      tp += adv;
-      wp += adv;
-      zinc = 2 * gE18 + (adv ? 513 : 0);   // a frozen candidate's position key stays put
-    } else {
-      tp += 1;
-      wp += 1;
-      zinc = zincv;
-    }
+  // the DP part of a turn: trow[] / wcode[] hold its score rows and window codes
+  auto sweep = [&](int32_t zinc) {
     {  // phase A: the lane's even diagonals; E comes from the odd diagonal below, F from the one above
       const int32_t ein = dpp_row_shr1(Eo[DPL - 1]);
       int32_t e[DPL / 2], f[DPL / 2];
@@ -679,8 +671,37 @@ __global__ __launch_bounds__(BS) void k_sw_band(kslam_overlap *__restrict__ ov, 
     ZrA = add_vv(ZrA, zinc);
     ZrB = add_vv(ZrB, zinc);
   };
-  for (int32_t n = 0; n < nmin; n++) turn(std::false_type{}, n);
-  for (int32_t n = nmin; n < nmax; n++) turn(std::true_type{}, n);
+  // Two turns per trip while every candidate of the wave still advances: the score rows and window
+  // codes of both are fetched together up front (the second turn's are the first's shifted by one
+  // entry), so the LDS latency is paid once per two turns and overlaps the first turn's arithmetic.
+  int32_t tn = 0;
+  for (; tn + 2 <= nmin; tn += 2) {
+    uint32_t TT[DPL / 2 + 1], WW[DPL / 2 + 2];
+#pragma unroll
+    for (int j = 0; j <= DPL / 2; j++) TT[j] = *reinterpret_cast<const uint32_t *>(tab0 + tofs + 4 * j);
+#pragma unroll
+    for (int x = 0; x <= DPL / 2 + 1; x++) WW[x] = win0[wofs + x];
+    tofs = add_vv(tofs, eight_v);
+    wofs = add_vv(wofs, two_v);
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+#pragma unroll
+      for (int h = 0; h < DPL / 2; h++) trow[h] = TT[DPL / 2 - 1 - h + u];
+#pragma unroll
+      for (int h = 0; h <= DPL / 2; h++) wcode[h] = WW[h + u];
+      sweep(zincv);
+    }
+  }
+  for (; tn < nmax; tn++) {
+#pragma unroll
+    for (int h = 0; h < DPL / 2; h++) trow[h] = *reinterpret_cast<const uint32_t *>(tab0 + tofs + 4 * (DPL / 2 - 1 - h));
+#pragma unroll
+    for (int h = 0; h <= DPL / 2; h++) wcode[h] = win0[wofs + h];
+    const int32_t adv = tn < nturns ? 1 : 0;
+    tofs += 4 * adv;
+    wofs += adv;
+    sweep(2 * gE18 + (adv ? 513 : 0));   // a frozen candidate's position key stays put
+  }
   // back to the lane's best as (score, origin key) and the cell's position key
   const v2i32 bb = __builtin_bit_cast(v2i32, best);
   const int32_t Gb = bb.y, lbO = bb.x;

@@ -58,6 +58,29 @@ __device__ inline Run find_run(uint64_t key, const GenomeIndexDev &g) {
   const uint32_t b = (uint32_t)(key >> (64 - g.bucket_bits));
   uint32_t lo = g.bucket[b], hi = g.bucket[b + 1];
   const uint32_t end = hi;
+  if (hi - lo <= 16u) {
+    // The usual bucket holds a handful of keys: fetch them all at once (independent loads, one
+    // round trip) and count instead of chasing a binary search through ten dependent loads.
+    const uint32_t nb = hi - lo;
+    uint32_t lt = 0, le = 0;
+#pragma unroll
+    for (uint32_t half = 0; half < 2; half++) {
+      if (half * 8u < nb) {
+        uint64_t k[8];
+#pragma unroll
+        for (uint32_t i = 0; i < 8; i++) k[i] = half * 8u + i < nb ? g.key[lo + half * 8u + i] : ~0ull;
+#pragma unroll
+        for (uint32_t i = 0; i < 8; i++) {
+          const bool in = half * 8u + i < nb;
+          lt += (in && k[i] < key) ? 1u : 0u;
+          le += (in && k[i] <= key) ? 1u : 0u;
+        }
+      }
+    }
+    r.lo = lo + lt;
+    r.cnt = le - lt;
+    return r;
+  }
   while (lo < hi) {  // lower_bound
     uint32_t mid = lo + ((hi - lo) >> 1);
     if (g.key[mid] < key) lo = mid + 1; else hi = mid;

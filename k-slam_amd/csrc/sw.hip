@@ -107,7 +107,7 @@ __device__ inline PassResult sw_origin_pass(const uint8_t *qcodes, int32_t qlen,
   const int32_t t = lane & 15;
   uint32_t tab[R];
   int32_t H[R], E[R], rowkey[R];
-  const int32_t gO = p.gap_open << KB, gE = p.gap_extend << KB;
+  const int32_t gO = in_vgpr(p.gap_open << KB), gE = in_vgpr(p.gap_extend << KB);   // VGPR operands: 2-cycle subtractions
   const int32_t NEG = -((p.gap_open + p.gap_extend + 1) << KB);
 #pragma unroll
   for (int r = 0; r < R; r++) {
@@ -130,7 +130,10 @@ __device__ inline PassResult sw_origin_pass(const uint8_t *qcodes, int32_t qlen,
   }
   int32_t prev_hl = t * R;                // virtual cell (tR - 1, -1): successor (tR, 0)
   int32_t out_h = 0, out_f = 0;
-  int32_t lbV = 0, lbZ = 0;               // lane-local best cell: packed value and its Z (= position + 1)
+  // lane-local best cell as a 64-bit (G, H) pair kept by one v_max_f64 per cell, G = (H | KEYMASK) - Z =
+  // score over the inverted position key (see k_sw_band); here G >= 0 always (no offset on the score)
+  double best = 0.0;
+  asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 9, 1), 0");   // MODE.IEEE = 0: NaN patterns are passed over
   const int32_t nsteps = ncols > 0 ? ncols + 15 : 0;
   for (int32_t step = 0;; step++) {
     if (__ballot(step < nsteps) == 0ull) break;   // the four groups of the wave iterate together
@@ -154,14 +157,17 @@ __device__ inline PassResult sw_origin_pass(const uint8_t *qcodes, int32_t qlen,
         const int32_t hg = h - gO;
         E[r] = max(E[r] - gE, hg);
         F = max(F - gE, hg);
-        const bool up = h > (lbV | KEYMASK);       // strictly larger score: first column, smallest row win
-        lbV = up ? h : lbV;
-        lbZ = up ? Z : lbZ;
+        const v2i32 gh = {h, sub_vv(h | KEYMASK, Z)};   // highest score, then first column, then smallest row
+        const double cand = __builtin_bit_cast(double, gh);
+        asm("v_max_f64 %0, %1, %2" : "=v"(best) : "v"(best), "v"(cand));
       }
       out_h = H[R - 1];
       out_f = F;
     }
   }
+  const v2i32 bb = __builtin_bit_cast(v2i32, best);
+  const int32_t lbV = bb.x;                                            // score and origin key of the best cell
+  const int32_t lbZ = (bb.x >> KB) > 0 ? KEYMASK - (bb.y & KEYMASK) : 0;   // its position key
   return reduce_best(lbV, lbZ);
 }
 

@@ -35,6 +35,7 @@ struct kslam_ctx {
   uint64_t n_reads = 0;
   uint32_t max_read_len = 0;
   std::vector<uint64_t> h_roff;  // [n_reads + 1]
+  std::vector<uint64_t> h_kpre, h_spre;   // [n_reads + 1] k-mers / extraction segments of the reads before i (chunk planning)
   DevBuf r_bases, r_off, r_len, r_codes;
 
   // ---- work buffers ----
@@ -268,7 +269,17 @@ void finish_load_reads(kslam_ctx *c) {
   const uint64_t n = c->n_reads;
   if (n >= (1ull << 30)) throw StatusError{KSLAM_ERR_UNSUPPORTED, "more than 2^30 reads (KMer.h:65 id field)"};
   uint64_t mx = 0;
-  for (uint64_t i = 0; i < n; i++) mx = std::max(mx, c->h_roff[i + 1] - c->h_roff[i]);
+  // per-read k-mer and segment counts as prefix sums, so that an align call plans its chunks with a
+  // binary search instead of walking every read while the GPU waits
+  c->h_kpre.assign(n + 1, 0);
+  c->h_spre.assign(n + 1, 0);
+  for (uint64_t i = 0; i < n; i++) {
+    const uint64_t len = c->h_roff[i + 1] - c->h_roff[i];
+    mx = std::max(mx, len);
+    const uint64_t k = len >= KSLAM_K ? len - KSLAM_K + 1 : 0;  // gap 1, KMer.h:378
+    c->h_kpre[i + 1] = c->h_kpre[i] + k;
+    c->h_spre[i + 1] = c->h_spre[i] + (k + SEG_KMERS - 1) / SEG_KMERS;
+  }
   if (mx > 511) throw StatusError{KSLAM_ERR_UNSUPPORTED, "reads longer than 511 bases are not supported yet"};
   if ((uint64_t)c->prm.match * mx > 8191) throw StatusError{KSLAM_ERR_UNSUPPORTED, "match * read length must stay below 8192 (14-bit score field of the SW kernel)"};
   c->max_read_len = (uint32_t)mx;
@@ -346,15 +357,12 @@ void align_resident(kslam_ctx *c, bool stop_after_join, uint64_t *n_raw_out) {
   uint32_t tb_err_total = 0;
   while (r0 < n) {
     // ---- chunk [r0, r1) ----
-    uint64_t r1 = r0, nk = 0, nsegs = 0;
-    while (r1 < n && (r1 - r0) < max_chunk_reads) {
-      uint64_t len = c->h_roff[r1 + 1] - c->h_roff[r1];
-      uint64_t k = len >= KSLAM_K ? len - KSLAM_K + 1 : 0;  // gap 1, KMer.h:378
-      if (r1 > r0 && nk + k > max_chunk_kmers) break;
-      nk += k;
-      nsegs += (k + SEG_KMERS - 1) / SEG_KMERS;
-      r1++;
-    }
+    // as many reads as fit max_chunk_reads and max_chunk_kmers, at least one
+    const uint64_t hi = std::min<uint64_t>(n, r0 + max_chunk_reads);
+    const uint64_t *kp = c->h_kpre.data();
+    uint64_t r1 = (uint64_t)(std::upper_bound(kp + r0 + 1, kp + hi + 1, kp[r0] + max_chunk_kmers) - kp) - 1;
+    r1 = std::max(r1, r0 + 1);
+    const uint64_t nk = kp[r1] - kp[r0], nsegs = c->h_spre[r1] - c->h_spre[r0];
     if (nk >= (1ull << 32)) throw StatusError{KSLAM_ERR_UNSUPPORTED, "a single read chunk exceeds 2^32 k-mers"};
     const uint64_t nr = r1 - r0;
     tm.n_chunks++;

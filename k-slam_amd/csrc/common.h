@@ -107,7 +107,7 @@ void extract_plan(const uint64_t *d_offsets, uint64_t n_seqs, uint32_t gap,
                   hipStream_t s);
 void extract_fill_segments(const uint32_t *d_nk, const uint64_t *d_rec_start,
                            const uint64_t *d_seg_start, uint64_t n_seqs, uint32_t gap,
-                           SegEntry *d_segs, hipStream_t s);
+                           SegEntry *d_segs, hipStream_t s, uint64_t n_segs = ~0ull);
 // AoS output (reference record layout); id_base is added to the sequence index
 void extract_kmers_launch(const uint8_t *d_bases, const uint64_t *d_offsets,
                           const SegEntry *d_segs, uint64_t n_segs, uint32_t gap,

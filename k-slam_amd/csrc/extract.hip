@@ -47,6 +47,23 @@ __global__ void k_fill_segments(const uint32_t *nk, const uint64_t *rec_start, c
   }
 }
 
+// short sequences (reads: one or two segments each): one thread per sequence
+__global__ void k_fill_segments_short(const uint32_t *nk, const uint64_t *rec_start, const uint64_t *seg_start,
+                                      uint64_t n, SegEntry *segs) {
+  const uint64_t seq = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (seq >= n) return;
+  const uint32_t k = nk[seq];
+  const uint32_t ns = (k + SEG_KMERS - 1) / SEG_KMERS;
+  const uint64_t s0 = seg_start[seq], r0 = rec_start[seq];
+  for (uint32_t j = 0; j < ns; j++) {
+    SegEntry e;
+    e.seq = (uint32_t)seq;
+    e.q0 = j * SEG_KMERS;
+    e.out = r0 + (uint64_t)j * SEG_KMERS;
+    segs[s0 + j] = e;
+  }
+}
+
 // 4 ASCII bytes (little endian dword) -> 8 bits, first base in bits 7:6
 __device__ inline uint32_t pack4(uint32_t x) {
   uint32_t r = 0;
@@ -139,9 +156,15 @@ void extract_plan(const uint64_t *d_offsets, uint64_t n_seqs, uint32_t gap, uint
 }
 
 void extract_fill_segments(const uint32_t *d_nk, const uint64_t *d_rec_start, const uint64_t *d_seg_start,
-                           uint64_t n_seqs, uint32_t gap, SegEntry *d_segs, hipStream_t s) {
+                           uint64_t n_seqs, uint32_t gap, SegEntry *d_segs, hipStream_t s, uint64_t n_segs) {
   (void)gap;
   if (n_seqs == 0) return;
+  if (n_segs <= 4 * n_seqs) {   // reads: a wave per sequence would write one entry with 63 idle lanes
+    hipLaunchKernelGGL(k_fill_segments_short, dim3((unsigned)((n_seqs + 255) / 256)), dim3(256), 0, s, d_nk,
+                       d_rec_start, d_seg_start, n_seqs, d_segs);
+    HIPCHK(hipGetLastError());
+    return;
+  }
   uint64_t threads = n_seqs * 64;
   unsigned blocks = (unsigned)((threads + 255) / 256);
   hipLaunchKernelGGL(k_fill_segments, dim3(blocks), dim3(256), 0, s, d_nk, d_rec_start, d_seg_start, n_seqs,

@@ -209,7 +209,7 @@ void run_extract(kslam_ctx *c, const uint8_t *d_bases, const uint64_t *d_off, ui
   extract_plan(d_off, n, gap, c->nk.as<uint32_t>(), c->nseg.as<uint32_t>(), c->rec_start.as<uint64_t>(),
                c->seg_start.as<uint64_t>(), c->totals.as<uint64_t>(), c->scan_tmp.p, s);
   extract_fill_segments(c->nk.as<uint32_t>(), c->rec_start.as<uint64_t>(), c->seg_start.as<uint64_t>(), n, gap,
-                        c->segs.as<SegEntry>(), s);
+                        c->segs.as<SegEntry>(), s, n_segs);
   extract_kmers_launch(d_bases, d_off, c->segs.as<SegEntry>(), n_segs, gap, is_gb, 0, d_out, s);
 }
 

@@ -389,7 +389,7 @@ __global__ __launch_bounds__(64) void k_banded_lds(CigJob J, SwInputs in, SwPara
 // covers completely (refLen <= 2 bw + 1), where the sentinel write of ssw.c:655 lands on a live cell.
 template <int LMAX, int GL, int DPL, int BS>
 __global__ __launch_bounds__(BS) void k_cigar_systolic(CigJob J, SwInputs in, SwParams p) {
-  constexpr int NG = BS / GL, ND = GL * DPL, WPT = (DPL + 5) / 6;   // six 5-bit cells per word
+  constexpr int NG = BS / GL, ND = GL * DPL;
   __shared__ __attribute__((aligned(16))) uint8_t s_w[NG][LMAX + STAGE_PAD];
   __shared__ __attribute__((aligned(16))) uint32_t s_tab[NG][LMAX + STAGE_PAD];
   const int32_t lane = threadIdx.x & 63;
@@ -452,7 +452,14 @@ __global__ __launch_bounds__(BS) void k_cigar_systolic(CigJob J, SwInputs in, Sw
   int32_t mx = 0;
   const int32_t nturns = have && J.variant != 2 ? ((readLen + refLen - 2 - k0) >> 1) + 1 : 0;   // (variant 2: staging only)
   uint32_t *D = reinterpret_cast<uint32_t *>(J.scratch) + ((uint64_t)blockIdx.x * NG + grp) * (J.wave_slab / 4);
-  uint32_t word[WPT];
+  // Direction words: six 5-bit cells per word, packed ALONG a diagonal -- word (m, lane, q) holds the
+  // cells of the lane's diagonal q on turns 6m .. 6m + 5 -- because that is how the traceback walks:
+  // a diagonal step stays in the same word five times out of six, so its chain of dependent loads
+  // is a fifth as long as with one word per turn.
+  uint32_t dw[DPL];
+#pragma unroll
+  for (int q = 0; q < DPL; q++) dw[q] = 0;
+  int32_t sh = 0, grp6 = 0;   // 5 x (turn mod 6), turn / 6: wave-uniform
   // score rows and window codes of a turn are fetched up front for all of the lane's cells, existing
   // or not (an address outside the candidate's rows reads a neighbour's or nothing; the value is
   // not used): inside the per-cell branches the loads would each be waited for in turn
@@ -477,13 +484,11 @@ __global__ __launch_bounds__(BS) void k_cigar_systolic(CigJob J, SwInputs in, Sw
       H[q] = hv;
       E[q] = ev;
       F[q] = fv;
-      word[q / 6] |= (de | (df << 1) | (dh << 2)) << (5 * (q % 6));
+      dw[q] |= (de | (df << 1) | (dh << 2)) << sh;
     }
   };
   for (int32_t n = 0;; n++) {
     if (__ballot(n < nturns) == 0ull) break;
-#pragma unroll
-    for (int w = 0; w < WPT; w++) word[w] = 0;
 #pragma unroll
     for (int h = 0; h < DPL / 2; h++) trow[h] = tp[DPL / 2 - 1 - h];
 #pragma unroll
@@ -514,13 +519,24 @@ __global__ __launch_bounds__(BS) void k_cigar_systolic(CigJob J, SwInputs in, Sw
 #pragma unroll
       for (int h = 0; h < DPL / 2; h++) cell(2 * h + 1, Hu[h], Eu[h], Hl[h], Fl[h]);
     }
-    if (n < nturns) {
+    sh += 5;
+    if (sh == 30) {   // six turns gathered: one DPL-word store per lane
+      if (6 * grp6 < nturns) {
 #pragma unroll
-      for (int w = 0; w < WPT; w++) D[((uint32_t)n * GL + (uint32_t)t) * WPT + w] = word[w];
+        for (int q = 0; q < DPL; q++) D[((uint32_t)grp6 * GL + (uint32_t)t) * DPL + q] = dw[q];
+      }
+#pragma unroll
+      for (int q = 0; q < DPL; q++) dw[q] = 0;
+      sh = 0;
+      grp6++;
     }
     tp += 1;
     wp += 1;
     nv += 1;
+  }
+  if (sh != 0 && 6 * grp6 < nturns) {
+#pragma unroll
+    for (int q = 0; q < DPL; q++) D[((uint32_t)grp6 * GL + (uint32_t)t) * DPL + q] = dw[q];
   }
 #pragma unroll
   for (int m = 1; m < GL; m <<= 1) mx = max(mx, __shfl_xor(mx, m, GL));
@@ -536,15 +552,21 @@ __global__ __launch_bounds__(BS) void k_cigar_systolic(CigJob J, SwInputs in, Sw
   struct Acc {
     const uint32_t *D;
     int32_t bw, k0;
-    __device__ uint32_t get_dir(int32_t i, int32_t col) const {
+    uint32_t have_idx, have_word;   // the word fetched last: a diagonal run reuses it
+    __device__ uint32_t get_dir(int32_t i, int32_t col) {
       const int32_t j = col + (i - bw > 0 ? i - bw : 0);
       const int32_t x = j - i + bw;
       const int32_t tt = x / DPL, q = x - tt * DPL;
-      const int32_t n = (i + j - k0 - (q & 1)) >> 1;
-      const uint32_t wv = D[((uint32_t)n * GL + (uint32_t)tt) * WPT + q / 6];
-      return (wv >> (5 * (q % 6))) & 31u;
+      const uint32_t n = (uint32_t)((i + j - k0 - (q & 1)) >> 1);
+      const uint32_t m = n / 6u, r = n - 6u * m;
+      const uint32_t idx = (m * GL + (uint32_t)tt) * DPL + (uint32_t)q;
+      if (idx != have_idx) {
+        have_idx = idx;
+        have_word = D[idx];
+      }
+      return (have_word >> (5u * r)) & 31u;
     }
-  } A{D, bw, k0};
+  } A{D, bw, k0, 0xFFFFFFFFu, 0u};
   uint32_t *tmp = J.tmp + (uint64_t)(J.big ? (J.list_base + li) : ci) * J.cap;
   bool ovf = false;
   const int32_t l = banded_traceback(A, refLen, readLen, bw, tmp, J.cap, &ovf);
@@ -684,8 +706,8 @@ void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, u
       const int lm = lmax <= 160 ? 0 : (lmax <= 256 ? 1 : 2);
       const uint32_t LM = lm == 0 ? 160 : (lm == 1 ? 256 : 512);
       const uint32_t GL = need > 64 ? 16 : 8, DPL = need <= 16 ? 2 : (need <= 32 ? 4 : 8);
-      const uint32_t WPT = (DPL + 5) / 6, NG = 128 / GL;
-      uint64_t slab = (uint64_t)(LM + 2) * GL * WPT * 4;   // direction words of one candidate
+      const uint32_t NG = 128 / GL;
+      uint64_t slab = (uint64_t)((LM + 2 + 5) / 6 + 1) * GL * DPL * 4;   // direction words of one candidate: one per lane, diagonal and six turns
       slab = (slab + 255) & ~255ull;
       const uint64_t SCRATCH_BUDGET = 3ull << 30;
       const uint64_t groups_per_launch = std::max<uint64_t>(NG, (SCRATCH_BUDGET / slab) / NG * NG);

@@ -183,8 +183,13 @@ __device__ inline void stage_codes_wave(const uint8_t *src, int32_t len, bool re
 template <int BW, class Seq>
 __device__ inline int32_t banded_attempt_reg(Seq &m, uint32_t *DW, uint32_t NL, uint32_t lane, int32_t refLen,
                                              int32_t readLen, int32_t bw, const SwParams &p, int32_t mx) {
-  constexpr int NX = 2 * BW + 1, WPR = (NX + 5) / 6;
+  constexpr int NX = 2 * BW + 1;
   int32_t H[NX + 1], E[NX + 1];
+  // direction words packed along a diagonal: word (i / 6, slot) holds rows 6 (i / 6) .. + 5 of the slot,
+  // so that the traceback's diagonal steps stay inside the word it already fetched
+  uint32_t dwx[NX];
+#pragma unroll
+  for (int x = 0; x < NX; x++) dwx[x] = 0;
   uint32_t R[NX];
 #pragma unroll
   for (int x = 0; x <= NX; x++) { H[x] = 0; E[x] = 0; }
@@ -198,9 +203,7 @@ __device__ inline int32_t banded_attempt_reg(Seq &m, uint32_t *DW, uint32_t NL, 
   for (int32_t i = 0; i < readLen; i++) {
     const uint32_t qc = m.q(i);
     int32_t hleft = 0, f = 0;
-    uint32_t word[WPR];
-#pragma unroll
-    for (int w = 0; w < WPR; w++) word[w] = 0;
+    const uint32_t i6 = (uint32_t)i / 6u, sh = 5u * ((uint32_t)i - 6u * i6);
 #pragma unroll
     for (int x = 0; x < NX; x++) {
       const int32_t j = i + x - bw;
@@ -223,10 +226,15 @@ __device__ inline int32_t banded_attempt_reg(Seq &m, uint32_t *DW, uint32_t NL, 
       hleft = H[x];
       f = valid ? fv : 0;
       mx = valid ? max(mx, hv) : mx;                                       // ssw.c:684
-      word[x / 6] |= valid ? (de | (df << 1) | (dh << 2)) << (5 * (x % 6)) : 0u;
+      dwx[x] |= valid ? (de | (df << 1) | (dh << 2)) << sh : 0u;
     }
+    if (sh == 25u || i == readLen - 1) {
 #pragma unroll
-    for (int w = 0; w < WPR; w++) DW[((uint32_t)i * WPR + w) * NL + lane] = word[w];
+      for (int x = 0; x < NX; x++) {
+        DW[(i6 * NX + x) * NL + lane] = dwx[x];
+        dwx[x] = 0;
+      }
+    }
 #pragma unroll
     for (int x = 0; x + 1 < NX; x++) R[x] = R[x + 1];
     const int32_t jn = i + 1 + (NX - 1) - bw;
@@ -321,7 +329,18 @@ __global__ __launch_bounds__(64) void k_banded_lds(CigJob J, SwInputs in, SwPara
         D[((size_t)i * width_d + (uint32_t)col) * NL + lane] = (uint8_t)v;
     }
     int32_t reg_bw = 0;                 // > 0: the words hold band slots (banded_attempt_reg), not columns
+    uint32_t nx = 0, have_idx = 0xFFFFFFFFu, have_word = 0;   // register variant: slots per row; the word fetched last
     __device__ uint32_t get_dir(int32_t i, int32_t col) {
+      if (reg_bw > 0) {                 // words (i / 6, slot): six rows of one band slot
+        if (i < reg_bw) col += reg_bw - i;   // slot = j - i + bw, col = j - max(0, i - bw)
+        const uint32_t i6 = (uint32_t)i / 6u, r = (uint32_t)i - 6u * i6;
+        const uint32_t idx = (i6 * nx + (uint32_t)col) * NL + lane;
+        if (idx != have_idx) {
+          have_idx = idx;
+          have_word = DW[idx];
+        }
+        return (have_word >> (5u * r)) & 31u;
+      }
       if (wpr) {
         if (reg_bw > 0 && i < reg_bw) col += reg_bw - i;   // slot = j - i + bw, col = j - max(0, i - bw)
         const uint32_t w = (uint32_t)col / 6u, sh = 5u * ((uint32_t)col - 6u * w);
@@ -342,6 +361,7 @@ __global__ __launch_bounds__(64) void k_banded_lds(CigJob J, SwInputs in, SwPara
     A.DW = reinterpret_cast<uint32_t *>(D);
     A.wpr = WPR;
     A.reg_bw = band_width;
+    A.nx = 2 * (REG_BW > 0 ? REG_BW : 1) + 1;
   } else {
     mx = banded_attempt(A, refLen, readLen, band_width, p, J.bmax[ci]);
   }

@@ -722,10 +722,14 @@ void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, u
     };
     auto launch_systolic = [&](uint64_t m, uint32_t slot_bw, uint32_t cls, const Route &R) -> bool {
       const uint32_t need = 2 * slot_bw + 1;
-      if (need > 128 || !((sys_mask >> std::min(cls, 7u)) & 1)) return false;
+      if (need > 256 || !((sys_mask >> std::min(cls, 7u)) & 1)) return false;
       const int lm = lmax <= 160 ? 0 : (lmax <= 256 ? 1 : 2);
       const uint32_t LM = lm == 0 ? 160 : (lm == 1 ? 256 : 512);
-      const uint32_t GL = need > 64 ? 16 : 8, DPL = need <= 16 ? 2 : (need <= 32 ? 4 : 8);
+      // lanes x diagonals per lane: 8 x 2 / 4 / 8 up to 64 slots, 16 x 8 / 16 up to 256 (a handful of
+      // candidates per batch ever need more than 64, but one wave of the one-lane kernel sweeping
+      // 129-cell rows alone takes milliseconds, with the whole chip waiting for it)
+      const uint32_t GL = need > 64 ? 16 : 8;
+      const uint32_t DPL = GL == 16 ? (need <= 128 ? 8 : 16) : (need <= 16 ? 2 : (need <= 32 ? 4 : 8));
       const uint32_t NG = 128 / GL;
       uint64_t slab = (uint64_t)((LM + 2 + 5) / 6 + 1) * GL * DPL * 4;   // direction words of one candidate: one per lane, diagonal and six turns
       slab = (slab + 255) & ~255ull;
@@ -753,7 +757,8 @@ void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, u
   hipLaunchKernelGGL((k_cigar_systolic<LMV, GLV, DPLV, 128>), dim3(nb), dim3(128), 0, s, J, in, p)
 #define KSLAM_SYS_LM(GLV, DPLV) \
   do { if (lm == 0) KSLAM_SYS(160, GLV, DPLV); else if (lm == 1) KSLAM_SYS(256, GLV, DPLV); else KSLAM_SYS(512, GLV, DPLV); } while (0)
-        if (GL == 16) KSLAM_SYS_LM(16, 8);
+        if (GL == 16 && DPL == 16) KSLAM_SYS_LM(16, 16);
+        else if (GL == 16) KSLAM_SYS_LM(16, 8);
         else if (DPL == 2) KSLAM_SYS_LM(8, 2);
         else if (DPL == 4) KSLAM_SYS_LM(8, 4);
         else KSLAM_SYS_LM(8, 8);

@@ -877,7 +877,7 @@ void sw_scores(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, uint32_
       if (nd == 16) KSLAM_BAND_LM(8, 2, 256);
       else if (nd == 32) KSLAM_BAND_LM(8, 4, 256);
       else if (nd == 48) KSLAM_BAND_LM(8, 6, 128);
-      else if (nd == 64) { if (lm == 0) KSLAM_BAND(160, 8, 8, 128); else KSLAM_BAND_LM(16, 4, 256); }
+      else if (nd == 64) KSLAM_BAND_LM(8, 8, 128);
       else KSLAM_BAND_LM(16, 8, 256);
 #undef KSLAM_BAND_LM
 #undef KSLAM_BAND

@@ -324,7 +324,8 @@ void align_resident(kslam_ctx *c, bool stop_after_join, uint64_t *n_raw_out) {
     throw StatusError{KSLAM_ERR_UNSUPPORTED, "entry count x entry length too large for the packed overlap key"};
   const uint32_t max_bits_read = 63 - lay.bits_entry - lay.bits_rel;
   const uint64_t max_chunk_reads = max_bits_read >= 31 ? (1ull << 31) : (1ull << max_bits_read);
-  const uint64_t max_chunk_kmers = c->prm.max_kmers_per_chunk ? c->prm.max_kmers_per_chunk : (1ull << 28);
+  // default: 2^30 read k-mers (4.2 M 150-bp pairs) per chunk = 32 GB of sort buffers, a ninth of the HBM
+  const uint64_t max_chunk_kmers = c->prm.max_kmers_per_chunk ? c->prm.max_kmers_per_chunk : (1ull << 30);
 
   GenomeIndexDev g;
   g.key = c->gk_key.as<uint64_t>(); g.meta = c->gk_meta.as<uint32_t>(); g.off = c->gk_off.as<uint32_t>();

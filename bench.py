@@ -361,6 +361,9 @@ def main():
                 "sort_phase": {"passes": passes, "bytes": int(sort_bytes), "ms": round(tm["ms_sort"], 3),
                                "frac": round(sort_bytes / (tm["ms_sort"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
                                if tm["ms_sort"] > 0 else 0.0},
+                # context, not the roofline: what the best hand-written streaming copy of the same bytes
+                # sustained on a bench box (tools/copy_peak.hip, profiles/r01h_copy_peak.txt)
+                "streaming_copy_ceiling": {"GB/s": 5590.0, "measured": "profiles/r01h_copy_peak.txt"},
             },
             "phases_ms": {k: round(tm[k], 3) for k in ("ms_extract", "ms_sort", "ms_join", "ms_sw",
                                                          "ms_cigar", "ms_total")},

@@ -150,8 +150,18 @@ __global__ __launch_bounds__(JB) void k_join_fill(const uint4 *__restrict__ recs
   __shared__ uint32_t bigq_n;
   __shared__ uint4 bigq[BIGQ];       // {rmeta, roff, run.lo, run.cnt}
   __shared__ uint32_t bigq_out[BIGQ];  // block-relative output offset
+  // flat emission: the block's runs {rmeta, roff, run.lo, first output slot} and, per output slot,
+  // the run it belongs to -- so that every thread then writes ONE overlap (parallel gathers of the
+  // genome records, consecutive stores) instead of walking its own runs with the wave idling
+  constexpr uint32_t FLAT_MAX = 4096;
+  __shared__ uint4 runq[JOIN_TILE];
+  __shared__ uint16_t owner[FLAT_MAX];
+  __shared__ uint32_t runq_n;
   const uint32_t base = blockIdx.x * JOIN_TILE;
-  if (threadIdx.x == 0) bigq_n = 0;
+  if (threadIdx.x == 0) {
+    bigq_n = 0;
+    runq_n = 0;
+  }
   uint4 r[JI];
   Run run[JI];
   uint32_t mine = 0;
@@ -178,15 +188,33 @@ __global__ __launch_bounds__(JB) void k_join_fill(const uint4 *__restrict__ recs
   uint32_t ex = inc - mine;
   for (int i = 0; i < w; i++) ex += wsum[i];
   uint64_t bb;
+  uint32_t tot = 0;
+  for (int i = 0; i < JB / 64; i++) tot += wsum[i];
   if (block_base) {
     bb = block_base[blockIdx.x];
   } else {
-    uint32_t tot = 0;
-    for (int i = 0; i < JB / 64; i++) tot += wsum[i];
     if (threadIdx.x == 0) s_base = tot ? atomicAdd(cursor, (unsigned long long)tot) : 0ull;
     __syncthreads();
     bb = s_base;
     if (bb + tot > cap) return;   // does not fit: only the cursor matters now (wave-uniform exit)
+  }
+  if (tot <= FLAT_MAX) {   // (block-uniform)
+#pragma unroll
+    for (int it = 0; it < JI; it++) {
+      const uint32_t c = run[it].cnt;
+      if (c == 0) continue;
+      const uint32_t slot = atomicAdd(&runq_n, 1u);
+      runq[slot] = make_uint4(r[it].z, r[it].w, run[it].lo, ex);
+      for (uint32_t j = 0; j < c; j++) owner[ex + j] = (uint16_t)slot;
+      ex += c;
+    }
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < tot; k += JB) {
+      const uint4 e = runq[owner[k]];
+      const uint32_t gi = e.z + (k - e.w);
+      out[bb + k] = make_overlap(e.x, e.y, g.meta[gi], g.off[gi], read_len, lay);
+    }
+    return;
   }
 #pragma unroll
   for (int it = 0; it < JI; it++) {

@@ -25,15 +25,18 @@
 // is only observable when a gap pair can beat a mismatch or when gapE >= gapO;
 // kslam_create rejects such scoring.
 //
-// MI355X design: integer ALU work, no MFMA.  A candidate is mapped onto one
-// DPP row (16 lanes) of a wavefront, four candidates per wave.  Lane t owns R
-// consecutive query rows; the 16 lanes sweep the DP matrix as a systolic
-// anti-diagonal: at step s lane t computes column s - t for its rows, entirely
-// in registers (H, E per row; 6-bit packed score table per row so the score is
-// one v_bfe_i32).  The only cross-lane traffic per step is two row_shr:1 DPP
-// moves: {H of the last row, F leaving the strip} and the running column
-// maximum packed as (H << 16 | 0xFFFF - row) so one v_max_u32 both maximises H
-// and minimises the row index.  Sequences sit in LDS as 1 byte/base codes.
+// MI355X design: integer ALU work, no MFMA; the kernels are bound by VALU issue cycles
+// (tools/valu_peak.hip), so the code is written against the instruction
+// count.  Candidates go through exact banded tiers (k_sw_band: 8 or 16 lanes per candidate,
+// 2..8 adjacent diagonals per lane, swept by anti-diagonals; a result is accepted only with a
+// certificate that the band held every optimal alignment), picked per candidate by k_sw_plan from
+// the seed diagonal; what no band can certify runs on the full-matrix kernel (k_sw: 16 lanes per
+// candidate, lane t owns R consecutive read rows and computes column s - t at step s).  Everything
+// is in registers (H, E, F per diagonal or row; a 6-bit packed score row per read base so a score
+// is one v_bfe_i32); neighbours are one DPP row shift away; sequences sit in LDS as 1 byte/base
+// codes staged from pre-encoded arrays.  The lane-local best cell is kept by ONE v_max_f64 per
+// cell over a (score | inverted position, H) pair, which is the reference's tie rule (highest
+// score, first column, smallest row) whatever order the cells are visited in.
 #include <type_traits>
 
 #include "common.h"

@@ -114,14 +114,6 @@ class Cursor {
     if (p_ < n_ && !is_ws(t_[p_])) throw ParseFail{p_, std::string(what) + ": no delimiter after its " + std::to_string(len) + " bytes"};
     return s;
   }
-  // a literal word (header)
-  void expect(const char *word) {
-    skip_ws();
-    const size_t k = strlen(word);
-    if (n_ - p_ < k || memcmp(t_ + p_, word, k) != 0 || (p_ + k < n_ && !is_ws(t_[p_ + k])))
-      throw ParseFail{p_, std::string("expected \"") + word + "\""};
-    p_ += k;
-  }
 
  private:
   static bool is_ws(char c) { return c == ' ' || c == '\n' || c == '\r' || c == '\t'; }

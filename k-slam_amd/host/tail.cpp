@@ -17,6 +17,9 @@
 //    radix-sorted copy, with the sums formed in integers (exact, hence equal to
 //    the reference's sequential double accumulation while they stay < 2^53).
 #include <algorithm>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 #include <atomic>
 #include <chrono>
 #include <climits>
@@ -123,15 +126,20 @@ struct Text {  // growable byte buffer (realloc: large blocks grow by mremap, no
   }
   void lit(const char *s) { put(s, strlen(s)); }
   void num(uint64_t v) {
+    char *d = need(20);
+    if (v < 10) {   // CIGAR and MD numbers are mostly one to three digits
+      d[0] = (char)('0' + v);
+      n += 1;
+      return;
+    }
     char t[24];
-    int k = 0;
+    int k = 24;
     do {
-      t[k++] = (char)('0' + v % 10);
+      t[--k] = (char)('0' + v % 10);
       v /= 10;
     } while (v);
-    char *d = need(k);
-    for (int i = 0; i < k; i++) d[i] = t[k - 1 - i];
-    n += k;
+    memcpy(d, t + k, 24 - k);
+    n += 24 - k;
   }
   void snum(int64_t v) {
     if (v < 0) {
@@ -860,6 +868,27 @@ struct MdWriter {
   }
 };
 
+#if defined(__SSE2__)
+// 16 query bases for columns i .. i + 15 of an M operation.  RC: the 16 read bytes ENDING at
+// base_at - i, reversed, with A<->T and C<->G swapped (upper case only, everything else unchanged:
+// the table of complement_lut()).
+template <bool RC>
+inline __m128i query16(const char *base_at, uint32_t i) {
+  if (!RC) return _mm_loadu_si128(reinterpret_cast<const __m128i *>(base_at + i));
+  __m128i v = _mm_loadu_si128(reinterpret_cast<const __m128i *>(base_at - (ptrdiff_t)i - 15));
+  // reverse the 16 bytes with SSE2 only: reverse the 16-bit units, then swap the bytes inside them
+  v = _mm_shuffle_epi32(v, _MM_SHUFFLE(0, 1, 2, 3));
+  v = _mm_shufflelo_epi16(v, _MM_SHUFFLE(2, 3, 0, 1));
+  v = _mm_shufflehi_epi16(v, _MM_SHUFFLE(2, 3, 0, 1));
+  v = _mm_or_si128(_mm_slli_epi16(v, 8), _mm_srli_epi16(v, 8));
+  // complement: x ^ ('A' ^ 'T') where x is A or T, x ^ ('C' ^ 'G') where x is C or G
+  const __m128i at = _mm_or_si128(_mm_cmpeq_epi8(v, _mm_set1_epi8('A')), _mm_cmpeq_epi8(v, _mm_set1_epi8('T')));
+  const __m128i cg = _mm_or_si128(_mm_cmpeq_epi8(v, _mm_set1_epi8('C')), _mm_cmpeq_epi8(v, _mm_set1_epi8('G')));
+  const __m128i flip = _mm_or_si128(_mm_and_si128(at, _mm_set1_epi8('A' ^ 'T')), _mm_and_si128(cg, _mm_set1_epi8('C' ^ 'G')));
+  return _mm_xor_si128(v, flip);
+}
+#endif
+
 // One M operation of `len` columns.  RC: the query is the reverse complement of
 // the read, walked backwards through bases/qual.  PROB: also accumulate the log
 // probability (a serial chain of double additions in column order -- its
@@ -873,7 +902,32 @@ inline void match_columns(const char *ref, const char *base_at, const char *qual
   // every column would pay a store-to-load round trip on the addition chain
   double logp = logp_io;
   uint32_t nm = nm_io, run = 0;
-  for (uint32_t i = 0; i < len; i++) {
+  uint32_t i = 0;
+#if defined(__SSE2__)
+  if (!PROB) {
+    // without the probability chain a column is a byte compare: 16 at a time, and only the
+    // mismatching columns (a handful per read) are visited one by one
+    for (; i + 16 <= len; i += 16) {
+      const __m128i r = _mm_loadu_si128(reinterpret_cast<const __m128i *>(ref + i));
+      uint32_t miss = 0xFFFFu ^ (uint32_t)_mm_movemask_epi8(_mm_cmpeq_epi8(r, query16<RC>(base_at, i)));
+      uint32_t from = 0;
+      while (miss) {
+        const uint32_t k = (uint32_t)__builtin_ctz(miss);
+        run += k - from;
+        nm++;
+        w.matches(run);
+        w.mismatch(ref[i + k]);
+        run = 0;
+        from = k + 1;
+        miss &= miss - 1;
+      }
+      run += 16 - from;
+    }
+    base_at += RC ? -(ptrdiff_t)i : (ptrdiff_t)i;
+    qual_at += RC ? -(ptrdiff_t)i : (ptrdiff_t)i;
+  }
+#endif
+  for (; i < len; i++) {
     const char qc = RC ? lut[(unsigned char)*base_at] : *base_at;
     int q = 0;
     if (PROB) {
@@ -1023,65 +1077,121 @@ void put_col(Text &out, const char *t, const uint64_t *off, uint64_t i) {
   out.put(t + off[i], off[i + 1] - off[i]);
 }
 
+// Appends to a Text whose capacity for the whole line was reserved up front: no capacity check
+// per field, literals with compile-time lengths, two digits per division.
+struct LineWriter {
+  char *w;
+  explicit LineWriter(char *at) : w(at) {}
+  void bytes(const char *s, size_t k) {
+    memcpy(w, s, k);
+    w += k;
+  }
+  void col(const char *t, const uint64_t *off, uint64_t i) { bytes(t + off[i], off[i + 1] - off[i]); }
+  void ch(char c) { *w++ = c; }
+  template <size_t N>
+  void lit(const char (&s)[N]) {
+    memcpy(w, s, N - 1);
+    w += N - 1;
+  }
+  void num(uint64_t v) {
+    static const char pairs[201] =
+        "00010203040506070809101112131415161718192021222324252627282930313233343536373839"
+        "40414243444546474849505152535455565758596061626364656667686970717273747576777879"
+        "8081828384858687888990919293949596979899";
+    char t[24];
+    int k = 24;
+    while (v >= 100) {
+      const uint64_t q = v / 100, r = v - q * 100;
+      k -= 2;
+      memcpy(t + k, pairs + 2 * r, 2);
+      v = q;
+    }
+    if (v >= 10) {
+      k -= 2;
+      memcpy(t + k, pairs + 2 * v, 2);
+    } else {
+      t[--k] = (char)('0' + v);
+    }
+    memcpy(w, t + k, 24 - k);
+    w += 24 - k;
+  }
+  void snum(int64_t v) {
+    if (v < 0) {
+      ch('-');
+      num((uint64_t)(-v));
+    } else
+      num((uint64_t)v);
+  }
+};
+
 // SAMEntry::getEntry, src/SAM.h:278-305
 void put_line(const SamInput &in, Text &out, const Text &scratch, const Row &r, uint32_t qname_read,
               int64_t gene, uint32_t xt, bool paired) {
   const kslam_index_view *ix = in.index;
-  put_col(out, in.reads->ids, in.reads->ids_off, qname_read);
-  out.put('\t');
-  out.num(r.flag);
-  out.put('\t');
-  put_col(out, ix->locus_tag, ix->locus_tag_off, r.rname_entry);
-  out.put('\t');
-  out.num(r.pos);
-  out.put('\t');
-  out.num(r.mapq);
-  out.put('\t');
+  const kslam_reads_view *rd = in.reads;
+  // everything variable in the line + room for the fixed text and 12 numbers of <= 20 digits
+  size_t bound = (rd->ids_off[qname_read + 1] - rd->ids_off[qname_read]) +
+                 (ix->locus_tag_off[r.rname_entry + 1] - ix->locus_tag_off[r.rname_entry]) + r.cigar_len + r.md_len + 384;
+  if (gene >= 0)
+    bound += (ix->gene_name_off[gene + 1] - ix->gene_name_off[gene]) + (ix->protein_id_off[gene + 1] - ix->protein_id_off[gene]) +
+             (ix->product_off[gene + 1] - ix->product_off[gene]);
+  LineWriter o(out.need(bound));
+  o.col(rd->ids, rd->ids_off, qname_read);
+  o.ch('\t');
+  o.num(r.flag);
+  o.ch('\t');
+  o.col(ix->locus_tag, ix->locus_tag_off, r.rname_entry);
+  o.ch('\t');
+  o.num(r.pos);
+  o.ch('\t');
+  o.num(r.mapq);
+  o.ch('\t');
   if (!in.p->report_cigar || r.cigar_star)
-    out.put('*');
+    o.ch('*');
   else
-    out.put(scratch.p + r.cigar_at, r.cigar_len);
-  out.put('\t');
-  out.put(paired ? '=' : '*');  // single end prints only the R1 row, whose rnext is "*" (src/SAM.h:416-420)
-  out.put('\t');
-  out.num(r.pnext);
-  out.put('\t');
-  out.snum(r.tlen);
-  out.lit("\t*\t*");
+    o.bytes(scratch.p + r.cigar_at, r.cigar_len);
+  o.ch('\t');
+  o.ch(paired ? '=' : '*');  // single end prints only the R1 row, whose rnext is "*" (src/SAM.h:416-420)
+  o.ch('\t');
+  o.num(r.pnext);
+  o.ch('\t');
+  o.snum(r.tlen);
+  o.lit("\t*\t*");
   if (r.mapped) {
     if (in.p->report_cigar) {
-      out.lit("\tMD:Z:");
-      out.put(scratch.p + r.md_at, r.md_len);
+      o.lit("\tMD:Z:");
+      o.bytes(scratch.p + r.md_at, r.md_len);
     }
-    out.lit("\tAS:i:");
-    out.num(r.as);
-    out.lit("\tXS:i:");
-    out.num(r.xs);
-    out.lit("\tNM:i:");
-    out.num(r.nm);
-    out.lit("\tX0:i:");
-    out.num(r.xo);
+    o.lit("\tAS:i:");
+    o.num(r.as);
+    o.lit("\tXS:i:");
+    o.num(r.xs);
+    o.lit("\tNM:i:");
+    o.num(r.nm);
+    o.lit("\tX0:i:");
+    o.num(r.xo);
     if (xt != 0) {
-      out.lit("\tXT:i:");
-      out.num(xt);
+      o.lit("\tXT:i:");
+      o.num(xt);
     }
     if (gene >= 0) {
       if (ix->gene_name_off[gene + 1] > ix->gene_name_off[gene]) {
-        out.lit("\tXG:Z:");
-        put_col(out, ix->gene_name, ix->gene_name_off, gene);
+        o.lit("\tXG:Z:");
+        o.col(ix->gene_name, ix->gene_name_off, gene);
       }
       if (ix->protein_id_off[gene + 1] > ix->protein_id_off[gene]) {
-        out.lit("\tXP:Z:");
-        put_col(out, ix->protein_id, ix->protein_id_off, gene);
+        o.lit("\tXP:Z:");
+        o.col(ix->protein_id, ix->protein_id_off, gene);
       }
       if (ix->product_off[gene + 1] > ix->product_off[gene]) {
-        out.lit("\tXR:Z:\"");
-        put_col(out, ix->product, ix->product_off, gene);
-        out.put('"');
+        o.lit("\tXR:Z:\"");
+        o.col(ix->product, ix->product_off, gene);
+        o.ch('"');
       }
     }
   }
-  out.put('\n');
+  o.ch('\n');
+  out.n = (size_t)(o.w - out.p);
 }
 
 // writeSAMOutputPairs (src/SAM.h:443-512) with getSAMFromPair (src/SAM.h:352-433)

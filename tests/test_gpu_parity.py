@@ -423,3 +423,20 @@ def test_low_complexity_parity(kslam, oracle, synth, read_len, scoring):
     exp, ecig, _ = oracle.align_to_database(reads, genomes, p)
     assert len(exp) > 2000 and (exp["cigar_len"] > 1).sum() > 300
     _compare_alignments(got, gcig, exp, ecig)
+
+
+def test_longest_supported_reads_and_the_limit(kslam, oracle, synth):
+    """511 bases is the longest read the library takes (9-bit row / column keys in the packed DP
+    values): such reads, mixed with short ones, must match the oracle; 512 must be refused, loudly."""
+    genomes = synth.make_genomes(301, 2, 2, 30000, strain_sub=0.02, strain_indel=0.002)
+    reads, _ = synth.make_paired_reads(302, genomes, 300, read_len=511, frag_mean=900, sub_rate=0.02,
+                                       indel_rate=0.003, n_rate=0.002, edge_frac=0.1)
+    short, _ = synth.make_paired_reads(303, genomes, 200, read_len=90, frag_mean=250, sub_rate=0.02, indel_rate=0.004)
+    rb, gb = synth.to_bytes(reads) + synth.to_bytes(short), synth.to_bytes(genomes)
+    assert max(len(r) for r in rb) == 511
+    got, gcig = kslam.align_to_database(rb, gb)
+    exp, ecig, _ = oracle.align_to_database(rb, gb)
+    assert len(exp) > 800 and (exp["cigar_len"] > 1).sum() > 100
+    _compare_alignments(got, gcig, exp, ecig)
+    with pytest.raises(kslam.KslamError, match="511"):
+        kslam.align_to_database([b"ACGT" * 128], gb)

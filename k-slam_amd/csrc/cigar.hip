@@ -702,8 +702,7 @@ void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, u
                          mode, W.flags.as<uint32_t>());
       exclusive_scan_u32(W.flags.as<uint32_t>(), W.pos.as<uint32_t>(), n, d_tot, W.scan_tmp.p, s);
       uint64_t m = 0;
-      HIPCHK(hipMemcpyAsync(&m, d_tot, sizeof m, hipMemcpyDeviceToHost, s));
-      HIPCHK(hipStreamSynchronize(s));
+      read_back(&m, d_tot, sizeof m, s);
       if (m) hipLaunchKernelGGL(k_scatter_list, dim3(nb), dim3(256), 0, s, W.flags.as<uint32_t>(),
                                 W.pos.as<uint32_t>(), n, W.list.as<uint32_t>());
       return m;
@@ -840,8 +839,7 @@ void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, u
     partition_bins(W.cls.as<uint8_t>(), n, lists, cnt, W.pos, s);
     uint32_t hc[10];
     for (uint32_t cls = 0; cls < 7; cls++) {
-      HIPCHK(hipMemcpyAsync(hc, cnt, sizeof hc, hipMemcpyDeviceToHost, s));
-      HIPCHK(hipStreamSynchronize(s));
+      read_back(hc, cnt, sizeof hc, s);
       const uint64_t m = hc[cls];
       if (m == 0) continue;
       if (debug) fprintf(stderr, "[kslam] cigar class %u (band <= %u): %llu candidates\n", cls, 1u << cls, (unsigned long long)m);
@@ -853,8 +851,7 @@ void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, u
       R.special_count = cnt + 8;
       R.big_count = cnt + 9;
       if (launch_systolic(m, 1u << cls, cls, R)) {
-        HIPCHK(hipMemcpyAsync(hc, cnt, sizeof hc, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
+        read_back(hc, cnt, sizeof hc, s);
         if (hc[8]) {   // the few it hands back (spans the band covers completely)
           if (debug) fprintf(stderr, "[kslam]   handed to the one-lane kernel: %u\n", hc[8]);
           Route R2 = R;
@@ -868,8 +865,7 @@ void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, u
       }
     }
     // wider than 64 (never seen on real reads): the flag / scan / scatter loop, class by class
-    HIPCHK(hipMemcpyAsync(hc, cnt, sizeof hc, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
+    read_back(hc, cnt, sizeof hc, s);
     if (hc[7]) {
       uint32_t last_cls = 7;
       for (uint32_t cls = 7; cls < 31; cls++) {
@@ -884,8 +880,7 @@ void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, u
         launch(m, 1u << cls, false, R);
         last_cls = cls + 1;
       }
-      HIPCHK(hipMemcpyAsync(hc, cnt, sizeof hc, hipMemcpyDeviceToHost, s));
-      HIPCHK(hipStreamSynchronize(s));
+      read_back(hc, cnt, sizeof hc, s);
     }
     // candidates whose cigar did not fit the small temp slot: rerun with full-size slots
     uint64_t n_big = hc[9] ? run_lists(0, 1) : 0;
@@ -896,8 +891,7 @@ void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, u
       hipLaunchKernelGGL(k_max_bw, dim3((unsigned)((n_big + 255) / 256)), dim3(256), 0, s, d_bw,
                          W.list.as<uint32_t>(), (uint32_t)n_big, reinterpret_cast<uint32_t *>(d_tot + 1));
       uint64_t mb = 0;
-      HIPCHK(hipMemcpyAsync(&mb, d_tot + 1, sizeof mb, hipMemcpyDeviceToHost, s));
-      HIPCHK(hipStreamSynchronize(s));
+      read_back(&mb, d_tot + 1, sizeof mb, s);
       launch(n_big, (uint32_t)mb, true, Route());
     }
   }
@@ -905,8 +899,7 @@ void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, u
   hipLaunchKernelGGL(k_cigar_lens, dim3(nb), dim3(256), 0, s, d_ov, n, W.flags.as<uint32_t>());
   exclusive_scan_u32_to_u64(W.flags.as<uint32_t>(), W.cig_off.as<uint64_t>(), n, d_tot, W.scan_tmp.p, s);
   uint64_t host_tot[3] = {0, 0, 0};
-  HIPCHK(hipMemcpyAsync(host_tot, d_tot, sizeof host_tot, hipMemcpyDeviceToHost, s));
-  HIPCHK(hipStreamSynchronize(s));
+  read_back(host_tot, d_tot, sizeof host_tot, s);
   *n_cigar_out = host_tot[0];
   *n_tb_err = (uint32_t)(host_tot[2] & 0xFFFFFFFFu);
 }

@@ -216,8 +216,7 @@ void run_extract(kslam_ctx *c, const uint8_t *d_bases, const uint64_t *d_off, ui
 void check_sort_error(kslam_ctx *c) {
   if (!c->sortws.errflag.p) return;   // the sort no longer waits on the device; kept for the ABI status
   uint32_t e = 0;
-  HIPCHK(hipMemcpyAsync(&e, c->sortws.errflag.p, sizeof e, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
+  read_back(&e, c->sortws.errflag.p, sizeof e, c->stream);
   if (e) {
     HIPCHK(hipMemsetAsync(c->sortws.errflag.p, 0, sizeof(uint32_t), c->stream));
     throw StatusError{KSLAM_ERR_INTERNAL, "radix sort look-back timed out"};
@@ -399,8 +398,7 @@ void align_resident(kslam_ctx *c, bool stop_after_join, uint64_t *n_raw_out) {
         c->ovk_a.ensure((cap + 1) * sizeof(uint64_t));
         join_fill_single_pass(sorted, (uint32_t)nk, g, c->r_len.as<uint32_t>() + r0, d_tot, cap, lay,
                               c->ovk_a.as<uint64_t>(), s);
-        HIPCHK(hipMemcpyAsync(&raw, d_tot, sizeof raw, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
+        read_back(&raw, d_tot, sizeof raw, s);
         if (raw <= cap) break;
         cap = raw + raw / 8;
       }
@@ -421,8 +419,7 @@ void align_resident(kslam_ctx *c, bool stop_after_join, uint64_t *n_raw_out) {
       c->scan_tmp.ensure(scan_tmp_bytes(raw));
       dedupe_flags(keys, raw, lay, c->flags.as<uint32_t>(), s);
       exclusive_scan_u32(c->flags.as<uint32_t>(), c->pos.as<uint32_t>(), raw, d_tot, c->scan_tmp.p, s);
-      HIPCHK(hipMemcpyAsync(&m, d_tot, sizeof m, hipMemcpyDeviceToHost, s));
-      HIPCHK(hipStreamSynchronize(s));
+      read_back(&m, d_tot, sizeof m, s);
       ensure_keep(c->res_ov, (c->n_res + m + 1) * sizeof(kslam_overlap), c->n_res * sizeof(kslam_overlap), s);
       dedupe_compact(keys, c->flags.as<uint32_t>(), c->pos.as<uint32_t>(), raw, lay, (uint32_t)r0,
                      c->res_ov.as<kslam_overlap>() + c->n_res, s);
@@ -464,8 +461,7 @@ void align_resident(kslam_ctx *c, bool stop_after_join, uint64_t *n_raw_out) {
   }
   tm.n_overlaps_raw = n_raw_total;
   tm.n_overlaps = c->n_res;
-  HIPCHK(hipMemcpyAsync(&tm.sw_cells, c->cells.p, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
-  HIPCHK(hipStreamSynchronize(s));
+  read_back(&tm.sw_cells, c->cells.p, sizeof(uint64_t), s);
   c->tm = tm;
   if (n_raw_out) *n_raw_out = n_raw_total;
   if (tb_err_total)
@@ -789,8 +785,7 @@ kslam_status kslam_selftest_sort(kslam_ctx *c, uint64_t n, uint32_t iters, float
     hipLaunchKernelGGL(k_count_inversions, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const uint4 *)sorted,
                        (uint32_t)n, c->cells.as<unsigned long long>());
     uint64_t inv = 0;
-    HIPCHK(hipMemcpyAsync(&inv, c->cells.p, sizeof inv, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
+    read_back(&inv, c->cells.p, sizeof inv, s);
     if (ms_per_sort) *ms_per_sort = tot / iters;
     if (ms_per_scatter_launch) *ms_per_scatter_launch = launches ? tot_sc / launches : 0.f;
     if (n_inversions) *n_inversions = inv;

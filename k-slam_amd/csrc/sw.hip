@@ -856,14 +856,12 @@ void sw_scores(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, uint32_
     hipLaunchKernelGGL(k_tier_scatter, dim3(n_blocks), dim3(256), 0, s, tier, n, W.pos.as<uint32_t>(), n_blocks, TL);
     uint32_t h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (debug) {
-      HIPCHK(hipMemcpyAsync(h, counts, sizeof h, hipMemcpyDeviceToHost, s));
-      HIPCHK(hipStreamSynchronize(s));
+      read_back(h, counts, sizeof h, s);
       fprintf(stderr, "[kslam] SW planned: %u / %u / %u / %u / %u\n", h[0], h[1], h[2], h[3], h[4]);
     }
     for (int k = 0; k < T.n; k++) {
       // the size of tier k: planned + sent on by the tiers before it (both in counts[k] by now)
-      HIPCHK(hipMemcpyAsync(h, counts, sizeof h, hipMemcpyDeviceToHost, s));
-      HIPCHK(hipStreamSynchronize(s));
+      read_back(h, counts, sizeof h, s);
       const uint64_t m = h[k];
       const int nd = T.nd[k];
       if (debug) fprintf(stderr, "[kslam] SW tier %d (%d diagonals): %llu candidates\n", k, nd, (unsigned long long)m);
@@ -885,8 +883,7 @@ void sw_scores(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, uint32_
 #undef KSLAM_BAND_LM
 #undef KSLAM_BAND
     }
-    HIPCHK(hipMemcpyAsync(h, counts, sizeof h, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
+    read_back(h, counts, sizeof h, s);
     n_full = h[NT_FULL];
     full_list = W.list.as<uint32_t>();
     if (debug) fprintf(stderr, "[kslam] SW full matrix: %llu candidates\n", (unsigned long long)n_full);

@@ -147,7 +147,7 @@ struct SortWorkspace {
 // pointer holding the sorted data.  ev0/ev1 bracket the scatter passes.
 void *radix_sort(void *a, void *b, uint64_t n, int rec_words, const SortPass *passes,
                  int n_passes, SortWorkspace &ws, hipStream_t s, hipEvent_t ev_scatter0,
-                 hipEvent_t ev_scatter1, uint32_t *n_launches);
+                 hipEvent_t ev_scatter1, uint32_t *n_launches, bool setup = false);   // setup: one-time sort (kernel names *_setup)
 
 // ---------------------------------------------------------------- join.hip
 struct GenomeIndexDev {

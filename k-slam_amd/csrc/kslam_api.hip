@@ -245,7 +245,7 @@ void build_index(kslam_ctx *c) {
   std::vector<SortPass> passes;
   full_key_passes(passes);
   void *sorted = radix_sort(c->recs_a.p, c->recs_b.p, m, 4, passes.data(), (int)passes.size(), c->sortws, s,
-                            nullptr, nullptr, nullptr);
+                            nullptr, nullptr, nullptr, /*setup=*/true);
   c->gk_key.ensure((m + 1) * sizeof(uint64_t));
   c->gk_meta.ensure((m + 1) * sizeof(uint32_t));
   c->gk_off.ensure((m + 1) * sizeof(uint32_t));

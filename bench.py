@@ -317,6 +317,17 @@ def main():
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
 
+    # RCCL announces itself on stdout through C stdio ("Librccl path : ..."), buffered when piped and
+    # otherwise flushed when each rank exits -- after rank 0's JSON.  Every rank pushes it out now,
+    # and rank 0 prints only once all have, so that the JSON line is the last line of the output.
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    if use_dist:
+        dist.barrier()
+
     if rank == 0:
         S = args.steps
         tm = {k: v / S for k, v in acc.items()}

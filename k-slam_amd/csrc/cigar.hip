@@ -196,20 +196,19 @@ __device__ inline int32_t banded_attempt_reg(Seq &m, uint32_t *DW, uint32_t NL, 
 #pragma unroll
   for (int x = 0; x < NX; x++) {
     const int32_t j = x - bw;
-    R[x] = (uint32_t)j < (uint32_t)refLen ? m.r(j) : 4u;
+    R[x] = (uint32_t)j < (uint32_t)refLen ? 6u * m.r(j) : 24u;   // window code x 6: the field of a packed score row
   }
   const int32_t live = 2 * bw;   // last live slot
   const int32_t gO = in_vgpr(p.gap_open), gE = in_vgpr(p.gap_extend);
   for (int32_t i = 0; i < readLen; i++) {
-    const uint32_t qc = m.q(i);
+    const uint32_t srow = score_row(m.q(i), p, 0);   // the read base against the five window codes, 6 bits each
     int32_t hleft = 0, f = 0;
     const uint32_t i6 = (uint32_t)i / 6u, sh = 5u * ((uint32_t)i - 6u * i6);
 #pragma unroll
     for (int x = 0; x < NX; x++) {
       const int32_t j = i + x - bw;
       const bool valid = x <= live && (uint32_t)j < (uint32_t)refLen;
-      const uint32_t rc = R[x];
-      const int32_t sc = (qc > 3u || rc > 3u) ? 0 : (qc == rc ? p.match : -p.mismatch);
+      const int32_t sc = __builtin_amdgcn_sbfe(srow, R[x], 6);
       int32_t t1 = H[x + 1] - gO, t2 = E[x + 1] - gE;                       // ssw.c:668-671
       const int32_t ev = max(t1, t2);
       const uint32_t de = t1 > t2 ? 1u : 0u;
@@ -238,7 +237,7 @@ __device__ inline int32_t banded_attempt_reg(Seq &m, uint32_t *DW, uint32_t NL, 
 #pragma unroll
     for (int x = 0; x + 1 < NX; x++) R[x] = R[x + 1];
     const int32_t jn = i + 1 + (NX - 1) - bw;
-    R[NX - 1] = (uint32_t)jn < (uint32_t)refLen ? m.r(jn) : 4u;
+    R[NX - 1] = (uint32_t)jn < (uint32_t)refLen ? 6u * m.r(jn) : 24u;
   }
   return mx;
 }

@@ -116,57 +116,31 @@ struct LdsLayout {
   uint32_t wpr;      // direction words per row kept in LDS (six 5-bit cells per word); 0: global slab
 };
 
-// Wave-cooperative staging of one span per lane: for each lane c of the wave in turn, all lanes
-// fetch c's span with coalesced aligned dword loads and store the SSW codes transposed into
-// dst as 4-bit codes, byte (k / 2) * NS + c, nibble k & 1 (NS = NL + 1 spreads the strided
-// accesses over the LDS banks; the buffer is zeroed first and filled with LDS atomic ORs).  When
-// `rev` the bases are complemented and written back to front (window of a revComp overlap).
-__device__ inline void stage_codes_wave(const uint8_t *src, int32_t len, bool rev, uint8_t *dst, uint32_t NS,
-                                        uint32_t nl_active) {
-  const uint32_t lane = threadIdx.x;
-  const uintptr_t a0 = reinterpret_cast<uintptr_t>(src);
-  const int32_t maxlen = [&] {   // longest span in the wave (wave-uniform loop bound)
-    int32_t m = len;
+// Lane-private staging for the one-candidate-per-lane kernels: the lane walks its own span of
+// PRE-ENCODED bases (encode_bases: bits 0-2 SSW code, bit 3 complementable) dword by dword and
+// writes its own column of dst -- two 4-bit codes per byte, byte (k / 2) * NS + lane -- with plain
+// byte stores.  `rev`: complemented and back to front (window of a revComp overlap).
+__device__ inline void stage_codes_lane(const uint8_t *codes, int32_t len, bool rev, uint8_t *dst, uint32_t NS,
+                                        uint32_t lane) {
+  if (len <= 0) return;
+  const uintptr_t a0 = reinterpret_cast<uintptr_t>(codes);
+  const int32_t shift = (int32_t)(a0 & 3u);
+  const uint32_t *w = reinterpret_cast<const uint32_t *>(a0 - (uintptr_t)shift);
+  const int32_t ndw = (shift + len + 3) >> 2;
+  uint32_t acc = 0;
+  for (int32_t d = 0; d < ndw; d++) {
+    const uint32_t v = codes_of_dword<1>(w[d], rev);
 #pragma unroll
-    for (int d = 32; d > 0; d >>= 1) m = max(m, __shfl_xor(m, d, 64));
-    return m;
-  }();
-  const int32_t nchunk = (maxlen + 3 + 255) / 256;   // 64 lanes x 4 bytes per chunk (+3 for misalignment)
-  for (int32_t ch = 0; ch < nchunk; ch++) {
-    for (uint32_t c0 = 0; c0 < nl_active; c0 += 8) {
-      uint32_t v[8];
-      int32_t clen[8], shift0[8];
-      uint32_t crev[8];
-#pragma unroll
-      for (uint32_t u = 0; u < 8; u++) {            // 8 candidates' loads in flight together
-        const uint32_t c = min(c0 + u, 63u);
-        const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)a0, c);
-        const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(a0 >> 32), c);
-        clen[u] = c0 + u < nl_active ? (int32_t)__builtin_amdgcn_readlane((uint32_t)len, c) : 0;
-        crev[u] = __builtin_amdgcn_readlane((uint32_t)rev, c);
-        const uintptr_t ca = ((uintptr_t)hi << 32) | lo;
-        const uintptr_t al = ca & ~(uintptr_t)3;
-        shift0[u] = (int32_t)(ca - al);
-        const int32_t nw = (shift0[u] + clen[u] + 3) >> 2;
-        const int32_t x = ch * 64 + (int32_t)lane;
-        v[u] = x < nw ? reinterpret_cast<const uint32_t *>(al)[x] : 0u;
-      }
-#pragma unroll
-      for (uint32_t u = 0; u < 8; u++) {
-        const uint32_t c = c0 + u;
-        const int32_t x = ch * 64 + (int32_t)lane;
-#pragma unroll
-        for (int32_t b = 0; b < 4; b++) {
-          const int32_t k = x * 4 + b - shift0[u];
-          if (k >= 0 && k < clen[u]) {
-            const uint32_t chh = (v[u] >> (8 * b)) & 0xFFu;
-            const uint32_t code = crev[u] ? ssw_code_complemented(chh) : ssw_code(chh);
-            const uint32_t kk = (uint32_t)(crev[u] ? clen[u] - 1 - k : k);
-            const uint32_t byte_addr = (kk >> 1) * NS + c;              // two 4-bit codes per byte
-            atomicOr(reinterpret_cast<uint32_t *>(dst) + (byte_addr >> 2),
-                     code << (8u * (byte_addr & 3u) + 4u * (kk & 1u)));
-          }
-        }
+    for (int32_t b = 0; b < 4; b++) {
+      const int32_t k = 4 * d + b - shift;
+      if (k < 0 || k >= len) continue;
+      const uint32_t kk = (uint32_t)(rev ? len - 1 - k : k);
+      acc |= ((v >> (8 * b)) & 15u) << (4u * (kk & 1u));
+      // a byte is complete with its second nibble in walking order (odd kk forwards, even kk
+      // backwards), or at the last base
+      if (((kk & 1u) == (rev ? 0u : 1u)) || k == len - 1) {
+        dst[(kk >> 1) * NS + lane] = (uint8_t)acc;
+        acc = 0;
       }
     }
   }
@@ -255,7 +229,6 @@ __global__ __launch_bounds__(64) void k_banded_lds(CigJob J, SwInputs in, SwPara
   const uint32_t NL = Y.nl, NS = NL + 1;
   const uint32_t li = blockIdx.x * NL + lane;
   const bool have = lane < NL && li < J.m;
-  const uint32_t n_here = min(NL, J.m - blockIdx.x * NL);
   const uint32_t half = (((Y.lmax + 1) / 2) * NS + 3) & ~3u;   // bytes per packed sequence buffer
   uint8_t *SQ = lds_raw;
   uint8_t *SR = SQ + half;
@@ -273,7 +246,7 @@ __global__ __launch_bounds__(64) void k_banded_lds(CigJob J, SwInputs in, SwPara
   memset(&o, 0, sizeof o);
   int32_t band_width = 1, refLen = 0, readLen = 0;
   bool skip = !have;
-  const uint8_t *qsrc = in.read_bases, *rsrc = in.genome_bases;
+  const uint8_t *qsrc = in.read_codes, *rsrc = in.genome_codes;
   if (have) {
     ci = J.list[J.list_base + li];
     o = J.ov[ci];
@@ -295,20 +268,19 @@ __global__ __launch_bounds__(64) void k_banded_lds(CigJob J, SwInputs in, SwPara
       const uint64_t G = in.genome_off[o.entry + 1] - go;
       const int64_t s0 = o.rel > 0 ? o.rel : 0;
       const int64_t wlen = (int64_t)min(L, G - (uint64_t)s0);
-      qsrc = in.read_bases + ro + o.query_begin;
+      qsrc = in.read_codes + ro + o.query_begin;
       // window position x of a flipped (revComp) window is genome position wlen - 1 - x
-      rsrc = in.genome_bases + go + s0 + (o.revcomp ? (wlen - 1 - o.ref_end) : (int64_t)o.ref_begin);
+      rsrc = in.genome_codes + go + s0 + (o.revcomp ? (wlen - 1 - o.ref_end) : (int64_t)o.ref_begin);
     }
   }
   if (J.variant == 4) return;   // ablation: candidate header loads only
-  if (J.variant == 5) { qsrc = in.read_bases + 64 * lane; rsrc = in.genome_bases + 64 * lane; }   // ablation: cache-resident sources
-  // stage the two spans as SSW codes (ssw_cpp.cpp:11-23), cooperatively and coalesced
-  stage_codes_wave(qsrc, skip ? 0 : readLen, false, SQ, NS, n_here);
-  stage_codes_wave(rsrc, skip ? 0 : refLen, !skip && o.revcomp != 0, SR, NS, n_here);
+  // stage the two spans as SSW codes (ssw_cpp.cpp:11-23), every lane its own
+  stage_codes_lane(qsrc, skip ? 0 : readLen, false, SQ, NS, lane);
+  stage_codes_lane(rsrc, skip ? 0 : refLen, !skip && o.revcomp != 0, SR, NS, lane);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  if (skip || J.variant == 2 || J.variant == 5) return;
+  if (skip || J.variant == 2) return;
   const int32_t score = o.score;
   struct Acc {
     int16_t *S; uint8_t *SQ, *SR, *D;   // row arrays as int16: |values| < 2^13 (14-bit score field)

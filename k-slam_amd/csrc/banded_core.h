@@ -86,16 +86,20 @@ __device__ inline int32_t banded_traceback(M &m, int32_t refLen, int32_t readLen
     uint32_t dir = 0;
     if (col >= 0 && j <= jend && j >= 0) {
       const uint32_t bb = m.get_dir(i, col);
-      dir = plane == 2 ? ((bb >> 2) & 7u) : (plane == 0 ? 2u + (bb & 1u) : 4u + ((bb >> 1) & 1u));
+      // plane 2 (H): bits 2..4 as they are; plane 0 (E): 2 + bit 0; plane 1 (F): 4 + bit 1 -- the base and
+      // the field mask of each plane sit in two small tables, so that lanes in different planes run
+      // the same instructions
+      dir = ((0x042u >> (4 * plane)) & 15u) + ((bb >> plane) & ((0x711u >> (4 * plane)) & 15u));
     }
-    switch (dir) {
-      case 1: --i; --j; plane = 2; op = 0; break;
-      case 2: --i; plane = 0; op = 1; break;
-      case 3: --i; plane = 2; op = 1; break;
-      case 4: --j; plane = 1; op = 2; break;
-      case 5: --j; plane = 2; op = 2; break;
-      default: return -1;
-    }
+    if (dir - 1u > 4u) return -1;   // the reference's "Trace back error" (ssw.c:747-750)
+    // what a direction does (ssw.c:704-745), one byte per direction 1..5:
+    // bit 0 --i, bit 1 --j, bits 2-3 the cigar op (M 0, I 1, D 2), bits 4-5 the next plane
+    //   1: --i --j, M, H    2: --i, I, E    3: --i, I, H    4: --j, D, F    5: --j, D, H
+    const uint32_t step = (uint32_t)(0x2A1A250523ull >> (8u * (dir - 1u)));
+    i -= (int32_t)(step & 1u);
+    j -= (int32_t)((step >> 1) & 1u);
+    op = (int32_t)((step >> 2) & 3u);
+    plane = (int32_t)((step >> 4) & 3u);
     if (op == cur) ++cnt;
     else {
       if ((uint32_t)l < cap) tmp[l] = (uint32_t)cnt << 4 | (uint32_t)cur; else *ovf = true;

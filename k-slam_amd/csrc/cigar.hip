@@ -182,24 +182,25 @@ __device__ inline int32_t banded_attempt_reg(Seq &m, uint32_t *DW, uint32_t NL, 
     for (int x = 0; x < NX; x++) {
       const int32_t j = i + x - bw;
       const bool valid = x <= live && (uint32_t)j < (uint32_t)refLen;
+      const int32_t vm = valid ? -1 : 0;   // one select, then masks: a cell that does not exist leaves zeros
       const int32_t sc = __builtin_amdgcn_sbfe(srow, R[x], 6);
       int32_t t1 = H[x + 1] - gO, t2 = E[x + 1] - gE;                       // ssw.c:668-671
       const int32_t ev = max(t1, t2);
-      const uint32_t de = t1 > t2 ? 1u : 0u;
+      const uint32_t de = (uint32_t)(t2 - t1) >> 31;                       // t1 > t2 (values are small: no overflow)
       t1 = hleft - gO;                                                     // ssw.c:673-676
       t2 = f - gE;
       const int32_t fv = max(t1, t2);
-      const uint32_t df = t1 > t2 ? 1u : 0u;
+      const uint32_t df = (uint32_t)(t2 - t1) >> 31;
       const int32_t e1 = max(ev, 0), f1 = max(fv, 0);                      // ssw.c:678-682
       const int32_t m1 = max(e1, f1), dg = H[x] + sc;
       const int32_t hv = max(m1, dg);
       const uint32_t dh = m1 <= dg ? 1u : (e1 > f1 ? 2u + de : 4u + df);   // ssw.c:686-690
-      H[x] = valid ? hv : 0;
-      E[x] = valid ? ev : 0;
+      H[x] = hv & vm;
+      E[x] = ev & vm;
       hleft = H[x];
-      f = valid ? fv : 0;
-      mx = valid ? max(mx, hv) : mx;                                       // ssw.c:684
-      dwx[x] |= valid ? (de | (df << 1) | (dh << 2)) << sh : 0u;
+      f = fv & vm;
+      mx = max(mx, H[x]);                                                  // ssw.c:684 (hv >= 0)
+      dwx[x] |= ((de | (df << 1) | (dh << 2)) & (uint32_t)vm) << sh;
     }
     if (sh == 25u || i == readLen - 1) {
 #pragma unroll

@@ -280,7 +280,9 @@ void finish_load_reads(kslam_ctx *c) {
     c->h_spre[i + 1] = c->h_spre[i] + (k + SEG_KMERS - 1) / SEG_KMERS;
   }
   if (mx > 511) throw StatusError{KSLAM_ERR_UNSUPPORTED, "reads longer than 511 bases are not supported yet"};
-  if ((uint64_t)c->prm.match * mx > 8191) throw StatusError{KSLAM_ERR_UNSUPPORTED, "match * read length must stay below 8192 (14-bit score field of the SW kernel)"};
+  // 13-bit score field of the packed DP values; and the (score | position, H) pairs of the running best go
+  // through v_max_f64, where a score of 8188 or more would read as a NaN bit pattern
+  if ((uint64_t)c->prm.match * mx > 8187) throw StatusError{KSLAM_ERR_UNSUPPORTED, "match * read length must stay below 8188 (score field of the SW kernels)"};
   c->max_read_len = (uint32_t)mx;
   c->r_off.ensure((n + 1) * sizeof(uint64_t));
   HIPCHK(hipMemcpyAsync(c->r_off.p, c->h_roff.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s));

@@ -804,7 +804,7 @@ void sw_scores(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, uint32_
   uint64_t n_full = n;
   const char *force_full = getenv("KSLAM_SW_FULL");
   // the band kernels carry gE x (i + j) on top of the score and 2 gE inside the 6-bit table fields
-  const bool band_ok = (int64_t)(p.match + 2 * p.gap_extend) * (int64_t)max_read_len <= 8191 &&
+  const bool band_ok = (int64_t)(p.match + 2 * p.gap_extend) * (int64_t)max_read_len <= 8187 &&
                        p.match + 2 * p.gap_extend <= 31;
   const bool debug = getenv("KSLAM_DEBUG") != nullptr;
   if (const char *ab = getenv("KSLAM_SW_ABLATE")) p.ablate = (uint32_t)atoi(ab);

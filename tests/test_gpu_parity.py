@@ -440,3 +440,22 @@ def test_longest_supported_reads_and_the_limit(kslam, oracle, synth):
     _compare_alignments(got, gcig, exp, ecig)
     with pytest.raises(kslam.KslamError, match="511"):
         kslam.align_to_database([b"ACGT" * 128], gb)
+
+
+@pytest.mark.parametrize("scoring", [(16, 10, 12, 4), (8, 6, 9, 2)])
+def test_scores_at_the_top_of_the_score_field(kslam, oracle, synth, scoring):
+    """Perfect 511-base reads under a large match score: 16 x 511 = 8176 is the largest score the packed
+    DP values (and the v_max_f64 pairs that keep the running best) can hold; with (16, ., ., 4) the band
+    kernels' offset range is exceeded and everything runs on the full-matrix kernel, with (8, ., ., 2)
+    the bands run near the top of theirs.  One more match point must be refused."""
+    genomes = synth.make_genomes(311, 2, 2, 20000, strain_sub=0.01, strain_indel=0.001)
+    reads, _ = synth.make_paired_reads(312, genomes, 150, read_len=511, frag_mean=900, sub_rate=0.0, indel_rate=0.0)
+    noisy, _ = synth.make_paired_reads(313, genomes, 150, read_len=511, frag_mean=900, sub_rate=0.02, indel_rate=0.003)
+    rb, gb = synth.to_bytes(reads) + synth.to_bytes(noisy), synth.to_bytes(genomes)
+    kw = dict(match=scoring[0], mismatch=scoring[1], gap_open=scoring[2], gap_extend=scoring[3])
+    got, gcig = kslam.align_to_database(rb, gb, **kw)
+    exp, ecig, _ = oracle.align_to_database(rb, gb, oracle.Params.default(**kw))
+    assert int(exp["score"].max()) == scoring[0] * 511
+    _compare_alignments(got, gcig, exp, ecig)
+    with pytest.raises(kslam.KslamError, match="8188"):
+        kslam.align_to_database(rb, gb, match=17, mismatch=10, gap_open=12, gap_extend=4)

@@ -135,3 +135,19 @@ def test_sharded_gather_world2_gloo(tmp_path):
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "GATHER_OK" in r.stdout
+
+
+@pytest.mark.parametrize("header", ["kslam.h", "kslam_tail.h", "kslam_fastq.h", "kslam_taxonomy.h", "kslam_db.h"])
+def test_headers_are_plain_c(header, tmp_path):
+    """The boundary is a C ABI: every header must compile on its own as C99 (pedantic) and as C++11."""
+    import shutil
+    import subprocess
+    src = tmp_path / "h.c"
+    src.write_text('#include "%s"\nint main(void) { return 0; }\n' % header)
+    inc = os.path.join(ROOT, "include")
+    for cc, std, lang in (("gcc", "-std=c99", "c"), ("g++", "-std=c++11", "c++")):
+        if not shutil.which(cc):
+            pytest.skip(cc + " not available")
+        r = subprocess.run([cc, std, "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", inc, "-x", lang, str(src)],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr

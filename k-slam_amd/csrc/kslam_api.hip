@@ -5,6 +5,8 @@
 // All device work runs on the context's own HIP stream; phases are bracketed
 // with HIP events.  No CPU fallback exists: without a HIP device every entry
 // point fails with KSLAM_ERR_NO_DEVICE.
+#include <sys/mman.h>
+
 #include "common.h"
 #include <algorithm>
 #include <new>
@@ -101,22 +103,53 @@ void ensure_keep(DevBuf &b, size_t bytes, size_t used, hipStream_t s) {
   b = nb;
 }
 
+// Page-locked host memory for the result / staging buffers: a private anonymous mapping advised for
+// transparent huge pages, then registered with the runtime.  (hipHostMalloc gives 4 KiB pages; the
+// host tail reads the overlap records in it at random, 3 M of them per batch, a TLB miss each.)
+static bool pinned_plain() { static const bool v = getenv("KSLAM_PINNED_PLAIN") != nullptr; return v; }
+void *pinned_alloc(size_t bytes) {
+  if (pinned_plain()) {
+    void *q = nullptr;
+    if (hipHostMalloc(&q, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return q;
+  }
+  const size_t HP = 2u << 20, len = (bytes + HP - 1) / HP * HP;
+  void *p = mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+  if (p == MAP_FAILED) return nullptr;
+#ifdef MADV_HUGEPAGE
+  (void)madvise(p, len, MADV_HUGEPAGE);
+#endif
+  if (hipHostRegister(p, len, hipHostRegisterDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    munmap(p, len);
+    return nullptr;
+  }
+  return p;
+}
+void pinned_free(void *p, size_t bytes) {
+  if (!p) return;
+  if (pinned_plain()) { (void)hipHostFree(p); return; }
+  const size_t HP = 2u << 20, len = (bytes + HP - 1) / HP * HP;
+  (void)hipHostUnregister(p);
+  munmap(p, len);
+}
+
 // pinned host buffers from a small per-context pool (pinning is expensive; reuse across batches)
 void *pinned_get(kslam_ctx *c, size_t bytes) {
   for (auto &b : c->pinned)
     if (!b.in_use && b.cap >= bytes) { b.in_use = true; return b.p; }
   for (auto &b : c->pinned)   // replace a free buffer that is too small
     if (!b.in_use) {
-      (void)hipHostFree(b.p);
+      pinned_free(b.p, b.cap);
       b.p = nullptr; b.cap = 0;
       size_t want = bytes + bytes / 4 + 4096;
-      if (hipHostMalloc(&b.p, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); b.p = nullptr; throw StatusError{KSLAM_ERR_OOM, "hipHostMalloc failed"}; }
+      if (!(b.p = pinned_alloc(want))) throw StatusError{KSLAM_ERR_OOM, "page-locked host allocation failed"};
       b.cap = want; b.in_use = true;
       return b.p;
     }
   kslam_ctx::Pinned nb{nullptr, 0, true};
   size_t want = bytes + bytes / 4 + 4096;
-  if (hipHostMalloc(&nb.p, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); throw StatusError{KSLAM_ERR_OOM, "hipHostMalloc failed"}; }
+  if (!(nb.p = pinned_alloc(want))) throw StatusError{KSLAM_ERR_OOM, "page-locked host allocation failed"};
   nb.cap = want;
   c->pinned.push_back(nb);
   return nb.p;
@@ -535,7 +568,7 @@ void kslam_destroy(kslam_ctx *c) {
                       &c->cig.scan_tmp, &c->cig.totals, &c->cig.cig_off, &c->cig.tmp, &c->cig.tmp_big,
                       &c->cig.big_pos, &c->cig.scratch, &c->sww.flags, &c->sww.pos, &c->sww.list, &c->sww.list2, &c->sww.scan_tmp, &c->sww.totals, &c->cells, &c->res_ov, &c->res_cig, &c->res_tmp};
     for (DevBuf *b : bufs) b->release();
-    for (auto &b : c->pinned) if (b.p) (void)hipHostFree(b.p);
+    for (auto &b : c->pinned) pinned_free(b.p, b.cap);
     for (auto &ev : c->ev) if (ev) (void)hipEventDestroy(ev);
     for (auto &ev : c->evs0) if (ev) (void)hipEventDestroy(ev);
     for (auto &ev : c->evs1) if (ev) (void)hipEventDestroy(ev);

@@ -34,6 +34,7 @@ struct CharBuf {
     free(p);
     p = (char *)malloc(m ? m : 1);
     if (!p) throw std::bad_alloc();
+    advise_huge(p, m);   // the tail reads ~150 bases at a random place of this column per alignment
     n = m;
   }
   char *data() { return p; }

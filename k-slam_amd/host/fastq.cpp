@@ -208,6 +208,7 @@ struct BlockCache {
     const size_t cap = bytes + bytes / 8 + 64;
     void *p = malloc(cap);
     if (!p) fail(KSLAM_ERR_OOM, "out of host memory for the read columns");
+    advise_huge(p, cap);   // the tail walks these columns per alignment
     // replace a parked block that was too small, so the cache does not grow without bound
     for (auto &b : blocks)
       if (!b.in_use) {

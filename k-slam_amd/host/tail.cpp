@@ -66,6 +66,7 @@ struct Buf {
       size_t want = std::max(n, cap + cap / 2);
       T *q = (T *)realloc((void *)p, want * sizeof(T));
       if (!q) fail(KSLAM_ERR_OOM, "out of host memory for the tail's work buffers");
+      advise_huge(q, want * sizeof(T));
       p = q;
       cap = want;
     }
@@ -104,6 +105,7 @@ struct Text {  // growable byte buffer (realloc: large blocks grow by mremap, no
     if (want <= cap) return;
     char *q = (char *)realloc(p, want);
     if (!q) fail(KSLAM_ERR_OOM, "out of host memory for SAM text");
+    advise_huge(q, want);
     p = q;
     cap = want;
   }

@@ -15,6 +15,9 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#if defined(__linux__)
+#include <sys/mman.h>
+#endif
 
 #include "../../include/kslam.h"
 
@@ -124,6 +127,23 @@ class Pool {
   bool failed_ = false;
   HostError error_;
 };
+
+// Asks for transparent huge pages under a large heap block (the boxes run THP in "madvise" mode).
+// The host stages walk multi-hundred-megabyte arrays at random -- overlap records, alignment pairs,
+// the genome columns -- and with 4 KiB pages nearly every such access also misses the TLB.  Must be
+// called before the block is first touched to take effect at once; harmless otherwise.
+inline void advise_huge(void *p, size_t bytes) {
+#if defined(__linux__) && defined(MADV_HUGEPAGE)
+  constexpr uintptr_t HP = 2u << 20;
+  if (!p || bytes < 2 * HP) return;
+  const uintptr_t a = (reinterpret_cast<uintptr_t>(p) + HP - 1) & ~(HP - 1);
+  const uintptr_t e = (reinterpret_cast<uintptr_t>(p) + bytes) & ~(HP - 1);
+  if (e > a) (void)madvise(reinterpret_cast<void *>(a), e - a, MADV_HUGEPAGE);
+#else
+  (void)p;
+  (void)bytes;
+#endif
+}
 
 // CPUs this process may actually use: the hardware threads, capped by a cgroup v2
 // CPU quota when there is one (more runnable threads than quota only get throttled)

@@ -9,6 +9,7 @@
 
 #include "common.h"
 #include <algorithm>
+#include <mutex>
 #include <new>
 #include <thread>
 
@@ -106,29 +107,44 @@ void ensure_keep(DevBuf &b, size_t bytes, size_t used, hipStream_t s) {
 // Page-locked host memory for the result / staging buffers: a private anonymous mapping advised for
 // transparent huge pages, then registered with the runtime.  (hipHostMalloc gives 4 KiB pages; the
 // host tail reads the overlap records in it at random, 3 M of them per batch, a TLB miss each.)
-static bool pinned_plain() { static const bool v = getenv("KSLAM_PINNED_PLAIN") != nullptr; return v; }
+// blocks that came from hipHostMalloc (KSLAM_PINNED_PLAIN, or registering a mapping failed)
+static std::vector<void *> &plain_blocks() { static std::vector<void *> v; return v; }
+static std::mutex &plain_mutex() { static std::mutex m; return m; }
+static void *pinned_plain_alloc(size_t bytes) {
+  void *q = nullptr;
+  if (hipHostMalloc(&q, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  std::lock_guard<std::mutex> lk(plain_mutex());
+  plain_blocks().push_back(q);
+  return q;
+}
 void *pinned_alloc(size_t bytes) {
-  if (pinned_plain()) {
-    void *q = nullptr;
-    if (hipHostMalloc(&q, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-    return q;
-  }
+  static const bool plain = getenv("KSLAM_PINNED_PLAIN") != nullptr;
+  if (plain) return pinned_plain_alloc(bytes);
   const size_t HP = 2u << 20, len = (bytes + HP - 1) / HP * HP;
   void *p = mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
-  if (p == MAP_FAILED) return nullptr;
+  if (p == MAP_FAILED) return pinned_plain_alloc(bytes);
 #ifdef MADV_HUGEPAGE
   (void)madvise(p, len, MADV_HUGEPAGE);
 #endif
   if (hipHostRegister(p, len, hipHostRegisterDefault) != hipSuccess) {
     (void)hipGetLastError();
     munmap(p, len);
-    return nullptr;
+    return pinned_plain_alloc(bytes);
   }
   return p;
 }
 void pinned_free(void *p, size_t bytes) {
   if (!p) return;
-  if (pinned_plain()) { (void)hipHostFree(p); return; }
+  {
+    std::lock_guard<std::mutex> lk(plain_mutex());
+    auto &v = plain_blocks();
+    auto it = std::find(v.begin(), v.end(), p);
+    if (it != v.end()) {
+      v.erase(it);
+      (void)hipHostFree(p);
+      return;
+    }
+  }
   const size_t HP = 2u << 20, len = (bytes + HP - 1) / HP * HP;
   (void)hipHostUnregister(p);
   munmap(p, len);

@@ -128,7 +128,7 @@ __device__ inline PassResult sw_origin_pass(const uint8_t *qcodes, int32_t qlen,
     }
     tab[r] = tb;
     H[r] = i + 1;                         // virtual cell (i, -1): score 0, successor (i + 1, 0)
-    E[r] = NEG;
+    E[r] = 512 | (i + 1);                 // no gap yet: the floor Z of (i, 0) rides on E (see the cell)
     rowkey[r] = i + 1;
   }
   int32_t prev_hl = t * R;                // virtual cell (tR - 1, -1): successor (tR, 0)
@@ -148,19 +148,20 @@ __device__ inline PassResult sw_origin_pass(const uint8_t *qcodes, int32_t qlen,
       int32_t diag = t == 0 ? (c << 9) : prev_hl;   // row -1: successor (0, c)
       prev_hl = in_h;
       int32_t F = t == 0 ? NEG : in_f;
-      const int32_t colkey = (c + 1) << 9;
+      const int32_t colkey2 = (c + 2) << 9;
 #pragma unroll
       for (int r = 0; r < R; r++) {
         const int32_t s = __builtin_amdgcn_sbfe(tab[r], shift, 6);
-        const int32_t Z = colkey | rowkey[r];
-        int32_t h = max(max(diag + (s << KB), E[r]), F);
-        h = max(h, Z);
+        // As in k_sw_band the zero floor rides on E: a cell hands max(E, Z of its right-hand neighbour)
+        // on, so H is one max3 (a floor carried further loses gE per column and is dominated).
+        const int32_t Zr = colkey2 | rowkey[r];           // Z of (i, c + 1) = Z of this cell + 512
+        const int32_t h = max(max(diag + (s << KB), E[r]), F);
         diag = H[r];
         H[r] = h;
         const int32_t hg = h - gO;
-        E[r] = max(E[r] - gE, hg);
+        E[r] = max(max(E[r] - gE, hg), Zr);
         F = max(F - gE, hg);
-        const v2i32 gh = {h, sub_vv(h | KEYMASK, Z)};   // highest score, then first column, then smallest row
+        const v2i32 gh = {h, sub_vv(h | KEYMASK, Zr)};   // highest score, then first column, then smallest row
         const double cand = __builtin_bit_cast(double, gh);
         asm("v_max_f64 %0, %1, %2" : "=v"(best) : "v"(best), "v"(cand));
       }
@@ -169,8 +170,11 @@ __device__ inline PassResult sw_origin_pass(const uint8_t *qcodes, int32_t qlen,
     }
   }
   const v2i32 bb = __builtin_bit_cast(v2i32, best);
-  const int32_t lbV = bb.x;                                            // score and origin key of the best cell
-  const int32_t lbZ = (bb.x >> KB) > 0 ? KEYMASK - (bb.y & KEYMASK) : 0;   // its position key
+  // G = score * 2^18 + KEYMASK - 512 - Z(cell): back to the score and the cell's position key
+  const int32_t gv = bb.y - (KEYMASK - 512);
+  const int32_t gsc = (bb.x | bb.y) == 0 ? 0 : (gv + KEYMASK) >> KB;
+  const int32_t lbV = gsc > 0 ? bb.x : 0;                       // score and origin key of the best cell
+  const int32_t lbZ = gsc > 0 ? (gsc << KB) - gv : 0;          // its position key
   return reduce_best(lbV, lbZ);
 }
 

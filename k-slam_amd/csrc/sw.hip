@@ -377,11 +377,11 @@ __global__ __launch_bounds__(256) void k_sw_plan(const kslam_overlap *__restrict
     const uint8_t *wa = wc + (i + d0 - 2);
     const uint32_t sh = (uint32_t)(reinterpret_cast<uintptr_t>(wa) & 3u);
     const uint32_t *wb = reinterpret_cast<const uint32_t *>(wa - sh);
-    const uint64_t lo = (uint64_t)wb[0] | ((uint64_t)wb[1] << 32), hi = (uint64_t)wb[1] | ((uint64_t)wb[2] << 32);
+    // the eight window bytes from wa on, byte-aligned (v_alignbyte_b32); diagonal k then starts at byte k
+    const uint32_t a0 = __builtin_amdgcn_alignbyte(wb[1], wb[0], sh), a1 = __builtin_amdgcn_alignbyte(wb[2], wb[1], sh);
 #pragma unroll
     for (int k = 0; k < 5; k++) {
-      const uint32_t o = sh + (uint32_t)k;   // byte offset of this diagonal's word in wb[0..2]
-      const uint32_t w = o < 4u ? (uint32_t)(lo >> (8u * o)) : (uint32_t)(hi >> (8u * (o - 4u)));
+      const uint32_t w = k == 0 ? a0 : (k == 4 ? a1 : __builtin_amdgcn_alignbyte(a1, a0, (uint32_t)k));
       const uint32_t x = q ^ w;
       const uint32_t ne = (x + LO7) & B7;            // bytes that differ
       const uint32_t inv = qn | ((w << 5) & B7);     // bytes that score 0

@@ -135,7 +135,8 @@ class Pool {
 inline void advise_huge(void *p, size_t bytes) {
 #if defined(__linux__) && defined(MADV_HUGEPAGE)
   constexpr uintptr_t HP = 2u << 20;
-  if (!p || bytes < 2 * HP) return;
+  static const bool off = getenv("KSLAM_NO_THP") != nullptr;
+  if (off || !p || bytes < 2 * HP) return;
   const uintptr_t a = (reinterpret_cast<uintptr_t>(p) + HP - 1) & ~(HP - 1);
   const uintptr_t e = (reinterpret_cast<uintptr_t>(p) + bytes) & ~(HP - 1);
   if (e > a) (void)madvise(reinterpret_cast<void *>(a), e - a, MADV_HUGEPAGE);

@@ -195,6 +195,10 @@ class Context:
         cat, off = _concat(reads)
         self._chk(self._L.kslam_load_reads(self._h, len(reads), cat.ctypes.data, off.ctypes.data))
 
+    def load_reads_arrays(self, cat_u8, offsets_u64):
+        """kslam_load_reads on columns that already exist (e.g. kslam_amd.fastq.Batch.bases_array())."""
+        self._chk(self._L.kslam_load_reads(self._h, len(offsets_u64) - 1, cat_u8.ctypes.data, offsets_u64.ctypes.data))
+
     def load_reads_device(self, n_reads, dev_ptr, host_offsets):
         off = np.ascontiguousarray(host_offsets, dtype=np.uint64)
         self._chk(self._L.kslam_load_reads_device(self._h, n_reads, dev_ptr, off.ctypes.data))

@@ -27,119 +27,15 @@ import __graft_entry__ as entry  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 READ_LEN = 150
-_ACGT = torch.tensor(list(b"ACGT"), dtype=torch.uint8)
+W = entry.load_package() and importlib.import_module("kslam_amd.workload")   # generator + ground truth
+make_database, make_reads = W.make_database, W.make_reads
 
 
-def _codes_of(x):
-    """ASCII uint8 tensor -> 0..3 for A,C,G,T (others 0)."""
-    c = torch.zeros_like(x)
-    c[x == ord("C")] = 1
-    c[x == ord("G")] = 2
-    c[x == ord("T")] = 3
-    return c
-
-
-def _revcomp_rows(x):
-    """reverse-complement each row of an ASCII uint8 [n, L] tensor."""
-    lut = torch.arange(256, dtype=torch.uint8, device=x.device)
-    for a, b in zip(b"ACGT", b"TGCA"):
-        lut[a] = b
-    return lut[x.flip(1).long()]
-
-
-def make_database(dev, gen, n_species, n_strains, length):
-    """Species x strains database as ONE device byte tensor + host offsets.
-    Strains derive from the species root by 1-3 % substitutions + sparse 1-10 bp indels."""
-    acgt = _ACGT.to(dev)
-    cap = int(n_species * n_strains * length * 1.01) + 1024
-    db = torch.empty(cap, dtype=torch.uint8, device=dev)
-    offs = [0]
-    for _ in range(n_species):
-        root_codes = torch.randint(0, 4, (length,), generator=gen, device=dev, dtype=torch.uint8)
-        for st in range(n_strains):
-            codes = root_codes
-            if st > 0:
-                rate = 0.01 + 0.02 * float(torch.rand(1, generator=gen, device=dev))
-                m = torch.rand(length, generator=gen, device=dev) < rate
-                shift = torch.randint(1, 4, (length,), generator=gen, device=dev, dtype=torch.uint8)
-                codes = torch.where(m, (root_codes + shift) % 4, root_codes)
-                # sparse indels: ~1 per 2 kb, 1-10 bp
-                ev = torch.rand(length, generator=gen, device=dev) < 0.0005
-                ln = torch.randint(1, 11, (length,), generator=gen, device=dev)
-                is_ins = torch.rand(length, generator=gen, device=dev) < 0.5
-                counts = torch.ones(length, dtype=torch.long, device=dev)
-                counts = torch.where(ev & is_ins, 1 + ln, counts)
-                # deletion of ln bases starting at the event
-                del_start = torch.nonzero(ev & ~is_ins).flatten()
-                if del_start.numel():
-                    dl = ln[del_start]
-                    idx = (del_start[:, None] + torch.arange(10, device=dev)[None, :])
-                    keep = torch.arange(10, device=dev)[None, :] < dl[:, None]
-                    idx = idx[keep]
-                    idx = idx[idx < length]
-                    counts[idx] = 0
-                src = torch.repeat_interleave(torch.arange(length, device=dev), counts)
-                out = codes[src]
-                dup = torch.zeros_like(src, dtype=torch.bool)
-                dup[1:] = src[1:] == src[:-1]
-                rnd = torch.randint(0, 4, (src.numel(),), generator=gen, device=dev, dtype=torch.uint8)
-                codes = torch.where(dup, rnd, out)
-            n = codes.numel()
-            db[offs[-1]:offs[-1] + n] = acgt[codes.long()]
-            offs.append(offs[-1] + n)
-    return db[:offs[-1]], np.array(offs, dtype=np.uint64)
-
-
-def make_reads(dev, gen, db, offs, n_pairs, read_len=READ_LEN, sub_rate=0.01, indel_rate=0.001,
-               unmapped=0.02):
-    """[2 * n_pairs, read_len] ASCII tensor in the reference batch layout (R1 block | R2 block)."""
-    acgt = _ACGT.to(dev)
-    goff = torch.from_numpy(offs.astype(np.int64)).to(dev)
-    glen = goff[1:] - goff[:-1]
-    ng = glen.numel()
-    g = torch.randint(0, ng, (n_pairs,), generator=gen, device=dev)
-    frag = (350 + 30 * torch.randn(n_pairs, generator=gen, device=dev)).round().long().clamp(read_len + 1, 1000)
-    span = (glen[g] - frag - 2).clamp(min=1)
-    start = (torch.rand(n_pairs, generator=gen, device=dev, dtype=torch.float64) * span).long()
-    W = read_len + 1
-    j = torch.arange(W, device=dev)[None, :]
-    a_idx = goff[g][:, None] + start[:, None] + j                       # forward window at s
-    b_idx = goff[g][:, None] + (start + frag - W)[:, None] + j          # window ending at s + f
-    A = db[a_idx]
-    B = _revcomp_rows(db[b_idx])
-    flip = torch.rand(n_pairs, generator=gen, device=dev) < 0.5
-    r1 = torch.where(flip[:, None], B, A)
-    r2 = torch.where(flip[:, None], A, B)
-    reads = torch.cat([r1, r2], 0)                                      # [2n, W]
-    n2 = 2 * n_pairs
-    # substitutions
-    m = torch.rand(n2, W, generator=gen, device=dev) < sub_rate
-    shift = torch.randint(1, 4, (n2, W), generator=gen, device=dev, dtype=torch.uint8)
-    reads = torch.where(m, acgt[((_codes_of(reads) + shift) % 4).long()], reads)
-    # at most one single-base indel per read
-    p_ind = 1.0 - (1.0 - indel_rate) ** read_len
-    has = torch.rand(n2, generator=gen, device=dev) < p_ind
-    pos = torch.randint(1, read_len - 1, (n2,), generator=gen, device=dev)
-    ins = torch.rand(n2, generator=gen, device=dev) < 0.5
-    jj = torch.arange(read_len, device=dev)[None, :].expand(n2, read_len)
-    d = torch.zeros(n2, read_len, dtype=torch.long, device=dev)
-    d = torch.where((has & ins)[:, None] & (jj > pos[:, None]), torch.full_like(d, -1), d)
-    d = torch.where((has & ~ins)[:, None] & (jj >= pos[:, None]), torch.full_like(d, 1), d)
-    out = torch.gather(reads, 1, jj + d)
-    rnd = acgt[torch.randint(0, 4, (n2,), generator=gen, device=dev)]
-    at = (has & ins)[:, None] & (jj == pos[:, None])
-    out = torch.where(at, rnd[:, None].expand(n2, read_len), out)
-    # pairs from a genome that is not in the database
-    um = torch.rand(n_pairs, generator=gen, device=dev) < unmapped
-    um2 = torch.cat([um, um])
-    junk = acgt[torch.randint(0, 4, (n2, read_len), generator=gen, device=dev)]
-    out = torch.where(um2[:, None], junk, out)
-    return out.contiguous()
-
-
-def cpu_baseline(db, offs, seed, n_genomes, n_pairs, read_len=READ_LEN):
+def cpu_baseline(K, db, offs, seed, n_genomes, n_pairs, read_len=READ_LEN, device=0):
     """The oracle's alignToDatabase timed on the host cores, on a bounded sample of the
-    same workload (reported baseline; the oracle is the checker, never the product)."""
+    same workload (reported baseline; the oracle is the checker, never the product).  The same
+    sample then goes through the HIP library and the two result sets are compared record by record:
+    the baseline leg doubles as a parity check inside the driver-run record."""
     import oracle as O
     n_genomes = min(n_genomes, len(offs) - 1)
     sub = db[:int(offs[n_genomes])].cpu()
@@ -159,16 +55,31 @@ def cpu_baseline(db, offs, seed, n_genomes, n_pairs, read_len=READ_LEN):
     al, cg, ph = O.align_to_database(rl, gl)
     dt = float(ph[5])          # seconds inside the C call (excludes the ctypes marshalling)
     O.use_reference_ssw(False)
-    return {
+    out = {
         "value": round(len(rl) / dt, 1), "unit": "reads/s", "cores": cores, "kind": "port",
-        "sample": "%d pairs x %d bp vs the first %d database genomes (%.0f Mb); whole reference batch "
+        "pairs": n_pairs, "read_len": read_len, "db_genomes": n_genomes, "db_bases": int(suboffs[-1]),
+        "seconds": round(dt, 2),
+        "phases_s": dict(zip(("extract", "genome_kmers", "sort", "join", "sw"), (round(float(x), 2) for x in ph[:5]))),
+        "sample": "%d pairs x %d bp vs the first %d database genomes (%.0f Mb) -- NOT the whole 5 Gb database, "
+                  "which the CPU path cannot finish inside the bounded 10-30 s; whole reference batch "
                   "path incl. genome k-mer re-extraction and the (reads+genomes) sort, OpenMP on the CPUs the "
-                  "job's cgroup quota allows; %s; "
-                  "%.1f s wall, phases extract/genome/sort/join/sw = %s s" % (
-                      n_pairs, read_len, n_genomes, float(suboffs[-1]) / 1e6, kind_ssw, dt,
-                      "/".join("%.2f" % x for x in ph[:5])),
+                  "job's cgroup quota allows; %s" % (n_pairs, read_len, n_genomes, float(suboffs[-1]) / 1e6, kind_ssw),
         "n_alignments": int(len(al)),
     }
+    try:   # the same sample through the HIP library: identical records and CIGARs?
+        c = K.Context(device=device)
+        c.set_index(gl)
+        c.load_reads_arrays(np.ascontiguousarray(reads).reshape(-1), np.arange(len(rl) + 1, dtype=np.uint64) * np.uint64(read_len))
+        n_out, n_cig = c.align_resident()
+        gov, gcg = c.fetch_results(n_out, n_cig)
+        c.close()
+        same = len(gov) == len(al) and all((gov[f] == al[f]).all() for f in (
+            "read", "entry", "rel", "revcomp", "score", "ref_begin", "ref_end", "query_begin", "query_end",
+            "cigar_len", "cigar_off")) and np.array_equal(gcg, cg)
+        out["gpu_equals_cpu_on_sample"] = {"identical": bool(same), "alignments": int(len(gov)), "cigar_ops": int(len(gcg))}
+    except Exception as e:   # never lose the bench line over the extra check
+        out["gpu_equals_cpu_on_sample"] = {"error": repr(e)}
+    return out
 
 
 def sam_pipeline(K, ctx, reads, db, offs, read_len, steps):
@@ -371,7 +282,7 @@ def main():
     t0 = time.time()
     db, offs = make_database(dev, gen, args.species, args.strains, args.genome_len)
     gen.manual_seed(2 + 1000 * rank)        # reads: a different shard of pairs per rank
-    reads = make_reads(dev, gen, db, offs, args.pairs, read_len=args.read_len)
+    reads, truth = make_reads(dev, gen, db, offs, args.pairs, read_len=args.read_len, with_truth=True)
     torch.cuda.synchronize()
     t_gen = time.time() - t0
 
@@ -424,6 +335,31 @@ def main():
         te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
+
+    # ---- outside the timed region: is what was just timed RIGHT?  (no oracle here: the generator's
+    # own ground truth, the reference's structural expectations of src/Tests.h:161-264, :321-330) ----
+    def device_results():
+        n_out, n_cig = ctx.align_resident()
+        ov = torch.empty(n_out * 48, dtype=torch.uint8, device=dev)
+        cg = torch.empty(max(n_cig, 1) * 4, dtype=torch.uint8, device=dev)
+        ctx.copy_results_device(ov.data_ptr(), cg.data_ptr())
+        return ov, cg[:n_cig * 4].view(torch.int32)
+    ov_a, cg_a = device_results()
+    verified = W.check_against_truth(ov_a, None if args.no_cigar else cg_a, truth, args.read_len)
+    ov_b, cg_b = device_results()
+    verified["run_to_run_identical"] = bool(ov_a.numel() == ov_b.numel() and torch.equal(ov_a, ov_b)
+                                            and torch.equal(cg_a, cg_b))
+    verified["ok"] = bool(verified["ok"] and verified["run_to_run_identical"])
+    del ov_a, cg_a, ov_b, cg_b
+    if use_dist:   # every rank checked its own shard: sum the counts, AND the verdicts
+        keys = [k for k, v in verified.items() if not isinstance(v, bool)]
+        t = torch.tensor([verified[k] for k in keys] + [int(verified["ok"]), int(verified["run_to_run_identical"])],
+                         dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        for k, v in zip(keys, t[:len(keys)].tolist()):
+            verified[k] = int(v)
+        verified["ok"] = bool(int(t[-2]) == world)
+        verified["run_to_run_identical"] = bool(int(t[-1]) == world)
 
     # RCCL announces itself on stdout through C stdio ("Librccl path : ..."), buffered when piped and
     # otherwise flushed when each rank exits -- after rank 0's JSON.  Every rank pushes it out now,
@@ -491,9 +427,10 @@ def main():
                        "cigar_ops": int(n_cig), "chunks": int(tm["n_chunks"])},
             "sw_gcups": round(tm["sw_cells"] / ((tm["ms_sw"]) * 1e-3) / 1e9, 1) if tm["ms_sw"] > 0 else 0.0,
             "setup_s": {"generate": round(t_gen, 2), "index_build": round(t_index, 2)},
+            "verified": verified,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(db, offs, 77, args.cpu_genomes, args.cpu_pairs, args.read_len)
+            out["cpu_baseline"] = cpu_baseline(K, db, offs, 77, args.cpu_genomes, args.cpu_pairs, args.read_len, local_rank)
         if world == 1 and not args.no_sam_pipeline and not args.no_cigar:
             try:
                 out["sam_pipeline"] = sam_pipeline(K, ctx, reads, db, offs, args.read_len, max(args.steps, 3))

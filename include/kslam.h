@@ -125,7 +125,11 @@ const char *kslam_last_error(const kslam_ctx *ctx);
 kslam_status kslam_set_index(kslam_ctx *ctx, uint64_t n_entries,
                              const char *const *bases, const uint64_t *lens);
 /* same, bases already in device memory: entry j occupies
- * d_bases[h_offsets[j] .. h_offsets[j+1]) */
+ * d_bases[h_offsets[j] .. h_offsets[j+1]).  The copy runs on the context's
+ * own stream, which knows nothing of the stream that produced d_bases: the
+ * caller must have synchronized with the producer (hipStreamSynchronize /
+ * hipDeviceSynchronize) before the call.  Same rule for
+ * kslam_load_reads_device. */
 kslam_status kslam_set_index_device(kslam_ctx *ctx, uint64_t n_entries,
                                     const void *d_bases,
                                     const uint64_t *h_offsets);
@@ -155,7 +159,11 @@ kslam_status kslam_fetch_results(kslam_ctx *ctx, kslam_overlap *out,
                                  uint32_t *cigar_pool);
 /* the last results in page-locked host buffers the library owns and reuses
  * (full PCIe rate, no allocation per batch); hand them back with
- * kslam_free_batch.  Several batches may be outstanding at once. */
+ * kslam_free_batch.  Several batches may be outstanding at once, and
+ * kslam_free_batch may be called from ANOTHER thread than the one that is
+ * inside kslam_take_results / kslam_align_batch (a host-tail worker handing
+ * batch k back while batch k+1 is taken): the buffer pool is locked.  Every
+ * other entry point of a context must be called from one thread at a time. */
 kslam_status kslam_take_results(kslam_ctx *ctx, kslam_overlap **out, uint64_t *n_out,
                                 uint32_t **cigar_pool, uint64_t *n_cigar);
 /* device-to-device copy of the last results (for a RCCL gather) */

@@ -50,8 +50,11 @@ struct kslam_ctx {
   DevBuf cells;
 
   // ---- pinned host staging (host-pointer entry point): reused across batches ----
+  // kslam_free_batch may run on another thread than the one taking results (a host-tail worker
+  // hands buffers back while the main thread takes the next batch's): the pool has its own lock
   struct Pinned { void *p; size_t cap; bool in_use; };
   std::vector<Pinned> pinned;
+  std::mutex pin_mu;
 
   // ---- results of the last align ----
   DevBuf res_ov, res_cig, res_tmp;
@@ -152,6 +155,7 @@ void pinned_free(void *p, size_t bytes) {
 
 // pinned host buffers from a small per-context pool (pinning is expensive; reuse across batches)
 void *pinned_get(kslam_ctx *c, size_t bytes) {
+  std::lock_guard<std::mutex> lk(c->pin_mu);
   for (auto &b : c->pinned)
     if (!b.in_use && b.cap >= bytes) { b.in_use = true; return b.p; }
   for (auto &b : c->pinned)   // replace a free buffer that is too small
@@ -171,6 +175,7 @@ void *pinned_get(kslam_ctx *c, size_t bytes) {
   return nb.p;
 }
 bool pinned_put(kslam_ctx *c, void *p) {
+  std::lock_guard<std::mutex> lk(c->pin_mu);
   for (auto &b : c->pinned)
     if (b.p == p) { b.in_use = false; return true; }
   return false;
@@ -317,22 +322,26 @@ void finish_load_reads(kslam_ctx *c) {
   hipStream_t s = c->stream;
   const uint64_t n = c->n_reads;
   if (n >= (1ull << 30)) throw StatusError{KSLAM_ERR_UNSUPPORTED, "more than 2^30 reads (KMer.h:65 id field)"};
-  uint64_t mx = 0;
+  uint64_t mx = 0, mx_at = 0;
   // per-read k-mer and segment counts as prefix sums, so that an align call plans its chunks with a
   // binary search instead of walking every read while the GPU waits
   c->h_kpre.assign(n + 1, 0);
   c->h_spre.assign(n + 1, 0);
   for (uint64_t i = 0; i < n; i++) {
     const uint64_t len = c->h_roff[i + 1] - c->h_roff[i];
-    mx = std::max(mx, len);
+    if (len > mx) { mx = len; mx_at = i; }
     const uint64_t k = len >= KSLAM_K ? len - KSLAM_K + 1 : 0;  // gap 1, KMer.h:378
     c->h_kpre[i + 1] = c->h_kpre[i] + k;
     c->h_spre[i + 1] = c->h_spre[i] + (k + SEG_KMERS - 1) / SEG_KMERS;
   }
-  if (mx > 511) throw StatusError{KSLAM_ERR_UNSUPPORTED, "reads longer than 511 bases are not supported yet"};
+  if (mx > 511)
+    throw StatusError{KSLAM_ERR_UNSUPPORTED, "reads longer than 511 bases are not supported yet (read " +
+                                                 std::to_string(mx_at) + " of the batch has " + std::to_string(mx) + ")"};
   // 13-bit score field of the packed DP values; and the (score | position, H) pairs of the running best go
   // through v_max_f64, where a score of 8188 or more would read as a NaN bit pattern
-  if ((uint64_t)c->prm.match * mx > 8187) throw StatusError{KSLAM_ERR_UNSUPPORTED, "match * read length must stay below 8188 (score field of the SW kernels)"};
+  if ((uint64_t)c->prm.match * mx > 8187)
+    throw StatusError{KSLAM_ERR_UNSUPPORTED, "match * read length must stay below 8188 (score field of the SW kernels); read " +
+                                                 std::to_string(mx_at) + " has " + std::to_string(mx) + " bases"};
   c->max_read_len = (uint32_t)mx;
   c->r_off.ensure((n + 1) * sizeof(uint64_t));
   HIPCHK(hipMemcpyAsync(c->r_off.p, c->h_roff.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s));
@@ -584,7 +593,11 @@ void kslam_destroy(kslam_ctx *c) {
                       &c->cig.scan_tmp, &c->cig.totals, &c->cig.cig_off, &c->cig.tmp, &c->cig.tmp_big,
                       &c->cig.big_pos, &c->cig.scratch, &c->sww.flags, &c->sww.pos, &c->sww.list, &c->sww.list2, &c->sww.scan_tmp, &c->sww.totals, &c->cells, &c->res_ov, &c->res_cig, &c->res_tmp};
     for (DevBuf *b : bufs) b->release();
-    for (auto &b : c->pinned) pinned_free(b.p, b.cap);
+    {
+      std::lock_guard<std::mutex> lk(c->pin_mu);
+      for (auto &b : c->pinned) pinned_free(b.p, b.cap);
+      c->pinned.clear();
+    }
     for (auto &ev : c->ev) if (ev) (void)hipEventDestroy(ev);
     for (auto &ev : c->evs0) if (ev) (void)hipEventDestroy(ev);
     for (auto &ev : c->evs1) if (ev) (void)hipEventDestroy(ev);

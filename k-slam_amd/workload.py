@@ -1,0 +1,234 @@
+"""The BASELINE workload, generated straight into HBM with torch, together with its ground truth.
+
+bench.py and tests/test_gpu_scale.py both build their inputs here, so what the bench times is what
+the scale test checks.  SURVEY.md section 8d: genomes are uniform i.i.d. ACGT organised as species x
+strains (strains = the species root with 1-3 % substitutions and sparse 1-10 bp indels), reads are
+paired fragments (length ~ N(350, 30)), 1 % substitutions, at most one single-base indel per read,
+2 % of the pairs from a genome that is not in the database.  Batch layout as in the reference:
+R1 block then R2 block, mate of i is i + n (src/FASTQsequence.h:111-123).
+
+The truth kept per pair is what the reference's own tests plant and expect to recover
+(src/Tests.h:161-264: entry, offset, revComp of every read; :321-330: score = 2 x overlap length).
+torch is plumbing here (device memory and a random generator), nothing of this is on the product path.
+"""
+import numpy as np
+import torch
+
+READ_LEN = 150
+_ACGT = torch.tensor(list(b"ACGT"), dtype=torch.uint8)
+
+
+def _codes_of(x):
+    """ASCII uint8 tensor -> 0..3 for A,C,G,T (others 0)."""
+    c = torch.zeros_like(x)
+    c[x == ord("C")] = 1
+    c[x == ord("G")] = 2
+    c[x == ord("T")] = 3
+    return c
+
+
+def _revcomp_rows(x):
+    """reverse-complement each row of an ASCII uint8 [n, L] tensor."""
+    lut = torch.arange(256, dtype=torch.uint8, device=x.device)
+    for a, b in zip(b"ACGT", b"TGCA"):
+        lut[a] = b
+    return lut[x.flip(1).long()]
+
+
+def make_database(dev, gen, n_species, n_strains, length):
+    """Species x strains database as ONE device byte tensor + host offsets.
+    Strains derive from the species root by 1-3 % substitutions + sparse 1-10 bp indels."""
+    acgt = _ACGT.to(dev)
+    cap = int(n_species * n_strains * length * 1.01) + 1024
+    db = torch.empty(cap, dtype=torch.uint8, device=dev)
+    offs = [0]
+    for _ in range(n_species):
+        root_codes = torch.randint(0, 4, (length,), generator=gen, device=dev, dtype=torch.uint8)
+        for st in range(n_strains):
+            codes = root_codes
+            if st > 0:
+                rate = 0.01 + 0.02 * float(torch.rand(1, generator=gen, device=dev))
+                m = torch.rand(length, generator=gen, device=dev) < rate
+                shift = torch.randint(1, 4, (length,), generator=gen, device=dev, dtype=torch.uint8)
+                codes = torch.where(m, (root_codes + shift) % 4, root_codes)
+                # sparse indels: ~1 per 2 kb, 1-10 bp
+                ev = torch.rand(length, generator=gen, device=dev) < 0.0005
+                ln = torch.randint(1, 11, (length,), generator=gen, device=dev)
+                is_ins = torch.rand(length, generator=gen, device=dev) < 0.5
+                counts = torch.ones(length, dtype=torch.long, device=dev)
+                counts = torch.where(ev & is_ins, 1 + ln, counts)
+                # deletion of ln bases starting at the event
+                del_start = torch.nonzero(ev & ~is_ins).flatten()
+                if del_start.numel():
+                    dl = ln[del_start]
+                    idx = (del_start[:, None] + torch.arange(10, device=dev)[None, :])
+                    keep = torch.arange(10, device=dev)[None, :] < dl[:, None]
+                    idx = idx[keep]
+                    idx = idx[idx < length]
+                    counts[idx] = 0
+                src = torch.repeat_interleave(torch.arange(length, device=dev), counts)
+                out = codes[src]
+                dup = torch.zeros_like(src, dtype=torch.bool)
+                dup[1:] = src[1:] == src[:-1]
+                rnd = torch.randint(0, 4, (src.numel(),), generator=gen, device=dev, dtype=torch.uint8)
+                codes = torch.where(dup, rnd, out)
+            n = codes.numel()
+            db[offs[-1]:offs[-1] + n] = acgt[codes.long()]
+            offs.append(offs[-1] + n)
+    return db[:offs[-1]], np.array(offs, dtype=np.uint64)
+
+
+def make_reads(dev, gen, db, offs, n_pairs, read_len=READ_LEN, sub_rate=0.01, indel_rate=0.001,
+               unmapped=0.02, with_truth=False):
+    """[2 * n_pairs, read_len] ASCII tensor in the reference batch layout (R1 block | R2 block).
+    with_truth: also a dict of device tensors, one row per READ (2 * n_pairs):
+      entry      source database entry, -1 for reads of the pairs that are not from the database
+      rel        the reference's relativePosition of the read on that entry (start of the read, or
+                 of its reverse complement, in entry coordinates)
+      revcomp    0 / 1: the read is the reverse complement of the entry
+      n_subs     substitutions applied to the read's bases
+      has_indel  the read carries the one single-base indel
+      seed_ok    an error-free 32-mer of the read sits on a 16-aligned entry offset (the genome
+                 sampling of src/SLAM.h:64), so the reference's join must report (entry, rel, revcomp)
+    The random draws are the same with and without truth."""
+    acgt = _ACGT.to(dev)
+    goff = torch.from_numpy(offs.astype(np.int64)).to(dev)
+    glen = goff[1:] - goff[:-1]
+    ng = glen.numel()
+    g = torch.randint(0, ng, (n_pairs,), generator=gen, device=dev)
+    frag = (350 + 30 * torch.randn(n_pairs, generator=gen, device=dev)).round().long().clamp(read_len + 1, 1000)
+    span = (glen[g] - frag - 2).clamp(min=1)
+    start = (torch.rand(n_pairs, generator=gen, device=dev, dtype=torch.float64) * span).long()
+    W = read_len + 1
+    j = torch.arange(W, device=dev)[None, :]
+    a_idx = goff[g][:, None] + start[:, None] + j                       # forward window at s
+    b_idx = goff[g][:, None] + (start + frag - W)[:, None] + j          # window ending at s + f
+    A = db[a_idx]
+    B = _revcomp_rows(db[b_idx])
+    flip = torch.rand(n_pairs, generator=gen, device=dev) < 0.5
+    r1 = torch.where(flip[:, None], B, A)
+    r2 = torch.where(flip[:, None], A, B)
+    reads = torch.cat([r1, r2], 0)                                      # [2n, W]
+    n2 = 2 * n_pairs
+    # substitutions
+    m = torch.rand(n2, W, generator=gen, device=dev) < sub_rate
+    shift = torch.randint(1, 4, (n2, W), generator=gen, device=dev, dtype=torch.uint8)
+    reads = torch.where(m, acgt[((_codes_of(reads) + shift) % 4).long()], reads)
+    # at most one single-base indel per read
+    p_ind = 1.0 - (1.0 - indel_rate) ** read_len
+    has = torch.rand(n2, generator=gen, device=dev) < p_ind
+    pos = torch.randint(1, read_len - 1, (n2,), generator=gen, device=dev)
+    ins = torch.rand(n2, generator=gen, device=dev) < 0.5
+    jj = torch.arange(read_len, device=dev)[None, :].expand(n2, read_len)
+    d = torch.zeros(n2, read_len, dtype=torch.long, device=dev)
+    d = torch.where((has & ins)[:, None] & (jj > pos[:, None]), torch.full_like(d, -1), d)
+    d = torch.where((has & ~ins)[:, None] & (jj >= pos[:, None]), torch.full_like(d, 1), d)
+    out = torch.gather(reads, 1, jj + d)
+    rnd = acgt[torch.randint(0, 4, (n2,), generator=gen, device=dev)]
+    at = (has & ins)[:, None] & (jj == pos[:, None])
+    out = torch.where(at, rnd[:, None].expand(n2, read_len), out)
+    # pairs from a genome that is not in the database
+    um = torch.rand(n_pairs, generator=gen, device=dev) < unmapped
+    um2 = torch.cat([um, um])
+    junk = acgt[torch.randint(0, 4, (n2, read_len), generator=gen, device=dev)]
+    out = torch.where(um2[:, None], junk, out)
+    out = out.contiguous()
+    if not with_truth:
+        return out
+    # ---- truth, per read ----
+    L = read_len
+    is_b = torch.cat([flip, ~flip])                    # the read is the B (reverse-complement) mate
+    g2, start2, frag2 = torch.cat([g, g]), torch.cat([start, start]), torch.cat([frag, frag])
+    rel = torch.where(is_b, start2 + frag2 - L, start2)
+    sub = m[:, :L]
+    n_subs = sub.sum(1)
+    # substitutions in entry order: column j of an A read is entry position rel + j, of a B read
+    # rel + L - 1 - j
+    err = torch.where(is_b[:, None], sub.flip(1), sub).to(torch.int32)
+    cs = torch.zeros(n2, L + 1, dtype=torch.int32, device=dev)
+    cs[:, 1:] = torch.cumsum(err, 1)
+    first = (rel + 15) // 16 * 16 - rel                # read-relative position of the first sampled entry offset
+    seed_ok = torch.zeros(n2, dtype=torch.bool, device=dev)
+    for t in range((L + 15) // 16):
+        o = first + 16 * t
+        valid = o + 32 <= L
+        oc = o.clamp(max=L - 32)
+        e = torch.gather(cs, 1, (oc + 32)[:, None]).squeeze(1) - torch.gather(cs, 1, oc[:, None]).squeeze(1)
+        seed_ok |= valid & (e == 0)
+    mapped = ~um2
+    truth = {
+        "entry": torch.where(mapped, g2, torch.full_like(g2, -1)),
+        "rel": rel, "revcomp": is_b.to(torch.int64), "n_subs": n_subs,
+        "has_indel": has, "seed_ok": seed_ok & mapped & ~has,
+    }
+    return out, truth
+
+
+# ---- checks of a result set against the planted truth (nothing but the generator's own record) ----
+
+def overlap_columns(ov_bytes):
+    """uint8 device/host tensor holding n kslam_overlap records (48 B) -> dict of int64 columns."""
+    w = ov_bytes.view(torch.int32).view(-1, 12)
+    x = w[:, 3].long() & 0xFFFFFFFF
+    return {
+        "read": w[:, 0].long() & 0xFFFFFFFF, "entry": w[:, 1].long() & 0xFFFFFFFF, "rel": w[:, 2].long(),
+        "revcomp": x & 0xFF, "score": x >> 16,
+        "ref_begin": w[:, 4].long(), "ref_end": w[:, 5].long(),
+        "query_begin": w[:, 6].long(), "query_end": w[:, 7].long(),
+        "cigar_len": w[:, 8].long() & 0xFFFFFFFF,
+        "cigar_off": (w[:, 10].long() & 0xFFFFFFFF) | (w[:, 11].long() << 32),
+    }
+
+
+def check_against_truth(ov_bytes, cig_words, truth, read_len, match=2, mismatch=3):
+    """What src/Tests.h:161-264 and :321-330 expect, on every read of the batch:
+      * sortedness: (read, entry, rel) non-decreasing (src/Overlap.h:87-98);
+      * every read with an error-free sampled 32-mer and no indel has the overlap
+        (entry, rel, revComp) it was planted with;
+      * that overlap's score is at least the plain diagonal's (2 L - 5 per substitution) and at most
+        2 L; for an error-free read it IS 2 L, the alignment spans the whole read and the CIGAR is <L>M;
+      * reads of the pairs that are not from the database have no overlap at all.
+    Returns a dict of counts; `ok` is True when nothing is missing or wrong."""
+    c = overlap_columns(ov_bytes)
+    n = c["read"].numel()
+    L = read_len
+    key = (c["read"] << 40) | (c["entry"] << 26) | (c["rel"] + 1024)
+    unsorted = int((key[1:] < key[:-1]).sum()) if n > 1 else 0
+    want = torch.nonzero(truth["seed_ok"]).flatten()
+    wkey = (want << 40) | (truth["entry"][want] << 26) | (truth["rel"][want] + 1024)
+    idx = torch.searchsorted(key, wkey).clamp(max=max(n - 1, 0))
+    found = (key[idx] == wkey) if n else torch.zeros_like(wkey, dtype=torch.bool)
+    # the reference leaves equal (read, entry, rel) with different revComp to an unstable sort; here
+    # revComp = false comes first, so the planted strand may be the second of two equal keys
+    rc_want = truth["revcomp"][want]
+    idx2 = (idx + 1).clamp(max=max(n - 1, 0))
+    second = found & (c["revcomp"][idx] != rc_want) & (key[idx2] == wkey) & (c["revcomp"][idx2] == rc_want)
+    idx = torch.where(second, idx2, idx)
+    strand_ok = found & (c["revcomp"][idx] == rc_want)
+    ns = truth["n_subs"][want]
+    sc = c["score"][idx]
+    floor = match * L - (match + mismatch) * ns
+    score_ok = strand_ok & (sc >= floor) & (sc <= match * L)
+    perfect = strand_ok & (ns == 0)
+    p_idx = idx[perfect]
+    rel_p = truth["rel"][want][perfect]
+    perfect_ok = (c["score"][p_idx] == match * L) & (c["ref_begin"][p_idx] == rel_p) & \
+                 (c["ref_end"][p_idx] == rel_p + L - 1) & (c["query_begin"][p_idx] == 0) & \
+                 (c["query_end"][p_idx] == L - 1)
+    if cig_words is not None and cig_words.numel():
+        one = c["cigar_len"][p_idx] == 1
+        op = cig_words.view(torch.int32)[c["cigar_off"][p_idx].clamp(max=cig_words.numel() - 1)].long()
+        perfect_ok &= one & (op == (L << 4))
+    unmapped = truth["entry"] < 0
+    hits_unmapped = int(unmapped[c["read"]].sum()) if n else 0
+    res = {
+        "overlaps": n, "unsorted_neighbours": unsorted,
+        "planted_expected": int(want.numel()), "planted_found": int(strand_ok.sum()),
+        "planted_missing": int(want.numel() - int(strand_ok.sum())),
+        "planted_score_out_of_bounds": int((strand_ok & ~score_ok).sum()),
+        "error_free_reads": int(perfect.sum()), "error_free_wrong": int((~perfect_ok).sum()),
+        "overlaps_on_reads_not_from_db": hits_unmapped,
+    }
+    res["ok"] = (unsorted == 0 and res["planted_missing"] == 0 and res["planted_score_out_of_bounds"] == 0
+                 and res["error_free_wrong"] == 0 and hits_unmapped == 0)
+    return res

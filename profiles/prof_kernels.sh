@@ -1,4 +1,4 @@
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT; rm -rf /tmp/prof; mkdir -p /tmp/prof gpurun_out/keep
+REPO="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"; cd /tmp && export TMPDIR=/tmp; cd "$REPO" || exit 1; rm -rf /tmp/prof; mkdir -p /tmp/prof gpurun_out/keep
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof/kt -o x -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > /tmp/o1 2> /tmp/e1
 python3 - <<'PY'
 import csv,glob

@@ -1,5 +1,5 @@
 # per-dispatch durations of selected kernels (rocprofv3 kernel trace), compact output
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT; rm -rf /tmp/prof2; mkdir -p /tmp/prof2
+REPO="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"; cd /tmp && export TMPDIR=/tmp; cd "$REPO" || exit 1; rm -rf /tmp/prof2; mkdir -p /tmp/prof2
 KSLAM_DEBUG=1 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof2 -o x -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > /tmp/o1 2> /tmp/e1
 grep kslam /tmp/e1
 python3 - "$1" <<'PY'

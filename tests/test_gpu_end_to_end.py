@@ -1,0 +1,149 @@
+"""FASTQ text + <db>/database + <db>/taxDB in, SAM text + _PerRead + abbreviated report out: the whole
+classification flow of the reference's low-memory driver (src/SLAM.h:159-268) with the MI355X hot
+path in the middle, against the CPU chain of restatements (oracle/), byte for byte.
+
+  product:  kslam_fastq_parse_pair -> kslam_db_load -> kslam_set_index (the database's own columns)
+            -> kslam_load_reads -> kslam_align_resident (HIP) -> kslam_tail_sam / kslam_tail_pairs
+            -> kslam_tail_classify (per-read LCA) -> kslam_taxonomy_summary
+  checker:  oracle fastq reader -> oracle/db_oracle.py -> oracle alignToDatabase -> oracle tail ->
+            oracle taxonomy tree
+
+This is the -m gpu evidence for SURVEY section 8f rows N2 (database load), N3 (FASTQ ingest) and the
+per-read LCA of N1.  Also here: the C++ binding header a k-SLAM maintainer would include
+(k-slam_amd/host/slam_hot_path.hpp) compiled and run against the library.
+"""
+import ctypes as C
+import importlib
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _taxdb_text(n_species, n_strains):
+    """root 1 -> 2 (Bacteria) -> genus 10+g -> species 100+s -> strain 1000+e; four lines per node
+    (src/TaxonomyDatabase.h:153-183)"""
+    recs = [(1, 1, b"root", b"no rank"), (2, 1, b"Bacteria", b"superkingdom")]
+    for s in range(n_species):
+        g = 10 + s // 2
+        if s % 2 == 0:
+            recs.append((g, 2, b"Genus%d" % g, b"genus"))
+        recs.append((100 + s, g, b"Genus%d species%d" % (g, s), b"species"))
+        for k in range(n_strains):
+            recs.append((1000 + s * n_strains + k, 100 + s, b"strain %d.%d" % (s, k), b"strain"))
+    return b"".join(b"%d\n%d\n%s\n%s\n" % r for r in recs)
+
+
+def _fastq_text(bases, quals, ids, mate, eol):
+    return b"".join(b"@" + i + b"/%d extra words" % mate + eol + b + eol + b"+" + eol + q + eol
+                    for b, q, i in zip(bases, quals, ids))
+
+
+@pytest.mark.parametrize("eol", [b"\n", b"\r\n"])
+def test_fastq_and_database_files_to_sam_and_per_read_taxa(kslam, oracle, synth, tmp_path, eol):
+    F = importlib.import_module("kslam_amd.fastq")
+    D = importlib.import_module("kslam_amd.db")
+    T = importlib.import_module("kslam_amd.tail")
+    X = importlib.import_module("kslam_amd.taxonomy")
+    dbo = importlib.import_module("oracle.db_oracle")
+    n_species, n_strains, n_pairs = 4, 3, 3000
+    rng = np.random.default_rng(2024)
+    genomes = synth.make_genomes(41, n_species, n_strains, 30000, strain_sub=0.02, strain_indel=0.001,
+                                 shared_segment=2500)
+    reads, _ = synth.make_paired_reads(42, genomes, n_pairs, read_len=120, frag_mean=320, frag_sd=40, sub_rate=0.015,
+                                       indel_rate=0.003, n_rate=0.001, edge_frac=0.04, unmapped_frac=0.05)
+    # ---- the files ----
+    gb = synth.to_bytes(genomes)
+    entries = [{"bases": g, "taxonomyID": 1000 + i if i != 5 else 0, "genbankID": 7000 + i,
+                "locusTag": b"NC_%06d.1" % i, "isPlasmid": i % 4 == 3,
+                "genes": [{"geneName": b"gene%d" % k, "proteinID": b"WP_%d.1" % (100 * i + k),
+                           "product": b"hypothetical protein %d" % k, "start": 500 + 1500 * k,
+                           "stop": 1700 + 1500 * k, "geneID": k, "complement": bool(k & 1)} for k in range(15)]}
+               for i, g in enumerate(gb)]
+    dbdir = tmp_path / "db"
+    dbdir.mkdir()
+    D.write(dbdir / "database", entries)
+    taxdb = _taxdb_text(n_species, n_strains)
+    (dbdir / "taxDB").write_bytes(taxdb)
+    rb = synth.to_bytes(reads)
+    quals = [bytes(rng.integers(35, 74, len(b), dtype=np.uint8)) for b in rb]
+    ids = [b"frag%05d" % i for i in range(n_pairs)]
+    r1 = _fastq_text(rb[:n_pairs], quals[:n_pairs], ids, 1, eol)
+    r2 = _fastq_text(rb[n_pairs:], quals[n_pairs:], ids, 2, eol)
+
+    # ---- product chain ----
+    batch, u1, u2 = F.parse_pair(r1, r2)
+    assert (u1, u2) == (len(r1), len(r2)) and batch.n_reads == 2 * n_pairs
+    db = D.Database.load(dbdir / "database")
+    ctx = kslam.Context()
+    bases_pp, lens_p = db.entry_pointers()               # kslam_set_index straight from the loaded columns
+    ctx._chk(ctx._L.kslam_set_index(ctx._h, db.n_entries, C.cast(bases_pp, C.c_void_p), C.cast(lens_p, C.c_void_p)))
+    cat, off = batch.bases_array()
+    ctx.load_reads_arrays(cat, off)
+    n_out, n_cig = ctx.align_resident()
+    ov, cg, release = ctx.take_results()
+    P = T.TailParams.default()
+    sam, st = T.tail_sam(P, batch, db, ov, cg)
+    rp, pr, _ = T.tail_pairs(P, batch, ov)
+    tax = X.TaxDB((dbdir / "taxDB").read_bytes())
+    tax_ids, per_read = tax.classify(P, batch, db, rp, pr)
+    summary = tax.summary(tax_ids, n_pairs)
+    header = T.sam_header(db, b"SLAM --db db R1.fq R2.fq")
+
+    # ---- checker chain ----
+    b1, q1, i1, _ = oracle.fastq_read(r1)
+    b2, q2, i2, _ = oracle.fastq_read(r2)
+    assert b1 + b2 == rb and q1 + q2 == quals and i1 == ids and i2 == ids
+    _, oentries = dbo.parse((dbdir / "database").read_bytes())
+    ogb = [e["bases"] for e in oentries]
+    assert ogb == gb
+    eal, ecig, _ = oracle.align_to_database(b1 + b2, ogb)
+    oR = T.Reads(b1 + b2, q1 + q2, i1 + i2)
+    oI = T.Index(ogb, locus_tags=[e["locusTag"] for e in oentries], taxonomy_ids=[e["taxonomyID"] for e in oentries],
+                 genes=[[(g["start"], g["stop"], g["geneName"], g["proteinID"], g["product"]) for g in e["genes"]]
+                        for e in oentries])
+    esam = oracle.tail_sam(P, oR.view, oI.view, eal, ecig)
+    erp, epr = oracle.tail_pairs(P, oR.view, eal)
+    otree = oracle.taxonomy_tree(taxdb)
+    etax = [otree.lca([oentries[int(e)]["taxonomyID"] for e in epr["entry"][int(g["first"]):int(g["first"]) + int(g["count"])]])
+            for g in erp]
+    eper_read = b"".join(b"%s\t%d\n" % (ids[int(g["r1_read"])], t) for g, t in zip(erp, etax))
+
+    assert len(eal) > 2 * n_pairs and (eal["cigar_len"] > 1).sum() > 300
+    assert len(ov) == len(eal)
+    for f in ("read", "entry", "rel", "revcomp", "score", "ref_begin", "ref_end", "query_begin", "query_end",
+              "cigar_len", "cigar_off"):
+        assert (ov[f] == eal[f]).all(), f
+    assert np.array_equal(cg, ecig)
+    assert sam == esam and sam.count(b"\n") > 2 * n_pairs * 0.9
+    assert tax_ids.tolist() == etax and len(set(etax)) > 6
+    assert per_read == eper_read
+    assert summary == oracle.taxonomy_summary(otree, etax, n_pairs)
+    assert header == oracle.sam_header(oI.view, b"SLAM --db db R1.fq R2.fq")
+    release()
+    ctx.close()
+    batch.close()
+    db.close()
+    tax.close()
+    otree.close()
+
+
+def test_cpp_binding_header_builds_and_runs(tmp_path):
+    """k-slam_amd/host/slam_hot_path.hpp is the binding INTEGRATION.md tells a k-SLAM maintainer to
+    include; tests/host_mirror_check.cpp instantiates it with look-alikes of the reference's Overlap /
+    Alignment / GenbankEntry / FASTQ types and aligns two planted reads."""
+    gxx = shutil.which("g++")
+    assert gxx, "g++ is part of the image"
+    exe = str(tmp_path / "host_mirror_check")
+    libdir = os.path.join(ROOT, "k-slam_amd")
+    subprocess.check_call([gxx, "-std=c++11", "-O1", os.path.join(ROOT, "tests", "host_mirror_check.cpp"), "-o", exe,
+                           "-L" + libdir, "-lkslam_hip", "-Wl,-rpath," + libdir])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = [l for l in out.stdout.splitlines() if l.startswith("read ")]
+    assert len(lines) == 2 and "score 300" in lines[0] and "cigar 150M" in lines[0] and "rel 3216" in lines[1]

@@ -124,6 +124,40 @@ def test_align_parity(kslam, oracle, synth, case):
     _compare_alignments(got, gcig, exp, ecig)
 
 
+def _sprinkle(rng, seqs, rate, alphabet):
+    out = []
+    for s in seqs:
+        a = np.frombuffer(s, dtype=np.uint8).copy()
+        m = rng.random(len(a)) < rate
+        a[m] = rng.choice(np.frombuffer(alphabet, dtype=np.uint8), int(m.sum()))
+        out.append(a.tobytes())
+    return out
+
+
+@pytest.mark.parametrize("read_len,rate", [(150, 0.004), (100, 0.01), (250, 0.003)])
+def test_align_parity_odd_alphabet(kslam, oracle, synth, read_len, rate):
+    """Lower case, U/u, IUPAC codes, N and '-' in reads AND entries, on both strands.  The three codings
+    of the path disagree exactly on these characters: k-mer coding maps everything but upper-case ACTG
+    to A (src/KMer.h:261-263), SSW coding takes lower case and maps U to A, the rest to N
+    (src/ssw_cpp.cpp:11-23), and the window reverse-complement only touches upper-case ACGT
+    (src/sequenceTools.h:98-116) -- a lower-case 'a' in a reverse-strand window stays an 'a'."""
+    rng = np.random.default_rng(4000 + read_len)
+    genomes = synth.make_genomes(400 + read_len, 3, 3, 25000, strain_sub=0.02, strain_indel=0.001, shared_segment=2000)
+    reads, _ = synth.make_paired_reads(401 + read_len, genomes, 1500, read_len=read_len, frag_mean=2 * read_len + 60,
+                                       sub_rate=0.01, indel_rate=0.003, edge_frac=0.1)
+    alphabet = b"acgtacgtNnUuRYKMSWBDHVrykm-*."
+    gb = _sprinkle(rng, synth.to_bytes(genomes), rate, alphabet)
+    rb = _sprinkle(rng, synth.to_bytes(reads), rate * 1.5, alphabet)
+    # whole stretches too: a lower-case (soft-masked) region in an entry, an all-lower-case read
+    g0 = bytearray(gb[0]); g0[5000:5400] = bytes(g0[5000:5400]).lower(); gb[0] = bytes(g0)
+    rb[7] = rb[7].lower()
+    rb[8] = rb[8].replace(b"T", b"U")
+    got, gcig = kslam.align_to_database(rb, gb)
+    exp, ecig, _ = oracle.align_to_database(rb, gb)
+    assert len(exp) > 4000 and (exp["revcomp"] == 1).sum() > 1500 and (exp["cigar_len"] > 1).sum() > 300
+    _compare_alignments(got, gcig, exp, ecig)
+
+
 def test_align_chunked_equals_unchunked(kslam, synth):
     reads, genomes, _ = _dataset(synth, 5, 600)
     a, ac = kslam.align_to_database(reads, genomes)
@@ -151,6 +185,42 @@ def test_resident_path_and_page_locked_results(kslam, synth):
     rel_a()
     rel_b()
     c.close()
+
+
+def test_results_released_from_a_second_thread(kslam, synth):
+    """The pipelined callers (bench.py's sam_pipeline) hand batch k's page-locked
+    buffers back from a worker thread while the main thread takes batch k+1's: the pool is locked
+    (ADVICE r1).  40 rounds with up to three batches outstanding, results identical every time."""
+    import queue
+    import threading
+    reads, genomes, _ = _dataset(synth, 8, 400)
+    c = kslam.Context()
+    c.set_index(genomes)
+    c.load_reads(reads)
+    c.align_resident()
+    ref_ov, ref_cg, rel = c.take_results()
+    ref_ov, ref_cg = ref_ov.copy(), ref_cg.copy()
+    rel()
+    q, bad = queue.Queue(maxsize=3), []
+
+    def worker():
+        while True:
+            item = q.get()
+            if item is None:
+                return
+            ov, cg, release = item
+            if not ((ov == ref_ov).all() and np.array_equal(cg, ref_cg)):
+                bad.append(1)
+            release()
+    t = threading.Thread(target=worker)
+    t.start()
+    for _ in range(40):
+        c.align_resident()
+        q.put(c.take_results())
+    q.put(None)
+    t.join()
+    c.close()
+    assert not bad
 
 
 def test_empty_batch(kslam, synth):
@@ -266,6 +336,16 @@ def test_properties_large_batch(kslam, synth):
             h = hits[0]
             assert int(ov["cigar_len"][h]) == 1 and int(cg[int(ov["cigar_off"][h])]) == (150 << 4)
             assert int(ov["ref_end"][h]) - int(ov["ref_begin"][h]) == 149
+            # src/Tests.h:161-264: the planted (offset, revComp) comes back.  The fragment starts at
+            # `start`; its first mate is the forward strand unless the fragment was flipped.
+            rel, rc = int(ov["rel"][h]), int(ov["revcomp"][h])
+            first_mate = rid == p
+            assert rc == int(first_mate == bool(flip)), (p, rid, rc, flip)
+            assert rel == int(ov["ref_begin"][h]) and int(ov["query_begin"][h]) == 0
+            if rc == 0:
+                assert rel == start, (p, rid, rel, start)
+            else:   # the reverse mate ends where the fragment ends: start + fragment length - 150
+                assert 150 <= rel - start + 150 <= 1000, (p, rid, rel, start)
             found += 1
     assert found > 30000
     # unmapped pairs (random sequence) have no alignment at all

@@ -1,4 +1,4 @@
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
+REPO="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"; cd /tmp && export TMPDIR=/tmp; cd "$REPO" || exit 1; mkdir -p gpurun_out
 for mode in auto slab; do
   rm -rf /tmp/prof_$mode
   if [ $mode = slab ]; then export KSLAM_CIGAR_DIRS=slab; fi

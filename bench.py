@@ -422,7 +422,8 @@ def main():
             },
             "phases_ms": {k: round(tm[k], 3) for k in ("ms_extract", "ms_sort", "ms_join", "ms_sw",
                                                          "ms_cigar", "ms_total")},
-            "counts": {"read_kmers": int(n_kmers), "genome_kmers": int(tm["n_genome_kmers"]),
+            "counts": {"read_kmers": int(n_kmers), "read_kmers_kept_by_filter": int(tm["n_kmers_kept"]),
+                       "genome_kmers": int(tm["n_genome_kmers"]),
                        "overlaps_raw": int(tm["n_overlaps_raw"]), "candidates": int(tm["n_overlaps"]),
                        "cigar_ops": int(n_cig), "chunks": int(tm["n_chunks"])},
             "sw_gcups": round(tm["sw_cells"] / ((tm["ms_sw"]) * 1e-3) / 1e9, 1) if tm["ms_sw"] > 0 else 0.0,

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define KSLAM_ABI_VERSION 1
+#define KSLAM_ABI_VERSION 2
 #define KSLAM_K 32u /* src/Globals.h:25 */
 
 typedef enum {
@@ -93,12 +93,12 @@ typedef struct {
 /* Device time per phase of the last kslam_align_* call, from HIP events on
  * the context's own stream, in milliseconds; plus work counters. */
 typedef struct {
-  float ms_extract;     /* read k-mer extraction */
-  float ms_sort;        /* k-mer radix sort (histogram + all passes) */
-  float ms_sort_scatter;/* the onesweep scatter passes only */
-  float ms_join;        /* merge-join + overlap sort + dedupe */
-  float ms_sw;          /* forward + reverse Smith-Waterman passes */
-  float ms_cigar;       /* banded traceback */
+  float ms_extract;     /* read k-mer extraction (with the membership filter when it is on) */
+  float ms_sort;        /* k-mer radix sort (histograms + scans + scatter passes) */
+  float ms_sort_scatter;/* the scatter launches of that sort only */
+  float ms_join;        /* lookup join + overlap-key sort + dedupe */
+  float ms_sw;          /* Smith-Waterman scores, ends and origins (planning + band tiers + full matrix) */
+  float ms_cigar;       /* banded DP + traceback + finalize */
   float ms_total;       /* first kernel to last kernel */
   uint32_t sort_passes; /* radix passes executed per k-mer sort */
   uint64_t n_read_kmers;
@@ -108,6 +108,8 @@ typedef struct {
   uint64_t sw_cells;         /* forward-pass DP cells (query_len * window_len) */
   uint32_t n_chunks;
   uint32_t n_scatter_launches;
+  uint64_t n_kmers_kept;     /* read k-mers that passed the genome-membership filter
+                                (= n_read_kmers when the filter is off); these are sorted and joined */
 } kslam_timings;
 
 typedef struct kslam_ctx kslam_ctx;

@@ -55,7 +55,7 @@ class Timings(C.Structure):
                 ("n_read_kmers", C.c_uint64), ("n_genome_kmers", C.c_uint64),
                 ("n_overlaps_raw", C.c_uint64), ("n_overlaps", C.c_uint64),
                 ("sw_cells", C.c_uint64), ("n_chunks", C.c_uint32),
-                ("n_scatter_launches", C.c_uint32)]
+                ("n_scatter_launches", C.c_uint32), ("n_kmers_kept", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -113,6 +113,16 @@ void extract_kmers_launch(const uint8_t *d_bases, const uint64_t *d_offsets,
                           const SegEntry *d_segs, uint64_t n_segs, uint32_t gap,
                           int is_gb, uint32_t id_base, uint4 *d_out, hipStream_t s);
 
+// -------------------------------------------------------------- filter.hip
+// Blocked Bloom filter over the genome k-mer set (2^log2_bits bits, 128-byte lines chosen by the
+// k-mer's minimizer) and the read extraction kernel that keeps only the k-mers the filter lets through.
+size_t filter_bytes(uint32_t log2_bits);
+void filter_build(const uint64_t *d_sorted_keys, uint32_t n, uint32_t log2_bits, void *d_filter, hipStream_t s);
+// reads d_off[0..n_reads] (gap 1, ids = position in d_off): surviving records appended at *d_cursor
+// (which ends as their number); nothing is written beyond `cap` (the caller reruns with a larger buffer)
+void extract_filtered(const uint8_t *d_bases, const uint64_t *d_off, uint32_t n_reads, const void *d_filter,
+                      uint32_t log2_bits, uint4 *d_out, uint64_t *d_cursor, uint64_t cap, hipStream_t s);
+
 // ---------------------------------------------------------- radix_sort.hip
 struct SortPass {
   uint32_t word;    // which 32-bit word of the record holds the digit
@@ -137,7 +147,6 @@ struct SortWorkspace {
   DevBuf hist;      // u32 [chunks][256] per-chunk digit totals -> bases
   DevBuf status;    // u32 [tiles][256] per-tile digit counts -> in-chunk prefixes
   DevBuf tickets;   // u32 [256] per-digit totals -> global bin bases
-  DevBuf errflag;   // unused (no device-side waiting any more)
   hipEvent_t *ev_sc0 = nullptr, *ev_sc1 = nullptr;   // optional per-pass events around k_scatter
   uint32_t epoch = 0;
 };
@@ -165,11 +174,6 @@ struct OverlapKeyLayout {  // packed u64 overlap: read | entry | rel + bias | re
 constexpr int JOIN_TILE = 1024;
 void build_bucket_table(const uint64_t *d_keys, uint32_t n, uint32_t bits, uint32_t *d_bucket,
                         hipStream_t s);
-void join_count(const uint4 *d_read_recs, uint32_t n_r, GenomeIndexDev g, uint32_t *d_block_tot,
-                hipStream_t s);
-void join_fill(const uint4 *d_read_recs, uint32_t n_r, GenomeIndexDev g, const uint32_t *d_read_len,
-               uint32_t read_id_base, const uint64_t *d_block_base, OverlapKeyLayout lay,
-               uint64_t *d_out, hipStream_t s);
 // single-pass join: output ranges reserved with one atomic per workgroup; *d_cursor ends as the
 // total number of overlaps; nothing beyond `cap` is written (caller reruns with a larger buffer)
 void join_fill_single_pass(const uint4 *d_read_recs, uint32_t n_r, GenomeIndexDev g, const uint32_t *d_read_len,

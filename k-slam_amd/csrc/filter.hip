@@ -1,0 +1,202 @@
+// filter.hip -- read k-mer extraction fused with a membership test against the genome k-mer set.
+//
+// The reference writes every read k-mer into the one list it sorts (src/KMer.h:373-381, src/SLAM.h:63-66)
+// although a read k-mer without an equal genome k-mer can never produce an overlap: processPileUp
+// skips every run that does not start with a genome record (src/Overlap.h:157-162).  The genome list is
+// sampled at every 16th offset, so of a read's 119 k-mers only the ~7 in phase with the sampling can
+// match at all -- on the BASELINE workload 97 % of the 238 M read k-mers per batch were written
+// (3.8 GB), sorted and looked up for nothing.  Here the extraction kernel asks a filter built once per
+// index ("is this k-mer possibly in the genome list?") and keeps only the survivors.  False positives
+// are harmless (the join finds no run for them), false negatives cannot happen, so the overlaps are
+// exactly the reference's.
+//
+// Filter layout (MI355X): a blocked Bloom filter of 2^b bits in 128-byte lines of eight 16-byte
+// pieces.  A k-mer's LINE is chosen by its canonical minimizer (the smallest 16-mer over both strands of
+// the 32-mer), its piece and its four bits (one per dword of the piece) by a hash of the whole k-mer.
+// Consecutive k-mers of a read share their minimizer for ~9 positions on average, so the 119 probes of a
+// read touch ~14 distinct lines instead of 119: the probe traffic drops from 238 M to ~28 M line fetches
+// per batch, and each probe is ONE 16-byte load.  512 MiB (b = 32) holds the 312 M keys of the 5 Gb
+// database at 9.3 keys per piece: false-positive rate ~0.5 %.
+//
+// Survivors are staged per wave in LDS and appended to the output with one atomic per flush; their order
+// is scheduling dependent, which no later stage observes (they are sorted / looked up individually and
+// the overlap list is re-sorted by (read, entry, rel)).
+#include "common.h"
+
+namespace kslam {
+
+namespace {
+
+__device__ inline uint64_t revcomp64(uint64_t fwd) {
+  uint64_t x = fwd ^ 0xAAAAAAAAAAAAAAAAull;
+  x = __brevll(x);
+  return ((x & 0x5555555555555555ull) << 1) | ((x >> 1) & 0x5555555555555555ull);
+}
+
+// 4 ASCII bytes (little endian dword) -> 8 bits, first base in bits 7:6 (A 0, C 1, T 2, G 3, else 0:
+// reference src/KMer.h:246-268)
+__device__ inline uint32_t pack4(uint32_t x) {
+  uint32_t r = 0;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    uint32_t c = (x >> (8 * j)) & 0xFFu;
+    uint32_t code = (c >> 1) & 3u;
+    uint32_t cand = (0x47544341u >> (8 * code)) & 0xFFu;
+    code = (cand == c) ? code : 0u;
+    r |= code << (6 - 2 * j);
+  }
+  return r;
+}
+
+// smallest 32-bit window (16 bases) of the 64-bit word, over all 17 base-aligned positions
+__device__ inline uint32_t min_window16(uint64_t v) {
+  const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+  uint32_t m = min(lo, hi);
+#pragma unroll
+  for (int j = 1; j < 16; j += 2) {
+    const uint32_t a = __builtin_amdgcn_alignbit(hi, lo, 2 * j);
+    const uint32_t b = j + 1 < 16 ? __builtin_amdgcn_alignbit(hi, lo, 2 * (j + 1)) : a;
+    m = min(m, min(a, b));
+  }
+  return m;
+}
+
+struct Probe {
+  uint32_t piece;          // index of the 16-byte piece
+  uint32_t s0, s1, s2, s3; // bit number inside each dword of the piece
+};
+
+// `kmer` and `rc` are the two strands of one 32-mer (either order): the result is the same for both
+__device__ inline Probe probe_of(uint64_t kmer, uint64_t rc, uint32_t line_bits) {
+  const uint32_t mini = min(min_window16(kmer), min_window16(rc));
+  const uint64_t canon = kmer < rc ? kmer : rc;
+  const uint32_t h = ((uint32_t)canon * 0x9E3779B1u) ^ ((uint32_t)(canon >> 32) * 0x85EBCA77u);
+  const uint32_t g = h ^ (h >> 15);
+  Probe p;
+  const uint32_t line = (mini * 0x9E3779B1u) >> (32 - line_bits);
+  p.piece = (line << 3) | (g >> 29);
+  p.s0 = g & 31u; p.s1 = (g >> 5) & 31u; p.s2 = (g >> 10) & 31u; p.s3 = (g >> 15) & 31u;
+  return p;
+}
+
+__global__ void k_filter_build(const uint64_t *__restrict__ keys, uint32_t n, uint32_t line_bits,
+                               uint32_t *__restrict__ filter) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t k = keys[i];
+  if (k == 0) return;                       // k-mer 0 never joins (src/Overlap.h:236)
+  if (i > 0 && keys[i - 1] == k) return;    // sorted list: one insert per distinct key
+  const Probe p = probe_of(k, revcomp64(k), line_bits);
+  uint32_t *w = filter + (size_t)p.piece * 4;
+  atomicOr(w + 0, 1u << p.s0);
+  atomicOr(w + 1, 1u << p.s1);
+  atomicOr(w + 2, 1u << p.s2);
+  atomicOr(w + 3, 1u << p.s3);
+}
+
+constexpr int FW = 4;              // waves per workgroup
+constexpr int STAGE = 256;         // survivor records staged per wave
+constexpr uint32_t LWORDS = 36;    // packed-base words per wave: reads up to 511 bases + alignment slack
+
+// One wave per read, `reads_per_wave` reads in turn.  Record layout and canonical choice as k_extract
+// (extract.hip): the survivors are bit-identical to the records the unfiltered kernel writes.
+__global__ __launch_bounds__(FW * 64) void k_extract_filter(const uint8_t *__restrict__ bases,
+                                                            const uint64_t *__restrict__ off, uint32_t n_reads,
+                                                            uint32_t reads_per_wave,
+                                                            const uint4 *__restrict__ filter, uint32_t line_bits,
+                                                            uint4 *__restrict__ out,
+                                                            unsigned long long *__restrict__ cursor, uint64_t cap) {
+  __shared__ uint32_t packed[FW][LWORDS];
+  __shared__ uint4 stage[FW][STAGE];
+  const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  uint32_t *my = packed[w];
+  uint8_t *my8 = reinterpret_cast<uint8_t *>(my);
+  uint4 *st = stage[w];
+  uint32_t staged = 0;   // wave-uniform
+  const uint32_t r_begin = (blockIdx.x * FW + w) * reads_per_wave;
+  const uint32_t r_end = min(n_reads, r_begin + reads_per_wave);
+
+  auto flush = [&]() {
+    if (staged == 0) return;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the staged records of every lane are visible
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(cursor, (unsigned long long)staged);
+    base = __shfl(base, 0, 64);
+    if (base + staged <= cap)
+      for (uint32_t i = lane; i < staged; i += 64) out[base + i] = st[i];
+    staged = 0;
+  };
+
+  for (uint32_t r = r_begin; r < r_end; r++) {
+    const uint64_t s0 = off[r];
+    const uint32_t len = (uint32_t)(off[r + 1] - s0);
+    if (len < KSLAM_K) continue;           // src/KMer.h:167
+    const uint32_t nk = len - KSLAM_K + 1; // gap 1 (src/KMer.h:378)
+    const uint64_t a_al = s0 & ~3ull;
+    const uint32_t m = (uint32_t)(s0 & 3ull);
+    const uint32_t ndw = (m + len + 3) >> 2;
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(bases + a_al);
+    __builtin_amdgcn_wave_barrier();       // the previous read's words are no longer needed
+    for (uint32_t d = lane; d < ndw; d += 64) my8[(d & ~3u) | (3u - (d & 3u))] = (uint8_t)pack4(src[d]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const uint32_t idbits = r & 0x3FFFFFFFu;
+    for (uint32_t q0 = 0; q0 < nk; q0 += 64) {
+      if (staged + 64 > STAGE) flush();
+      const uint32_t q = q0 + lane;
+      bool keep = false;
+      uint4 rec = make_uint4(0, 0, 0, 0);
+      if (q < nk) {
+        const uint32_t sidx = m + q;
+        const uint32_t wi = sidx >> 4, sh = (sidx & 15u) * 2u;
+        const uint32_t W0 = my[wi], W1 = my[wi + 1], W2 = my[wi + 2];
+        const uint64_t a = ((uint64_t)W0 << 32) | W1, b = ((uint64_t)W1 << 32) | W2;
+        const uint64_t fwd = ((a << sh) & 0xFFFFFFFF00000000ull) | ((b << sh) >> 32);
+        const uint64_t rc = revcomp64(fwd);
+        const bool is_fwd = fwd < rc;       // src/KMer.h:173 (palindromes take the rc branch)
+        const uint64_t kmer = is_fwd ? fwd : rc;
+        if (kmer != 0) {                    // src/Overlap.h:236
+          const Probe p = probe_of(fwd, rc, line_bits);
+          const uint4 f = filter[p.piece];
+          keep = ((f.x >> p.s0) & (f.y >> p.s1) & (f.z >> p.s2) & (f.w >> p.s3) & 1u) != 0;
+        }
+        rec.x = (uint32_t)kmer; rec.y = (uint32_t)(kmer >> 32);
+        rec.z = is_fwd ? idbits : (idbits | (1u << 30));
+        rec.w = is_fwd ? q : (len - KSLAM_K - q);   // src/KMer.h:176
+      }
+      const unsigned long long mask = __ballot(keep);
+      if (keep) st[staged + __popcll(mask & ((1ull << lane) - 1ull))] = rec;
+      staged += (uint32_t)__popcll(mask);
+    }
+  }
+  flush();
+}
+
+}  // namespace
+
+size_t filter_bytes(uint32_t log2_bits) { return (size_t)1 << (log2_bits - 3); }
+
+void filter_build(const uint64_t *d_sorted_keys, uint32_t n, uint32_t log2_bits, void *d_filter, hipStream_t s) {
+  HIPCHK(hipMemsetAsync(d_filter, 0, filter_bytes(log2_bits), s));
+  if (n == 0) return;
+  hipLaunchKernelGGL(k_filter_build, dim3((n + 255) / 256), dim3(256), 0, s, d_sorted_keys, n, log2_bits - 10,
+                     (uint32_t *)d_filter);
+  HIPCHK(hipGetLastError());
+}
+
+void extract_filtered(const uint8_t *d_bases, const uint64_t *d_off, uint32_t n_reads, const void *d_filter,
+                      uint32_t log2_bits, uint4 *d_out, uint64_t *d_cursor, uint64_t cap, hipStream_t s) {
+  HIPCHK(hipMemsetAsync(d_cursor, 0, sizeof(uint64_t), s));
+  if (n_reads == 0) return;
+  const uint32_t rpw = 16;
+  const uint32_t per_block = FW * rpw;
+  hipLaunchKernelGGL(k_extract_filter, dim3((n_reads + per_block - 1) / per_block), dim3(FW * 64), 0, s, d_bases, d_off,
+                     n_reads, rpw, (const uint4 *)d_filter, log2_bits - 10, d_out,
+                     reinterpret_cast<unsigned long long *>(d_cursor), cap);
+  HIPCHK(hipGetLastError());
+}
+
+}  // namespace kslam

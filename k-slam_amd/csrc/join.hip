@@ -96,34 +96,6 @@ __device__ inline Run find_run(uint64_t key, const GenomeIndexDev &g) {
   return r;
 }
 
-__device__ inline uint32_t block_reduce_u32(uint32_t v, uint32_t *sm) {
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) v += __shfl_down(v, d, 64);
-  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
-  __syncthreads();
-  uint32_t t = 0;
-  for (int i = 0; i < JB / 64; i++) t += sm[i];
-  __syncthreads();
-  return t;
-}
-
-__global__ __launch_bounds__(JB) void k_join_count(const uint4 *__restrict__ recs, uint32_t n,
-                                                   GenomeIndexDev g, uint32_t *__restrict__ block_tot) {
-  __shared__ uint32_t sm[JB / 64];
-  const uint32_t base = blockIdx.x * JOIN_TILE;
-  uint32_t acc = 0;
-#pragma unroll
-  for (int it = 0; it < JI; it++) {
-    uint32_t i = base + it * JB + threadIdx.x;
-    if (i < n) {
-      uint4 r = recs[i];
-      acc += find_run(((uint64_t)r.y << 32) | r.x, g).cnt;
-    }
-  }
-  uint32_t tot = block_reduce_u32(acc, sm);
-  if (threadIdx.x == 0) block_tot[blockIdx.x] = tot;
-}
-
 __device__ inline uint64_t make_overlap(uint32_t rmeta, uint32_t roff, uint32_t gmeta, uint32_t goff,
                                         const uint32_t *read_len, const OverlapKeyLayout &lay) {
   const uint32_t rid = rmeta & 0x3FFFFFFFu, gid = gmeta & 0x3FFFFFFFu;
@@ -135,14 +107,12 @@ __device__ inline uint64_t make_overlap(uint32_t rmeta, uint32_t roff, uint32_t 
          (relb << 1) | (uint64_t)(grc != rrc);
 }
 
-// block_base != nullptr: deterministic positions from the count pass.  block_base == nullptr:
-// single-pass mode, the workgroup reserves its output range with one atomic add on cursor[0]
-// and skips its writes when the range would exceed `cap` (the host then reruns with a larger
-// buffer); output ORDER then depends on scheduling, which is harmless because the overlap keys
-// are totally ordered by the sort that follows (equal keys are indistinguishable).
+// Single pass: the workgroup reserves its output range with one atomic add on cursor[0] and skips
+// its writes when the range would exceed `cap` (the host then reruns with a larger buffer); the
+// output ORDER depends on scheduling, which is harmless because the overlap keys are totally ordered
+// by the sort that follows (equal keys are indistinguishable).
 __global__ __launch_bounds__(JB) void k_join_fill(const uint4 *__restrict__ recs, uint32_t n,
                                                   GenomeIndexDev g, const uint32_t *__restrict__ read_len,
-                                                  const uint64_t *__restrict__ block_base,
                                                   unsigned long long *__restrict__ cursor, uint64_t cap,
                                                   OverlapKeyLayout lay, uint64_t *__restrict__ out) {
   __shared__ uint32_t wsum[JB / 64];
@@ -190,14 +160,10 @@ __global__ __launch_bounds__(JB) void k_join_fill(const uint4 *__restrict__ recs
   uint64_t bb;
   uint32_t tot = 0;
   for (int i = 0; i < JB / 64; i++) tot += wsum[i];
-  if (block_base) {
-    bb = block_base[blockIdx.x];
-  } else {
-    if (threadIdx.x == 0) s_base = tot ? atomicAdd(cursor, (unsigned long long)tot) : 0ull;
-    __syncthreads();
-    bb = s_base;
-    if (bb + tot > cap) return;   // does not fit: only the cursor matters now (wave-uniform exit)
-  }
+  if (threadIdx.x == 0) s_base = tot ? atomicAdd(cursor, (unsigned long long)tot) : 0ull;
+  __syncthreads();
+  bb = s_base;
+  if (bb + tot > cap) return;   // does not fit: only the cursor matters now (block-uniform exit)
   if (tot <= FLAT_MAX) {   // (block-uniform)
 #pragma unroll
     for (int it = 0; it < JI; it++) {
@@ -295,32 +261,13 @@ void build_bucket_table(const uint64_t *d_keys, uint32_t n, uint32_t bits, uint3
   HIPCHK(hipGetLastError());
 }
 
-void join_count(const uint4 *d_read_recs, uint32_t n_r, GenomeIndexDev g, uint32_t *d_block_tot,
-                hipStream_t s) {
-  if (n_r == 0) return;
-  unsigned blocks = (n_r + JOIN_TILE - 1) / JOIN_TILE;
-  hipLaunchKernelGGL(k_join_count, dim3(blocks), dim3(JB), 0, s, d_read_recs, n_r, g, d_block_tot);
-  HIPCHK(hipGetLastError());
-}
-
-void join_fill(const uint4 *d_read_recs, uint32_t n_r, GenomeIndexDev g, const uint32_t *d_read_len,
-               uint32_t read_id_base, const uint64_t *d_block_base, OverlapKeyLayout lay, uint64_t *d_out,
-               hipStream_t s) {
-  (void)read_id_base;
-  if (n_r == 0) return;
-  unsigned blocks = (n_r + JOIN_TILE - 1) / JOIN_TILE;
-  hipLaunchKernelGGL(k_join_fill, dim3(blocks), dim3(JB), 0, s, d_read_recs, n_r, g, d_read_len, d_block_base,
-                     (unsigned long long *)nullptr, (uint64_t)0, lay, d_out);
-  HIPCHK(hipGetLastError());
-}
-
 void join_fill_single_pass(const uint4 *d_read_recs, uint32_t n_r, GenomeIndexDev g, const uint32_t *d_read_len,
                            uint64_t *d_cursor, uint64_t cap, OverlapKeyLayout lay, uint64_t *d_out, hipStream_t s) {
   HIPCHK(hipMemsetAsync(d_cursor, 0, sizeof(uint64_t), s));
   if (n_r == 0) return;
   unsigned blocks = (n_r + JOIN_TILE - 1) / JOIN_TILE;
   hipLaunchKernelGGL(k_join_fill, dim3(blocks), dim3(JB), 0, s, d_read_recs, n_r, g, d_read_len,
-                     (const uint64_t *)nullptr, reinterpret_cast<unsigned long long *>(d_cursor), cap, lay, d_out);
+                     reinterpret_cast<unsigned long long *>(d_cursor), cap, lay, d_out);
   HIPCHK(hipGetLastError());
 }
 

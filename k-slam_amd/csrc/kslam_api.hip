@@ -32,6 +32,9 @@ struct kslam_ctx {
   uint64_t n_gk = 0;
   DevBuf gk_key, gk_meta, gk_off, g_bucket;
   uint32_t bucket_bits = 8;
+  DevBuf g_filter;            // membership filter over the genome k-mers (filter.hip); filter_bits = 0: off
+  uint32_t filter_bits = 0;
+  uint64_t kept_last = 0;     // survivors of the last chunk (sizes the next chunk's record buffers)
 
   // ---- resident read batch ----
   bool have_reads = false;
@@ -267,16 +270,6 @@ void run_extract(kslam_ctx *c, const uint8_t *d_bases, const uint64_t *d_off, ui
   extract_kmers_launch(d_bases, d_off, c->segs.as<SegEntry>(), n_segs, gap, is_gb, 0, d_out, s);
 }
 
-void check_sort_error(kslam_ctx *c) {
-  if (!c->sortws.errflag.p) return;   // the sort no longer waits on the device; kept for the ABI status
-  uint32_t e = 0;
-  read_back(&e, c->sortws.errflag.p, sizeof e, c->stream);
-  if (e) {
-    HIPCHK(hipMemsetAsync(c->sortws.errflag.p, 0, sizeof(uint32_t), c->stream));
-    throw StatusError{KSLAM_ERR_INTERNAL, "radix sort look-back timed out"};
-  }
-}
-
 void build_index(kslam_ctx *c) {
   hipStream_t s = c->stream;
   const uint64_t n = c->n_entries;
@@ -313,8 +306,24 @@ void build_index(kslam_ctx *c) {
   c->bucket_bits = bits;
   c->g_bucket.ensure(((1ull << bits) + 2) * sizeof(uint32_t));
   build_bucket_table(c->gk_key.as<uint64_t>(), (uint32_t)m, bits, c->g_bucket.as<uint32_t>(), s);
+  // membership filter for the read extraction: ~14 bits per genome k-mer (9.3 keys per 128-bit piece),
+  // 2^32 bits = 512 MiB for the 312 M k-mers of a 5 Gb database.  KSLAM_FILTER_BITS: log2 of the size
+  // in bits, 0 = extract, sort and look up every read k-mer as the reference does.
+  {
+    uint32_t fb = 20;
+    while (fb < 35 && ((uint64_t)1 << fb) < m * 12) fb++;
+    if (const char *e = getenv("KSLAM_FILTER_BITS")) {
+      const int v = atoi(e);
+      fb = v <= 0 ? 0u : std::min(36u, std::max(20u, (uint32_t)v));
+    }
+    c->filter_bits = fb;
+    if (fb) {
+      c->g_filter.ensure(filter_bytes(fb));
+      filter_build(c->gk_key.as<uint64_t>(), (uint32_t)m, fb, c->g_filter.p, s);
+    }
+  }
   HIPCHK(hipStreamSynchronize(s));
-  check_sort_error(c);
+  c->kept_last = 0;
   c->have_index = true;
 }
 
@@ -407,8 +416,8 @@ void align_resident(kslam_ctx *c, bool stop_after_join, uint64_t *n_raw_out) {
   std::vector<SortPass> kpasses;
   {
     uint32_t nbytes = (std::min(c->bucket_bits, 24u) + 7) / 8;
-    if (const char *e = getenv("KSLAM_SORT_BYTES")) nbytes = (uint32_t)atoi(e);
-    nbytes = std::min(8u, std::max(1u, nbytes));
+    if (const char *e = getenv("KSLAM_SORT_BYTES")) nbytes = (uint32_t)std::max(0, atoi(e));
+    nbytes = std::min(8u, std::max(c->filter_bits ? 0u : 1u, nbytes));   // 0: look the survivors up unsorted
     for (uint32_t b = 8 - nbytes; b < 8; b++) kpasses.push_back(SortPass{b / 4, 8 * (b % 4), 0});
   }
   tm.sort_passes = (uint32_t)kpasses.size();
@@ -423,19 +432,41 @@ void align_resident(kslam_ctx *c, bool stop_after_join, uint64_t *n_raw_out) {
     const uint64_t *kp = c->h_kpre.data();
     uint64_t r1 = (uint64_t)(std::upper_bound(kp + r0 + 1, kp + hi + 1, kp[r0] + max_chunk_kmers) - kp) - 1;
     r1 = std::max(r1, r0 + 1);
-    const uint64_t nk = kp[r1] - kp[r0], nsegs = c->h_spre[r1] - c->h_spre[r0];
-    if (nk >= (1ull << 32)) throw StatusError{KSLAM_ERR_UNSUPPORTED, "a single read chunk exceeds 2^32 k-mers"};
+    const uint64_t nk_all = kp[r1] - kp[r0], nsegs = c->h_spre[r1] - c->h_spre[r0];
+    if (nk_all >= (1ull << 32)) throw StatusError{KSLAM_ERR_UNSUPPORTED, "a single read chunk exceeds 2^32 k-mers"};
     const uint64_t nr = r1 - r0;
     tm.n_chunks++;
-    tm.n_read_kmers += nk;
+    tm.n_read_kmers += nk_all;
     lay.bits_read = bits_for(nr ? nr - 1 : 0);
     const uint64_t *d_off = c->r_off.as<uint64_t>() + r0;
+    uint64_t *d_tot = c->totals.as<uint64_t>();
 
     // ---- a-3: read k-mer extraction ----
     HIPCHK(hipEventRecord(c->ev[0], s));
-    c->recs_a.ensure((nk + 1) * sizeof(uint4));
-    c->recs_b.ensure((nk + 1) * sizeof(uint4));
-    run_extract(c, c->r_bases.as<uint8_t>(), d_off, nr, 1, 0, nsegs, c->recs_a.as<uint4>());
+    uint64_t nk = nk_all;
+    if (c->filter_bits && nk_all) {
+      // only the k-mers the genome filter lets through are written; buffer sized from the last chunk,
+      // rerun once with the exact size if it was too small
+      c->totals.ensure(8 * sizeof(uint64_t));
+      d_tot = c->totals.as<uint64_t>();
+      uint64_t cap = std::max<uint64_t>(c->kept_last + c->kept_last / 4, nk_all / 12) + 4096;
+      cap = std::min(cap, nk_all);
+      for (int attempt = 0; attempt < 2; attempt++) {
+        c->recs_a.ensure((cap + 1) * sizeof(uint4));
+        extract_filtered(c->r_bases.as<uint8_t>(), d_off, (uint32_t)nr, c->g_filter.p, c->filter_bits,
+                         c->recs_a.as<uint4>(), d_tot + 2, cap, s);
+        read_back(&nk, d_tot + 2, sizeof nk, s);
+        if (nk <= cap) break;
+        cap = nk;
+      }
+      c->kept_last = nk;
+      c->recs_b.ensure((nk + 1) * sizeof(uint4));
+    } else {
+      c->recs_a.ensure((nk + 1) * sizeof(uint4));
+      c->recs_b.ensure((nk + 1) * sizeof(uint4));
+      run_extract(c, c->r_bases.as<uint8_t>(), d_off, nr, 1, 0, nsegs, c->recs_a.as<uint4>());
+    }
+    tm.n_kmers_kept += nk;
     HIPCHK(hipEventRecord(c->ev[1], s));
     // ---- a-4: sort by k-mer ----
     c->sortws.ev_sc0 = c->evs0; c->sortws.ev_sc1 = c->evs1;
@@ -449,12 +480,14 @@ void align_resident(kslam_ctx *c, bool stop_after_join, uint64_t *n_raw_out) {
     c->block_tot.ensure((n_tiles + 1) * sizeof(uint32_t));
     c->block_base.ensure((n_tiles + 1) * sizeof(uint64_t));
     c->scan_tmp.ensure(scan_tmp_bytes(std::max<uint64_t>(n_tiles, 1)));
-    uint64_t *d_tot = c->totals.as<uint64_t>();
+    c->totals.ensure(8 * sizeof(uint64_t));
+    d_tot = c->totals.as<uint64_t>();
     uint64_t raw = 0;
     if (nk) {
       // single-pass join into a buffer sized from the last batch; rerun once if it was too small
       const uint64_t have_cap = c->ovk_a.cap / sizeof(uint64_t);
-      uint64_t cap = have_cap > nk / 6 + 1024 ? have_cap - 1 : nk / 6 + 1024;   // never grows a big-enough buffer
+      const uint64_t guess = (c->filter_bits ? 4 * nk : nk / 6) + 1024;
+      uint64_t cap = have_cap > guess ? have_cap - 1 : guess;   // never grows a big-enough buffer
       for (int attempt = 0; attempt < 2; attempt++) {
         c->ovk_a.ensure((cap + 1) * sizeof(uint64_t));
         join_fill_single_pass(sorted, (uint32_t)nk, g, c->r_len.as<uint32_t>() + r0, d_tot, cap, lay,
@@ -508,7 +541,6 @@ void align_resident(kslam_ctx *c, bool stop_after_join, uint64_t *n_raw_out) {
     }
     HIPCHK(hipEventRecord(c->ev[7], s));
     HIPCHK(hipStreamSynchronize(s));
-    check_sort_error(c);
     tm.ms_extract += ev_ms(c->ev[0], c->ev[1]);
     tm.ms_sort += ev_ms(c->ev[1], c->ev[4]);
     if (nk) for (size_t q = 0; q < kpasses.size(); q++) tm.ms_sort_scatter += ev_ms(c->evs0[q], c->evs1[q]);
@@ -585,11 +617,11 @@ void kslam_destroy(kslam_ctx *c) {
   if (c->device >= 0) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    DevBuf *bufs[] = {&c->g_codes, &c->r_codes, &c->g_bases, &c->g_off, &c->gk_key, &c->gk_meta, &c->gk_off, &c->g_bucket, &c->r_bases,
+    DevBuf *bufs[] = {&c->g_codes, &c->r_codes, &c->g_bases, &c->g_off, &c->gk_key, &c->gk_meta, &c->gk_off, &c->g_bucket, &c->g_filter, &c->r_bases,
                       &c->r_off, &c->r_len, &c->nk, &c->nseg, &c->rec_start, &c->seg_start, &c->segs, &c->scan_tmp,
                       &c->totals, &c->recs_a, &c->recs_b, &c->block_tot, &c->block_base, &c->ovk_a, &c->ovk_b,
                       &c->flags, &c->pos, &c->band0, &c->sortws.hist, &c->sortws.status, &c->sortws.tickets,
-                      &c->sortws.errflag, &c->cig.flags, &c->cig.pos, &c->cig.list, &c->cig.bmax, &c->cig.needbig,
+                      &c->cig.flags, &c->cig.pos, &c->cig.list, &c->cig.bmax, &c->cig.needbig,
                       &c->cig.scan_tmp, &c->cig.totals, &c->cig.cig_off, &c->cig.tmp, &c->cig.tmp_big,
                       &c->cig.big_pos, &c->cig.scratch, &c->sww.flags, &c->sww.pos, &c->sww.list, &c->sww.list2, &c->sww.scan_tmp, &c->sww.totals, &c->cells, &c->res_ov, &c->res_cig, &c->res_tmp};
     for (DevBuf *b : bufs) b->release();
@@ -814,7 +846,6 @@ kslam_status kslam_sort_kmers(kslam_ctx *c, kslam_kmer *recs, uint64_t n) {
                               nullptr);
     HIPCHK(hipMemcpyAsync(recs, sorted, n * sizeof(uint4), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    check_sort_error(c);
     a.release(); b.release();
   });
 }
@@ -845,7 +876,6 @@ kslam_status kslam_selftest_sort(kslam_ctx *c, uint64_t n, uint32_t iters, float
       tot += ev_ms(c->ev[0], c->ev[1]);
       for (size_t q = 0; q < passes.size(); q++) tot_sc += ev_ms(c->evs0[q], c->evs1[q]);
     }
-    check_sort_error(c);
     HIPCHK(hipMemsetAsync(c->cells.p, 0, sizeof(uint64_t), s));
     hipLaunchKernelGGL(k_count_inversions, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const uint4 *)sorted,
                        (uint32_t)n, c->cells.as<unsigned long long>());

@@ -18,7 +18,7 @@
 // per batch, and each probe is ONE 16-byte load.  512 MiB (b = 32) holds the 312 M keys of the 5 Gb
 // database at 9.3 keys per piece: false-positive rate ~0.5 %.
 //
-// Survivors are staged per wave in LDS and appended to the output with one atomic per flush; their order
+// Survivors are staged per workgroup in LDS and appended to the output with one atomic; their order
 // is scheduling dependent, which no later stage observes (they are sorted / looked up individually and
 // the overlap list is re-sorted by (read, entry, rel)).
 #include "common.h"
@@ -94,85 +94,145 @@ __global__ void k_filter_build(const uint64_t *__restrict__ keys, uint32_t n, ui
   atomicOr(w + 3, 1u << p.s3);
 }
 
-constexpr int FW = 4;              // waves per workgroup
-constexpr int STAGE = 256;         // survivor records staged per wave
+constexpr int FW = 8;              // waves per workgroup
+constexpr int STAGE = 2048;        // survivor records staged per workgroup (128 reads x ~12.6 on the bench workload)
 constexpr uint32_t LWORDS = 36;    // packed-base words per wave: reads up to 511 bases + alignment slack
+constexpr uint32_t RPW = 16;       // reads per wave (their offsets are fetched with one load)
 
-// One wave per read, `reads_per_wave` reads in turn.  Record layout and canonical choice as k_extract
+struct Cut {        // one k-mer of the read, cut out of the packed words
+  uint64_t fwd, rc;
+  bool valid;
+};
+
+// One wave per read, RPW reads in turn.  Record layout and canonical choice as k_extract
 // (extract.hip): the survivors are bit-identical to the records the unfiltered kernel writes.
+// Not bound by bytes (150 B in, ~12 survivors out per read) but by round trips: the wave's read
+// offsets come with one load up front, the bases of read r+1 are in flight while read r is
+// processed, the filter probes of 128 k-mers (two per lane) are issued together -- and the output
+// cursor is touched ONCE per workgroup: a first version appended per wave (250 k returning atomic adds
+// on one address per batch) and ran at exactly 12 ns per atomic, 3.1 ms, whatever else it did.
 __global__ __launch_bounds__(FW * 64) void k_extract_filter(const uint8_t *__restrict__ bases,
                                                             const uint64_t *__restrict__ off, uint32_t n_reads,
-                                                            uint32_t reads_per_wave,
                                                             const uint4 *__restrict__ filter, uint32_t line_bits,
                                                             uint4 *__restrict__ out,
-                                                            unsigned long long *__restrict__ cursor, uint64_t cap) {
+                                                            unsigned long long *__restrict__ cursor, uint64_t cap,
+                                                            uint32_t ablate) {
   __shared__ uint32_t packed[FW][LWORDS];
-  __shared__ uint4 stage[FW][STAGE];
+  __shared__ uint4 stage[STAGE];
+  __shared__ uint32_t staged;              // slots handed out (may count past STAGE)
+  __shared__ uint32_t stage_valid;         // first slot that was handed out but not written (stage full)
+  __shared__ unsigned long long wg_base;
   const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   uint32_t *my = packed[w];
   uint8_t *my8 = reinterpret_cast<uint8_t *>(my);
-  uint4 *st = stage[w];
-  uint32_t staged = 0;   // wave-uniform
-  const uint32_t r_begin = (blockIdx.x * FW + w) * reads_per_wave;
-  const uint32_t r_end = min(n_reads, r_begin + reads_per_wave);
+  if (threadIdx.x == 0) { staged = 0; stage_valid = STAGE; }
+  __syncthreads();
+  const uint32_t r_begin = (blockIdx.x * FW + w) * RPW;
+  const uint32_t r_cnt = r_begin < n_reads ? min(n_reads - r_begin, RPW) : 0u;
+  const uint64_t my_off = r_cnt ? off[r_begin + min(lane, r_cnt)] : 0ull;   // lanes 0..r_cnt: this wave's read offsets
 
-  auto flush = [&]() {
-    if (staged == 0) return;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the staged records of every lane are visible
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    unsigned long long base = 0;
-    if (lane == 0) base = atomicAdd(cursor, (unsigned long long)staged);
-    base = __shfl(base, 0, 64);
-    if (base + staged <= cap)
-      for (uint32_t i = lane; i < staged; i += 64) out[base + i] = st[i];
-    staged = 0;
+  auto offset_of = [&](uint32_t i) -> uint64_t {   // i is wave-uniform
+    const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)my_off, i);
+    const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(my_off >> 32), i);
+    return ((uint64_t)hi << 32) | lo;
   };
+  // the dwords of one read (up to 3 per lane: 511 bases + 3 of misalignment = 129 dwords)
+  uint32_t nx0 = 0, nx1 = 0, nx2 = 0;
+  auto fetch = [&](uint32_t i) {
+    const uint64_t s0 = offset_of(i);
+    const uint32_t len = (uint32_t)(offset_of(i + 1) - s0);
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(bases + (s0 & ~3ull));
+    const uint32_t ndw = ((uint32_t)(s0 & 3ull) + len + 3) >> 2;
+    if (lane < ndw) nx0 = src[lane];
+    if (lane + 64 < ndw) nx1 = src[lane + 64];
+    if (lane + 128 < ndw) nx2 = src[lane + 128];
+  };
+  if (r_cnt) fetch(0);
 
-  for (uint32_t r = r_begin; r < r_end; r++) {
-    const uint64_t s0 = off[r];
-    const uint32_t len = (uint32_t)(off[r + 1] - s0);
-    if (len < KSLAM_K) continue;           // src/KMer.h:167
-    const uint32_t nk = len - KSLAM_K + 1; // gap 1 (src/KMer.h:378)
-    const uint64_t a_al = s0 & ~3ull;
+  for (uint32_t i = 0; i < r_cnt; i++) {
+    const uint64_t s0 = offset_of(i);
+    const uint32_t len = (uint32_t)(offset_of(i + 1) - s0);
     const uint32_t m = (uint32_t)(s0 & 3ull);
     const uint32_t ndw = (m + len + 3) >> 2;
-    const uint32_t *src = reinterpret_cast<const uint32_t *>(bases + a_al);
     __builtin_amdgcn_wave_barrier();       // the previous read's words are no longer needed
-    for (uint32_t d = lane; d < ndw; d += 64) my8[(d & ~3u) | (3u - (d & 3u))] = (uint8_t)pack4(src[d]);
+    if (lane < ndw) my8[(lane & ~3u) | (3u - (lane & 3u))] = (uint8_t)pack4(nx0);
+    if (lane + 64 < ndw) my8[((lane + 64) & ~3u) | (3u - (lane & 3u))] = (uint8_t)pack4(nx1);
+    if (lane + 128 < ndw) my8[((lane + 128) & ~3u) | (3u - (lane & 3u))] = (uint8_t)pack4(nx2);
+    if (i + 1 < r_cnt) fetch(i + 1);       // in flight while this read is processed
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const uint32_t idbits = r & 0x3FFFFFFFu;
-    for (uint32_t q0 = 0; q0 < nk; q0 += 64) {
-      if (staged + 64 > STAGE) flush();
-      const uint32_t q = q0 + lane;
-      bool keep = false;
-      uint4 rec = make_uint4(0, 0, 0, 0);
-      if (q < nk) {
-        const uint32_t sidx = m + q;
-        const uint32_t wi = sidx >> 4, sh = (sidx & 15u) * 2u;
-        const uint32_t W0 = my[wi], W1 = my[wi + 1], W2 = my[wi + 2];
-        const uint64_t a = ((uint64_t)W0 << 32) | W1, b = ((uint64_t)W1 << 32) | W2;
-        const uint64_t fwd = ((a << sh) & 0xFFFFFFFF00000000ull) | ((b << sh) >> 32);
-        const uint64_t rc = revcomp64(fwd);
-        const bool is_fwd = fwd < rc;       // src/KMer.h:173 (palindromes take the rc branch)
-        const uint64_t kmer = is_fwd ? fwd : rc;
-        if (kmer != 0) {                    // src/Overlap.h:236
-          const Probe p = probe_of(fwd, rc, line_bits);
-          const uint4 f = filter[p.piece];
-          keep = ((f.x >> p.s0) & (f.y >> p.s1) & (f.z >> p.s2) & (f.w >> p.s3) & 1u) != 0;
-        }
-        rec.x = (uint32_t)kmer; rec.y = (uint32_t)(kmer >> 32);
-        rec.z = is_fwd ? idbits : (idbits | (1u << 30));
-        rec.w = is_fwd ? q : (len - KSLAM_K - q);   // src/KMer.h:176
-      }
+    if (len < KSLAM_K) continue;           // src/KMer.h:167
+    const uint32_t nk = len - KSLAM_K + 1; // gap 1 (src/KMer.h:378)
+    const uint32_t idbits = (r_begin + i) & 0x3FFFFFFFu;
+
+    auto cut = [&](uint32_t q) -> Cut {
+      Cut c;
+      c.valid = q < nk;
+      const uint32_t sidx = m + (c.valid ? q : 0u);
+      const uint32_t wi = sidx >> 4, sh = (sidx & 15u) * 2u;
+      const uint32_t W0 = my[wi], W1 = my[wi + 1], W2 = my[wi + 2];
+      const uint64_t a = ((uint64_t)W0 << 32) | W1, b = ((uint64_t)W1 << 32) | W2;
+      c.fwd = ((a << sh) & 0xFFFFFFFF00000000ull) | ((b << sh) >> 32);
+      c.rc = revcomp64(c.fwd);
+      return c;
+    };
+    auto keep_record = [&](const Cut &c, uint32_t q, bool pass) {
+      const bool is_fwd = c.fwd < c.rc;    // src/KMer.h:173 (palindromes take the rc branch)
+      const uint64_t kmer = is_fwd ? c.fwd : c.rc;
+      const bool keep = c.valid && pass && kmer != 0;   // k-mer 0 never joins (src/Overlap.h:236)
       const unsigned long long mask = __ballot(keep);
-      if (keep) st[staged + __popcll(mask & ((1ull << lane) - 1ull))] = rec;
-      staged += (uint32_t)__popcll(mask);
+      if (mask == 0) return;               // (wave-uniform)
+      const uint32_t cnt = (uint32_t)__popcll(mask);
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(&staged, cnt);   // LDS
+      base = __builtin_amdgcn_readfirstlane(base);
+      uint4 rec;
+      rec.x = (uint32_t)kmer; rec.y = (uint32_t)(kmer >> 32);
+      rec.z = is_fwd ? idbits : (idbits | (1u << 30));
+      rec.w = is_fwd ? q : (len - KSLAM_K - q);   // src/KMer.h:176
+      const uint32_t slot = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+      if (base + cnt <= STAGE) {
+        if (keep) stage[slot] = rec;
+      } else {
+        // the workgroup's stage is full (reads with many genome k-mers): this wave's records go out
+        // with an atomic of their own, and so will everything handed out after them
+        if (lane == 0) atomicMin(&stage_valid, base);
+        unsigned long long gb = 0;
+        if (lane == 0) gb = atomicAdd(cursor, (unsigned long long)cnt);
+        gb = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(gb >> 32)) << 32) |
+             __builtin_amdgcn_readfirstlane((uint32_t)gb);
+        if (keep && gb + cnt <= cap) out[gb + (slot - base)] = rec;
+      }
+    };
+    for (uint32_t q0 = 0; q0 < nk; q0 += 128) {
+      const uint32_t qa = q0 + lane, qb = q0 + 64 + lane;
+      const Cut ca = cut(qa), cb = cut(qb);
+      Probe pa, pb;
+      if (ablate & 2u) {   // measurement only: no minimizer (a pseudo-random line per k-mer)
+        pa.piece = (uint32_t)((ca.fwd * 0x9E3779B97F4A7C15ull) >> (64 - line_bits - 3)); pa.s0 = pa.s1 = pa.s2 = pa.s3 = (uint32_t)ca.rc & 31u;
+        pb.piece = (uint32_t)((cb.fwd * 0x9E3779B97F4A7C15ull) >> (64 - line_bits - 3)); pb.s0 = pb.s1 = pb.s2 = pb.s3 = (uint32_t)cb.rc & 31u;
+      } else {
+        pa = probe_of(ca.fwd, ca.rc, line_bits); pb = probe_of(cb.fwd, cb.rc, line_bits);
+      }
+      uint4 fa, fb;
+      if (ablate & 1u) {   // measurement only: no probe load
+        fa = make_uint4(pa.piece, pa.piece >> 3, pa.piece >> 5, 0x11111111u); fb = make_uint4(pb.piece, pb.piece >> 2, pb.piece >> 7, 0x11111111u);
+      } else {
+        fa = filter[pa.piece];
+        fb = filter[pb.piece];   // (a lane beyond the read probes k-mer 0 of it: in bounds, ignored)
+      }
+      keep_record(ca, qa, ((fa.x >> pa.s0) & (fa.y >> pa.s1) & (fa.z >> pa.s2) & (fa.w >> pa.s3) & 1u) != 0);
+      keep_record(cb, qb, ((fb.x >> pb.s0) & (fb.y >> pb.s1) & (fb.z >> pb.s2) & (fb.w >> pb.s3) & 1u) != 0);
     }
   }
-  flush();
+  __syncthreads();
+  const uint32_t n_st = min(staged, stage_valid);
+  if (threadIdx.x == 0) wg_base = n_st ? atomicAdd(cursor, (unsigned long long)n_st) : 0ull;
+  __syncthreads();
+  const unsigned long long gb = wg_base;
+  if (gb + n_st <= cap)
+    for (uint32_t k = threadIdx.x; k < n_st; k += FW * 64) out[gb + k] = stage[k];
 }
 
 }  // namespace
@@ -191,11 +251,11 @@ void extract_filtered(const uint8_t *d_bases, const uint64_t *d_off, uint32_t n_
                       uint32_t log2_bits, uint4 *d_out, uint64_t *d_cursor, uint64_t cap, hipStream_t s) {
   HIPCHK(hipMemsetAsync(d_cursor, 0, sizeof(uint64_t), s));
   if (n_reads == 0) return;
-  const uint32_t rpw = 16;
-  const uint32_t per_block = FW * rpw;
+  const uint32_t per_block = FW * RPW;
   hipLaunchKernelGGL(k_extract_filter, dim3((n_reads + per_block - 1) / per_block), dim3(FW * 64), 0, s, d_bases, d_off,
-                     n_reads, rpw, (const uint4 *)d_filter, log2_bits - 10, d_out,
-                     reinterpret_cast<unsigned long long *>(d_cursor), cap);
+                     n_reads, (const uint4 *)d_filter, log2_bits - 10, d_out,
+                     reinterpret_cast<unsigned long long *>(d_cursor), cap,
+                     (uint32_t)(getenv("KSLAM_FILTER_ABLATE") ? atoi(getenv("KSLAM_FILTER_ABLATE")) : 0));
   HIPCHK(hipGetLastError());
 }
 

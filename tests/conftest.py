@@ -29,6 +29,15 @@ def load_kslam():
 
 @pytest.fixture(scope="session")
 def kslam():
+    # torch carries its own copy of the HIP runtime; the product library uses the system one.  When the
+    # library's copy opens the GPU first, torch's then reports no device (seen on the MI355X boxes), so
+    # tests that generate inputs with torch on the GPU (tests/test_gpu_scale.py) let torch go first.
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass
     return load_kslam()
 
 

@@ -26,10 +26,9 @@ SPECIES, STRAINS, GENOME_LEN, PAIRS = 250, 5, 4_000_000, 1_000_000
 @pytest.fixture(scope="module")
 def big(kslam):
     import torch
-    if not torch.cuda.is_available():
-        pytest.skip("needs a HIP device")
-    if torch.cuda.get_device_properties(0).total_memory < 100e9:
-        pytest.skip("needs the 5 Gb database resident (MI355X: 288 GB)")
+    # no skip on a GPU box: if torch cannot see the device this must fail, not pass silently
+    assert torch.cuda.is_available(), "torch sees no HIP device (did another HIP runtime open it first?)"
+    assert torch.cuda.get_device_properties(0).total_memory > 100e9, "needs the 5 Gb database resident (MI355X: 288 GB)"
     W = importlib.import_module("kslam_amd.workload")
     dev = torch.device("cuda", 0)
     gen = torch.Generator(device=dev)

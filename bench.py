@@ -254,6 +254,12 @@ def main():
     ap.add_argument("--no-sam-pipeline", action="store_true", help="skip the GPU + host-tail pipeline leg")
     ap.add_argument("--no-full-pipeline", action="store_true", help="skip the FASTQ text -> SAM text leg")
     ap.add_argument("--read-len", type=int, default=READ_LEN, help="150 (BASELINE configs[1..3]) or 250 (configs[4])")
+    ap.add_argument("--strong", action="store_true",
+                    help="BASELINE configs[3] shape: ONE batch of --total-pairs pairs per step, split over the GPUs, "
+                         "timed until rank 0 holds the merged result (default when --gpus > 1)")
+    ap.add_argument("--weak", action="store_true", help="with --gpus > 1: --pairs fresh pairs per GPU instead")
+    ap.add_argument("--total-pairs", type=int, default=10_000_000,
+                    help="pairs per batch in --strong mode (the reference's --num-reads-at-once default, src/main.cpp:56)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -275,14 +281,35 @@ def main():
 
     K = entry.load_package()
     kdist = importlib.import_module("kslam_amd.dist")
+    strong = args.strong or (world > 1 and not args.weak)
+    PIECES = 8          # the strong batch is generated in 8 fixed pieces, so it is the same batch for N = 1, 2, 4, 8
+    if strong and (8 % world or args.total_pairs % PIECES):
+        raise SystemExit("--strong needs 1, 2, 4 or 8 ranks and --total-pairs divisible by 8")
 
     # ---- synthetic inputs, generated straight into HBM (data: synthetic) ----
     gen = torch.Generator(device=dev)
     gen.manual_seed(1)                      # database: same on every rank (replicated index)
     t0 = time.time()
     db, offs = make_database(dev, gen, args.species, args.strains, args.genome_len)
-    gen.manual_seed(2 + 1000 * rank)        # reads: a different shard of pairs per rank
-    reads, truth = make_reads(dev, gen, db, offs, args.pairs, read_len=args.read_len, with_truth=True)
+    if strong:
+        # this rank's pairs [pair_lo, pair_hi) of the one batch, local layout [R1 of them | R2 of them]
+        piece = args.total_pairs // PIECES
+        mine = range(rank * PIECES // world, (rank + 1) * PIECES // world)
+        pair_lo, pair_hi = mine[0] * piece, (mine[-1] + 1) * piece
+        r1s, r2s, tr = [], [], []
+        for pc in mine:
+            gen.manual_seed(2 + 1000 * pc)
+            r, t = make_reads(dev, gen, db, offs, piece, read_len=args.read_len, with_truth=True)
+            r1s.append(r[:piece]); r2s.append(r[piece:]); tr.append(t)
+        reads = torch.cat(r1s + r2s, 0).contiguous()
+        truth = {k: torch.cat([t[k][:piece] for t in tr] + [t[k][piece:] for t in tr]) for k in tr[0]}
+        del r1s, r2s, tr
+        n_batch_pairs = args.total_pairs
+    else:
+        gen.manual_seed(2 + 1000 * rank)        # reads: a different shard of pairs per rank
+        reads, truth = make_reads(dev, gen, db, offs, args.pairs, read_len=args.read_len, with_truth=True)
+        pair_lo, pair_hi = rank * args.pairs, (rank + 1) * args.pairs
+        n_batch_pairs = args.pairs * world
     torch.cuda.synchronize()
     t_gen = time.time() - t0
 
@@ -295,10 +322,23 @@ def main():
     ctx.load_reads_device(n_reads, reads.data_ptr(), roffs)
 
     pending = []   # the gather of the previous batch, still in flight while this one is aligned
+    merged = {}    # rank 0, --strong: the batch-global result of the last finished batch (device tensors)
 
     def drain():
         while pending:
-            kdist.finish_gather(pending.pop())
+            got = kdist.finish_gather(pending.pop())
+            if strong and rank == 0:
+                # rank 0 re-bases read ids and CIGAR offsets and restores the reference's order ON THE
+                # DEVICE (kslam_merge_shards_device); the batch is done when this result exists
+                rows_all, pool_all, sz = got
+                piece = args.total_pairs // PIECES
+                shards = [(r * PIECES // world * piece, (r + 1) * PIECES // world * piece, a // 48, b // 4)
+                          for r, (a, b) in enumerate(sz)]
+                out_ov = torch.empty_like(rows_all)
+                out_cg = torch.empty_like(pool_all)
+                ctx.merge_shards_device(shards, args.total_pairs, rows_all.data_ptr(), pool_all.data_ptr(),
+                                        out_ov.data_ptr(), out_cg.data_ptr())
+                merged["ov"], merged["cg"] = out_ov, out_cg
 
     def step():
         n_out, n_cig = ctx.align_resident()
@@ -310,7 +350,7 @@ def main():
             cg = torch.empty(n_cig * 4, dtype=torch.uint8, device=dev)
             ctx.copy_results_device(ov.data_ptr(), cg.data_ptr())
             drain()
-            pending.append(kdist.start_gather(ov, cg))
+            pending.append((kdist.start_gather_concat if strong else kdist.start_gather)(ov, cg))
         return n_out, n_cig
 
     def barrier():
@@ -350,6 +390,19 @@ def main():
     verified["run_to_run_identical"] = bool(ov_a.numel() == ov_b.numel() and torch.equal(ov_a, ov_b)
                                             and torch.equal(cg_a, cg_b))
     verified["ok"] = bool(verified["ok"] and verified["run_to_run_identical"])
+    if strong and use_dist and rank == 0 and "ov" in merged:
+        # the merged batch: row count, order, and -- when this rank aligned the whole batch itself (one
+        # rank) -- byte identity with the single-context result
+        mc = W.overlap_columns(merged["ov"])
+        mkey = (mc["read"] << 40) | (mc["entry"] << 26) | (mc["rel"] + 1024)
+        verified["merged_rows"] = int(mkey.numel())
+        verified["merged_unsorted_neighbours"] = int((mkey[1:] < mkey[:-1]).sum()) if mkey.numel() > 1 else 0
+        if world == 1:
+            verified["merged_equals_single_context"] = bool(
+                merged["ov"].numel() == ov_a.numel() and torch.equal(merged["ov"], ov_a) and
+                torch.equal(merged["cg"].view(torch.int32), cg_a))
+            verified["ok"] = bool(verified["ok"] and verified["merged_equals_single_context"])
+        verified["ok"] = bool(verified["ok"] and verified["merged_unsorted_neighbours"] == 0)
     del ov_a, cg_a, ov_b, cg_b
     if use_dist:   # every rank checked its own shard: sum the counts, AND the verdicts
         keys = [k for k, v in verified.items() if not isinstance(v, bool)]
@@ -375,7 +428,7 @@ def main():
     if rank == 0:
         S = args.steps
         tm = {k: v / S for k, v in acc.items()}
-        total_reads = n_reads * world * S
+        total_reads = 2 * n_batch_pairs * S
         n_kmers = tm["n_read_kmers"]
         passes = int(round(tm["sort_passes"]))
         launches = max(tm["n_scatter_launches"], 1)
@@ -397,16 +450,19 @@ def main():
             "unit": "reads/s",
             "n_gpus": world, "steps": S, "warmup": args.warmup,
             "ms_per_step": round(elapsed / S * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "u64 k-mers / i32 DP", "data": "synthetic",
             "config": {
-                "workload": "BASELINE configs[%d]: %d x 2 x %d bp reads per GPU vs %d-genome "
+                "workload": ("BASELINE configs[3]: ONE batch of %d x 2 x %d bp reads per step, read pairs split over %d GPU(s), "
+                             "timed until rank 0 holds the merged result, vs %d-genome " % (
+                                 args.total_pairs, args.read_len, world, len(offs) - 1) if strong else
+                             "BASELINE configs[%d]: %d x 2 x %d bp reads per GPU vs %d-genome " % (
+                                 4 if args.read_len > 150 else 1, args.pairs, args.read_len, len(offs) - 1)) +
                             "(%d species x %d strains x %.1f Mb = %.2f Gb) synthetic bacterial db, "
                             "hot path alignToDatabase incl. CIGAR, inputs resident in HBM" % (
-                                4 if args.read_len > 150 else 1, args.pairs, args.read_len, len(offs) - 1,
-                                args.species, args.strains,
-                                args.genome_len / 1e6, float(offs[-1]) / 1e9),
-                "pairs_per_gpu": args.pairs, "db_bases": int(offs[-1]),
+                                args.species, args.strains, args.genome_len / 1e6, float(offs[-1]) / 1e9),
+                "pairs_per_batch": n_batch_pairs,
+                "pairs_per_gpu": n_reads // 2, "db_bases": int(offs[-1]),
                 "parallelism": "read pairs sharded x%d, genome k-mer list replicated, gather to rank 0" % world,
             },
             "roofline": {
@@ -434,12 +490,12 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(K, db, offs, 77, args.cpu_genomes, args.cpu_pairs, args.read_len, local_rank)
-        if world == 1 and not args.no_sam_pipeline and not args.no_cigar:
+        if world == 1 and not strong and not args.no_sam_pipeline and not args.no_cigar:
             try:
                 out["sam_pipeline"] = sam_pipeline(K, ctx, reads, db, offs, args.read_len, max(args.steps, 3))
             except Exception as e:   # extra evidence only: never lose the bench line over it
                 out["sam_pipeline"] = {"error": repr(e)}
-        if world == 1 and not args.no_full_pipeline and not args.no_cigar:
+        if world == 1 and not strong and not args.no_full_pipeline and not args.no_cigar:
             try:
                 out["full_pipeline"] = full_pipeline(K, ctx, reads, db, offs, args.read_len, max(args.steps, 3))
             except Exception as e:

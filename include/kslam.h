@@ -173,6 +173,51 @@ kslam_status kslam_copy_results_device(kslam_ctx *ctx, void *d_overlaps,
                                        void *d_cigar_pool);
 kslam_status kslam_get_timings(const kslam_ctx *ctx, kslam_timings *out);
 
+/* ---- read-sharded batches: several GPUs of one node ----
+ * The batch loop of the reference (src/SLAM.h:194-209) hands alignToDatabase
+ * readsPerGo pairs at a time; the pairs of one batch are independent, so shard
+ * g of N aligns pairs [g n / N, (g + 1) n / N) against its own replica of the
+ * index and the only exchange is one gather of the result records.  Local
+ * batches keep the block layout: [R1 of the shard's pairs | R2 of them].
+ *
+ * kslam_merge_shards_device is the collecting side: the shards' records and
+ * CIGAR pools, gathered back to back into device memory of ctx's GPU by
+ * whatever moved them (hipMemcpyPeerAsync in kslam_multi_*, RCCL send/recv
+ * in a one-process-per-GPU host), become the batch-global result in the
+ * reference's order -- byte for byte what one context returns for the whole
+ * batch.  d_out_overlaps must hold sum(n_rows) records, d_out_cigars
+ * sum(n_cigar) words; unpaired batches pass n_pairs = number of reads. */
+typedef struct {
+  uint64_t pair_lo, pair_hi; /* the batch's pairs [lo, hi) this shard aligned */
+  uint64_t n_rows;           /* overlap records it produced */
+  uint64_t n_cigar;          /* words of its CIGAR pool */
+} kslam_shard;
+kslam_status kslam_merge_shards_device(kslam_ctx *ctx, uint32_t n_shards,
+                                       const kslam_shard *shards,
+                                       uint64_t n_pairs, const void *d_overlaps,
+                                       const void *d_cigar_pools,
+                                       void *d_out_overlaps, void *d_out_cigars);
+
+/* One process driving several devices: one context per entry of `devices`
+ * (params->device is ignored; an ordinal may repeat, which puts two shards on
+ * one GPU), the index replicated, kslam_multi_align_batch = shard, align on
+ * every device concurrently, gather to devices[0] over the peer links,
+ * merge there, one copy to the host.  Same result and same ownership rules
+ * as kslam_align_batch.  paired != 0: n_reads is even and reads[i], reads[i +
+ * n_reads / 2] are mates (they stay on one shard). */
+typedef struct kslam_multi kslam_multi;
+kslam_status kslam_multi_create(const kslam_params *params, const int32_t *devices,
+                                uint32_t n_devices, kslam_multi **out);
+void kslam_multi_destroy(kslam_multi *m);
+const char *kslam_multi_last_error(const kslam_multi *m);
+kslam_status kslam_multi_set_index(kslam_multi *m, uint64_t n_entries,
+                                   const char *const *bases, const uint64_t *lens);
+kslam_status kslam_multi_align_batch(kslam_multi *m, uint64_t n_reads,
+                                     const char *const *bases, const uint32_t *lens,
+                                     int paired, kslam_overlap **out, uint64_t *n_out,
+                                     uint32_t **cigar_pool, uint64_t *n_cigar);
+void kslam_multi_free_batch(kslam_multi *m, kslam_overlap *out, uint32_t *cigar_pool);
+
 /* ---- stage-level entry points (parity tests of SURVEY section 8a rows) - */
 /* getKMers_parallel, src/KMer.h:190-241 */
 kslam_status kslam_extract_kmers(kslam_ctx *ctx, uint64_t n,

@@ -37,7 +37,8 @@ EXPORTS = ["kslam_abi_version", "kslam_create", "kslam_destroy", "kslam_last_err
            "kslam_load_reads", "kslam_load_reads_device", "kslam_align_resident",
            "kslam_fetch_results", "kslam_take_results", "kslam_copy_results_device", "kslam_get_timings",
            "kslam_extract_kmers", "kslam_sort_kmers", "kslam_find_overlaps", "kslam_free",
-           "kslam_selftest_sort"]
+           "kslam_selftest_sort", "kslam_merge_shards_device", "kslam_multi_create", "kslam_multi_destroy",
+           "kslam_multi_last_error", "kslam_multi_set_index", "kslam_multi_align_batch", "kslam_multi_free_batch"]
 
 
 class Params(C.Structure):
@@ -110,6 +111,15 @@ def lib():
         L.kslam_free.argtypes = [vp]
         L.kslam_selftest_sort.argtypes = [vp, u64, u32, C.POINTER(C.c_float), C.POINTER(C.c_float),
                                           C.POINTER(u64)]
+        L.kslam_merge_shards_device.argtypes = [vp, u32, vp, u64, vp, vp, vp, vp]
+        L.kslam_multi_create.argtypes = [C.POINTER(Params), vp, u32, C.POINTER(vp)]
+        L.kslam_multi_destroy.argtypes = [vp]
+        L.kslam_multi_last_error.restype = C.c_char_p
+        L.kslam_multi_last_error.argtypes = [vp]
+        L.kslam_multi_set_index.argtypes = [vp, u64, vp, vp]
+        L.kslam_multi_align_batch.argtypes = [vp, u64, vp, vp, C.c_int, C.POINTER(vp), C.POINTER(u64),
+                                              C.POINTER(vp), C.POINTER(u64)]
+        L.kslam_multi_free_batch.argtypes = [vp, vp, vp]
         _lib = L
     return _lib
 
@@ -231,6 +241,13 @@ class Context:
     def copy_results_device(self, d_overlaps, d_cigars):
         self._chk(self._L.kslam_copy_results_device(self._h, d_overlaps, d_cigars))
 
+    def merge_shards_device(self, shards, n_pairs, d_overlaps, d_cigars, d_out_overlaps, d_out_cigars):
+        """kslam_merge_shards_device: shards = [(pair_lo, pair_hi, n_rows, n_cigar), ...] in batch order;
+        the four pointers are device addresses on this context's GPU."""
+        sh = np.array([tuple(int(v) for v in x) for x in shards], dtype=SHARD_DT)
+        self._chk(self._L.kslam_merge_shards_device(self._h, len(sh), sh.ctypes.data, n_pairs, d_overlaps, d_cigars,
+                                                    d_out_overlaps, d_out_cigars))
+
     def timings(self):
         t = Timings()
         self._chk(self._L.kslam_get_timings(self._h, C.byref(t)))
@@ -269,6 +286,65 @@ class Context:
                            dtype=OVERLAP_TEMP_DT).copy() if m else np.zeros(0, dtype=OVERLAP_TEMP_DT)
         self._L.kslam_free(out)
         return ov, int(raw.value)
+
+
+SHARD_DT = np.dtype([("pair_lo", "<u8"), ("pair_hi", "<u8"), ("n_rows", "<u8"), ("n_cigar", "<u8")])
+
+
+class MultiContext:
+    """kslam_multi: one process, one context per entry of `devices` (an ordinal may repeat), read
+    pairs sharded, results gathered to devices[0] and merged there (include/kslam.h)."""
+
+    def __init__(self, devices, match=2, mismatch=3, gap_open=5, gap_extend=2, score_threshold=0,
+                 report_cigar=True, max_kmers_per_chunk=0):
+        self._L = lib()
+        self._h = C.c_void_p()
+        p = Params(match, mismatch, gap_open, gap_extend, score_threshold, 1 if report_cigar else 0, 0,
+                   max_kmers_per_chunk)
+        dv = np.ascontiguousarray(devices, dtype=np.int32)
+        st = self._L.kslam_multi_create(C.byref(p), dv.ctypes.data, len(dv), C.byref(self._h))
+        if st != 0:
+            msg = self._L.kslam_multi_last_error(self._h).decode() if self._h else "create failed"
+            if self._h:
+                self._L.kslam_multi_destroy(self._h)
+                self._h = C.c_void_p()
+            raise KslamError(st, msg)
+
+    def close(self):
+        if self._h:
+            self._L.kslam_multi_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, st):
+        if st != 0:
+            raise KslamError(st, self._L.kslam_multi_last_error(self._h).decode())
+
+    def set_index(self, entries):
+        ptrs, keep = _seq_arrays(entries)
+        lens = np.array([len(s) for s in entries], dtype=np.uint64)
+        self._chk(self._L.kslam_multi_set_index(self._h, len(entries), C.cast(ptrs, C.c_void_p), lens.ctypes.data))
+
+    def align_batch(self, reads, paired=True):
+        ptrs, keep = _seq_arrays(reads)
+        lens = np.array([len(s) for s in reads], dtype=np.uint32)
+        out, cig = C.c_void_p(), C.c_void_p()
+        n_out, n_cig = C.c_uint64(), C.c_uint64()
+        self._chk(self._L.kslam_multi_align_batch(self._h, len(reads), C.cast(ptrs, C.c_void_p), lens.ctypes.data,
+                                                  1 if paired else 0, C.byref(out), C.byref(n_out),
+                                                  C.byref(cig), C.byref(n_cig)))
+        n, nc = int(n_out.value), int(n_cig.value)
+        ov = np.frombuffer((C.c_char * (n * 48)).from_address(out.value), dtype=OVERLAP_DT).copy() \
+            if n else np.zeros(0, dtype=OVERLAP_DT)
+        cg = np.frombuffer((C.c_char * (nc * 4)).from_address(cig.value), dtype=np.uint32).copy() \
+            if nc else np.zeros(0, dtype=np.uint32)
+        self._L.kslam_multi_free_batch(self._h, out, cig)
+        return ov, cg
 
 
 def align_to_database(reads, entries, **params):

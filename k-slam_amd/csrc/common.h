@@ -184,6 +184,20 @@ void dedupe_compact(const uint64_t *d_keys, const uint32_t *d_flags, const uint3
                     uint64_t n, OverlapKeyLayout lay, uint32_t read_id_base, kslam_overlap *d_out,
                     hipStream_t s);
 
+// --------------------------------------------------------------- merge.hip
+constexpr uint32_t MERGE_MAX_SHARDS = 256;
+struct MergeShard {            // one read shard of a batch, as the collecting device sees it
+  uint64_t pair_lo, pair_hi;   // the batch's pairs [lo, hi) this shard aligned (local ids: R1 block | R2 block)
+  uint64_t row_base, n_rows;   // its rows inside the gathered row array
+  uint64_t pool_base;          // its CIGAR pool inside the gathered pools
+  uint64_t n_r1, out_r1, out_r2;   // filled on the device: rows of its R1 block, output positions of its two blocks
+};
+// d_shards: n_shards entries with the host-known fields set.  d_out / d_pool_out receive the batch-global
+// result in the reference's order with the pool in row order; *d_total ends as the number of CIGAR ops.
+void merge_shards(const kslam_overlap *d_rows, uint64_t n_rows, const uint32_t *d_pool_in, MergeShard *d_shards,
+                  uint32_t n_shards, uint64_t n_pairs, kslam_overlap *d_out, uint32_t *d_pool_out, uint32_t *d_lens,
+                  uint64_t *d_new_off, uint64_t *d_total, void *d_scan_tmp, hipStream_t s);
+
 // ------------------------------------------------------------------ sw.hip
 struct SwParams {
   int32_t match, mismatch, gap_open, gap_extend;

@@ -59,10 +59,19 @@ struct kslam_ctx {
   std::vector<Pinned> pinned;
   std::mutex pin_mu;
 
+  // ---- merge of gathered shard results (merge.hip) ----
+  DevBuf mg_shards, mg_lens, mg_off, mg_scan;
+
   // ---- results of the last align ----
   DevBuf res_ov, res_cig, res_tmp;
   uint64_t n_res = 0, n_cig = 0;
   kslam_timings tm{};
+};
+
+struct kslam_multi {
+  std::vector<kslam_ctx *> ctx;
+  std::string err;
+  DevBuf rows_in, pool_in, rows_out, pool_out;   // on ctx[0]'s device
 };
 
 namespace {
@@ -577,6 +586,24 @@ void validate_params(const kslam_params &p) {
   if (p.score_threshold > 65535) throw StatusError{KSLAM_ERR_UNSUPPORTED, "score_threshold must fit uint16_t (ssw_cpp.h Filter)"};
 }
 
+kslam_status multi_fail(kslam_multi *m, kslam_status st, const std::string &msg) {
+  m->err = msg;
+  return st;
+}
+
+// run f(k) for every shard on its own host thread (every entry point of a context blocks on its stream)
+template <typename F> kslam_status multi_for_each(kslam_multi *m, F &&f) {
+  const size_t n = m->ctx.size();
+  std::vector<kslam_status> st(n, KSLAM_OK);
+  std::vector<std::thread> th;
+  for (size_t k = 1; k < n; k++) th.emplace_back([&, k] { st[k] = f(k); });
+  st[0] = f(0);
+  for (auto &t : th) t.join();
+  for (size_t k = 0; k < n; k++)
+    if (st[k] != KSLAM_OK) return multi_fail(m, st[k], "shard " + std::to_string(k) + ": " + kslam_last_error(m->ctx[k]));
+  return KSLAM_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -623,7 +650,7 @@ void kslam_destroy(kslam_ctx *c) {
                       &c->flags, &c->pos, &c->band0, &c->sortws.hist, &c->sortws.status, &c->sortws.tickets,
                       &c->cig.flags, &c->cig.pos, &c->cig.list, &c->cig.bmax, &c->cig.needbig,
                       &c->cig.scan_tmp, &c->cig.totals, &c->cig.cig_off, &c->cig.tmp, &c->cig.tmp_big,
-                      &c->cig.big_pos, &c->cig.scratch, &c->sww.flags, &c->sww.pos, &c->sww.list, &c->sww.list2, &c->sww.scan_tmp, &c->sww.totals, &c->cells, &c->res_ov, &c->res_cig, &c->res_tmp};
+                      &c->cig.big_pos, &c->cig.scratch, &c->sww.flags, &c->sww.pos, &c->sww.list, &c->sww.list2, &c->sww.scan_tmp, &c->sww.totals, &c->cells, &c->res_ov, &c->res_cig, &c->res_tmp, &c->mg_shards, &c->mg_lens, &c->mg_off, &c->mg_scan};
     for (DevBuf *b : bufs) b->release();
     {
       std::lock_guard<std::mutex> lk(c->pin_mu);
@@ -803,6 +830,167 @@ void kslam_free_batch(kslam_ctx *c, kslam_overlap *out, uint32_t *cigar_pool) {
   if (cigar_pool && !pinned_put(c, cigar_pool)) free(cigar_pool);
 }
 void kslam_free(void *p) { free(p); }
+
+kslam_status kslam_merge_shards_device(kslam_ctx *c, uint32_t n_shards, const kslam_shard *shards, uint64_t n_pairs,
+                                       const void *d_overlaps, const void *d_cigar_pools, void *d_out_overlaps,
+                                       void *d_out_cigars) {
+  return guarded(c, [&] {
+    if (!shards || n_shards == 0 || n_shards > MERGE_MAX_SHARDS) throw StatusError{KSLAM_ERR_ARG, "1..256 shards"};
+    std::vector<MergeShard> h(n_shards);
+    uint64_t rows = 0, ops = 0;
+    for (uint32_t k = 0; k < n_shards; k++) {
+      const kslam_shard &sh = shards[k];
+      if (sh.pair_hi < sh.pair_lo || sh.pair_hi > n_pairs || sh.pair_hi - sh.pair_lo >= (1ull << 31))
+        throw StatusError{KSLAM_ERR_ARG, "shard " + std::to_string(k) + ": bad pair range"};
+      if (k && sh.pair_lo < shards[k - 1].pair_hi) throw StatusError{KSLAM_ERR_ARG, "shards must be in batch order"};
+      memset(&h[k], 0, sizeof(MergeShard));
+      h[k].pair_lo = sh.pair_lo; h[k].pair_hi = sh.pair_hi;
+      h[k].row_base = rows; h[k].n_rows = sh.n_rows; h[k].pool_base = ops;
+      rows += sh.n_rows; ops += sh.n_cigar;
+    }
+    if (n_pairs >= (1ull << 31)) throw StatusError{KSLAM_ERR_UNSUPPORTED, "more than 2^31 pairs in one batch"};
+    if (rows && (!d_overlaps || !d_out_overlaps)) throw StatusError{KSLAM_ERR_ARG, "null overlap buffers"};
+    if (ops && (!d_cigar_pools || !d_out_cigars)) throw StatusError{KSLAM_ERR_ARG, "null cigar buffers"};
+    hipStream_t s = c->stream;
+    c->mg_shards.ensure(n_shards * sizeof(MergeShard));
+    c->mg_lens.ensure((rows + 1) * sizeof(uint32_t));
+    c->mg_off.ensure((rows + 1) * sizeof(uint64_t));
+    c->mg_scan.ensure(scan_tmp_bytes(std::max<uint64_t>(rows, 1)));
+    c->totals.ensure(8 * sizeof(uint64_t));
+    HIPCHK(hipMemcpyAsync(c->mg_shards.p, h.data(), n_shards * sizeof(MergeShard), hipMemcpyHostToDevice, s));
+    merge_shards((const kslam_overlap *)d_overlaps, rows, (const uint32_t *)d_cigar_pools, c->mg_shards.as<MergeShard>(),
+                 n_shards, n_pairs, (kslam_overlap *)d_out_overlaps, (uint32_t *)d_out_cigars, c->mg_lens.as<uint32_t>(),
+                 c->mg_off.as<uint64_t>(), c->totals.as<uint64_t>() + 4, c->mg_scan.p, s);
+    HIPCHK(hipStreamSynchronize(s));   // h[] is read by the copy above
+  });
+}
+
+// ---- one process, several devices ---------------------------------------------------------------
+kslam_status kslam_multi_create(const kslam_params *params, const int32_t *devices, uint32_t n_devices, kslam_multi **out) {
+  if (!params || !devices || !out || n_devices == 0 || n_devices > MERGE_MAX_SHARDS) return KSLAM_ERR_ARG;
+  kslam_multi *m = new (std::nothrow) kslam_multi();
+  if (!m) return KSLAM_ERR_OOM;
+  *out = m;
+  for (uint32_t k = 0; k < n_devices; k++) {
+    kslam_params p = *params;
+    p.device = devices[k];
+    kslam_ctx *c = nullptr;
+    const kslam_status st = kslam_create(&p, &c);
+    if (st != KSLAM_OK) {
+      m->err = "device " + std::to_string(devices[k]) + ": " + (c ? kslam_last_error(c) : "create failed");
+      kslam_destroy(c);
+      return st;   // the caller reads the message and destroys m
+    }
+    m->ctx.push_back(c);
+  }
+  // peer access from the collecting device to the others (hipMemcpyPeerAsync works without it, through
+  // the host; with it the copy goes over xGMI)
+  for (uint32_t k = 1; k < n_devices; k++) {
+    if (devices[k] == devices[0]) continue;
+    int can = 0;
+    if (hipDeviceCanAccessPeer(&can, devices[0], devices[k]) == hipSuccess && can) {
+      (void)hipSetDevice(devices[0]);
+      (void)hipDeviceEnablePeerAccess(devices[k], 0);
+      (void)hipGetLastError();   // "already enabled" is fine
+    }
+  }
+  return KSLAM_OK;
+}
+
+void kslam_multi_destroy(kslam_multi *m) {
+  if (!m) return;
+  if (!m->ctx.empty() && m->ctx[0]->device >= 0) {
+    (void)hipSetDevice(m->ctx[0]->device);
+    m->rows_in.release(); m->pool_in.release(); m->rows_out.release(); m->pool_out.release();
+  }
+  for (kslam_ctx *c : m->ctx) kslam_destroy(c);
+  delete m;
+}
+
+const char *kslam_multi_last_error(const kslam_multi *m) { return m ? m->err.c_str() : "null handle"; }
+
+kslam_status kslam_multi_set_index(kslam_multi *m, uint64_t n_entries, const char *const *bases, const uint64_t *lens) {
+  if (!m || m->ctx.empty()) return KSLAM_ERR_ARG;
+  return multi_for_each(m, [&](size_t k) { return kslam_set_index(m->ctx[k], n_entries, bases, lens); });
+}
+
+kslam_status kslam_multi_align_batch(kslam_multi *m, uint64_t n_reads, const char *const *bases, const uint32_t *lens,
+                                     int paired, kslam_overlap **out, uint64_t *n_out, uint32_t **cigar_pool,
+                                     uint64_t *n_cigar) {
+  if (!m || m->ctx.empty() || !out || !n_out || !cigar_pool || !n_cigar) return KSLAM_ERR_ARG;
+  *out = nullptr; *cigar_pool = nullptr; *n_out = 0; *n_cigar = 0;
+  if (n_reads && (!bases || !lens)) return multi_fail(m, KSLAM_ERR_ARG, "null bases/lens");
+  if (paired && (n_reads & 1)) return multi_fail(m, KSLAM_ERR_ARG, "a paired batch has an even number of reads");
+  const uint64_t n_units = paired ? n_reads / 2 : n_reads;   // what is sharded: pairs, or single reads
+  const size_t N = m->ctx.size();
+  std::vector<kslam_shard> sh(N);
+  // ---- shard + align, every device at once ----
+  kslam_status st = multi_for_each(m, [&](size_t k) -> kslam_status {
+    const uint64_t lo = n_units * k / N, hi = n_units * (k + 1) / N, nl = hi - lo;
+    kslam_ctx *c = m->ctx[k];
+    std::vector<uint64_t> off((paired ? 2 : 1) * nl + 1, 0);
+    for (uint64_t i = 0; i < nl; i++) off[i + 1] = off[i] + lens[lo + i];
+    if (paired) for (uint64_t i = 0; i < nl; i++) off[nl + i + 1] = off[nl + i] + lens[n_units + lo + i];
+    const uint64_t n_loc = off.size() - 1;
+    char *cat = nullptr;
+    kslam_status s1 = guarded(c, [&] {
+      cat = (char *)pinned_get(c, off[n_loc] + 64);
+      for (uint64_t i = 0; i < nl; i++) memcpy(cat + off[i], bases[lo + i], lens[lo + i]);
+      if (paired) for (uint64_t i = 0; i < nl; i++) memcpy(cat + off[nl + i], bases[n_units + lo + i], lens[n_units + lo + i]);
+    });
+    if (s1 == KSLAM_OK) s1 = kslam_load_reads(c, n_loc, cat, off.data());
+    if (cat) pinned_put(c, cat);
+    if (s1 == KSLAM_OK) s1 = kslam_align_resident(c, &sh[k].n_rows, &sh[k].n_cigar);
+    sh[k].pair_lo = lo; sh[k].pair_hi = hi;
+    return s1;
+  });
+  if (st != KSLAM_OK) return st;
+  // ---- the one exchange of the path: every shard's records to the collecting device ----
+  kslam_ctx *c0 = m->ctx[0];
+  uint64_t rows = 0, ops = 0;
+  for (size_t k = 0; k < N; k++) { rows += sh[k].n_rows; ops += sh[k].n_cigar; }
+  kslam_overlap *ho = nullptr;
+  uint32_t *hc = nullptr;
+  st = guarded(c0, [&] {
+    m->rows_in.ensure((rows + 1) * sizeof(kslam_overlap));
+    m->pool_in.ensure((ops + 1) * sizeof(uint32_t));
+    m->rows_out.ensure((rows + 1) * sizeof(kslam_overlap));
+    m->pool_out.ensure((ops + 1) * sizeof(uint32_t));
+    uint64_t r = 0, o = 0;
+    for (size_t k = 0; k < N; k++) {
+      kslam_ctx *ck = m->ctx[k];
+      if (sh[k].n_rows)
+        HIPCHK(hipMemcpyPeerAsync(m->rows_in.as<kslam_overlap>() + r, c0->device, ck->res_ov.p, ck->device,
+                                  sh[k].n_rows * sizeof(kslam_overlap), c0->stream));
+      if (sh[k].n_cigar)
+        HIPCHK(hipMemcpyPeerAsync(m->pool_in.as<uint32_t>() + o, c0->device, ck->res_cig.p, ck->device,
+                                  sh[k].n_cigar * sizeof(uint32_t), c0->stream));
+      r += sh[k].n_rows; o += sh[k].n_cigar;
+    }
+  });
+  if (st != KSLAM_OK) return multi_fail(m, st, kslam_last_error(c0));
+  st = kslam_merge_shards_device(c0, (uint32_t)N, sh.data(), n_units, m->rows_in.p, m->pool_in.p, m->rows_out.p, m->pool_out.p);
+  if (st != KSLAM_OK) return multi_fail(m, st, kslam_last_error(c0));
+  st = guarded(c0, [&] {
+    ho = (kslam_overlap *)pinned_get(c0, (rows + 1) * sizeof(kslam_overlap));
+    hc = (uint32_t *)pinned_get(c0, (ops + 1) * sizeof(uint32_t));
+    if (rows) HIPCHK(hipMemcpyAsync(ho, m->rows_out.p, rows * sizeof(kslam_overlap), hipMemcpyDeviceToHost, c0->stream));
+    if (ops) HIPCHK(hipMemcpyAsync(hc, m->pool_out.p, ops * sizeof(uint32_t), hipMemcpyDeviceToHost, c0->stream));
+    HIPCHK(hipStreamSynchronize(c0->stream));
+  });
+  if (st != KSLAM_OK) {
+    if (ho) pinned_put(c0, ho);
+    if (hc) pinned_put(c0, hc);
+    return multi_fail(m, st, kslam_last_error(c0));
+  }
+  *out = ho; *n_out = rows; *cigar_pool = hc; *n_cigar = ops;
+  return KSLAM_OK;
+}
+
+void kslam_multi_free_batch(kslam_multi *m, kslam_overlap *out, uint32_t *cigar_pool) {
+  if (m && !m->ctx.empty()) kslam_free_batch(m->ctx[0], out, cigar_pool);
+}
+
 
 kslam_status kslam_extract_kmers(kslam_ctx *c, uint64_t n, const char *const *bases, const uint64_t *lens,
                                  int is_from_genbank, uint32_t gap, kslam_kmer *out, uint64_t cap, uint64_t *n_out) {

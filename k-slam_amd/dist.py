@@ -61,6 +61,42 @@ def start_gather(ov_bytes, cig_bytes, group=None):
     return {"reqs": reqs, "parts": parts, "keep": (ov_bytes, cig_bytes)}
 
 
+def start_gather_concat(ov_bytes, cig_bytes, group=None):
+    """As start_gather, but rank 0 receives every rank's records straight into ONE row tensor and ONE
+    pool tensor, shard after shard -- the layout kslam_merge_shards_device takes.  finish_gather then
+    returns on rank 0 (rows_all, pool_all, [(row_bytes, pool_bytes) per rank]); elsewhere None."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    dev = ov_bytes.device
+    sizes = torch.tensor([ov_bytes.numel(), cig_bytes.numel()], dtype=torch.int64, device=dev)
+    all_sizes = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(all_sizes, sizes, group=group)
+    ops, parts = [], None
+    if rank == 0:
+        sz = [(int(a[0]), int(a[1])) for a in all_sizes]
+        rows_all = torch.empty(sum(a for a, _ in sz), dtype=torch.uint8, device=dev)
+        pool_all = torch.empty(sum(b for _, b in sz), dtype=torch.uint8, device=dev)
+        ro, po = sz[0]
+        rows_all[:ro].copy_(ov_bytes)
+        pool_all[:po].copy_(cig_bytes)
+        for r in range(1, world):
+            a, b = sz[r]
+            if a:
+                ops.append(dist.P2POp(dist.irecv, rows_all[ro:ro + a], r, group))
+            if b:
+                ops.append(dist.P2POp(dist.irecv, pool_all[po:po + b], r, group))
+            ro += a
+            po += b
+        parts = (rows_all, pool_all, sz)
+    else:
+        if ov_bytes.numel():
+            ops.append(dist.P2POp(dist.isend, ov_bytes, 0, group))
+        if cig_bytes.numel():
+            ops.append(dist.P2POp(dist.isend, cig_bytes, 0, group))
+    reqs = dist.batch_isend_irecv(ops) if ops else []
+    return {"reqs": reqs, "parts": parts, "keep": (ov_bytes, cig_bytes)}
+
+
 def finish_gather(handle):
     """Wait for a gather begun with start_gather.  Returns on rank 0 a list of (ov, cig) uint8
     tensors per rank, elsewhere None."""

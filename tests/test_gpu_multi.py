@@ -1,0 +1,103 @@
+"""Read-sharded batches on the GPU (BASELINE configs[3]): the single-process
+multi-device entry of the C ABI (kslam_multi_*), the device-side merge both hosts share
+(kslam_merge_shards_device), and bench.py's --strong mode run through the RCCL code path at world
+size 1.  Every result must be BYTE-identical to what one context returns for the whole batch.
+
+The GPU boxes have one device, so the multi-device entry is given the same ordinal several times:
+two or three contexts on one GPU, peer copies that are device-to-device copies.  The 8-GPU run itself
+is the driver's (SCALE record)."""
+import importlib
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _data(synth, seed, n_pairs, **kw):
+    genomes = synth.make_genomes(seed, 3, 3, 30000, strain_sub=0.02, strain_indel=0.001, shared_segment=2000)
+    reads, _ = synth.make_paired_reads(seed + 1, genomes, n_pairs, sub_rate=0.015, indel_rate=0.004, edge_frac=0.05, **kw)
+    return synth.to_bytes(reads), synth.to_bytes(genomes)
+
+
+@pytest.mark.parametrize("devices,n_pairs", [([0, 0], 3001), ([0, 0, 0], 2000), ([0], 500), ([0, 0, 0, 0, 0], 3)])
+def test_multi_device_entry_equals_single_context(kslam, synth, devices, n_pairs):
+    rb, gb = _data(synth, 600 + len(devices), n_pairs)
+    exp, ecig = kslam.align_to_database(rb, gb)
+    m = kslam.MultiContext(devices)
+    m.set_index(gb)
+    got, gcig = m.align_batch(rb, paired=True)
+    again, acig = m.align_batch(rb, paired=True)
+    m.close()
+    assert len(exp) > n_pairs
+    assert got.tobytes() == exp.tobytes() and gcig.tobytes() == ecig.tobytes()
+    assert again.tobytes() == exp.tobytes() and acig.tobytes() == ecig.tobytes()
+
+
+def test_multi_device_entry_unpaired_and_errors(kslam, synth):
+    rb, gb = _data(synth, 650, 1000)
+    rb = rb[:1501]                                    # an odd number of single reads
+    exp, ecig = kslam.align_to_database(rb, gb)
+    m = kslam.MultiContext([0, 0, 0])
+    m.set_index(gb)
+    got, gcig = m.align_batch(rb, paired=False)
+    assert got.tobytes() == exp.tobytes() and gcig.tobytes() == ecig.tobytes()
+    with pytest.raises(kslam.KslamError, match="even"):
+        m.align_batch(rb, paired=True)
+    e, c = m.align_batch([], paired=True)
+    assert len(e) == 0 and len(c) == 0
+    m.close()
+    with pytest.raises(kslam.KslamError):
+        kslam.MultiContext([0, 99])                   # no such device
+
+
+def test_device_merge_equals_host_reassembly(kslam, synth):
+    """kslam_merge_shards_device on gathered buffers == kslam_amd.dist.reassemble (numpy, covered on the
+    CPU by the gloo test) == the single-context result, for an uneven three-way split."""
+    import torch
+    kd = importlib.import_module("kslam_amd.dist")
+    n_pairs = 2500
+    rb, gb = _data(synth, 700, n_pairs)
+    c = kslam.Context()
+    c.set_index(gb)
+    exp, ecig = c.align_batch(rb)
+    bounds = [(0, 700), (700, 701), (701, n_pairs)]
+    parts = [c.align_batch(kd.local_reads(rb, n_pairs, lo, hi)) for lo, hi in bounds]
+    host, hpool = kd.reassemble(parts, bounds, n_pairs, kslam.OVERLAP_DT)
+    for f in ("read", "entry", "rel", "revcomp", "score", "ref_begin", "ref_end", "query_begin", "query_end", "cigar_len"):
+        assert (host[f] == exp[f]).all(), f
+    dev = torch.device("cuda", 0)
+    rows = torch.from_numpy(np.concatenate([p[0] for p in parts]).view(np.uint8).copy()).to(dev)
+    pool = torch.from_numpy(np.concatenate([p[1] for p in parts]).view(np.uint8).copy()).to(dev)
+    out_rows, out_pool = torch.empty_like(rows), torch.empty_like(pool)
+    torch.cuda.synchronize()
+    c.merge_shards_device([(lo, hi, len(p[0]), len(p[1])) for (lo, hi), p in zip(bounds, parts)], n_pairs,
+                          rows.data_ptr(), pool.data_ptr(), out_rows.data_ptr(), out_pool.data_ptr())
+    got = np.frombuffer(out_rows.cpu().numpy().tobytes(), dtype=kslam.OVERLAP_DT)
+    gpool = out_pool.cpu().numpy().view(np.uint32)
+    assert got.tobytes() == exp.tobytes() and gpool.tobytes() == ecig.tobytes()
+    with pytest.raises(kslam.KslamError, match="order"):
+        c.merge_shards_device([(700, 800, 0, 0), (0, 700, 0, 0)], n_pairs, 0, 0, 0, 0)
+    c.close()
+
+
+def test_bench_strong_mode_through_the_rccl_path_at_world_1():
+    """bench.py --strong with KSLAM_BENCH_FORCE_DIST=1: process group (RCCL), count exchange, gather,
+    device merge -- everything the 8-GPU run does, with one rank; the merged batch must be byte-identical
+    to the single-context result and pass the planted-truth checks."""
+    env = dict(os.environ, KSLAM_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29577",
+               RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--strong", "--total-pairs", "40000",
+                        "--species", "4", "--strains", "3", "--genome-len", "300000", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    v = line["verified"]
+    assert line["scaling"] == "strong" and line["config"]["pairs_per_batch"] == 40000
+    assert v["ok"] and v["merged_equals_single_context"] and v["merged_unsorted_neighbours"] == 0
+    assert v["planted_missing"] == 0 and v["planted_expected"] > 50000 and v["merged_rows"] == v["overlaps"]

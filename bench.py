@@ -328,29 +328,25 @@ def main():
         while pending:
             got = kdist.finish_gather(pending.pop())
             if strong and rank == 0:
-                # rank 0 re-bases read ids and CIGAR offsets and restores the reference's order ON THE
-                # DEVICE (kslam_merge_shards_device); the batch is done when this result exists
-                rows_all, pool_all, sz = got
-                piece = args.total_pairs // PIECES
-                shards = [(r * PIECES // world * piece, (r + 1) * PIECES // world * piece, a // 48, b // 4)
-                          for r, (a, b) in enumerate(sz)]
-                out_ov = torch.empty_like(rows_all)
-                out_cg = torch.empty_like(pool_all)
-                ctx.merge_shards_device(shards, args.total_pairs, rows_all.data_ptr(), pool_all.data_ptr(),
-                                        out_ov.data_ptr(), out_cg.data_ptr())
-                merged["ov"], merged["cg"] = out_ov, out_cg
+                # every transfer landed in its final place (kslam_amd.dist.start_gather_sharded): rank 0
+                # now HOLDS the batch-global result in the reference's order, and ran no kernel for it
+                merged["ov"], merged["cg"] = got
 
     def step():
         n_out, n_cig = ctx.align_resident()
-        if use_dist:
-            # the one exchange of the path: this rank's results go to rank 0 (point-to-point over xGMI).
-            # The transfer of batch k overlaps the alignment of batch k + 1; it is waited for before the
-            # next one starts and before the clock stops.
+        if use_dist and strong:
+            # the one exchange of the path (point-to-point over xGMI): count exchange, every rank re-bases
+            # its own records on its own GPU, four sends per rank into their final places on rank 0.  The
+            # transfer of batch k overlaps the alignment of batch k + 1; it is waited for before the next
+            # one starts and before the clock stops.
+            drain()
+            pending.append(kdist.start_gather_sharded(ctx, n_reads // 2, pair_lo, args.total_pairs, dev))
+        elif use_dist:
             ov = torch.empty(n_out * 48, dtype=torch.uint8, device=dev)
             cg = torch.empty(n_cig * 4, dtype=torch.uint8, device=dev)
             ctx.copy_results_device(ov.data_ptr(), cg.data_ptr())
             drain()
-            pending.append((kdist.start_gather_concat if strong else kdist.start_gather)(ov, cg))
+            pending.append(kdist.start_gather(ov, cg))
         return n_out, n_cig
 
     def barrier():
@@ -394,7 +390,8 @@ def main():
         # the merged batch: row count, order, and -- when this rank aligned the whole batch itself (one
         # rank) -- byte identity with the single-context result
         mc = W.overlap_columns(merged["ov"])
-        mkey = (mc["read"] << 40) | (mc["entry"] << 26) | (mc["rel"] + 1024)
+        n_rel = int(mc["rel"].max()) + 1026 if mc["rel"].numel() else 1026
+        mkey = (mc["read"] * (len(offs) - 1) + mc["entry"]) * n_rel + (mc["rel"] + 1024)
         verified["merged_rows"] = int(mkey.numel())
         verified["merged_unsorted_neighbours"] = int((mkey[1:] < mkey[:-1]).sum()) if mkey.numel() > 1 else 0
         if world == 1:

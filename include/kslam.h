@@ -198,11 +198,35 @@ kslam_status kslam_merge_shards_device(kslam_ctx *ctx, uint32_t n_shards,
                                        const void *d_cigar_pools,
                                        void *d_out_overlaps, void *d_out_cigars);
 
+/* The sending side, for a gather that needs no merge: the last results of a
+ * context whose batch was the local block layout of n_local_pairs pairs
+ * ([R1 of them | R2 of them]).  kslam_shard_counts reports how its rows and
+ * CIGAR words split into the R1 and the R2 block; once every shard's counts are
+ * known (one all-gather of four numbers), kslam_export_shard_device writes the
+ * shard's records in BATCH terms -- read ids re-based with pair_lo / n_pairs_total,
+ * cigar_off pointing into the batch-global pool whose words of R1 rows start at
+ * pool_base_r1 and of R2 rows at pool_base_r2 -- into four device buffers, which
+ * may be the final places themselves (the shard on the collecting GPU) or send
+ * buffers.  With bases = running sums over the shards (all R1 blocks first, then
+ * all R2 blocks) the gathered arrays are byte for byte the single-context result. */
+typedef struct {
+  uint64_t n_rows, n_rows_r1;   /* overlap records; those of the R1 block */
+  uint64_t n_cigar, n_cigar_r1; /* CIGAR words; those of the R1 rows */
+} kslam_shard_counts;
+kslam_status kslam_shard_counts_device(kslam_ctx *ctx, uint64_t n_local_pairs,
+                                       kslam_shard_counts *out);
+kslam_status kslam_export_shard_device(kslam_ctx *ctx, uint64_t n_local_pairs,
+                                       uint64_t pair_lo, uint64_t n_pairs_total,
+                                       uint64_t pool_base_r1, uint64_t pool_base_r2,
+                                       void *d_rows_r1, void *d_rows_r2,
+                                       void *d_pool_r1, void *d_pool_r2);
+
 /* One process driving several devices: one context per entry of `devices`
  * (params->device is ignored; an ordinal may repeat, which puts two shards on
  * one GPU), the index replicated, kslam_multi_align_batch = shard, align on
- * every device concurrently, gather to devices[0] over the peer links,
- * merge there, one copy to the host.  Same result and same ownership rules
+ * every device concurrently, count exchange, every shard exports its records
+ * in batch terms, peer copies into their final places on devices[0], one copy
+ * to the host.  Same result and same ownership rules
  * as kslam_align_batch.  paired != 0: n_reads is even and reads[i], reads[i +
  * n_reads / 2] are mates (they stay on one shard). */
 typedef struct kslam_multi kslam_multi;

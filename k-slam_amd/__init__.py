@@ -37,7 +37,8 @@ EXPORTS = ["kslam_abi_version", "kslam_create", "kslam_destroy", "kslam_last_err
            "kslam_load_reads", "kslam_load_reads_device", "kslam_align_resident",
            "kslam_fetch_results", "kslam_take_results", "kslam_copy_results_device", "kslam_get_timings",
            "kslam_extract_kmers", "kslam_sort_kmers", "kslam_find_overlaps", "kslam_free",
-           "kslam_selftest_sort", "kslam_merge_shards_device", "kslam_multi_create", "kslam_multi_destroy",
+           "kslam_selftest_sort", "kslam_merge_shards_device", "kslam_shard_counts_device",
+           "kslam_export_shard_device", "kslam_multi_create", "kslam_multi_destroy",
            "kslam_multi_last_error", "kslam_multi_set_index", "kslam_multi_align_batch", "kslam_multi_free_batch"]
 
 
@@ -112,6 +113,8 @@ def lib():
         L.kslam_selftest_sort.argtypes = [vp, u64, u32, C.POINTER(C.c_float), C.POINTER(C.c_float),
                                           C.POINTER(u64)]
         L.kslam_merge_shards_device.argtypes = [vp, u32, vp, u64, vp, vp, vp, vp]
+        L.kslam_shard_counts_device.argtypes = [vp, u64, vp]
+        L.kslam_export_shard_device.argtypes = [vp, u64, u64, u64, u64, u64, vp, vp, vp, vp]
         L.kslam_multi_create.argtypes = [C.POINTER(Params), vp, u32, C.POINTER(vp)]
         L.kslam_multi_destroy.argtypes = [vp]
         L.kslam_multi_last_error.restype = C.c_char_p
@@ -247,6 +250,17 @@ class Context:
         sh = np.array([tuple(int(v) for v in x) for x in shards], dtype=SHARD_DT)
         self._chk(self._L.kslam_merge_shards_device(self._h, len(sh), sh.ctypes.data, n_pairs, d_overlaps, d_cigars,
                                                     d_out_overlaps, d_out_cigars))
+
+    def shard_counts_device(self, n_local_pairs):
+        """kslam_shard_counts_device -> (n_rows, n_rows_r1, n_cigar, n_cigar_r1) of the last results"""
+        a = np.zeros(4, dtype=np.uint64)
+        self._chk(self._L.kslam_shard_counts_device(self._h, n_local_pairs, a.ctypes.data))
+        return tuple(int(v) for v in a)
+
+    def export_shard_device(self, n_local_pairs, pair_lo, n_pairs_total, pool_base_r1, pool_base_r2,
+                            d_rows_r1, d_rows_r2, d_pool_r1, d_pool_r2):
+        self._chk(self._L.kslam_export_shard_device(self._h, n_local_pairs, pair_lo, n_pairs_total, pool_base_r1,
+                                                    pool_base_r2, d_rows_r1, d_rows_r2, d_pool_r1, d_pool_r2))
 
     def timings(self):
         t = Timings()

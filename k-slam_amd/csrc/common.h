@@ -198,6 +198,13 @@ void merge_shards(const kslam_overlap *d_rows, uint64_t n_rows, const uint32_t *
                   uint32_t n_shards, uint64_t n_pairs, kslam_overlap *d_out, uint32_t *d_pool_out, uint32_t *d_lens,
                   uint64_t *d_new_off, uint64_t *d_total, void *d_scan_tmp, hipStream_t s);
 
+// d_out2[0] = rows of the R1 block, d_out2[1] = CIGAR words of those rows
+void shard_counts(const kslam_overlap *d_rows, uint64_t n, uint32_t n_local_pairs, uint64_t n_cigar, uint64_t *d_out2,
+                  hipStream_t s);
+void export_rows(const kslam_overlap *d_rows, uint64_t n, uint64_t n_r1, uint32_t n_local_pairs, uint64_t pair_lo,
+                 uint64_t n_pairs_total, uint64_t n_cigar_r1, uint64_t pool_base_r1, uint64_t pool_base_r2,
+                 kslam_overlap *d_out_r1, kslam_overlap *d_out_r2, hipStream_t s);
+
 // ------------------------------------------------------------------ sw.hip
 struct SwParams {
   int32_t match, mismatch, gap_open, gap_extend;

@@ -71,7 +71,8 @@ struct kslam_ctx {
 struct kslam_multi {
   std::vector<kslam_ctx *> ctx;
   std::string err;
-  DevBuf rows_in, pool_in, rows_out, pool_out;   // on ctx[0]'s device
+  DevBuf rows_out, pool_out;     // on ctx[0]'s device: the batch-global result
+  std::vector<DevBuf> send;      // per shard, on its own device: its records in batch terms, ready to copy
 };
 
 namespace {
@@ -865,6 +866,49 @@ kslam_status kslam_merge_shards_device(kslam_ctx *c, uint32_t n_shards, const ks
   });
 }
 
+kslam_status kslam_shard_counts_device(kslam_ctx *c, uint64_t n_local_pairs, kslam_shard_counts *out) {
+  return guarded(c, [&] {
+    if (!out) throw StatusError{KSLAM_ERR_ARG, "null out"};
+    if (n_local_pairs >= (1ull << 31)) throw StatusError{KSLAM_ERR_ARG, "n_local_pairs"};
+    c->totals.ensure(8 * sizeof(uint64_t));
+    uint64_t *d = c->totals.as<uint64_t>() + 4;
+    shard_counts(c->res_ov.as<kslam_overlap>(), c->n_res, (uint32_t)n_local_pairs, c->n_cig, d, c->stream);
+    uint64_t h[2] = {0, 0};
+    read_back(h, d, sizeof h, c->stream);
+    out->n_rows = c->n_res; out->n_rows_r1 = h[0];
+    out->n_cigar = c->n_cig; out->n_cigar_r1 = h[1] == ~0ull ? c->n_cig : h[1];
+  });
+}
+
+kslam_status kslam_export_shard_device(kslam_ctx *c, uint64_t n_local_pairs, uint64_t pair_lo, uint64_t n_pairs_total,
+                                       uint64_t pool_base_r1, uint64_t pool_base_r2, void *d_rows_r1, void *d_rows_r2,
+                                       void *d_pool_r1, void *d_pool_r2) {
+  return guarded(c, [&] {
+    kslam_shard_counts sc;
+    // (the split again: cheap, and the caller cannot hand in counts that do not match the results)
+    c->totals.ensure(8 * sizeof(uint64_t));
+    uint64_t *d = c->totals.as<uint64_t>() + 4;
+    shard_counts(c->res_ov.as<kslam_overlap>(), c->n_res, (uint32_t)n_local_pairs, c->n_cig, d, c->stream);
+    uint64_t h[2] = {0, 0};
+    read_back(h, d, sizeof h, c->stream);
+    sc.n_rows = c->n_res; sc.n_rows_r1 = h[0]; sc.n_cigar = c->n_cig; sc.n_cigar_r1 = h[1] == ~0ull ? c->n_cig : h[1];
+    if (pair_lo + n_local_pairs > n_pairs_total || n_pairs_total >= (1ull << 31))
+      throw StatusError{KSLAM_ERR_ARG, "pair range outside the batch"};
+    if ((sc.n_rows_r1 && !d_rows_r1) || (sc.n_rows > sc.n_rows_r1 && !d_rows_r2) || (sc.n_cigar_r1 && !d_pool_r1) ||
+        (sc.n_cigar > sc.n_cigar_r1 && !d_pool_r2))
+      throw StatusError{KSLAM_ERR_ARG, "null destination"};
+    export_rows(c->res_ov.as<kslam_overlap>(), sc.n_rows, sc.n_rows_r1, (uint32_t)n_local_pairs, pair_lo, n_pairs_total,
+                sc.n_cigar_r1, pool_base_r1, pool_base_r2, (kslam_overlap *)d_rows_r1, (kslam_overlap *)d_rows_r2,
+                c->stream);
+    if (sc.n_cigar_r1)
+      HIPCHK(hipMemcpyAsync(d_pool_r1, c->res_cig.p, sc.n_cigar_r1 * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+    if (sc.n_cigar > sc.n_cigar_r1)
+      HIPCHK(hipMemcpyAsync(d_pool_r2, c->res_cig.as<uint32_t>() + sc.n_cigar_r1,
+                            (sc.n_cigar - sc.n_cigar_r1) * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+  });
+}
+
 // ---- one process, several devices ---------------------------------------------------------------
 kslam_status kslam_multi_create(const kslam_params *params, const int32_t *devices, uint32_t n_devices, kslam_multi **out) {
   if (!params || !devices || !out || n_devices == 0 || n_devices > MERGE_MAX_SHARDS) return KSLAM_ERR_ARG;
@@ -883,6 +927,7 @@ kslam_status kslam_multi_create(const kslam_params *params, const int32_t *devic
     }
     m->ctx.push_back(c);
   }
+  m->send.resize(n_devices);
   // peer access from the collecting device to the others (hipMemcpyPeerAsync works without it, through
   // the host; with it the copy goes over xGMI)
   for (uint32_t k = 1; k < n_devices; k++) {
@@ -901,8 +946,10 @@ void kslam_multi_destroy(kslam_multi *m) {
   if (!m) return;
   if (!m->ctx.empty() && m->ctx[0]->device >= 0) {
     (void)hipSetDevice(m->ctx[0]->device);
-    m->rows_in.release(); m->pool_in.release(); m->rows_out.release(); m->pool_out.release();
+    m->rows_out.release(); m->pool_out.release();
   }
+  for (size_t k = 0; k < m->send.size() && k < m->ctx.size(); k++)
+    if (m->ctx[k]->device >= 0) { (void)hipSetDevice(m->ctx[k]->device); m->send[k].release(); }
   for (kslam_ctx *c : m->ctx) kslam_destroy(c);
   delete m;
 }
@@ -945,32 +992,58 @@ kslam_status kslam_multi_align_batch(kslam_multi *m, uint64_t n_reads, const cha
     return s1;
   });
   if (st != KSLAM_OK) return st;
-  // ---- the one exchange of the path: every shard's records to the collecting device ----
+  // ---- count exchange: where every shard's R1 rows, R2 rows and CIGAR words go in the batch ----
+  std::vector<kslam_shard_counts> cnt(N);
+  st = multi_for_each(m, [&](size_t k) { return kslam_shard_counts_device(m->ctx[k], sh[k].pair_hi - sh[k].pair_lo, &cnt[k]); });
+  if (st != KSLAM_OK) return st;
   kslam_ctx *c0 = m->ctx[0];
-  uint64_t rows = 0, ops = 0;
-  for (size_t k = 0; k < N; k++) { rows += sh[k].n_rows; ops += sh[k].n_cigar; }
+  uint64_t rows = 0, ops = 0, rows_r1 = 0, ops_r1 = 0;
+  for (size_t k = 0; k < N; k++) { rows += cnt[k].n_rows; ops += cnt[k].n_cigar; rows_r1 += cnt[k].n_rows_r1; ops_r1 += cnt[k].n_cigar_r1; }
+  std::vector<uint64_t> row1(N), row2(N), op1(N), op2(N);
+  {
+    uint64_t a = 0, b = rows_r1, c = 0, d = ops_r1;
+    for (size_t k = 0; k < N; k++) {
+      row1[k] = a; a += cnt[k].n_rows_r1;
+      row2[k] = b; b += cnt[k].n_rows - cnt[k].n_rows_r1;
+      op1[k] = c; c += cnt[k].n_cigar_r1;
+      op2[k] = d; d += cnt[k].n_cigar - cnt[k].n_cigar_r1;
+    }
+  }
   kslam_overlap *ho = nullptr;
   uint32_t *hc = nullptr;
   st = guarded(c0, [&] {
-    m->rows_in.ensure((rows + 1) * sizeof(kslam_overlap));
-    m->pool_in.ensure((ops + 1) * sizeof(uint32_t));
     m->rows_out.ensure((rows + 1) * sizeof(kslam_overlap));
     m->pool_out.ensure((ops + 1) * sizeof(uint32_t));
-    uint64_t r = 0, o = 0;
-    for (size_t k = 0; k < N; k++) {
-      kslam_ctx *ck = m->ctx[k];
-      if (sh[k].n_rows)
-        HIPCHK(hipMemcpyPeerAsync(m->rows_in.as<kslam_overlap>() + r, c0->device, ck->res_ov.p, ck->device,
-                                  sh[k].n_rows * sizeof(kslam_overlap), c0->stream));
-      if (sh[k].n_cigar)
-        HIPCHK(hipMemcpyPeerAsync(m->pool_in.as<uint32_t>() + o, c0->device, ck->res_cig.p, ck->device,
-                                  sh[k].n_cigar * sizeof(uint32_t), c0->stream));
-      r += sh[k].n_rows; o += sh[k].n_cigar;
-    }
   });
   if (st != KSLAM_OK) return multi_fail(m, st, kslam_last_error(c0));
-  st = kslam_merge_shards_device(c0, (uint32_t)N, sh.data(), n_units, m->rows_in.p, m->pool_in.p, m->rows_out.p, m->pool_out.p);
-  if (st != KSLAM_OK) return multi_fail(m, st, kslam_last_error(c0));
+  // ---- the one exchange of the path: every shard re-bases its own records (its own GPU, all at once);
+  // the shard on the collecting device writes straight into the final arrays, the others into a send
+  // buffer that one peer copy per piece moves into place ----
+  st = multi_for_each(m, [&](size_t k) -> kslam_status {
+    kslam_ctx *ck = m->ctx[k];
+    kslam_overlap *fo = m->rows_out.as<kslam_overlap>();
+    uint32_t *fp = m->pool_out.as<uint32_t>();
+    const uint64_t n1 = cnt[k].n_rows_r1, n2 = cnt[k].n_rows - n1, c1 = cnt[k].n_cigar_r1, c2 = cnt[k].n_cigar - c1;
+    const uint64_t nl = sh[k].pair_hi - sh[k].pair_lo;
+    if (k == 0)
+      return kslam_export_shard_device(ck, nl, sh[k].pair_lo, n_units, op1[k], op2[k], fo + row1[k], fo + row2[k],
+                                       fp + op1[k], fp + op2[k]);
+    DevBuf &sb = m->send[k];
+    kslam_status s1 = guarded(ck, [&] { sb.ensure((n1 + n2 + 1) * sizeof(kslam_overlap) + (c1 + c2 + 1) * sizeof(uint32_t)); });
+    if (s1 != KSLAM_OK) return s1;
+    kslam_overlap *so = sb.as<kslam_overlap>();
+    uint32_t *sp = reinterpret_cast<uint32_t *>(so + n1 + n2);
+    s1 = kslam_export_shard_device(ck, nl, sh[k].pair_lo, n_units, op1[k], op2[k], so, so + n1, sp, sp + c1);
+    if (s1 != KSLAM_OK) return s1;
+    return guarded(ck, [&] {
+      if (n1) HIPCHK(hipMemcpyPeerAsync(fo + row1[k], c0->device, so, ck->device, n1 * sizeof(kslam_overlap), ck->stream));
+      if (n2) HIPCHK(hipMemcpyPeerAsync(fo + row2[k], c0->device, so + n1, ck->device, n2 * sizeof(kslam_overlap), ck->stream));
+      if (c1) HIPCHK(hipMemcpyPeerAsync(fp + op1[k], c0->device, sp, ck->device, c1 * sizeof(uint32_t), ck->stream));
+      if (c2) HIPCHK(hipMemcpyPeerAsync(fp + op2[k], c0->device, sp + c1, ck->device, c2 * sizeof(uint32_t), ck->stream));
+      HIPCHK(hipStreamSynchronize(ck->stream));
+    });
+  });
+  if (st != KSLAM_OK) return st;
   st = guarded(c0, [&] {
     ho = (kslam_overlap *)pinned_get(c0, (rows + 1) * sizeof(kslam_overlap));
     hc = (uint32_t *)pinned_get(c0, (ops + 1) * sizeof(uint32_t));

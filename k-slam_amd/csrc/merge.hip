@@ -12,6 +12,11 @@
 //   * the CIGAR pool re-laid in row order (an exclusive scan of cigar_len), which is the layout the
 //     single-context path produces (cigar.hip k_finalize).
 // All of it is streaming: every row is read once and written once, every CIGAR op likewise.
+//
+// The second half of the file is the cheaper protocol the library's own multi-GPU paths use: after a
+// count exchange every shard knows where its R1 rows, R2 rows and CIGAR words go in the batch-global
+// arrays, re-bases its own records (k_export_rows, on its own GPU, all shards in parallel) and the
+// transfers land in their final place -- the collecting device runs no kernel at all.
 #include "common.h"
 
 namespace kslam {
@@ -74,7 +79,71 @@ __global__ __launch_bounds__(256) void k_merge_cigars(kslam_overlap *__restrict_
   out[i].cigar_off = dst;
 }
 
+// ---- the sending side: a shard's own results, already in batch terms --------------------------
+// Split of the rows into the R1 / R2 blocks (binary search: rows are sorted by local read id) and the
+// CIGAR words that belong to the R1 rows: the pool is in row order, so that is the offset of the
+// first R2 row that has a CIGAR (rows without one carry offset 0, hence no binary search there).
+__global__ void k_shard_split(const kslam_overlap *__restrict__ rows, uint64_t n, uint32_t n_local_pairs,
+                              uint64_t *__restrict__ out /*[0] rows of R1, [1] = ~0 (no R2 row with a CIGAR seen yet)*/) {
+  uint64_t lo = 0, hi = n;
+  while (lo < hi) {
+    const uint64_t mid = lo + ((hi - lo) >> 1);
+    if (rows[mid].read < n_local_pairs) lo = mid + 1; else hi = mid;
+  }
+  out[0] = lo;
+  out[1] = ~0ull;
+}
+__global__ __launch_bounds__(256) void k_shard_first_cigar(const kslam_overlap *__restrict__ rows, uint64_t n,
+                                                           uint64_t *__restrict__ out) {
+  // smallest cigar_off among the R2 rows that have a CIGAR (offsets grow with the row number)
+  const uint64_t i = out[0] + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long v = ~0ull;
+  if (i < n && rows[i].cigar_len != 0) v = rows[i].cigar_off;
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    const unsigned long long o = __shfl_down(v, d, 64);
+    v = o < v ? o : v;
+  }
+  if ((threadIdx.x & 63) == 0 && v != ~0ull) atomicMin(reinterpret_cast<unsigned long long *>(out + 1), v);
+}
+
+__global__ __launch_bounds__(256) void k_export_rows(const kslam_overlap *__restrict__ rows, uint64_t n, uint64_t n_r1,
+                                                     uint32_t n_local_pairs, uint64_t pair_lo, uint64_t n_pairs_total,
+                                                     uint64_t n_cigar_r1, uint64_t pool_base_r1, uint64_t pool_base_r2,
+                                                     kslam_overlap *__restrict__ out_r1, kslam_overlap *__restrict__ out_r2) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  kslam_overlap o = rows[i];
+  if (i < n_r1) {
+    o.read = (uint32_t)(pair_lo + o.read);
+    o.cigar_off = o.cigar_len ? pool_base_r1 + o.cigar_off : 0;
+    out_r1[i] = o;
+  } else {
+    o.read = (uint32_t)(n_pairs_total + pair_lo + (o.read - n_local_pairs));
+    o.cigar_off = o.cigar_len ? pool_base_r2 + (o.cigar_off - n_cigar_r1) : 0;
+    out_r2[i - n_r1] = o;
+  }
+}
+
 }  // namespace
+
+void shard_counts(const kslam_overlap *d_rows, uint64_t n, uint32_t n_local_pairs, uint64_t n_cigar, uint64_t *d_out2,
+                  hipStream_t s) {
+  hipLaunchKernelGGL(k_shard_split, dim3(1), dim3(1), 0, s, d_rows, n, n_local_pairs, d_out2);
+  // (the R2 block is at most all rows; blocks beyond it find i >= n and do nothing)
+  if (n && n_cigar)
+    hipLaunchKernelGGL(k_shard_first_cigar, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_rows, n, d_out2);
+  HIPCHK(hipGetLastError());
+}
+
+void export_rows(const kslam_overlap *d_rows, uint64_t n, uint64_t n_r1, uint32_t n_local_pairs, uint64_t pair_lo,
+                 uint64_t n_pairs_total, uint64_t n_cigar_r1, uint64_t pool_base_r1, uint64_t pool_base_r2,
+                 kslam_overlap *d_out_r1, kslam_overlap *d_out_r2, hipStream_t s) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(k_export_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_rows, n, n_r1, n_local_pairs,
+                     pair_lo, n_pairs_total, n_cigar_r1, pool_base_r1, pool_base_r2, d_out_r1, d_out_r2);
+  HIPCHK(hipGetLastError());
+}
 
 void merge_shards(const kslam_overlap *d_rows, uint64_t n_rows, const uint32_t *d_pool_in, MergeShard *d_shards,
                   uint32_t n_shards, uint64_t n_pairs, kslam_overlap *d_out, uint32_t *d_pool_out, uint32_t *d_lens,

@@ -97,6 +97,55 @@ def start_gather_concat(ov_bytes, cig_bytes, group=None):
     return {"reqs": reqs, "parts": parts, "keep": (ov_bytes, cig_bytes)}
 
 
+def start_gather_sharded(ctx, n_local_pairs, pair_lo, n_pairs_total, dev, group=None):
+    """The gather without a merge step.  Every rank asks its context how its last results split into the
+    R1 / R2 blocks (kslam_shard_counts_device), the counts are all-gathered, every rank exports its
+    records in BATCH terms (kslam_export_shard_device: read ids and CIGAR offsets re-based on its own
+    GPU) and sends four pieces that land in their final places on rank 0.  finish_gather returns on
+    rank 0 (rows, pool) -- uint8 device tensors holding the batch-global result, byte for byte what
+    one context returns for the whole batch -- elsewhere None."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    mine = ctx.shard_counts_device(n_local_pairs)
+    t = torch.tensor(mine, dtype=torch.int64, device=dev)
+    allc = [torch.zeros(4, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(allc, t, group=group)
+    cnt = [tuple(int(v) for v in a.tolist()) for a in allc]       # (rows, rows_r1, ops, ops_r1) per rank
+    rows_r1 = sum(c[1] for c in cnt)
+    ops_r1 = sum(c[3] for c in cnt)
+    row1 = [sum(c[1] for c in cnt[:r]) for r in range(world)]
+    row2 = [rows_r1 + sum(c[0] - c[1] for c in cnt[:r]) for r in range(world)]
+    op1 = [sum(c[3] for c in cnt[:r]) for r in range(world)]
+    op2 = [ops_r1 + sum(c[2] - c[3] for c in cnt[:r]) for r in range(world)]
+    ops, parts, keep = [], None, None
+    if rank == 0:
+        rows = torch.empty(sum(c[0] for c in cnt) * 48, dtype=torch.uint8, device=dev)
+        pool = torch.empty(sum(c[2] for c in cnt) * 4, dtype=torch.uint8, device=dev)
+        rp, pp = rows.data_ptr(), pool.data_ptr()
+        ctx.export_shard_device(n_local_pairs, pair_lo, n_pairs_total, op1[0], op2[0], rp + 48 * row1[0],
+                                rp + 48 * row2[0], pp + 4 * op1[0], pp + 4 * op2[0])
+        for r in range(1, world):
+            n, n1, c, c1 = cnt[r]
+            for buf, start, count, unit in ((rows, row1[r], n1, 48), (rows, row2[r], n - n1, 48),
+                                            (pool, op1[r], c1, 4), (pool, op2[r], c - c1, 4)):
+                if count:
+                    ops.append(dist.P2POp(dist.irecv, buf[start * unit:(start + count) * unit], r, group))
+        parts = (rows, pool)
+    else:
+        n, n1, c, c1 = cnt[rank]
+        srows = torch.empty(max(n, 1) * 48, dtype=torch.uint8, device=dev)
+        spool = torch.empty(max(c, 1) * 4, dtype=torch.uint8, device=dev)
+        rp, pp = srows.data_ptr(), spool.data_ptr()
+        ctx.export_shard_device(n_local_pairs, pair_lo, n_pairs_total, op1[rank], op2[rank], rp, rp + 48 * n1,
+                                pp, pp + 4 * c1)
+        for buf, start, count, unit in ((srows, 0, n1, 48), (srows, n1, n - n1, 48), (spool, 0, c1, 4), (spool, c1, c - c1, 4)):
+            if count:
+                ops.append(dist.P2POp(dist.isend, buf[start * unit:(start + count) * unit], 0, group))
+        keep = (srows, spool)
+    reqs = dist.batch_isend_irecv(ops) if ops else []
+    return {"reqs": reqs, "parts": parts, "keep": keep}
+
+
 def finish_gather(handle):
     """Wait for a gather begun with start_gather.  Returns on rank 0 a list of (ov, cig) uint8
     tensors per rank, elsewhere None."""

@@ -192,10 +192,15 @@ def check_against_truth(ov_bytes, cig_words, truth, read_len, match=2, mismatch=
     c = overlap_columns(ov_bytes)
     n = c["read"].numel()
     L = read_len
-    key = (c["read"] << 40) | (c["entry"] << 26) | (c["rel"] + 1024)
+    # one int64 key per row, (read, entry, rel) in that significance; the field widths follow the data
+    # (20 M reads x 1 250 entries x 4 M positions of a 10 M-pair batch need 59 bits)
+    n_entry = int(max(int(c["entry"].max()) if n else 0, int(truth["entry"].max()))) + 1
+    n_rel = int(max(int(c["rel"].max()) if n else 0, int(truth["rel"].max()))) + 1026
+    assert (int(truth["entry"].numel()) + 1) * n_entry * n_rel < 2 ** 63, "key does not fit int64"
+    key = (c["read"] * n_entry + c["entry"]) * n_rel + (c["rel"] + 1024)
     unsorted = int((key[1:] < key[:-1]).sum()) if n > 1 else 0
     want = torch.nonzero(truth["seed_ok"]).flatten()
-    wkey = (want << 40) | (truth["entry"][want] << 26) | (truth["rel"][want] + 1024)
+    wkey = (want * n_entry + truth["entry"][want]) * n_rel + (truth["rel"][want] + 1024)
     idx = torch.searchsorted(key, wkey).clamp(max=max(n - 1, 0))
     found = (key[idx] == wkey) if n else torch.zeros_like(wkey, dtype=torch.bool)
     # the reference leaves equal (read, entry, rel) with different revComp to an unstable sort; here

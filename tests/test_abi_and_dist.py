@@ -122,6 +122,37 @@ if rank == 0:
         b = epool[int(exp["cigar_off"][i]):int(exp["cigar_off"][i]) + int(exp["cigar_len"][i])]
         assert (a == b).all()
     print("GATHER_OK", len(got))
+
+# ---- the gather without a merge step (kslam_amd.dist.start_gather_sharded): the context's two device
+# functions restated in numpy on host memory, the protocol itself (count exchange, bases, four pieces
+# per rank landing in their final places) is the product's ----
+import ctypes
+class HostShard:
+    def __init__(self, al, cg):
+        self.al, self.cg = al, cg
+    def shard_counts_device(self, n_loc):
+        r1 = self.al["read"] < n_loc
+        n1 = int(r1.sum())
+        return len(self.al), n1, len(self.cg), int(self.al["cigar_len"][:n1].sum())
+    def export_shard_device(self, n_loc, pair_lo, n_total, pb1, pb2, d_r1, d_r2, d_p1, d_p2):
+        n, n1, c, c1 = self.shard_counts_device(n_loc)
+        o = self.al.copy()
+        has = o["cigar_len"] > 0
+        o["read"][:n1] += np.uint32(pair_lo)
+        o["read"][n1:] = o["read"][n1:] - np.uint32(n_loc) + np.uint32(n_total + pair_lo)
+        o["cigar_off"][:n1] = np.where(has[:n1], o["cigar_off"][:n1] + np.uint64(pb1), 0)
+        o["cigar_off"][n1:] = np.where(has[n1:], o["cigar_off"][n1:] - np.uint64(c1) + np.uint64(pb2), 0)
+        for ptr, data in ((d_r1, o[:n1]), (d_r2, o[n1:]), (d_p1, self.cg[:c1]), (d_p2, self.cg[c1:])):
+            b = data.tobytes()
+            if b:
+                ctypes.memmove(ptr, b, len(b))
+h = kd.start_gather_sharded(HostShard(al.view(K.OVERLAP_DT), cg), hi - lo, lo, n_pairs, torch.device("cpu"))
+res = kd.finish_gather(h)
+if rank == 0:
+    rows, pool = res
+    exp, epool, _ = O.align_to_database(reads, genomes)
+    assert rows.numpy().tobytes() == exp.view(K.OVERLAP_DT).tobytes() and pool.numpy().tobytes() == epool.tobytes()
+    print("SHARDED_GATHER_OK")
 dist.barrier(); dist.destroy_process_group()
 '''
 
@@ -134,7 +165,7 @@ def test_sharded_gather_world2_gloo(tmp_path):
                         "--master-addr", "127.0.0.1", "--master-port", "29541", str(script)],
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert "GATHER_OK" in r.stdout
+    assert "GATHER_OK" in r.stdout and "SHARDED_GATHER_OK" in r.stdout
 
 
 @pytest.mark.parametrize("header", ["kslam.h", "kslam_tail.h", "kslam_fastq.h", "kslam_taxonomy.h", "kslam_db.h"])

@@ -82,6 +82,64 @@ def cpu_baseline(K, db, offs, seed, n_genomes, n_pairs, read_len=READ_LEN, devic
     return out
 
 
+def abi_path(K, ctx, reads, read_len, steps):
+    """What a k-SLAM host linking the library sees: reads[i].bases in host memory in (char **, lengths),
+    overlap records + CIGAR pool back in host memory (page-locked, library-owned), batch after batch
+    through kslam_align_batch_async / kslam_wait_batch with two batches in flight -- upload, kernels and
+    download of neighbouring batches overlap.  Every PCIe byte is inside this number; it is not `value`."""
+    import ctypes as C
+    host = np.ascontiguousarray(reads.cpu().numpy())
+    n = host.shape[0]
+    ptrs = (host.ctypes.data + np.arange(n, dtype=np.uint64) * np.uint64(read_len)).astype(np.uint64)
+    lens = np.full(n, read_len, dtype=np.uint32)
+    pp, lp = ptrs.ctypes.data, lens.ctypes.data
+
+    t_sub, t_wait = [], []
+
+    def run(k):
+        t0 = time.perf_counter()
+        rows = 0
+        pend = [ctx.submit_batch_pointers(n, pp, lp)]
+        for i in range(k):
+            ta = time.perf_counter()
+            if i + 1 < k:
+                pend.append(ctx.submit_batch_pointers(n, pp, lp))
+            tb = time.perf_counter()
+            ov, cg, release = ctx.wait_batch(pend.pop(0), copy=False)
+            rows = len(ov)
+            release()
+            t_sub.append(tb - ta)
+            t_wait.append(time.perf_counter() - tb)
+            done_at.append(time.perf_counter())
+        return time.perf_counter() - t0, rows
+    done_at = []
+    run(3)                                             # lanes, page-locked buffers and work buffers exist now
+    del t_sub[:], t_wait[:], done_at[:]
+    wall, rows = run(steps)
+    steady = (done_at[-1] - done_at[0]) / (len(done_at) - 1)   # batch-to-batch, without the pipeline fill of the first
+    t0 = time.perf_counter()
+    for _ in range(3):
+        ov, cg, release = ctx.align_batch_pointers(n, pp, lp, copy=False)
+        if _ < 2:
+            release()
+    sync_wall = (time.perf_counter() - t0) / 3
+    # identity with the resident path
+    n_out, n_cig = ctx.align_resident()
+    r_ov, r_cg = ctx.fetch_results(n_out, n_cig)
+    same = ov.tobytes() == r_ov.tobytes() and cg.tobytes() == r_cg.tobytes()
+    release()
+    return {
+        "ms_in_submit": round(1e3 * sum(t_sub) / max(len(t_sub), 1), 2), "ms_in_wait": round(1e3 * sum(t_wait) / max(len(t_wait), 1), 2),
+        "reads_per_s": round(n / steady, 1), "ms_per_batch": round(steady * 1e3, 2), "steps": steps,
+        "including_pipeline_fill": {"reads_per_s": round(n * steps / wall, 1), "ms_per_batch": round(wall / steps * 1e3, 2)},
+        "one_batch_at_a_time": {"reads_per_s": round(n / sync_wall, 1), "ms_per_batch": round(sync_wall * 1e3, 2)},
+        "h2d_mb_per_batch": round(n * read_len / 1e6, 1), "d2h_mb_per_batch": round((rows * 48 + n_cig * 4) / 1e6, 1),
+        "equals_resident_result": bool(same),
+        "what": "host pointers in -> kslam_align_batch_async / kslam_wait_batch (two batches in flight) -> host "
+                "results out; `one_batch_at_a_time` = kslam_align_batch in a loop",
+    }
+
+
 def sam_pipeline(K, ctx, reads, db, offs, read_len, steps):
     """Reads resident in HBM -> SAM records on the host, the way a streaming caller would run it:
     batch k's results are copied to the host and go through the host tail (include/kslam_tail.h:
@@ -251,6 +309,7 @@ def main():
     ap.add_argument("--cpu-pairs", type=int, default=300000)
     ap.add_argument("--cpu-genomes", type=int, default=25)
     ap.add_argument("--no-cigar", action="store_true")
+    ap.add_argument("--no-abi-path", action="store_true", help="skip the host-pointers-in / host-results-out leg")
     ap.add_argument("--no-sam-pipeline", action="store_true", help="skip the GPU + host-tail pipeline leg")
     ap.add_argument("--no-full-pipeline", action="store_true", help="skip the FASTQ text -> SAM text leg")
     ap.add_argument("--read-len", type=int, default=READ_LEN, help="150 (BASELINE configs[1..3]) or 250 (configs[4])")
@@ -487,6 +546,11 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(K, db, offs, 77, args.cpu_genomes, args.cpu_pairs, args.read_len, local_rank)
+        if world == 1 and not strong and not args.no_abi_path:
+            try:
+                out["abi_path"] = abi_path(K, ctx, reads, args.read_len, max(args.steps, 12))
+            except Exception as e:   # extra evidence only: never lose the bench line over it
+                out["abi_path"] = {"error": repr(e)}
         if world == 1 and not strong and not args.no_sam_pipeline and not args.no_cigar:
             try:
                 out["sam_pipeline"] = sam_pipeline(K, ctx, reads, db, offs, args.read_len, max(args.steps, 3))

@@ -148,6 +148,25 @@ kslam_status kslam_align_batch(kslam_ctx *ctx, uint64_t n_reads,
                                uint32_t **cigar_pool, uint64_t *n_cigar);
 void kslam_free_batch(kslam_ctx *ctx, kslam_overlap *out, uint32_t *cigar_pool);
 
+/* ---- the same operator, pipelined ---------------------------------------
+ * The reference's batch loop (src/SLAM.h:194-241) is: read a batch, align it,
+ * post-process it, next.  kslam_align_batch_async takes the batch (the reads are
+ * copied out of the caller's memory before it returns) and hands back a ticket;
+ * kslam_wait_batch blocks until that batch's result is in page-locked host
+ * memory (same ownership as kslam_align_batch: give it back with
+ * kslam_free_batch, from any thread).  Batches alternate between two internal
+ * worker lanes with their own streams, so with two batches submitted the upload
+ * of one and the download of another run under the kernels of a third phase:
+ *     submit(0); for k: submit(k + 1); wait(k); <host tail of batch k>
+ * Results are those of kslam_align_batch, batch by batch.  Not to be mixed with
+ * a kslam_set_index call while tickets are outstanding. */
+kslam_status kslam_align_batch_async(kslam_ctx *ctx, uint64_t n_reads,
+                                     const char *const *bases, const uint32_t *lens,
+                                     uint64_t *ticket);
+kslam_status kslam_wait_batch(kslam_ctx *ctx, uint64_t ticket, kslam_overlap **out,
+                              uint64_t *n_out, uint32_t **cigar_pool,
+                              uint64_t *n_cigar);
+
 /* ---- the same operator in three steps, for callers that keep the batch
  * resident in HBM (bench.py, multi-GPU sharding) --------------------------- */
 kslam_status kslam_load_reads(kslam_ctx *ctx, uint64_t n_reads,

@@ -34,6 +34,7 @@ STATUS = {0: "OK", 1: "ERR_ARG", 2: "ERR_NO_DEVICE", 3: "ERR_OOM", 4: "ERR_UNSUP
 # every symbol include/kslam.h declares
 EXPORTS = ["kslam_abi_version", "kslam_create", "kslam_destroy", "kslam_last_error",
            "kslam_set_index", "kslam_set_index_device", "kslam_align_batch", "kslam_free_batch",
+           "kslam_align_batch_async", "kslam_wait_batch",
            "kslam_load_reads", "kslam_load_reads_device", "kslam_align_resident",
            "kslam_fetch_results", "kslam_take_results", "kslam_copy_results_device", "kslam_get_timings",
            "kslam_extract_kmers", "kslam_sort_kmers", "kslam_find_overlaps", "kslam_free",
@@ -99,6 +100,8 @@ def lib():
         L.kslam_align_batch.argtypes = [vp, u64, vp, vp, C.POINTER(vp), C.POINTER(u64),
                                         C.POINTER(vp), C.POINTER(u64)]
         L.kslam_free_batch.argtypes = [vp, vp, vp]
+        L.kslam_align_batch_async.argtypes = [vp, u64, vp, vp, C.POINTER(u64)]
+        L.kslam_wait_batch.argtypes = [vp, u64, C.POINTER(vp), C.POINTER(u64), C.POINTER(vp), C.POINTER(u64)]
         L.kslam_load_reads.argtypes = [vp, u64, vp, vp]
         L.kslam_load_reads_device.argtypes = [vp, u64, vp, vp]
         L.kslam_align_resident.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
@@ -203,6 +206,57 @@ class Context:
             if nc else np.zeros(0, dtype=np.uint32)
         self._L.kslam_free_batch(self._h, out, cig)
         return ov, cg
+
+    def align_batch_pointers(self, n_reads, bases_pp, lens_p, copy=True):
+        """kslam_align_batch on a ready `const char *const *` / `const uint32_t *` pair; copy=False returns
+        views of the library's page-locked buffers plus the function that hands them back"""
+        out, cig = C.c_void_p(), C.c_void_p()
+        n_out, n_cig = C.c_uint64(), C.c_uint64()
+        self._chk(self._L.kslam_align_batch(self._h, n_reads, bases_pp, lens_p, C.byref(out), C.byref(n_out),
+                                            C.byref(cig), C.byref(n_cig)))
+        n, nc = int(n_out.value), int(n_cig.value)
+        ov = np.frombuffer((C.c_char * (n * 48)).from_address(out.value), dtype=OVERLAP_DT) \
+            if n else np.zeros(0, dtype=OVERLAP_DT)
+        cg = np.frombuffer((C.c_char * (nc * 4)).from_address(cig.value), dtype=np.uint32) \
+            if nc else np.zeros(0, dtype=np.uint32)
+
+        def release():
+            self._L.kslam_free_batch(self._h, out, cig)
+        if copy:
+            ov, cg = ov.copy(), cg.copy()
+            release()
+            return ov, cg
+        return ov, cg, release
+
+    def submit_batch(self, reads):
+        """kslam_align_batch_async on a list of bytes -> ticket"""
+        ptrs, keep = _seq_arrays(reads)
+        lens = np.array([len(s) for s in reads], dtype=np.uint32)
+        return self.submit_batch_pointers(len(reads), C.cast(ptrs, C.c_void_p), lens.ctypes.data)
+
+    def submit_batch_pointers(self, n_reads, bases_pp, lens_p):
+        """kslam_align_batch_async on a ready `const char *const *` / `const uint32_t *` pair"""
+        t = C.c_uint64()
+        self._chk(self._L.kslam_align_batch_async(self._h, n_reads, bases_pp, lens_p, C.byref(t)))
+        return int(t.value)
+
+    def wait_batch(self, ticket, copy=True):
+        """kslam_wait_batch -> (overlaps, cigar_pool[, release]); copy=False returns views of the library's
+        page-locked buffers plus the function that hands them back"""
+        po, pc, no, nc = C.c_void_p(), C.c_void_p(), C.c_uint64(), C.c_uint64()
+        self._chk(self._L.kslam_wait_batch(self._h, ticket, C.byref(po), C.byref(no), C.byref(pc), C.byref(nc)))
+        ov = np.frombuffer((C.c_char * (no.value * OVERLAP_DT.itemsize)).from_address(po.value),
+                           dtype=OVERLAP_DT) if no.value else np.zeros(0, dtype=OVERLAP_DT)
+        cg = np.frombuffer((C.c_char * (nc.value * 4)).from_address(pc.value),
+                           dtype=np.uint32) if nc.value else np.zeros(0, dtype=np.uint32)
+
+        def release():
+            self._L.kslam_free_batch(self._h, po, pc)
+        if copy:
+            ov, cg = ov.copy(), cg.copy()
+            release()
+            return ov, cg
+        return ov, cg, release
 
     def load_reads(self, reads):
         cat, off = _concat(reads)

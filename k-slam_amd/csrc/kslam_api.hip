@@ -9,6 +9,10 @@
 
 #include "common.h"
 #include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <map>
 #include <mutex>
 #include <new>
 #include <thread>
@@ -59,6 +63,32 @@ struct kslam_ctx {
   std::vector<Pinned> pinned;
   std::mutex pin_mu;
 
+  // ---- pipelined entry (kslam_align_batch_async): worker lanes, each a sibling context that BORROWS
+  // this context's index (same device pointers, never freed by the sibling) ----
+  bool borrowed_index = false;
+  struct AsyncJob {
+    uint64_t ticket = 0;
+    uint64_t n_reads = 0;
+    char *cat = nullptr;              // pinned, from the lane context's pool
+    std::vector<uint64_t> off;
+    bool done = false;
+    kslam_status st = KSLAM_OK;
+    std::string err;
+    kslam_overlap *out = nullptr; uint64_t n_out = 0;
+    uint32_t *pool = nullptr; uint64_t n_cig = 0;
+  };
+  struct AsyncLane {
+    kslam_ctx *c = nullptr;
+    std::thread th;
+    std::deque<AsyncJob *> q;
+  };
+  std::vector<AsyncLane *> lanes;
+  std::mutex as_mu, as_compute;
+  std::condition_variable as_cv;
+  std::map<uint64_t, AsyncJob *> jobs;   // submitted, not yet waited for
+  uint64_t next_ticket = 0;
+  bool as_stop = false;
+
   // ---- merge of gathered shard results (merge.hip) ----
   DevBuf mg_shards, mg_lens, mg_off, mg_scan;
 
@@ -76,6 +106,8 @@ struct kslam_multi {
 };
 
 namespace {
+
+void share_index(kslam_ctx *dst, const kslam_ctx *src);
 
 template <typename F> kslam_status guarded(kslam_ctx *ctx, F &&f) {
   if (!ctx) return KSLAM_ERR_ARG;
@@ -335,6 +367,7 @@ void build_index(kslam_ctx *c) {
   HIPCHK(hipStreamSynchronize(s));
   c->kept_last = 0;
   c->have_index = true;
+  for (auto *l : c->lanes) share_index(l->c, c);   // (no batch may be in flight across kslam_set_index)
 }
 
 void finish_load_reads(kslam_ctx *c) {
@@ -605,6 +638,82 @@ template <typename F> kslam_status multi_for_each(kslam_multi *m, F &&f) {
   return KSLAM_OK;
 }
 
+
+// a sibling context sees the primary's index through the same device pointers
+void share_index(kslam_ctx *dst, const kslam_ctx *src) {
+  dst->borrowed_index = true;
+  dst->have_index = src->have_index;
+  dst->n_entries = src->n_entries; dst->max_entry_len = src->max_entry_len; dst->h_goff = src->h_goff;
+  dst->g_bases = src->g_bases; dst->g_off = src->g_off; dst->g_codes = src->g_codes;
+  dst->n_gk = src->n_gk; dst->gk_key = src->gk_key; dst->gk_meta = src->gk_meta; dst->gk_off = src->gk_off;
+  dst->g_bucket = src->g_bucket; dst->bucket_bits = src->bucket_bits;
+  dst->g_filter = src->g_filter; dst->filter_bits = src->filter_bits;
+  dst->kept_last = 0;
+}
+
+void lane_main(kslam_ctx *primary, kslam_ctx::AsyncLane *lane) {
+  for (;;) {
+    kslam_ctx::AsyncJob *job = nullptr;
+    {
+      std::unique_lock<std::mutex> lk(primary->as_mu);
+      primary->as_cv.wait(lk, [&] { return primary->as_stop || !lane->q.empty(); });
+      if (lane->q.empty()) return;   // stop requested and nothing left
+      job = lane->q.front();
+      lane->q.pop_front();
+    }
+    kslam_ctx *c = lane->c;
+    static const bool dbg = getenv("KSLAM_DEBUG") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
+    double t1 = 0, t2 = 0, t3 = 0;
+    kslam_status st = kslam_load_reads(c, job->n_reads, job->cat, job->off.data());
+    t1 = now();
+    pinned_put(c, job->cat);
+    job->cat = nullptr;
+    if (st == KSLAM_OK) {
+      // one lane computes at a time: the kernels of a batch fill the chip, so two batches computing at
+      // once only time-slice -- and, worse, fall into step, both lanes copying while the GPU idles and
+      // both computing afterwards (measured: 32.6 ms per batch against 27.3 resident).  With the token
+      // the lanes run in anti-phase: one computes while the other downloads its last result and
+      // uploads its next batch.
+      std::lock_guard<std::mutex> compute(primary->as_compute);
+      t2 = now();
+      st = kslam_align_resident(c, nullptr, nullptr);
+    }
+    t3 = now();
+    if (st == KSLAM_OK) st = kslam_take_results(c, &job->out, &job->n_out, &job->pool, &job->n_cig);
+    if (dbg) fprintf(stderr, "[kslam] lane %p ticket %llu: upload %.2f, token wait %.2f, align %.2f, download %.2f ms\n", (void *)lane,
+                     (unsigned long long)job->ticket, t1 - t0, t2 - t1, t3 - t2, now() - t3);
+    {
+      std::lock_guard<std::mutex> lk(primary->as_mu);
+      job->st = st;
+      if (st != KSLAM_OK) job->err = c->err;
+      job->done = true;
+    }
+    primary->as_cv.notify_all();
+  }
+}
+
+void stop_lanes(kslam_ctx *c) {
+  {
+    std::lock_guard<std::mutex> lk(c->as_mu);
+    c->as_stop = true;
+  }
+  c->as_cv.notify_all();
+  for (auto *l : c->lanes) {
+    if (l->th.joinable()) l->th.join();
+    kslam_destroy(l->c);
+    delete l;
+  }
+  c->lanes.clear();
+  for (auto &kv : c->jobs) {   // results nobody waited for
+    kslam_ctx::AsyncJob *j = kv.second;
+    delete j;
+  }
+  c->jobs.clear();
+  c->as_stop = false;
+}
+
 }  // namespace
 
 extern "C" {
@@ -642,9 +751,14 @@ kslam_status kslam_create(const kslam_params *params, kslam_ctx **out) {
 
 void kslam_destroy(kslam_ctx *c) {
   if (!c) return;
+  if (!c->lanes.empty()) stop_lanes(c);   // workers first: they use this context's index
   if (c->device >= 0) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->borrowed_index) {   // a lane's view of its primary's index: not ours to free
+      DevBuf *idx[] = {&c->g_codes, &c->g_bases, &c->g_off, &c->gk_key, &c->gk_meta, &c->gk_off, &c->g_bucket, &c->g_filter};
+      for (DevBuf *b : idx) { b->p = nullptr; b->cap = 0; }
+    }
     DevBuf *bufs[] = {&c->g_codes, &c->r_codes, &c->g_bases, &c->g_off, &c->gk_key, &c->gk_meta, &c->gk_off, &c->g_bucket, &c->g_filter, &c->r_bases,
                       &c->r_off, &c->r_len, &c->nk, &c->nseg, &c->rec_start, &c->seg_start, &c->segs, &c->scan_tmp,
                       &c->totals, &c->recs_a, &c->recs_b, &c->block_tot, &c->block_base, &c->ovk_a, &c->ovk_b,
@@ -827,8 +941,104 @@ kslam_status kslam_align_batch(kslam_ctx *c, uint64_t n_reads, const char *const
 
 void kslam_free_batch(kslam_ctx *c, kslam_overlap *out, uint32_t *cigar_pool) {
   if (!c) return;
-  if (out && !pinned_put(c, out)) free(out);
-  if (cigar_pool && !pinned_put(c, cigar_pool)) free(cigar_pool);
+  auto give_back = [&](void *p) {
+    if (!p || pinned_put(c, p)) return;
+    for (auto *l : c->lanes)
+      if (pinned_put(l->c, p)) return;
+    free(p);
+  };
+  give_back(out);
+  give_back(cigar_pool);
+}
+
+// ---- the operator, pipelined: batches alternate between two worker lanes (a host thread + a sibling
+// context with its own stream and work buffers each), so the upload of batch k+1 and the download of
+// batch k-1 run under the kernels of batch k, and one lane's host read-backs are covered by the other
+// lane's kernels ----
+kslam_status kslam_align_batch_async(kslam_ctx *c, uint64_t n_reads, const char *const *bases, const uint32_t *lens,
+                                     uint64_t *ticket) {
+  if (!c || !ticket) return KSLAM_ERR_ARG;
+  kslam_ctx::AsyncJob *job = nullptr;
+  kslam_status st = guarded(c, [&] {
+    if (n_reads && (!bases || !lens)) throw StatusError{KSLAM_ERR_ARG, "null bases/lens"};
+    if (!c->have_index) throw StatusError{KSLAM_ERR_STATE, "kslam_set_index has not been called"};
+    if (c->lanes.empty()) {
+      for (int k = 0; k < 2; k++) {
+        kslam_ctx *lc = nullptr;
+        const kslam_status s1 = kslam_create(&c->prm, &lc);
+        if (s1 != KSLAM_OK) {
+          const std::string msg = lc ? lc->err : "lane context";
+          kslam_destroy(lc);
+          throw StatusError{s1, msg};
+        }
+        share_index(lc, c);
+        auto *l = new kslam_ctx::AsyncLane();
+        l->c = lc;
+        c->lanes.push_back(l);
+      }
+      for (auto *l : c->lanes) l->th = std::thread(lane_main, c, l);
+    }
+    job = new kslam_ctx::AsyncJob();
+    job->n_reads = n_reads;
+    job->off.assign(n_reads + 1, 0);
+    for (uint64_t i = 0; i < n_reads; i++) job->off[i + 1] = job->off[i] + lens[i];
+  });
+  if (st != KSLAM_OK) { delete job; return st; }
+  // the reads leave the caller's memory now (parallel gather into a page-locked buffer of the lane that
+  // will run the batch): the caller may reuse its buffers as soon as this call returns
+  uint64_t tk;
+  {
+    std::lock_guard<std::mutex> lk(c->as_mu);
+    tk = c->next_ticket++;
+  }
+  kslam_ctx::AsyncLane *lane = c->lanes[tk % c->lanes.size()];
+  st = guarded(c, [&] {
+    job->cat = (char *)pinned_get(lane->c, job->off[n_reads] + 64);
+    unsigned nt = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    if (n_reads < 100000) nt = 1;
+    std::vector<std::thread> th;
+    char *cat = job->cat;
+    const std::vector<uint64_t> &off = job->off;
+    for (unsigned t = 0; t < nt; t++) {
+      const uint64_t lo = n_reads * t / nt, hi = n_reads * (t + 1) / nt;
+      auto work = [=, &off] { for (uint64_t i = lo; i < hi; i++) memcpy(cat + off[i], bases[i], lens[i]); };
+      if (nt == 1) work(); else th.emplace_back(work);
+    }
+    for (auto &x : th) x.join();
+  });
+  if (st != KSLAM_OK) { if (job->cat) pinned_put(lane->c, job->cat); delete job; return st; }
+  job->ticket = tk;
+  {
+    std::lock_guard<std::mutex> lk(c->as_mu);
+    c->jobs[tk] = job;
+    lane->q.push_back(job);
+  }
+  c->as_cv.notify_all();
+  *ticket = tk;
+  return KSLAM_OK;
+}
+
+kslam_status kslam_wait_batch(kslam_ctx *c, uint64_t ticket, kslam_overlap **out, uint64_t *n_out, uint32_t **cigar_pool,
+                              uint64_t *n_cigar) {
+  if (!c || !out || !n_out || !cigar_pool || !n_cigar) return KSLAM_ERR_ARG;
+  *out = nullptr; *cigar_pool = nullptr; *n_out = 0; *n_cigar = 0;
+  kslam_ctx::AsyncJob *job = nullptr;
+  {
+    std::unique_lock<std::mutex> lk(c->as_mu);
+    auto it = c->jobs.find(ticket);
+    if (it == c->jobs.end()) { c->err = "no such ticket (already waited for?)"; return KSLAM_ERR_ARG; }
+    job = it->second;
+    c->as_cv.wait(lk, [&] { return job->done; });
+    c->jobs.erase(it);
+  }
+  const kslam_status st = job->st;
+  if (st == KSLAM_OK) {
+    *out = job->out; *n_out = job->n_out; *cigar_pool = job->pool; *n_cigar = job->n_cig;
+  } else {
+    c->err = job->err;
+  }
+  delete job;
+  return st;
 }
 void kslam_free(void *p) { free(p); }
 

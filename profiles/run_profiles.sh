@@ -3,9 +3,9 @@
 # (kernel-trace/stats and the two PMC passes are separate runs, as the pool requires)
 R=${1:-r01}
 REPO="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"; cd /tmp && export TMPDIR=/tmp; cd "$REPO" || exit 1; rm -rf /tmp/prof; mkdir -p /tmp/prof gpurun_out/keep
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof/kt -o x -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-sam-pipeline > gpurun_out/keep/${R}_bench_under_rocprof.json 2> /tmp/e1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/prof/pf -o x -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-sam-pipeline > /tmp/o2 2> /tmp/e2
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/prof/pw -o x -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-sam-pipeline > /tmp/o3 2> /tmp/e3
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof/kt -o x -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-abi-path --no-sam-pipeline > gpurun_out/keep/${R}_bench_under_rocprof.json 2> /tmp/e1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/prof/pf -o x -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-abi-path --no-sam-pipeline > /tmp/o2 2> /tmp/e2
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/prof/pw -o x -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-abi-path --no-sam-pipeline > /tmp/o3 2> /tmp/e3
 python3 - "$R" <<'PY'
 import csv, glob, json, sys
 R = sys.argv[1]

@@ -223,6 +223,51 @@ def test_results_released_from_a_second_thread(kslam, synth):
     assert not bad
 
 
+def test_pipelined_entry_gives_the_same_batches(kslam, synth):
+    """kslam_align_batch_async / kslam_wait_batch: three different batches kept in flight over the two
+    worker lanes, waited for out of order, repeated; every result equals the synchronous entry's.
+    An unsupported batch fails at ITS wait, with its message, and the lanes keep working."""
+    genomes = synth.make_genomes(31, 3, 2, 25000, shared_segment=1500)
+    batches = []
+    for k, n in enumerate([300, 1, 451]):
+        reads, _ = synth.make_paired_reads(40 + k, genomes, n, indel_rate=0.004, edge_frac=0.05)
+        batches.append(synth.to_bytes(reads))
+    batches.append([])                                   # an empty batch is a batch
+    gb = synth.to_bytes(genomes)
+    c = kslam.Context()
+    c.set_index(gb)
+    expect = [c.align_batch(b) for b in batches]
+    order = [0, 1, 2, 3, 2, 0, 1, 1, 3, 0, 2, 2]
+    tickets = [c.submit_batch(batches[i]) for i in order[:3]]
+    assert tickets == [0, 1, 2]
+    for k in range(3, len(order) + 3):
+        if k < len(order):
+            tickets.append(c.submit_batch(batches[order[k]]))
+        j = k - 3
+        ov, cg = c.wait_batch(tickets[j])
+        e_ov, e_cg = expect[order[j]]
+        assert ov.tobytes() == e_ov.tobytes() and cg.tobytes() == e_cg.tobytes(), j
+    with pytest.raises(kslam.KslamError, match="ticket"):
+        c.wait_batch(tickets[0])
+    # out-of-order waits + an unsupported batch in the middle
+    t0 = c.submit_batch(batches[0])
+    t_bad = c.submit_batch([b"ACGT" * 200])              # 800 bases: beyond the supported read length
+    t2 = c.submit_batch(batches[2])
+    ov, cg = c.wait_batch(t2)
+    assert ov.tobytes() == expect[2][0].tobytes()
+    with pytest.raises(kslam.KslamError, match="511"):
+        c.wait_batch(t_bad)
+    ov, cg = c.wait_batch(t0)
+    assert ov.tobytes() == expect[0][0].tobytes() and cg.tobytes() == expect[0][1].tobytes()
+    # a new index while the lanes exist: they see it
+    c.set_index(gb[:2])
+    e2 = c.align_batch(batches[0])
+    got = c.wait_batch(c.submit_batch(batches[0]))
+    assert got[0].tobytes() == e2[0].tobytes() and len(e2[0]) < len(expect[0][0])
+    c.submit_batch(batches[2])                           # left outstanding on purpose: destroy cleans up
+    c.close()
+
+
 def test_empty_batch(kslam, synth):
     _, genomes, _ = _dataset(synth, 5, 1)
     ov, cg = kslam.align_to_database([], genomes)

@@ -2,7 +2,7 @@
 REPO="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"; cd "$REPO" || exit 1; mkdir -p gpurun_out
 for cfg in "0 3" "32 3" "32 2" "32 1" "32 0" "31 2" "33 2" "30 2"; do
   set -- $cfg
-  KSLAM_FILTER_BITS=$1 KSLAM_SORT_BYTES=$2 python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-sam-pipeline --no-full-pipeline > /tmp/fs.json 2>/tmp/fs.err
+  KSLAM_FILTER_BITS=$1 KSLAM_SORT_BYTES=$2 python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-abi-path --no-sam-pipeline --no-full-pipeline > /tmp/fs.json 2>/tmp/fs.err
   python3 - "$1" "$2" <<'PY'
 import json, sys
 try:

@@ -1,6 +1,6 @@
 # usage: bash tools/pmc.sh "<counters>" <kernel substring>   (bench 1 step; counters only, no trace domains)
 REPO="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"; cd /tmp && export TMPDIR=/tmp; cd "$REPO" || exit 1; rm -rf /tmp/prof3; mkdir -p /tmp/prof3
-rocprofv3 --pmc $1 --output-format csv -d /tmp/prof3 -o x -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-sam-pipeline --no-full-pipeline > /tmp/o1 2> /tmp/e1
+rocprofv3 --pmc $1 --output-format csv -d /tmp/prof3 -o x -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-abi-path --no-sam-pipeline --no-full-pipeline > /tmp/o1 2> /tmp/e1
 python3 - "$2" <<'PY'
 import csv,glob,sys,collections
 pat=sys.argv[1]

@@ -2,7 +2,7 @@ REPO="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"; cd /tmp && export TMPDI
 for mode in auto slab; do
   rm -rf /tmp/prof_$mode
   if [ $mode = slab ]; then export KSLAM_CIGAR_DIRS=slab; fi
-  rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_$mode -o x -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-abi-path --no-sam-pipeline > /tmp/o_$mode.json 2>/tmp/e_$mode
+  rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_$mode -o x -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-abi-path --no-sam-pipeline --no-full-pipeline > /tmp/o_$mode.json 2>/tmp/e_$mode
   python3 - $mode <<'PY'
 import csv, glob, sys, json
 mode = sys.argv[1]

@@ -1,6 +1,6 @@
 # idle time between consecutive kernels of one bench step (where the GPU waits for the host)
 REPO="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"; cd /tmp && export TMPDIR=/tmp; cd "$REPO" || exit 1; rm -rf /tmp/gp
-rocprofv3 --kernel-trace --output-format csv -d /tmp/gp -o x -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-abi-path --no-sam-pipeline > /tmp/gp.json 2>/tmp/gp.err
+rocprofv3 --kernel-trace --output-format csv -d /tmp/gp -o x -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-abi-path --no-sam-pipeline --no-full-pipeline > /tmp/gp.json 2>/tmp/gp.err
 python3 - <<'PY'
 import csv, glob
 rows = list(csv.DictReader(open(glob.glob('/tmp/gp/**/*kernel_trace.csv', recursive=True)[0])))

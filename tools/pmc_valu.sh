@@ -1,8 +1,8 @@
 # SQ instruction counters of the SW kernels for one bench step -> gpurun_out/keep/<tag>_valu.json
 TAG=${1:-r01f}
 REPO="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"; cd /tmp && export TMPDIR=/tmp; cd "$REPO" || exit 1; rm -rf /tmp/prof4; mkdir -p /tmp/prof4 gpurun_out/keep
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS --output-format csv -d /tmp/prof4 -o x -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-abi-path --no-sam-pipeline > /tmp/o4 2> /tmp/e4
-rm -rf /tmp/prof5; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof5 -o x -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-abi-path --no-sam-pipeline > /tmp/o5 2> /tmp/e5
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS --output-format csv -d /tmp/prof4 -o x -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-abi-path --no-sam-pipeline --no-full-pipeline > /tmp/o4 2> /tmp/e4
+rm -rf /tmp/prof5; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof5 -o x -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-abi-path --no-sam-pipeline --no-full-pipeline > /tmp/o5 2> /tmp/e5
 python3 - "$TAG" <<'PY'
 import csv, glob, json, sys
 tag = sys.argv[1]
@@ -11,7 +11,7 @@ agg = {}
 for f in glob.glob('/tmp/prof4/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
         k = clean(r['Kernel_Name'])
-        if not k.startswith(('k_sw', 'k_cigar_systolic', 'k_banded')): continue
+        if not k.startswith(('k_sw', 'k_cigar_systolic', 'k_banded', 'k_extract_filter', 'k_join_fill')): continue
         agg.setdefault(k, {}).setdefault(r['Counter_Name'], 0.0)
         agg[k][r['Counter_Name']] += float(r['Counter_Value'])
 dur = {}

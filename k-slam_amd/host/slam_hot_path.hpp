@@ -72,7 +72,17 @@ class HotPath {
     }
     kslam_overlap* ov = nullptr; uint32_t* pool = nullptr; uint64_t n = 0, nc = 0;
     check(kslam_align_batch(ctx_, ptr.size(), ptr.data(), len.data(), &ov, &n, &pool, &nc));
-    std::vector<OverlapT> out(n);
+    std::vector<OverlapT> out;
+    convert(ov, n, pool, out);
+    kslam_free_batch(ctx_, ov, pool);
+    return out;
+  }
+
+  // kslam_overlap records + pool -> the caller's Overlap objects (each Alignment owns a malloc'ed
+  // cigar array, src/ssw_cpp.h:23-77)
+  template <class OverlapT>
+  static void convert(const kslam_overlap* ov, uint64_t n, const uint32_t* pool, std::vector<OverlapT>& out) {
+    out.resize(n);
     for (uint64_t i = 0; i < n; i++) {
       OverlapT& o = out[i];
       o.readPosInArray = ov[i].read;
@@ -86,13 +96,11 @@ class HotPath {
       o.alignment.sw_score = ov[i].score;
       o.alignment.cigarLen = (int32_t)ov[i].cigar_len;
       o.alignment.cigar = nullptr;
-      if (ov[i].cigar_len) {  // Alignment owns a malloc'ed array, src/ssw_cpp.h:23-77
+      if (ov[i].cigar_len) {
         o.alignment.cigar = (uint32_t*)std::malloc(sizeof(uint32_t) * ov[i].cigar_len);
         std::memcpy(o.alignment.cigar, pool + ov[i].cigar_off, sizeof(uint32_t) * ov[i].cigar_len);
       }
     }
-    kslam_free_batch(ctx_, ov, pool);
-    return out;
   }
 
  private:
@@ -100,6 +108,63 @@ class HotPath {
     if (st != KSLAM_OK) throw std::runtime_error(std::string("kslam: ") + kslam_last_error(ctx_));
   }
   kslam_ctx* ctx_ = nullptr;
+};
+
+// The same operator over several GPUs of one node (kslam_multi_*, include/kslam.h): the batch's read
+// pairs are sharded, the index is replicated, the result is byte for byte the single-GPU one.
+// `pairedData` as the reference's global (src/Globals.h): reads = [R1 block | R2 block].
+class HotPathMulti {
+ public:
+  HotPathMulti(const std::vector<int>& devices, uint32_t match, uint32_t misMatch, uint32_t gapOpen,
+               uint32_t gapExtend, uint32_t scoreThreshold, bool reportCigar) {
+    kslam_params p;
+    std::memset(&p, 0, sizeof p);
+    p.match = match; p.mismatch = misMatch; p.gap_open = gapOpen; p.gap_extend = gapExtend;
+    p.score_threshold = scoreThreshold; p.report_cigar = reportCigar ? 1 : 0;
+    std::vector<int32_t> dv(devices.begin(), devices.end());
+    kslam_status st = kslam_multi_create(&p, dv.data(), (uint32_t)dv.size(), &m_);
+    if (st != KSLAM_OK) {
+      std::string msg = m_ ? kslam_multi_last_error(m_) : "kslam_multi_create failed";
+      if (m_) kslam_multi_destroy(m_);
+      m_ = nullptr;
+      throw std::runtime_error("kslam: " + msg);
+    }
+  }
+  ~HotPathMulti() { if (m_) kslam_multi_destroy(m_); }
+  HotPathMulti(const HotPathMulti&) = delete;
+  HotPathMulti& operator=(const HotPathMulti&) = delete;
+
+  template <class Index> void setIndex(const Index& index) {
+    std::vector<const char*> ptr(index.entries.size());
+    std::vector<uint64_t> len(index.entries.size());
+    for (size_t j = 0; j < index.entries.size(); j++) {
+      ptr[j] = index.entries[j].bases.data();
+      len[j] = index.entries[j].bases.size();
+    }
+    check(kslam_multi_set_index(m_, ptr.size(), ptr.data(), len.data()));
+  }
+
+  template <class OverlapT, class FASTQType>
+  std::vector<OverlapT> alignToDatabase(const std::vector<FASTQType>& reads, bool pairedData) {
+    std::vector<const char*> ptr(reads.size());
+    std::vector<uint32_t> len(reads.size());
+    for (size_t i = 0; i < reads.size(); i++) {
+      ptr[i] = reads[i].bases.data();
+      len[i] = (uint32_t)reads[i].bases.size();
+    }
+    kslam_overlap* ov = nullptr; uint32_t* pool = nullptr; uint64_t n = 0, nc = 0;
+    check(kslam_multi_align_batch(m_, ptr.size(), ptr.data(), len.data(), pairedData ? 1 : 0, &ov, &n, &pool, &nc));
+    std::vector<OverlapT> out;
+    HotPath::convert(ov, n, pool, out);
+    kslam_multi_free_batch(m_, ov, pool);
+    return out;
+  }
+
+ private:
+  void check(kslam_status st) {
+    if (st != KSLAM_OK) throw std::runtime_error(std::string("kslam: ") + kslam_multi_last_error(m_));
+  }
+  kslam_multi* m_ = nullptr;
 };
 
 }  // namespace kslam_host

@@ -31,7 +31,18 @@ int main() {
       std::printf("\n");
       std::free(o.alignment.cigar);
     }
-    return (ov.size() == 2 && ov[0].alignment.sw_score == 300 && ov[1].relativePosition == 3216) ? 0 : 1;
+    // the same two reads as one PAIR through the multi-device mirror (two shards on device 0)
+    kslam_host::HotPathMulti mp({0, 0}, 2, 3, 5, 2, 0, true);
+    mp.setIndex(idx);
+    std::vector<Overlap> mv = mp.alignToDatabase<Overlap>(reads, /*pairedData=*/true);
+    bool same = mv.size() == ov.size();
+    for (size_t i = 0; same && i < mv.size(); i++) {
+      same = mv[i].readPosInArray == ov[i].readPosInArray && mv[i].relativePosition == ov[i].relativePosition &&
+             mv[i].alignment.sw_score == ov[i].alignment.sw_score && mv[i].alignment.cigarLen == ov[i].alignment.cigarLen;
+      std::free(mv[i].alignment.cigar);
+    }
+    std::printf("multi %s\n", same ? "identical" : "DIFFERENT");
+    return (same && ov.size() == 2 && ov[0].alignment.sw_score == 300 && ov[1].relativePosition == 3216) ? 0 : 1;
   } catch (const std::exception& e) {
     std::printf("error: %s\n", e.what());
     return 2;

@@ -147,3 +147,4 @@ def test_cpp_binding_header_builds_and_runs(tmp_path):
     assert out.returncode == 0, out.stdout + out.stderr
     lines = [l for l in out.stdout.splitlines() if l.startswith("read ")]
     assert len(lines) == 2 and "score 300" in lines[0] and "cigar 150M" in lines[0] and "rel 3216" in lines[1]
+    assert "multi identical" in out.stdout

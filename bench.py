@@ -140,52 +140,60 @@ def abi_path(K, ctx, reads, read_len, steps):
     }
 
 
+def _host_copy(t, keep):
+    """a host copy in a private anonymous mapping advised for transparent huge pages (what kslam_db_load /
+    kslam_fastq_parse do for their columns)"""
+    import mmap
+    n = t.numel() * t.element_size()
+    m = mmap.mmap(-1, max((n + (2 << 20) - 1) // (2 << 20) * (2 << 20), 2 << 20),
+                  flags=mmap.MAP_PRIVATE | mmap.MAP_ANONYMOUS)
+    if hasattr(mmap, "MADV_HUGEPAGE"):
+        m.madvise(mmap.MADV_HUGEPAGE)
+    a = np.frombuffer(m, dtype=np.uint8, count=n).reshape(tuple(t.shape))
+    torch.from_numpy(a).copy_(t)
+    keep.append(m)
+    return a
+
+
 def sam_pipeline(K, ctx, reads, db, offs, read_len, steps):
     """Reads resident in HBM -> SAM records on the host, the way a streaming caller would run it:
     batch k's results are copied to the host and go through the host tail (include/kslam_tail.h:
     pairing, insert-size / score screens, pseudo-assembly, SAM text) on a worker thread while the
-    GPU aligns batch k+1.  Reported next to the headline number; it is not `value`."""
+    GPU aligns batch k+1.  Since round 2 the GPU also walks every alignment's CIGAR + read + quality +
+    entry window (kslam_row_details: NM, log-probability, MD text per row), so the host writer formats
+    text and never reads the 5 GB database.  Reported next to the headline number; it is not `value`."""
     import threading
     T = importlib.import_module("kslam_amd.tail")
     n_reads = reads.shape[0]
     t0 = time.time()
-    # Host copies of the reads and of the database, in private anonymous mappings advised for
-    # transparent huge pages -- what kslam_db_load / kslam_fastq_parse do for their columns: the SAM
-    # stage reads ~150 bases at a random place of the 5 GB database per alignment, with 4 KiB pages a
-    # TLB miss each (measured on the bench box: SAM stage 61 -> 51 ms)
     keep = []
-
-    def host_copy(t):
-        import mmap
-        n = t.numel() * t.element_size()
-        m = mmap.mmap(-1, max((n + (2 << 20) - 1) // (2 << 20) * (2 << 20), 2 << 20),
-                      flags=mmap.MAP_PRIVATE | mmap.MAP_ANONYMOUS)
-        if hasattr(mmap, "MADV_HUGEPAGE"):
-            m.madvise(mmap.MADV_HUGEPAGE)
-        a = np.frombuffer(m, dtype=np.uint8, count=n).reshape(tuple(t.shape))
-        torch.from_numpy(a).copy_(t)
-        keep.append(m)
-        return a
-    R = T.ReadsArrays(host_copy(reads), read_len)
-    I = T.IndexArrays(host_copy(db), offs, taxonomy_ids=np.arange(1, len(offs), dtype=np.uint32))
+    R = T.ReadsArrays(_host_copy(reads, keep), read_len)          # quality: constant 'I' (phred 40)
+    # the index view the writer gets: offsets, names, taxonomy ids -- and NO copy of the database
+    I = T.IndexArrays(np.zeros(1, dtype=np.uint8), offs, taxonomy_ids=np.arange(1, len(offs), dtype=np.uint32))
     P = T.TailParams.default()
+    ctx.load_qualities_array(np.full(n_reads * read_len + 1, ord("I"), dtype=np.uint8))
     t_host_copy = time.time() - t0
-    stats, box = [], {}
+    stats = []
 
-    def tail(ov, cg, release):
-        st = T.tail_sam_discard(P, R, I, ov, cg)
+    def gpu_batch():
+        n_out, n_cig = ctx.align_resident()
+        ctx.row_details()
+        ov, cg, rel1 = ctx.take_results()
+        det, md, rel2 = ctx.take_row_details(n_out, copy=False)
+        return ov, cg, det, md, lambda: (rel1(), rel2())
+
+    def tail(ov, cg, det, md, release):
+        st = T.tail_sam_discard_rows(P, R, I, ov, cg, det, md)
         release()                                  # page-locked result buffers back to the library
         stats.append(st.as_dict())
 
-    ctx.align_resident()
-    tail(*ctx.take_results())                      # warm the tail's work buffers
+    tail(*gpu_batch())                             # warm the tail's work buffers
     stats.clear()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     worker = None
     for _ in range(steps):
-        ctx.align_resident()                       # GPU: batch k+1
-        res = ctx.take_results()                   # D2H of its results into page-locked buffers
+        res = gpu_batch()                          # GPU: batch k+1, its rows into page-locked buffers
         if worker is not None:
             worker.join()                          # host tail of batch k must be done
         worker = threading.Thread(target=tail, args=res)
@@ -200,20 +208,21 @@ def sam_pipeline(K, ctx, reads, db, offs, read_len, steps):
         "host_tail_phases_ms": {k[3:]: round(last[k], 2) for k in last if k.startswith("ms_")},
         "host_threads": int(last["threads"]), "sam_mb_per_batch": round(last["sam_bytes"] / 1e6, 1),
         "alignment_pairs": int(last["n_paired_final"]), "read_pairs_aligned": int(last["n_read_pairs"]),
-        "what": "align (GPU) -> D2H -> pairing/screens/pseudo-assembly/SAM text (host, discarded by the "
-                "writer), host stage of batch k overlapped with the GPU stage of batch k+1; reads stay "
-                "resident in HBM; one-time host copies of reads + database took %.1f s" % t_host_copy,
+        "what": "align + per-row NM / log-probability / MD (GPU) -> D2H -> pairing/screens/pseudo-assembly/SAM text "
+                "(host, discarded by the writer; no host copy of the database), host stage of batch k overlapped "
+                "with the GPU stage of batch k+1; reads stay resident in HBM; one-time host copy of the reads took %.1f s" % t_host_copy,
     }
 
 
 def full_pipeline(K, ctx, reads, db, offs, read_len, steps):
     """First FASTQ byte to last SAM byte, the way the reference's low-memory driver loops
     (src/SLAM.h:193-241): per batch the two FASTQ texts are parsed on the host (include/kslam_fastq.h),
-    the bases go to the GPU (kslam_load_reads), are aligned, the results come back and go through the
-    host tail to SAM text -- the tail of batch k on a second thread while batch k+1 is parsed and
-    aligned.  Synthetic FASTQ text of the bench's own read batch, held in memory; the SAM text is
-    handed to a writer that discards it.  Reported next to the headline number; it is not `value`."""
-    import mmap
+    bases and qualities go to the GPU through the pipelined entry (kslam_submit_batch_columns: by DMA from
+    the parser's page-locked columns), come back as
+    overlap records + CIGARs + per-row NM / log-probability / MD (kslam_collect_batch) and go through the
+    host tail to SAM text -- parse of batch k+1, GPU work of batch k and tail of batch k-1 at the same
+    time.  Synthetic FASTQ text of the bench's own read batch, held in memory; the SAM text is handed to
+    a writer that discards it.  Reported next to the headline number; it is not `value`."""
     import threading
     F = importlib.import_module("kslam_amd.fastq")
     T = importlib.import_module("kslam_amd.tail")
@@ -235,64 +244,57 @@ def full_pipeline(K, ctx, reads, db, offs, read_len, steps):
         a[:, W - 1] = ord("\n")
         return a.tobytes()
     r1, r2 = fastq_text(host[:n], 1), fastq_text(host[n:], 2)
-    keep = []
-
-    def host_copy(t):   # the database on the host, in huge pages (as kslam_db_load leaves it)
-        nb = t.numel() * t.element_size()
-        m = mmap.mmap(-1, max((nb + (2 << 20) - 1) // (2 << 20) * (2 << 20), 2 << 20),
-                      flags=mmap.MAP_PRIVATE | mmap.MAP_ANONYMOUS)
-        if hasattr(mmap, "MADV_HUGEPAGE"):
-            m.madvise(mmap.MADV_HUGEPAGE)
-        a = np.frombuffer(m, dtype=np.uint8, count=nb).reshape(tuple(t.shape))
-        torch.from_numpy(a).copy_(t)
-        keep.append(m)
-        return a
-    I = T.IndexArrays(host_copy(db), offs, taxonomy_ids=np.arange(1, len(offs), dtype=np.uint32))
+    I = T.IndexArrays(np.zeros(1, dtype=np.uint8), offs, taxonomy_ids=np.arange(1, len(offs), dtype=np.uint32))
     P = T.TailParams.default()
-    stats, sam_bytes = [], []
+    stats = []
 
-    def tail(batch, ov, cg, release):
-        st = T.tail_sam_discard(P, batch, I, ov, cg)
+    def tail(batch, ov, cg, det, md, release):
+        st = T.tail_sam_discard_rows(P, batch, I, ov, cg, det, md)
         release()
         batch.close()
         stats.append(st.as_dict())
 
-    def one(worker):
+    def parse_and_submit():
         t0 = time.perf_counter()
         batch, u1, u2 = F.parse_pair(r1, r2)
         t1 = time.perf_counter()
-        cat, off = batch.bases_array()
-        ctx.load_reads_arrays(cat, off)
-        t2 = time.perf_counter()
-        ctx.align_resident()
-        res = ctx.take_results()
-        t3 = time.perf_counter()
-        if worker is not None:
-            worker.join()
-        w = threading.Thread(target=tail, args=(batch,) + tuple(res))
-        w.start()
-        return w, (t1 - t0, t2 - t1, t3 - t2)
-    w, _ = one(None)          # warm-up batch
-    w.join()
+        c = batch._cols                                # the parser's columns, page-locked: no copy at submission
+        tk = ctx.submit_batch_columns(batch.n_reads, c.bases, c.quality, c.bases_off)
+        return batch, tk, (t1 - t0, time.perf_counter() - t1)
+    import ctypes as C
+    b0, t0_, _ = parse_and_submit()                # warm-up batch
+    res = ctx.collect_batch(t0_)
+    tail(b0, *res)
     stats.clear()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    worker, parts = None, []
-    for _ in range(steps):
-        worker, p3 = one(worker)
-        parts.append(p3)
+    t_start = time.perf_counter()
+    worker, parts, waits = None, [], []
+    cur = parse_and_submit()
+    for k in range(steps):
+        nxt = parse_and_submit() if k + 1 < steps else None        # batch k+1 parsed and queued
+        tw = time.perf_counter()
+        res = ctx.collect_batch(cur[1])                            # batch k back from the GPU
+        waits.append(time.perf_counter() - tw)
+        if worker is not None:
+            worker.join()                                          # tail of batch k-1 done
+        worker = threading.Thread(target=tail, args=(cur[0],) + tuple(res))
+        worker.start()
+        parts.append(cur[2])
+        cur = nxt
     worker.join()
-    wall = time.perf_counter() - t0
+    wall = time.perf_counter() - t_start
     n_reads = 2 * n
     ms = lambda k: round(1e3 * sum(p[k] for p in parts) / len(parts), 2)   # noqa: E731
     return {
         "reads_per_s": round(n_reads * steps / wall, 1), "ms_per_batch": round(wall / steps * 1e3, 2), "steps": steps,
-        "ms_fastq_parse": ms(0), "ms_load_reads": ms(1), "ms_align_and_results": ms(2),
+        "ms_fastq_parse": ms(0), "ms_submit": ms(1), "ms_waiting_for_gpu": round(1e3 * sum(waits) / len(waits), 2),
         "host_tail_ms": round(sum(sum(v for k, v in s.items() if k.startswith("ms_")) for s in stats) / len(stats), 2),
+        "host_tail_phases_ms": {k[3:]: round(stats[-1][k], 2) for k in stats[-1] if k.startswith("ms_")},
         "fastq_mb_per_batch": round((len(r1) + len(r2)) / 1e6, 1), "sam_mb_per_batch": round(stats[-1]["sam_bytes"] / 1e6, 1),
-        "what": "FASTQ text (2 files, in memory) -> parse (host) -> H2D -> align (GPU) -> D2H -> pairing ... SAM text "
-                "(host, discarded by the writer); the tail of batch k runs on a second thread while batch k+1 is "
-                "parsed and aligned; parse and tail share the library's one worker pool",
+        "what": "FASTQ text (2 files, in memory) -> parse (host) -> kslam_submit_batch (bases + qualities up, align, per-row "
+                "NM / log-probability / MD on the GPU) -> kslam_collect_batch -> pairing ... SAM text (host, discarded by "
+                "the writer; no host copy of the database); parse of batch k+1, GPU of batch k and tail of batch k-1 "
+                "overlap; parse and tail share the library's one worker pool",
     }
 
 

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define KSLAM_ABI_VERSION 2
+#define KSLAM_ABI_VERSION 3
 #define KSLAM_K 32u /* src/Globals.h:25 */
 
 typedef enum {
@@ -166,6 +166,61 @@ kslam_status kslam_align_batch_async(kslam_ctx *ctx, uint64_t n_reads,
 kslam_status kslam_wait_batch(kslam_ctx *ctx, uint64_t ticket, kslam_overlap **out,
                               uint64_t *n_out, uint32_t **cigar_pool,
                               uint64_t *n_cigar);
+
+/* ---- per-row details for the SAM writer (row N1 of SURVEY section 8f) ----
+ * getCigarAndMD (src/SAM.h:101-237) walks CIGAR + read + quality + entry bases
+ * of every reported alignment; on the host that is a random walk through the
+ * whole database.  With the batch's quality strings on the device as well
+ * (kslam_load_qualities: same layout and offsets as the loaded reads),
+ * kslam_row_details computes for every overlap record of the last result
+ *   nm    = sequenceDiff.NM                       (SAM.h:150, 169, 181)
+ *   logp  = sequenceDiff.logProbability           (SAM.h:146-152; the tables of
+ *           SAM.h:33-48 come from the host's libm, the additions run in column
+ *           order, so the double is the reference's)
+ *   MD    = sequenceDiff.MD as text, md_pool[md_off .. md_off + md_len)
+ * and include/kslam_tail.h takes them instead of walking the database itself.
+ * flags: 1 = a quality character outside phred+33 0..99 in an aligned column,
+ * 2 = the CIGAR runs past the read or the entry (both are errors the host
+ * tail reports when it meets such a row). */
+typedef struct {
+  double logp;
+  uint64_t md_off;
+  uint32_t md_len;
+  uint32_t nm;
+  uint32_t flags;
+  uint32_t pad;
+} kslam_row_detail;
+kslam_status kslam_load_qualities(kslam_ctx *ctx, const char *concat_quality);
+kslam_status kslam_load_qualities_device(kslam_ctx *ctx, const void *d_concat_quality);
+kslam_status kslam_row_details(kslam_ctx *ctx, uint64_t *n_md);
+/* page-locked, library-owned copies; hand each back with kslam_free_pinned */
+kslam_status kslam_take_row_details(kslam_ctx *ctx, kslam_row_detail **details,
+                                    char **md_pool, uint64_t *n_md);
+void kslam_free_pinned(kslam_ctx *ctx, void *p);
+
+/* The pipelined entry with everything a SAM-writing host needs in one result:
+ * quality may be NULL (then details / md_pool come back NULL). */
+typedef struct {
+  kslam_overlap *overlaps;
+  uint64_t n_overlaps;
+  uint32_t *cigar_pool;
+  uint64_t n_cigar;
+  kslam_row_detail *details;
+  char *md_pool;
+  uint64_t n_md;
+} kslam_batch_result;
+kslam_status kslam_submit_batch(kslam_ctx *ctx, uint64_t n_reads, const char *const *bases,
+                                const char *const *quality, const uint32_t *lens,
+                                uint64_t *ticket);
+/* the same for a batch that already lies in columns (what kslam_fastq_parse returns, include/kslam_fastq.h:
+ * read i = bases[offsets[i] .. offsets[i+1]), quality likewise or NULL): nothing is copied at submission,
+ * the columns go to the device straight from where they are -- by DMA when they are page-locked, which the
+ * FASTQ parser's columns are once a context exists -- and must stay valid until the batch is collected. */
+kslam_status kslam_submit_batch_columns(kslam_ctx *ctx, uint64_t n_reads, const char *bases,
+                                        const char *quality, const uint64_t *offsets,
+                                        uint64_t *ticket);
+kslam_status kslam_collect_batch(kslam_ctx *ctx, uint64_t ticket, kslam_batch_result *out);
+void kslam_release_batch(kslam_ctx *ctx, kslam_batch_result *r);
 
 /* ---- the same operator in three steps, for callers that keep the batch
  * resident in HBM (bench.py, multi-GPU sharding) --------------------------- */

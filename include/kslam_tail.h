@@ -184,6 +184,29 @@ kslam_status kslam_tail_sam_write(const kslam_tail_params *params,
                                   const uint32_t *cigar_pool, uint64_t n_cigar,
                                   kslam_write_fn write, void *user, kslam_tail_stats *stats);
 
+/* The same two with the per-row details of kslam_row_details (include/kslam.h):
+ * NM, the log-probability and the MD text of every overlap record were computed
+ * on the GPU, so the writer formats text and never reads index->bases (whose
+ * 3 M scattered 150-byte windows per batch are what bounds the plain entry on
+ * a multi-gigabyte database).  details[i] belongs to overlaps[i]; identical
+ * output.  details == NULL: the plain walk. */
+kslam_status kslam_tail_sam_rows(const kslam_tail_params *params,
+                                 const kslam_reads_view *reads,
+                                 const kslam_index_view *index,
+                                 const kslam_overlap *overlaps, uint64_t n_overlaps,
+                                 const uint32_t *cigar_pool, uint64_t n_cigar,
+                                 const kslam_row_detail *details, const char *md_pool,
+                                 uint64_t n_md, char **text, uint64_t *text_len,
+                                 kslam_tail_stats *stats);
+kslam_status kslam_tail_sam_write_rows(const kslam_tail_params *params,
+                                       const kslam_reads_view *reads,
+                                       const kslam_index_view *index,
+                                       const kslam_overlap *overlaps, uint64_t n_overlaps,
+                                       const uint32_t *cigar_pool, uint64_t n_cigar,
+                                       const kslam_row_detail *details, const char *md_pool,
+                                       uint64_t n_md, kslam_write_fn write, void *user,
+                                       kslam_tail_stats *stats);
+
 /* The tail keeps its work buffers (a few hundred bytes per overlap) between
  * calls; this returns them to the allocator.  Calls are serialised internally:
  * each one already spreads over all worker threads. */

@@ -27,6 +27,9 @@ OVERLAP_DT = np.dtype([("read", "<u4"), ("entry", "<u4"), ("rel", "<i4"),
                        ("query_begin", "<i4"), ("query_end", "<i4"),
                        ("cigar_len", "<u4"), ("pad2", "<u4"), ("cigar_off", "<u8")])
 assert OVERLAP_DT.itemsize == 48
+ROW_DETAIL_DT = np.dtype([("logp", "<f8"), ("md_off", "<u8"), ("md_len", "<u4"), ("nm", "<u4"),
+                          ("flags", "<u4"), ("pad", "<u4")])
+assert ROW_DETAIL_DT.itemsize == 32
 
 STATUS = {0: "OK", 1: "ERR_ARG", 2: "ERR_NO_DEVICE", 3: "ERR_OOM", 4: "ERR_UNSUPPORTED",
           5: "ERR_STATE", 6: "ERR_INTERNAL"}
@@ -34,7 +37,9 @@ STATUS = {0: "OK", 1: "ERR_ARG", 2: "ERR_NO_DEVICE", 3: "ERR_OOM", 4: "ERR_UNSUP
 # every symbol include/kslam.h declares
 EXPORTS = ["kslam_abi_version", "kslam_create", "kslam_destroy", "kslam_last_error",
            "kslam_set_index", "kslam_set_index_device", "kslam_align_batch", "kslam_free_batch",
-           "kslam_align_batch_async", "kslam_wait_batch",
+           "kslam_align_batch_async", "kslam_wait_batch", "kslam_load_qualities", "kslam_load_qualities_device",
+           "kslam_row_details", "kslam_take_row_details", "kslam_free_pinned", "kslam_submit_batch",
+           "kslam_submit_batch_columns", "kslam_collect_batch", "kslam_release_batch",
            "kslam_load_reads", "kslam_load_reads_device", "kslam_align_resident",
            "kslam_fetch_results", "kslam_take_results", "kslam_copy_results_device", "kslam_get_timings",
            "kslam_extract_kmers", "kslam_sort_kmers", "kslam_find_overlaps", "kslam_free",
@@ -49,6 +54,12 @@ class Params(C.Structure):
                 ("gap_extend", C.c_uint32), ("score_threshold", C.c_uint32),
                 ("report_cigar", C.c_int32), ("device", C.c_int32),
                 ("max_kmers_per_chunk", C.c_uint32)]
+
+
+class BatchResult(C.Structure):
+    """kslam_batch_result"""
+    _fields_ = [("overlaps", C.c_void_p), ("n_overlaps", C.c_uint64), ("cigar_pool", C.c_void_p),
+                ("n_cigar", C.c_uint64), ("details", C.c_void_p), ("md_pool", C.c_void_p), ("n_md", C.c_uint64)]
 
 
 class Timings(C.Structure):
@@ -102,6 +113,15 @@ def lib():
         L.kslam_free_batch.argtypes = [vp, vp, vp]
         L.kslam_align_batch_async.argtypes = [vp, u64, vp, vp, C.POINTER(u64)]
         L.kslam_wait_batch.argtypes = [vp, u64, C.POINTER(vp), C.POINTER(u64), C.POINTER(vp), C.POINTER(u64)]
+        L.kslam_load_qualities.argtypes = [vp, vp]
+        L.kslam_load_qualities_device.argtypes = [vp, vp]
+        L.kslam_row_details.argtypes = [vp, C.POINTER(u64)]
+        L.kslam_take_row_details.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64)]
+        L.kslam_free_pinned.argtypes = [vp, vp]
+        L.kslam_submit_batch.argtypes = [vp, u64, vp, vp, vp, C.POINTER(u64)]
+        L.kslam_submit_batch_columns.argtypes = [vp, u64, vp, vp, vp, C.POINTER(u64)]
+        L.kslam_collect_batch.argtypes = [vp, u64, C.POINTER(BatchResult)]
+        L.kslam_release_batch.argtypes = [vp, C.POINTER(BatchResult)]
         L.kslam_load_reads.argtypes = [vp, u64, vp, vp]
         L.kslam_load_reads_device.argtypes = [vp, u64, vp, vp]
         L.kslam_align_resident.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
@@ -257,6 +277,72 @@ class Context:
             release()
             return ov, cg
         return ov, cg, release
+
+    # ---- per-row details for the SAM writer ----
+    def load_qualities(self, quals):
+        """kslam_load_qualities from a list of bytes (same lengths as the loaded reads)"""
+        cat = np.frombuffer(b"".join(quals) + b"\0", dtype=np.uint8)
+        self._chk(self._L.kslam_load_qualities(self._h, cat.ctypes.data))
+
+    def load_qualities_array(self, cat_u8):
+        self._chk(self._L.kslam_load_qualities(self._h, cat_u8.ctypes.data))
+
+    def load_qualities_device(self, dev_ptr):
+        self._chk(self._L.kslam_load_qualities_device(self._h, dev_ptr))
+
+    def row_details(self):
+        n = C.c_uint64()
+        self._chk(self._L.kslam_row_details(self._h, C.byref(n)))
+        return int(n.value)
+
+    def take_row_details(self, n_rows, copy=True):
+        """kslam_take_row_details -> (details[ROW_DETAIL_DT], md_pool[uint8][, release])"""
+        pd, pm, nm = C.c_void_p(), C.c_void_p(), C.c_uint64()
+        self._chk(self._L.kslam_take_row_details(self._h, C.byref(pd), C.byref(pm), C.byref(nm)))
+        det = np.frombuffer((C.c_char * (n_rows * 32)).from_address(pd.value), dtype=ROW_DETAIL_DT) \
+            if n_rows else np.zeros(0, dtype=ROW_DETAIL_DT)
+        md = np.frombuffer((C.c_char * int(nm.value)).from_address(pm.value), dtype=np.uint8) \
+            if nm.value else np.zeros(0, dtype=np.uint8)
+
+        def release():
+            self._L.kslam_free_pinned(self._h, pd)
+            self._L.kslam_free_pinned(self._h, pm)
+        if copy:
+            det, md = det.copy(), md.copy()
+            release()
+            return det, md
+        return det, md, release
+
+    def submit_batch_full(self, n_reads, bases_pp, quals_pp, lens_p):
+        """kslam_submit_batch on ready pointer arrays (quals_pp may be None)"""
+        t = C.c_uint64()
+        self._chk(self._L.kslam_submit_batch(self._h, n_reads, bases_pp, quals_pp, lens_p, C.byref(t)))
+        return int(t.value)
+
+    def submit_batch_columns(self, n_reads, bases_p, quality_p, offsets_p):
+        """kslam_submit_batch_columns: addresses of the concatenated bases / qualities and the uint64 offsets;
+        they must stay valid until collect_batch"""
+        t = C.c_uint64()
+        self._chk(self._L.kslam_submit_batch_columns(self._h, n_reads, bases_p, quality_p, offsets_p, C.byref(t)))
+        return int(t.value)
+
+    def collect_batch(self, ticket):
+        """kslam_collect_batch -> (overlaps, cigar_pool, details, md_pool, release): views of the library's
+        page-locked buffers (details / md_pool empty when no qualities were submitted)"""
+        r = BatchResult()
+        self._chk(self._L.kslam_collect_batch(self._h, ticket, C.byref(r)))
+
+        def view(ptr, n, dt):
+            return np.frombuffer((C.c_char * (int(n) * dt.itemsize)).from_address(ptr), dtype=dt) \
+                if n and ptr else np.zeros(0, dtype=dt)
+        ov = view(r.overlaps, r.n_overlaps, OVERLAP_DT)
+        cg = view(r.cigar_pool, r.n_cigar, np.dtype(np.uint32))
+        det = view(r.details, r.n_overlaps if r.details else 0, ROW_DETAIL_DT)
+        md = view(r.md_pool, r.n_md, np.dtype(np.uint8))
+
+        def release():
+            self._L.kslam_release_batch(self._h, C.byref(r))
+        return ov, cg, det, md, release
 
     def load_reads(self, reads):
         cat, off = _concat(reads)

@@ -256,4 +256,15 @@ void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, u
 void cigar_finalize(kslam_overlap *d_ov, uint64_t n, SwInputs in, uint32_t lmax, CigarWork &W,
                     const uint32_t *d_bw, uint32_t *d_pool, uint64_t pool_base, uint64_t *d_cells, hipStream_t s);
 
+// ------------------------------------------------------------- details.hip
+struct DetailWork {
+  DevBuf lens, off, slots, scan_tmp, totals, md_pool;
+};
+// NM / log-probability / MD text of every row (see details.hip); d_tables = matchTable[100] then
+// misMatchTable[100] of reference src/SAM.h:33-48, computed by the host
+void row_details(const kslam_overlap *d_ov, uint64_t n, const uint32_t *d_pool, const uint8_t *d_rbases,
+                 const uint8_t *d_rqual, const uint64_t *d_roff, const uint8_t *d_gbases, const uint64_t *d_goff,
+                 const double *d_tables, kslam_row_detail *d_out, DetailWork &W, uint8_t **d_md_pool_out,
+                 uint64_t *n_md_out, uint32_t *flags_out, hipStream_t s);
+
 }  // namespace kslam

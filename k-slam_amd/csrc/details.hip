@@ -1,0 +1,246 @@
+// details.hip -- what the SAM writer needs to know about an alignment beyond its CIGAR: the MD tag,
+// the edit distance NM and the log-probability of the read given the alignment.
+//
+// Replaces the walk of getCigarAndMD (reference src/SAM.h:101-237) over CIGAR + read + quality + entry
+// bases.  On the host that walk is bound by scattered reads into a multi-gigabyte database (3 M random
+// 150-byte windows per batch); here reads, qualities, entries and CIGARs are in HBM
+// already, one thread walks one alignment, and the host tail receives per row
+//   nm      -- mismatching M columns + inserted + deleted bases                 (SAM.h:150,169,181)
+//   logp    -- sum over the M columns, IN COLUMN ORDER, of matchTable[q] / misMatchTable[q]
+//              (SAM.h:146-152; the tables of SAM.h:33-48 are computed on the host with libm and handed
+//              in, and a chain of IEEE double additions in a fixed order is the same on every machine)
+//   MD text -- the merged components of SAM.h:204-235: match counts added up, mismatched reference bases,
+//              ^deleted bases, a "0" between a deletion and a mismatch
+// Semantics kept: the query is the read, or its reverse complement with only upper-case A/C/G/T
+// complemented (reverseComplement, src/sequenceTools.h:77-116) and the quality string reversed
+// (SAM.h:113-116); columns compare raw characters (SAM.h:144); the walk starts at ref_begin and at
+// query position query_begin (SAM.h:118-125).
+//
+// MI355X: each lane streams three byte sequences (entry window, read, quality) with one unaligned
+// 16-byte load per 16 columns and stream; MD bytes go to a 48-byte slot per row first (it fits for all
+// but pathological rows), an exclusive scan of the lengths lays out the pool, and a gather pass moves the
+// slots into it (rows that did not fit are walked again, straight into the pool).
+#include "common.h"
+
+namespace kslam {
+
+namespace {
+
+constexpr uint32_t MD_SLOT = 48;
+
+struct __attribute__((packed, aligned(1))) Bytes16 {
+  uint32_t w[4];
+};
+__device__ inline uint32_t byte_of(const Bytes16 &v, int j) { return (v.w[j >> 2] >> (8 * (j & 3))) & 0xFFu; }
+
+// complement of reverseComplement: A<->T, C<->G, upper case only (src/sequenceTools.h:77-97)
+__device__ inline uint32_t complement(uint32_t c) {
+  const uint32_t at = (c == 'A' || c == 'T') ? (uint32_t)('A' ^ 'T') : 0u;
+  const uint32_t cg = (c == 'C' || c == 'G') ? (uint32_t)('C' ^ 'G') : 0u;
+  return c ^ at ^ cg;
+}
+
+struct MdOut {          // the streaming form of SAM.h:204-235 (host: MdWriter in host/tail.cpp)
+  uint8_t *dst;
+  uint32_t cap, n = 0;
+  uint32_t pending = 0;
+  bool have_pending = false, after_del = false;
+  __device__ void put(uint32_t c) {
+    if (n < cap) dst[n] = (uint8_t)c;
+    n++;
+  }
+  __device__ void num(uint32_t v) {
+    uint32_t d[10];
+    int k = 0;
+    do { d[k++] = v % 10u; v /= 10u; } while (v);
+    while (k) put('0' + d[--k]);
+  }
+  __device__ void matches(uint32_t run) {
+    if (run) { pending += run; have_pending = true; }
+  }
+  __device__ void flush() {
+    if (have_pending) { num(pending); pending = 0; have_pending = false; after_del = false; }
+  }
+  __device__ void mismatch(uint32_t ref_base) {
+    flush();
+    if (after_del) { put('0'); after_del = false; }
+    put(ref_base);
+  }
+};
+
+struct WalkResult {
+  double logp;
+  uint32_t nm, md_len, flags;
+};
+
+// flags: 1 = a quality character outside phred+33 0..99 (the host tail rejects the batch when it needs
+// that probability), 2 = the CIGAR runs past the read or the entry (the host tail rejects the batch)
+__device__ inline WalkResult walk_row(const kslam_overlap &o, const uint32_t *__restrict__ pool,
+                                      const uint8_t *__restrict__ rbases, const uint8_t *__restrict__ rqual,
+                                      const uint64_t *__restrict__ roff, const uint8_t *__restrict__ gbases,
+                                      const uint64_t *__restrict__ goff, const double *__restrict__ tab /*[200] LDS*/,
+                                      uint8_t *md_dst, uint32_t md_cap) {
+  WalkResult res{0.0, 0u, 0u, 0u};
+  if (o.cigar_len == 0) return res;
+  const uint64_t rb = roff[o.read];
+  const int64_t L = (int64_t)(roff[o.read + 1] - rb);
+  const uint64_t gb = goff[o.entry];
+  const int64_t ref_len = (int64_t)(goff[o.entry + 1] - gb);
+  const uint8_t *ref = gbases + gb;
+  const bool rc = o.revcomp != 0;
+  MdOut w;
+  w.dst = md_dst;
+  w.cap = md_cap;
+  int64_t rp = o.ref_begin, qp = o.query_begin > 0 ? o.query_begin : 0;
+  double logp = 0.0;
+  uint32_t nm = 0;
+  for (uint32_t k = 0; k < o.cigar_len; k++) {
+    const uint32_t c = pool[o.cigar_off + k], len = c >> 4, op = c & 15u;
+    if (op == 0) {
+      if (rp < 0 || qp < 0 || rp + (int64_t)len > ref_len || qp + (int64_t)len > L) { res.flags |= 2u; break; }
+      const int64_t at = rc ? L - 1 - qp : qp;         // index of column 0's base in the read
+      uint32_t run = 0;
+      for (uint32_t i0 = 0; i0 < len; i0 += 16) {
+        const uint32_t nn = min(16u, len - i0);
+        const Bytes16 R = *reinterpret_cast<const Bytes16 *>(ref + rp + i0);
+        // forward: bytes at .. at + 15; reverse: the 16 bytes ENDING at `at - i0`, read back to front
+        const int64_t first = rc ? (int64_t)rb + at - (int64_t)i0 - 15 : (int64_t)rb + at + (int64_t)i0;
+        Bytes16 B, Q;
+        if (first >= 0) {
+          B = *reinterpret_cast<const Bytes16 *>(rbases + first);
+          Q = *reinterpret_cast<const Bytes16 *>(rqual + first);
+        } else {            // (reverse strand at the very start of the batch's first read: stay inside the array)
+#pragma unroll
+          for (int x = 0; x < 4; x++) B.w[x] = Q.w[x] = 0;
+          for (int j = 0; j < 16; j++)
+            if (first + j >= 0) {
+              B.w[j >> 2] |= (uint32_t)rbases[first + j] << (8 * (j & 3));
+              Q.w[j >> 2] |= (uint32_t)rqual[first + j] << (8 * (j & 3));
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+          if ((uint32_t)j < nn) {
+            const uint32_t r = byte_of(R, j);
+            const uint32_t qc = rc ? complement(byte_of(B, 15 - j)) : byte_of(B, j);
+            uint32_t q = (rc ? byte_of(Q, 15 - j) : byte_of(Q, j)) - 33u;
+            if (q >= 100u) { res.flags |= 1u; q = 0; }
+            if (r == qc) {
+              run++;
+              logp += tab[q];
+            } else {
+              nm++;
+              w.matches(run);
+              w.mismatch(r);
+              logp += tab[100 + q];
+              run = 0;
+            }
+          }
+        }
+      }
+      w.matches(run);
+      rp += len;
+      qp += len;
+    } else if (op == 1) {
+      nm += len;
+      qp += len;
+    } else if (op == 2) {
+      if (rp < 0 || rp + (int64_t)len > ref_len) { res.flags |= 2u; break; }
+      w.flush();
+      w.put('^');
+      for (uint32_t i = 0; i < len; i++) w.put(ref[rp + i]);
+      w.after_del = true;
+      rp += len;
+      nm += len;
+    }
+  }
+  w.flush();
+  res.logp = logp;
+  res.nm = nm;
+  res.md_len = w.n;
+  return res;
+}
+
+__global__ __launch_bounds__(256) void k_row_details(const kslam_overlap *__restrict__ ov, uint64_t n,
+                                                     const uint32_t *__restrict__ pool, const uint8_t *__restrict__ rbases,
+                                                     const uint8_t *__restrict__ rqual, const uint64_t *__restrict__ roff,
+                                                     const uint8_t *__restrict__ gbases, const uint64_t *__restrict__ goff,
+                                                     const double *__restrict__ tables, kslam_row_detail *__restrict__ out,
+                                                     uint32_t *__restrict__ md_lens, uint8_t *__restrict__ slots,
+                                                     uint32_t *__restrict__ flags_or) {
+  __shared__ double tab[200];
+  for (uint32_t k = threadIdx.x; k < 200; k += blockDim.x) tab[k] = tables[k];
+  __syncthreads();
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const kslam_overlap o = ov[i];
+  const WalkResult r = walk_row(o, pool, rbases, rqual, roff, gbases, goff, tab, slots + i * MD_SLOT, MD_SLOT);
+  kslam_row_detail d;
+  d.logp = r.logp;
+  d.md_off = 0;
+  d.md_len = r.md_len;
+  d.nm = r.nm;
+  d.flags = r.flags;
+  d.pad = 0;
+  out[i] = d;
+  md_lens[i] = r.md_len;
+  if (r.flags) atomicOr(flags_or, r.flags);
+}
+
+__global__ __launch_bounds__(256) void k_md_gather(const kslam_overlap *__restrict__ ov, uint64_t n,
+                                                   const uint32_t *__restrict__ pool, const uint8_t *__restrict__ rbases,
+                                                   const uint8_t *__restrict__ rqual, const uint64_t *__restrict__ roff,
+                                                   const uint8_t *__restrict__ gbases, const uint64_t *__restrict__ goff,
+                                                   const double *__restrict__ tables, kslam_row_detail *__restrict__ out,
+                                                   const uint64_t *__restrict__ md_off, const uint8_t *__restrict__ slots,
+                                                   uint8_t *__restrict__ md_pool) {
+  __shared__ double tab[200];
+  for (uint32_t k = threadIdx.x; k < 200; k += blockDim.x) tab[k] = tables[k];
+  __syncthreads();
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t len = out[i].md_len;
+  const uint64_t off = md_off[i];
+  out[i].md_off = off;
+  if (len <= MD_SLOT) {
+    const uint8_t *src = slots + i * MD_SLOT;
+    for (uint32_t j = 0; j < len; j++) md_pool[off + j] = src[j];
+  } else {   // did not fit its slot: once more, straight into the pool
+    const kslam_overlap o = ov[i];
+    (void)walk_row(o, pool, rbases, rqual, roff, gbases, goff, tab, md_pool + off, len);
+  }
+}
+
+}  // namespace
+
+void row_details(const kslam_overlap *d_ov, uint64_t n, const uint32_t *d_pool, const uint8_t *d_rbases,
+                 const uint8_t *d_rqual, const uint64_t *d_roff, const uint8_t *d_gbases, const uint64_t *d_goff,
+                 const double *d_tables, kslam_row_detail *d_out, DetailWork &W, uint8_t **d_md_pool_out,
+                 uint64_t *n_md_out, uint32_t *flags_out, hipStream_t s) {
+  *n_md_out = 0;
+  *flags_out = 0;
+  *d_md_pool_out = nullptr;
+  if (n == 0) return;
+  W.lens.ensure((n + 1) * sizeof(uint32_t));
+  W.off.ensure((n + 1) * sizeof(uint64_t));
+  W.slots.ensure(n * MD_SLOT + 64);
+  W.scan_tmp.ensure(scan_tmp_bytes(n));
+  W.totals.ensure(4 * sizeof(uint64_t));
+  uint64_t *d_tot = W.totals.as<uint64_t>();
+  HIPCHK(hipMemsetAsync(d_tot, 0, 4 * sizeof(uint64_t), s));
+  const unsigned nb = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL(k_row_details, dim3(nb), dim3(256), 0, s, d_ov, n, d_pool, d_rbases, d_rqual, d_roff, d_gbases, d_goff,
+                     d_tables, d_out, W.lens.as<uint32_t>(), W.slots.as<uint8_t>(), reinterpret_cast<uint32_t *>(d_tot + 1));
+  exclusive_scan_u32_to_u64(W.lens.as<uint32_t>(), W.off.as<uint64_t>(), n, d_tot, W.scan_tmp.p, s);
+  uint64_t h[2] = {0, 0};
+  read_back(h, d_tot, sizeof h, s);
+  W.md_pool.ensure(h[0] + 64);
+  hipLaunchKernelGGL(k_md_gather, dim3(nb), dim3(256), 0, s, d_ov, n, d_pool, d_rbases, d_rqual, d_roff, d_gbases, d_goff,
+                     d_tables, d_out, W.off.as<uint64_t>(), W.slots.as<uint8_t>(), W.md_pool.as<uint8_t>());
+  HIPCHK(hipGetLastError());
+  *d_md_pool_out = W.md_pool.as<uint8_t>();
+  *n_md_out = h[0];
+  *flags_out = (uint32_t)h[1];
+}
+
+}  // namespace kslam

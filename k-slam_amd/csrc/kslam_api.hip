@@ -8,8 +8,10 @@
 #include <sys/mman.h>
 
 #include "common.h"
+#include "../host/workers.hpp"
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <condition_variable>
 #include <deque>
 #include <map>
@@ -63,6 +65,14 @@ struct kslam_ctx {
   std::vector<Pinned> pinned;
   std::mutex pin_mu;
 
+  // ---- per-row details for the SAM writer (details.hip) ----
+  DevBuf r_qual, d_tables, res_det;
+  bool have_qual = false, have_details = false;
+  uint8_t *d_md_pool = nullptr;   // inside detw.md_pool
+  uint64_t n_md = 0;
+  uint32_t det_flags = 0;
+  DetailWork detw;
+
   // ---- pipelined entry (kslam_align_batch_async): worker lanes, each a sibling context that BORROWS
   // this context's index (same device pointers, never freed by the sibling) ----
   bool borrowed_index = false;
@@ -70,12 +80,16 @@ struct kslam_ctx {
     uint64_t ticket = 0;
     uint64_t n_reads = 0;
     char *cat = nullptr;              // pinned, from the lane context's pool
+    char *qcat = nullptr;             // the quality strings, same layout (optional)
+    bool borrowed = false;            // cat / qcat / off_ptr are the caller's columns (kslam_submit_batch_columns)
+    const uint64_t *off_ptr = nullptr;
     std::vector<uint64_t> off;
     bool done = false;
     kslam_status st = KSLAM_OK;
     std::string err;
     kslam_overlap *out = nullptr; uint64_t n_out = 0;
     uint32_t *pool = nullptr; uint64_t n_cig = 0;
+    kslam_row_detail *det = nullptr; char *md = nullptr; uint64_t n_md = 0;
   };
   struct AsyncLane {
     kslam_ctx *c = nullptr;
@@ -404,6 +418,8 @@ void finish_load_reads(kslam_ctx *c) {
                             c->r_len.as<uint32_t>());
   HIPCHK(hipStreamSynchronize(s));
   c->have_reads = true;
+  c->have_qual = false;      // a new batch: its quality strings have not been loaded
+  c->have_details = false;
   c->n_res = 0;
   c->n_cig = 0;
 }
@@ -423,6 +439,7 @@ void align_resident(kslam_ctx *c, bool stop_after_join, uint64_t *n_raw_out) {
   tm.n_genome_kmers = c->n_gk;
   c->n_res = 0;
   c->n_cig = 0;
+  c->have_details = false;
   c->cells.ensure(sizeof(uint64_t));
   HIPCHK(hipMemsetAsync(c->cells.p, 0, sizeof(uint64_t), s));
   uint64_t n_raw_total = 0;
@@ -666,9 +683,12 @@ void lane_main(kslam_ctx *primary, kslam_ctx::AsyncLane *lane) {
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = now();
     double t1 = 0, t2 = 0, t3 = 0;
-    kslam_status st = kslam_load_reads(c, job->n_reads, job->cat, job->off.data());
+    kslam_status st = kslam_load_reads(c, job->n_reads, job->cat, job->borrowed ? job->off_ptr : job->off.data());
+    if (st == KSLAM_OK && job->qcat)
+      st = kslam_load_qualities(c, job->borrowed && job->n_reads ? job->qcat + job->off_ptr[0] : job->qcat);
+    if (job->qcat && !job->borrowed) { pinned_put(c, job->qcat); }
     t1 = now();
-    pinned_put(c, job->cat);
+    if (!job->borrowed) pinned_put(c, job->cat);
     job->cat = nullptr;
     if (st == KSLAM_OK) {
       // one lane computes at a time: the kernels of a batch fill the chip, so two batches computing at
@@ -679,9 +699,11 @@ void lane_main(kslam_ctx *primary, kslam_ctx::AsyncLane *lane) {
       std::lock_guard<std::mutex> compute(primary->as_compute);
       t2 = now();
       st = kslam_align_resident(c, nullptr, nullptr);
+      if (st == KSLAM_OK && job->qcat) st = kslam_row_details(c, nullptr);
     }
     t3 = now();
     if (st == KSLAM_OK) st = kslam_take_results(c, &job->out, &job->n_out, &job->pool, &job->n_cig);
+    if (st == KSLAM_OK && job->qcat) st = kslam_take_row_details(c, &job->det, &job->md, &job->n_md);
     if (dbg) fprintf(stderr, "[kslam] lane %p ticket %llu: upload %.2f, token wait %.2f, align %.2f, download %.2f ms\n", (void *)lane,
                      (unsigned long long)job->ticket, t1 - t0, t2 - t1, t3 - t2, now() - t3);
     {
@@ -692,6 +714,25 @@ void lane_main(kslam_ctx *primary, kslam_ctx::AsyncLane *lane) {
     }
     primary->as_cv.notify_all();
   }
+}
+
+
+void ensure_lanes(kslam_ctx *c) {
+  if (!c->lanes.empty()) return;
+  for (int k = 0; k < 2; k++) {
+    kslam_ctx *lc = nullptr;
+    const kslam_status s1 = kslam_create(&c->prm, &lc);
+    if (s1 != KSLAM_OK) {
+      const std::string msg = lc ? lc->err : "lane context";
+      kslam_destroy(lc);
+      throw StatusError{s1, msg};
+    }
+    share_index(lc, c);
+    auto *l = new kslam_ctx::AsyncLane();
+    l->c = lc;
+    c->lanes.push_back(l);
+  }
+  for (auto *l : c->lanes) l->th = std::thread(lane_main, c, l);
 }
 
 void stop_lanes(kslam_ctx *c) {
@@ -740,6 +781,12 @@ kslam_status kslam_create(const kslam_params *params, kslam_ctx **out) {
   }
   kslam_status st = guarded(c, [&] {
     validate_params(c->prm);
+    // from now on the FASTQ parser's big column blocks are page-locked (DMA-able as they stand)
+    if (!getenv("KSLAM_PAGEABLE_COLUMNS")) {
+      kslam_host::BigAlloc &h = kslam_host::big_alloc_hook();
+      h.alloc = pinned_alloc;
+      h.release = pinned_free;
+    }
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     for (auto &ev : c->ev) HIPCHK(hipEventCreate(&ev));
     for (auto &ev : c->evs0) HIPCHK(hipEventCreate(&ev));
@@ -765,7 +812,8 @@ void kslam_destroy(kslam_ctx *c) {
                       &c->flags, &c->pos, &c->band0, &c->sortws.hist, &c->sortws.status, &c->sortws.tickets,
                       &c->cig.flags, &c->cig.pos, &c->cig.list, &c->cig.bmax, &c->cig.needbig,
                       &c->cig.scan_tmp, &c->cig.totals, &c->cig.cig_off, &c->cig.tmp, &c->cig.tmp_big,
-                      &c->cig.big_pos, &c->cig.scratch, &c->sww.flags, &c->sww.pos, &c->sww.list, &c->sww.list2, &c->sww.scan_tmp, &c->sww.totals, &c->cells, &c->res_ov, &c->res_cig, &c->res_tmp, &c->mg_shards, &c->mg_lens, &c->mg_off, &c->mg_scan};
+                      &c->cig.big_pos, &c->cig.scratch, &c->sww.flags, &c->sww.pos, &c->sww.list, &c->sww.list2, &c->sww.scan_tmp, &c->sww.totals, &c->cells, &c->res_ov, &c->res_cig, &c->res_tmp, &c->r_qual, &c->d_tables, &c->res_det, &c->detw.lens, &c->detw.off,
+                      &c->detw.slots, &c->detw.scan_tmp, &c->detw.totals, &c->detw.md_pool, &c->mg_shards, &c->mg_lens, &c->mg_off, &c->mg_scan};
     for (DevBuf *b : bufs) b->release();
     {
       std::lock_guard<std::mutex> lk(c->pin_mu);
@@ -951,33 +999,107 @@ void kslam_free_batch(kslam_ctx *c, kslam_overlap *out, uint32_t *cigar_pool) {
   give_back(cigar_pool);
 }
 
+kslam_status kslam_load_qualities(kslam_ctx *c, const char *concat_quality) {
+  return guarded(c, [&] {
+    if (!c->have_reads) throw StatusError{KSLAM_ERR_STATE, "kslam_load_reads first: the quality strings share its offsets"};
+    const uint64_t total = c->h_roff[c->n_reads];
+    if (total && !concat_quality) throw StatusError{KSLAM_ERR_ARG, "null quality"};
+    c->r_qual.ensure(total + 64);
+    if (total) HIPCHK(hipMemcpyAsync(c->r_qual.p, concat_quality, total, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemsetAsync(c->r_qual.as<uint8_t>() + total, 0, 64, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->have_qual = true;
+    c->have_details = false;
+  });
+}
+
+kslam_status kslam_load_qualities_device(kslam_ctx *c, const void *d_concat_quality) {
+  return guarded(c, [&] {
+    if (!c->have_reads) throw StatusError{KSLAM_ERR_STATE, "kslam_load_reads first: the quality strings share its offsets"};
+    const uint64_t total = c->h_roff[c->n_reads];
+    if (total && !d_concat_quality) throw StatusError{KSLAM_ERR_ARG, "null quality"};
+    c->r_qual.ensure(total + 64);
+    if (total) HIPCHK(hipMemcpyAsync(c->r_qual.p, d_concat_quality, total, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipMemsetAsync(c->r_qual.as<uint8_t>() + total, 0, 64, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->have_qual = true;
+    c->have_details = false;
+  });
+}
+
+kslam_status kslam_row_details(kslam_ctx *c, uint64_t *n_md) {
+  return guarded(c, [&] {
+    if (!c->have_qual) throw StatusError{KSLAM_ERR_STATE, "kslam_load_qualities has not been called for this batch"};
+    if (!c->d_tables.p) {
+      // matchTable / misMatchTable of src/SAM.h:33-48, with the host's libm (the values the host tail uses)
+      double t[200];
+      t[0] = std::log10(1.0 - std::pow(10.0, 1.0 / -10.0));
+      t[100] = 1 / -10.0;
+      for (int i = 1; i < 100; i++) {
+        t[i] = std::log10(1.0 - std::pow(10.0, i / -10.0));
+        t[100 + i] = i / -10.0;
+      }
+      c->d_tables.ensure(sizeof t);
+      HIPCHK(hipMemcpyAsync(c->d_tables.p, t, sizeof t, hipMemcpyHostToDevice, c->stream));
+      HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    c->res_det.ensure((c->n_res + 1) * sizeof(kslam_row_detail));
+    row_details(c->res_ov.as<kslam_overlap>(), c->n_res, c->res_cig.as<uint32_t>(), c->r_bases.as<uint8_t>(),
+                c->r_qual.as<uint8_t>(), c->r_off.as<uint64_t>(), c->g_bases.as<uint8_t>(), c->g_off.as<uint64_t>(),
+                c->d_tables.as<double>(), c->res_det.as<kslam_row_detail>(), c->detw, &c->d_md_pool, &c->n_md,
+                &c->det_flags, c->stream);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->have_details = true;
+    if (n_md) *n_md = c->n_md;
+  });
+}
+
+kslam_status kslam_take_row_details(kslam_ctx *c, kslam_row_detail **details, char **md_pool, uint64_t *n_md) {
+  if (!c || !details || !md_pool || !n_md) return KSLAM_ERR_ARG;
+  *details = nullptr; *md_pool = nullptr; *n_md = 0;
+  kslam_row_detail *hd = nullptr;
+  char *hm = nullptr;
+  kslam_status st = guarded(c, [&] {
+    if (!c->have_details) throw StatusError{KSLAM_ERR_STATE, "kslam_row_details has not been called for this result"};
+    hd = (kslam_row_detail *)pinned_get(c, (c->n_res + 1) * sizeof(kslam_row_detail));
+    hm = (char *)pinned_get(c, c->n_md + 64);
+    if (c->n_res) HIPCHK(hipMemcpyAsync(hd, c->res_det.p, c->n_res * sizeof(kslam_row_detail), hipMemcpyDeviceToHost, c->stream));
+    if (c->n_md) HIPCHK(hipMemcpyAsync(hm, c->d_md_pool, c->n_md, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+  });
+  if (st != KSLAM_OK) {
+    if (hd) pinned_put(c, hd);
+    if (hm) pinned_put(c, hm);
+    return st;
+  }
+  *details = hd; *md_pool = hm; *n_md = c->n_md;
+  return KSLAM_OK;
+}
+
+void kslam_free_pinned(kslam_ctx *c, void *p) {
+  if (!c || !p) return;
+  if (pinned_put(c, p)) return;
+  for (auto *l : c->lanes)
+    if (pinned_put(l->c, p)) return;
+}
+
 // ---- the operator, pipelined: batches alternate between two worker lanes (a host thread + a sibling
 // context with its own stream and work buffers each), so the upload of batch k+1 and the download of
 // batch k-1 run under the kernels of batch k, and one lane's host read-backs are covered by the other
 // lane's kernels ----
 kslam_status kslam_align_batch_async(kslam_ctx *c, uint64_t n_reads, const char *const *bases, const uint32_t *lens,
                                      uint64_t *ticket) {
+  return kslam_submit_batch(c, n_reads, bases, nullptr, lens, ticket);
+}
+
+kslam_status kslam_submit_batch(kslam_ctx *c, uint64_t n_reads, const char *const *bases, const char *const *quality,
+                                const uint32_t *lens, uint64_t *ticket) {
   if (!c || !ticket) return KSLAM_ERR_ARG;
   kslam_ctx::AsyncJob *job = nullptr;
   kslam_status st = guarded(c, [&] {
     if (n_reads && (!bases || !lens)) throw StatusError{KSLAM_ERR_ARG, "null bases/lens"};
     if (!c->have_index) throw StatusError{KSLAM_ERR_STATE, "kslam_set_index has not been called"};
-    if (c->lanes.empty()) {
-      for (int k = 0; k < 2; k++) {
-        kslam_ctx *lc = nullptr;
-        const kslam_status s1 = kslam_create(&c->prm, &lc);
-        if (s1 != KSLAM_OK) {
-          const std::string msg = lc ? lc->err : "lane context";
-          kslam_destroy(lc);
-          throw StatusError{s1, msg};
-        }
-        share_index(lc, c);
-        auto *l = new kslam_ctx::AsyncLane();
-        l->c = lc;
-        c->lanes.push_back(l);
-      }
-      for (auto *l : c->lanes) l->th = std::thread(lane_main, c, l);
-    }
+    ensure_lanes(c);
     job = new kslam_ctx::AsyncJob();
     job->n_reads = n_reads;
     job->off.assign(n_reads + 1, 0);
@@ -994,19 +1116,28 @@ kslam_status kslam_align_batch_async(kslam_ctx *c, uint64_t n_reads, const char 
   kslam_ctx::AsyncLane *lane = c->lanes[tk % c->lanes.size()];
   st = guarded(c, [&] {
     job->cat = (char *)pinned_get(lane->c, job->off[n_reads] + 64);
+    if (quality) job->qcat = (char *)pinned_get(lane->c, job->off[n_reads] + 64);
     unsigned nt = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
     if (n_reads < 100000) nt = 1;
     std::vector<std::thread> th;
-    char *cat = job->cat;
+    char *cat = job->cat, *qcat = job->qcat;
     const std::vector<uint64_t> &off = job->off;
     for (unsigned t = 0; t < nt; t++) {
       const uint64_t lo = n_reads * t / nt, hi = n_reads * (t + 1) / nt;
-      auto work = [=, &off] { for (uint64_t i = lo; i < hi; i++) memcpy(cat + off[i], bases[i], lens[i]); };
+      auto work = [=, &off] {
+        for (uint64_t i = lo; i < hi; i++) memcpy(cat + off[i], bases[i], lens[i]);
+        if (qcat) for (uint64_t i = lo; i < hi; i++) memcpy(qcat + off[i], quality[i], lens[i]);
+      };
       if (nt == 1) work(); else th.emplace_back(work);
     }
     for (auto &x : th) x.join();
   });
-  if (st != KSLAM_OK) { if (job->cat) pinned_put(lane->c, job->cat); delete job; return st; }
+  if (st != KSLAM_OK) {
+    if (job->cat) pinned_put(lane->c, job->cat);
+    if (job->qcat) pinned_put(lane->c, job->qcat);
+    delete job;
+    return st;
+  }
   job->ticket = tk;
   {
     std::lock_guard<std::mutex> lk(c->as_mu);
@@ -1018,10 +1149,59 @@ kslam_status kslam_align_batch_async(kslam_ctx *c, uint64_t n_reads, const char 
   return KSLAM_OK;
 }
 
+kslam_status kslam_submit_batch_columns(kslam_ctx *c, uint64_t n_reads, const char *bases, const char *quality,
+                                        const uint64_t *offsets, uint64_t *ticket) {
+  if (!c || !ticket) return KSLAM_ERR_ARG;
+  kslam_ctx::AsyncJob *job = nullptr;
+  kslam_status st = guarded(c, [&] {
+    if (n_reads && (!bases || !offsets)) throw StatusError{KSLAM_ERR_ARG, "null bases/offsets"};
+    if (!c->have_index) throw StatusError{KSLAM_ERR_STATE, "kslam_set_index has not been called"};
+    ensure_lanes(c);
+    job = new kslam_ctx::AsyncJob();
+    job->n_reads = n_reads;
+    job->borrowed = true;
+    job->cat = const_cast<char *>(bases);
+    job->qcat = const_cast<char *>(quality);
+    job->off_ptr = offsets;
+  });
+  if (st != KSLAM_OK) { delete job; return st; }
+  uint64_t tk;
+  {
+    std::lock_guard<std::mutex> lk(c->as_mu);
+    tk = c->next_ticket++;
+    job->ticket = tk;
+    c->jobs[tk] = job;
+    c->lanes[tk % c->lanes.size()]->q.push_back(job);
+  }
+  c->as_cv.notify_all();
+  *ticket = tk;
+  return KSLAM_OK;
+}
+
 kslam_status kslam_wait_batch(kslam_ctx *c, uint64_t ticket, kslam_overlap **out, uint64_t *n_out, uint32_t **cigar_pool,
                               uint64_t *n_cigar) {
   if (!c || !out || !n_out || !cigar_pool || !n_cigar) return KSLAM_ERR_ARG;
   *out = nullptr; *cigar_pool = nullptr; *n_out = 0; *n_cigar = 0;
+  kslam_batch_result r;
+  const kslam_status st = kslam_collect_batch(c, ticket, &r);
+  if (st != KSLAM_OK) return st;
+  kslam_free_pinned(c, r.details);
+  kslam_free_pinned(c, r.md_pool);
+  *out = r.overlaps; *n_out = r.n_overlaps; *cigar_pool = r.cigar_pool; *n_cigar = r.n_cigar;
+  return KSLAM_OK;
+}
+
+void kslam_release_batch(kslam_ctx *c, kslam_batch_result *r) {
+  if (!c || !r) return;
+  kslam_free_batch(c, r->overlaps, r->cigar_pool);
+  kslam_free_pinned(c, r->details);
+  kslam_free_pinned(c, r->md_pool);
+  memset(r, 0, sizeof *r);
+}
+
+kslam_status kslam_collect_batch(kslam_ctx *c, uint64_t ticket, kslam_batch_result *res) {
+  if (!c || !res) return KSLAM_ERR_ARG;
+  memset(res, 0, sizeof *res);
   kslam_ctx::AsyncJob *job = nullptr;
   {
     std::unique_lock<std::mutex> lk(c->as_mu);
@@ -1033,9 +1213,13 @@ kslam_status kslam_wait_batch(kslam_ctx *c, uint64_t ticket, kslam_overlap **out
   }
   const kslam_status st = job->st;
   if (st == KSLAM_OK) {
-    *out = job->out; *n_out = job->n_out; *cigar_pool = job->pool; *n_cigar = job->n_cig;
+    res->overlaps = job->out; res->n_overlaps = job->n_out; res->cigar_pool = job->pool; res->n_cigar = job->n_cig;
+    res->details = job->det; res->md_pool = job->md; res->n_md = job->n_md;
   } else {
     c->err = job->err;
+    kslam_free_batch(c, job->out, job->pool);
+    kslam_free_pinned(c, job->det);
+    kslam_free_pinned(c, job->md);
   }
   delete job;
   return st;

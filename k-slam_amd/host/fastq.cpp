@@ -192,7 +192,11 @@ struct BlockCache {
     void *p;
     size_t cap;
     bool in_use;
+    void (*release)(void *, size_t);   // nullptr: free()
   };
+  static void drop(const Block &b) {
+    if (b.release) b.release(b.p, b.cap); else free(b.p);
+  }
   std::mutex m;
   std::vector<Block> blocks;
   void *get(size_t bytes) {
@@ -206,17 +210,28 @@ struct BlockCache {
       return blocks[best].p;
     }
     const size_t cap = bytes + bytes / 8 + 64;
-    void *p = malloc(cap);
-    if (!p) fail(KSLAM_ERR_OOM, "out of host memory for the read columns");
-    advise_huge(p, cap);   // the tail walks these columns per alignment
+    // big blocks (bases, qualities, identifiers of a batch) come from the library's page-locked allocator
+    // once a GPU context has installed it (workers.hpp: big_alloc_hook), so they reach the device by DMA
+    const BigAlloc hook = big_alloc_hook();
+    void *p = nullptr;
+    void (*rel)(void *, size_t) = nullptr;
+    if (hook.alloc && cap >= (8u << 20)) {
+      p = hook.alloc(cap);
+      if (p) rel = hook.release;
+    }
+    if (!p) {
+      p = malloc(cap);
+      if (!p) fail(KSLAM_ERR_OOM, "out of host memory for the read columns");
+      advise_huge(p, cap);   // the tail walks these columns per alignment
+    }
     // replace a parked block that was too small, so the cache does not grow without bound
     for (auto &b : blocks)
       if (!b.in_use) {
-        free(b.p);
-        b = Block{p, cap, true};
+        drop(b);
+        b = Block{p, cap, true, rel};
         return p;
       }
-    blocks.push_back(Block{p, cap, true});
+    blocks.push_back(Block{p, cap, true, rel});
     return p;
   }
   void put(void *p) {
@@ -227,7 +242,7 @@ struct BlockCache {
     for (size_t i = 0; i < blocks.size(); i++)
       if (blocks[i].p == p) {
         if (parked >= 12) {  // two batches' worth of columns is plenty
-          free(p);
+          drop(blocks[i]);
           blocks.erase(blocks.begin() + i);
         } else
           blocks[i].in_use = false;

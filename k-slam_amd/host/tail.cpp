@@ -803,6 +803,11 @@ struct SamInput {
   uint64_t n_ov;
   const uint32_t *pool;
   uint64_t n_pool;
+  // per-row NM / log-probability / MD computed on the GPU (kslam_row_details, include/kslam.h); when
+  // present the writer never reads the entry bases
+  const kslam_row_detail *det = nullptr;
+  const char *md_pool = nullptr;
+  uint64_t n_md = 0;
 };
 
 struct Row {  // SAMEntry, src/SAM.h:238-277, text fields as slices of the task's scratch
@@ -972,6 +977,41 @@ bool cigar_and_md(const SamInput &in, const kslam_overlap &o, Text &scratch, Row
   const uint64_t qb = in.reads->quality_off[o.read];
   if (in.reads->quality_off[o.read + 1] - qb != L)
     fail(KSLAM_ERR_ARG, "quality string length differs from the read length");
+  if (in.det) {
+    // The walk over CIGAR + read + quality + entry bases was done on the GPU: NM, the log-probability
+    // (same tables, same order of additions) and the MD text come with the row; only the CIGAR text is
+    // formatted here, from the ops alone.
+    const kslam_row_detail &d = in.det[&o - in.ov];
+    if (d.flags & 2u) fail(KSLAM_ERR_ARG, "cigar runs past the end of the read or the entry");
+    if (d.md_off + d.md_len > in.n_md) fail(KSLAM_ERR_ARG, "MD slice outside the MD pool");
+    Text &cg = scratch;
+    if (o.query_begin > 0) {
+      cg.num((uint64_t)o.query_begin);
+      cg.put('S');
+    }
+    for (uint32_t k = 0; k < o.cigar_len; k++) {
+      const uint32_t c = in.pool[o.cigar_off + k], len = c >> 4, op = c & 15;
+      cg.num(len);
+      if (op < 3) cg.put("MID"[op]);
+    }
+    const int64_t tail = (int64_t)L - o.query_end - 1;
+    if (tail > 0) {
+      cg.num((uint64_t)tail);
+      cg.put('S');
+    }
+    r.cigar_len = cg.n - r.cigar_at;
+    r.md_at = cg.n;
+    cg.put(in.md_pool + d.md_off, d.md_len);
+    r.md_len = d.md_len;
+    r.nm = d.nm;
+    // 10^logp only where its value matters: when it is summed with other rows' (want_prob), or when
+    // it could underflow to 0 (then prob / prob is 0 / 0 in the reference, not 1)
+    if (want_prob || d.logp <= -300.0) {
+      if (d.flags & 1u) fail(KSLAM_ERR_ARG, "quality character outside phred+33 0..99");
+      r.prob = std::pow(10, d.logp);
+    }
+    return true;
+  }
   const char *bases = in.reads->bases + rb, *qual = in.reads->quality + qb;
   const char *ref = in.index->bases + in.index->bases_off[o.entry];
   const int64_t ref_len = (int64_t)(in.index->bases_off[o.entry + 1] - in.index->bases_off[o.entry]);
@@ -1339,6 +1379,16 @@ inline void prefetch_overlaps(const SamInput &in, const Group &g, const Rec *rec
 }
 inline void prefetch_windows(const SamInput &in, const Group &g, const Rec *recs) {
   if (!in.pool) return;
+  if (in.det) {   // no entry window to fetch: the row's detail record, its MD bytes and its CIGAR ops
+    const size_t n = std::min<size_t>(g.count, std::max<uint32_t>(in.p->num_sam_alignments, 1));
+    for (size_t k = 0; k < n; k++)
+      for (uint32_t idx : {recs[k].r1, recs[k].r2}) {
+        if (idx == KSLAM_NO_OVERLAP || idx >= in.n_ov) continue;
+        __builtin_prefetch(&in.det[idx]);
+        __builtin_prefetch(in.pool + in.ov[idx].cigar_off);
+      }
+    return;
+  }
   const size_t n = std::min<size_t>(g.count, std::max<uint32_t>(in.p->num_sam_alignments, 1));
   for (size_t k = 0; k < n; k++)
     for (uint32_t idx : {recs[k].r1, recs[k].r2}) {
@@ -1433,7 +1483,8 @@ Input make_input(const kslam_tail_params *p, const kslam_reads_view *reads, cons
 void tail_to_sam(const kslam_tail_params *params, const kslam_reads_view *reads,
                  const kslam_index_view *index, const kslam_overlap *overlaps, uint64_t n_overlaps,
                  const uint32_t *cigar_pool, uint64_t n_cigar, const SamSink &sink,
-                 kslam_tail_stats *stats) {
+                 kslam_tail_stats *stats, const kslam_row_detail *det = nullptr, const char *md_pool = nullptr,
+                 uint64_t n_md = 0) {
   Input in = make_input(params, reads, overlaps, n_overlaps);
   Arena &A = arena();
   std::lock_guard<std::mutex> one(A.call);
@@ -1442,6 +1493,12 @@ void tail_to_sam(const kslam_tail_params *params, const kslam_reads_view *reads,
   memset(&st, 0, sizeof st);
   run_tail(in, A, ts, st);
   SamInput si{params, reads, index, overlaps, n_overlaps, cigar_pool, n_cigar};
+  if (det && cigar_pool) {
+    if (!md_pool && n_md) fail(KSLAM_ERR_ARG, "null MD pool");
+    si.det = det;
+    si.md_pool = md_pool;
+    si.n_md = n_md;
+  }
   double t0 = now_ms();
   sam_stage(si, A, in.threads, ts.groups, ts.n_groups, ts.recs, sink, &st.sam_bytes);
   st.ms_sam = now_ms() - t0;
@@ -1547,6 +1604,34 @@ kslam_status kslam_tail_sam_write(const kslam_tail_params *params, const kslam_r
     sink.write = write;
     sink.user = user;
     tail_to_sam(params, reads, index, overlaps, n_overlaps, cigar_pool, n_cigar, sink, stats);
+  });
+}
+
+kslam_status kslam_tail_sam_rows(const kslam_tail_params *params, const kslam_reads_view *reads,
+                                 const kslam_index_view *index, const kslam_overlap *overlaps,
+                                 uint64_t n_overlaps, const uint32_t *cigar_pool, uint64_t n_cigar,
+                                 const kslam_row_detail *details, const char *md_pool, uint64_t n_md,
+                                 char **text, uint64_t *text_len, kslam_tail_stats *stats) {
+  return guarded([&] {
+    if (!text || !text_len) fail(KSLAM_ERR_ARG, "null output argument");
+    SamSink sink;
+    sink.text = text;
+    sink.text_len = text_len;
+    tail_to_sam(params, reads, index, overlaps, n_overlaps, cigar_pool, n_cigar, sink, stats, details, md_pool, n_md);
+  });
+}
+
+kslam_status kslam_tail_sam_write_rows(const kslam_tail_params *params, const kslam_reads_view *reads,
+                                       const kslam_index_view *index, const kslam_overlap *overlaps,
+                                       uint64_t n_overlaps, const uint32_t *cigar_pool, uint64_t n_cigar,
+                                       const kslam_row_detail *details, const char *md_pool, uint64_t n_md,
+                                       kslam_write_fn write, void *user, kslam_tail_stats *stats) {
+  return guarded([&] {
+    if (!write) fail(KSLAM_ERR_ARG, "null writer");
+    SamSink sink;
+    sink.write = write;
+    sink.user = user;
+    tail_to_sam(params, reads, index, overlaps, n_overlaps, cigar_pool, n_cigar, sink, stats, details, md_pool, n_md);
   });
 }
 

@@ -132,6 +132,19 @@ class Pool {
 // The host stages walk multi-hundred-megabyte arrays at random -- overlap records, alignment pairs,
 // the genome columns -- and with 4 KiB pages nearly every such access also misses the TLB.  Must be
 // called before the block is first touched to take effect at once; harmless otherwise.
+// Allocator of the big column blocks the host stages hand out (FASTQ columns).  Plain malloc + huge-page
+// advice by default; once a GPU context exists the HIP side of the library installs page-locked
+// allocation (kslam_api.hip: pinned_alloc), so that those columns go to the device by DMA straight from
+// where the parser wrote them (kslam_submit_batch_columns) instead of through a gather copy.
+struct BigAlloc {
+  void *(*alloc)(size_t) = nullptr;   // nullptr: malloc
+  void (*release)(void *, size_t) = nullptr;
+};
+inline BigAlloc &big_alloc_hook() {
+  static BigAlloc h;
+  return h;
+}
+
 inline void advise_huge(void *p, size_t bytes) {
 #if defined(__linux__) && defined(MADV_HUGEPAGE)
   constexpr uintptr_t HP = 2u << 20;

@@ -21,7 +21,8 @@ assert PAIRED_OVERLAP_DT.itemsize == 32 and READ_PAIR_DT.itemsize == 24
 
 # every symbol include/kslam_tail.h declares
 EXPORTS = ["kslam_tail_last_error", "kslam_tail_pairs", "kslam_sam_records", "kslam_tail_sam",
-           "kslam_tail_sam_write", "kslam_tail_release_buffers", "kslam_sam_header"]
+           "kslam_tail_sam_write", "kslam_tail_sam_rows", "kslam_tail_sam_write_rows", "kslam_tail_release_buffers",
+           "kslam_sam_header"]
 WRITE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64)
 
 _vp, _u64, _u32, _i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int32
@@ -177,6 +178,10 @@ def lib():
                                      P(_vp), P(_u64), P(TailStats)]
         L.kslam_tail_sam_write.argtypes = [P(TailParams), P(ReadsView), P(IndexView), _vp, _u64, _vp, _u64,
                                            WRITE_FN, _vp, P(TailStats)]
+        L.kslam_tail_sam_rows.argtypes = [P(TailParams), P(ReadsView), P(IndexView), _vp, _u64, _vp, _u64,
+                                          _vp, _vp, _u64, P(_vp), P(_u64), P(TailStats)]
+        L.kslam_tail_sam_write_rows.argtypes = [P(TailParams), P(ReadsView), P(IndexView), _vp, _u64, _vp, _u64,
+                                                _vp, _vp, _u64, WRITE_FN, _vp, P(TailStats)]
         L.kslam_tail_release_buffers.restype = None
         L.kslam_sam_header.argtypes = [P(IndexView), C.c_char_p, P(_vp), P(_u64)]
         _lib = L
@@ -265,6 +270,36 @@ def tail_sam_discard(params, reads, index, overlaps, cigar_pool):
     cb = WRITE_FN(lambda user, data, n: 0)
     _chk(L.kslam_tail_sam_write(C.byref(params), C.byref(reads.view), C.byref(index.view), pov, len(ov),
                                 _p(pool) if len(pool) else None, len(pool), cb, None, C.byref(st)))
+    return st
+
+
+def tail_sam_rows(params, reads, index, overlaps, cigar_pool, details, md_pool):
+    """kslam_tail_sam_rows: as tail_sam with the per-row details of kslam_row_details (ROW_DETAIL_DT array +
+    MD bytes as a uint8 array) -> (SAM records as bytes, stats)"""
+    L = lib()
+    ov, pov = _ov(overlaps)
+    pool = np.ascontiguousarray(cigar_pool, dtype=np.uint32)
+    det = np.ascontiguousarray(details)
+    md = np.ascontiguousarray(md_pool, dtype=np.uint8)
+    txt, n, st = _vp(), _u64(), TailStats()
+    _chk(L.kslam_tail_sam_rows(C.byref(params), C.byref(reads.view), C.byref(index.view), pov, len(ov),
+                               _p(pool) if len(pool) else None, len(pool), _p(det) if len(det) else None,
+                               _p(md) if len(md) else None, len(md), C.byref(txt), C.byref(n), C.byref(st)))
+    return _text(txt, n), st
+
+
+def tail_sam_discard_rows(params, reads, index, overlaps, cigar_pool, details, md_pool):
+    """kslam_tail_sam_write_rows with a writer that drops the text (timing runs) -> stats"""
+    L = lib()
+    ov, pov = _ov(overlaps)
+    pool = np.ascontiguousarray(cigar_pool, dtype=np.uint32)
+    det = np.ascontiguousarray(details)
+    md = np.ascontiguousarray(md_pool, dtype=np.uint8)
+    st = TailStats()
+    cb = WRITE_FN(lambda user, data, n: 0)
+    _chk(L.kslam_tail_sam_write_rows(C.byref(params), C.byref(reads.view), C.byref(index.view), pov, len(ov),
+                                     _p(pool) if len(pool) else None, len(pool), _p(det) if len(det) else None,
+                                     _p(md) if len(md) else None, len(md), cb, None, C.byref(st)))
     return st
 
 

@@ -125,6 +125,33 @@ def test_fastq_and_database_files_to_sam_and_per_read_taxa(kslam, oracle, synth,
     assert per_read == eper_read
     assert summary == oracle.taxonomy_summary(otree, etax, n_pairs)
     assert header == oracle.sam_header(oI.view, b"SLAM --db db R1.fq R2.fq")
+    # ---- the same SAM text with NM / log-probability / MD computed on the GPU (kslam_row_details):
+    # qualities straight from the parsed batch's column, rows checked against the restatement of the
+    # reference's walk, and the writer given an index whose bases it must not need ----
+    from rowdetails_ref import row_details
+    qcol = np.frombuffer(b"".join(batch.quality) + b"\0", dtype=np.uint8)
+    ctx.load_qualities_array(qcol)
+    ctx.row_details()
+    det, md = ctx.take_row_details(len(ov))
+    edet, emd = row_details(eal, ecig, b1 + b2, q1 + q2, ogb, kslam.ROW_DETAIL_DT)
+    for f in ("nm", "md_len", "md_off", "flags"):
+        assert (det[f] == edet[f]).all(), f
+    assert (det["logp"].view(np.uint64) == edet["logp"].view(np.uint64)).all()      # the same double, bit for bit
+    assert md.tobytes() == emd.tobytes() and (det["nm"] > 0).sum() > 1000
+    blind = T.Index([bytes(len(g)) for g in ogb], locus_tags=[e["locusTag"] for e in oentries],
+                    taxonomy_ids=[e["taxonomyID"] for e in oentries],
+                    genes=[[(g["start"], g["stop"], g["geneName"], g["proteinID"], g["product"]) for g in e["genes"]]
+                           for e in oentries])
+    sam2, _ = T.tail_sam_rows(P, batch, blind, ov, cg, det, md)
+    assert sam2 == esam
+    # ---- and through the pipelined column entry: the parser's (page-locked) columns are not copied ----
+    cols = batch._cols
+    tk = [ctx.submit_batch_columns(batch.n_reads, cols.bases, cols.quality, cols.bases_off) for _ in range(3)]
+    for t in tk:
+        o3, c3, d3, m3, rel3 = ctx.collect_batch(t)
+        assert o3.tobytes() == ov.tobytes() and c3.tobytes() == cg.tobytes()
+        assert d3.tobytes() == det.tobytes() and m3.tobytes() == md.tobytes()
+        rel3()
     release()
     ctx.close()
     batch.close()

@@ -268,6 +268,65 @@ def test_pipelined_entry_gives_the_same_batches(kslam, synth):
     c.close()
 
 
+@pytest.mark.parametrize("read_len,odd", [(150, False), (100, True), (250, False)])
+def test_row_details_equal_the_reference_walk(kslam, synth, read_len, odd):
+    """kslam_row_details (NM, log-probability, MD text per overlap record) against the plain restatement of
+    getCigarAndMD's walk (src/SAM.h:101-237, tests/rowdetails_ref.py): indels, clipped ends, reads over
+    the entry ends, both strands, odd characters, qualities over the whole phred range; and the pipelined
+    entry returns the same rows."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from rowdetails_ref import row_details
+    rng = np.random.default_rng(77 + read_len)
+    genomes = synth.make_genomes(500 + read_len, 3, 3, 25000, strain_sub=0.02, strain_indel=0.002, shared_segment=2000)
+    reads, _ = synth.make_paired_reads(501 + read_len, genomes, 1200, read_len=read_len, frag_mean=2 * read_len + 60,
+                                       sub_rate=0.02, indel_rate=0.006, edge_frac=0.1, n_rate=0.002)
+    rb, gb = synth.to_bytes(reads), synth.to_bytes(genomes)
+    if odd:
+        gb = _sprinkle(rng, gb, 0.004, b"acgtNnUuRY-")
+        rb = _sprinkle(rng, rb, 0.006, b"acgtNnUuRY-")
+    quals = [bytes(rng.integers(33, 33 + 94, len(b), dtype=np.uint8)) for b in rb]
+    c = kslam.Context()
+    c.set_index(gb)
+    c.load_reads(rb)
+    n_out, n_cig = c.align_resident()
+    ov, cg = c.fetch_results(n_out, n_cig)
+    with pytest.raises(kslam.KslamError, match="load_qualities"):
+        c.row_details()
+    c.load_qualities(quals)
+    c.row_details()
+    det, md = c.take_row_details(n_out)
+    edet, emd = row_details(ov, cg, rb, quals, gb, kslam.ROW_DETAIL_DT)
+    assert (ov["revcomp"] == 1).sum() > 1000 and (ov["cigar_len"] > 1).sum() > 500 and (ov["query_begin"] > 0).sum() > 50
+    for f in ("nm", "md_len", "md_off", "flags"):
+        assert (det[f] == edet[f]).all(), f
+    assert (det["logp"].view(np.uint64) == edet["logp"].view(np.uint64)).all()
+    assert md.tobytes() == emd.tobytes()
+    # the pipelined entry with qualities: same rows
+    import ctypes as C
+    keep_b = [C.create_string_buffer(b, len(b) + 1) for b in rb]
+    keep_q = [C.create_string_buffer(q, len(q) + 1) for q in quals]
+    bp = (C.c_char_p * len(rb))(*[C.cast(x, C.c_char_p) for x in keep_b])
+    qp = (C.c_char_p * len(rb))(*[C.cast(x, C.c_char_p) for x in keep_q])
+    lens = np.array([len(b) for b in rb], dtype=np.uint32)
+    t1 = c.submit_batch_full(len(rb), C.cast(bp, C.c_void_p), C.cast(qp, C.c_void_p), lens.ctypes.data)
+    t2 = c.submit_batch_full(len(rb), C.cast(bp, C.c_void_p), None, lens.ctypes.data)
+    o1, c1, d1, m1, rel1 = c.collect_batch(t1)
+    o2, c2, d2, m2, rel2 = c.collect_batch(t2)
+    assert o1.tobytes() == ov.tobytes() and c1.tobytes() == cg.tobytes() and o2.tobytes() == ov.tobytes()
+    assert d1.tobytes() == det.tobytes() and m1.tobytes() == md.tobytes() and len(d2) == 0 and len(m2) == 0
+    rel1()
+    rel2()
+    # a quality character that is no phred+33 value, in an aligned column: flagged, not fatal here
+    bad = list(quals)
+    bad[int(ov["read"][0])] = b"\x10" * len(rb[int(ov["read"][0])])
+    c.load_qualities(bad)
+    c.row_details()
+    d3, _ = c.take_row_details(n_out)
+    assert (d3["flags"][ov["read"] == ov["read"][0]] & 1).all() and (d3["flags"] & 1).sum() < len(d3)
+    c.close()
+
+
 def test_empty_batch(kslam, synth):
     _, genomes, _ = _dataset(synth, 5, 1)
     ov, cg = kslam.align_to_database([], genomes)

@@ -265,6 +265,36 @@ def test_sam_text_matches_restatement_and_the_sam_definition(kslam, oracle, synt
     assert checked > 2 * n_pairs * 0.8 and primaries == st.n_read_pairs
 
 
+@pytest.mark.parametrize("kw", [{}, {"num_sam_alignments": 1}, {"paired": False}, {"score_threshold": 120}])
+def test_sam_from_precomputed_row_details_is_the_same_text(kslam, oracle, synth, T, kw):
+    """kslam_tail_sam_rows: NM / log-probability / MD handed in per row (what kslam_row_details computes
+    on the GPU; here from tests/rowdetails_ref.py) -> byte-identical SAM text, without the writer
+    touching the entry bases (the index view it gets holds garbage there)."""
+    from rowdetails_ref import row_details
+    n_pairs = 700
+    rb, gb, quals, R, I = _aligned_case(oracle, synth, T, 51, n_pairs, n_rate=0.004)
+    al, cig, _ = oracle.align_to_database(rb, gb, oracle.Params.default(score_threshold=kw.get("score_threshold", 0)))
+    det, md = row_details(al, cig, rb, quals, gb, kslam.ROW_DETAIL_DT)
+    assert (det["nm"] > 0).sum() > 500 and (det["md_len"] > 3).sum() > 500
+    P = T.TailParams.default(threads=3, **kw)
+    exp, _ = T.tail_sam(P, R, I, al, cig)
+    genes = [[(100 + 900 * k, 900 * k + 900, b"gene%d" % k, b"WP_%d" % k if k % 3 else b"", b"product %d" % k)
+              for k in range(20)] for _ in gb]
+    scrambled = T.Index([bytes(len(g)) for g in gb], locus_tags=[b"NC_%06d" % i for i in range(len(gb))],
+                        taxonomy_ids=[100 + i // 3 for i in range(len(gb))], genes=genes)
+    got, st = T.tail_sam_rows(P, R, scrambled, al, cig, det, md)
+    assert got == exp and len(got) > 100000
+    # errors travel: a row whose CIGAR ran off its read, a quality character that is no phred+33 value
+    bad = det.copy()
+    bad["flags"][:] = 2
+    with pytest.raises(kslam.KslamError, match="cigar runs past"):
+        T.tail_sam_rows(P, R, scrambled, al, cig, bad, md)
+    bad = det.copy()
+    bad["md_off"] += np.uint64(len(md))
+    with pytest.raises(kslam.KslamError, match="MD slice"):
+        T.tail_sam_rows(P, R, scrambled, al, cig, bad, md)
+
+
 def test_tail_with_score_threshold_and_n_bases(kslam, oracle, synth, T):
     rb, gb, quals, R, I = _aligned_case(oracle, synth, T, 21, 500, n_rate=0.01)
     al, cig, _ = oracle.align_to_database(rb, gb, oracle.Params.default(score_threshold=150))

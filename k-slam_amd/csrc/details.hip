@@ -118,25 +118,38 @@ __device__ inline WalkResult walk_row(const kslam_overlap &o, const uint32_t *__
               Q.w[j >> 2] |= (uint32_t)rqual[first + j] << (8 * (j & 3));
             }
         }
+        // Columns first, branch-free: the mismatch mask of the chunk and the probability chain (its
+        // additions stay in column order).  The MD bookkeeping then runs once per MISMATCH, not once per
+        // column: with 64 alignments per wave some lane mismatches in most columns, and the first
+        // version of this loop took the heavy path (number formatting) for nearly every column.
+        uint32_t miss = 0;
 #pragma unroll
         for (int j = 0; j < 16; j++) {
           if ((uint32_t)j < nn) {
             const uint32_t r = byte_of(R, j);
             const uint32_t qc = rc ? complement(byte_of(B, 15 - j)) : byte_of(B, j);
             uint32_t q = (rc ? byte_of(Q, 15 - j) : byte_of(Q, j)) - 33u;
-            if (q >= 100u) { res.flags |= 1u; q = 0; }
-            if (r == qc) {
-              run++;
-              logp += tab[q];
-            } else {
-              nm++;
-              w.matches(run);
-              w.mismatch(r);
-              logp += tab[100 + q];
-              run = 0;
-            }
+            const bool badq = q >= 100u;
+            res.flags |= badq ? 1u : 0u;
+            q = badq ? 0u : q;
+            const bool mm = r != qc;
+            miss |= (mm ? 1u : 0u) << j;
+            logp += tab[(mm ? 100u : 0u) + q];
           }
         }
+        uint32_t from = 0;
+        while (miss) {
+          const uint32_t kk = (uint32_t)__builtin_ctz(miss);
+          const uint32_t word = kk < 4 ? R.w[0] : (kk < 8 ? R.w[1] : (kk < 12 ? R.w[2] : R.w[3]));
+          run += kk - from;
+          nm++;
+          w.matches(run);
+          w.mismatch((word >> (8 * (kk & 3u))) & 0xFFu);
+          run = 0;
+          from = kk + 1;
+          miss &= miss - 1;
+        }
+        run += nn - from;
       }
       w.matches(run);
       rp += len;

@@ -1,6 +1,6 @@
 # per-kernel time of one bench run: bash tools/kprof.sh [extra bench args]
 REPO="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"; cd /tmp && export TMPDIR=/tmp; cd "$REPO" || exit 1; mkdir -p gpurun_out; rm -rf /tmp/kprof
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kprof -o x -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-abi-path --no-sam-pipeline "$@" > /tmp/kprof.json 2>/tmp/kprof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kprof -o x -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-abi-path --no-sam-pipeline --no-full-pipeline "$@" > /tmp/kprof.json 2>/tmp/kprof.err
 python3 - <<'PY'
 import csv, glob, json
 rows = list(csv.DictReader(open(glob.glob('/tmp/kprof/**/*kernel_stats.csv', recursive=True)[0])))

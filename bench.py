@@ -245,7 +245,8 @@ def full_pipeline(K, ctx, reads, db, offs, read_len, steps):
         return a.tobytes()
     r1, r2 = fastq_text(host[:n], 1), fastq_text(host[n:], 2)
     I = T.IndexArrays(np.zeros(1, dtype=np.uint8), offs, taxonomy_ids=np.arange(1, len(offs), dtype=np.uint32))
-    P = T.TailParams.default()
+    nthr = int(os.environ.get("KSLAM_BENCH_HOST_THREADS", "0"))
+    P = T.TailParams.default(threads=nthr)
     stats = []
 
     def tail(batch, ov, cg, det, md, release):
@@ -256,7 +257,7 @@ def full_pipeline(K, ctx, reads, db, offs, read_len, steps):
 
     def parse_and_submit():
         t0 = time.perf_counter()
-        batch, u1, u2 = F.parse_pair(r1, r2)
+        batch, u1, u2 = F.parse_pair(r1, r2, threads=nthr)
         t1 = time.perf_counter()
         c = batch._cols                                # the parser's columns, page-locked: no copy at submission
         tk = ctx.submit_batch_columns(batch.n_reads, c.bases, c.quality, c.bases_off)

@@ -333,8 +333,9 @@ struct Tiers {
 // gapped alignments, whose diagonal sums are poor, start in the 32-diagonal band and move up on
 // failure as before.
 template <int LMAX>
-__global__ __launch_bounds__(256) void k_sw_plan(const kslam_overlap *__restrict__ ov, uint64_t n, SwInputs in,
-                                                 SwParams p, Tiers T, uint8_t *__restrict__ tier) {
+__global__ __launch_bounds__(256) void k_sw_plan(kslam_overlap *__restrict__ ov, uint64_t n, SwInputs in,
+                                                 SwParams p, Tiers T, uint8_t *__restrict__ tier,
+                                                 uint32_t *__restrict__ band0) {
   constexpr int GL = 8, NG = 256 / GL, PW = 16;   // PW: bytes of "N" padding either side of a span
   __shared__ __attribute__((aligned(16))) uint8_t s_q[NG][LMAX + STAGE_PAD + 2 * PW];
   __shared__ __attribute__((aligned(16))) uint8_t s_w[NG][LMAX + STAGE_PAD + 2 * PW];
@@ -396,6 +397,22 @@ __global__ __launch_bounds__(256) void k_sw_plan(const kslam_overlap *__restrict
 #pragma unroll
     for (int m = 1; m < GL; m <<= 1) v += __shfl_xor(v, m, GL);
     best = max(best, v);
+  }
+  // A read that matches its whole window base for base (seed diagonal, W = L, every column a real
+  // match: no N) needs no DP at all: score match x L; any other alignment has fewer matched pairs or
+  // pays for a gap, so it is the unique optimum -- end (L-1, L-1), begin (0, 0), CIGAR <L>M -- and
+  // the reference's tie rules never come into play.  ~5 % of the candidates of the bench workload.
+  int32_t full = (int32_t)nm[2];
+#pragma unroll
+  for (int m = 1; m < GL; m <<= 1) full += __shfl_xor(full, m, GL);
+  const bool perfect = have && rel >= 0 && W == L && L > 0 && full == L && p.ablate == 0;
+  {
+    PassResult f{p.match * L, L - 1, L - 1, 0, 0};
+    sw_epilogue<GL, 1>(ov, gi, perfect, t, L, f, qc, wc, p, band0);
+  }
+  if (perfect) {
+    if (t == 0) tier[gi] = 255;   // in no tier's list
+    return;
   }
   if (have && t == 0) {
     int choice = T.unknown;   // no diagonal certifies anything (gapped alignment): see sw_scores
@@ -852,9 +869,9 @@ void sw_scores(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, uint32_
     T.full_list = W.list.as<uint32_t>();
     T.counts = counts;
     const unsigned pb = (unsigned)((n + 31) / 32);
-    if (lm == 0) hipLaunchKernelGGL(k_sw_plan<160>, dim3(pb), dim3(256), 0, s, d_ov, n, in, p, T, tier);
-    else if (lm == 1) hipLaunchKernelGGL(k_sw_plan<256>, dim3(pb), dim3(256), 0, s, d_ov, n, in, p, T, tier);
-    else hipLaunchKernelGGL(k_sw_plan<512>, dim3(pb), dim3(256), 0, s, d_ov, n, in, p, T, tier);
+    if (lm == 0) hipLaunchKernelGGL(k_sw_plan<160>, dim3(pb), dim3(256), 0, s, d_ov, n, in, p, T, tier, d_band0);
+    else if (lm == 1) hipLaunchKernelGGL(k_sw_plan<256>, dim3(pb), dim3(256), 0, s, d_ov, n, in, p, T, tier, d_band0);
+    else hipLaunchKernelGGL(k_sw_plan<512>, dim3(pb), dim3(256), 0, s, d_ov, n, in, p, T, tier, d_band0);
     hipLaunchKernelGGL(k_tier_hist, dim3(n_blocks), dim3(256), 0, s, tier, n, W.pos.as<uint32_t>(), n_blocks);
     hipLaunchKernelGGL(k_tier_scan, dim3(NT), dim3(1024), 0, s, W.pos.as<uint32_t>(), n_blocks, counts);
     hipLaunchKernelGGL(k_tier_scatter, dim3(n_blocks), dim3(256), 0, s, tier, n, W.pos.as<uint32_t>(), n_blocks, TL);

@@ -167,6 +167,13 @@ kslam_status kslam_wait_batch(kslam_ctx *ctx, uint64_t ticket, kslam_overlap **o
                               uint64_t *n_out, uint32_t **cigar_pool,
                               uint64_t *n_cigar);
 
+/* ---- page-locked host memory ------------------------------------------------
+ * Buffers a host fills itself (read columns, FASTQ text) reach the device by DMA, without a staging
+ * copy, when they come from here: huge-page backed, registered with the runtime.  Needs no context
+ * (but a HIP device).  bytes is what was asked for. */
+void *kslam_host_alloc(uint64_t bytes);
+void kslam_host_free(void *p, uint64_t bytes);
+
 /* ---- per-row details for the SAM writer (row N1 of SURVEY section 8f) ----
  * getCigarAndMD (src/SAM.h:101-237) walks CIGAR + read + quality + entry bases
  * of every reported alignment; on the host that is a random walk through the

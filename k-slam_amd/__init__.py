@@ -39,7 +39,8 @@ EXPORTS = ["kslam_abi_version", "kslam_create", "kslam_destroy", "kslam_last_err
            "kslam_set_index", "kslam_set_index_device", "kslam_align_batch", "kslam_free_batch",
            "kslam_align_batch_async", "kslam_wait_batch", "kslam_load_qualities", "kslam_load_qualities_device",
            "kslam_row_details", "kslam_take_row_details", "kslam_free_pinned", "kslam_submit_batch",
-           "kslam_submit_batch_columns", "kslam_collect_batch", "kslam_release_batch",
+           "kslam_submit_batch_columns", "kslam_collect_batch", "kslam_release_batch", "kslam_host_alloc",
+           "kslam_host_free",
            "kslam_load_reads", "kslam_load_reads_device", "kslam_align_resident",
            "kslam_fetch_results", "kslam_take_results", "kslam_copy_results_device", "kslam_get_timings",
            "kslam_extract_kmers", "kslam_sort_kmers", "kslam_find_overlaps", "kslam_free",
@@ -119,6 +120,9 @@ def lib():
         L.kslam_take_row_details.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64)]
         L.kslam_free_pinned.argtypes = [vp, vp]
         L.kslam_submit_batch.argtypes = [vp, u64, vp, vp, vp, C.POINTER(u64)]
+        L.kslam_host_alloc.restype = vp
+        L.kslam_host_alloc.argtypes = [u64]
+        L.kslam_host_free.argtypes = [vp, u64]
         L.kslam_submit_batch_columns.argtypes = [vp, u64, vp, vp, vp, C.POINTER(u64)]
         L.kslam_collect_batch.argtypes = [vp, u64, C.POINTER(BatchResult)]
         L.kslam_release_batch.argtypes = [vp, C.POINTER(BatchResult)]
@@ -443,6 +447,24 @@ class Context:
 
 
 SHARD_DT = np.dtype([("pair_lo", "<u8"), ("pair_hi", "<u8"), ("n_rows", "<u8"), ("n_cigar", "<u8")])
+
+
+class HostBuffer:
+    """kslam_host_alloc: page-locked host memory as a numpy uint8 array (`.a`); free with close()."""
+
+    def __init__(self, nbytes):
+        self._L = lib()
+        self.nbytes = int(nbytes)
+        self.ptr = self._L.kslam_host_alloc(self.nbytes)
+        if not self.ptr:
+            raise MemoryError("kslam_host_alloc(%d) failed" % nbytes)
+        self.a = np.frombuffer((C.c_char * self.nbytes).from_address(self.ptr), dtype=np.uint8)
+
+    def close(self):
+        if self.ptr:
+            self.a = None
+            self._L.kslam_host_free(self.ptr, self.nbytes)
+            self.ptr = None
 
 
 class MultiContext:

@@ -1225,6 +1225,8 @@ kslam_status kslam_collect_batch(kslam_ctx *c, uint64_t ticket, kslam_batch_resu
   return st;
 }
 void kslam_free(void *p) { free(p); }
+void *kslam_host_alloc(uint64_t bytes) { return pinned_alloc((size_t)bytes); }
+void kslam_host_free(void *p, uint64_t bytes) { pinned_free(p, (size_t)bytes); }
 
 kslam_status kslam_merge_shards_device(kslam_ctx *c, uint32_t n_shards, const kslam_shard *shards, uint64_t n_pairs,
                                        const void *d_overlaps, const void *d_cigar_pools, void *d_out_overlaps,

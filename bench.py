@@ -253,6 +253,12 @@ def full_pipeline(K, ctx, reads, db, offs, read_len, steps, pseudo_assembly=Fals
         a[:, W - 1] = ord("\n")
         return a.tobytes()
     r1, r2 = fastq_text(host[:n], 1), fastq_text(host[n:], 2)
+    # the two "files" as a host would hold them for this library: read into page-locked buffers
+    h1, h2 = K.HostBuffer(len(r1) + 64), K.HostBuffer(len(r2) + 64)
+    h1.a[:len(r1)] = np.frombuffer(r1, dtype=np.uint8)
+    h2.a[:len(r2)] = np.frombuffer(r2, dtype=np.uint8)
+    len1, len2 = len(r1), len(r2)
+    del r1, r2
     I = T.IndexArrays(np.zeros(1, dtype=np.uint8), offs, taxonomy_ids=np.arange(1, len(offs), dtype=np.uint32))
     nthr = int(os.environ.get("KSLAM_BENCH_HOST_THREADS", "0"))
     P = T.TailParams.default(threads=nthr, pseudo_assembly=pseudo_assembly)
@@ -266,10 +272,12 @@ def full_pipeline(K, ctx, reads, db, offs, read_len, steps, pseudo_assembly=Fals
 
     def parse_and_submit():
         t0 = time.perf_counter()
-        batch, u1, u2 = F.parse_pair(r1, r2, threads=nthr)
+        # the host only INDEXES the records (line ends, identifiers, offsets); the texts go up as they
+        # are and the bases / quality columns are cut out of them on the GPU
+        batch, u1, u2 = F.index_pair(h1.ptr, len1, h2.ptr, len2, threads=nthr)
         t1 = time.perf_counter()
-        c = batch._cols                                # the parser's columns, page-locked: no copy at submission
-        tk = ctx.submit_batch_columns(batch.n_reads, c.bases, c.quality, c.bases_off)
+        tk = ctx.submit_batch_fastq(h1.ptr, len1, h2.ptr, len2, batch.n_reads, batch._cols.bases_off,
+                                    batch.layout.bases_at, batch.layout.quality_at)
         return batch, tk, (t1 - t0, time.perf_counter() - t1)
     import ctypes as C
     for _ in range(3):                             # warm-up batches (both lanes, the parser's block cache, the tail)
@@ -295,17 +303,20 @@ def full_pipeline(K, ctx, reads, db, offs, read_len, steps, pseudo_assembly=Fals
     wall = time.perf_counter() - t_start
     n_reads = 2 * n
     ms = lambda k: round(1e3 * sum(p[k] for p in parts) / len(parts), 2)   # noqa: E731
+    h1.close()
+    h2.close()
     return {
         "reads_per_s": round(n_reads * steps / wall, 1), "ms_per_batch": round(wall / steps * 1e3, 2), "steps": steps,
         "ms_fastq_parse": ms(0), "ms_submit": ms(1), "ms_waiting_for_gpu": round(1e3 * sum(waits) / len(waits), 2),
         "host_tail_ms": round(sum(sum(v for k, v in s.items() if k.startswith("ms_")) for s in stats) / len(stats), 2),
         "host_tail_phases_ms": {k[3:]: round(stats[-1][k], 2) for k in stats[-1] if k.startswith("ms_")},
-        "fastq_mb_per_batch": round((len(r1) + len(r2)) / 1e6, 1), "sam_mb_per_batch": round(stats[-1]["sam_bytes"] / 1e6, 1),
+        "fastq_mb_per_batch": round((len1 + len2) / 1e6, 1), "sam_mb_per_batch": round(stats[-1]["sam_bytes"] / 1e6, 1),
         "pseudo_assembly": bool(pseudo_assembly),
-        "what": "FASTQ text (2 files, in memory) -> parse (host) -> kslam_submit_batch (bases + qualities up, align, per-row "
-                "NM / log-probability / MD on the GPU) -> kslam_collect_batch -> pairing ... SAM text (host, discarded by "
-                "the writer; no host copy of the database); parse of batch k+1, GPU of batch k and tail of batch k-1 "
-                "overlap; parse and tail share the library's one worker pool",
+        "what": "FASTQ text (2 files, in page-locked memory) -> record index (host: line ends, identifiers, offsets) -> "
+                "kslam_submit_batch_fastq (texts up by DMA, bases / quality columns cut out on the GPU, align, per-row "
+                "NM / log-probability / MD) -> kslam_collect_batch -> pairing ... SAM text (host, discarded by the "
+                "writer; no host copy of the database); index of batch k+1, GPU of batch k and tail of batch k-1 "
+                "overlap; index and tail share the library's one worker pool",
     }
 
 

@@ -226,6 +226,14 @@ kslam_status kslam_submit_batch(kslam_ctx *ctx, uint64_t n_reads, const char *co
 kslam_status kslam_submit_batch_columns(kslam_ctx *ctx, uint64_t n_reads, const char *bases,
                                         const char *quality, const uint64_t *offsets,
                                         uint64_t *ticket);
+/* and for a batch that is still FASTQ text: the host has only INDEXED it (kslam_fastq_index_pair,
+ * include/kslam_fastq.h: offsets = its bases_off, bases_at / quality_at = its layout); the two texts go
+ * up as they are (by DMA when they lie in kslam_host_alloc memory) and the bases and quality columns are
+ * cut out of them on the device.  Texts and arrays must stay valid until the batch is collected. */
+kslam_status kslam_submit_batch_fastq(kslam_ctx *ctx, const char *r1, uint64_t len1,
+                                      const char *r2, uint64_t len2, uint64_t n_reads,
+                                      const uint64_t *offsets, const uint64_t *bases_at,
+                                      const uint64_t *quality_at, uint64_t *ticket);
 kslam_status kslam_collect_batch(kslam_ctx *ctx, uint64_t ticket, kslam_batch_result *out);
 void kslam_release_batch(kslam_ctx *ctx, kslam_batch_result *r);
 

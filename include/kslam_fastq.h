@@ -69,6 +69,26 @@ kslam_status kslam_fastq_parse_pair(const char *r1, uint64_t len1, const char *r
 
 void kslam_reads_free(kslam_reads_columns *cols);
 
+/* The same batch WITHOUT its two big columns: the records are indexed, identifiers and offsets are
+ * built (out->ids, ids_off, bases_off, quality_off; out->bases and out->quality stay NULL), and
+ * `layout` says where every read's bases and quality line lie in the two texts taken as one,
+ * [r1 | r2] (positions of R2 fields are len1 + their position in r2).  kslam_submit_batch_fastq
+ * (include/kslam.h) then uploads the TEXTS and cuts the bases / quality columns out on the GPU, where
+ * they are needed, instead of the host copying 2 x 300 MB per batch into columns first; with the row
+ * details of kslam_row_details the host tail never needs them.  A read whose quality line is not as
+ * long as its bases line is refused here (KSLAM_ERR_ARG; the plain parser keeps both and the tail
+ * rejects the batch).  Release out with kslam_reads_free and layout with kslam_fastq_layout_free. */
+typedef struct {
+  uint64_t n_reads;
+  uint64_t *bases_at;   /* n_reads */
+  uint64_t *quality_at; /* n_reads */
+} kslam_fastq_layout;
+kslam_status kslam_fastq_index_pair(const char *r1, uint64_t len1, const char *r2, uint64_t len2,
+                                    uint64_t max_pairs, int at_eof, int threads,
+                                    kslam_reads_columns *out, kslam_fastq_layout *layout,
+                                    uint64_t *consumed1, uint64_t *consumed2);
+void kslam_fastq_layout_free(kslam_fastq_layout *layout);
+
 #ifdef __cplusplus
 }
 #endif

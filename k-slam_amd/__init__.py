@@ -39,7 +39,7 @@ EXPORTS = ["kslam_abi_version", "kslam_create", "kslam_destroy", "kslam_last_err
            "kslam_set_index", "kslam_set_index_device", "kslam_align_batch", "kslam_free_batch",
            "kslam_align_batch_async", "kslam_wait_batch", "kslam_load_qualities", "kslam_load_qualities_device",
            "kslam_row_details", "kslam_take_row_details", "kslam_free_pinned", "kslam_submit_batch",
-           "kslam_submit_batch_columns", "kslam_collect_batch", "kslam_release_batch", "kslam_host_alloc",
+           "kslam_submit_batch_columns", "kslam_submit_batch_fastq", "kslam_collect_batch", "kslam_release_batch", "kslam_host_alloc",
            "kslam_host_free",
            "kslam_load_reads", "kslam_load_reads_device", "kslam_align_resident",
            "kslam_fetch_results", "kslam_take_results", "kslam_copy_results_device", "kslam_get_timings",
@@ -124,6 +124,7 @@ def lib():
         L.kslam_host_alloc.argtypes = [u64]
         L.kslam_host_free.argtypes = [vp, u64]
         L.kslam_submit_batch_columns.argtypes = [vp, u64, vp, vp, vp, C.POINTER(u64)]
+        L.kslam_submit_batch_fastq.argtypes = [vp, vp, u64, vp, u64, u64, vp, vp, vp, C.POINTER(u64)]
         L.kslam_collect_batch.argtypes = [vp, u64, C.POINTER(BatchResult)]
         L.kslam_release_batch.argtypes = [vp, C.POINTER(BatchResult)]
         L.kslam_load_reads.argtypes = [vp, u64, vp, vp]
@@ -328,6 +329,14 @@ class Context:
         they must stay valid until collect_batch"""
         t = C.c_uint64()
         self._chk(self._L.kslam_submit_batch_columns(self._h, n_reads, bases_p, quality_p, offsets_p, C.byref(t)))
+        return int(t.value)
+
+    def submit_batch_fastq(self, r1_p, len1, r2_p, len2, n_reads, offsets_p, bases_at_p, quality_at_p):
+        """kslam_submit_batch_fastq: addresses of the two texts and of the index arrays of
+        kslam_amd.fastq.index_pair; all must stay valid until collect_batch"""
+        t = C.c_uint64()
+        self._chk(self._L.kslam_submit_batch_fastq(self._h, r1_p, len1, r2_p, len2, n_reads, offsets_p, bases_at_p,
+                                                   quality_at_p, C.byref(t)))
         return int(t.value)
 
     def collect_batch(self, ticket):

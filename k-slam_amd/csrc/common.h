@@ -267,4 +267,9 @@ void row_details(const kslam_overlap *d_ov, uint64_t n, const uint32_t *d_pool, 
                  const double *d_tables, kslam_row_detail *d_out, DetailWork &W, uint8_t **d_md_pool_out,
                  uint64_t *n_md_out, uint32_t *flags_out, hipStream_t s);
 
+// bases / quality columns cut out of FASTQ text on the device: read i = text[bases_at[i] ..) and
+// text[quality_at[i] ..), d_off[i + 1] - d_off[i] bytes each, to d_bases / d_quality + d_off[i]
+void gather_fields(const uint8_t *d_text, const uint64_t *d_bases_at, const uint64_t *d_quality_at, const uint64_t *d_off,
+                   uint64_t n_reads, uint8_t *d_bases, uint8_t *d_quality, hipStream_t s);
+
 }  // namespace kslam

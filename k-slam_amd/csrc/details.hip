@@ -226,6 +226,42 @@ __global__ __launch_bounds__(256) void k_md_gather(const kslam_overlap *__restri
 
 }  // namespace
 
+// ---- bases / quality columns cut out of uploaded FASTQ text (kslam_submit_batch_fastq) ----------------
+namespace {
+// 16 lanes per read: lane j moves bytes [16 j, 16 j + 16) of the read's bases line and of its quality
+// line from the text into the two columns (unaligned 16-byte loads and stores; the last piece byte-wise)
+__global__ __launch_bounds__(256) void k_gather_fields(const uint8_t *__restrict__ text, const uint64_t *__restrict__ bases_at,
+                                                       const uint64_t *__restrict__ quality_at,
+                                                       const uint64_t *__restrict__ off, uint64_t n_reads,
+                                                       uint8_t *__restrict__ bases, uint8_t *__restrict__ quality) {
+  const uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  if (i >= n_reads) return;
+  const uint32_t j = threadIdx.x & 15u;
+  const uint64_t o = off[i], len = off[i + 1] - o;
+  const uint8_t *sb = text + bases_at[i], *sq = text + quality_at[i];
+  for (uint64_t at = 16ull * j; at < len; at += 256) {
+    if (at + 16 <= len) {
+      *reinterpret_cast<Bytes16 *>(bases + o + at) = *reinterpret_cast<const Bytes16 *>(sb + at);
+      *reinterpret_cast<Bytes16 *>(quality + o + at) = *reinterpret_cast<const Bytes16 *>(sq + at);
+    } else {
+      for (uint64_t b = at; b < len; b++) {
+        bases[o + b] = sb[b];
+        quality[o + b] = sq[b];
+      }
+    }
+  }
+}
+}  // namespace
+
+void gather_fields(const uint8_t *d_text, const uint64_t *d_bases_at, const uint64_t *d_quality_at, const uint64_t *d_off,
+                   uint64_t n_reads, uint8_t *d_bases, uint8_t *d_quality, hipStream_t s) {
+  if (n_reads == 0) return;
+  const uint64_t threads = n_reads * 16;
+  hipLaunchKernelGGL(k_gather_fields, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, d_text, d_bases_at,
+                     d_quality_at, d_off, n_reads, d_bases, d_quality);
+  HIPCHK(hipGetLastError());
+}
+
 void row_details(const kslam_overlap *d_ov, uint64_t n, const uint32_t *d_pool, const uint8_t *d_rbases,
                  const uint8_t *d_rqual, const uint64_t *d_roff, const uint8_t *d_gbases, const uint64_t *d_goff,
                  const double *d_tables, kslam_row_detail *d_out, DetailWork &W, uint8_t **d_md_pool_out,

@@ -67,6 +67,7 @@ struct kslam_ctx {
 
   // ---- per-row details for the SAM writer (details.hip) ----
   DevBuf r_qual, d_tables, res_det;
+  DevBuf fq_text, fq_bases_at, fq_qual_at;   // kslam_submit_batch_fastq: the uploaded texts and field positions
   bool have_qual = false, have_details = false;
   uint8_t *d_md_pool = nullptr;   // inside detw.md_pool
   uint64_t n_md = 0;
@@ -83,6 +84,10 @@ struct kslam_ctx {
     char *qcat = nullptr;             // the quality strings, same layout (optional)
     bool borrowed = false;            // cat / qcat / off_ptr are the caller's columns (kslam_submit_batch_columns)
     const uint64_t *off_ptr = nullptr;
+    // kslam_submit_batch_fastq: the two texts (cat = r1, qcat = r2) and where the fields lie in [r1 | r2]
+    bool fastq = false;
+    uint64_t len1 = 0, len2 = 0;
+    const uint64_t *bases_at = nullptr, *quality_at = nullptr;
     std::vector<uint64_t> off;
     bool done = false;
     kslam_status st = KSLAM_OK;
@@ -668,6 +673,52 @@ void share_index(kslam_ctx *dst, const kslam_ctx *src) {
   dst->kept_last = 0;
 }
 
+
+// The batch's bases and quality columns cut out of the two FASTQ texts on the device (the host only
+// indexed the records: kslam_fastq_index_pair).  Leaves the context as kslam_load_reads +
+// kslam_load_qualities would.
+kslam_status load_reads_from_fastq(kslam_ctx *c, uint64_t n_reads, const char *r1, uint64_t len1, const char *r2,
+                                   uint64_t len2, const uint64_t *offsets, const uint64_t *bases_at,
+                                   const uint64_t *quality_at) {
+  return guarded(c, [&] {
+    if (n_reads && (!offsets || !bases_at || !quality_at || (len1 && !r1) || (len2 && !r2)))
+      throw StatusError{KSLAM_ERR_ARG, "null argument"};
+    hipStream_t s = c->stream;
+    c->have_reads = false;
+    c->n_reads = n_reads;
+    c->h_roff.assign(n_reads + 1, 0);
+    const uint64_t o0 = n_reads ? offsets[0] : 0;
+    for (uint64_t i = 0; i <= n_reads && n_reads; i++) c->h_roff[i] = offsets[i] - o0;
+    const uint64_t total = c->h_roff[n_reads];
+    c->fq_text.ensure(len1 + len2 + 64);
+    if (len1) HIPCHK(hipMemcpyAsync(c->fq_text.p, r1, len1, hipMemcpyHostToDevice, s));
+    if (len2) HIPCHK(hipMemcpyAsync(c->fq_text.as<uint8_t>() + len1, r2, len2, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(c->fq_text.as<uint8_t>() + len1 + len2, 0, 64, s));
+    c->fq_bases_at.ensure((n_reads + 1) * sizeof(uint64_t));
+    c->fq_qual_at.ensure((n_reads + 1) * sizeof(uint64_t));
+    c->r_off.ensure((n_reads + 1) * sizeof(uint64_t));
+    if (n_reads) {
+      HIPCHK(hipMemcpyAsync(c->fq_bases_at.p, bases_at, n_reads * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+      HIPCHK(hipMemcpyAsync(c->fq_qual_at.p, quality_at, n_reads * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+    }
+    HIPCHK(hipMemcpyAsync(c->r_off.p, c->h_roff.data(), (n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+    c->r_bases.ensure(total + 64);
+    c->r_qual.ensure(total + 64);
+    // a field that reaches past the end of the texts would be a broken index: check on the host
+    for (uint64_t i = 0; i < n_reads; i++) {
+      const uint64_t len = c->h_roff[i + 1] - c->h_roff[i];
+      if (bases_at[i] + len > len1 + len2 || quality_at[i] + len > len1 + len2)
+        throw StatusError{KSLAM_ERR_ARG, "field " + std::to_string(i) + " lies outside the FASTQ texts"};
+    }
+    gather_fields(c->fq_text.as<uint8_t>(), c->fq_bases_at.as<uint64_t>(), c->fq_qual_at.as<uint64_t>(),
+                  c->r_off.as<uint64_t>(), n_reads, c->r_bases.as<uint8_t>(), c->r_qual.as<uint8_t>(), s);
+    HIPCHK(hipMemsetAsync(c->r_bases.as<uint8_t>() + total, 0, 64, s));
+    HIPCHK(hipMemsetAsync(c->r_qual.as<uint8_t>() + total, 0, 64, s));
+    finish_load_reads(c);
+    c->have_qual = true;
+  });
+}
+
 void lane_main(kslam_ctx *primary, kslam_ctx::AsyncLane *lane) {
   for (;;) {
     kslam_ctx::AsyncJob *job = nullptr;
@@ -683,8 +734,13 @@ void lane_main(kslam_ctx *primary, kslam_ctx::AsyncLane *lane) {
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = now();
     double t1 = 0, t2 = 0, t3 = 0;
-    kslam_status st = kslam_load_reads(c, job->n_reads, job->cat, job->borrowed ? job->off_ptr : job->off.data());
-    if (st == KSLAM_OK && job->qcat)
+    kslam_status st;
+    if (job->fastq)
+      st = load_reads_from_fastq(c, job->n_reads, job->cat, job->len1, job->qcat, job->len2, job->off_ptr,
+                                 job->bases_at, job->quality_at);
+    else
+      st = kslam_load_reads(c, job->n_reads, job->cat, job->borrowed ? job->off_ptr : job->off.data());
+    if (st == KSLAM_OK && job->qcat && !job->fastq)
       st = kslam_load_qualities(c, job->borrowed && job->n_reads ? job->qcat + job->off_ptr[0] : job->qcat);
     if (job->qcat && !job->borrowed) { pinned_put(c, job->qcat); }
     t1 = now();
@@ -699,11 +755,11 @@ void lane_main(kslam_ctx *primary, kslam_ctx::AsyncLane *lane) {
       std::lock_guard<std::mutex> compute(primary->as_compute);
       t2 = now();
       st = kslam_align_resident(c, nullptr, nullptr);
-      if (st == KSLAM_OK && job->qcat) st = kslam_row_details(c, nullptr);
+      if (st == KSLAM_OK && (job->qcat || job->fastq)) st = kslam_row_details(c, nullptr);
     }
     t3 = now();
     if (st == KSLAM_OK) st = kslam_take_results(c, &job->out, &job->n_out, &job->pool, &job->n_cig);
-    if (st == KSLAM_OK && job->qcat) st = kslam_take_row_details(c, &job->det, &job->md, &job->n_md);
+    if (st == KSLAM_OK && (job->qcat || job->fastq)) st = kslam_take_row_details(c, &job->det, &job->md, &job->n_md);
     if (dbg) fprintf(stderr, "[kslam] lane %p ticket %llu: upload %.2f, token wait %.2f, align %.2f, download %.2f ms\n", (void *)lane,
                      (unsigned long long)job->ticket, t1 - t0, t2 - t1, t3 - t2, now() - t3);
     {
@@ -812,7 +868,7 @@ void kslam_destroy(kslam_ctx *c) {
                       &c->flags, &c->pos, &c->band0, &c->sortws.hist, &c->sortws.status, &c->sortws.tickets,
                       &c->cig.flags, &c->cig.pos, &c->cig.list, &c->cig.bmax, &c->cig.needbig,
                       &c->cig.scan_tmp, &c->cig.totals, &c->cig.cig_off, &c->cig.tmp, &c->cig.tmp_big,
-                      &c->cig.big_pos, &c->cig.scratch, &c->sww.flags, &c->sww.pos, &c->sww.list, &c->sww.list2, &c->sww.scan_tmp, &c->sww.totals, &c->cells, &c->res_ov, &c->res_cig, &c->res_tmp, &c->r_qual, &c->d_tables, &c->res_det, &c->detw.lens, &c->detw.off,
+                      &c->cig.big_pos, &c->cig.scratch, &c->sww.flags, &c->sww.pos, &c->sww.list, &c->sww.list2, &c->sww.scan_tmp, &c->sww.totals, &c->cells, &c->res_ov, &c->res_cig, &c->res_tmp, &c->r_qual, &c->d_tables, &c->res_det, &c->fq_text, &c->fq_bases_at, &c->fq_qual_at, &c->detw.lens, &c->detw.off,
                       &c->detw.slots, &c->detw.scan_tmp, &c->detw.totals, &c->detw.md_pool, &c->mg_shards, &c->mg_lens, &c->mg_off, &c->mg_scan};
     for (DevBuf *b : bufs) b->release();
     {
@@ -1163,6 +1219,39 @@ kslam_status kslam_submit_batch_columns(kslam_ctx *c, uint64_t n_reads, const ch
     job->cat = const_cast<char *>(bases);
     job->qcat = const_cast<char *>(quality);
     job->off_ptr = offsets;
+  });
+  if (st != KSLAM_OK) { delete job; return st; }
+  uint64_t tk;
+  {
+    std::lock_guard<std::mutex> lk(c->as_mu);
+    tk = c->next_ticket++;
+    job->ticket = tk;
+    c->jobs[tk] = job;
+    c->lanes[tk % c->lanes.size()]->q.push_back(job);
+  }
+  c->as_cv.notify_all();
+  *ticket = tk;
+  return KSLAM_OK;
+}
+
+kslam_status kslam_submit_batch_fastq(kslam_ctx *c, const char *r1, uint64_t len1, const char *r2, uint64_t len2,
+                                      uint64_t n_reads, const uint64_t *offsets, const uint64_t *bases_at,
+                                      const uint64_t *quality_at, uint64_t *ticket) {
+  if (!c || !ticket) return KSLAM_ERR_ARG;
+  kslam_ctx::AsyncJob *job = nullptr;
+  kslam_status st = guarded(c, [&] {
+    if (n_reads && (!offsets || !bases_at || !quality_at)) throw StatusError{KSLAM_ERR_ARG, "null layout"};
+    if (!c->have_index) throw StatusError{KSLAM_ERR_STATE, "kslam_set_index has not been called"};
+    ensure_lanes(c);
+    job = new kslam_ctx::AsyncJob();
+    job->n_reads = n_reads;
+    job->borrowed = true;
+    job->fastq = true;
+    job->cat = const_cast<char *>(r1);
+    job->qcat = const_cast<char *>(r2);
+    job->len1 = len1; job->len2 = len2;
+    job->off_ptr = offsets;
+    job->bases_at = bases_at; job->quality_at = quality_at;
   });
   if (st != KSLAM_OK) { delete job; return st; }
   uint64_t tk;

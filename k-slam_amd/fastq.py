@@ -11,7 +11,8 @@ from . import KslamError, lib as _base_lib
 from .tail import ReadsView
 
 # every symbol include/kslam_fastq.h declares
-EXPORTS = ["kslam_fastq_parse", "kslam_fastq_parse_pair", "kslam_reads_free"]
+EXPORTS = ["kslam_fastq_parse", "kslam_fastq_parse_pair", "kslam_reads_free", "kslam_fastq_index_pair",
+           "kslam_fastq_layout_free"]
 
 _vp, _u64 = C.c_void_p, C.c_uint64
 
@@ -19,6 +20,11 @@ _vp, _u64 = C.c_void_p, C.c_uint64
 class ReadsColumns(C.Structure):
     """kslam_reads_columns: field for field a kslam_reads_view with library-owned arrays."""
     _fields_ = ReadsView._fields_
+
+
+class Layout(C.Structure):
+    """kslam_fastq_layout"""
+    _fields_ = [("n_reads", _u64), ("bases_at", _vp), ("quality_at", _vp)]
 
 
 _lib = None
@@ -32,6 +38,10 @@ def lib():
         L.kslam_fastq_parse.argtypes = [C.c_char_p, _u64, _u64, C.c_int, C.c_int, P(ReadsColumns), P(_u64)]
         L.kslam_fastq_parse_pair.argtypes = [C.c_char_p, _u64, C.c_char_p, _u64, _u64, C.c_int, C.c_int,
                                              P(ReadsColumns), P(_u64), P(_u64)]
+        L.kslam_fastq_index_pair.argtypes = [_vp, _u64, _vp, _u64, _u64, C.c_int, C.c_int, P(ReadsColumns),
+                                             P(Layout), P(_u64), P(_u64)]
+        L.kslam_fastq_layout_free.argtypes = [P(Layout)]
+        L.kslam_fastq_layout_free.restype = None
         L.kslam_reads_free.argtypes = [P(ReadsColumns)]
         L.kslam_reads_free.restype = None
         L.kslam_tail_last_error.restype = C.c_char_p
@@ -105,6 +115,29 @@ def parse(text, max_reads=0, at_eof=True, threads=0):
     _chk(lib().kslam_fastq_parse(text, len(text), max_reads, int(at_eof), threads, C.byref(cols),
                                  C.byref(used)))
     return Batch(cols), int(used.value)
+
+
+class IndexedBatch(Batch):
+    """kslam_fastq_index_pair: identifiers and offsets on the host, `layout` (where the bases / quality lines
+    lie in [r1 | r2]) for kslam_submit_batch_fastq; no bases / quality columns."""
+
+    def __init__(self, cols, layout):
+        super().__init__(cols)
+        self.layout = layout
+
+    def close(self):
+        if self.layout is not None:
+            lib().kslam_fastq_layout_free(C.byref(self.layout))
+            self.layout = None
+        super().close()
+
+
+def index_pair(r1_ptr, len1, r2_ptr, len2, max_pairs=0, at_eof=True, threads=0):
+    """kslam_fastq_index_pair on two text ADDRESSES (e.g. of kslam_amd.HostBuffer) -> (IndexedBatch, consumed1, consumed2)"""
+    cols, lay, u1, u2 = ReadsColumns(), Layout(), _u64(), _u64()
+    _chk(lib().kslam_fastq_index_pair(r1_ptr, len1, r2_ptr, len2, max_pairs, int(at_eof), threads, C.byref(cols),
+                                      C.byref(lay), C.byref(u1), C.byref(u2)))
+    return IndexedBatch(cols, lay), int(u1.value), int(u2.value)
 
 
 def parse_pair(r1, r2, max_pairs=0, at_eof=True, threads=0):

@@ -360,4 +360,71 @@ kslam_status kslam_fastq_parse_pair(const char *r1, uint64_t len1, const char *r
 void kslam_reads_free(kslam_reads_columns *cols) {
   if (cols) free_columns(cols);
 }
+
+kslam_status kslam_fastq_index_pair(const char *r1, uint64_t len1, const char *r2, uint64_t len2,
+                                    uint64_t max_pairs, int at_eof, int threads, kslam_reads_columns *out,
+                                    kslam_fastq_layout *layout, uint64_t *consumed1, uint64_t *consumed2) {
+  return guarded([&] {
+    if (!out || !layout) fail(KSLAM_ERR_ARG, "null output argument");
+    memset(out, 0, sizeof *out);
+    memset(layout, 0, sizeof *layout);
+    const int nt = thread_count(threads);
+    std::lock_guard<std::mutex> one(g_parse_call);
+    StreamIndex a, b;
+    index_stream(r1, len1, max_pairs, at_eof != 0, nt, g_arena[0], a);
+    index_stream(r2, len2, max_pairs, at_eof != 0, nt, g_arena[1], b);
+    if (a.n != b.n) fail(KSLAM_ERR_ARG, "mismatch in R1 and R2 size");  // src/FASTQsequence.h:118-122
+    const uint64_t n = a.n + b.n;
+    try {
+      out->n_reads = n;
+      out->bases_off = alloc<uint64_t>(n + 1);
+      out->quality_off = alloc<uint64_t>(n + 1);
+      out->ids_off = alloc<uint64_t>(n + 1);
+      layout->n_reads = n;
+      layout->bases_at = alloc<uint64_t>(n + 1);
+      layout->quality_at = alloc<uint64_t>(n + 1);
+      uint64_t bsum = 0, isum = 0, r = 0;
+      for (const StreamIndex *s : {&a, &b}) {
+        const uint64_t shift = s == &a ? 0 : len1;
+        for (uint64_t k = 0; k < s->n; k++, r++) {
+          if (s->qual[k].len != s->bases[k].len)
+            fail(KSLAM_ERR_ARG, "a read's quality line is not as long as its bases line");
+          out->bases_off[r] = bsum;
+          out->quality_off[r] = bsum;
+          out->ids_off[r] = isum;
+          layout->bases_at[r] = shift + s->bases[k].start;
+          layout->quality_at[r] = shift + s->qual[k].start;
+          bsum += s->bases[k].len;
+          isum += s->id[k].len;
+        }
+      }
+      out->bases_off[n] = out->quality_off[n] = bsum;
+      out->ids_off[n] = isum;
+      out->ids = alloc<char>(isum + 1);
+      out->ids[isum] = 0;
+      uint64_t first = 0;
+      for (const StreamIndex *s : {&a, &b}) {
+        const uint64_t grain = 16384, n_tasks = (s->n + grain - 1) / grain;
+        Pool::get().tasks(nt, n_tasks, [&](size_t t) {
+          for (uint64_t k = t * grain; k < std::min(s->n, (t + 1) * grain); k++)
+            memcpy(out->ids + out->ids_off[first + k], s->text + s->id[k].start, s->id[k].len);
+        });
+        first += s->n;
+      }
+    } catch (...) {
+      free_columns(out);
+      kslam_fastq_layout_free(layout);
+      throw;
+    }
+    if (consumed1) *consumed1 = a.consumed;
+    if (consumed2) *consumed2 = b.consumed;
+  });
+}
+
+void kslam_fastq_layout_free(kslam_fastq_layout *layout) {
+  if (!layout) return;
+  cache().put(layout->bases_at);
+  cache().put(layout->quality_at);
+  memset(layout, 0, sizeof *layout);
+}
 }

@@ -145,6 +145,51 @@ def test_pairs_layout_and_mismatch(kslam, F, oracle):
     assert e.value.status == 1 and "mismatch in R1 and R2 size" in str(e.value)
 
 
+@pytest.mark.parametrize("seed,eol_mix,max_pairs", [(1, True, 0), (2, False, 0), (3, True, 37), (4, True, 0)])
+def test_index_only_entry_describes_the_same_batch(kslam, F, seed, eol_mix, max_pairs):
+    """kslam_fastq_index_pair (no bases / quality columns: their places in [r1 | r2] instead) against the
+    full parser: same identifiers and offsets, and the text cut at the layout's positions IS the columns."""
+    import ctypes as C
+    rng = np.random.default_rng(500 + seed)
+
+    def text(n, ragged):
+        out = []
+        for k in range(n):
+            h = HEADERS[int(rng.integers(0, len(HEADERS)))]
+            h = h % k if b"%d" in h else h
+            L = int(rng.choice([0, 1, 5, 36, 150]))
+            seq = bytes(rng.choice(np.frombuffer(b"ACGTNacgt", dtype=np.uint8), L))
+            qual = bytes(rng.integers(33, 75, L + (1 if ragged and k == n // 2 else 0), dtype=np.uint8))
+            for line in (h, seq, b"+", qual):
+                # (no lone "\r" here: before an empty line it would fuse with that line's "\n" into one terminator)
+                out.append(line + (EOLS[int(rng.integers(0, 2))] if eol_mix else b"\n"))
+        return b"".join(out)
+    t1, t2 = text(120, False), text(120, seed == 4)
+    b1, b2 = C.create_string_buffer(t1, len(t1)), C.create_string_buffer(t2, len(t2))
+    if seed == 4:
+        with pytest.raises(kslam.KslamError, match="quality line"):
+            F.index_pair(C.addressof(b1), len(t1), C.addressof(b2), len(t2))
+        return
+    full, f1, f2 = F.parse_pair(t1, t2, max_pairs=max_pairs)
+    ix, u1, u2 = F.index_pair(C.addressof(b1), len(t1), C.addressof(b2), len(t2), max_pairs=max_pairs)
+    assert (u1, u2) == (f1, f2) and ix.n_reads == full.n_reads
+    n = ix.n_reads
+    assert ix.ids == full.ids
+    c = ix._cols
+    off = np.frombuffer((C.c_char * (8 * (n + 1))).from_address(c.bases_off), dtype=np.uint64)
+    qoff = np.frombuffer((C.c_char * (8 * (n + 1))).from_address(c.quality_off), dtype=np.uint64)
+    _, foff = full.bases_array()
+    assert (off == foff).all() and (qoff == foff).all() and not c.bases and not c.quality
+    at = np.frombuffer((C.c_char * (8 * n)).from_address(ix.layout.bases_at), dtype=np.uint64)
+    qat = np.frombuffer((C.c_char * (8 * n)).from_address(ix.layout.quality_at), dtype=np.uint64)
+    both = t1 + t2
+    for i in range(n):
+        ln = int(off[i + 1] - off[i])
+        assert both[int(at[i]):int(at[i]) + ln] == full.bases[i] and both[int(qat[i]):int(qat[i]) + ln] == full.quality[i]
+    ix.close()
+    full.close()
+
+
 def test_golden_records_from_the_real_reference(F, oracle):
     cases = json.load(open(os.path.join(ROOT, "tests", "golden", "fastq_cases.json")))["cases"]
     assert len(cases) >= 8

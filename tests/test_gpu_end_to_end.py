@@ -152,6 +152,25 @@ def test_fastq_and_database_files_to_sam_and_per_read_taxa(kslam, oracle, synth,
         assert o3.tobytes() == ov.tobytes() and c3.tobytes() == cg.tobytes()
         assert d3.tobytes() == det.tobytes() and m3.tobytes() == md.tobytes()
         rel3()
+    # ---- and straight from the FASTQ TEXT: the host only indexes the records (kslam_fastq_index_pair),
+    # the texts go up from page-locked memory and the columns are cut out of them on the device ----
+    h1, h2 = kslam.HostBuffer(len(r1) + 64), kslam.HostBuffer(len(r2) + 64)
+    h1.a[:len(r1)] = np.frombuffer(r1, dtype=np.uint8)
+    h2.a[:len(r2)] = np.frombuffer(r2, dtype=np.uint8)
+    ix, v1, v2 = F.index_pair(h1.ptr, len(r1), h2.ptr, len(r2))
+    assert (v1, v2) == (len(r1), len(r2)) and ix.n_reads == batch.n_reads and ix.ids == batch.ids
+    tk = [ctx.submit_batch_fastq(h1.ptr, len(r1), h2.ptr, len(r2), ix.n_reads, ix._cols.bases_off,
+                                 ix.layout.bases_at, ix.layout.quality_at) for _ in range(2)]
+    for t in tk:
+        o4, c4, d4, m4, rel4 = ctx.collect_batch(t)
+        assert o4.tobytes() == ov.tobytes() and c4.tobytes() == cg.tobytes()
+        assert d4.tobytes() == det.tobytes() and m4.tobytes() == md.tobytes()
+        sam4, _ = T.tail_sam_rows(P, ix, blind, o4, c4, d4, m4)      # the indexed batch as the tail's reads view
+        assert sam4 == esam
+        rel4()
+    ix.close()
+    h1.close()
+    h2.close()
     release()
     ctx.close()
     batch.close()

@@ -182,20 +182,28 @@ def sam_pipeline(K, ctx, reads, db, offs, read_len, steps, pseudo_assembly=False
     def submit():
         return ctx.submit_batch_columns(n_reads, hb.ptr, hq.ptr, off.ctypes.data)
 
-    def tail(ov, cg, det, md, release):
-        st = T.tail_sam_discard_rows(P, R, I, ov, cg, det, md)
-        release()                                  # page-locked result buffers back to the library
-        stats.append(st.as_dict())
+    def collect(tk):
+        res = ctx.collect_batch(tk)
+        return res + (ctx.last_pairs,)
 
+    def tail(ov, cg, det, md, release, pairs):
+        rp, pr, pst = pairs                        # read pairs / alignment pairs from the GPU (views: modified in place)
+        st = T.tail_finish_rows(P, R, I, ov, cg, det, md, rp, pr)
+        release()                                  # page-locked result buffers back to the library
+        d = st.as_dict()
+        d["gpu_pairing"] = pst
+        stats.append(d)
+
+    ctx.set_pairing(paired=True)                   # score screen, pairing, insert-size statistics, screens: on the GPU
     for tk in [submit(), submit(), submit()]:       # warm both lanes' buffers and the tail's work buffers
-        tail(*ctx.collect_batch(tk))
+        tail(*collect(tk))
     stats.clear()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     worker, done_at = None, []
     pend = [submit(), submit()]                    # two batches on the GPU lanes
     for k in range(steps):
-        res = ctx.collect_batch(pend.pop(0))       # batch k: its rows in page-locked buffers
+        res = collect(pend.pop(0))                 # batch k: its rows in page-locked buffers
         if k + 2 < steps:
             pend.append(submit())
         if worker is not None:
@@ -207,6 +215,7 @@ def sam_pipeline(K, ctx, reads, db, offs, read_len, steps, pseudo_assembly=False
     wall = time.perf_counter() - t0
     tail_ms = [sum(v for k, v in s.items() if k.startswith("ms_")) for s in stats]
     last = stats[-1]
+    ctx.set_pairing(stages=0)
     hb.close()
     hq.close()
     return {
@@ -215,11 +224,12 @@ def sam_pipeline(K, ctx, reads, db, offs, read_len, steps, pseudo_assembly=False
         "host_tail_phases_ms": {k[3:]: round(last[k], 2) for k in last if k.startswith("ms_")},
         "host_threads": int(last["threads"]), "sam_mb_per_batch": round(last["sam_bytes"] / 1e6, 1),
         "alignment_pairs": int(last["n_paired_final"]), "read_pairs_aligned": int(last["n_read_pairs"]),
-        "pseudo_assembly": bool(pseudo_assembly),
+        "pseudo_assembly": bool(pseudo_assembly), "gpu_pairing": last["gpu_pairing"],
         "what": "read columns in page-locked host memory -> kslam_submit_batch_columns (align + per-row NM / "
-                "log-probability / MD on the GPU, two batches in flight) -> kslam_collect_batch -> pairing/screens/"
-                "%sSAM text (host, discarded by the writer; no host copy of the database) on a worker thread; "
-                "one-time host copy of the reads took %.1f s" % ("pseudo-assembly/" if pseudo_assembly else "", t_host_copy),
+                "log-probability / MD + score screen / pairing / insert-size statistics / screens on the GPU, two "
+                "batches in flight) -> kslam_collect_batch -> %sSAM text (host, discarded by the writer; no host copy "
+                "of the database) on a worker thread; one-time host copy of the reads took %.1f s" % (
+                    "pseudo-assembly / second screen / " if pseudo_assembly else "", t_host_copy),
     }
 
 
@@ -264,11 +274,18 @@ def full_pipeline(K, ctx, reads, db, offs, read_len, steps, pseudo_assembly=Fals
     P = T.TailParams.default(threads=nthr, pseudo_assembly=pseudo_assembly)
     stats = []
 
-    def tail(batch, ov, cg, det, md, release):
-        st = T.tail_sam_discard_rows(P, batch, I, ov, cg, det, md)
+    def collect(tk):
+        res = ctx.collect_batch(tk)
+        return res + (ctx.last_pairs,)
+
+    def tail(batch, ov, cg, det, md, release, pairs):
+        rp, pr, pst = pairs
+        st = T.tail_finish_rows(P, batch, I, ov, cg, det, md, rp, pr)
         release()
         batch.close()
         stats.append(st.as_dict())
+
+    ctx.set_pairing(paired=True)
 
     def parse_and_submit():
         t0 = time.perf_counter()
@@ -282,7 +299,7 @@ def full_pipeline(K, ctx, reads, db, offs, read_len, steps, pseudo_assembly=Fals
     import ctypes as C
     for _ in range(3):                             # warm-up batches (both lanes, the parser's block cache, the tail)
         b0, t0_, _ = parse_and_submit()
-        tail(b0, *ctx.collect_batch(t0_))
+        tail(b0, *collect(t0_))
     stats.clear()
     torch.cuda.synchronize()
     t_start = time.perf_counter()
@@ -291,7 +308,7 @@ def full_pipeline(K, ctx, reads, db, offs, read_len, steps, pseudo_assembly=Fals
     for k in range(steps):
         nxt = parse_and_submit() if k + 1 < steps else None        # batch k+1 parsed and queued
         tw = time.perf_counter()
-        res = ctx.collect_batch(cur[1])                            # batch k back from the GPU
+        res = collect(cur[1])                                      # batch k back from the GPU
         waits.append(time.perf_counter() - tw)
         if worker is not None:
             worker.join()                                          # tail of batch k-1 done
@@ -303,6 +320,7 @@ def full_pipeline(K, ctx, reads, db, offs, read_len, steps, pseudo_assembly=Fals
     wall = time.perf_counter() - t_start
     n_reads = 2 * n
     ms = lambda k: round(1e3 * sum(p[k] for p in parts) / len(parts), 2)   # noqa: E731
+    ctx.set_pairing(stages=0)
     h1.close()
     h2.close()
     return {
@@ -314,9 +332,10 @@ def full_pipeline(K, ctx, reads, db, offs, read_len, steps, pseudo_assembly=Fals
         "pseudo_assembly": bool(pseudo_assembly),
         "what": "FASTQ text (2 files, in page-locked memory) -> record index (host: line ends, identifiers, offsets) -> "
                 "kslam_submit_batch_fastq (texts up by DMA, bases / quality columns cut out on the GPU, align, per-row "
-                "NM / log-probability / MD) -> kslam_collect_batch -> pairing ... SAM text (host, discarded by the "
-                "writer; no host copy of the database); index of batch k+1, GPU of batch k and tail of batch k-1 "
-                "overlap; index and tail share the library's one worker pool",
+                "NM / log-probability / MD, score screen / pairing / insert-size statistics / screens) -> "
+                "kslam_collect_batch -> [pseudo-assembly / second screen] SAM text (host, discarded by the "
+                "writer; no host copy of the database); index of batch k+1, GPU of batch k and host stage of batch "
+                "k-1 overlap; index and host stage share the library's one worker pool",
     }
 
 

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define KSLAM_ABI_VERSION 3
+#define KSLAM_ABI_VERSION 4
 #define KSLAM_K 32u /* src/Globals.h:25 */
 
 typedef enum {
@@ -205,6 +205,61 @@ kslam_status kslam_take_row_details(kslam_ctx *ctx, kslam_row_detail **details,
                                     char **md_pool, uint64_t *n_md);
 void kslam_free_pinned(kslam_ctx *ctx, void *p);
 
+/* ---- the first half of the host tail on the GPU ----
+ * From the overlap records of the last result, still in HBM: the score screen
+ * (src/Overlap.h:329-341), read pairing (getPairedOverlaps, src/PairedOverlap.h:107-270; single end:
+ * dummy pairs, :280-298), the batch-global insert-size statistics (getMaxAllowedInsertSize, :314-360)
+ * and the two per-read-pair screens (:361-436) -- i.e. include/kslam_tail.h's kslam_tail_pairs with
+ * stages = INSERT_SCREEN | SCORE_SCREEN, record for record (the reference's std::sort permutations
+ * included).  The host is left with pseudo-assembly and the SAM text (kslam_tail_finish_write_rows).
+ * stages: KSLAM_TAIL_INSERT_SCREEN (1) | KSLAM_TAIL_SCORE_SCREEN (2) of include/kslam_tail.h. */
+#define KSLAM_NO_OVERLAP 0xFFFFFFFFu
+
+/* PairedOverlap, src/PairedOverlap.h:32-57; the two Overlap copies become
+ * indices into the caller's kslam_overlap array */
+typedef struct {
+  uint32_t combined_score;
+  uint32_t entry;
+  int32_t ref_start;
+  int32_t ref_end;
+  uint32_t insert_size;
+  uint32_t r1; /* KSLAM_NO_OVERLAP when hasR1 is false */
+  uint32_t r2;
+  uint32_t pad;
+} kslam_paired_overlap;
+
+/* ReadPairAndOverlaps, src/PairedOverlap.h:62-75: alignmentPairs is
+ * pairs[first .. first + count) */
+typedef struct {
+  uint32_t r1_read;
+  uint32_t r2_read;
+  uint64_t first;
+  uint64_t count;
+} kslam_read_pair;
+
+typedef struct {
+  uint64_t n_overlaps_screened; /* after the score threshold */
+  uint64_t n_paired_initial;    /* alignment pairs out of pairing */
+  uint64_t n_insert_sizes;
+  uint64_t n_read_pairs;        /* read pairs (or reads) with >= 1 alignment pair left */
+  uint64_t n_pairs;             /* alignment pairs left */
+  uint32_t max_insert_size;     /* getMaxAllowedInsertSize; UINT32_MAX when not computed */
+  uint32_t pad;
+} kslam_pair_stats;
+kslam_status kslam_pair_screen(kslam_ctx *ctx, int paired, uint32_t score_threshold,
+                               double score_fraction, uint32_t stages, kslam_pair_stats *stats);
+/* the same on overlap records and read lengths handed in from the host (stage-level parity tests) */
+kslam_status kslam_pair_screen_overlaps(kslam_ctx *ctx, const kslam_overlap *overlaps, uint64_t n_overlaps,
+                                        const uint32_t *read_lens, uint64_t n_reads, int paired,
+                                        uint32_t score_threshold, double score_fraction,
+                                        uint32_t stages, kslam_pair_stats *stats);
+/* page-locked, library-owned copies of the last kslam_pair_screen* result; kslam_free_pinned each */
+kslam_status kslam_take_pairs(kslam_ctx *ctx, kslam_read_pair **read_pairs, uint64_t *n_read_pairs,
+                              kslam_paired_overlap **pairs, uint64_t *n_pairs);
+/* what the pipelined lanes run after the alignment: stages == 0 switches the pairing off (default) */
+kslam_status kslam_set_pairing(kslam_ctx *ctx, int paired, uint32_t score_threshold,
+                               double score_fraction, uint32_t stages);
+
 /* The pipelined entry with everything a SAM-writing host needs in one result:
  * quality may be NULL (then details / md_pool come back NULL). */
 typedef struct {
@@ -215,6 +270,11 @@ typedef struct {
   kslam_row_detail *details;
   char *md_pool;
   uint64_t n_md;
+  kslam_read_pair *read_pairs;  /* NULL unless kslam_set_pairing switched the device pairing on */
+  uint64_t n_read_pairs;
+  kslam_paired_overlap *pairs;
+  uint64_t n_pairs;
+  kslam_pair_stats pair_stats;
 } kslam_batch_result;
 kslam_status kslam_submit_batch(kslam_ctx *ctx, uint64_t n_reads, const char *const *bases,
                                 const char *const *quality, const uint32_t *lens,

@@ -96,29 +96,7 @@ typedef struct {
   const uint64_t *product_off;
 } kslam_index_view;
 
-#define KSLAM_NO_OVERLAP 0xFFFFFFFFu
-
-/* PairedOverlap, src/PairedOverlap.h:32-57; the two Overlap copies become
- * indices into the caller's kslam_overlap array */
-typedef struct {
-  uint32_t combined_score;
-  uint32_t entry;
-  int32_t ref_start;
-  int32_t ref_end;
-  uint32_t insert_size;
-  uint32_t r1; /* KSLAM_NO_OVERLAP when hasR1 is false */
-  uint32_t r2;
-  uint32_t pad;
-} kslam_paired_overlap;
-
-/* ReadPairAndOverlaps, src/PairedOverlap.h:62-75: alignmentPairs is
- * pairs[first .. first + count) */
-typedef struct {
-  uint32_t r1_read;
-  uint32_t r2_read;
-  uint64_t first;
-  uint64_t count;
-} kslam_read_pair;
+/* kslam_paired_overlap, kslam_read_pair and KSLAM_NO_OVERLAP: include/kslam.h */
 
 typedef struct {
   uint64_t n_overlaps_in;
@@ -206,6 +184,22 @@ kslam_status kslam_tail_sam_write_rows(const kslam_tail_params *params,
                                        const kslam_row_detail *details, const char *md_pool,
                                        uint64_t n_md, kslam_write_fn write, void *user,
                                        kslam_tail_stats *stats);
+
+/* Everything up to the SAM writer's input computed on the GPU (kslam_pair_screen, include/kslam.h:
+ * score screen, pairing, insert-size statistics, the two per-read-pair screens): this entry takes those
+ * read pairs / alignment pairs (both are modified: pseudo-assembly rewrites scores, the sorts run in
+ * place), runs pseudo-assembly + the second score screen when params ask for them, and writes the SAM
+ * records.  details may be NULL (then the writer walks the database itself). */
+kslam_status kslam_tail_finish_write_rows(const kslam_tail_params *params,
+                                          const kslam_reads_view *reads,
+                                          const kslam_index_view *index,
+                                          const kslam_overlap *overlaps, uint64_t n_overlaps,
+                                          const uint32_t *cigar_pool, uint64_t n_cigar,
+                                          const kslam_row_detail *details, const char *md_pool,
+                                          uint64_t n_md, kslam_read_pair *read_pairs,
+                                          uint64_t n_read_pairs, kslam_paired_overlap *pairs,
+                                          uint64_t n_pairs, kslam_write_fn write, void *user,
+                                          kslam_tail_stats *stats);
 
 /* The tail keeps its work buffers (a few hundred bytes per overlap) between
  * calls; this returns them to the allocator.  Calls are serialised internally:

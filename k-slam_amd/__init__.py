@@ -27,6 +27,9 @@ OVERLAP_DT = np.dtype([("read", "<u4"), ("entry", "<u4"), ("rel", "<i4"),
                        ("query_begin", "<i4"), ("query_end", "<i4"),
                        ("cigar_len", "<u4"), ("pad2", "<u4"), ("cigar_off", "<u8")])
 assert OVERLAP_DT.itemsize == 48
+PAIRED_OVERLAP_DT = np.dtype([("combined_score", "<u4"), ("entry", "<u4"), ("ref_start", "<i4"), ("ref_end", "<i4"),
+                              ("insert_size", "<u4"), ("r1", "<u4"), ("r2", "<u4"), ("pad", "<u4")])
+READ_PAIR_DT = np.dtype([("r1_read", "<u4"), ("r2_read", "<u4"), ("first", "<u8"), ("count", "<u8")])
 ROW_DETAIL_DT = np.dtype([("logp", "<f8"), ("md_off", "<u8"), ("md_len", "<u4"), ("nm", "<u4"),
                           ("flags", "<u4"), ("pad", "<u4")])
 assert ROW_DETAIL_DT.itemsize == 32
@@ -40,7 +43,7 @@ EXPORTS = ["kslam_abi_version", "kslam_create", "kslam_destroy", "kslam_last_err
            "kslam_align_batch_async", "kslam_wait_batch", "kslam_load_qualities", "kslam_load_qualities_device",
            "kslam_row_details", "kslam_take_row_details", "kslam_free_pinned", "kslam_submit_batch",
            "kslam_submit_batch_columns", "kslam_submit_batch_fastq", "kslam_collect_batch", "kslam_release_batch", "kslam_host_alloc",
-           "kslam_host_free",
+           "kslam_host_free", "kslam_pair_screen", "kslam_pair_screen_overlaps", "kslam_take_pairs", "kslam_set_pairing",
            "kslam_load_reads", "kslam_load_reads_device", "kslam_align_resident",
            "kslam_fetch_results", "kslam_take_results", "kslam_copy_results_device", "kslam_get_timings",
            "kslam_extract_kmers", "kslam_sort_kmers", "kslam_find_overlaps", "kslam_free",
@@ -57,10 +60,22 @@ class Params(C.Structure):
                 ("max_kmers_per_chunk", C.c_uint32)]
 
 
+class PairStats(C.Structure):
+    """kslam_pair_stats"""
+    _fields_ = [("n_overlaps_screened", C.c_uint64), ("n_paired_initial", C.c_uint64), ("n_insert_sizes", C.c_uint64),
+                ("n_read_pairs", C.c_uint64), ("n_pairs", C.c_uint64), ("max_insert_size", C.c_uint32),
+                ("pad", C.c_uint32)]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_ if k != "pad"}
+
+
 class BatchResult(C.Structure):
     """kslam_batch_result"""
     _fields_ = [("overlaps", C.c_void_p), ("n_overlaps", C.c_uint64), ("cigar_pool", C.c_void_p),
-                ("n_cigar", C.c_uint64), ("details", C.c_void_p), ("md_pool", C.c_void_p), ("n_md", C.c_uint64)]
+                ("n_cigar", C.c_uint64), ("details", C.c_void_p), ("md_pool", C.c_void_p), ("n_md", C.c_uint64),
+                ("read_pairs", C.c_void_p), ("n_read_pairs", C.c_uint64), ("pairs", C.c_void_p),
+                ("n_pairs", C.c_uint64), ("pair_stats", PairStats)]
 
 
 class Timings(C.Structure):
@@ -120,6 +135,10 @@ def lib():
         L.kslam_take_row_details.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64)]
         L.kslam_free_pinned.argtypes = [vp, vp]
         L.kslam_submit_batch.argtypes = [vp, u64, vp, vp, vp, C.POINTER(u64)]
+        L.kslam_pair_screen.argtypes = [vp, C.c_int, u32, C.c_double, u32, C.POINTER(PairStats)]
+        L.kslam_pair_screen_overlaps.argtypes = [vp, vp, u64, vp, u64, C.c_int, u32, C.c_double, u32, C.POINTER(PairStats)]
+        L.kslam_take_pairs.argtypes = [vp, C.POINTER(vp), C.POINTER(u64), C.POINTER(vp), C.POINTER(u64)]
+        L.kslam_set_pairing.argtypes = [vp, C.c_int, u32, C.c_double, u32]
         L.kslam_host_alloc.restype = vp
         L.kslam_host_alloc.argtypes = [u64]
         L.kslam_host_free.argtypes = [vp, u64]
@@ -318,6 +337,45 @@ class Context:
             return det, md
         return det, md, release
 
+    # ---- the first half of the host tail on the device ----
+    def pair_screen(self, paired=True, score_threshold=0, score_fraction=0.95, stages=3):
+        """kslam_pair_screen on the last results -> stats dict"""
+        st = PairStats()
+        self._chk(self._L.kslam_pair_screen(self._h, int(paired), score_threshold, score_fraction, stages, C.byref(st)))
+        return st.as_dict()
+
+    def pair_screen_overlaps(self, overlaps, read_lens, paired=True, score_threshold=0, score_fraction=0.95, stages=3):
+        """kslam_pair_screen_overlaps on host arrays -> stats dict"""
+        ov = np.ascontiguousarray(overlaps, dtype=OVERLAP_DT)
+        rl = np.ascontiguousarray(read_lens, dtype=np.uint32)
+        st = PairStats()
+        self._chk(self._L.kslam_pair_screen_overlaps(self._h, ov.ctypes.data if len(ov) else None, len(ov),
+                                                     rl.ctypes.data if len(rl) else None, len(rl), int(paired),
+                                                     score_threshold, score_fraction, stages, C.byref(st)))
+        return st.as_dict()
+
+    def take_pairs(self, copy=True):
+        """kslam_take_pairs -> (read_pairs[READ_PAIR_DT], pairs[PAIRED_OVERLAP_DT][, release])"""
+        pg, pp, ng, npr = C.c_void_p(), C.c_void_p(), C.c_uint64(), C.c_uint64()
+        self._chk(self._L.kslam_take_pairs(self._h, C.byref(pg), C.byref(ng), C.byref(pp), C.byref(npr)))
+        rp = np.frombuffer((C.c_char * (int(ng.value) * 24)).from_address(pg.value), dtype=READ_PAIR_DT) \
+            if ng.value else np.zeros(0, dtype=READ_PAIR_DT)
+        pr = np.frombuffer((C.c_char * (int(npr.value) * 32)).from_address(pp.value), dtype=PAIRED_OVERLAP_DT) \
+            if npr.value else np.zeros(0, dtype=PAIRED_OVERLAP_DT)
+
+        def release():
+            self._L.kslam_free_pinned(self._h, pg)
+            self._L.kslam_free_pinned(self._h, pp)
+        if copy:
+            rp, pr = rp.copy(), pr.copy()
+            release()
+            return rp, pr
+        return rp, pr, release
+
+    def set_pairing(self, paired=True, score_threshold=0, score_fraction=0.95, stages=3):
+        """kslam_set_pairing: what the pipelined lanes run after the alignment (stages=0: off)"""
+        self._chk(self._L.kslam_set_pairing(self._h, int(paired), score_threshold, score_fraction, stages))
+
     def submit_batch_full(self, n_reads, bases_pp, quals_pp, lens_p):
         """kslam_submit_batch on ready pointer arrays (quals_pp may be None)"""
         t = C.c_uint64()
@@ -352,6 +410,8 @@ class Context:
         cg = view(r.cigar_pool, r.n_cigar, np.dtype(np.uint32))
         det = view(r.details, r.n_overlaps if r.details else 0, ROW_DETAIL_DT)
         md = view(r.md_pool, r.n_md, np.dtype(np.uint8))
+        self.last_pairs = (view(r.read_pairs, r.n_read_pairs, READ_PAIR_DT), view(r.pairs, r.n_pairs, PAIRED_OVERLAP_DT),
+                           r.pair_stats.as_dict()) if r.read_pairs or r.pairs else None
 
         def release():
             self._L.kslam_release_batch(self._h, C.byref(r))

@@ -267,6 +267,22 @@ void row_details(const kslam_overlap *d_ov, uint64_t n, const uint32_t *d_pool, 
                  const double *d_tables, kslam_row_detail *d_out, DetailWork &W, uint8_t **d_md_pool_out,
                  uint64_t *n_md_out, uint32_t *flags_out, hipStream_t s);
 
+// --------------------------------------------------------------- pairs.hip
+struct PairWork {
+  DevBuf recs, count, base, inserts, flags, gpos, rpos, scan_tmp, totals, groups, dense, sort_a, sort_b, idx, picked;
+};
+struct PairResult {
+  uint64_t n_overlaps_screened, n_paired_initial, n_insert_sizes, n_read_pairs, n_pairs;
+  uint32_t max_insert_size;
+  const kslam_read_pair *d_groups;       // n_read_pairs, `first` indexes d_pairs
+  const kslam_paired_overlap *d_pairs;   // n_pairs, dense
+};
+// score screen + pairing + insert-size limit + the two per-read-pair screens (see pairs.hip); d_ov in
+// alignToDatabase order, d_read_len[read]; blocks on the stream (small read-backs between the kernels)
+void pair_and_screen(const kslam_overlap *d_ov, uint64_t n, const uint32_t *d_read_len, uint64_t n_reads, int paired,
+                     uint32_t score_threshold, double score_fraction, int do_insert, int do_score, PairWork &W,
+                     SortWorkspace &sortws, PairResult *res, hipStream_t s);
+
 // bases / quality columns cut out of FASTQ text on the device: read i = text[bases_at[i] ..) and
 // text[quality_at[i] ..), d_off[i + 1] - d_off[i] bytes each, to d_bases / d_quality + d_off[i]
 void gather_fields(const uint8_t *d_text, const uint64_t *d_bases_at, const uint64_t *d_quality_at, const uint64_t *d_off,

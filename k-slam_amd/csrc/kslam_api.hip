@@ -74,6 +74,13 @@ struct kslam_ctx {
   uint32_t det_flags = 0;
   DetailWork detw;
 
+  // ---- device pairing / screens (pairs.hip) ----
+  PairWork pw;
+  PairResult pres{};
+  bool have_pairs = false;
+  DevBuf pr_ov, pr_len;          // kslam_pair_screen_overlaps: the records and read lengths handed in
+  struct { int paired = 1; uint32_t thr = 0; double fraction = 0.95; uint32_t stages = 0; } pairing;   // for the lanes
+
   // ---- pipelined entry (kslam_align_batch_async): worker lanes, each a sibling context that BORROWS
   // this context's index (same device pointers, never freed by the sibling) ----
   bool borrowed_index = false;
@@ -95,6 +102,8 @@ struct kslam_ctx {
     kslam_overlap *out = nullptr; uint64_t n_out = 0;
     uint32_t *pool = nullptr; uint64_t n_cig = 0;
     kslam_row_detail *det = nullptr; char *md = nullptr; uint64_t n_md = 0;
+    kslam_read_pair *rp = nullptr; uint64_t n_rp = 0; kslam_paired_overlap *pr = nullptr; uint64_t n_pr = 0;
+    kslam_pair_stats pstats{};
   };
   struct AsyncLane {
     kslam_ctx *c = nullptr;
@@ -445,6 +454,7 @@ void align_resident(kslam_ctx *c, bool stop_after_join, uint64_t *n_raw_out) {
   c->n_res = 0;
   c->n_cig = 0;
   c->have_details = false;
+  c->have_pairs = false;
   c->cells.ensure(sizeof(uint64_t));
   HIPCHK(hipMemsetAsync(c->cells.p, 0, sizeof(uint64_t), s));
   uint64_t n_raw_total = 0;
@@ -671,6 +681,7 @@ void share_index(kslam_ctx *dst, const kslam_ctx *src) {
   dst->g_bucket = src->g_bucket; dst->bucket_bits = src->bucket_bits;
   dst->g_filter = src->g_filter; dst->filter_bits = src->filter_bits;
   dst->kept_last = 0;
+  dst->pairing = src->pairing;
 }
 
 
@@ -756,10 +767,14 @@ void lane_main(kslam_ctx *primary, kslam_ctx::AsyncLane *lane) {
       t2 = now();
       st = kslam_align_resident(c, nullptr, nullptr);
       if (st == KSLAM_OK && (job->qcat || job->fastq)) st = kslam_row_details(c, nullptr);
+      if (st == KSLAM_OK && primary->pairing.stages)
+        st = kslam_pair_screen(c, primary->pairing.paired, primary->pairing.thr, primary->pairing.fraction,
+                               primary->pairing.stages, &job->pstats);
     }
     t3 = now();
     if (st == KSLAM_OK) st = kslam_take_results(c, &job->out, &job->n_out, &job->pool, &job->n_cig);
     if (st == KSLAM_OK && (job->qcat || job->fastq)) st = kslam_take_row_details(c, &job->det, &job->md, &job->n_md);
+    if (st == KSLAM_OK && primary->pairing.stages) st = kslam_take_pairs(c, &job->rp, &job->n_rp, &job->pr, &job->n_pr);
     if (dbg) fprintf(stderr, "[kslam] lane %p ticket %llu: upload %.2f, token wait %.2f, align %.2f, download %.2f ms\n", (void *)lane,
                      (unsigned long long)job->ticket, t1 - t0, t2 - t1, t3 - t2, now() - t3);
     {
@@ -869,7 +884,9 @@ void kslam_destroy(kslam_ctx *c) {
                       &c->cig.flags, &c->cig.pos, &c->cig.list, &c->cig.bmax, &c->cig.needbig,
                       &c->cig.scan_tmp, &c->cig.totals, &c->cig.cig_off, &c->cig.tmp, &c->cig.tmp_big,
                       &c->cig.big_pos, &c->cig.scratch, &c->sww.flags, &c->sww.pos, &c->sww.list, &c->sww.list2, &c->sww.scan_tmp, &c->sww.totals, &c->cells, &c->res_ov, &c->res_cig, &c->res_tmp, &c->r_qual, &c->d_tables, &c->res_det, &c->fq_text, &c->fq_bases_at, &c->fq_qual_at, &c->detw.lens, &c->detw.off,
-                      &c->detw.slots, &c->detw.scan_tmp, &c->detw.totals, &c->detw.md_pool, &c->mg_shards, &c->mg_lens, &c->mg_off, &c->mg_scan};
+                      &c->detw.slots, &c->detw.scan_tmp, &c->detw.totals, &c->detw.md_pool, &c->pw.recs, &c->pw.count, &c->pw.base,
+                      &c->pw.inserts, &c->pw.flags, &c->pw.gpos, &c->pw.rpos, &c->pw.scan_tmp, &c->pw.totals, &c->pw.groups,
+                      &c->pw.dense, &c->pw.sort_a, &c->pw.sort_b, &c->pw.idx, &c->pw.picked, &c->pr_ov, &c->pr_len, &c->mg_shards, &c->mg_lens, &c->mg_off, &c->mg_scan};
     for (DevBuf *b : bufs) b->release();
     {
       std::lock_guard<std::mutex> lk(c->pin_mu);
@@ -1132,6 +1149,87 @@ kslam_status kslam_take_row_details(kslam_ctx *c, kslam_row_detail **details, ch
   return KSLAM_OK;
 }
 
+static void fill_pair_stats(const PairResult &r, kslam_pair_stats *st) {
+  if (!st) return;
+  memset(st, 0, sizeof *st);
+  st->n_overlaps_screened = r.n_overlaps_screened; st->n_paired_initial = r.n_paired_initial;
+  st->n_insert_sizes = r.n_insert_sizes; st->n_read_pairs = r.n_read_pairs; st->n_pairs = r.n_pairs;
+  st->max_insert_size = r.max_insert_size;
+}
+
+kslam_status kslam_pair_screen(kslam_ctx *c, int paired, uint32_t score_threshold, double score_fraction, uint32_t stages,
+                               kslam_pair_stats *stats) {
+  return guarded(c, [&] {
+    if (!c->have_reads) throw StatusError{KSLAM_ERR_STATE, "no batch loaded"};
+    if (paired && (c->n_reads < 2 || (c->n_reads & 1)))
+      throw StatusError{KSLAM_ERR_ARG, "paired data needs an even, non-zero number of reads ([R1 block | R2 block])"};
+    if (c->n_res >= (1ull << 30)) throw StatusError{KSLAM_ERR_UNSUPPORTED, "2^30 or more overlaps in one batch"};
+    c->have_pairs = false;
+    pair_and_screen(c->res_ov.as<kslam_overlap>(), c->n_res, c->r_len.as<uint32_t>(), c->n_reads, paired ? 1 : 0,
+                    score_threshold, score_fraction, (stages & 1u) != 0, (stages & 2u) != 0, c->pw, c->sortws, &c->pres,
+                    c->stream);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->have_pairs = true;
+    fill_pair_stats(c->pres, stats);
+  });
+}
+
+kslam_status kslam_pair_screen_overlaps(kslam_ctx *c, const kslam_overlap *overlaps, uint64_t n_overlaps,
+                                        const uint32_t *read_lens, uint64_t n_reads, int paired, uint32_t score_threshold,
+                                        double score_fraction, uint32_t stages, kslam_pair_stats *stats) {
+  return guarded(c, [&] {
+    if ((n_overlaps && !overlaps) || (n_reads && !read_lens)) throw StatusError{KSLAM_ERR_ARG, "null argument"};
+    if (paired && (n_reads < 2 || (n_reads & 1)))
+      throw StatusError{KSLAM_ERR_ARG, "paired data needs an even, non-zero number of reads ([R1 block | R2 block])"};
+    if (n_overlaps >= (1ull << 30)) throw StatusError{KSLAM_ERR_UNSUPPORTED, "2^30 or more overlaps in one batch"};
+    c->have_pairs = false;
+    c->pr_ov.ensure((n_overlaps + 1) * sizeof(kslam_overlap));
+    c->pr_len.ensure((n_reads + 1) * sizeof(uint32_t));
+    if (n_overlaps)
+      HIPCHK(hipMemcpyAsync(c->pr_ov.p, overlaps, n_overlaps * sizeof(kslam_overlap), hipMemcpyHostToDevice, c->stream));
+    if (n_reads) HIPCHK(hipMemcpyAsync(c->pr_len.p, read_lens, n_reads * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    pair_and_screen(c->pr_ov.as<kslam_overlap>(), n_overlaps, c->pr_len.as<uint32_t>(), n_reads, paired ? 1 : 0,
+                    score_threshold, score_fraction, (stages & 1u) != 0, (stages & 2u) != 0, c->pw, c->sortws, &c->pres,
+                    c->stream);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->have_pairs = true;
+    fill_pair_stats(c->pres, stats);
+  });
+}
+
+kslam_status kslam_take_pairs(kslam_ctx *c, kslam_read_pair **read_pairs, uint64_t *n_read_pairs, kslam_paired_overlap **pairs,
+                              uint64_t *n_pairs) {
+  if (!c || !read_pairs || !n_read_pairs || !pairs || !n_pairs) return KSLAM_ERR_ARG;
+  *read_pairs = nullptr; *pairs = nullptr; *n_read_pairs = 0; *n_pairs = 0;
+  kslam_read_pair *hg = nullptr;
+  kslam_paired_overlap *hp = nullptr;
+  kslam_status st = guarded(c, [&] {
+    if (!c->have_pairs) throw StatusError{KSLAM_ERR_STATE, "kslam_pair_screen has not been called for this result"};
+    hg = (kslam_read_pair *)pinned_get(c, (c->pres.n_read_pairs + 1) * sizeof(kslam_read_pair));
+    hp = (kslam_paired_overlap *)pinned_get(c, (c->pres.n_pairs + 1) * sizeof(kslam_paired_overlap));
+    if (c->pres.n_read_pairs)
+      HIPCHK(hipMemcpyAsync(hg, c->pres.d_groups, c->pres.n_read_pairs * sizeof(kslam_read_pair), hipMemcpyDeviceToHost, c->stream));
+    if (c->pres.n_pairs)
+      HIPCHK(hipMemcpyAsync(hp, c->pres.d_pairs, c->pres.n_pairs * sizeof(kslam_paired_overlap), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+  });
+  if (st != KSLAM_OK) {
+    if (hg) pinned_put(c, hg);
+    if (hp) pinned_put(c, hp);
+    return st;
+  }
+  *read_pairs = hg; *n_read_pairs = c->pres.n_read_pairs; *pairs = hp; *n_pairs = c->pres.n_pairs;
+  return KSLAM_OK;
+}
+
+kslam_status kslam_set_pairing(kslam_ctx *c, int paired, uint32_t score_threshold, double score_fraction, uint32_t stages) {
+  if (!c) return KSLAM_ERR_ARG;
+  std::lock_guard<std::mutex> lk(c->as_mu);
+  c->pairing.paired = paired; c->pairing.thr = score_threshold; c->pairing.fraction = score_fraction;
+  c->pairing.stages = stages & 3u;
+  return KSLAM_OK;
+}
+
 void kslam_free_pinned(kslam_ctx *c, void *p) {
   if (!c || !p) return;
   if (pinned_put(c, p)) return;
@@ -1276,6 +1374,8 @@ kslam_status kslam_wait_batch(kslam_ctx *c, uint64_t ticket, kslam_overlap **out
   if (st != KSLAM_OK) return st;
   kslam_free_pinned(c, r.details);
   kslam_free_pinned(c, r.md_pool);
+  kslam_free_pinned(c, r.read_pairs);
+  kslam_free_pinned(c, r.pairs);
   *out = r.overlaps; *n_out = r.n_overlaps; *cigar_pool = r.cigar_pool; *n_cigar = r.n_cigar;
   return KSLAM_OK;
 }
@@ -1285,6 +1385,8 @@ void kslam_release_batch(kslam_ctx *c, kslam_batch_result *r) {
   kslam_free_batch(c, r->overlaps, r->cigar_pool);
   kslam_free_pinned(c, r->details);
   kslam_free_pinned(c, r->md_pool);
+  kslam_free_pinned(c, r->read_pairs);
+  kslam_free_pinned(c, r->pairs);
   memset(r, 0, sizeof *r);
 }
 
@@ -1304,11 +1406,15 @@ kslam_status kslam_collect_batch(kslam_ctx *c, uint64_t ticket, kslam_batch_resu
   if (st == KSLAM_OK) {
     res->overlaps = job->out; res->n_overlaps = job->n_out; res->cigar_pool = job->pool; res->n_cigar = job->n_cig;
     res->details = job->det; res->md_pool = job->md; res->n_md = job->n_md;
+    res->read_pairs = job->rp; res->n_read_pairs = job->n_rp; res->pairs = job->pr; res->n_pairs = job->n_pr;
+    res->pair_stats = job->pstats;
   } else {
     c->err = job->err;
     kslam_free_batch(c, job->out, job->pool);
     kslam_free_pinned(c, job->det);
     kslam_free_pinned(c, job->md);
+    kslam_free_pinned(c, job->rp);
+    kslam_free_pinned(c, job->pr);
   }
   delete job;
   return st;

@@ -1,0 +1,427 @@
+// pairs.hip -- the first half of the host tail on the device: score screen, read pairing, insert-size
+// statistics, insert-size screen and score-fraction screen, straight
+// from the overlap records the hot path left in HBM.
+//
+// Replaces, in the reference:
+//   screenOverlapsByScoreThreshold                      src/Overlap.h:329-341
+//   getPairedOverlaps / getPairsFromRead / makePair     src/PairedOverlap.h:107-270
+//   getPerReadOverlaps (paired and single end)          src/PairedOverlap.h:437-470, src/Overlap.h:303-327
+//   getDummyAlignmentPairsFromSingleEndReads            src/PairedOverlap.h:280-298
+//   getMaxAllowedInsertSize                             src/PairedOverlap.h:314-360
+//   screenPairedAlignmentsByInsertSize(replace = true)  src/PairedOverlap.h:396-436
+//   screenPairedAlignmentsByScore                       src/PairedOverlap.h:361-390
+// and follows k-slam_amd/host/tail.cpp (pair_stage, max_allowed_insert, screen_stage) decision for
+// decision, including the points where the reference leaves the result to an unstable sort: the pairing
+// "sort" is a merge of the R1 and R2 rows with ties in input order (R1 first), and the two per-read-pair
+// std::sort calls are reproduced with the permutation libstdc++ produces (gnu_sort.h).
+//
+// MI355X: one thread per read pair.  A pair's rows are two short runs of the overlap array (found by
+// binary search), its alignment pairs go to a private region of 4 x (its rows) records -- pairing emits
+// at most 2 per row, the insert-size screen at most doubles that -- so nothing is counted twice and no
+// thread waits for another; the survivors are compacted with two scans.  The insert sizes are appended
+// with one atomic per wave and sorted with the library's radix sort; quartiles and the percentile ladder
+// are read from the sorted array by index, the sums are exact 64-bit integers (and fall back to the
+// reference's sequential double accumulation on the host when they could exceed 2^53).
+#include <cmath>
+
+#include "common.h"
+#include "gnu_sort.h"
+
+namespace kslam {
+
+namespace {
+
+constexpr uint32_t NONE = 0xFFFFFFFFu;   // KSLAM_NO_OVERLAP
+using Rec = kslam_paired_overlap;
+
+__device__ inline uint64_t first_read_at_least(const kslam_overlap *ov, uint64_t lo, uint64_t hi, uint64_t read) {
+  while (lo < hi) {
+    const uint64_t m = (lo + hi) >> 1;
+    if (ov[m].read < read) lo = m + 1; else hi = m;
+  }
+  return lo;
+}
+
+__device__ inline Rec single_rec(const kslam_overlap &o, uint32_t idx, bool is_r1) {
+  Rec r;
+  r.combined_score = o.score;
+  r.entry = o.entry;
+  r.ref_start = o.ref_begin;
+  r.ref_end = o.ref_end;
+  r.insert_size = 0;
+  r.r1 = is_r1 ? idx : NONE;
+  r.r2 = is_r1 ? NONE : idx;
+  r.pad = 0;
+  return r;
+}
+
+struct PairArgs {
+  const kslam_overlap *ov;
+  uint64_t n;              // overlap records
+  const uint64_t *split;   // device: first row of the R2 block (paired)
+  const uint32_t *read_len;
+  uint64_t units, mid;     // read pairs (or reads); reads per block
+  uint32_t thr;            // score threshold
+  int paired;
+  Rec *recs;               // 4 x n records of room
+  uint32_t *count;         // per unit
+  uint64_t *base;          // per unit: where its region starts
+  int32_t *inserts;        // n x 2 of room
+  unsigned long long *n_inserts, *n_kept, *n_initial;
+};
+
+// getPairsFromRead as a streaming state (host/tail.cpp: Pairer): one candidate slot per (mate, strand)
+__global__ __launch_bounds__(256) void k_pair(PairArgs a) {
+  const uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t n_recs = 0, kept = 0;
+  Rec *out = nullptr;
+  if (u < a.units) {
+    const kslam_overlap *ov = a.ov;
+    if (a.paired) {
+      const uint64_t split = *a.split;
+      uint64_t i = first_read_at_least(ov, 0, split, u), i1 = first_read_at_least(ov, i, split, u + 1);
+      uint64_t j = first_read_at_least(ov, split, a.n, a.mid + u), j1 = first_read_at_least(ov, j, a.n, a.mid + u + 1);
+      const uint64_t base = 4 * (i + (j - split));
+      a.base[u] = base;
+      out = a.recs + base;
+      uint32_t slot[2][2] = {{NONE, NONE}, {NONE, NONE}};
+      bool used[2][2] = {{false, false}, {false, false}};
+      bool open = false;
+      uint32_t cur_entry = 0;
+      auto emit_single = [&](uint32_t idx, bool is_r1) { out[n_recs++] = single_rec(ov[idx], idx, is_r1); };
+      auto close_run = [&]() {   // the order of src/PairedOverlap.h:217-240
+        if (!used[1][0] && slot[1][0] != NONE) emit_single(slot[1][0], false);
+        if (!used[1][1] && slot[1][1] != NONE) emit_single(slot[1][1], false);
+        if (!used[0][0] && slot[0][0] != NONE) emit_single(slot[0][0], true);
+        if (!used[0][1] && slot[0][1] != NONE) emit_single(slot[0][1], true);
+        for (int m = 0; m < 2; m++)
+          for (int s = 0; s < 2; s++) { slot[m][s] = NONE; used[m][s] = false; }
+      };
+      while (i < i1 || j < j1) {
+        bool take1;
+        if (j >= j1) take1 = true;
+        else if (i >= i1) take1 = false;
+        else {
+          const kslam_overlap &x = ov[i], &y = ov[j];
+          take1 = x.entry != y.entry ? x.entry < y.entry : x.rel <= y.rel;
+        }
+        const uint32_t idx = (uint32_t)(take1 ? i++ : j++);
+        const kslam_overlap o = ov[idx];
+        if (o.score < a.thr) continue;   // src/Overlap.h:329-341
+        kept++;
+        if (open && o.entry != cur_entry) close_run();
+        open = true;
+        cur_entry = o.entry;
+        const int s = o.revcomp ? 1 : 0, m = take1 ? 0 : 1;
+        if (!used[m][s] && slot[m][s] != NONE) emit_single(slot[m][s], m == 0);
+        slot[m][s] = idx;
+        used[m][s] = false;
+        const uint32_t other = slot[1 - m][1 - s];
+        if (other != NONE) {   // makePair, src/PairedOverlap.h:107-125
+          const uint32_t i1x = m == 0 ? idx : other, i2x = m == 0 ? other : idx;
+          const kslam_overlap &p = ov[i1x], &q = ov[i2x];
+          const bool r1_first = m != 0;
+          const uint32_t ins = r1_first ? (uint32_t)((int64_t)q.rel - p.rel + a.read_len[q.read])
+                                        : (uint32_t)((int64_t)p.rel - q.rel + a.read_len[p.read]);
+          Rec r;
+          r.combined_score = (uint16_t)(p.score + q.score);   // PairedOverlap's uint16_t parameter
+          r.entry = q.entry;
+          r.ref_start = min(p.ref_begin, q.ref_begin);
+          r.ref_end = max(p.ref_end, q.ref_end);
+          r.insert_size = ins;
+          r.r1 = i1x;
+          r.r2 = i2x;
+          r.pad = 0;
+          out[n_recs++] = r;
+          used[m][s] = true;
+          used[1 - m][1 - s] = true;
+        }
+      }
+      if (open) close_run();
+    } else {
+      // getPerReadOverlaps (single end) + dummy pairs: every overlap of the read as an R1-only record
+      uint64_t i = first_read_at_least(ov, 0, a.n, u), i1 = first_read_at_least(ov, i, a.n, u + 1);
+      const uint64_t base = 4 * i;
+      a.base[u] = base;
+      out = a.recs + base;
+      for (; i < i1; i++) {
+        const kslam_overlap o = ov[i];
+        if (o.score < a.thr) continue;
+        kept++;
+        out[n_recs++] = single_rec(o, (uint32_t)i, true);
+      }
+    }
+    a.count[u] = n_recs;
+  }
+  // insert sizes of this thread's records, appended with one atomic per wave
+  uint32_t n_ins = 0;
+  for (uint32_t k = 0; k < n_recs; k++) n_ins += out[k].insert_size != 0;
+  const uint32_t lane = threadIdx.x & 63;
+  uint32_t incl = n_ins, tot_k = kept, tot_r = n_recs;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t t = __shfl_up(incl, d, 64);
+    if (lane >= (uint32_t)d) incl += t;
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    tot_k += __shfl_down(tot_k, d, 64);
+    tot_r += __shfl_down(tot_r, d, 64);
+  }
+  const uint32_t wave_total = __shfl(incl, 63, 64);
+  unsigned long long wbase = 0;
+  if (lane == 0) {
+    if (wave_total) wbase = atomicAdd(a.n_inserts, (unsigned long long)wave_total);
+    if (tot_k) atomicAdd(a.n_kept, (unsigned long long)tot_k);
+    if (tot_r) atomicAdd(a.n_initial, (unsigned long long)tot_r);
+  }
+  wbase = __shfl(wbase, 0, 64);
+  unsigned long long at = wbase + (incl - n_ins);
+  for (uint32_t k = 0; k < n_recs; k++)
+    if (out[k].insert_size != 0) a.inserts[at++] = (int32_t)out[k].insert_size;
+}
+
+__global__ void k_widen(const int32_t *__restrict__ v, uint64_t n, uint2 *__restrict__ out) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = make_uint2((uint32_t)v[i], 0u);
+}
+__global__ void k_pick(const uint2 *__restrict__ sorted, const uint64_t *__restrict__ idx, uint32_t k, int32_t *__restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < k) out[i] = (int32_t)sorted[idx[i]].x;
+}
+// sums over the kept values lo <= v <= hi: sum, sum of squares (the reference multiplies in int: the
+// wrap-around is kept), sum of |squares| (to know whether the double accumulation stays exact), count
+__global__ __launch_bounds__(256) void k_insert_sums(const uint2 *__restrict__ sorted, uint64_t n, int32_t lo, int32_t hi,
+                                                     long long *__restrict__ out /*[4]*/) {
+  long long s1 = 0, s2 = 0, mag = 0, cnt = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const int32_t v = (int32_t)sorted[i].x;
+    if (v < lo || v > hi) continue;
+    const int32_t sq = (int32_t)((uint32_t)v * (uint32_t)v);
+    s1 += v;
+    s2 += sq;
+    mag += sq < 0 ? -(long long)sq : (long long)sq;
+    cnt++;
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    s1 += __shfl_down(s1, d, 64);
+    s2 += __shfl_down(s2, d, 64);
+    mag += __shfl_down(mag, d, 64);
+    cnt += __shfl_down(cnt, d, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(reinterpret_cast<unsigned long long *>(out + 0), (unsigned long long)s1);
+    atomicAdd(reinterpret_cast<unsigned long long *>(out + 1), (unsigned long long)s2);
+    atomicAdd(reinterpret_cast<unsigned long long *>(out + 2), (unsigned long long)mag);
+    atomicAdd(reinterpret_cast<unsigned long long *>(out + 3), (unsigned long long)cnt);
+  }
+}
+
+struct ByInsert {
+  __host__ __device__ bool operator()(const Rec &x, const Rec &y) const { return x.insert_size < y.insert_size; }
+};
+struct ByScoreDesc {
+  __host__ __device__ bool operator()(const Rec &x, const Rec &y) const { return x.combined_score > y.combined_score; }
+};
+
+// screenPairedAlignmentsByInsertSize(replace = true) then screenPairedAlignmentsByScore on one read
+// pair's records (host/tail.cpp: insert_screen, score_screen)
+__global__ __launch_bounds__(256) void k_screen(const kslam_overlap *__restrict__ ov, Rec *__restrict__ recs,
+                                                const uint64_t *__restrict__ base, uint32_t *__restrict__ count,
+                                                uint64_t units, int do_insert, uint32_t limit, int do_score,
+                                                double fraction, uint32_t *__restrict__ flags) {
+  const uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= units) return;
+  uint32_t n = count[u];
+  if (n) {
+    Rec *v = recs + base[u];
+    if (do_insert) {
+      kslam_gnu::sort(v, v + n, ByInsert());
+      uint32_t cut = 0;
+      while (cut < n && !(v[cut].insert_size > limit)) cut++;
+      uint32_t end = n;
+      for (uint32_t i = cut; i < n; i++) {
+        const kslam_overlap &o1 = ov[v[i].r1], &o2 = ov[v[i].r2];
+        Rec r;
+        r.combined_score = o1.score;
+        r.entry = v[i].entry;
+        r.ref_start = o1.ref_begin;
+        r.ref_end = o1.ref_end;
+        r.insert_size = 0;
+        r.r1 = v[i].r1;
+        r.r2 = NONE;
+        r.pad = 0;
+        v[end++] = r;
+        Rec &c = v[i];
+        c.combined_score = o2.score;
+        c.insert_size = 0;
+        c.r1 = NONE;
+        c.ref_start = o2.ref_begin;
+        c.ref_end = o2.ref_end;
+      }
+      n = end;
+    }
+    if (do_score) {
+      kslam_gnu::sort(v, v + n, ByScoreDesc());
+      const unsigned top = v[0].combined_score;
+      const double bar = top * fraction;
+      uint32_t k = 0;
+      while (k < n && !((double)v[k].combined_score < bar)) k++;
+      n = k;
+    }
+    count[u] = n;
+  }
+  flags[u] = n ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(256) void k_emit_groups(const Rec *__restrict__ recs, const uint64_t *__restrict__ base,
+                                                     const uint32_t *__restrict__ count, const uint32_t *__restrict__ gpos,
+                                                     const uint64_t *__restrict__ rpos, uint64_t units, uint64_t mid,
+                                                     int paired, kslam_read_pair *__restrict__ groups,
+                                                     Rec *__restrict__ dense) {
+  const uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= units) return;
+  const uint32_t n = count[u];
+  if (!n) return;
+  kslam_read_pair g;
+  g.r1_read = (uint32_t)u;
+  g.r2_read = paired ? (uint32_t)(u + mid) : 0u;
+  g.first = rpos[u];
+  g.count = n;
+  groups[gpos[u]] = g;
+  const Rec *src = recs + base[u];
+  Rec *dst = dense + rpos[u];
+  for (uint32_t k = 0; k < n; k++) dst[k] = src[k];
+}
+
+}  // namespace
+
+// getMaxAllowedInsertSize on the device-resident insert sizes (host/tail.cpp: max_allowed_insert)
+static uint32_t max_allowed_insert_device(int32_t *d_ins, uint64_t n, PairWork &W, SortWorkspace &sortws, hipStream_t s) {
+  if (!n) return 0xFFFFFFFFu;
+  W.sort_a.ensure((n + 1) * sizeof(uint2));
+  W.sort_b.ensure((n + 1) * sizeof(uint2));
+  hipLaunchKernelGGL(k_widen, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_ins, n, W.sort_a.as<uint2>());
+  SortPass passes[4];
+  for (uint32_t b = 0; b < 4; b++) passes[b] = SortPass{0, 8 * b, 0x80000000u};   // signed order
+  const uint2 *sorted = (const uint2 *)radix_sort(W.sort_a.p, W.sort_b.p, n, 2, passes, 4, sortws, s, nullptr, nullptr, nullptr);
+  // the percentile ladder, the quartiles: 102 reads by index (indices as the reference computes them, in double)
+  uint64_t idx[102];
+  for (int i = 0; i < 100; i++) idx[i] = (uint64_t)std::floor(n * (i) / 100.0);
+  idx[100] = (uint64_t)std::floor(n * 0.25);
+  idx[101] = (uint64_t)std::floor(n * 0.75);
+  // (floor(n * (i + 1) / 100.0) for i = 98 is index 99's value: idx[99]; index 100 = n would be past the end
+  // and the reference never reads it: its loop stops at i = 98)
+  W.idx.ensure(sizeof idx);
+  W.picked.ensure(102 * sizeof(int32_t) + 8 * sizeof(long long));
+  HIPCHK(hipMemcpyAsync(W.idx.p, idx, sizeof idx, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(k_pick, dim3(1), dim3(128), 0, s, sorted, W.idx.as<uint64_t>(), 102u, W.picked.as<int32_t>());
+  int32_t v[102];
+  HIPCHK(hipMemcpyAsync(v, W.picked.p, sizeof v, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  int32_t limit = 0;
+  for (int i = 0; i < 99; i++)
+    if (v[i + 1] - v[i] > 1000) {
+      limit = v[i];   // sz[floor(n * i / 100)]: integer division in the reference, same index for n < 2^53
+      break;
+    }
+  const int32_t lq = v[100], uq = v[101];
+  const int32_t lo = 0;
+  int32_t hi = uq + 2 * (uq - lq);
+  if (limit) hi = limit;
+  if (hi == 0) hi = INT32_MAX;
+  long long *d_sums = reinterpret_cast<long long *>(W.picked.as<int32_t>() + 104);
+  HIPCHK(hipMemsetAsync(d_sums, 0, 4 * sizeof(long long), s));
+  const unsigned nb = (unsigned)std::min<uint64_t>((n + 255) / 256, 2048);
+  hipLaunchKernelGGL(k_insert_sums, dim3(nb), dim3(256), 0, s, sorted, n, lo, hi, d_sums);
+  long long h[4];
+  HIPCHK(hipMemcpyAsync(h, d_sums, sizeof h, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  const long long t1 = h[0], t2 = h[1], tm = h[2], kept = h[3];
+  double sum, sq;
+  if (tm < (1ll << 53) && std::llabs(t1) < (1ll << 53)) {
+    sum = (double)t1;   // every partial sum of the reference's sequential accumulation is exact too
+    sq = (double)t2;
+  } else {
+    // beyond 2^53 the reference's result depends on its order of additions: do them in that order
+    std::vector<uint2> hs(n);
+    HIPCHK(hipMemcpyAsync(hs.data(), sorted, n * sizeof(uint2), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    sum = 0;
+    sq = 0;
+    for (uint64_t i = 0; i < n; i++) {
+      const int32_t x = (int32_t)hs[i].x;
+      if (x < lo || x > hi) continue;
+      sum += x;
+      sq = sq + (int32_t)((uint32_t)x * (uint32_t)x);
+    }
+  }
+  const double mean = sum / kept;
+  const double sd = std::sqrt(sq / kept - mean * mean);
+  const double r = std::floor(mean + 6 * sd);
+  return std::isnan(r) ? 0xFFFFFFFFu : (uint32_t)r;
+}
+
+void pair_and_screen(const kslam_overlap *d_ov, uint64_t n, const uint32_t *d_read_len, uint64_t n_reads, int paired,
+                     uint32_t score_threshold, double score_fraction, int do_insert, int do_score, PairWork &W,
+                     SortWorkspace &sortws, PairResult *res, hipStream_t s) {
+  memset(res, 0, sizeof *res);
+  res->max_insert_size = 0xFFFFFFFFu;
+  const uint64_t units = paired ? n_reads / 2 : n_reads, mid = n_reads / 2;
+  if (units == 0) return;
+  W.recs.ensure((4 * n + 4) * sizeof(Rec));
+  W.count.ensure((units + 1) * sizeof(uint32_t));
+  W.base.ensure((units + 1) * sizeof(uint64_t));
+  W.inserts.ensure((2 * n + 2) * sizeof(int32_t));
+  W.flags.ensure((units + 1) * sizeof(uint32_t));
+  W.gpos.ensure((units + 1) * sizeof(uint32_t));
+  W.rpos.ensure((units + 1) * sizeof(uint64_t));
+  W.scan_tmp.ensure(scan_tmp_bytes(units));
+  W.totals.ensure(16 * sizeof(uint64_t));
+  uint64_t *tot = W.totals.as<uint64_t>();
+  HIPCHK(hipMemsetAsync(tot, 0, 16 * sizeof(uint64_t), s));
+  // tot[0..1]: split (rows of the R1 block) by the shard kernel; [4] inserts, [5] kept, [6] pairs after pairing
+  shard_counts(d_ov, n, (uint32_t)mid, 0, tot, s);
+  PairArgs a;
+  a.ov = d_ov; a.n = n; a.split = tot; a.read_len = d_read_len; a.units = units; a.mid = mid;
+  a.thr = score_threshold; a.paired = paired;
+  a.recs = W.recs.as<Rec>(); a.count = W.count.as<uint32_t>(); a.base = W.base.as<uint64_t>();
+  a.inserts = W.inserts.as<int32_t>();
+  a.n_inserts = reinterpret_cast<unsigned long long *>(tot + 4);
+  a.n_kept = reinterpret_cast<unsigned long long *>(tot + 5);
+  a.n_initial = reinterpret_cast<unsigned long long *>(tot + 6);
+  const unsigned nb = (unsigned)((units + 255) / 256);
+  hipLaunchKernelGGL(k_pair, dim3(nb), dim3(256), 0, s, a);
+  uint64_t h[3];
+  HIPCHK(hipMemcpyAsync(h, tot + 4, sizeof h, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  res->n_insert_sizes = h[0];
+  res->n_overlaps_screened = h[1];
+  res->n_paired_initial = h[2];
+  uint32_t limit = 0xFFFFFFFFu;
+  if (do_insert && paired) {
+    limit = max_allowed_insert_device(W.inserts.as<int32_t>(), h[0], W, sortws, s);
+    res->max_insert_size = limit;
+  }
+  hipLaunchKernelGGL(k_screen, dim3(nb), dim3(256), 0, s, d_ov, W.recs.as<Rec>(), W.base.as<uint64_t>(),
+                     W.count.as<uint32_t>(), units, (do_insert && paired) ? 1 : 0, limit, do_score ? 1 : 0, score_fraction,
+                     W.flags.as<uint32_t>());
+  exclusive_scan_u32(W.flags.as<uint32_t>(), W.gpos.as<uint32_t>(), units, tot + 8, W.scan_tmp.p, s);
+  exclusive_scan_u32_to_u64(W.count.as<uint32_t>(), W.rpos.as<uint64_t>(), units, tot + 9, W.scan_tmp.p, s);
+  uint64_t g2[2];
+  HIPCHK(hipMemcpyAsync(g2, tot + 8, sizeof g2, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  res->n_read_pairs = g2[0];
+  res->n_pairs = g2[1];
+  W.groups.ensure((g2[0] + 1) * sizeof(kslam_read_pair));
+  W.dense.ensure((g2[1] + 1) * sizeof(Rec));
+  hipLaunchKernelGGL(k_emit_groups, dim3(nb), dim3(256), 0, s, W.recs.as<Rec>(), W.base.as<uint64_t>(), W.count.as<uint32_t>(),
+                     W.gpos.as<uint32_t>(), W.rpos.as<uint64_t>(), units, mid, paired, W.groups.as<kslam_read_pair>(),
+                     W.dense.as<Rec>());
+  HIPCHK(hipGetLastError());
+  res->d_groups = W.groups.as<kslam_read_pair>();
+  res->d_pairs = W.dense.as<Rec>();
+}
+
+}  // namespace kslam

@@ -1635,6 +1635,61 @@ kslam_status kslam_tail_sam_write_rows(const kslam_tail_params *params, const ks
   });
 }
 
+kslam_status kslam_tail_finish_write_rows(const kslam_tail_params *params, const kslam_reads_view *reads,
+                                          const kslam_index_view *index, const kslam_overlap *overlaps,
+                                          uint64_t n_overlaps, const uint32_t *cigar_pool, uint64_t n_cigar,
+                                          const kslam_row_detail *details, const char *md_pool, uint64_t n_md,
+                                          kslam_read_pair *read_pairs, uint64_t n_read_pairs,
+                                          kslam_paired_overlap *pairs, uint64_t n_pairs, kslam_write_fn write,
+                                          void *user, kslam_tail_stats *stats) {
+  return guarded([&] {
+    if (!write) fail(KSLAM_ERR_ARG, "null writer");
+    if ((!read_pairs && n_read_pairs) || (!pairs && n_pairs)) fail(KSLAM_ERR_ARG, "null argument");
+    Input in = make_input(params, reads, overlaps, n_overlaps);
+    for (uint64_t g = 0; g < n_read_pairs; g++)
+      if (read_pairs[g].first + read_pairs[g].count > n_pairs) fail(KSLAM_ERR_ARG, "read pair slice outside the pairs array");
+    Arena &A = arena();
+    std::lock_guard<std::mutex> one(A.call);
+    kslam_tail_stats st;
+    memset(&st, 0, sizeof st);
+    st.n_overlaps_in = n_overlaps;
+    TailState ts;
+    ts.recs = pairs;
+    ts.groups = read_pairs;
+    ts.n_groups = n_read_pairs;
+    ts.n_recs = n_pairs;
+    ts.rec_extent = n_pairs;
+    double t0 = now_ms();
+    if (in.p->pseudo_assembly && (in.stages & KSLAM_TAIL_PSEUDO_ASM)) {
+      uint32_t mx = 0;
+      for (uint64_t k = 0; k < n_pairs; k++) mx = std::max(mx, pairs[k].entry);
+      ts.max_entry = mx;
+      pseudo_stage(in, A, ts);
+      rescreen_stage(in, ts);
+    }
+    st.ms_pseudo = now_ms() - t0;
+    st.n_read_pairs = ts.n_groups;
+    uint64_t total = 0;
+    for (size_t g = 0; g < ts.n_groups; g++) total += ts.groups[g].count;
+    st.n_paired_final = total;
+    st.threads = in.threads;
+    SamInput si{params, reads, index, overlaps, n_overlaps, cigar_pool, n_cigar};
+    if (details && cigar_pool) {
+      if (!md_pool && n_md) fail(KSLAM_ERR_ARG, "null MD pool");
+      si.det = details;
+      si.md_pool = md_pool;
+      si.n_md = n_md;
+    }
+    SamSink sink;
+    sink.write = write;
+    sink.user = user;
+    double t1 = now_ms();
+    sam_stage(si, A, in.threads, ts.groups, ts.n_groups, ts.recs, sink, &st.sam_bytes);
+    st.ms_sam = now_ms() - t1;
+    if (stats) *stats = st;
+  });
+}
+
 void kslam_tail_release_buffers(void) {
   Arena &A = arena();
   std::lock_guard<std::mutex> one(A.call);

@@ -21,7 +21,8 @@ assert PAIRED_OVERLAP_DT.itemsize == 32 and READ_PAIR_DT.itemsize == 24
 
 # every symbol include/kslam_tail.h declares
 EXPORTS = ["kslam_tail_last_error", "kslam_tail_pairs", "kslam_sam_records", "kslam_tail_sam",
-           "kslam_tail_sam_write", "kslam_tail_sam_rows", "kslam_tail_sam_write_rows", "kslam_tail_release_buffers",
+           "kslam_tail_sam_write", "kslam_tail_sam_rows", "kslam_tail_sam_write_rows", "kslam_tail_finish_write_rows",
+           "kslam_tail_release_buffers",
            "kslam_sam_header"]
 WRITE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64)
 
@@ -182,6 +183,8 @@ def lib():
                                           _vp, _vp, _u64, P(_vp), P(_u64), P(TailStats)]
         L.kslam_tail_sam_write_rows.argtypes = [P(TailParams), P(ReadsView), P(IndexView), _vp, _u64, _vp, _u64,
                                                 _vp, _vp, _u64, WRITE_FN, _vp, P(TailStats)]
+        L.kslam_tail_finish_write_rows.argtypes = [P(TailParams), P(ReadsView), P(IndexView), _vp, _u64, _vp, _u64,
+                                                   _vp, _vp, _u64, _vp, _u64, _vp, _u64, WRITE_FN, _vp, P(TailStats)]
         L.kslam_tail_release_buffers.restype = None
         L.kslam_sam_header.argtypes = [P(IndexView), C.c_char_p, P(_vp), P(_u64)]
         _lib = L
@@ -300,6 +303,36 @@ def tail_sam_discard_rows(params, reads, index, overlaps, cigar_pool, details, m
     _chk(L.kslam_tail_sam_write_rows(C.byref(params), C.byref(reads.view), C.byref(index.view), pov, len(ov),
                                      _p(pool) if len(pool) else None, len(pool), _p(det) if len(det) else None,
                                      _p(md) if len(md) else None, len(md), cb, None, C.byref(st)))
+    return st
+
+
+def tail_finish_rows(params, reads, index, overlaps, cigar_pool, details, md_pool, read_pairs, pairs, sink=None):
+    """kslam_tail_finish_write_rows: read pairs / alignment pairs from kslam_pair_screen (both arrays are
+    MODIFIED in place) -> [pseudo-assembly + second score screen] -> SAM text to sink(bytes) (None: dropped)
+    -> stats.  details / md_pool may be None."""
+    L = lib()
+    ov, pov = _ov(overlaps)
+    pool = np.ascontiguousarray(cigar_pool, dtype=np.uint32)
+    det = np.ascontiguousarray(details) if details is not None else None
+    md = np.ascontiguousarray(md_pool, dtype=np.uint8) if md_pool is not None else np.zeros(0, dtype=np.uint8)
+    assert read_pairs.dtype == READ_PAIR_DT and pairs.dtype == PAIRED_OVERLAP_DT
+    assert read_pairs.flags["C_CONTIGUOUS"] and pairs.flags["C_CONTIGUOUS"] and read_pairs.flags["WRITEABLE"] and pairs.flags["WRITEABLE"]
+    st = TailStats()
+
+    def _cb(user, data, n):
+        try:
+            if sink is not None:
+                sink(C.string_at(data, n))
+            return 0
+        except Exception:
+            return 1
+    cb = WRITE_FN(_cb)
+    _chk(L.kslam_tail_finish_write_rows(C.byref(params), C.byref(reads.view), C.byref(index.view), pov, len(ov),
+                                        _p(pool) if len(pool) else None, len(pool),
+                                        _p(det) if det is not None and len(det) else None,
+                                        _p(md) if len(md) else None, len(md),
+                                        _p(read_pairs) if len(read_pairs) else None, len(read_pairs),
+                                        _p(pairs) if len(pairs) else None, len(pairs), cb, None, C.byref(st)))
     return st
 
 

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol(kslam):
     for name in declared:
         assert hasattr(L, name), "missing export " + name
     assert sorted(kslam.EXPORTS) == declared
-    assert L.kslam_abi_version() == 3
+    assert L.kslam_abi_version() == 4
 
 
 def test_library_exports_every_tail_symbol(kslam):
@@ -37,7 +37,7 @@ def test_library_exports_every_tail_symbol(kslam):
     T = importlib.import_module("kslam_amd.tail")
     L = ctypes.CDLL(kslam.LIB_PATH)
     declared = _declared_symbols("kslam_tail.h")
-    assert len(declared) == 9
+    assert len(declared) == 10
     for name in declared:
         assert hasattr(L, name), "missing export " + name
     assert sorted(T.EXPORTS) == declared

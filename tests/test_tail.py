@@ -11,6 +11,7 @@ pinned by what the output must satisfy on its own:
 These tests are host-only except the last one (hot path on the GPU -> tail).
 """
 import importlib
+import os
 import re
 
 import numpy as np
@@ -348,3 +349,17 @@ def test_gpu_hot_path_into_tail_matches_cpu_chain(kslam, oracle, synth, T):
     eal, ecig, _ = oracle.align_to_database(rb, gb, oracle.Params.default())
     assert sam == oracle.tail_sam(P, R.view, I.view, eal, ecig)
     assert sam.count(b"\n") >= 2 * st.n_read_pairs > n_pairs
+
+
+def test_gnu_sort_header_reproduces_std_sort(tmp_path):
+    """csrc/gnu_sort.h (the std::sort restatement the device pairing / screens use) against the real
+    std::sort of this toolchain: 120 k tie-heavy, adversarial and random arrays, element for element."""
+    import shutil
+    import subprocess
+    gxx = shutil.which("g++")
+    assert gxx
+    exe = str(tmp_path / "gnu_sort_check")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call([gxx, "-O2", "-std=c++17", os.path.join(root, "tests", "gnu_sort_check.cpp"), "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "GNU_SORT_OK" in r.stdout, r.stdout + r.stderr

@@ -215,20 +215,34 @@ __global__ __launch_bounds__(JB) void k_join_fill(const uint4 *__restrict__ recs
   }
 }
 
+// std::unique with "same read & entry & |delta rel| < 3 against the LAST KEPT element" (Overlap.h:79-85, 290)
+// is a greedy scan, but it only carries state across neighbours that are closer than 3: an element whose
+// predecessor (same read and entry) lies 3 or more below it is kept whatever happened before -- the last
+// kept element is at most that predecessor.  So the list falls into independent RUNS (chains of
+// neighbours less than 3 apart) and one lane walks one run, not one whole (read, entry) segment: hits
+// along a tandem repeat of period >= 3, thousands per segment, are all run heads and resolve in parallel;
+// only dense runs (consecutive positions: homopolymers) are walked serially, and those are bounded by
+// what one read can seed.
 __global__ void k_dedupe_flags(const uint64_t *__restrict__ keys, uint64_t n, uint32_t seg_shift,
                                uint64_t rel_mask, uint32_t *__restrict__ flags) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint64_t k = keys[i];
   const uint64_t seg = k >> seg_shift;
-  if (i > 0 && (keys[i - 1] >> seg_shift) == seg) return;  // not a (read, entry) head
-  int64_t last = (int64_t)((k >> 1) & rel_mask);
+  const int64_t rel = (int64_t)((k >> 1) & rel_mask);
+  if (i > 0) {
+    const uint64_t kp = keys[i - 1];
+    if ((kp >> seg_shift) == seg && rel - (int64_t)((kp >> 1) & rel_mask) < 3) return;  // inside a run: its head decides
+  }
+  int64_t last = rel, prev = rel;
   flags[i] = 1;
   for (uint64_t j = i + 1; j < n; j++) {
     const uint64_t kj = keys[j];
     if ((kj >> seg_shift) != seg) break;
     const int64_t rj = (int64_t)((kj >> 1) & rel_mask);
-    if (rj - last < 3) flags[j] = 0;  // Overlap.h:83 vs the last kept element
+    if (rj - prev >= 3) break;           // the next run: its own head
+    prev = rj;
+    if (rj - last < 3) flags[j] = 0;     // Overlap.h:83 vs the last kept element
     else { flags[j] = 1; last = rj; }
   }
 }

@@ -545,6 +545,41 @@ def test_repeated_genomes_long_runs(kslam, oracle, synth):
     _compare_alignments(got, gcig, exp, ecig)
 
 
+@pytest.mark.parametrize("period", [7, 2])
+def test_long_tandem_repeat_thousands_of_hits_per_read_and_entry(kslam, oracle, synth, period):
+    """One entry that is a 21 kb tandem repeat: every read k-mer meets hundreds of genome k-mers, a read has
+    thousands of candidate positions on ONE entry.  Period 7: neighbouring hits lie >= 3 apart, every one is
+    kept (each is the head of its own run in k_dedupe_flags -- the ADVICE-r1 case that used to walk a whole
+    (read, entry) segment on one lane); period 2: dense runs, the greedy rule thins them."""
+    rng = np.random.default_rng(31 + period)
+    unit = synth.random_bases(rng, period)
+    if period == 2:
+        unit = np.frombuffer(b"AC", dtype=np.uint8)
+    g = np.resize(unit, 21000)
+    flank = synth.random_bases(rng, 3000)
+    genome = np.concatenate([flank, g, flank])
+    reads = []
+    for _ in range(24):
+        p = int(rng.integers(2900, 3000 + 21000 - 100))
+        r = synth.mutate(rng, genome[p:p + 150], 0.01, 0.0)
+        reads.append(synth.revcomp(r) if rng.random() < 0.5 else r)
+    rb, gb = synth.to_bytes(reads), [genome.tobytes(), synth.random_bases(rng, 5000).tobytes()]
+    c = kslam.Context()
+    c.set_index(gb)
+    c.load_reads(rb)
+    got_t, raw = c.find_overlaps()
+    recs = np.concatenate([oracle.extract_kmers(rb, False, 1), oracle.extract_kmers(gb, True, 16)])
+    exp_t, exp_raw = oracle.find_overlaps(oracle.sort_kmers(recs), [len(r) for r in rb])
+    assert raw == exp_raw and raw > 100000
+    assert len(got_t) == len(exp_t) and (len(exp_t) > 20000 if period == 7 else len(exp_t) > 3000)
+    for f in ("read", "entry", "rel", "revcomp"):
+        assert (got_t[f] == exp_t[f]).all(), f
+    got, gcig = c.align_batch(rb)
+    c.close()
+    exp, ecig, _ = oracle.align_to_database(rb, gb)
+    _compare_alignments(got, gcig, exp, ecig)
+
+
 @pytest.mark.parametrize("unknown_nd", [None, "32", "48", "64"])
 def test_equal_best_scores_on_neighbouring_diagonals(kslam, oracle, monkeypatch, unknown_nd):
     """tests/golden/sw_tie_cases.json: reads whose best score is reached by two alignments ending a few

@@ -276,47 +276,58 @@ def full_pipeline(K, ctx, reads, db, offs, read_len, steps, pseudo_assembly=Fals
 
     def collect(tk):
         res = ctx.collect_batch(tk)
-        return res + (ctx.last_pairs,)
+        return res + (ctx.last_pairs, ctx.last_reads)
 
-    def tail(batch, ov, cg, det, md, release, pairs):
+    def tail(batch, ov, cg, det, md, release, pairs, reads_view):
         rp, pr, pst = pairs
-        st = T.tail_finish_rows(P, batch, I, ov, cg, det, md, rp, pr)
+        st = T.tail_finish_rows(P, reads_view if reads_view is not None else batch, I, ov, cg, det, md, rp, pr)
         release()
-        batch.close()
+        if batch is not None:
+            batch.close()
         stats.append(st.as_dict())
 
     ctx.set_pairing(paired=True)
+    host_index = os.environ.get("KSLAM_BENCH_HOST_FASTQ_INDEX") == "1"   # A/B: the record index on the host (round-2 first form)
 
     def parse_and_submit():
         t0 = time.perf_counter()
         # the host only INDEXES the records (line ends, identifiers, offsets); the texts go up as they
         # are and the bases / quality columns are cut out of them on the GPU
+        if not host_index:
+            # nothing is scanned on the host: line index, identifiers, offsets and columns are all made on the GPU
+            tk = ctx.submit_batch_fastq_text(h1.ptr, len1, h2.ptr, len2)
+            return None, tk, (0.0, time.perf_counter() - t0)
         batch, u1, u2 = F.index_pair(h1.ptr, len1, h2.ptr, len2, threads=nthr)
         t1 = time.perf_counter()
         tk = ctx.submit_batch_fastq(h1.ptr, len1, h2.ptr, len2, batch.n_reads, batch._cols.bases_off,
                                     batch.layout.bases_at, batch.layout.quality_at)
         return batch, tk, (t1 - t0, time.perf_counter() - t1)
     import ctypes as C
-    for _ in range(3):                             # warm-up batches (both lanes, the parser's block cache, the tail)
-        b0, t0_, _ = parse_and_submit()
-        tail(b0, *collect(t0_))
+    worker, parts, waits = None, [], []
+
+    def run(nsteps):
+        nonlocal worker
+        queue = [parse_and_submit()]                               # batch 0 on its way
+        for k in range(nsteps):
+            while len(queue) < 3 and k + len(queue) < nsteps:      # two more batches indexed and queued behind it
+                queue.append(parse_and_submit())
+            cur = queue.pop(0)
+            tw = time.perf_counter()
+            res = collect(cur[1])                                  # batch k back from the GPU
+            waits.append(time.perf_counter() - tw)
+            if worker is not None:
+                worker.join()                                      # host stage of batch k-1 done
+            worker = threading.Thread(target=tail, args=(cur[0],) + tuple(res))
+            worker.start()
+            parts.append(cur[2])
+        worker.join()
+        worker = None
+    run(6)          # warm-up in the same shape: both lanes, the parser's page-locked block cache, the tail's arenas
     stats.clear()
+    del parts[:], waits[:]
     torch.cuda.synchronize()
     t_start = time.perf_counter()
-    worker, parts, waits = None, [], []
-    cur = parse_and_submit()
-    for k in range(steps):
-        nxt = parse_and_submit() if k + 1 < steps else None        # batch k+1 parsed and queued
-        tw = time.perf_counter()
-        res = collect(cur[1])                                      # batch k back from the GPU
-        waits.append(time.perf_counter() - tw)
-        if worker is not None:
-            worker.join()                                          # tail of batch k-1 done
-        worker = threading.Thread(target=tail, args=(cur[0],) + tuple(res))
-        worker.start()
-        parts.append(cur[2])
-        cur = nxt
-    worker.join()
+    run(steps)
     wall = time.perf_counter() - t_start
     n_reads = 2 * n
     ms = lambda k: round(1e3 * sum(p[k] for p in parts) / len(parts), 2)   # noqa: E731
@@ -330,12 +341,13 @@ def full_pipeline(K, ctx, reads, db, offs, read_len, steps, pseudo_assembly=Fals
         "host_tail_phases_ms": {k[3:]: round(stats[-1][k], 2) for k in stats[-1] if k.startswith("ms_")},
         "fastq_mb_per_batch": round((len1 + len2) / 1e6, 1), "sam_mb_per_batch": round(stats[-1]["sam_bytes"] / 1e6, 1),
         "pseudo_assembly": bool(pseudo_assembly),
-        "what": "FASTQ text (2 files, in page-locked memory) -> record index (host: line ends, identifiers, offsets) -> "
-                "kslam_submit_batch_fastq (texts up by DMA, bases / quality columns cut out on the GPU, align, per-row "
+        "fastq_index": "host" if host_index else "gpu",
+        "what": "FASTQ text (2 files, in page-locked memory) -> kslam_submit_batch_fastq_text (texts up by DMA; line index, "
+                "identifiers, offsets and the bases / quality columns made on the GPU; align, per-row "
                 "NM / log-probability / MD, score screen / pairing / insert-size statistics / screens) -> "
                 "kslam_collect_batch -> [pseudo-assembly / second screen] SAM text (host, discarded by the "
-                "writer; no host copy of the database); index of batch k+1, GPU of batch k and host stage of batch "
-                "k-1 overlap; index and host stage share the library's one worker pool",
+                "writer; no host copy of the database); three batches in flight, the host stage of batch k-1 under the GPU "
+                "work of batches k, k+1",
     }
 
 

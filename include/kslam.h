@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define KSLAM_ABI_VERSION 4
+#define KSLAM_ABI_VERSION 5
 #define KSLAM_K 32u /* src/Globals.h:25 */
 
 typedef enum {
@@ -275,6 +275,12 @@ typedef struct {
   kslam_paired_overlap *pairs;
   uint64_t n_pairs;
   kslam_pair_stats pair_stats;
+  /* kslam_submit_batch_fastq_text only (else 0 / NULL): the batch as the host tail needs it */
+  uint64_t n_reads;
+  uint64_t *reads_bases_off; /* n_reads + 1 */
+  char *reads_ids;
+  uint64_t *reads_ids_off;   /* n_reads + 1 */
+  uint64_t consumed1, consumed2;
 } kslam_batch_result;
 kslam_status kslam_submit_batch(kslam_ctx *ctx, uint64_t n_reads, const char *const *bases,
                                 const char *const *quality, const uint32_t *lens,
@@ -294,6 +300,15 @@ kslam_status kslam_submit_batch_fastq(kslam_ctx *ctx, const char *r1, uint64_t l
                                       const char *r2, uint64_t len2, uint64_t n_reads,
                                       const uint64_t *offsets, const uint64_t *bases_at,
                                       const uint64_t *quality_at, uint64_t *ticket);
+/* and with the record index built on the device as well: the host hands over the two texts and nothing
+ * else.  The batch's read columns the host still needs come back in the result (reads_*: identifiers,
+ * their offsets, the base offsets = lengths; read i's bases and quality stay on the device), with
+ * consumed1 / consumed2 = where the reference's streams would stand (kslam_fastq_parse_pair's rule:
+ * up to max_pairs records per stream, 0 = no limit; at_eof as there).  Same errors as
+ * kslam_fastq_index_pair, reported by kslam_collect_batch. */
+kslam_status kslam_submit_batch_fastq_text(kslam_ctx *ctx, const char *r1, uint64_t len1,
+                                           const char *r2, uint64_t len2, uint64_t max_pairs,
+                                           int at_eof, uint64_t *ticket);
 kslam_status kslam_collect_batch(kslam_ctx *ctx, uint64_t ticket, kslam_batch_result *out);
 void kslam_release_batch(kslam_ctx *ctx, kslam_batch_result *r);
 

@@ -42,7 +42,7 @@ EXPORTS = ["kslam_abi_version", "kslam_create", "kslam_destroy", "kslam_last_err
            "kslam_set_index", "kslam_set_index_device", "kslam_align_batch", "kslam_free_batch",
            "kslam_align_batch_async", "kslam_wait_batch", "kslam_load_qualities", "kslam_load_qualities_device",
            "kslam_row_details", "kslam_take_row_details", "kslam_free_pinned", "kslam_submit_batch",
-           "kslam_submit_batch_columns", "kslam_submit_batch_fastq", "kslam_collect_batch", "kslam_release_batch", "kslam_host_alloc",
+           "kslam_submit_batch_columns", "kslam_submit_batch_fastq", "kslam_submit_batch_fastq_text", "kslam_collect_batch", "kslam_release_batch", "kslam_host_alloc",
            "kslam_host_free", "kslam_pair_screen", "kslam_pair_screen_overlaps", "kslam_take_pairs", "kslam_set_pairing",
            "kslam_load_reads", "kslam_load_reads_device", "kslam_align_resident",
            "kslam_fetch_results", "kslam_take_results", "kslam_copy_results_device", "kslam_get_timings",
@@ -75,7 +75,9 @@ class BatchResult(C.Structure):
     _fields_ = [("overlaps", C.c_void_p), ("n_overlaps", C.c_uint64), ("cigar_pool", C.c_void_p),
                 ("n_cigar", C.c_uint64), ("details", C.c_void_p), ("md_pool", C.c_void_p), ("n_md", C.c_uint64),
                 ("read_pairs", C.c_void_p), ("n_read_pairs", C.c_uint64), ("pairs", C.c_void_p),
-                ("n_pairs", C.c_uint64), ("pair_stats", PairStats)]
+                ("n_pairs", C.c_uint64), ("pair_stats", PairStats),
+                ("n_reads", C.c_uint64), ("reads_bases_off", C.c_void_p), ("reads_ids", C.c_void_p),
+                ("reads_ids_off", C.c_void_p), ("consumed1", C.c_uint64), ("consumed2", C.c_uint64)]
 
 
 class Timings(C.Structure):
@@ -144,6 +146,7 @@ def lib():
         L.kslam_host_free.argtypes = [vp, u64]
         L.kslam_submit_batch_columns.argtypes = [vp, u64, vp, vp, vp, C.POINTER(u64)]
         L.kslam_submit_batch_fastq.argtypes = [vp, vp, u64, vp, u64, u64, vp, vp, vp, C.POINTER(u64)]
+        L.kslam_submit_batch_fastq_text.argtypes = [vp, vp, u64, vp, u64, u64, C.c_int, C.POINTER(u64)]
         L.kslam_collect_batch.argtypes = [vp, u64, C.POINTER(BatchResult)]
         L.kslam_release_batch.argtypes = [vp, C.POINTER(BatchResult)]
         L.kslam_load_reads.argtypes = [vp, u64, vp, vp]
@@ -397,6 +400,12 @@ class Context:
                                                    quality_at_p, C.byref(t)))
         return int(t.value)
 
+    def submit_batch_fastq_text(self, r1_p, len1, r2_p, len2, max_pairs=0, at_eof=True):
+        """kslam_submit_batch_fastq_text: the two texts (addresses; valid until collect_batch), nothing else"""
+        t = C.c_uint64()
+        self._chk(self._L.kslam_submit_batch_fastq_text(self._h, r1_p, len1, r2_p, len2, max_pairs, int(at_eof), C.byref(t)))
+        return int(t.value)
+
     def collect_batch(self, ticket):
         """kslam_collect_batch -> (overlaps, cigar_pool, details, md_pool, release): views of the library's
         page-locked buffers (details / md_pool empty when no qualities were submitted)"""
@@ -412,6 +421,17 @@ class Context:
         md = view(r.md_pool, r.n_md, np.dtype(np.uint8))
         self.last_pairs = (view(r.read_pairs, r.n_read_pairs, READ_PAIR_DT), view(r.pairs, r.n_pairs, PAIRED_OVERLAP_DT),
                            r.pair_stats.as_dict()) if r.read_pairs or r.pairs else None
+        # kslam_submit_batch_fastq_text: the batch's host columns as a reads view for kslam_amd.tail
+        self.last_reads = None
+        if r.reads_bases_off:
+            from . import tail as _T
+            n = int(r.n_reads)
+            rv = _T.ReadsView(n, None, r.reads_bases_off, None, r.reads_bases_off, r.reads_ids, r.reads_ids_off)
+            ids_off = view(r.reads_ids_off, n + 1, np.dtype(np.uint64))
+            self.last_reads = type("ReadsFromDevice", (), {
+                "view": rv, "n_reads": n, "consumed": (int(r.consumed1), int(r.consumed2)),
+                "bases_off": view(r.reads_bases_off, n + 1, np.dtype(np.uint64)), "ids_off": ids_off,
+                "ids_bytes": view(r.reads_ids, int(ids_off[n]) if n else 0, np.dtype(np.uint8))})()
 
         def release():
             self._L.kslam_release_batch(self._h, C.byref(r))

@@ -283,6 +283,22 @@ void pair_and_screen(const kslam_overlap *d_ov, uint64_t n, const uint32_t *d_re
                      uint32_t score_threshold, double score_fraction, int do_insert, int do_score, PairWork &W,
                      SortWorkspace &sortws, PairResult *res, hipStream_t s);
 
+// --------------------------------------------------------- fastq_index.hip
+struct FastqWork {
+  DevBuf tile_count, tile_base, scan_tmp, totals, ev[2], bases_at, quality_at, blen, id_at, id_len, bases_off, ids_off, ids;
+};
+struct FastqIndexResult {
+  uint64_t n_reads, bases_total, ids_total;
+  uint64_t consumed[2];
+  const uint64_t *d_bases_at, *d_quality_at;   // n_reads: positions in [r1 | r2]
+  const uint64_t *d_bases_off, *d_ids_off;     // n_reads + 1
+  const uint8_t *d_ids;                        // ids_total bytes
+};
+// d_text = [r1 | r2] on the device; h_last1 / h_last2: the streams' last bytes on the host (or nullptr for
+// an empty stream).  Semantics of host/fastq.cpp's index (kslam_fastq_index_pair).
+void fastq_index_device(const uint8_t *d_text, uint64_t len1, uint64_t len2, const uint8_t *h_last1, const uint8_t *h_last2,
+                        uint64_t max_pairs, bool at_eof, FastqWork &W, FastqIndexResult *res, hipStream_t s);
+
 // bases / quality columns cut out of FASTQ text on the device: read i = text[bases_at[i] ..) and
 // text[quality_at[i] ..), d_off[i + 1] - d_off[i] bytes each, to d_bases / d_quality + d_off[i]
 void gather_fields(const uint8_t *d_text, const uint64_t *d_bases_at, const uint64_t *d_quality_at, const uint64_t *d_off,

@@ -68,6 +68,7 @@ struct kslam_ctx {
   // ---- per-row details for the SAM writer (details.hip) ----
   DevBuf r_qual, d_tables, res_det;
   DevBuf fq_text, fq_bases_at, fq_qual_at;   // kslam_submit_batch_fastq: the uploaded texts and field positions
+  FastqWork fqw;                              // kslam_submit_batch_fastq_text: the record index built on the device
   bool have_qual = false, have_details = false;
   uint8_t *d_md_pool = nullptr;   // inside detw.md_pool
   uint64_t n_md = 0;
@@ -92,7 +93,9 @@ struct kslam_ctx {
     bool borrowed = false;            // cat / qcat / off_ptr are the caller's columns (kslam_submit_batch_columns)
     const uint64_t *off_ptr = nullptr;
     // kslam_submit_batch_fastq: the two texts (cat = r1, qcat = r2) and where the fields lie in [r1 | r2]
-    bool fastq = false;
+    bool fastq = false, fastq_text = false;   // fastq_text: the index is built on the device too
+    uint64_t max_pairs = 0; int at_eof = 1;
+    uint64_t r_n = 0, *r_off = nullptr, *r_ids_off = nullptr; char *r_ids = nullptr; uint64_t consumed[2] = {0, 0};
     uint64_t len1 = 0, len2 = 0;
     const uint64_t *bases_at = nullptr, *quality_at = nullptr;
     std::vector<uint64_t> off;
@@ -730,6 +733,52 @@ kslam_status load_reads_from_fastq(kslam_ctx *c, uint64_t n_reads, const char *r
   });
 }
 
+
+// kslam_submit_batch_fastq_text: texts up, record index + columns on the device, the host's columns back
+kslam_status load_reads_from_fastq_text(kslam_ctx *c, kslam_ctx::AsyncJob *job) {
+  return guarded(c, [&] {
+    const char *r1 = job->cat, *r2 = job->qcat;
+    const uint64_t len1 = job->len1, len2 = job->len2;
+    if ((len1 && !r1) || (len2 && !r2)) throw StatusError{KSLAM_ERR_ARG, "null text"};
+    hipStream_t s = c->stream;
+    c->have_reads = false;
+    c->fq_text.ensure(len1 + len2 + 64);
+    if (len1) HIPCHK(hipMemcpyAsync(c->fq_text.p, r1, len1, hipMemcpyHostToDevice, s));
+    if (len2) HIPCHK(hipMemcpyAsync(c->fq_text.as<uint8_t>() + len1, r2, len2, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(c->fq_text.as<uint8_t>() + len1 + len2, 0, 64, s));
+    FastqIndexResult ix;
+    fastq_index_device(c->fq_text.as<uint8_t>(), len1, len2, len1 ? (const uint8_t *)r1 + len1 - 1 : nullptr,
+                       len2 ? (const uint8_t *)r2 + len2 - 1 : nullptr, job->max_pairs, job->at_eof != 0, c->fqw, &ix, s);
+    const uint64_t n = ix.n_reads;
+    // the host's columns: offsets (= lengths), identifiers
+    job->r_n = n;
+    job->r_off = (uint64_t *)pinned_get(c, (n + 2) * sizeof(uint64_t));
+    job->r_ids_off = (uint64_t *)pinned_get(c, (n + 2) * sizeof(uint64_t));
+    job->r_ids = (char *)pinned_get(c, ix.ids_total + 64);
+    HIPCHK(hipMemcpyAsync(job->r_off, ix.d_bases_off, (n + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(job->r_ids_off, ix.d_ids_off, (n + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    if (ix.ids_total) HIPCHK(hipMemcpyAsync(job->r_ids, ix.d_ids, ix.ids_total, hipMemcpyDeviceToHost, s));
+    job->consumed[0] = ix.consumed[0];
+    job->consumed[1] = ix.consumed[1];
+    // the device's columns
+    c->n_reads = n;
+    c->r_off.ensure((n + 1) * sizeof(uint64_t));
+    HIPCHK(hipMemcpyAsync(c->r_off.p, ix.d_bases_off, (n + 1) * sizeof(uint64_t), hipMemcpyDeviceToDevice, s));
+    c->r_bases.ensure(ix.bases_total + 64);
+    c->r_qual.ensure(ix.bases_total + 64);
+    gather_fields(c->fq_text.as<uint8_t>(), ix.d_bases_at, ix.d_quality_at, c->r_off.as<uint64_t>(), n,
+                  c->r_bases.as<uint8_t>(), c->r_qual.as<uint8_t>(), s);
+    HIPCHK(hipMemsetAsync(c->r_bases.as<uint8_t>() + ix.bases_total, 0, 64, s));
+    HIPCHK(hipMemsetAsync(c->r_qual.as<uint8_t>() + ix.bases_total, 0, 64, s));
+    HIPCHK(hipStreamSynchronize(s));
+    job->r_ids[ix.ids_total] = 0;
+    c->h_roff.assign(job->r_off, job->r_off + n + 1);
+    finish_load_reads(c);
+    c->have_qual = true;
+    job->n_reads = n;
+  });
+}
+
 void lane_main(kslam_ctx *primary, kslam_ctx::AsyncLane *lane) {
   for (;;) {
     kslam_ctx::AsyncJob *job = nullptr;
@@ -746,7 +795,9 @@ void lane_main(kslam_ctx *primary, kslam_ctx::AsyncLane *lane) {
     const double t0 = now();
     double t1 = 0, t2 = 0, t3 = 0;
     kslam_status st;
-    if (job->fastq)
+    if (job->fastq_text)
+      st = load_reads_from_fastq_text(c, job);
+    else if (job->fastq)
       st = load_reads_from_fastq(c, job->n_reads, job->cat, job->len1, job->qcat, job->len2, job->off_ptr,
                                  job->bases_at, job->quality_at);
     else
@@ -883,7 +934,9 @@ void kslam_destroy(kslam_ctx *c) {
                       &c->flags, &c->pos, &c->band0, &c->sortws.hist, &c->sortws.status, &c->sortws.tickets,
                       &c->cig.flags, &c->cig.pos, &c->cig.list, &c->cig.bmax, &c->cig.needbig,
                       &c->cig.scan_tmp, &c->cig.totals, &c->cig.cig_off, &c->cig.tmp, &c->cig.tmp_big,
-                      &c->cig.big_pos, &c->cig.scratch, &c->sww.flags, &c->sww.pos, &c->sww.list, &c->sww.list2, &c->sww.scan_tmp, &c->sww.totals, &c->cells, &c->res_ov, &c->res_cig, &c->res_tmp, &c->r_qual, &c->d_tables, &c->res_det, &c->fq_text, &c->fq_bases_at, &c->fq_qual_at, &c->detw.lens, &c->detw.off,
+                      &c->cig.big_pos, &c->cig.scratch, &c->sww.flags, &c->sww.pos, &c->sww.list, &c->sww.list2, &c->sww.scan_tmp, &c->sww.totals, &c->cells, &c->res_ov, &c->res_cig, &c->res_tmp, &c->r_qual, &c->d_tables, &c->res_det, &c->fq_text, &c->fq_bases_at, &c->fq_qual_at, &c->fqw.tile_count, &c->fqw.tile_base, &c->fqw.scan_tmp,
+                      &c->fqw.totals, &c->fqw.ev[0], &c->fqw.ev[1], &c->fqw.bases_at, &c->fqw.quality_at, &c->fqw.blen, &c->fqw.id_at,
+                      &c->fqw.id_len, &c->fqw.bases_off, &c->fqw.ids_off, &c->fqw.ids, &c->detw.lens, &c->detw.off,
                       &c->detw.slots, &c->detw.scan_tmp, &c->detw.totals, &c->detw.md_pool, &c->pw.recs, &c->pw.count, &c->pw.base,
                       &c->pw.inserts, &c->pw.flags, &c->pw.gpos, &c->pw.rpos, &c->pw.scan_tmp, &c->pw.totals, &c->pw.groups,
                       &c->pw.dense, &c->pw.sort_a, &c->pw.sort_b, &c->pw.idx, &c->pw.picked, &c->pr_ov, &c->pr_len, &c->mg_shards, &c->mg_lens, &c->mg_off, &c->mg_scan};
@@ -1365,6 +1418,37 @@ kslam_status kslam_submit_batch_fastq(kslam_ctx *c, const char *r1, uint64_t len
   return KSLAM_OK;
 }
 
+kslam_status kslam_submit_batch_fastq_text(kslam_ctx *c, const char *r1, uint64_t len1, const char *r2, uint64_t len2,
+                                           uint64_t max_pairs, int at_eof, uint64_t *ticket) {
+  if (!c || !ticket) return KSLAM_ERR_ARG;
+  kslam_ctx::AsyncJob *job = nullptr;
+  kslam_status st = guarded(c, [&] {
+    if ((len1 && !r1) || (len2 && !r2)) throw StatusError{KSLAM_ERR_ARG, "null text"};
+    if (!c->have_index) throw StatusError{KSLAM_ERR_STATE, "kslam_set_index has not been called"};
+    ensure_lanes(c);
+    job = new kslam_ctx::AsyncJob();
+    job->borrowed = true;
+    job->fastq = true;
+    job->fastq_text = true;
+    job->cat = const_cast<char *>(r1);
+    job->qcat = const_cast<char *>(r2);
+    job->len1 = len1; job->len2 = len2;
+    job->max_pairs = max_pairs; job->at_eof = at_eof;
+  });
+  if (st != KSLAM_OK) { delete job; return st; }
+  uint64_t tk;
+  {
+    std::lock_guard<std::mutex> lk(c->as_mu);
+    tk = c->next_ticket++;
+    job->ticket = tk;
+    c->jobs[tk] = job;
+    c->lanes[tk % c->lanes.size()]->q.push_back(job);
+  }
+  c->as_cv.notify_all();
+  *ticket = tk;
+  return KSLAM_OK;
+}
+
 kslam_status kslam_wait_batch(kslam_ctx *c, uint64_t ticket, kslam_overlap **out, uint64_t *n_out, uint32_t **cigar_pool,
                               uint64_t *n_cigar) {
   if (!c || !out || !n_out || !cigar_pool || !n_cigar) return KSLAM_ERR_ARG;
@@ -1376,6 +1460,9 @@ kslam_status kslam_wait_batch(kslam_ctx *c, uint64_t ticket, kslam_overlap **out
   kslam_free_pinned(c, r.md_pool);
   kslam_free_pinned(c, r.read_pairs);
   kslam_free_pinned(c, r.pairs);
+  kslam_free_pinned(c, r.reads_bases_off);
+  kslam_free_pinned(c, r.reads_ids_off);
+  kslam_free_pinned(c, r.reads_ids);
   *out = r.overlaps; *n_out = r.n_overlaps; *cigar_pool = r.cigar_pool; *n_cigar = r.n_cigar;
   return KSLAM_OK;
 }
@@ -1387,6 +1474,9 @@ void kslam_release_batch(kslam_ctx *c, kslam_batch_result *r) {
   kslam_free_pinned(c, r->md_pool);
   kslam_free_pinned(c, r->read_pairs);
   kslam_free_pinned(c, r->pairs);
+  kslam_free_pinned(c, r->reads_bases_off);
+  kslam_free_pinned(c, r->reads_ids_off);
+  kslam_free_pinned(c, r->reads_ids);
   memset(r, 0, sizeof *r);
 }
 
@@ -1408,6 +1498,8 @@ kslam_status kslam_collect_batch(kslam_ctx *c, uint64_t ticket, kslam_batch_resu
     res->details = job->det; res->md_pool = job->md; res->n_md = job->n_md;
     res->read_pairs = job->rp; res->n_read_pairs = job->n_rp; res->pairs = job->pr; res->n_pairs = job->n_pr;
     res->pair_stats = job->pstats;
+    res->n_reads = job->r_n; res->reads_bases_off = job->r_off; res->reads_ids = job->r_ids; res->reads_ids_off = job->r_ids_off;
+    res->consumed1 = job->consumed[0]; res->consumed2 = job->consumed[1];
   } else {
     c->err = job->err;
     kslam_free_batch(c, job->out, job->pool);
@@ -1415,6 +1507,9 @@ kslam_status kslam_collect_batch(kslam_ctx *c, uint64_t ticket, kslam_batch_resu
     kslam_free_pinned(c, job->md);
     kslam_free_pinned(c, job->rp);
     kslam_free_pinned(c, job->pr);
+    kslam_free_pinned(c, job->r_off);
+    kslam_free_pinned(c, job->r_ids_off);
+    kslam_free_pinned(c, job->r_ids);
   }
   delete job;
   return st;

@@ -194,3 +194,81 @@ def test_cpp_binding_header_builds_and_runs(tmp_path):
     lines = [l for l in out.stdout.splitlines() if l.startswith("read ")]
     assert len(lines) == 2 and "score 300" in lines[0] and "cigar 150M" in lines[0] and "rel 3216" in lines[1]
     assert "multi identical" in out.stdout
+
+
+@pytest.mark.parametrize("seed,eol_mix,at_eof,max_pairs,tail_cut", [
+    (1, False, True, 0, 0), (2, True, True, 0, 0), (3, True, True, 50, 0), (4, True, False, 0, 0), (5, True, True, 0, 1),
+    (6, True, True, 0, 2), (7, True, False, 70, 0), (8, False, True, 0, 3)])
+def test_fastq_records_found_on_the_device(kslam, synth, seed, eol_mix, at_eof, max_pairs, tail_cut):
+    """kslam_submit_batch_fastq_text (line index, identifiers, offsets and columns all built on the GPU)
+    against the host parser (k-slam_amd/host/fastq.cpp, which tests/test_fastq.py pins against the REAL
+    reference reader): mixed "\\n" / "\\r\\n", headers with spaces and slashes, empty reads, a stream that ends
+    without its last terminator / in the middle of a record / right after a "\\r", a prefix of a longer stream,
+    a cap on the number of pairs; and the alignment of that batch equals the alignment of the host's columns."""
+    F = importlib.import_module("kslam_amd.fastq")
+    rng = np.random.default_rng(900 + seed)
+    genomes = synth.make_genomes(70 + seed, 2, 2, 12000)
+    reads, _ = synth.make_paired_reads(71 + seed, genomes, 120, read_len=100, frag_mean=260, frag_sd=30)
+    rb = synth.to_bytes(reads)
+    heads = [b"@r%d", b"@r%d desc text", b"@r%d/1", b"@r%d/2 x/y", b"@ r%d", b"@a/b/c%d", b"@/r%d", b"@r%d\tTAB/9", b"@", b"x"]
+    eols = [b"\n", b"\r\n"]
+
+    def text(block):
+        out = []
+        for k, seq in enumerate(block):
+            h = heads[int(rng.integers(0, len(heads)))]
+            h = h % k if b"%d" in h else h
+            if rng.random() < 0.05:
+                seq = b""
+            q = bytes(rng.integers(33, 75, len(seq), dtype=np.uint8))
+            for line in (h, seq, b"+", q):
+                out.append(line + (eols[int(rng.integers(0, 2))] if eol_mix else b"\n"))
+        return b"".join(out)
+    t1, t2 = text(rb[:120]), text(rb[120:])
+    if tail_cut == 1:      # no terminator after the last quality line
+        t1, t2 = t1.rstrip(b"\r\n"), t2.rstrip(b"\r\n")
+    if tail_cut == 2:      # the last record has no quality line at all: the empty line read at end of stream completes it
+        def drop_last_line(t):
+            body = t.rstrip(b"\r\n")
+            return body[:max(body.rfind(b"\n"), body.rfind(b"\r")) + 1]
+        t1, t2 = drop_last_line(t1), drop_last_line(t2)
+        # (that record's bases line is then longer than its empty quality line: both parsers must refuse it)
+    if tail_cut == 3:      # blank lines after the last record
+        t1, t2 = t1 + b"\n\n\n", t2 + b"\n\n\n"
+    if not at_eof:
+        t1, t2 = t1 + b"@partial\nACG", t2 + b"@partial\r"
+    h1, h2 = kslam.HostBuffer(len(t1) + 64), kslam.HostBuffer(len(t2) + 64)
+    h1.a[:len(t1)] = np.frombuffer(t1, dtype=np.uint8)
+    h2.a[:len(t2)] = np.frombuffer(t2, dtype=np.uint8)
+    c = kslam.Context()
+    c.set_index(synth.to_bytes(genomes))
+    tk = c.submit_batch_fastq_text(h1.ptr, len(t1), h2.ptr, len(t2), max_pairs=max_pairs, at_eof=at_eof)
+    try:
+        full, f1, f2 = F.parse_pair(t1, t2, max_pairs=max_pairs, at_eof=at_eof)
+        ok = all(len(b) == len(q) for b, q in zip(full.bases, full.quality))
+    except kslam.KslamError as e:
+        full, ok = None, False
+        host_err = str(e)
+    if not ok:
+        with pytest.raises(kslam.KslamError, match="quality line|mismatch in R1 and R2"):
+            c.collect_batch(tk)
+        assert tail_cut == 2 or full is None
+        c.close()
+        return
+    ov, cg, det, md, release = c.collect_batch(tk)
+    R = c.last_reads
+    assert R.n_reads == full.n_reads and R.consumed == (f1, f2)
+    _, foff = full.bases_array()
+    assert (R.bases_off == foff).all()
+    ids = [R.ids_bytes[int(R.ids_off[i]):int(R.ids_off[i + 1])].tobytes() for i in range(R.n_reads)]
+    assert ids == full.ids
+    # the device's columns are the host's: same alignment, same row details
+    cols = full._cols
+    o2, c2, d2, m2, rel2 = c.collect_batch(c.submit_batch_columns(full.n_reads, cols.bases, cols.quality, cols.bases_off))
+    assert ov.tobytes() == o2.tobytes() and cg.tobytes() == c2.tobytes() and det.tobytes() == d2.tobytes() and md.tobytes() == m2.tobytes()
+    assert len(ov) > 100 or max_pairs
+    release()
+    rel2()
+    c.close()
+    h1.close()
+    h2.close()

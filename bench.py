@@ -176,6 +176,8 @@ def sam_pipeline(K, ctx, reads, db, offs, read_len, steps, pseudo_assembly=False
     # the index view the writer gets: offsets, names, taxonomy ids -- and NO copy of the database
     I = T.IndexArrays(np.zeros(1, dtype=np.uint8), offs, taxonomy_ids=np.arange(1, len(offs), dtype=np.uint32))
     P = T.TailParams.default(pseudo_assembly=pseudo_assembly)
+    P_write = T.TailParams.default(pseudo_assembly=False)         # when the GPU has run that stage too
+    gpu_stages = 7 if pseudo_assembly and os.environ.get("KSLAM_BENCH_HOST_PSEUDO") != "1" else 3
     t_host_copy = time.time() - t0
     stats = []
 
@@ -188,13 +190,14 @@ def sam_pipeline(K, ctx, reads, db, offs, read_len, steps, pseudo_assembly=False
 
     def tail(ov, cg, det, md, release, pairs):
         rp, pr, pst = pairs                        # read pairs / alignment pairs from the GPU (views: modified in place)
-        st = T.tail_finish_rows(P, R, I, ov, cg, det, md, rp, pr)
+        st = T.tail_finish_rows(P_write if pst["stages_done"] & 4 else P, R, I, ov, cg, det, md, rp, pr)
         release()                                  # page-locked result buffers back to the library
         d = st.as_dict()
         d["gpu_pairing"] = pst
         stats.append(d)
 
-    ctx.set_pairing(paired=True)                   # score screen, pairing, insert-size statistics, screens: on the GPU
+    # score screen, pairing, insert-size statistics, screens [, pseudo-assembly, second screen]: on the GPU
+    ctx.set_pairing(paired=True, stages=gpu_stages)
     for tk in [submit(), submit(), submit()]:       # warm both lanes' buffers and the tail's work buffers
         tail(*collect(tk))
     stats.clear()
@@ -225,11 +228,12 @@ def sam_pipeline(K, ctx, reads, db, offs, read_len, steps, pseudo_assembly=False
         "host_threads": int(last["threads"]), "sam_mb_per_batch": round(last["sam_bytes"] / 1e6, 1),
         "alignment_pairs": int(last["n_paired_final"]), "read_pairs_aligned": int(last["n_read_pairs"]),
         "pseudo_assembly": bool(pseudo_assembly), "gpu_pairing": last["gpu_pairing"],
+        "pseudo_assembly_on": ("gpu" if last["gpu_pairing"]["stages_done"] & 4 else "host") if pseudo_assembly else None,
         "what": "read columns in page-locked host memory -> kslam_submit_batch_columns (align + per-row NM / "
-                "log-probability / MD + score screen / pairing / insert-size statistics / screens on the GPU, two "
-                "batches in flight) -> kslam_collect_batch -> %sSAM text (host, discarded by the writer; no host copy "
+                "log-probability / MD + score screen / pairing / insert-size statistics / screens%s on the GPU, two "
+                "batches in flight) -> kslam_collect_batch -> SAM text (host, discarded by the writer; no host copy "
                 "of the database) on a worker thread; one-time host copy of the reads took %.1f s" % (
-                    "pseudo-assembly / second screen / " if pseudo_assembly else "", t_host_copy),
+                    " / pseudo-assembly / second screen" if pseudo_assembly else "", t_host_copy),
     }
 
 
@@ -272,7 +276,9 @@ def full_pipeline(K, ctx, reads, db, offs, read_len, steps, pseudo_assembly=Fals
     I = T.IndexArrays(np.zeros(1, dtype=np.uint8), offs, taxonomy_ids=np.arange(1, len(offs), dtype=np.uint32))
     nthr = int(os.environ.get("KSLAM_BENCH_HOST_THREADS", "0"))
     P = T.TailParams.default(threads=nthr, pseudo_assembly=pseudo_assembly)
-    stats = []
+    P_write = T.TailParams.default(threads=nthr, pseudo_assembly=False)   # when the GPU has run that stage too
+    gpu_stages = 7 if pseudo_assembly and os.environ.get("KSLAM_BENCH_HOST_PSEUDO") != "1" else 3
+    stats, on_gpu = [], []
 
     def collect(tk):
         res = ctx.collect_batch(tk)
@@ -280,13 +286,15 @@ def full_pipeline(K, ctx, reads, db, offs, read_len, steps, pseudo_assembly=Fals
 
     def tail(batch, ov, cg, det, md, release, pairs, reads_view):
         rp, pr, pst = pairs
-        st = T.tail_finish_rows(P, reads_view if reads_view is not None else batch, I, ov, cg, det, md, rp, pr)
+        on_gpu.append(bool(pst["stages_done"] & 4))
+        st = T.tail_finish_rows(P_write if on_gpu[-1] else P, reads_view if reads_view is not None else batch, I, ov, cg,
+                                det, md, rp, pr)
         release()
         if batch is not None:
             batch.close()
         stats.append(st.as_dict())
 
-    ctx.set_pairing(paired=True)
+    ctx.set_pairing(paired=True, stages=gpu_stages)
     host_index = os.environ.get("KSLAM_BENCH_HOST_FASTQ_INDEX") == "1"   # A/B: the record index on the host (round-2 first form)
 
     def parse_and_submit():
@@ -341,11 +349,12 @@ def full_pipeline(K, ctx, reads, db, offs, read_len, steps, pseudo_assembly=Fals
         "host_tail_phases_ms": {k[3:]: round(stats[-1][k], 2) for k in stats[-1] if k.startswith("ms_")},
         "fastq_mb_per_batch": round((len1 + len2) / 1e6, 1), "sam_mb_per_batch": round(stats[-1]["sam_bytes"] / 1e6, 1),
         "pseudo_assembly": bool(pseudo_assembly),
+        "pseudo_assembly_on": ("gpu" if all(on_gpu) else "host") if pseudo_assembly else None,
         "fastq_index": "host" if host_index else "gpu",
         "what": "FASTQ text (2 files, in page-locked memory) -> kslam_submit_batch_fastq_text (texts up by DMA; line index, "
                 "identifiers, offsets and the bases / quality columns made on the GPU; align, per-row "
-                "NM / log-probability / MD, score screen / pairing / insert-size statistics / screens) -> "
-                "kslam_collect_batch -> [pseudo-assembly / second screen] SAM text (host, discarded by the "
+                "NM / log-probability / MD, score screen / pairing / insert-size statistics / screens [/ pseudo-assembly / "
+                "second screen]) -> kslam_collect_batch -> SAM text (host, discarded by the "
                 "writer; no host copy of the database); three batches in flight, the host stage of batch k-1 under the GPU "
                 "work of batches k, k+1",
     }

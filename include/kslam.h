@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define KSLAM_ABI_VERSION 5
+#define KSLAM_ABI_VERSION 6
 #define KSLAM_K 32u /* src/Globals.h:25 */
 
 typedef enum {
@@ -210,9 +210,13 @@ void kslam_free_pinned(kslam_ctx *ctx, void *p);
  * (src/Overlap.h:329-341), read pairing (getPairedOverlaps, src/PairedOverlap.h:107-270; single end:
  * dummy pairs, :280-298), the batch-global insert-size statistics (getMaxAllowedInsertSize, :314-360)
  * and the two per-read-pair screens (:361-436) -- i.e. include/kslam_tail.h's kslam_tail_pairs with
- * stages = INSERT_SCREEN | SCORE_SCREEN, record for record (the reference's std::sort permutations
- * included).  The host is left with pseudo-assembly and the SAM text (kslam_tail_finish_write_rows).
- * stages: KSLAM_TAIL_INSERT_SCREEN (1) | KSLAM_TAIL_SCORE_SCREEN (2) of include/kslam_tail.h. */
+ * the same stages, record for record (the reference's std::sort permutations included) -- and, with
+ * KSLAM_TAIL_PSEUDO_ASM, pseudoAssembly (:480-582) and the second score screen as well, in place: the
+ * records keep their positions, the groups' counts shrink, combined_score holds the chain scores.  The
+ * host is left with the SAM text (kslam_tail_finish_write_rows, with the stages in stages_done masked
+ * out of its params).
+ * stages: KSLAM_TAIL_INSERT_SCREEN (1) | KSLAM_TAIL_SCORE_SCREEN (2) | KSLAM_TAIL_PSEUDO_ASM (4) of
+ * include/kslam_tail.h. */
 #define KSLAM_NO_OVERLAP 0xFFFFFFFFu
 
 /* PairedOverlap, src/PairedOverlap.h:32-57; the two Overlap copies become
@@ -244,7 +248,9 @@ typedef struct {
   uint64_t n_read_pairs;        /* read pairs (or reads) with >= 1 alignment pair left */
   uint64_t n_pairs;             /* alignment pairs left */
   uint32_t max_insert_size;     /* getMaxAllowedInsertSize; UINT32_MAX when not computed */
-  uint32_t pad;
+  uint32_t stages_done;         /* KSLAM_TAIL_* bits of the stages the device ran: the host tail runs the rest
+                                   (PSEUDO_ASM is left to the host when one entry holds more alignment pairs
+                                   than a workgroup's LDS takes, 4000) */
 } kslam_pair_stats;
 kslam_status kslam_pair_screen(kslam_ctx *ctx, int paired, uint32_t score_threshold,
                                double score_fraction, uint32_t stages, kslam_pair_stats *stats);
@@ -256,6 +262,11 @@ kslam_status kslam_pair_screen_overlaps(kslam_ctx *ctx, const kslam_overlap *ove
 /* page-locked, library-owned copies of the last kslam_pair_screen* result; kslam_free_pinned each */
 kslam_status kslam_take_pairs(kslam_ctx *ctx, kslam_read_pair **read_pairs, uint64_t *n_read_pairs,
                               kslam_paired_overlap **pairs, uint64_t *n_pairs);
+/* Test hook for the sort pseudo-assembly stands on (csrc/wave_gnu_sort.h: libstdc++'s std::sort permutation
+ * by one wavefront): segment i = keys[seg_off[i] .. seg_off[i+1]), at most 4000 keys, is sorted ascending by
+ * key; perm[seg_off[i] + k] = the index within the segment of the element that ends up k-th. */
+kslam_status kslam_debug_wave_sort(kslam_ctx *ctx, const int32_t *keys, const uint64_t *seg_off,
+                                   uint64_t n_seg, uint32_t *perm);
 /* what the pipelined lanes run after the alignment: stages == 0 switches the pairing off (default) */
 kslam_status kslam_set_pairing(kslam_ctx *ctx, int paired, uint32_t score_threshold,
                                double score_fraction, uint32_t stages);

@@ -43,7 +43,7 @@ EXPORTS = ["kslam_abi_version", "kslam_create", "kslam_destroy", "kslam_last_err
            "kslam_align_batch_async", "kslam_wait_batch", "kslam_load_qualities", "kslam_load_qualities_device",
            "kslam_row_details", "kslam_take_row_details", "kslam_free_pinned", "kslam_submit_batch",
            "kslam_submit_batch_columns", "kslam_submit_batch_fastq", "kslam_submit_batch_fastq_text", "kslam_collect_batch", "kslam_release_batch", "kslam_host_alloc",
-           "kslam_host_free", "kslam_pair_screen", "kslam_pair_screen_overlaps", "kslam_take_pairs", "kslam_set_pairing",
+           "kslam_host_free", "kslam_pair_screen", "kslam_pair_screen_overlaps", "kslam_take_pairs", "kslam_set_pairing", "kslam_debug_wave_sort",
            "kslam_load_reads", "kslam_load_reads_device", "kslam_align_resident",
            "kslam_fetch_results", "kslam_take_results", "kslam_copy_results_device", "kslam_get_timings",
            "kslam_extract_kmers", "kslam_sort_kmers", "kslam_find_overlaps", "kslam_free",
@@ -64,10 +64,10 @@ class PairStats(C.Structure):
     """kslam_pair_stats"""
     _fields_ = [("n_overlaps_screened", C.c_uint64), ("n_paired_initial", C.c_uint64), ("n_insert_sizes", C.c_uint64),
                 ("n_read_pairs", C.c_uint64), ("n_pairs", C.c_uint64), ("max_insert_size", C.c_uint32),
-                ("pad", C.c_uint32)]
+                ("stages_done", C.c_uint32)]
 
     def as_dict(self):
-        return {k: int(getattr(self, k)) for k, _ in self._fields_ if k != "pad"}
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
 
 
 class BatchResult(C.Structure):
@@ -141,6 +141,7 @@ def lib():
         L.kslam_pair_screen_overlaps.argtypes = [vp, vp, u64, vp, u64, C.c_int, u32, C.c_double, u32, C.POINTER(PairStats)]
         L.kslam_take_pairs.argtypes = [vp, C.POINTER(vp), C.POINTER(u64), C.POINTER(vp), C.POINTER(u64)]
         L.kslam_set_pairing.argtypes = [vp, C.c_int, u32, C.c_double, u32]
+        L.kslam_debug_wave_sort.argtypes = [vp, vp, vp, u64, vp]
         L.kslam_host_alloc.restype = vp
         L.kslam_host_alloc.argtypes = [u64]
         L.kslam_host_free.argtypes = [vp, u64]
@@ -374,6 +375,15 @@ class Context:
             release()
             return rp, pr
         return rp, pr, release
+
+    def debug_wave_sort(self, keys, seg_off):
+        """kslam_debug_wave_sort -> the permutation (per segment) the device's std::sort restatement produces"""
+        keys = np.ascontiguousarray(keys, dtype=np.int32)
+        seg_off = np.ascontiguousarray(seg_off, dtype=np.uint64)
+        perm = np.zeros(len(keys), dtype=np.uint32)
+        self._chk(self._L.kslam_debug_wave_sort(self._h, keys.ctypes.data, seg_off.ctypes.data, len(seg_off) - 1,
+                                                perm.ctypes.data))
+        return perm
 
     def set_pairing(self, paired=True, score_threshold=0, score_fraction=0.95, stages=3):
         """kslam_set_pairing: what the pipelined lanes run after the alignment (stages=0: off)"""

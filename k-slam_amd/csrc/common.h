@@ -274,6 +274,7 @@ struct PairWork {
 struct PairResult {
   uint64_t n_overlaps_screened, n_paired_initial, n_insert_sizes, n_read_pairs, n_pairs;
   uint32_t max_insert_size;
+  uint32_t stages_done;                  // KSLAM_TAIL_* bits of the stages the device ran
   const kslam_read_pair *d_groups;       // n_read_pairs, `first` indexes d_pairs
   const kslam_paired_overlap *d_pairs;   // n_pairs, dense
 };
@@ -298,6 +299,13 @@ struct FastqIndexResult {
 // an empty stream).  Semantics of host/fastq.cpp's index (kslam_fastq_index_pair).
 void fastq_index_device(const uint8_t *d_text, uint64_t len1, uint64_t len2, const uint8_t *h_last1, const uint8_t *h_last2,
                         uint64_t max_pairs, bool at_eof, FastqWork &W, FastqIndexResult *res, hipStream_t s);
+
+// pseudoAssembly + the second score screen on pair_and_screen's result, in place; false (nothing changed)
+// when an entry has more spans than a workgroup's LDS holds: the host then runs that stage itself
+bool pseudo_and_rescreen(PairWork &W, PairResult *res, double score_fraction, SortWorkspace &sortws, hipStream_t s);
+
+// test hook for wave_gnu_sort.h (kslam_debug_wave_sort)
+void debug_wave_sort(const int32_t *keys, const uint64_t *seg_off, uint64_t n_seg, uint32_t *perm, hipStream_t s);
 
 // bases / quality columns cut out of FASTQ text on the device: read i = text[bases_at[i] ..) and
 // text[quality_at[i] ..), d_off[i + 1] - d_off[i] bytes each, to d_bases / d_quality + d_off[i]

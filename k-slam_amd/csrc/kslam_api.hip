@@ -1208,6 +1208,7 @@ static void fill_pair_stats(const PairResult &r, kslam_pair_stats *st) {
   st->n_overlaps_screened = r.n_overlaps_screened; st->n_paired_initial = r.n_paired_initial;
   st->n_insert_sizes = r.n_insert_sizes; st->n_read_pairs = r.n_read_pairs; st->n_pairs = r.n_pairs;
   st->max_insert_size = r.max_insert_size;
+  st->stages_done = r.stages_done;
 }
 
 kslam_status kslam_pair_screen(kslam_ctx *c, int paired, uint32_t score_threshold, double score_fraction, uint32_t stages,
@@ -1221,6 +1222,7 @@ kslam_status kslam_pair_screen(kslam_ctx *c, int paired, uint32_t score_threshol
     pair_and_screen(c->res_ov.as<kslam_overlap>(), c->n_res, c->r_len.as<uint32_t>(), c->n_reads, paired ? 1 : 0,
                     score_threshold, score_fraction, (stages & 1u) != 0, (stages & 2u) != 0, c->pw, c->sortws, &c->pres,
                     c->stream);
+    if (stages & 4u) pseudo_and_rescreen(c->pw, &c->pres, score_fraction, c->sortws, c->stream);
     HIPCHK(hipStreamSynchronize(c->stream));
     c->have_pairs = true;
     fill_pair_stats(c->pres, stats);
@@ -1244,6 +1246,7 @@ kslam_status kslam_pair_screen_overlaps(kslam_ctx *c, const kslam_overlap *overl
     pair_and_screen(c->pr_ov.as<kslam_overlap>(), n_overlaps, c->pr_len.as<uint32_t>(), n_reads, paired ? 1 : 0,
                     score_threshold, score_fraction, (stages & 1u) != 0, (stages & 2u) != 0, c->pw, c->sortws, &c->pres,
                     c->stream);
+    if (stages & 4u) pseudo_and_rescreen(c->pw, &c->pres, score_fraction, c->sortws, c->stream);
     HIPCHK(hipStreamSynchronize(c->stream));
     c->have_pairs = true;
     fill_pair_stats(c->pres, stats);
@@ -1275,11 +1278,18 @@ kslam_status kslam_take_pairs(kslam_ctx *c, kslam_read_pair **read_pairs, uint64
   return KSLAM_OK;
 }
 
+kslam_status kslam_debug_wave_sort(kslam_ctx *c, const int32_t *keys, const uint64_t *seg_off, uint64_t n_seg, uint32_t *perm) {
+  return guarded(c, [&] {
+    if (!seg_off || (n_seg && seg_off[n_seg] && (!keys || !perm))) throw StatusError{KSLAM_ERR_ARG, "null argument"};
+    debug_wave_sort(keys, seg_off, n_seg, perm, c->stream);
+  });
+}
+
 kslam_status kslam_set_pairing(kslam_ctx *c, int paired, uint32_t score_threshold, double score_fraction, uint32_t stages) {
   if (!c) return KSLAM_ERR_ARG;
   std::lock_guard<std::mutex> lk(c->as_mu);
   c->pairing.paired = paired; c->pairing.thr = score_threshold; c->pairing.fraction = score_fraction;
-  c->pairing.stages = stages & 3u;
+  c->pairing.stages = stages & 7u;
   return KSLAM_OK;
 }
 

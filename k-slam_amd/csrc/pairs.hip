@@ -26,6 +26,7 @@
 
 #include "common.h"
 #include "gnu_sort.h"
+#include "wave_gnu_sort.h"
 
 namespace kslam {
 
@@ -295,7 +296,242 @@ __global__ __launch_bounds__(256) void k_emit_groups(const Rec *__restrict__ rec
   for (uint32_t k = 0; k < n; k++) dst[k] = src[k];
 }
 
+// ---- pseudoAssembly (src/PairedOverlap.h:480-582; host/tail.cpp: pseudo_stage, chain_entry) -----------
+// The reference buckets the alignment pairs per entry in iteration order, sorts each bucket by refStart
+// with std::sort and walks it once: alignments that overlap along the genome (the next one starts more
+// than 20 bases before the highest position reached) form a chain, and every member of a chain of two or
+// more gets the score  coverage x average score per base x length.  The sums of that walk are doubles
+// added in the SORTED order, and equal starts are common, so the permutation of ties is part of the
+// result: the sort is libstdc++'s, reproduced by one wave per entry with the entry's spans in LDS
+// (wave_gnu_sort.h; ~1 300 spans per entry on the bench workload, all entries at once across the chip).
+struct PSpan {   // host: Span {start, stop, rec} + the record's score (abs(stop - start) is its span)
+  int32_t start, stop;
+  uint32_t rec, score;
+};
+struct ByStart {
+  __host__ __device__ bool operator()(const PSpan &a, const PSpan &b) const { return a.start < b.start; }
+};
+constexpr uint32_t PSEUDO_CAP = 4000;   // spans per entry that fit the workgroup's LDS (64 000 B)
+
+__global__ void k_spans(const Rec *__restrict__ recs, const kslam_read_pair *__restrict__ groups, uint64_t n_groups,
+                        uint4 *__restrict__ out, uint32_t *__restrict__ max_entry) {
+  // one thread per read pair: its records, in order, as {entry, start, stop, rec} (the bucket sort is stable,
+  // so the buckets come out in the reference's iteration order)
+  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n_groups) return;
+  const uint64_t first = groups[g].first, cnt = groups[g].count;
+  uint32_t mx = 0;
+  for (uint64_t k = 0; k < cnt; k++) {
+    const Rec r = recs[first + k];
+    out[first + k] = make_uint4(r.entry, (uint32_t)r.ref_start, (uint32_t)r.ref_end, (uint32_t)(first + k));
+    mx = max(mx, r.entry);
+  }
+  atomicMax(max_entry, mx);
+}
+
+__global__ void k_entry_runs(const uint4 *__restrict__ sorted, uint64_t n, uint32_t *__restrict__ flags) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) flags[i] = (i == 0 || sorted[i].x != sorted[i - 1].x) ? 1u : 0u;
+}
+__global__ void k_run_starts(const uint32_t *__restrict__ flags, const uint32_t *__restrict__ pos, uint64_t n,
+                             uint32_t *__restrict__ run_start, uint32_t *__restrict__ longest) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || !flags[i]) return;
+  run_start[pos[i]] = (uint32_t)i;
+  (void)longest;
+}
+__global__ void k_run_longest(const uint32_t *__restrict__ run_start, uint32_t n_runs, uint32_t n, uint32_t *__restrict__ longest) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_runs) return;
+  const uint32_t len = (r + 1 < n_runs ? run_start[r + 1] : n) - run_start[r];
+  atomicMax(longest, len);
+}
+
+// the reference's `uint32_t s = score;` as x86-64 evaluates it (cvttsd2si to 64 bits, low half kept):
+// NaN, infinities and values outside int64 give 0
+__device__ inline uint32_t cvt_u32_like_x86(double d) {
+  if (!(d > -9223372036854775808.0 && d < 9223372036854775808.0)) return 0u;
+  return (uint32_t)(uint64_t)(long long)d;
+}
+
+// one chain of an entry's sorted spans: [from, to); host/tail.cpp chain_entry's sums, operation for operation
+__device__ inline void score_chain(const PSpan *v, uint32_t from, uint32_t to, Rec *__restrict__ recs) {
+#pragma clang fp contract(off)
+  const long len = (long)to - (long)from;
+  if (len <= 1) return;
+  int reach = v[from].stop;
+  int span = abs(v[from].stop - v[from].start);
+  double per_base = v[from].score * 1.0 / span;
+  uint32_t bases = (uint32_t)span;
+  for (uint32_t i = from + 1; i < to; i++) {
+    span = abs(v[i].stop - v[i].start);
+    if (v[i].stop > reach) reach = v[i].stop;
+    per_base += v[i].score * 1.0 / span;
+    bases += (uint32_t)span;
+  }
+  const double length = reach - v[from].start;
+  const double coverage = bases / length;
+  const double avg = per_base / len;
+  const double score = coverage * avg * length;
+  const uint32_t s = cvt_u32_like_x86(score);
+  for (uint32_t k = from; k < to; k++) recs[v[k].rec & 0x7FFFFFFFu].combined_score = s;
+}
+
+// One wave per entry.  (1) its spans into LDS; (2) std::sort by start, the permutation included, by the
+// whole wave (wave_gnu_sort.h); (3) chain starts: the reference starts a chain where start > reach - 20 with
+// reach = the highest stop of the chain so far -- and, the starts being sorted, every stop of an earlier
+// chain is below this chain's first start + 20, so reach can be the running maximum over ALL earlier spans:
+// a prefix maximum, 64 spans a step; (4) one lane per chain adds up the chain in order (the chains are
+// independent; the additions inside one are the reference's sequence) and writes the members' new scores.
+__global__ __launch_bounds__(64) void k_pseudo_entry(const uint4 *__restrict__ sorted, const uint32_t *__restrict__ run_start,
+                                                     uint32_t n_runs, uint32_t n, Rec *__restrict__ recs) {
+  extern __shared__ PSpan v[];
+  __shared__ kslam_gnu::WaveSortLds S;
+  const uint32_t r = blockIdx.x, lane = threadIdx.x;
+  const uint32_t lo = run_start[r], cnt = (r + 1 < n_runs ? run_start[r + 1] : n) - lo;
+  for (uint32_t k = lane; k < cnt; k += 64) {
+    const uint4 e = sorted[lo + k];
+    PSpan p;
+    p.start = (int32_t)e.y;
+    p.stop = (int32_t)e.z;
+    p.rec = e.w;
+    p.score = recs[e.w].combined_score;
+    v[k] = p;
+  }
+  __syncthreads();
+  kslam_gnu::wave_sort(v, cnt, ByStart(), S);
+  __syncthreads();
+  int carry = -1000000;
+  for (uint32_t base = 0; base < cnt; base += 64) {
+    const uint32_t i = base + lane;
+    const int stop = i < cnt ? v[i].stop : INT32_MIN;
+    int incl = stop;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int t = __shfl_up(incl, d, 64);
+      if (lane >= (uint32_t)d) incl = max(incl, t);
+    }
+    int before = __shfl_up(incl, 1, 64);
+    before = lane ? max(before, carry) : carry;
+    if (i < cnt && v[i].start > before - 20) v[i].rec |= 0x80000000u;   // a chain starts here
+    carry = max(carry, __shfl(incl, 63, 64));
+  }
+  __syncthreads();
+  for (uint32_t i = lane; i < cnt; i += 64) {
+    if (!(v[i].rec & 0x80000000u)) continue;
+    uint32_t to = i + 1;
+    while (to < cnt && !(v[to].rec & 0x80000000u)) to++;
+    score_chain(v, i, to, recs);
+  }
+}
+
+// kslam_debug_wave_sort: segments of keys, sorted by key with wave_sort; out = the permutation (element ids)
+__global__ __launch_bounds__(64) void k_debug_wave_sort(const int32_t *__restrict__ keys, const uint64_t *__restrict__ seg_off,
+                                                        uint32_t *__restrict__ perm) {
+  extern __shared__ PSpan v[];
+  __shared__ kslam_gnu::WaveSortLds S;
+  const uint64_t lo = seg_off[blockIdx.x];
+  const uint32_t cnt = (uint32_t)(seg_off[blockIdx.x + 1] - lo);
+  for (uint32_t k = threadIdx.x; k < cnt; k += 64) {
+    PSpan p;
+    p.start = keys[lo + k];
+    p.stop = 0;
+    p.rec = k;
+    p.score = 0;
+    v[k] = p;
+  }
+  __syncthreads();
+  kslam_gnu::wave_sort(v, cnt, ByStart(), S);
+  __syncthreads();
+  for (uint32_t k = threadIdx.x; k < cnt; k += 64) perm[lo + k] = v[k].rec;
+}
+
+// screenPairedAlignmentsByScore once more, in place on the dense records (host/tail.cpp: rescreen_stage)
+__global__ __launch_bounds__(256) void k_rescreen(Rec *__restrict__ recs, kslam_read_pair *__restrict__ groups, uint64_t n_groups,
+                                                  double fraction) {
+  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n_groups) return;
+  const uint32_t n = (uint32_t)groups[g].count;
+  if (!n) return;
+  Rec *v = recs + groups[g].first;
+  kslam_gnu::sort(v, v + n, ByScoreDesc());
+  const unsigned top = v[0].combined_score;
+  const double bar = top * fraction;
+  uint32_t k = 0;
+  while (k < n && !((double)v[k].combined_score < bar)) k++;
+  groups[g].count = k;
+}
+
 }  // namespace
+
+// pseudo-assembly + second score screen on the result of pair_and_screen, in place.  Returns false, having
+// changed nothing, when an entry holds more spans than one workgroup's LDS takes (the host then runs the stage).
+bool pseudo_and_rescreen(PairWork &W, PairResult *res, double score_fraction, SortWorkspace &sortws, hipStream_t s) {
+  const uint64_t n = res->n_pairs, n_groups = res->n_read_pairs;
+  if (n == 0) { res->stages_done |= 4u; return true; }
+  if (n >= (1ull << 31)) return false;
+  Rec *recs = const_cast<Rec *>(res->d_pairs);
+  kslam_read_pair *groups = const_cast<kslam_read_pair *>(res->d_groups);
+  W.sort_a.ensure((n + 1) * sizeof(uint4));
+  W.sort_b.ensure((n + 1) * sizeof(uint4));
+  W.flags.ensure((n + 1) * sizeof(uint32_t));
+  W.gpos.ensure((n + 1) * sizeof(uint32_t));
+  W.count.ensure((n + 2) * sizeof(uint32_t));          // run starts
+  W.scan_tmp.ensure(scan_tmp_bytes(n));
+  uint64_t *tot = W.totals.as<uint64_t>();
+  HIPCHK(hipMemsetAsync(tot + 12, 0, 2 * sizeof(uint64_t), s));
+  uint32_t *d_max_entry = reinterpret_cast<uint32_t *>(tot + 12), *d_longest = reinterpret_cast<uint32_t *>(tot + 13);
+  hipLaunchKernelGGL(k_spans, dim3((unsigned)((n_groups + 255) / 256)), dim3(256), 0, s, recs, groups, n_groups,
+                     W.sort_a.as<uint4>(), d_max_entry);
+  uint32_t max_entry = 0;
+  read_back(&max_entry, d_max_entry, sizeof max_entry, s);
+  uint32_t bits = 1;
+  while (bits < 32 && (max_entry >> bits)) bits++;
+  SortPass passes[4];
+  int np = 0;
+  for (uint32_t b = 0; b < (bits + 7) / 8; b++) passes[np++] = SortPass{0, 8 * b, 0};
+  const uint4 *sorted = (const uint4 *)radix_sort(W.sort_a.p, W.sort_b.p, n, 4, passes, np, sortws, s, nullptr, nullptr, nullptr);
+  const unsigned nb = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL(k_entry_runs, dim3(nb), dim3(256), 0, s, sorted, n, W.flags.as<uint32_t>());
+  exclusive_scan_u32(W.flags.as<uint32_t>(), W.gpos.as<uint32_t>(), n, tot + 14, W.scan_tmp.p, s);
+  uint64_t n_runs64 = 0;
+  read_back(&n_runs64, tot + 14, sizeof n_runs64, s);
+  const uint32_t n_runs = (uint32_t)n_runs64;
+  hipLaunchKernelGGL(k_run_starts, dim3(nb), dim3(256), 0, s, W.flags.as<uint32_t>(), W.gpos.as<uint32_t>(), n,
+                     W.count.as<uint32_t>(), d_longest);
+  hipLaunchKernelGGL(k_run_longest, dim3((n_runs + 255) / 256), dim3(256), 0, s, W.count.as<uint32_t>(), n_runs, (uint32_t)n, d_longest);
+  uint32_t longest = 0;
+  read_back(&longest, d_longest, sizeof longest, s);
+  if (longest > PSEUDO_CAP) return false;
+  hipLaunchKernelGGL(k_pseudo_entry, dim3(n_runs), dim3(64), (size_t)longest * sizeof(PSpan), s, sorted, W.count.as<uint32_t>(),
+                     n_runs, (uint32_t)n, recs);
+  hipLaunchKernelGGL(k_rescreen, dim3((unsigned)((n_groups + 255) / 256)), dim3(256), 0, s, recs, groups, n_groups, score_fraction);
+  HIPCHK(hipGetLastError());
+  res->stages_done |= 4u;
+  return true;
+}
+
+void debug_wave_sort(const int32_t *keys, const uint64_t *seg_off, uint64_t n_seg, uint32_t *perm, hipStream_t s) {
+  if (!n_seg) return;
+  const uint64_t n = seg_off[n_seg];
+  uint32_t longest = 0;
+  for (uint64_t i = 0; i < n_seg; i++) {
+    if (seg_off[i + 1] < seg_off[i] || seg_off[i + 1] - seg_off[i] > PSEUDO_CAP)
+      throw StatusError{KSLAM_ERR_ARG, "segments must be ascending and hold at most 4000 keys each"};
+    longest = std::max<uint32_t>(longest, (uint32_t)(seg_off[i + 1] - seg_off[i]));
+  }
+  DevBuf dk, doff, dp;
+  dk.ensure((n + 1) * sizeof(int32_t));
+  doff.ensure((n_seg + 1) * sizeof(uint64_t));
+  dp.ensure((n + 1) * sizeof(uint32_t));
+  HIPCHK(hipMemcpyAsync(dk.p, keys, n * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(doff.p, seg_off, (n_seg + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(k_debug_wave_sort, dim3((unsigned)n_seg), dim3(64), (size_t)longest * sizeof(PSpan), s, dk.as<int32_t>(),
+                     doff.as<uint64_t>(), dp.as<uint32_t>());
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(perm, dp.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+}
 
 // getMaxAllowedInsertSize on the device-resident insert sizes (host/tail.cpp: max_allowed_insert)
 static uint32_t max_allowed_insert_device(int32_t *d_ins, uint64_t n, PairWork &W, SortWorkspace &sortws, hipStream_t s) {
@@ -422,6 +658,7 @@ void pair_and_screen(const kslam_overlap *d_ov, uint64_t n, const uint32_t *d_re
   HIPCHK(hipGetLastError());
   res->d_groups = W.groups.as<kslam_read_pair>();
   res->d_pairs = W.dense.as<Rec>();
+  res->stages_done = ((do_insert && paired) ? 1u : 0u) | (do_score ? 2u : 0u);
 }
 
 }  // namespace kslam

@@ -4,6 +4,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <random>
+#include <string>
 #include <vector>
 #include "../k-slam_amd/csrc/gnu_sort.h"
 
@@ -31,7 +32,36 @@ static std::vector<El> killer(size_t n) {
   return v;
 }
 
-int main() {
+// `gnu_sort_check perm IN OUT`: IN = u64 n_seg, u64 seg_off[n_seg + 1], i32 keys[]; OUT = u32 perm[]: what the
+// real std::sort does to each segment of {key, id} elements compared by key (tests/test_gpu_tail.py compares
+// the device's wave sort with it)
+static int perm_mode(const char *in, const char *out) {
+  FILE *f = std::fopen(in, "rb");
+  if (!f) return 2;
+  uint64_t n_seg = 0;
+  if (std::fread(&n_seg, 8, 1, f) != 1) return 2;
+  std::vector<uint64_t> off(n_seg + 1);
+  if (std::fread(off.data(), 8, n_seg + 1, f) != n_seg + 1) return 2;
+  std::vector<int32_t> keys(off[n_seg]);
+  if (!keys.empty() && std::fread(keys.data(), 4, keys.size(), f) != keys.size()) return 2;
+  std::fclose(f);
+  struct SEl { int32_t key; uint32_t id; };
+  std::vector<uint32_t> perm(keys.size());
+  for (uint64_t s = 0; s < n_seg; s++) {
+    std::vector<SEl> v(off[s + 1] - off[s]);
+    for (size_t i = 0; i < v.size(); i++) v[i] = SEl{keys[off[s] + i], (uint32_t)i};
+    std::sort(v.begin(), v.end(), [](const SEl &a, const SEl &b) { return a.key < b.key; });
+    for (size_t i = 0; i < v.size(); i++) perm[off[s] + i] = v[i].id;
+  }
+  f = std::fopen(out, "wb");
+  if (!f) return 2;
+  std::fwrite(perm.data(), 4, perm.size(), f);
+  std::fclose(f);
+  return 0;
+}
+
+int main(int argc, char **argv) {
+  if (argc == 4 && std::string(argv[1]) == "perm") return perm_mode(argv[2], argv[3]);
   std::mt19937_64 rng(12345);
   auto asc = [](const El &a, const El &b) { return a.key < b.key; };
   auto desc = [](const El &a, const El &b) { return a.key > b.key; };

@@ -1,5 +1,6 @@
 """The first half of the host tail on the GPU (csrc/pairs.hip): score
-screen, read pairing, insert-size statistics, insert-size screen and score-fraction screen -- against the
+screen, read pairing, insert-size statistics, insert-size screen, score-fraction screen, pseudo-assembly
+and the second score screen -- against the
 host tail (k-slam_amd/host/tail.cpp, itself compared with the oracle's serial restatement in
 tests/test_tail.py), record for record.  Equal keys are the rule in these sorts, so the comparison is on
 the exact permutation: the device reproduces libstdc++'s std::sort (csrc/gnu_sort.h,
@@ -59,6 +60,104 @@ def test_device_pairing_and_screens_equal_the_host_tail(kslam, T, ctx, seed, pai
         assert got["max_insert_size"] == st.max_insert_size and got["n_insert_sizes"] == st.n_insert_sizes
 
 
+def test_wave_sort_produces_the_std_sort_permutation(kslam, ctx, tmp_path):
+    """csrc/wave_gnu_sort.h (std::sort by one wavefront: parallel Hoare partition, per-leaf insertion sorts)
+    against the real std::sort of this toolchain on ~3 000 arrays: every size from 0 to 300, sizes up to the
+    4000-element limit, few / many distinct keys, sorted / reversed / organ-pipe / all-equal / median-of-three
+    killer inputs (the last drives std::sort into its heap-sort fallback)"""
+    import shutil
+    import subprocess
+    gxx = shutil.which("g++")
+    assert gxx
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "gnu_sort_check")
+    subprocess.check_call([gxx, "-O2", "-std=c++17", os.path.join(root, "tests", "gnu_sort_check.cpp"), "-o", exe])
+    rng = np.random.default_rng(5)
+    segs = []
+    sizes = list(range(0, 301)) * 4 + [int(x) for x in rng.integers(300, 4001, 1500)] + [4000] * 8 + [17, 33, 64, 65, 127, 128, 129]
+    for i, n in enumerate(sizes):
+        distinct = [1, 2, 3, 20, 100000][i % 5]
+        k = rng.integers(0, distinct, n).astype(np.int32)
+        shape = i % 7
+        if shape == 1:
+            k.sort()
+        elif shape == 2:
+            k = np.sort(k)[::-1].copy()
+        elif shape == 3 and n > 2:
+            k.sort()
+            k[n // 2:] = k[n // 2:][::-1]
+        segs.append(k)
+    for n in (17, 33, 64, 100, 257, 1000, 4000):      # Musser's median-of-three killer
+        v = np.zeros(n, dtype=np.int32)
+        h = n // 2
+        for i in range(1, h + 1):
+            if i % 2 == 1:
+                v[i - 1] = i
+                v[i] = h + i
+            v[h + i - 1] = 2 * i
+        segs.append(v)
+    off = np.zeros(len(segs) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(x) for x in segs])
+    keys = np.concatenate(segs).astype(np.int32)
+    fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    with open(fin, "wb") as fh:
+        fh.write(np.uint64(len(segs)).tobytes() + off.tobytes() + keys.tobytes())
+    subprocess.check_call([exe, "perm", fin, fout])
+    exp = np.fromfile(fout, dtype=np.uint32)
+    got = ctx.debug_wave_sort(keys, off)
+    bad = np.nonzero(got != exp)[0]
+    assert len(bad) == 0, "first difference in segment %d (size %d)" % (
+        np.searchsorted(off, bad[0], side="right") - 1, len(segs[np.searchsorted(off, bad[0], side="right") - 1]))
+    # the permutations are not the stable ones (else this test would not see a wrong tie order)
+    stable = np.concatenate([np.argsort(x, kind="stable") for x in segs]).astype(np.uint32)
+    assert (stable != exp).sum() > 100000
+
+
+def _compacted(rp, pr):
+    """the device leaves the records where they are when the second screen shrinks a group; the host tail
+    hands back the survivors packed -- pack the device's the same way"""
+    cnt = rp["count"].astype(np.int64)
+    starts = np.cumsum(cnt) - cnt
+    idx = np.repeat(rp["first"].astype(np.int64) - starts, cnt) + np.arange(int(cnt.sum()))
+    out = rp.copy()
+    out["first"] = starts
+    return out, pr[idx]
+
+
+@pytest.mark.parametrize("seed,paired,thr,frac,per_read,n_entries,expect_device", [
+    (21, True, 0, 0.95, 3.0, 12, True), (22, True, 150, 0.8, 3.0, 12, True), (23, False, 0, 0.95, 3.0, 12, True),
+    (24, True, 0, 0.95, 3.0, 300, True), (25, True, 0, 0.5, 12.0, 40, True), (26, True, 0, 0.95, 12.0, 2, False),
+    (27, True, 0, 1.0, 3.0, 7, True)])
+def test_device_pseudo_assembly_equals_the_host_tail(kslam, T, ctx, seed, paired, thr, frac, per_read, n_entries, expect_device):
+    """pseudoAssembly + the second score screen on the device (stages = 7): chains of overlapping alignments
+    per entry, scores from double sums in std::sort's order of equal starts -> the host tail's records, byte
+    for byte; an entry too big for one workgroup's LDS leaves the stage to the host, and says so"""
+    from test_tail import _fuzz_overlaps
+    rng = np.random.default_rng(100 + seed)
+    ov, n_reads = _fuzz_overlaps(kslam, rng, 3000, n_entries, per_read=per_read, paired=paired)
+    if seed == 24:      # degenerate spans (refEnd == refStart: the reference divides by zero) and reversed ones
+        z = rng.random(len(ov)) < 0.02
+        ov["ref_end"][z] = ov["ref_begin"][z]
+        w = rng.random(len(ov)) < 0.02
+        ov["ref_end"][w] = ov["ref_begin"][w] - 5
+    reads = T.Reads([b"A" * 100] * n_reads)
+    got = ctx.pair_screen_overlaps(ov, np.full(n_reads, 100, dtype=np.uint32), paired=paired, score_threshold=thr,
+                                   score_fraction=frac, stages=7)
+    grp, gpr = ctx.take_pairs()
+    assert bool(got["stages_done"] & 4) == expect_device and got["stages_done"] & 3 == (3 if paired else 2)
+    P = T.TailParams.default(paired=paired, report_cigar=False, threads=4, score_threshold=thr, score_fraction=frac,
+                             pseudo_assembly=True, stages=7 if expect_device else 3)
+    rp, pr, st = T.tail_pairs(P, reads, ov)
+    crp, cpr = _compacted(grp, gpr)
+    assert len(pr) > 500
+    assert crp.tobytes() == rp.tobytes() and cpr.tobytes() == pr.tobytes()
+    if expect_device:   # the stage did something: chain scores differ from the pairing's sums
+        P3 = T.TailParams.default(paired=paired, report_cigar=False, threads=4, score_threshold=thr, score_fraction=frac,
+                                  pseudo_assembly=False, stages=3)
+        _, pr3, _ = T.tail_pairs(P3, reads, ov)
+        assert len(pr3) != len(pr) or pr3.tobytes() != pr.tobytes()
+
+
 @pytest.mark.parametrize("pseudo", [False, True])
 def test_alignment_to_sam_with_the_tail_front_on_the_gpu(kslam, oracle, synth, T, pseudo):
     """align -> row details -> pairing / screens on the GPU -> host: [pseudo-assembly, second screen,] SAM
@@ -103,6 +202,19 @@ def test_alignment_to_sam_with_the_tail_front_on_the_gpu(kslam, oracle, synth, T
         out = []
         T.tail_finish_rows(P, R, I, o, g, d, m, lrp.copy(), lpr.copy(), out.append)
         assert b"".join(out) == exp
+        release()
+    if pseudo:   # pseudo-assembly and the second screen on the device too: the host only writes
+        c.set_pairing(paired=True, stages=7)
+        o, g, d, m, release = c.collect_batch(c.submit_batch_full(len(rb), C.cast(bp, C.c_void_p), C.cast(qp, C.c_void_p), lens.ctypes.data))
+        lrp, lpr, lst = c.last_pairs
+        assert lst["stages_done"] == 7
+        hrp7, hpr7, _ = T.tail_pairs(P, R, ov)
+        crp, cpr = _compacted(lrp, lpr)
+        assert crp.tobytes() == hrp7.tobytes() and cpr.tobytes() == hpr7.tobytes()
+        out = []
+        P_write = T.TailParams.default(pseudo_assembly=False)
+        wst = T.tail_finish_rows(P_write, R, I, o, g, d, m, lrp.copy(), lpr.copy(), out.append)
+        assert b"".join(out) == exp and wst.n_paired_final == est.n_paired_final
         release()
     c.set_pairing(stages=0)
     o, g, d, m, release = c.collect_batch(c.submit_batch_full(len(rb), C.cast(bp, C.c_void_p), None, lens.ctypes.data))

@@ -179,7 +179,7 @@ def sam_pipeline(K, ctx, reads, db, offs, read_len, steps, pseudo_assembly=False
     P_write = T.TailParams.default(pseudo_assembly=False)         # when the GPU has run that stage too
     gpu_stages = 7 if pseudo_assembly and os.environ.get("KSLAM_BENCH_HOST_PSEUDO") != "1" else 3
     t_host_copy = time.time() - t0
-    stats = []
+    stats, finished = [], []
 
     def submit():
         return ctx.submit_batch_columns(n_reads, hb.ptr, hq.ptr, off.ctypes.data)
@@ -195,12 +195,14 @@ def sam_pipeline(K, ctx, reads, db, offs, read_len, steps, pseudo_assembly=False
         d = st.as_dict()
         d["gpu_pairing"] = pst
         stats.append(d)
+        finished.append(time.perf_counter())       # batch complete: SAM text written
 
     # score screen, pairing, insert-size statistics, screens [, pseudo-assembly, second screen]: on the GPU
     ctx.set_pairing(paired=True, stages=gpu_stages)
     for tk in [submit(), submit(), submit()]:       # warm both lanes' buffers and the tail's work buffers
         tail(*collect(tk))
     stats.clear()
+    del finished[:]
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     worker, done_at = None, []
@@ -221,8 +223,14 @@ def sam_pipeline(K, ctx, reads, db, offs, read_len, steps, pseudo_assembly=False
     ctx.set_pairing(stages=0)
     hb.close()
     hq.close()
+    # batch-to-batch in the steady state (completion of batch 0 to completion of the last): what a long run of
+    # batches sees; the wall clock of a short run also holds the pipeline's fill (first batch: upload + align +
+    # download with nothing to overlap) and drain (last host stage)
+    steady = (finished[-1] - finished[0]) / (len(finished) - 1) if len(finished) > 1 else wall / steps
     return {
-        "reads_per_s": round(n_reads * steps / wall, 1), "ms_per_batch": round(wall / steps * 1e3, 2),
+        "reads_per_s": round(n_reads / steady, 1), "ms_per_batch": round(steady * 1e3, 2),
+        "including_pipeline_fill_and_drain": {"reads_per_s": round(n_reads * steps / wall, 1),
+                                              "ms_per_batch": round(wall / steps * 1e3, 2)},
         "steps": steps, "host_tail_ms": round(sum(tail_ms) / len(tail_ms), 2),
         "host_tail_phases_ms": {k[3:]: round(last[k], 2) for k in last if k.startswith("ms_")},
         "host_threads": int(last["threads"]), "sam_mb_per_batch": round(last["sam_bytes"] / 1e6, 1),
@@ -278,7 +286,7 @@ def full_pipeline(K, ctx, reads, db, offs, read_len, steps, pseudo_assembly=Fals
     P = T.TailParams.default(threads=nthr, pseudo_assembly=pseudo_assembly)
     P_write = T.TailParams.default(threads=nthr, pseudo_assembly=False)   # when the GPU has run that stage too
     gpu_stages = 7 if pseudo_assembly and os.environ.get("KSLAM_BENCH_HOST_PSEUDO") != "1" else 3
-    stats, on_gpu = [], []
+    stats, on_gpu, finished = [], [], []
 
     def collect(tk):
         res = ctx.collect_batch(tk)
@@ -293,6 +301,7 @@ def full_pipeline(K, ctx, reads, db, offs, read_len, steps, pseudo_assembly=Fals
         if batch is not None:
             batch.close()
         stats.append(st.as_dict())
+        finished.append(time.perf_counter())
 
     ctx.set_pairing(paired=True, stages=gpu_stages)
     host_index = os.environ.get("KSLAM_BENCH_HOST_FASTQ_INDEX") == "1"   # A/B: the record index on the host (round-2 first form)
@@ -311,20 +320,24 @@ def full_pipeline(K, ctx, reads, db, offs, read_len, steps, pseudo_assembly=Fals
                                     batch.layout.bases_at, batch.layout.quality_at)
         return batch, tk, (t1 - t0, time.perf_counter() - t1)
     import ctypes as C
-    worker, parts, waits = None, [], []
+    worker, parts, waits, joins = None, [], [], []
+
+    depth = int(os.environ.get("KSLAM_LANES", "2")) + 1
 
     def run(nsteps):
         nonlocal worker
         queue = [parse_and_submit()]                               # batch 0 on its way
         for k in range(nsteps):
-            while len(queue) < 3 and k + len(queue) < nsteps:      # two more batches indexed and queued behind it
+            while len(queue) < depth and k + len(queue) < nsteps:  # more batches queued behind it: one per lane + 1
                 queue.append(parse_and_submit())
             cur = queue.pop(0)
             tw = time.perf_counter()
             res = collect(cur[1])                                  # batch k back from the GPU
             waits.append(time.perf_counter() - tw)
+            tj = time.perf_counter()
             if worker is not None:
                 worker.join()                                      # host stage of batch k-1 done
+            joins.append(time.perf_counter() - tj)
             worker = threading.Thread(target=tail, args=(cur[0],) + tuple(res))
             worker.start()
             parts.append(cur[2])
@@ -332,7 +345,7 @@ def full_pipeline(K, ctx, reads, db, offs, read_len, steps, pseudo_assembly=Fals
         worker = None
     run(6)          # warm-up in the same shape: both lanes, the parser's page-locked block cache, the tail's arenas
     stats.clear()
-    del parts[:], waits[:]
+    del parts[:], waits[:], joins[:], finished[:]
     torch.cuda.synchronize()
     t_start = time.perf_counter()
     run(steps)
@@ -342,9 +355,13 @@ def full_pipeline(K, ctx, reads, db, offs, read_len, steps, pseudo_assembly=Fals
     ctx.set_pairing(stages=0)
     h1.close()
     h2.close()
+    steady = (finished[-1] - finished[0]) / (len(finished) - 1) if len(finished) > 1 else wall / steps   # see sam_pipeline
     return {
-        "reads_per_s": round(n_reads * steps / wall, 1), "ms_per_batch": round(wall / steps * 1e3, 2), "steps": steps,
+        "reads_per_s": round(n_reads / steady, 1), "ms_per_batch": round(steady * 1e3, 2), "steps": steps,
+        "including_pipeline_fill_and_drain": {"reads_per_s": round(n_reads * steps / wall, 1),
+                                              "ms_per_batch": round(wall / steps * 1e3, 2)},
         "ms_fastq_parse": ms(0), "ms_submit": ms(1), "ms_waiting_for_gpu": round(1e3 * sum(waits) / len(waits), 2),
+        "ms_waiting_for_host_stage": round(1e3 * sum(joins) / len(joins), 2),
         "host_tail_ms": round(sum(sum(v for k, v in s.items() if k.startswith("ms_")) for s in stats) / len(stats), 2),
         "host_tail_phases_ms": {k[3:]: round(stats[-1][k], 2) for k in stats[-1] if k.startswith("ms_")},
         "fastq_mb_per_batch": round((len1 + len2) / 1e6, 1), "sam_mb_per_batch": round(stats[-1]["sam_bytes"] / 1e6, 1),
@@ -392,15 +409,25 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the hot path has no CPU fallback")
+    # KSLAM_BENCH_SHARE_GPU=1 (tests only): the ranks share the GPUs that exist, and talk through gloo with
+    # host-staged pieces -- RCCL refuses two ranks on one device.  Everything else (sharding, count exchange,
+    # export in batch terms, placement, verification) is the code a real N-GPU run executes.
+    share = os.environ.get("KSLAM_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cdev = torch.device("cpu") if share else dev          # where the communicator's small tensors live
     dist = None
     use_dist = world > 1 or os.environ.get("KSLAM_BENCH_FORCE_DIST") == "1"   # the override runs the RCCL code path at N=1
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     K = entry.load_package()
     kdist = importlib.import_module("kslam_amd.dist")
@@ -491,7 +518,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if use_dist:
-        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        te = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
 
@@ -509,6 +536,15 @@ def main():
     verified["run_to_run_identical"] = bool(ov_a.numel() == ov_b.numel() and torch.equal(ov_a, ov_b)
                                             and torch.equal(cg_a, cg_b))
     verified["ok"] = bool(verified["ok"] and verified["run_to_run_identical"])
+    if use_dist:   # every rank checked its own shard: sum the counts, AND the verdicts
+        keys = [k for k, v in verified.items() if not isinstance(v, bool)]
+        t = torch.tensor([verified[k] for k in keys] + [int(verified["ok"]), int(verified["run_to_run_identical"])],
+                         dtype=torch.int64, device=cdev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        for k, v in zip(keys, t[:len(keys)].tolist()):
+            verified[k] = int(v)
+        verified["ok"] = bool(int(t[-2]) == world)
+        verified["run_to_run_identical"] = bool(int(t[-1]) == world)
     if strong and use_dist and rank == 0 and "ov" in merged:
         # the merged batch: row count, order, and -- when this rank aligned the whole batch itself (one
         # rank) -- byte identity with the single-context result
@@ -517,22 +553,29 @@ def main():
         mkey = (mc["read"] * (len(offs) - 1) + mc["entry"]) * n_rel + (mc["rel"] + 1024)
         verified["merged_rows"] = int(mkey.numel())
         verified["merged_unsorted_neighbours"] = int((mkey[1:] < mkey[:-1]).sum()) if mkey.numel() > 1 else 0
-        if world == 1:
-            verified["merged_equals_single_context"] = bool(
-                merged["ov"].numel() == ov_a.numel() and torch.equal(merged["ov"], ov_a) and
-                torch.equal(merged["cg"].view(torch.int32), cg_a))
-            verified["ok"] = bool(verified["ok"] and verified["merged_equals_single_context"])
+        if world > 1:
+            # the whole batch once more, in THIS rank's context alone (outside the timed region): what the N ranks
+            # produced together must be, byte for byte, what one context returns for the batch
+            del ov_a, cg_a, ov_b, cg_b
+            piece = args.total_pairs // PIECES
+            r1s, r2s = [], []
+            for pc in range(PIECES):
+                gen.manual_seed(2 + 1000 * pc)
+                r = make_reads(dev, gen, db, offs, piece, read_len=args.read_len)
+                r1s.append(r[:piece]); r2s.append(r[piece:])
+            whole = torch.cat(r1s + r2s, 0).contiguous()
+            del r1s, r2s
+            ctx.load_reads_device(whole.shape[0], whole.data_ptr(),
+                                  np.arange(whole.shape[0] + 1, dtype=np.uint64) * np.uint64(args.read_len))
+            ov_a, cg_a = device_results()
+            ov_b = cg_b = None
+            del whole
+        verified["merged_equals_single_context"] = bool(
+            merged["ov"].numel() == ov_a.numel() and torch.equal(merged["ov"], ov_a) and
+            torch.equal(merged["cg"].view(torch.int32), cg_a))
+        verified["ok"] = bool(verified["ok"] and verified["merged_equals_single_context"])
         verified["ok"] = bool(verified["ok"] and verified["merged_unsorted_neighbours"] == 0)
     del ov_a, cg_a, ov_b, cg_b
-    if use_dist:   # every rank checked its own shard: sum the counts, AND the verdicts
-        keys = [k for k, v in verified.items() if not isinstance(v, bool)]
-        t = torch.tensor([verified[k] for k in keys] + [int(verified["ok"]), int(verified["run_to_run_identical"])],
-                         dtype=torch.int64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        for k, v in zip(keys, t[:len(keys)].tolist()):
-            verified[k] = int(v)
-        verified["ok"] = bool(int(t[-2]) == world)
-        verified["run_to_run_identical"] = bool(int(t[-1]) == world)
 
     # RCCL announces itself on stdout through C stdio ("Librccl path : ..."), buffered when piped and
     # otherwise flushed when each rank exits -- after rank 0's JSON.  Every rank pushes it out now,

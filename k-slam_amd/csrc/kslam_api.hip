@@ -232,17 +232,22 @@ void pinned_free(void *p, size_t bytes) {
 // pinned host buffers from a small per-context pool (pinning is expensive; reuse across batches)
 void *pinned_get(kslam_ctx *c, size_t bytes) {
   std::lock_guard<std::mutex> lk(c->pin_mu);
+  // best fit: a small request must not take the buffer a large one of the same batch needs (first fit
+  // did, and the large request then re-pinned ~60 MB -- ~10 ms -- on every batch)
+  kslam_ctx::Pinned *best = nullptr;
   for (auto &b : c->pinned)
-    if (!b.in_use && b.cap >= bytes) { b.in_use = true; return b.p; }
-  for (auto &b : c->pinned)   // replace a free buffer that is too small
-    if (!b.in_use) {
-      pinned_free(b.p, b.cap);
-      b.p = nullptr; b.cap = 0;
-      size_t want = bytes + bytes / 4 + 4096;
-      if (!(b.p = pinned_alloc(want))) throw StatusError{KSLAM_ERR_OOM, "page-locked host allocation failed"};
-      b.cap = want; b.in_use = true;
-      return b.p;
-    }
+    if (!b.in_use && b.cap >= bytes && (!best || b.cap < best->cap)) best = &b;
+  if (best) { best->in_use = true; return best->p; }
+  if (c->pinned.size() >= 64)
+    for (auto &b : c->pinned)   // many buffers already: replace a free one that is too small
+      if (!b.in_use) {
+        pinned_free(b.p, b.cap);
+        b.p = nullptr; b.cap = 0;
+        size_t want = bytes + bytes / 4 + 4096;
+        if (!(b.p = pinned_alloc(want))) throw StatusError{KSLAM_ERR_OOM, "page-locked host allocation failed"};
+        b.cap = want; b.in_use = true;
+        return b.p;
+      }
   kslam_ctx::Pinned nb{nullptr, 0, true};
   size_t want = bytes + bytes / 4 + 4096;
   if (!(nb.p = pinned_alloc(want))) throw StatusError{KSLAM_ERR_OOM, "page-locked host allocation failed"};
@@ -824,10 +829,12 @@ void lane_main(kslam_ctx *primary, kslam_ctx::AsyncLane *lane) {
     }
     t3 = now();
     if (st == KSLAM_OK) st = kslam_take_results(c, &job->out, &job->n_out, &job->pool, &job->n_cig);
+    const double t4 = now();
     if (st == KSLAM_OK && (job->qcat || job->fastq)) st = kslam_take_row_details(c, &job->det, &job->md, &job->n_md);
+    const double t5 = now();
     if (st == KSLAM_OK && primary->pairing.stages) st = kslam_take_pairs(c, &job->rp, &job->n_rp, &job->pr, &job->n_pr);
-    if (dbg) fprintf(stderr, "[kslam] lane %p ticket %llu: upload %.2f, token wait %.2f, align %.2f, download %.2f ms\n", (void *)lane,
-                     (unsigned long long)job->ticket, t1 - t0, t2 - t1, t3 - t2, now() - t3);
+    if (dbg) fprintf(stderr, "[kslam] t=%.1f lane %p ticket %llu: upload %.2f, token wait %.2f, align %.2f, download %.2f (rows %.2f, details %.2f, pairs %.2f) ms\n",
+                     fmod(t0, 100000.0), (void *)lane, (unsigned long long)job->ticket, t1 - t0, t2 - t1, t3 - t2, now() - t3, t4 - t3, t5 - t4, now() - t5);
     {
       std::lock_guard<std::mutex> lk(primary->as_mu);
       job->st = st;
@@ -841,7 +848,9 @@ void lane_main(kslam_ctx *primary, kslam_ctx::AsyncLane *lane) {
 
 void ensure_lanes(kslam_ctx *c) {
   if (!c->lanes.empty()) return;
-  for (int k = 0; k < 2; k++) {
+  int n_lanes = 2;
+  if (const char *e = getenv("KSLAM_LANES")) n_lanes = std::min(8, std::max(1, atoi(e)));
+  for (int k = 0; k < n_lanes; k++) {
     kslam_ctx *lc = nullptr;
     const kslam_status s1 = kslam_create(&c->prm, &lc);
     if (s1 != KSLAM_OK) {

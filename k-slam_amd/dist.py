@@ -103,12 +103,17 @@ def start_gather_sharded(ctx, n_local_pairs, pair_lo, n_pairs_total, dev, group=
     records in BATCH terms (kslam_export_shard_device: read ids and CIGAR offsets re-based on its own
     GPU) and sends four pieces that land in their final places on rank 0.  finish_gather returns on
     rank 0 (rows, pool) -- uint8 device tensors holding the batch-global result, byte for byte what
-    one context returns for the whole batch -- elsewhere None."""
+    one context returns for the whole batch -- elsewhere None.
+
+    With the gloo backend (no device-to-device transport: the CPU tests, and the N = 2 test that runs two
+    ranks on ONE GPU) the pieces are staged through host memory; the protocol is the same."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
+    staged = dist.get_backend(group) == "gloo"
+    cdev = torch.device("cpu") if staged else dev        # where the communicator's tensors live
     mine = ctx.shard_counts_device(n_local_pairs)
-    t = torch.tensor(mine, dtype=torch.int64, device=dev)
-    allc = [torch.zeros(4, dtype=torch.int64, device=dev) for _ in range(world)]
+    t = torch.tensor(mine, dtype=torch.int64, device=cdev)
+    allc = [torch.zeros(4, dtype=torch.int64, device=cdev) for _ in range(world)]
     dist.all_gather(allc, t, group=group)
     cnt = [tuple(int(v) for v in a.tolist()) for a in allc]       # (rows, rows_r1, ops, ops_r1) per rank
     rows_r1 = sum(c[1] for c in cnt)
@@ -117,7 +122,7 @@ def start_gather_sharded(ctx, n_local_pairs, pair_lo, n_pairs_total, dev, group=
     row2 = [rows_r1 + sum(c[0] - c[1] for c in cnt[:r]) for r in range(world)]
     op1 = [sum(c[3] for c in cnt[:r]) for r in range(world)]
     op2 = [ops_r1 + sum(c[2] - c[3] for c in cnt[:r]) for r in range(world)]
-    ops, parts, keep = [], None, None
+    ops, parts, keep, landed = [], None, None, []
     if rank == 0:
         rows = torch.empty(sum(c[0] for c in cnt) * 48, dtype=torch.uint8, device=dev)
         pool = torch.empty(sum(c[2] for c in cnt) * 4, dtype=torch.uint8, device=dev)
@@ -129,7 +134,12 @@ def start_gather_sharded(ctx, n_local_pairs, pair_lo, n_pairs_total, dev, group=
             for buf, start, count, unit in ((rows, row1[r], n1, 48), (rows, row2[r], n - n1, 48),
                                             (pool, op1[r], c1, 4), (pool, op2[r], c - c1, 4)):
                 if count:
-                    ops.append(dist.P2POp(dist.irecv, buf[start * unit:(start + count) * unit], r, group))
+                    dst = buf[start * unit:(start + count) * unit]
+                    if staged:
+                        h = torch.empty(count * unit, dtype=torch.uint8)
+                        landed.append((dst, h))
+                        dst = h
+                    ops.append(dist.P2POp(dist.irecv, dst, r, group))
         parts = (rows, pool)
     else:
         n, n1, c, c1 = cnt[rank]
@@ -138,12 +148,14 @@ def start_gather_sharded(ctx, n_local_pairs, pair_lo, n_pairs_total, dev, group=
         rp, pp = srows.data_ptr(), spool.data_ptr()
         ctx.export_shard_device(n_local_pairs, pair_lo, n_pairs_total, op1[rank], op2[rank], rp, rp + 48 * n1,
                                 pp, pp + 4 * c1)
+        if staged:
+            srows, spool = srows.cpu(), spool.cpu()
         for buf, start, count, unit in ((srows, 0, n1, 48), (srows, n1, n - n1, 48), (spool, 0, c1, 4), (spool, c1, c - c1, 4)):
             if count:
                 ops.append(dist.P2POp(dist.isend, buf[start * unit:(start + count) * unit], 0, group))
         keep = (srows, spool)
     reqs = dist.batch_isend_irecv(ops) if ops else []
-    return {"reqs": reqs, "parts": parts, "keep": keep}
+    return {"reqs": reqs, "parts": parts, "keep": keep, "landed": landed}
 
 
 def finish_gather(handle):
@@ -151,6 +163,8 @@ def finish_gather(handle):
     tensors per rank, elsewhere None."""
     for q in handle["reqs"]:
         q.wait()
+    for dst, h in handle.get("landed", ()):     # host-staged pieces (gloo) into their final places
+        dst.copy_(h)
     return handle["parts"]
 
 

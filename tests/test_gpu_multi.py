@@ -101,3 +101,28 @@ def test_bench_strong_mode_through_the_rccl_path_at_world_1():
     assert line["scaling"] == "strong" and line["config"]["pairs_per_batch"] == 40000
     assert v["ok"] and v["merged_equals_single_context"] and v["merged_unsorted_neighbours"] == 0
     assert v["planted_missing"] == 0 and v["planted_expected"] > 50000 and v["merged_rows"] == v["overlaps"]
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_bench_strong_mode_with_several_ranks_on_one_gpu(world):
+    """bench.py --gpus N --strong, launched the way the driver launches it (torch.distributed.run, one process
+    per rank), with the ranks SHARING the box's one GPU (KSLAM_BENCH_SHARE_GPU=1: gloo with host-staged pieces
+    instead of RCCL, which refuses two ranks on a device).  Every rank aligns its pairs of the batch in its own
+    context; count exchange, export in batch terms, placement on rank 0 and the verification are the code of a
+    real N-GPU run.  Rank 0 then aligns the WHOLE batch in one context: the merged result must equal it byte
+    for byte."""
+    env = dict(os.environ, KSLAM_BENCH_SHARE_GPU="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                        "--master-addr", "127.0.0.1", "--master-port", str(29580 + world), os.path.join(ROOT, "bench.py"),
+                        "--gpus", str(world), "--total-pairs", "48000", "--species", "4", "--strains", "3",
+                        "--genome-len", "300000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = json.loads([x for x in r.stdout.strip().splitlines() if x.startswith("{")][-1])
+    v = line["verified"]
+    assert line["scaling"] == "strong" and line["n_gpus"] == world and line["config"]["pairs_per_batch"] == 48000
+    assert line["config"]["pairs_per_gpu"] == 48000 // world
+    assert v["ok"] and v["merged_equals_single_context"] and v["merged_unsorted_neighbours"] == 0
+    assert v["planted_missing"] == 0 and v["planted_expected"] > 60000 and v["merged_rows"] == v["overlaps"]

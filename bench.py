@@ -664,13 +664,13 @@ def main():
         if world == 1 and not strong and not args.no_sam_pipeline and not args.no_cigar:
             for key, pa in (("sam_pipeline", False), ("sam_pipeline_with_pseudo_assembly", True)):
                 try:
-                    out[key] = sam_pipeline(K, ctx, reads, db, offs, args.read_len, max(args.steps, 3), pa)
+                    out[key] = sam_pipeline(K, ctx, reads, db, offs, args.read_len, max(args.steps, 12), pa)
                 except Exception as e:   # extra evidence only: never lose the bench line over it
                     out[key] = {"error": repr(e)}
         if world == 1 and not strong and not args.no_full_pipeline and not args.no_cigar:
             for key, pa in (("full_pipeline", False), ("full_pipeline_with_pseudo_assembly", True)):
                 try:
-                    out[key] = full_pipeline(K, ctx, reads, db, offs, args.read_len, max(args.steps, 3), pa)
+                    out[key] = full_pipeline(K, ctx, reads, db, offs, args.read_len, max(args.steps, 12), pa)
                 except Exception as e:
                     out[key] = {"error": repr(e)}
         print(json.dumps(out), flush=True)

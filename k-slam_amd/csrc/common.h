@@ -229,7 +229,7 @@ void encode_bases(const uint8_t *d_src, uint8_t *d_dst, uint64_t n, hipStream_t 
 // unflipped coordinates); d_band0[i] = initial band width for banded_sw
 // (0 = no cigar wanted, ssw.c:924-927)
 struct SwWork {
-  DevBuf flags, pos, list, list2, scan_tmp, totals, tier_list[5];
+  DevBuf flags, pos, list, list2, scan_tmp, totals, tier_list[6];
 };
 // *n_full_out: candidates that needed the full-matrix kernel (the rest ran in a proven band)
 void sw_scores(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, uint32_t max_read_len,

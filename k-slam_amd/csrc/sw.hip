@@ -315,7 +315,7 @@ __device__ inline bool band_certifies(int32_t score, int32_t L, int32_t W, int32
 // The banded tiers of one launch configuration: diagonals swept per tier, the list each tier works
 // through and the counters behind the lists (counts[k]: entries of list k; counts[NT_FULL]: entries of
 // the full-matrix list).
-constexpr int NT_MAX = 5, NT_FULL = 7;
+constexpr int NT_MAX = 6, NT_FULL = 7;
 struct Tiers {
   int n;                  // tiers in use
   int unknown;            // tier a candidate starts in when its seed diagonals certify nothing
@@ -837,12 +837,13 @@ void sw_scores(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, uint32_
     Tiers T;
     memset(&T, 0, sizeof T);
     {
-      const int nd0[4] = {16, 32, 48, 64}, nd1[5] = {16, 32, 48, 64, 128};
+      const int nd0[5] = {16, 32, 48, 64, 96}, nd1[6] = {16, 32, 48, 64, 96, 128};
       const bool no48 = getenv("KSLAM_SW_NO48") != nullptr;   // ablation
+      const bool no96 = getenv("KSLAM_SW_NO96") != nullptr;   // ablation
       T.n = 0;
-      for (int k = 0; k < (lm == 0 ? 4 : 5); k++) {
+      for (int k = 0; k < (lm == 0 ? 5 : 6); k++) {
         const int nd = lm == 0 ? nd0[k] : nd1[k];
-        if (nd == 48 && no48) continue;
+        if ((nd == 48 && no48) || (nd == 96 && no96)) continue;
         T.nd[T.n++] = nd;
       }
     }
@@ -878,7 +879,7 @@ void sw_scores(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, uint32_
     uint32_t h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (debug) {
       read_back(h, counts, sizeof h, s);
-      fprintf(stderr, "[kslam] SW planned: %u / %u / %u / %u / %u\n", h[0], h[1], h[2], h[3], h[4]);
+      fprintf(stderr, "[kslam] SW planned: %u / %u / %u / %u / %u / %u\n", h[0], h[1], h[2], h[3], h[4], h[5]);
     }
     for (int k = 0; k < T.n; k++) {
       // the size of tier k: planned + sent on by the tiers before it (both in counts[k] by now)
@@ -900,6 +901,7 @@ void sw_scores(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, uint32_
       else if (nd == 32) KSLAM_BAND_LM(8, 4, 256);
       else if (nd == 48) KSLAM_BAND_LM(8, 6, 128);
       else if (nd == 64) KSLAM_BAND_LM(8, 8, 128);
+      else if (nd == 96) KSLAM_BAND_LM(16, 6, 256);
       else KSLAM_BAND_LM(16, 8, 256);
 #undef KSLAM_BAND_LM
 #undef KSLAM_BAND

@@ -34,10 +34,34 @@ struct __attribute__((packed, aligned(1))) Bytes16 {
 __device__ inline uint32_t byte_of(const Bytes16 &v, int j) { return (v.w[j >> 2] >> (8 * (j & 3))) & 0xFFu; }
 
 // complement of reverseComplement: A<->T, C<->G, upper case only (src/sequenceTools.h:77-97)
-__device__ inline uint32_t complement(uint32_t c) {
+__host__ __device__ inline uint32_t complement(uint32_t c) {
   const uint32_t at = (c == 'A' || c == 'T') ? (uint32_t)('A' ^ 'T') : 0u;
   const uint32_t cg = (c == 'C' || c == 'G') ? (uint32_t)('C' ^ 'G') : 0u;
   return c ^ at ^ cg;
+}
+
+// What a block keeps in LDS for the walk:
+//   tab[0..99] matchTable, tab[100] = matchTable[0] (a quality character outside 0..99 is flagged and walks
+//   on as 0, as before), tab[101..200] misMatchTable, tab[201] = misMatchTable[0], tab[202] = 0.0 (columns
+//   past the end of a run add nothing: x + 0.0 is x);
+//   lut[0..255] identity, lut[256..511] complement: a lane reads lut[its strand's half + base], so the
+//   complement costs one LDS byte read and no VALU work.
+constexpr uint32_t TAB_MM = 101, TAB_ZERO = 202, TAB_N = 203, Q_CLAMP = 100;
+struct WalkLds {
+  double tab[TAB_N];
+  uint8_t lut[512];
+};
+__device__ inline void fill_walk_lds(WalkLds &S, const double *__restrict__ tables) {
+  for (uint32_t k = threadIdx.x; k < TAB_N; k += blockDim.x) {
+    double v = 0.0;
+    if (k < 100) v = tables[k];
+    else if (k == 100) v = tables[0];
+    else if (k <= 200) v = tables[100 + (k - TAB_MM)];
+    else if (k == 201) v = tables[100];
+    S.tab[k] = v;
+  }
+  for (uint32_t k = threadIdx.x; k < 512; k += blockDim.x) S.lut[k] = (uint8_t)(k < 256 ? k : complement(k - 256));
+  __syncthreads();
 }
 
 struct MdOut {          // the streaming form of SAM.h:204-235 (host: MdWriter in host/tail.cpp)
@@ -50,10 +74,20 @@ struct MdOut {          // the streaming form of SAM.h:204-235 (host: MdWriter i
     n++;
   }
   __device__ void num(uint32_t v) {
-    uint32_t d[10];
-    int k = 0;
-    do { d[k++] = v % 10u; v /= 10u; } while (v);
-    while (k) put('0' + d[--k]);
+    if (v < 1000u) {            // a run of matches is at most a read long: up to three digits, constant divisions
+      const uint32_t h = v / 100u, t = (v - 100u * h) / 10u, u = v - 100u * h - 10u * t;
+      if (v >= 100u) put('0' + h);
+      if (v >= 10u) put('0' + t);
+      put('0' + u);
+      return;
+    }
+    uint32_t p = 1000u;
+    while (v / p >= 10u) p *= 10u;
+    while (p) {
+      put('0' + v / p);
+      v %= p;
+      p /= 10u;
+    }
   }
   __device__ void matches(uint32_t run) {
     if (run) { pending += run; have_pending = true; }
@@ -75,11 +109,12 @@ struct WalkResult {
 
 // flags: 1 = a quality character outside phred+33 0..99 (the host tail rejects the batch when it needs
 // that probability), 2 = the CIGAR runs past the read or the entry (the host tail rejects the batch)
+__device__ inline uint32_t bswap_(uint32_t x) { return __builtin_bswap32(x); }
+
 __device__ inline WalkResult walk_row(const kslam_overlap &o, const uint32_t *__restrict__ pool,
                                       const uint8_t *__restrict__ rbases, const uint8_t *__restrict__ rqual,
                                       const uint64_t *__restrict__ roff, const uint8_t *__restrict__ gbases,
-                                      const uint64_t *__restrict__ goff, const double *__restrict__ tab /*[200] LDS*/,
-                                      uint8_t *md_dst, uint32_t md_cap) {
+                                      const uint64_t *__restrict__ goff, const WalkLds &S, uint8_t *md_dst, uint32_t md_cap) {
   WalkResult res{0.0, 0u, 0u, 0u};
   if (o.cigar_len == 0) return res;
   const uint64_t rb = roff[o.read];
@@ -88,19 +123,61 @@ __device__ inline WalkResult walk_row(const kslam_overlap &o, const uint32_t *__
   const int64_t ref_len = (int64_t)(goff[o.entry + 1] - gb);
   const uint8_t *ref = gbases + gb;
   const bool rc = o.revcomp != 0;
+  const uint8_t *lut = S.lut + (rc ? 256 : 0);
   MdOut w;
   w.dst = md_dst;
   w.cap = md_cap;
   int64_t rp = o.ref_begin, qp = o.query_begin > 0 ? o.query_begin : 0;
   double logp = 0.0;
-  uint32_t nm = 0;
-  for (uint32_t k = 0; k < o.cigar_len; k++) {
-    const uint32_t c = pool[o.cigar_off + k], len = c >> 4, op = c & 15u;
-    if (op == 0) {
-      if (rp < 0 || qp < 0 || rp + (int64_t)len > ref_len || qp + (int64_t)len > L) { res.flags |= 2u; break; }
-      const int64_t at = rc ? L - 1 - qp : qp;         // index of column 0's base in the read
-      uint32_t run = 0;
-      for (uint32_t i0 = 0; i0 < len; i0 += 16) {
+  uint32_t nm = 0, worst = 0;
+  // ONE loop over 16-column chunks for the whole row, whatever CIGAR operation a chunk belongs to: the lanes of
+  // a wave walk different CIGARs, and a loop per operation made the wave run every operation slot's chunk loop
+  // to the longest run any lane has there (~20 chunk rounds per wave for ~10 chunks per row).  A lane that has
+  // used up its M run fetches operations until the next one (I and D are handled on the way).
+  uint32_t k = 0, m_len = 0, i0 = 0, run = 0;
+  int64_t at = 0;
+  for (;;) {
+    if (i0 >= m_len) {
+      bool got = false;
+      while (k < o.cigar_len) {
+        const uint32_t c = pool[o.cigar_off + k], len = c >> 4, op = c & 15u;
+        k++;
+        if (op == 0) {
+          if (rp < 0 || qp < 0 || rp + (int64_t)len > ref_len || qp + (int64_t)len > L) {
+            res.flags |= 2u;
+            k = o.cigar_len;
+            break;
+          }
+          if (len) {
+            at = rc ? L - 1 - qp : qp;         // index of column 0's base in the read
+            run = 0;
+            m_len = len;
+            i0 = 0;
+            got = true;
+            break;
+          }
+        } else if (op == 1) {
+          nm += len;
+          qp += len;
+        } else if (op == 2) {
+          if (rp < 0 || rp + (int64_t)len > ref_len) {
+            res.flags |= 2u;
+            k = o.cigar_len;
+            break;
+          }
+          w.flush();
+          w.put('^');
+          for (uint32_t i = 0; i < len; i++) w.put(ref[rp + i]);
+          w.after_del = true;
+          rp += len;
+          nm += len;
+        }
+      }
+      if (!got) break;
+    }
+    {
+      const uint32_t len = m_len;
+      {
         const uint32_t nn = min(16u, len - i0);
         const Bytes16 R = *reinterpret_cast<const Bytes16 *>(ref + rp + i0);
         // forward: bytes at .. at + 15; reverse: the 16 bytes ENDING at `at - i0`, read back to front
@@ -118,24 +195,30 @@ __device__ inline WalkResult walk_row(const kslam_overlap &o, const uint32_t *__
               Q.w[j >> 2] |= (uint32_t)rqual[first + j] << (8 * (j & 3));
             }
         }
-        // Columns first, branch-free: the mismatch mask of the chunk and the probability chain (its
-        // additions stay in column order).  The MD bookkeeping then runs once per MISMATCH, not once per
-        // column: with 64 alignments per wave some lane mismatches in most columns, and the first
-        // version of this loop took the heavy path (number formatting) for nearly every column.
+        // reverse strand: byte j of the chunk is byte 15 - j of what was loaded
+        {
+          const uint32_t b0 = bswap_(B.w[3]), b1 = bswap_(B.w[2]), b2 = bswap_(B.w[1]), b3 = bswap_(B.w[0]);
+          const uint32_t q0 = bswap_(Q.w[3]), q1 = bswap_(Q.w[2]), q2 = bswap_(Q.w[1]), q3 = bswap_(Q.w[0]);
+          B.w[0] = rc ? b0 : B.w[0]; B.w[1] = rc ? b1 : B.w[1]; B.w[2] = rc ? b2 : B.w[2]; B.w[3] = rc ? b3 : B.w[3];
+          Q.w[0] = rc ? q0 : Q.w[0]; Q.w[1] = rc ? q1 : Q.w[1]; Q.w[2] = rc ? q2 : Q.w[2]; Q.w[3] = rc ? q3 : Q.w[3];
+        }
+        // Columns first, without a branch: every lane runs all 16 columns of the chunk, the ones past the end
+        // of its run add tab[TAB_ZERO] = 0.0 and set no bit (the walk had 66 VALU instructions and 25 scalar
+        // ones per column when the columns were predicated and both strands' byte picks computed).
+        // The probability chain's additions stay in column order.  The MD bookkeeping then runs once per
+        // MISMATCH, not once per column.
         uint32_t miss = 0;
 #pragma unroll
         for (int j = 0; j < 16; j++) {
-          if ((uint32_t)j < nn) {
-            const uint32_t r = byte_of(R, j);
-            const uint32_t qc = rc ? complement(byte_of(B, 15 - j)) : byte_of(B, j);
-            uint32_t q = (rc ? byte_of(Q, 15 - j) : byte_of(Q, j)) - 33u;
-            const bool badq = q >= 100u;
-            res.flags |= badq ? 1u : 0u;
-            q = badq ? 0u : q;
-            const bool mm = r != qc;
-            miss |= (mm ? 1u : 0u) << j;
-            logp += tab[(mm ? 100u : 0u) + q];
-          }
+          const bool valid = (uint32_t)j < nn;
+          const uint32_t r = byte_of(R, j);
+          const uint32_t qc = lut[byte_of(B, j)];
+          const uint32_t qq = min(byte_of(Q, j) - 33u, Q_CLAMP);     // (below 33 wraps around: clamped too)
+          worst = max(worst, valid ? qq : 0u);
+          const bool mm = valid && r != qc;
+          miss |= (mm ? 1u : 0u) << j;
+          const uint32_t idx = valid ? qq + (mm ? TAB_MM : 0u) : TAB_ZERO;
+          logp += S.tab[idx];
         }
         uint32_t from = 0;
         while (miss) {
@@ -151,23 +234,16 @@ __device__ inline WalkResult walk_row(const kslam_overlap &o, const uint32_t *__
         }
         run += nn - from;
       }
-      w.matches(run);
-      rp += len;
-      qp += len;
-    } else if (op == 1) {
-      nm += len;
-      qp += len;
-    } else if (op == 2) {
-      if (rp < 0 || rp + (int64_t)len > ref_len) { res.flags |= 2u; break; }
-      w.flush();
-      w.put('^');
-      for (uint32_t i = 0; i < len; i++) w.put(ref[rp + i]);
-      w.after_del = true;
-      rp += len;
-      nm += len;
+      i0 += 16;
+      if (i0 >= len) {      // the run is done
+        w.matches(run);
+        rp += len;
+        qp += len;
+      }
     }
   }
   w.flush();
+  res.flags |= worst == Q_CLAMP ? 1u : 0u;
   res.logp = logp;
   res.nm = nm;
   res.md_len = w.n;
@@ -181,13 +257,12 @@ __global__ __launch_bounds__(256) void k_row_details(const kslam_overlap *__rest
                                                      const double *__restrict__ tables, kslam_row_detail *__restrict__ out,
                                                      uint32_t *__restrict__ md_lens, uint8_t *__restrict__ slots,
                                                      uint32_t *__restrict__ flags_or) {
-  __shared__ double tab[200];
-  for (uint32_t k = threadIdx.x; k < 200; k += blockDim.x) tab[k] = tables[k];
-  __syncthreads();
+  __shared__ WalkLds S;
+  fill_walk_lds(S, tables);
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const kslam_overlap o = ov[i];
-  const WalkResult r = walk_row(o, pool, rbases, rqual, roff, gbases, goff, tab, slots + i * MD_SLOT, MD_SLOT);
+  const WalkResult r = walk_row(o, pool, rbases, rqual, roff, gbases, goff, S, slots + i * MD_SLOT, MD_SLOT);
   kslam_row_detail d;
   d.logp = r.logp;
   d.md_off = 0;
@@ -207,9 +282,8 @@ __global__ __launch_bounds__(256) void k_md_gather(const kslam_overlap *__restri
                                                    const double *__restrict__ tables, kslam_row_detail *__restrict__ out,
                                                    const uint64_t *__restrict__ md_off, const uint8_t *__restrict__ slots,
                                                    uint8_t *__restrict__ md_pool) {
-  __shared__ double tab[200];
-  for (uint32_t k = threadIdx.x; k < 200; k += blockDim.x) tab[k] = tables[k];
-  __syncthreads();
+  __shared__ WalkLds S;
+  fill_walk_lds(S, tables);
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint32_t len = out[i].md_len;
@@ -220,7 +294,7 @@ __global__ __launch_bounds__(256) void k_md_gather(const kslam_overlap *__restri
     for (uint32_t j = 0; j < len; j++) md_pool[off + j] = src[j];
   } else {   // did not fit its slot: once more, straight into the pool
     const kslam_overlap o = ov[i];
-    (void)walk_row(o, pool, rbases, rqual, roff, gbases, goff, tab, md_pool + off, len);
+    (void)walk_row(o, pool, rbases, rqual, roff, gbases, goff, S, md_pool + off, len);
   }
 }
 

@@ -833,6 +833,8 @@ void lane_main(kslam_ctx *primary, kslam_ctx::AsyncLane *lane) {
     if (st == KSLAM_OK && (job->qcat || job->fastq)) st = kslam_take_row_details(c, &job->det, &job->md, &job->n_md);
     const double t5 = now();
     if (st == KSLAM_OK && primary->pairing.stages) st = kslam_take_pairs(c, &job->rp, &job->n_rp, &job->pr, &job->n_pr);
+    if (dbg) fprintf(stderr, "[kslam]   align phases: extract %.2f sort %.2f join %.2f sw %.2f cigar %.2f total %.2f ms\n", c->tm.ms_extract,
+                     c->tm.ms_sort, c->tm.ms_join, c->tm.ms_sw, c->tm.ms_cigar, c->tm.ms_total);
     if (dbg) fprintf(stderr, "[kslam] t=%.1f lane %p ticket %llu: upload %.2f, token wait %.2f, align %.2f, download %.2f (rows %.2f, details %.2f, pairs %.2f) ms\n",
                      fmod(t0, 100000.0), (void *)lane, (unsigned long long)job->ticket, t1 - t0, t2 - t1, t3 - t2, now() - t3, t4 - t3, t5 - t4, now() - t5);
     {

@@ -249,8 +249,8 @@ typedef struct {
   uint64_t n_pairs;             /* alignment pairs left */
   uint32_t max_insert_size;     /* getMaxAllowedInsertSize; UINT32_MAX when not computed */
   uint32_t stages_done;         /* KSLAM_TAIL_* bits of the stages the device ran: the host tail runs the rest
-                                   (PSEUDO_ASM is left to the host when one entry holds more alignment pairs
-                                   than a workgroup's LDS takes, 4000) */
+                                   (PSEUDO_ASM is left to the host when one entry holds more than 262144
+                                   alignment pairs: one wavefront per entry is the wrong tool there) */
 } kslam_pair_stats;
 kslam_status kslam_pair_screen(kslam_ctx *ctx, int paired, uint32_t score_threshold,
                                double score_fraction, uint32_t stages, kslam_pair_stats *stats);
@@ -263,7 +263,8 @@ kslam_status kslam_pair_screen_overlaps(kslam_ctx *ctx, const kslam_overlap *ove
 kslam_status kslam_take_pairs(kslam_ctx *ctx, kslam_read_pair **read_pairs, uint64_t *n_read_pairs,
                               kslam_paired_overlap **pairs, uint64_t *n_pairs);
 /* Test hook for the sort pseudo-assembly stands on (csrc/wave_gnu_sort.h: libstdc++'s std::sort permutation
- * by one wavefront): segment i = keys[seg_off[i] .. seg_off[i+1]), at most 4000 keys, is sorted ascending by
+ * by one wavefront): segment i = keys[seg_off[i] .. seg_off[i+1]), at most 262144 keys (up to 4000 are sorted
+ * in LDS, longer ones in global memory, as pseudo-assembly does with small and big entries), is sorted ascending by
  * key; perm[seg_off[i] + k] = the index within the segment of the element that ends up k-th. */
 kslam_status kslam_debug_wave_sort(kslam_ctx *ctx, const int32_t *keys, const uint64_t *seg_off,
                                    uint64_t n_seg, uint32_t *perm);

@@ -304,29 +304,34 @@ __global__ __launch_bounds__(256) void k_emit_groups(const Rec *__restrict__ rec
 // added in the SORTED order, and equal starts are common, so the permutation of ties is part of the
 // result: the sort is libstdc++'s, reproduced by one wave per entry with the entry's spans in LDS
 // (wave_gnu_sort.h; ~1 300 spans per entry on the bench workload, all entries at once across the chip).
-struct PSpan {   // host: Span {start, stop, rec} + the record's score (abs(stop - start) is its span)
-  int32_t start, stop;
-  uint32_t rec, score;
+struct PSpan {   // host: Span {start, stop, rec} + the record's score (abs(stop - start) is its span).  The layout
+  uint32_t score;  // is the bucket sort's record {entry, start, stop, rec} with the score in the entry's place,
+  int32_t start, stop;   // so that a big entry can be worked on where the sort left it
+  uint32_t rec;
 };
 struct ByStart {
   __host__ __device__ bool operator()(const PSpan &a, const PSpan &b) const { return a.start < b.start; }
 };
-constexpr uint32_t PSEUDO_CAP = 4000;   // spans per entry that fit the workgroup's LDS (64 000 B)
+constexpr uint32_t PSEUDO_CAP = 4000;         // spans per entry that fit a workgroup's LDS (64 000 B)
+constexpr uint32_t PSEUDO_CAP_GLOBAL = 1u << 18;   // beyond that one wave per entry is the wrong tool: the host runs the stage
 
 __global__ void k_spans(const Rec *__restrict__ recs, const kslam_read_pair *__restrict__ groups, uint64_t n_groups,
                         uint4 *__restrict__ out, uint32_t *__restrict__ max_entry) {
   // one thread per read pair: its records, in order, as {entry, start, stop, rec} (the bucket sort is stable,
   // so the buckets come out in the reference's iteration order)
   const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= n_groups) return;
-  const uint64_t first = groups[g].first, cnt = groups[g].count;
   uint32_t mx = 0;
-  for (uint64_t k = 0; k < cnt; k++) {
-    const Rec r = recs[first + k];
-    out[first + k] = make_uint4(r.entry, (uint32_t)r.ref_start, (uint32_t)r.ref_end, (uint32_t)(first + k));
-    mx = max(mx, r.entry);
+  if (g < n_groups) {
+    const uint64_t first = groups[g].first, cnt = groups[g].count;
+    for (uint64_t k = 0; k < cnt; k++) {
+      const Rec r = recs[first + k];
+      out[first + k] = make_uint4(r.entry, (uint32_t)r.ref_start, (uint32_t)r.ref_end, (uint32_t)(first + k));
+      mx = max(mx, r.entry);
+    }
   }
-  atomicMax(max_entry, mx);
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
+  if ((threadIdx.x & 63) == 0 && mx) atomicMax(max_entry, mx);   // one atomic per wave
 }
 
 __global__ void k_entry_runs(const uint4 *__restrict__ sorted, uint64_t n, uint32_t *__restrict__ flags) {
@@ -355,7 +360,8 @@ __device__ inline uint32_t cvt_u32_like_x86(double d) {
 }
 
 // one chain of an entry's sorted spans: [from, to); host/tail.cpp chain_entry's sums, operation for operation
-__device__ inline void score_chain(const PSpan *v, uint32_t from, uint32_t to, Rec *__restrict__ recs) {
+template <typename P>
+__device__ inline void score_chain(P v, uint32_t from, uint32_t to, Rec *__restrict__ recs) {
 #pragma clang fp contract(off)
   const long len = (long)to - (long)from;
   if (len <= 1) return;
@@ -377,28 +383,16 @@ __device__ inline void score_chain(const PSpan *v, uint32_t from, uint32_t to, R
   for (uint32_t k = from; k < to; k++) recs[v[k].rec & 0x7FFFFFFFu].combined_score = s;
 }
 
-// One wave per entry.  (1) its spans into LDS; (2) std::sort by start, the permutation included, by the
+// One wave per entry.  (1) its spans into LDS -- or, for an entry with more spans than LDS takes, left where
+// the bucket sort put them in global memory (BIG) --; (2) std::sort by start, the permutation included, by the
 // whole wave (wave_gnu_sort.h); (3) chain starts: the reference starts a chain where start > reach - 20 with
 // reach = the highest stop of the chain so far -- and, the starts being sorted, every stop of an earlier
 // chain is below this chain's first start + 20, so reach can be the running maximum over ALL earlier spans:
 // a prefix maximum, 64 spans a step; (4) one lane per chain adds up the chain in order (the chains are
 // independent; the additions inside one are the reference's sequence) and writes the members' new scores.
-__global__ __launch_bounds__(64) void k_pseudo_entry(const uint4 *__restrict__ sorted, const uint32_t *__restrict__ run_start,
-                                                     uint32_t n_runs, uint32_t n, Rec *__restrict__ recs) {
-  extern __shared__ PSpan v[];
-  __shared__ kslam_gnu::WaveSortLds S;
-  const uint32_t r = blockIdx.x, lane = threadIdx.x;
-  const uint32_t lo = run_start[r], cnt = (r + 1 < n_runs ? run_start[r + 1] : n) - lo;
-  for (uint32_t k = lane; k < cnt; k += 64) {
-    const uint4 e = sorted[lo + k];
-    PSpan p;
-    p.start = (int32_t)e.y;
-    p.stop = (int32_t)e.z;
-    p.rec = e.w;
-    p.score = recs[e.w].combined_score;
-    v[k] = p;
-  }
-  __syncthreads();
+template <typename P>
+__device__ inline void pseudo_entry_body(P v, uint32_t cnt, Rec *__restrict__ recs, kslam_gnu::WaveSortLds &S) {
+  const uint32_t lane = threadIdx.x;
   kslam_gnu::wave_sort(v, cnt, ByStart(), S);
   __syncthreads();
   int carry = -1000000;
@@ -425,25 +419,48 @@ __global__ __launch_bounds__(64) void k_pseudo_entry(const uint4 *__restrict__ s
   }
 }
 
-// kslam_debug_wave_sort: segments of keys, sorted by key with wave_sort; out = the permutation (element ids)
+template <bool BIG>
+__global__ __launch_bounds__(64) void k_pseudo_entry(uint4 *__restrict__ sorted, const uint32_t *__restrict__ run_start,
+                                                     uint32_t n_runs, uint32_t n, Rec *__restrict__ recs) {
+  extern __shared__ PSpan v_lds[];
+  __shared__ kslam_gnu::WaveSortLds S;
+  const uint32_t r = blockIdx.x, lane = threadIdx.x;
+  const uint32_t lo = run_start[r], cnt = (r + 1 < n_runs ? run_start[r + 1] : n) - lo;
+  if ((cnt > PSEUDO_CAP) != BIG) return;     // the other launch's entry
+  PSpan *g = reinterpret_cast<PSpan *>(sorted + lo);
+  for (uint32_t k = lane; k < cnt; k += 64) {
+    PSpan p = g[k];                     // {entry, start, stop, rec}
+    p.score = recs[p.rec].combined_score;
+    if (BIG) g[k] = p; else v_lds[k] = p;
+  }
+  __syncthreads();
+  if (BIG) pseudo_entry_body(g, cnt, recs, S);
+  else pseudo_entry_body(v_lds, cnt, recs, S);
+}
+
+// kslam_debug_wave_sort: segments of keys, sorted by key with wave_sort (in LDS up to PSEUDO_CAP keys, in
+// global memory beyond, as k_pseudo_entry does); out = the permutation (element ids)
 __global__ __launch_bounds__(64) void k_debug_wave_sort(const int32_t *__restrict__ keys, const uint64_t *__restrict__ seg_off,
-                                                        uint32_t *__restrict__ perm) {
-  extern __shared__ PSpan v[];
+                                                        uint32_t *__restrict__ perm, PSpan *__restrict__ scratch) {
+  extern __shared__ PSpan v_lds[];
   __shared__ kslam_gnu::WaveSortLds S;
   const uint64_t lo = seg_off[blockIdx.x];
   const uint32_t cnt = (uint32_t)(seg_off[blockIdx.x + 1] - lo);
+  const bool big = cnt > PSEUDO_CAP;
+  PSpan *g = scratch + lo;
   for (uint32_t k = threadIdx.x; k < cnt; k += 64) {
     PSpan p;
     p.start = keys[lo + k];
     p.stop = 0;
     p.rec = k;
     p.score = 0;
-    v[k] = p;
+    if (big) g[k] = p; else v_lds[k] = p;
   }
   __syncthreads();
-  kslam_gnu::wave_sort(v, cnt, ByStart(), S);
+  if (big) kslam_gnu::wave_sort(g, cnt, ByStart(), S);
+  else kslam_gnu::wave_sort(v_lds, cnt, ByStart(), S);
   __syncthreads();
-  for (uint32_t k = threadIdx.x; k < cnt; k += 64) perm[lo + k] = v[k].rec;
+  for (uint32_t k = threadIdx.x; k < cnt; k += 64) perm[lo + k] = big ? g[k].rec : v_lds[k].rec;
 }
 
 // screenPairedAlignmentsByScore once more, in place on the dense records (host/tail.cpp: rescreen_stage)
@@ -469,7 +486,7 @@ __global__ __launch_bounds__(256) void k_rescreen(Rec *__restrict__ recs, kslam_
 bool pseudo_and_rescreen(PairWork &W, PairResult *res, double score_fraction, SortWorkspace &sortws, hipStream_t s) {
   const uint64_t n = res->n_pairs, n_groups = res->n_read_pairs;
   if (n == 0) { res->stages_done |= 4u; return true; }
-  if (n >= (1ull << 31)) return false;
+  if (n >= (1ull << 28)) return false;
   Rec *recs = const_cast<Rec *>(res->d_pairs);
   kslam_read_pair *groups = const_cast<kslam_read_pair *>(res->d_groups);
   W.sort_a.ensure((n + 1) * sizeof(uint4));
@@ -502,9 +519,12 @@ bool pseudo_and_rescreen(PairWork &W, PairResult *res, double score_fraction, So
   hipLaunchKernelGGL(k_run_longest, dim3((n_runs + 255) / 256), dim3(256), 0, s, W.count.as<uint32_t>(), n_runs, (uint32_t)n, d_longest);
   uint32_t longest = 0;
   read_back(&longest, d_longest, sizeof longest, s);
-  if (longest > PSEUDO_CAP) return false;
-  hipLaunchKernelGGL(k_pseudo_entry, dim3(n_runs), dim3(64), (size_t)longest * sizeof(PSpan), s, sorted, W.count.as<uint32_t>(),
-                     n_runs, (uint32_t)n, recs);
+  if (longest > PSEUDO_CAP_GLOBAL) return false;
+  uint4 *work = const_cast<uint4 *>(sorted);
+  hipLaunchKernelGGL(k_pseudo_entry<false>, dim3(n_runs), dim3(64), (size_t)std::min(longest, PSEUDO_CAP) * sizeof(PSpan), s, work,
+                     W.count.as<uint32_t>(), n_runs, (uint32_t)n, recs);
+  if (longest > PSEUDO_CAP)   // entries too big for LDS: the same wave algorithm on the spans where they lie
+    hipLaunchKernelGGL(k_pseudo_entry<true>, dim3(n_runs), dim3(64), 0, s, work, W.count.as<uint32_t>(), n_runs, (uint32_t)n, recs);
   hipLaunchKernelGGL(k_rescreen, dim3((unsigned)((n_groups + 255) / 256)), dim3(256), 0, s, recs, groups, n_groups, score_fraction);
   HIPCHK(hipGetLastError());
   res->stages_done |= 4u;
@@ -516,18 +536,19 @@ void debug_wave_sort(const int32_t *keys, const uint64_t *seg_off, uint64_t n_se
   const uint64_t n = seg_off[n_seg];
   uint32_t longest = 0;
   for (uint64_t i = 0; i < n_seg; i++) {
-    if (seg_off[i + 1] < seg_off[i] || seg_off[i + 1] - seg_off[i] > PSEUDO_CAP)
-      throw StatusError{KSLAM_ERR_ARG, "segments must be ascending and hold at most 4000 keys each"};
+    if (seg_off[i + 1] < seg_off[i] || seg_off[i + 1] - seg_off[i] > PSEUDO_CAP_GLOBAL)
+      throw StatusError{KSLAM_ERR_ARG, "segments must be ascending and hold at most 262144 keys each"};
     longest = std::max<uint32_t>(longest, (uint32_t)(seg_off[i + 1] - seg_off[i]));
   }
-  DevBuf dk, doff, dp;
+  DevBuf dk, doff, dp, dscratch;
+  dscratch.ensure((n + 1) * sizeof(PSpan));
   dk.ensure((n + 1) * sizeof(int32_t));
   doff.ensure((n_seg + 1) * sizeof(uint64_t));
   dp.ensure((n + 1) * sizeof(uint32_t));
   HIPCHK(hipMemcpyAsync(dk.p, keys, n * sizeof(int32_t), hipMemcpyHostToDevice, s));
   HIPCHK(hipMemcpyAsync(doff.p, seg_off, (n_seg + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(k_debug_wave_sort, dim3((unsigned)n_seg), dim3(64), (size_t)longest * sizeof(PSpan), s, dk.as<int32_t>(),
-                     doff.as<uint64_t>(), dp.as<uint32_t>());
+  hipLaunchKernelGGL(k_debug_wave_sort, dim3((unsigned)n_seg), dim3(64), (size_t)std::min(longest, PSEUDO_CAP) * sizeof(PSpan), s,
+                     dk.as<int32_t>(), doff.as<uint64_t>(), dp.as<uint32_t>(), dscratch.as<PSpan>());
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(perm, dp.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));

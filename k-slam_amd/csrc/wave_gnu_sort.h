@@ -31,11 +31,12 @@
 namespace kslam_gnu {
 
 struct WaveSortLds {
-  uint16_t pos_l[64], pos_r[64];
-  uint32_t leaf[64];          // lo | len << 16
-  uint16_t stack_lo[64], stack_hi[64];
+  uint32_t pos_l[64], pos_r[64];
+  uint32_t leaf[64];          // lo | (len - 1) << 28   (len 2..16, lo < 2^28)
+  uint32_t stack_lo[64], stack_hi[64];
   uint8_t stack_depth[64];
 };
+constexpr uint32_t WAVE_SORT_MAX = 1u << 28;   // elements
 
 // __unguarded_partition(a + first, a + last, pivot) by one wave; returns the cut
 template <typename T, typename Less>
@@ -51,8 +52,8 @@ __device__ inline uint32_t wave_partition(T *a, uint32_t first, uint32_t last, c
     if (lane < wr) sr = !less(pivot, a[l - 1 - lane]);       // stops the scan from the right (lane k: k-th from the right)
     const uint64_t ml = __ballot(sl), mr = __ballot(sr);
     const uint32_t cl = __popcll(ml), cr = __popcll(mr), m = min(cl, cr);
-    if (sl) S.pos_l[__popcll(ml & below)] = (uint16_t)(f + lane);
-    if (sr) S.pos_r[__popcll(mr & below)] = (uint16_t)(l - 1 - lane);
+    if (sl) S.pos_l[__popcll(ml & below)] = f + lane;
+    if (sr) S.pos_r[__popcll(mr & below)] = l - 1 - lane;
     __syncthreads();
     if (lane < m) {
       const uint32_t p = S.pos_l[lane], q = S.pos_r[lane];
@@ -84,13 +85,14 @@ __device__ inline void wave_sort_flush_leaves(T *a, uint32_t n_leaves, Less less
   __syncthreads();
   const uint32_t lane = threadIdx.x & 63;
   if (lane < n_leaves) {
-    const uint32_t lo = S.leaf[lane] & 0xFFFFu, len = S.leaf[lane] >> 16;
+    const uint32_t lo = S.leaf[lane] & 0x0FFFFFFFu, len = (S.leaf[lane] >> 28) + 1;
     insertion_sort(a + lo, a + lo + len, less);
   }
   __syncthreads();
 }
 
-// std::sort(a, a + n, less) for n < 65536 elements in LDS
+// std::sort(a, a + n, less) for n < WAVE_SORT_MAX elements in LDS, or in global memory (the array's home
+// decides the instructions after inlining; the barriers order one wave's accesses either way)
 template <typename T, typename Less>
 __device__ inline void wave_sort(T *a, uint32_t n, Less less, WaveSortLds &S) {
   if (n < 2) return;
@@ -100,7 +102,7 @@ __device__ inline void wave_sort(T *a, uint32_t n, Less less, WaveSortLds &S) {
   uint32_t sp = 0, n_leaves = 0;
   auto add_leaf = [&](uint32_t lo, uint32_t hi) {
     if (hi - lo < 2) return;
-    if (lane == 0) S.leaf[n_leaves] = lo | ((hi - lo) << 16);
+    if (lane == 0) S.leaf[n_leaves] = lo | ((hi - lo - 1) << 28);
     if (++n_leaves == 64) {
       wave_sort_flush_leaves(a, 64, less, S);
       n_leaves = 0;
@@ -126,8 +128,8 @@ __device__ inline void wave_sort(T *a, uint32_t n, Less less, WaveSortLds &S) {
       const uint32_t cut = wave_partition(a, lo + 1, hi, pivot, less, S);
       if (hi - cut > 16) {
         if (lane == 0) {
-          S.stack_lo[sp] = (uint16_t)cut;
-          S.stack_hi[sp] = (uint16_t)hi;
+          S.stack_lo[sp] = cut;
+          S.stack_hi[sp] = hi;
           S.stack_depth[sp] = (uint8_t)depth;
         }
         sp++;

@@ -63,7 +63,7 @@ def test_device_pairing_and_screens_equal_the_host_tail(kslam, T, ctx, seed, pai
 def test_wave_sort_produces_the_std_sort_permutation(kslam, ctx, tmp_path):
     """csrc/wave_gnu_sort.h (std::sort by one wavefront: parallel Hoare partition, per-leaf insertion sorts)
     against the real std::sort of this toolchain on ~3 000 arrays: every size from 0 to 300, sizes up to the
-    4000-element limit, few / many distinct keys, sorted / reversed / organ-pipe / all-equal / median-of-three
+    4000 elements that are sorted in LDS, a dozen up to 262 144 that are sorted in global memory, few / many distinct keys, sorted / reversed / organ-pipe / all-equal / median-of-three
     killer inputs (the last drives std::sort into its heap-sort fallback)"""
     import shutil
     import subprocess
@@ -75,6 +75,7 @@ def test_wave_sort_produces_the_std_sort_permutation(kslam, ctx, tmp_path):
     rng = np.random.default_rng(5)
     segs = []
     sizes = list(range(0, 301)) * 4 + [int(x) for x in rng.integers(300, 4001, 1500)] + [4000] * 8 + [17, 33, 64, 65, 127, 128, 129]
+    sizes += [4001, 4002, 5000, 8191, 8192, 20000, 20001, 65535, 65536, 65537, 100000, 262144]   # sorted in global memory
     for i, n in enumerate(sizes):
         distinct = [1, 2, 3, 20, 100000][i % 5]
         k = rng.integers(0, distinct, n).astype(np.int32)
@@ -87,7 +88,7 @@ def test_wave_sort_produces_the_std_sort_permutation(kslam, ctx, tmp_path):
             k.sort()
             k[n // 2:] = k[n // 2:][::-1]
         segs.append(k)
-    for n in (17, 33, 64, 100, 257, 1000, 4000):      # Musser's median-of-three killer
+    for n in (17, 33, 64, 100, 257, 1000, 4000, 30000):      # Musser's median-of-three killer
         v = np.zeros(n, dtype=np.int32)
         h = n // 2
         for i in range(1, h + 1):
@@ -126,12 +127,13 @@ def _compacted(rp, pr):
 
 @pytest.mark.parametrize("seed,paired,thr,frac,per_read,n_entries,expect_device", [
     (21, True, 0, 0.95, 3.0, 12, True), (22, True, 150, 0.8, 3.0, 12, True), (23, False, 0, 0.95, 3.0, 12, True),
-    (24, True, 0, 0.95, 3.0, 300, True), (25, True, 0, 0.5, 12.0, 40, True), (26, True, 0, 0.95, 12.0, 2, False),
-    (27, True, 0, 1.0, 3.0, 7, True)])
+    (24, True, 0, 0.95, 3.0, 300, True), (25, True, 0, 0.5, 12.0, 40, True), (26, True, 0, 0.95, 12.0, 2, True),
+    (27, True, 0, 1.0, 3.0, 7, True), (28, True, 0, 0.3, 60.0, 1, False)])
 def test_device_pseudo_assembly_equals_the_host_tail(kslam, T, ctx, seed, paired, thr, frac, per_read, n_entries, expect_device):
     """pseudoAssembly + the second score screen on the device (stages = 7): chains of overlapping alignments
     per entry, scores from double sums in std::sort's order of equal starts -> the host tail's records, byte
-    for byte; an entry too big for one workgroup's LDS leaves the stage to the host, and says so"""
+    for byte; entries too big for a workgroup's LDS (seed 26: ~20 k spans each) are sorted in global memory; an
+    entry beyond 262 144 spans (seed 28) leaves the stage to the host, and says so"""
     from test_tail import _fuzz_overlaps
     rng = np.random.default_rng(100 + seed)
     ov, n_reads = _fuzz_overlaps(kslam, rng, 3000, n_entries, per_read=per_read, paired=paired)

@@ -851,7 +851,8 @@ void sw_scores(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, uint32_
     // them end up needing more than 32 diagonals, so starting them at 48 (3.1 us) is cheaper than 32
     // first (2.25 us) and 48 again for most.
     {
-      const int unk = getenv("KSLAM_SW_UNKNOWN_ND") ? atoi(getenv("KSLAM_SW_UNKNOWN_ND")) : 48;
+      // (reads of 161-256 bases: 64 -- 83.2 against 85.0 ms per 1 M pairs of 250 bp, 89.5 when started at 32)
+      const int unk = getenv("KSLAM_SW_UNKNOWN_ND") ? atoi(getenv("KSLAM_SW_UNKNOWN_ND")) : (lm == 0 ? 48 : 64);
       T.unknown = 1;
       for (int k = 0; k < T.n; k++) if (T.nd[k] <= unk) T.unknown = k;
     }

@@ -81,6 +81,9 @@ struct CigJob {
   uint32_t *next_list = nullptr, *next_count = nullptr;         // band doubled: the next class
   uint32_t *special_list = nullptr, *special_count = nullptr;   // handed back by the systolic kernel
   uint32_t *big_count = nullptr;                                // cigar longer than the small temp slot
+  // systolic kernels: list positions whose attempt reached the score, for k_systolic_traceback (nullptr: the
+  // group's lane 0 walks the traceback itself, at the end of the DP kernel)
+  uint32_t *tb_list = nullptr, *tb_count = nullptr;
 };
 
 // wave-aggregated append of candidate ci to a list (one atomic per wave)
@@ -365,6 +368,50 @@ __global__ __launch_bounds__(64) void k_banded_lds(CigJob J, SwInputs in, SwPara
   J.needbig[ci] = J.big ? 2 : 0;  // 2: ops live in the big temp area
 }
 
+// traceback of one candidate from the direction words a systolic attempt left in its slab
+template <int GL, int DPL>
+__device__ inline void systolic_traceback(const CigJob &J, uint32_t li, uint32_t ci, kslam_overlap o, int32_t bw,
+                                          int32_t refLen, int32_t readLen, const uint32_t *D) {
+  const int32_t k0 = (bw & 1) ? -1 : 0;
+  struct Acc {
+    const uint32_t *D;
+    int32_t bw, k0;
+    uint32_t have_idx, have_word;   // the word fetched last: a diagonal run reuses it
+    __device__ uint32_t get_dir(int32_t i, int32_t col) {
+      const int32_t j = col + (i - bw > 0 ? i - bw : 0);
+      const int32_t x = j - i + bw;
+      const int32_t tt = x / DPL, q = x - tt * DPL;
+      const uint32_t n = (uint32_t)((i + j - k0 - (q & 1)) >> 1);
+      const uint32_t m = n / 6u, r = n - 6u * m;
+      const uint32_t idx = (m * GL + (uint32_t)tt) * DPL + (uint32_t)q;
+      if (idx != have_idx) {
+        have_idx = idx;
+        have_word = D[idx];
+      }
+      return (have_word >> (5u * r)) & 31u;
+    }
+  } A{D, bw, k0, 0xFFFFFFFFu, 0u};
+  uint32_t *tmp = J.tmp + (uint64_t)(J.big ? (J.list_base + li) : ci) * J.cap;
+  bool ovf = false;
+  const int32_t l = banded_traceback(A, refLen, readLen, bw, tmp, J.cap, &ovf);
+  if (l < 0) {
+    atomicAdd(&J.err[0], 1u);
+    o.cigar_len = 0;
+    J.ov[ci] = o;
+    J.bw[ci] = 0;
+    return;
+  }
+  if (ovf) {
+    J.needbig[ci] = 1;  // rerun with a full-size temp slot
+    if (J.big_count) atomicAdd(J.big_count, 1u);
+    return;
+  }
+  o.cigar_len = (uint32_t)l;
+  J.ov[ci] = o;
+  J.bw[ci] = 0;
+  J.needbig[ci] = J.big ? 2 : 0;  // 2: ops live in the big temp area
+}
+
 // ---- systolic banded attempt ----------------------------------------------------------------------
 // The same recurrence as banded_attempt (ssw.c:645-693), but a candidate is spread over GL lanes the
 // way the scoring kernels are: lane t owns DPL adjacent diagonals d = j - i of the band
@@ -541,43 +588,27 @@ __global__ __launch_bounds__(BS) void k_cigar_systolic(CigJob J, SwInputs in, Sw
     if (J.next_list) append_candidate(true, ci, J.next_list, J.next_count);
     return;
   }
-  struct Acc {
-    const uint32_t *D;
-    int32_t bw, k0;
-    uint32_t have_idx, have_word;   // the word fetched last: a diagonal run reuses it
-    __device__ uint32_t get_dir(int32_t i, int32_t col) {
-      const int32_t j = col + (i - bw > 0 ? i - bw : 0);
-      const int32_t x = j - i + bw;
-      const int32_t tt = x / DPL, q = x - tt * DPL;
-      const uint32_t n = (uint32_t)((i + j - k0 - (q & 1)) >> 1);
-      const uint32_t m = n / 6u, r = n - 6u * m;
-      const uint32_t idx = (m * GL + (uint32_t)tt) * DPL + (uint32_t)q;
-      if (idx != have_idx) {
-        have_idx = idx;
-        have_word = D[idx];
-      }
-      return (have_word >> (5u * r)) & 31u;
-    }
-  } A{D, bw, k0, 0xFFFFFFFFu, 0u};
-  uint32_t *tmp = J.tmp + (uint64_t)(J.big ? (J.list_base + li) : ci) * J.cap;
-  bool ovf = false;
-  const int32_t l = banded_traceback(A, refLen, readLen, bw, tmp, J.cap, &ovf);
-  if (l < 0) {
-    atomicAdd(&J.err[0], 1u);
-    o.cigar_len = 0;
-    J.ov[ci] = o;
-    J.bw[ci] = 0;
+  if (J.tb_list) {   // the walk is a chain of dependent loads: it runs in its own kernel, 64 candidates to the wave
+    append_candidate(true, li, J.tb_list, J.tb_count);
     return;
   }
-  if (ovf) {
-    J.needbig[ci] = 1;  // rerun with a full-size temp slot
-    if (J.big_count) atomicAdd(J.big_count, 1u);
-    return;
-  }
-  o.cigar_len = (uint32_t)l;
-  J.ov[ci] = o;
-  J.bw[ci] = 0;
-  J.needbig[ci] = J.big ? 2 : 0;  // 2: ops live in the big temp area
+  systolic_traceback<GL, DPL>(J, li, ci, o, bw, refLen, readLen, D);
+}
+
+// The tracebacks of a systolic launch, one candidate per LANE.  At the end of the DP kernel only lane 0 of a
+// group of 8 or 16 walked -- a chain of ~28 dependent loads per candidate with an eighth of the wave's lanes
+// busy, which was ~40 % of those kernels' time; here a wave has 64 walks in flight.
+template <int GL, int DPL>
+__global__ __launch_bounds__(256) void k_systolic_traceback(CigJob J) {
+  const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= *J.tb_count) return;
+  const uint32_t li = J.tb_list[x];
+  const uint32_t ci = J.list[J.list_base + li];
+  kslam_overlap o = J.ov[ci];
+  const int32_t bw = (int32_t)J.bw[ci];
+  const int32_t refLen = o.ref_end - o.ref_begin + 1, readLen = o.query_end - o.query_begin + 1;
+  const uint32_t *D = reinterpret_cast<const uint32_t *>(J.scratch) + (uint64_t)li * (J.wave_slab / 4);
+  systolic_traceback<GL, DPL>(J, li, ci, o, bw, refLen, readLen, D);
 }
 
 __global__ void k_cigar_lens(const kslam_overlap *__restrict__ ov, uint64_t n, uint32_t *__restrict__ lens) {
@@ -669,6 +700,8 @@ void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, u
   HIPCHK(hipMemsetAsync(d_tot, 0, 4 * sizeof(uint64_t), s));
   const uint32_t cap_big = 2 * lmax + 4;
   if (p.report_cigar) {
+    W.counters.ensure(16 * sizeof(uint32_t));
+    uint32_t *cnt = W.counters.as<uint32_t>();   // [0..7] class list sizes, [8] handed back, [9] long cigars, [10] tracebacks of a systolic launch
     auto run_lists = [&](uint32_t cls, uint32_t mode) -> uint64_t {   // mode: 0 class, 1 big rerun, 2 handed back
       hipLaunchKernelGGL(k_class_flags, dim3(nb), dim3(256), 0, s, d_bw, W.needbig.as<uint8_t>(), n, cls,
                          mode, W.flags.as<uint32_t>());
@@ -724,8 +757,18 @@ void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, u
         J.err = d_err;
         { const char *cv = getenv("KSLAM_CIGAR_VARIANT"); J.variant = cv ? (uint32_t)atoi(cv) : 0u; }
         const unsigned nb = (unsigned)((J.m + NG - 1) / NG);
+        // the tracebacks of this launch in a kernel of their own (KSLAM_CIGAR_TB=inline: at the end of the DP kernel)
+        const bool tb_inline = getenv("KSLAM_CIGAR_TB") && getenv("KSLAM_CIGAR_TB")[0] == 'i';
+        if (!tb_inline) {
+          W.tb_list.ensure(((uint64_t)J.m + 1) * sizeof(uint32_t));
+          J.tb_list = W.tb_list.as<uint32_t>();
+          J.tb_count = cnt + 10;
+          HIPCHK(hipMemsetAsync(J.tb_count, 0, sizeof(uint32_t), s));
+        }
+        const unsigned nb_tb = (unsigned)(((uint64_t)J.m + 255) / 256);
 #define KSLAM_SYS(LMV, GLV, DPLV) \
-  hipLaunchKernelGGL((k_cigar_systolic<LMV, GLV, DPLV, 128>), dim3(nb), dim3(128), 0, s, J, in, p)
+  do { hipLaunchKernelGGL((k_cigar_systolic<LMV, GLV, DPLV, 128>), dim3(nb), dim3(128), 0, s, J, in, p); \
+       if (J.tb_list) hipLaunchKernelGGL((k_systolic_traceback<GLV, DPLV>), dim3(nb_tb), dim3(256), 0, s, J); } while (0)
 #define KSLAM_SYS_LM(GLV, DPLV) \
   do { if (lm == 0) KSLAM_SYS(160, GLV, DPLV); else if (lm == 1) KSLAM_SYS(256, GLV, DPLV); else KSLAM_SYS(512, GLV, DPLV); } while (0)
         if (GL == 16 && DPL == 16) KSLAM_SYS_LM(16, 16);
@@ -802,8 +845,6 @@ void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, u
     W.cls.ensure(n);
     for (int k = 0; k < 8; k++) W.cls_list[k].ensure((n + 1) * sizeof(uint32_t));
     W.special.ensure((n + 1) * sizeof(uint32_t));
-    W.counters.ensure(16 * sizeof(uint32_t));
-    uint32_t *cnt = W.counters.as<uint32_t>();   // [0..7] class list sizes, [8] handed back, [9] long cigars
     HIPCHK(hipMemsetAsync(cnt, 0, 16 * sizeof(uint32_t), s));
     hipLaunchKernelGGL(k_cig_class, dim3(nb), dim3(256), 0, s, d_bw, n, W.cls.as<uint8_t>());
     uint32_t *lists[8];

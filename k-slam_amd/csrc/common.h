@@ -243,7 +243,7 @@ void partition_bins(const uint8_t *d_bins, uint64_t n, uint32_t *const d_lists[8
 // --------------------------------------------------------------- cigar.hip
 struct CigarWork {
   DevBuf flags, pos, list, bmax, needbig, scan_tmp, totals, cig_off, tmp, tmp_big, big_pos, scratch, cls, cls_list[8],
-      special, counters;
+      special, counters, tb_list;
 };
 constexpr uint32_t CIG_CAP = 24;  // ops per small temp cigar slot
 // allocates and clears the per-candidate cigar state; call before sw_scores

@@ -497,8 +497,11 @@ def test_every_kernel_variant_gives_the_same_alignments(kslam, synth, monkeypatc
                 {"KSLAM_CIGAR_SYS": "255"},                          # systolic for every band class
                 {"KSLAM_CIGAR_SYS": "0"},                            # registers for narrow, one-lane for wide
                 {"KSLAM_CIGAR_DIRS": "lds", "KSLAM_CIGAR_SYS": "0", "KSLAM_CIGAR_REG": "0"},
+                {"KSLAM_CIGAR_TB": "inline"},                        # systolic tracebacks at the end of the DP kernel
+                {"KSLAM_CIGAR_TB": "inline", "KSLAM_CIGAR_SYS": "255"},
                 {"KSLAM_SW_FULL": "1"},                              # full-matrix scores only
-                {"KSLAM_SW_NO48": "1"},                              # tiers 16 / 32 / 64
+                {"KSLAM_SW_NO48": "1"},                              # tiers 16 / 32 / 64 / 96
+                {"KSLAM_SW_NO96": "1"},                              # no 96-diagonal tier
                 {"KSLAM_SW_UNKNOWN_ND": "16"},                       # gapped candidates start at the narrowest band
                 {"KSLAM_SW_UNKNOWN_ND": "64"}]
     for env in variants:

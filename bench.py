@@ -482,15 +482,23 @@ def main():
                 # now HOLDS the batch-global result in the reference's order, and ran no kernel for it
                 merged["ov"], merged["cg"] = got
 
+    split = {"align": 0.0, "wait_for_previous_gather": 0.0, "counts_export_post": 0.0}   # host clock, this rank, timed steps
+
     def step():
+        ta = time.perf_counter()
         n_out, n_cig = ctx.align_resident()
+        tb = time.perf_counter()
+        split["align"] += tb - ta
         if use_dist and strong:
             # the one exchange of the path (point-to-point over xGMI): count exchange, every rank re-bases
             # its own records on its own GPU, four sends per rank into their final places on rank 0.  The
             # transfer of batch k overlaps the alignment of batch k + 1; it is waited for before the next
             # one starts and before the clock stops.
             drain()
+            tc = time.perf_counter()
             pending.append(kdist.start_gather_sharded(ctx, n_reads // 2, pair_lo, args.total_pairs, dev))
+            split["wait_for_previous_gather"] += tc - tb
+            split["counts_export_post"] += time.perf_counter() - tc
         elif use_dist:
             ov = torch.empty(n_out * 48, dtype=torch.uint8, device=dev)
             cg = torch.empty(n_cig * 4, dtype=torch.uint8, device=dev)
@@ -509,6 +517,8 @@ def main():
     for _ in range(args.warmup):
         step()
     acc = {}
+    for k in split:
+        split[k] = 0.0
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -518,9 +528,10 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if use_dist:
-        te = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+        te = torch.tensor([elapsed] + [split[k] for k in sorted(split)], dtype=torch.float64, device=cdev)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te.item())
+        elapsed = float(te[0].item())
+        split_max = {k: float(v) for k, v in zip(sorted(split), te[1:].tolist())}     # slowest rank per part
 
     # ---- outside the timed region: is what was just timed RIGHT?  (no oracle here: the generator's
     # own ground truth, the reference's structural expectations of src/Tests.h:161-264, :321-330) ----
@@ -651,6 +662,12 @@ def main():
             "setup_s": {"generate": round(t_gen, 2), "index_build": round(t_index, 2)},
             "verified": verified,
         }
+        if use_dist and strong:
+            # where a step's time goes on the host clock (per step; max over ranks, and rank 0 = the collecting rank):
+            # the align call, the wait for the previous batch's gather to land, and count exchange + export + posting
+            out["strong_step_split_ms"] = {
+                "max_over_ranks": {k: round(v / S * 1e3, 3) for k, v in split_max.items()},
+                "rank0": {k: round(v / S * 1e3, 3) for k, v in split.items()}}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(K, db, offs, 77, args.cpu_genomes, args.cpu_pairs, args.read_len, local_rank)
         if world == 1 and not strong and not args.no_abi_path:

@@ -223,3 +223,36 @@ def test_alignment_to_sam_with_the_tail_front_on_the_gpu(kslam, oracle, synth, T
     assert c.last_pairs is None
     release()
     c.close()
+
+
+def test_round2_entry_points_refuse_misuse_loudly(kslam, synth):
+    """state and argument errors of the entry points added this round: a status code and a message, never a
+    crash or a silent default (the reference's tail throws / aborts on the same conditions)"""
+    c = kslam.Context()
+    with pytest.raises(kslam.KslamError, match="no batch loaded|STATE"):
+        c.pair_screen(paired=True)                                  # nothing aligned yet
+    with pytest.raises(kslam.KslamError, match="kslam_pair_screen has not been called|STATE"):
+        c.take_pairs()
+    genomes = synth.make_genomes(5, 1, 1, 5000)
+    reads, _ = synth.make_paired_reads(6, genomes, 11, read_len=100, frag_mean=250, frag_sd=20)
+    rb = synth.to_bytes(reads)
+    c.set_index(synth.to_bytes(genomes))
+    c.load_reads(rb[:21])                                           # an odd number of reads
+    c.align_resident()
+    with pytest.raises(kslam.KslamError, match="even, non-zero number of reads"):
+        c.pair_screen(paired=True)
+    st = c.pair_screen(paired=False, stages=7)                      # single-end: fine, insert screen not applicable
+    assert st["stages_done"] == 6
+    ov = np.zeros(3, dtype=kslam.OVERLAP_DT)
+    with pytest.raises(kslam.KslamError, match="even, non-zero number of reads"):
+        c.pair_screen_overlaps(ov, np.full(3, 100, dtype=np.uint32), paired=True)
+    # the sort hook: descending segment bounds, a segment over the limit
+    with pytest.raises(kslam.KslamError, match="segments must be ascending"):
+        c.debug_wave_sort(np.zeros(10, dtype=np.int32), np.array([0, 8, 4, 10], dtype=np.uint64))
+    with pytest.raises(kslam.KslamError, match="segments must be ascending and hold at most"):
+        c.debug_wave_sort(np.zeros(300000, dtype=np.int32), np.array([0, 300000], dtype=np.uint64))
+    assert len(c.debug_wave_sort(np.zeros(0, dtype=np.int32), np.array([0], dtype=np.uint64))) == 0
+    # a ticket that was never issued, a ticket collected twice
+    with pytest.raises(kslam.KslamError):
+        c.collect_batch(12345)
+    c.close()

@@ -618,6 +618,24 @@ def main():
             except Exception:
                 traffic = None
         sort_bytes = n_sorted * 16 * (2 * passes + 1)
+        # the SW phase against the VALU issue rate: instruction count of the phase's kernels per alignment call from the
+        # committed counter run of this same workload (tools/pmc_valu.sh -> profiles/sw_valu.json), time measured live
+        sw_valu = None
+        vpath = os.path.join(ROOT, "profiles", "sw_valu.json")
+        if os.path.exists(vpath) and args.read_len == READ_LEN and not strong and args.pairs == 1_000_000 and tm["ms_sw"] > 0:
+            try:
+                vj = json.load(open(vpath))
+                instr = float(vj["sw_phase_per_align"]["valu_wave_instr"])
+                rate = instr / (tm["ms_sw"] * 1e-3) / 1e9
+                sw_valu = {"bound": "valu-issue", "kernels": "k_sw_plan + k_sw_band<...> tiers + k_sw (the SW phase, 61 % of the step)",
+                           "achieved": round(rate, 1), "peak": 1228.8, "unit": "G wave-instr/s", "frac": round(rate / 1228.8, 4),
+                           "sustained_for_4_cycle_kinds": 575.0, "sustained_for_2_cycle_kinds": 1084.0,
+                           "valu_wave_instr_per_step": int(instr), "ms": round(tm["ms_sw"], 3),
+                           "note": "peak = 256 CUs x 4 SIMD x 2.4 GHz / 2 cycles; the sweeps' instruction mix is mostly 4-cycle kinds "
+                                   "(v_max_i32, VOP3, DPP, v_max_f64: tools/valu_peak.hip, profiles/r01g_valu_peak.txt), whose sustained "
+                                   "rate is the realistic ceiling; instruction count from profiles/sw_valu.json (PMC, separate run)"}
+            except Exception:
+                sw_valu = None
         out = {
             "metric": "paired %dbp reads/sec classified (bit-exact SAM)" % args.read_len,
             "value": round(total_reads / elapsed, 1),
@@ -652,6 +670,7 @@ def main():
                 # sustained on a bench box (tools/copy_peak.hip, profiles/r01h_copy_peak.txt)
                 "streaming_copy_ceiling": {"GB/s": 5590.0, "measured": "profiles/r01h_copy_peak.txt"},
             },
+            "roofline_valu": sw_valu,
             "phases_ms": {k: round(tm[k], 3) for k in ("ms_extract", "ms_sort", "ms_join", "ms_sw",
                                                          "ms_cigar", "ms_total")},
             "counts": {"read_kmers": int(n_kmers), "read_kmers_kept_by_filter": int(tm["n_kmers_kept"]),

@@ -116,6 +116,28 @@ __device__ inline void line_span(const FqStream &s, uint64_t l, uint64_t *start,
   }
 }
 
+// first k in [0, n) with h[k] == c, or n: 16 bytes a step (one unaligned load), equal bytes found with the exact
+// zero-byte test on h ^ cccc.  Reads up to 15 bytes past h + n: the text buffer has 64 spare bytes after its end.
+struct __attribute__((packed, aligned(1))) FqBytes16 {
+  uint32_t w[4];
+};
+__device__ inline uint64_t find_byte(const uint8_t *h, uint64_t n, uint32_t c) {
+  const uint32_t pat = c * 0x01010101u;
+  for (uint64_t k0 = 0; k0 < n; k0 += 16) {
+    const FqBytes16 v = *reinterpret_cast<const FqBytes16 *>(h + k0);
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+      const uint32_t t = v.w[w] ^ pat;
+      const uint32_t z = ~(((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t | 0x7F7F7F7Fu);   // 0x80 in the bytes that are equal
+      if (z) {
+        const uint64_t k = k0 + 4u * (uint32_t)w + ((uint32_t)__builtin_ctz(z) >> 3);
+        return k < n ? k : n;
+      }
+    }
+  }
+  return n;
+}
+
 __global__ __launch_bounds__(256) void k_fq_fields(FqStream s, uint64_t *__restrict__ bases_at, uint64_t *__restrict__ quality_at,
                                                    uint32_t *__restrict__ blen, uint64_t *__restrict__ id_at,
                                                    uint32_t *__restrict__ id_len, uint64_t *__restrict__ misc /*[0] after_quality of the last record, [1] error flags*/) {
@@ -129,14 +151,10 @@ __global__ __launch_bounds__(256) void k_fq_fields(FqStream s, uint64_t *__restr
   if (b - a > 1) {
     const uint8_t *h = s.text + a;
     const uint64_t flen = b - a;
-    uint64_t end = flen;
-    for (uint64_t k = 0; k < flen; k++)
-      if (h[k] == ' ') { end = k == 0 ? 1 : k; break; }
+    const uint64_t sp = find_byte(h, flen, ' ');
+    const uint64_t end = sp == flen ? flen : (sp == 0 ? 1 : sp);
     istart = a + 1;
-    uint64_t nn = end - 1;
-    for (uint64_t k = 0; k < nn; k++)
-      if (h[1 + k] == '/') { nn = k; break; }
-    ilen = (uint32_t)nn;
+    ilen = (uint32_t)find_byte(h + 1, end - 1, '/');
   }
   line_span(s, 4 * r + 1, &a, &b, &nx);
   const uint64_t bs = a, bl = b - a;

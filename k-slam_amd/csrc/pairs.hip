@@ -352,11 +352,10 @@ __global__ void k_entry_runs(const uint4 *__restrict__ sorted, uint64_t n, uint3
   if (i < n) flags[i] = (i == 0 || sorted[i].x != sorted[i - 1].x) ? 1u : 0u;
 }
 __global__ void k_run_starts(const uint32_t *__restrict__ flags, const uint32_t *__restrict__ pos, uint64_t n,
-                             uint32_t *__restrict__ run_start, uint32_t *__restrict__ longest) {
+                             uint32_t *__restrict__ run_start) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n || !flags[i]) return;
   run_start[pos[i]] = (uint32_t)i;
-  (void)longest;
 }
 __global__ void k_run_longest(const uint32_t *__restrict__ run_start, uint32_t n_runs, uint32_t n, uint32_t *__restrict__ longest) {
   const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -528,7 +527,7 @@ bool pseudo_and_rescreen(PairWork &W, PairResult *res, double score_fraction, So
   read_back(&n_runs64, tot + 14, sizeof n_runs64, s);
   const uint32_t n_runs = (uint32_t)n_runs64;
   hipLaunchKernelGGL(k_run_starts, dim3(nb), dim3(256), 0, s, W.flags.as<uint32_t>(), W.gpos.as<uint32_t>(), n,
-                     W.count.as<uint32_t>(), d_longest);
+                     W.count.as<uint32_t>());
   hipLaunchKernelGGL(k_run_longest, dim3((n_runs + 255) / 256), dim3(256), 0, s, W.count.as<uint32_t>(), n_runs, (uint32_t)n, d_longest);
   uint32_t longest = 0;
   read_back(&longest, d_longest, sizeof longest, s);

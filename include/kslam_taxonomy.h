@@ -18,9 +18,10 @@
  *   combineTaxonomies + sortResults + writeAbbreviatedResultsFile (read counts
  *   per taxon)                               src/MetagenomicResults.h:149-177, 237-274
  *
- * Not replaced: the XML report (writeResults / getXML, src/MetagenomicResults.h:
- * 213-224, 302-366), which lists every gene hit with fields the database builder
- * stores (locus tag, GeneID, reference sequence) -- see DESIGN.md section 7.
+ *   the gene list of getResultFromPairedOverlaps (:88-112), combineTaxonomies /
+ *   combineRangeOfIdentifiedTaxonomy with their genes and reads (:118-177),
+ *   sortResults (:254-273), correctXML / getXML / writeResults (:213-224, 275-366)
+ *   -- the XML report: kslam_taxreport_* below
  *
  * The reference walks hash-map lookups up the tree and compares root-ward paths
  * level by level; here the tree is a dense parent/depth array and the LCA of a
@@ -76,6 +77,43 @@ kslam_status kslam_tail_classify(const kslam_tail_params *params, const kslam_re
  * kept here (it only matters for which record that quirk drops). */
 kslam_status kslam_taxonomy_summary(const kslam_taxdb *db, const uint32_t *tax_ids, uint64_t n,
                                     uint64_t num_reads, char **text, uint64_t *text_len);
+
+/* ---- the XML report (writeResults, src/MetagenomicResults.h:213-224) -------------------------
+ * A report object collects one IdentifiedTaxonomy per read pair over the batches of a run
+ * (src/SLAM.h:244-248) and renders the report at the end (src/SLAM.h:257-265).  The gene fields the
+ * report prints beyond kslam_index_view come from the database columns (include/kslam_db.h); every
+ * pointer may be NULL (empty strings / GeneID 0).  `index` must be the same index in every call.
+ *
+ * As in the reference: per read pair the best-overlapping gene (GenbankEntry::getGene,
+ * src/GenbankTools.h:170-185) of every alignment pair, std::sort by geneSort + std::unique
+ * (operator==: the surviving representative is the one libstdc++'s sort puts first); per taxon the
+ * genes of all its read pairs, sorted and merged with counts, reads sorted by name; taxa by
+ * (reads descending, id ascending); abundance = reads * 100.0 / num_reads printed with
+ * std::to_string (six decimals).  combineTaxonomies' bookkeeping quirk is kept (without an
+ * unclassified read pair the first record of the lowest id is dropped, :159-175).  The reference orders
+ * records of equal taxonomy id with an unstable PARALLEL sort, so which of several equal genes
+ * represents its class there depends on the thread count; here the records keep their input order. */
+typedef struct kslam_taxreport kslam_taxreport;
+typedef struct {
+  const char *gene_locus_tag;      /* Gene::locusTag, by gene */
+  const uint64_t *gene_locus_tag_off;
+  const char *gene_reference;      /* Gene::referenceSequence */
+  const uint64_t *gene_reference_off;
+  const uint32_t *gene_id;         /* Gene::geneID */
+} kslam_gene_extras;
+
+kslam_status kslam_taxreport_create(kslam_taxreport **out);
+void kslam_taxreport_free(kslam_taxreport *report);
+/* one batch: tax_ids as returned by kslam_tail_classify for the same read pairs */
+kslam_status kslam_taxreport_add_batch(kslam_taxreport *report, const kslam_reads_view *reads,
+                                       const kslam_index_view *index,
+                                       const kslam_read_pair *read_pairs, uint64_t n_read_pairs,
+                                       const kslam_paired_overlap *pairs, uint64_t n_pairs,
+                                       const uint32_t *tax_ids);
+/* end of run: the text writeResults streams to the output file (malloc'ed, kslam_free) */
+kslam_status kslam_taxreport_xml(const kslam_taxreport *report, const kslam_index_view *index,
+                                 const kslam_gene_extras *extras, const kslam_taxdb *db,
+                                 uint64_t num_reads, char **text, uint64_t *text_len);
 
 #ifdef __cplusplus
 }

@@ -103,6 +103,14 @@ class Database:
         self.library_version = int(lib().kslam_db_library_version(handle))
         self.variant = int(lib().kslam_db_variant(handle))
 
+    def gene_extras(self):
+        """kslam_gene_extras over this database's columns (for kslam_amd.taxonomy's XML report)"""
+        from .taxonomy import GeneExtras
+        c = self.columns
+        x = GeneExtras(c.gene_locus_tag, c.gene_locus_tag_off, c.gene_reference, c.gene_reference_off, c.gene_id)
+        x._keep = self
+        return x
+
     @classmethod
     def parse(cls, text, threads=0):
         h = _vp()

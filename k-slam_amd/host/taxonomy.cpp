@@ -6,9 +6,11 @@
 // input id and compares them level by level.  Here the tree is dense: nodes numbered in file
 // order, a parent-index and a depth array, and the LCA of a set is a fold of pairwise walks that
 // first level the depths.  The conventions that make the answers equal are in the header.
+#include <algorithm>
 #include <cmath>
 #include <memory>
 #include <string>
+#include <string_view>
 #include <unordered_map>
 #include <vector>
 
@@ -40,8 +42,68 @@ struct kslam_taxdb {
   }
 };
 
+// One IdentifiedTaxonomy (src/MetagenomicResults.h:32-43) as collected per read pair: the genes are numbers
+// into the index view's gene columns
+struct TaxRecord {
+  uint32_t tax = 0;
+  bool has_read = false;
+  std::string read;
+  std::vector<uint64_t> genes;
+};
+struct kslam_taxreport {
+  std::vector<TaxRecord> recs;
+};
+
 namespace {
 using namespace kslam_host;
+
+std::string_view col(const char *text, const uint64_t *off, uint64_t i) {
+  if (!text || !off) return std::string_view();
+  return std::string_view(text + off[i], off[i + 1] - off[i]);
+}
+// geneSort and Gene::operator==, src/GenbankTools.h:84-91, 116-125 (std::string compares bytes as unsigned)
+struct GeneOrder {
+  const kslam_index_view *ix;
+  std::string_view name(uint64_t g) const { return col(ix->gene_name, ix->gene_name_off, g); }
+  std::string_view protein(uint64_t g) const { return col(ix->protein_id, ix->protein_id_off, g); }
+  std::string_view product(uint64_t g) const { return col(ix->product, ix->product_off, g); }
+  bool less(uint64_t i, uint64_t j) const {
+    if (protein(i).empty() && protein(j).empty()) return name(i) < name(j);
+    if (protein(i) == protein(j)) return product(i) < product(j);
+    return protein(i) < protein(j);
+  }
+  bool equal(uint64_t i, uint64_t j) const {
+    if (protein(i).empty() && protein(j).empty()) return name(i) == name(j);
+    if (protein(i) == protein(j)) return product(i) == product(j);
+    return false;
+  }
+};
+// GenbankEntry::getGene, src/GenbankTools.h:170-185: largest overlap, the first gene on ties, none at <= 0
+int64_t best_gene_of(const kslam_index_view *ix, uint32_t e, int32_t start, int32_t stop) {
+  if (!ix->n_genes || !ix->gene_first) return -1;
+  int64_t best = -1;
+  int32_t largest = 0;
+  for (uint64_t g = ix->gene_first[e]; g < ix->gene_first[e + 1]; g++) {
+    const int32_t shared = std::min<int>(stop, ix->gene_stop[g]) - std::max<int>(start, ix->gene_start[g]);
+    if (shared > largest) {
+      best = (int64_t)g;
+      largest = shared;
+    }
+  }
+  return best;
+}
+void xml_escaped(std::string &out, std::string_view in) {   // correctXML, src/MetagenomicResults.h:275-301
+  for (char c : in) {
+    switch (c) {
+      case '<': out += "&lt;"; break;
+      case '>': out += "&gt;"; break;
+      case '&': out += "&amp;"; break;
+      case '\'': out += "&apos;"; break;
+      case '"': out += "&quot;"; break;
+      default: out += c;
+    }
+  }
+}
 
 bool to_number(const char *s, size_t n, uint32_t *out) {
   // std::stoi: optional whitespace, optional sign, digits; trailing text ignored
@@ -332,6 +394,156 @@ kslam_status kslam_taxonomy_summary(const kslam_taxdb *db, const uint32_t *tax_i
       if (db->known(g.first)) out += db->name[db->node(g.first)];
       snprintf(num, sizeof num, "\t%g\n", g.second * 100.0 / reads32);
       out += num;
+    }
+    *text = dup_text(out, text_len);
+  });
+}
+kslam_status kslam_taxreport_create(kslam_taxreport **out) {
+  return guarded([&] {
+    if (!out) fail(KSLAM_ERR_ARG, "null argument");
+    *out = new kslam_taxreport();
+  });
+}
+
+void kslam_taxreport_free(kslam_taxreport *report) { delete report; }
+
+// getResultFromPairedOverlaps for every read pair of the batch, src/MetagenomicResults.h:88-112
+kslam_status kslam_taxreport_add_batch(kslam_taxreport *report, const kslam_reads_view *reads,
+                                       const kslam_index_view *index, const kslam_read_pair *read_pairs,
+                                       uint64_t n_read_pairs, const kslam_paired_overlap *pairs, uint64_t n_pairs,
+                                       const uint32_t *tax_ids) {
+  return guarded([&] {
+    if (!report || !reads || !index || (n_read_pairs && (!read_pairs || !pairs || !tax_ids)))
+      fail(KSLAM_ERR_ARG, "null argument");
+    if (!reads->ids || !reads->ids_off) fail(KSLAM_ERR_ARG, "the report needs the read identifiers");
+    const GeneOrder ord{index};
+    const size_t base = report->recs.size();
+    report->recs.resize(base + n_read_pairs);
+    for (uint64_t g = 0; g < n_read_pairs; g++) {
+      const kslam_read_pair &rp = read_pairs[g];
+      TaxRecord &rec = report->recs[base + g];
+      if (rp.first + rp.count > n_pairs) fail(KSLAM_ERR_ARG, "read pair slice outside the pairs array");
+      if (rp.count == 0) continue;                      // an empty result: id 0, no read, no genes (:93)
+      for (uint64_t k = 0; k < rp.count; k++) {
+        const kslam_paired_overlap &p = pairs[rp.first + k];
+        if (p.entry >= index->n_entries) fail(KSLAM_ERR_ARG, "alignment pair refers outside the index");
+        const int64_t gene = best_gene_of(index, p.entry, p.ref_start, p.ref_end);
+        if (gene >= 0) rec.genes.push_back((uint64_t)gene);
+      }
+      std::sort(rec.genes.begin(), rec.genes.end(), [&](uint64_t a, uint64_t b) { return ord.less(a, b); });
+      rec.genes.erase(std::unique(rec.genes.begin(), rec.genes.end(), [&](uint64_t a, uint64_t b) { return ord.equal(a, b); }),
+                      rec.genes.end());
+      if (rp.r1_read >= reads->n_reads) fail(KSLAM_ERR_ARG, "read pair refers to a read outside the batch");
+      rec.read.assign(reads->ids + reads->ids_off[rp.r1_read], reads->ids_off[rp.r1_read + 1] - reads->ids_off[rp.r1_read]);
+      rec.has_read = true;
+      rec.tax = tax_ids[g];
+    }
+  });
+}
+
+kslam_status kslam_taxreport_xml(const kslam_taxreport *report, const kslam_index_view *index,
+                                 const kslam_gene_extras *extras, const kslam_taxdb *db, uint64_t num_reads,
+                                 char **text, uint64_t *text_len) {
+  return guarded([&] {
+    if (!report || !index || !db || !text || !text_len) fail(KSLAM_ERR_ARG, "null argument");
+    const GeneOrder ord{index};
+    struct Counted { uint64_t gene; int count; };
+    struct Taxon { uint32_t tax; std::vector<std::string> reads; std::vector<Counted> genes; };
+    // combineTaxonomies, src/MetagenomicResults.h:149-177 (records of equal id in input order: see the header)
+    const size_t n = report->recs.size();
+    std::vector<uint32_t> order(n);
+    for (size_t i = 0; i < n; i++) order[i] = (uint32_t)i;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return report->recs[a].tax < report->recs[b].tax; });
+    std::vector<Taxon> taxa;
+    auto combine = [&](size_t from, size_t to) {        // combineRangeOfIdentifiedTaxonomy, :118-142
+      Taxon t;
+      t.tax = report->recs[order[from]].tax;
+      std::vector<uint64_t> all;
+      for (size_t i = from; i < to; i++) {
+        const TaxRecord &r = report->recs[order[i]];
+        all.insert(all.end(), r.genes.begin(), r.genes.end());
+        if (r.has_read) t.reads.push_back(r.read);
+      }
+      std::sort(all.begin(), all.end(), [&](uint64_t a, uint64_t b) { return ord.less(a, b); });
+      for (size_t i = 0; i < all.size(); i++) {
+        if (!t.genes.empty() && ord.equal(t.genes.back().gene, all[i])) t.genes.back().count++;
+        else t.genes.push_back(Counted{all[i], 1});
+      }
+      taxa.push_back(std::move(t));
+    };
+    if (n) {
+      uint32_t test = 0;
+      size_t start = 0;
+      for (size_t i = 1; i < n; i++) {
+        const uint32_t id = report->recs[order[i]].tax;
+        if (id != test) {
+          if (test != 0) combine(start, i);
+          test = id;
+          start = i;
+        }
+      }
+      if (report->recs[order[start]].tax != 0) combine(start, n);
+    }
+    // sortResults, src/MetagenomicResults.h:254-273
+    std::sort(taxa.begin(), taxa.end(), [](const Taxon &a, const Taxon &b) {
+      return a.reads.size() == b.reads.size() ? a.tax < b.tax : a.reads.size() > b.reads.size();
+    });
+    auto locus = [&](uint64_t g) { return extras ? col(extras->gene_locus_tag, extras->gene_locus_tag_off, g) : std::string_view(); };
+    for (Taxon &t : taxa) {
+      std::sort(t.reads.begin(), t.reads.end());
+      std::sort(t.genes.begin(), t.genes.end(), [&](const Counted &a, const Counted &b) {
+        if (a.count == b.count) {
+          const uint32_t sa = (uint32_t)index->gene_start[a.gene], sb = (uint32_t)index->gene_start[b.gene];
+          if (sa == sb) return locus(a.gene) < locus(b.gene);
+          return sa < sb;
+        }
+        return a.count > b.count;
+      });
+    }
+    // getXML, src/MetagenomicResults.h:302-366
+    std::string out;
+    const unsigned reads32 = (unsigned)num_reads;   // the reference's `const unsigned numReads`
+    for (const Taxon &t : taxa) {
+      out += "<taxon>\n  <abundance numReads=\"";
+      out += std::to_string(t.reads.size());
+      out += "\">";
+      out += std::to_string(t.reads.size() * 100.0 / reads32);
+      out += "</abundance>\n  <taxonomyID>";
+      out += std::to_string(t.tax);
+      out += "</taxonomyID>\n  <lineage>";
+      xml_escaped(out, lineage_of(*db, t.tax));
+      out += "</lineage>\n  <name>";
+      if (db->known(t.tax)) xml_escaped(out, db->name[db->node(t.tax)]);
+      out += "</name>\n  <genes>\n";
+      for (const Counted &c : t.genes) {
+        const uint64_t g = c.gene;
+        out += "    <gene protein=\"";
+        xml_escaped(out, ord.protein(g));
+        out += "\" locus=\"";
+        xml_escaped(out, locus(g));
+        out += "\" product=\"";
+        xml_escaped(out, ord.product(g));
+        out += "\" GeneID=\"";
+        out += std::to_string(extras && extras->gene_id ? extras->gene_id[g] : 0u);
+        out += "\" reference=\"";
+        xml_escaped(out, extras ? col(extras->gene_reference, extras->gene_reference_off, g) : std::string_view());
+        out += "\" numReads=\"";
+        out += std::to_string(c.count);
+        out += "\" cdsStart=\"";
+        out += std::to_string((uint32_t)index->gene_start[g]);
+        out += "\" cdsEnd=\"";
+        out += std::to_string((uint32_t)index->gene_stop[g]);
+        out += "\">";
+        xml_escaped(out, ord.name(g));
+        out += "</gene>\n";
+      }
+      out += "  </genes>\n  <reads>\n";
+      for (const std::string &r : t.reads) {
+        out += "    <read>";
+        xml_escaped(out, r);
+        out += "</read>\n";
+      }
+      out += "  </reads>\n</taxon>\n";
     }
     *text = dup_text(out, text_len);
   });

@@ -93,6 +93,9 @@ def test_fastq_and_database_files_to_sam_and_per_read_taxa(kslam, oracle, synth,
     tax = X.TaxDB((dbdir / "taxDB").read_bytes())
     tax_ids, per_read = tax.classify(P, batch, db, rp, pr)
     summary = tax.summary(tax_ids, n_pairs)
+    report = X.Report()
+    report.add_batch(batch, db, rp, pr, tax_ids)
+    xml = tax.report_xml(report, db, db.gene_extras(), n_pairs)
     header = T.sam_header(db, b"SLAM --db db R1.fq R2.fq")
 
     # ---- checker chain ----
@@ -124,6 +127,12 @@ def test_fastq_and_database_files_to_sam_and_per_read_taxa(kslam, oracle, synth,
     assert tax_ids.tolist() == etax and len(set(etax)) > 6
     assert per_read == eper_read
     assert summary == oracle.taxonomy_summary(otree, etax, n_pairs)
+    # the XML report (writeResults): restated step by step in tests/test_taxonomy.py, from the checker chain's pairs
+    from test_taxonomy import _xml_restatement
+    ogenes = [[{"start": g["start"], "stop": g["stop"], "name": g["geneName"], "protein": g["proteinID"], "product": g["product"],
+                "locus": g["locusTag"], "reference": g["referenceSequence"], "id": g["geneID"]} for g in e["genes"]] for e in oentries]
+    exml, taxa = _xml_restatement(tax, [e["taxonomyID"] for e in oentries], ogenes, None, [(ids, erp, epr)], n_pairs)
+    assert xml == exml and len(taxa) > 6 and sum(len(t["genes"]) for t in taxa) > 50 and xml.count(b"<read>") > 0.8 * n_pairs
     assert header == oracle.sam_header(oI.view, b"SLAM --db db R1.fq R2.fq")
     # ---- the same SAM text with NM / log-probability / MD computed on the GPU (kslam_row_details):
     # qualities straight from the parsed batch's column, rows checked against the restatement of the
@@ -175,6 +184,7 @@ def test_fastq_and_database_files_to_sam_and_per_read_taxa(kslam, oracle, synth,
     ctx.close()
     batch.close()
     db.close()
+    report.close()
     tax.close()
     otree.close()
 

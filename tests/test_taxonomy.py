@@ -174,3 +174,170 @@ def test_golden_answers_from_the_real_reference(X, oracle):
         assert (db.parent(i), db.is_subspecies(i), db.at_rank(i, b"species")) == (parent, sub, species)
         assert [db.text(i, w).decode() for w in (0, 1, 2)] == [name, rank, lineage]
         assert orc.text(i, 2).decode() == lineage
+
+
+# ---- the XML report (writeResults, src/MetagenomicResults.h:213-224): a plain restatement of the reference's
+# steps for small cases -- getGene (src/GenbankTools.h:170-185), geneSort / operator== (:84-91, 116-125),
+# getResultFromPairedOverlaps (:88-112), combineTaxonomies + combineRangeOfIdentifiedTaxonomy (:118-177, records
+# of equal id in input order), sortResults (:254-273), correctXML / getXML (:275-366).  Python's sort is stable
+# where std::sort is not, so the exact comparison uses data without equal-but-different genes; the tie-heavy case
+# compares what does not depend on the representative.
+def _xml_restatement(db, entry_tax, genes, extras, batches, num_reads):
+    import functools
+
+    def less(a, b):
+        if not a["protein"] and not b["protein"]:
+            return a["name"] < b["name"]
+        if a["protein"] == b["protein"]:
+            return a["product"] < b["product"]
+        return a["protein"] < b["protein"]
+
+    def equal(a, b):
+        if not a["protein"] and not b["protein"]:
+            return a["name"] == b["name"]
+        if a["protein"] == b["protein"]:
+            return a["product"] == b["product"]
+        return False
+    key = functools.cmp_to_key(lambda a, b: -1 if less(a, b) else (1 if less(b, a) else 0))
+
+    def i32(v):
+        return v - (1 << 32) if v >= (1 << 31) else v
+    recs = []
+    for ids, rp, pr in batches:
+        for g in rp:
+            rec = {"tax": 0, "read": None, "genes": []}
+            recs.append(rec)
+            if int(g["count"]) == 0:
+                continue
+            taxs = []
+            for p in pr[int(g["first"]):int(g["first"]) + int(g["count"])]:
+                e = int(p["entry"])
+                taxs.append(entry_tax[e])
+                best, largest = None, 0
+                for gene in genes[e]:
+                    shared = min(int(p["ref_end"]), i32(gene["stop"])) - max(int(p["ref_start"]), i32(gene["start"]))
+                    if shared > largest:
+                        best, largest = gene, shared
+                if best is not None:
+                    rec["genes"].append(best)
+            rec["genes"].sort(key=key)
+            uniq = []
+            for x in rec["genes"]:
+                if not uniq or not equal(uniq[-1], x):
+                    uniq.append(x)
+            rec["genes"] = uniq
+            rec["read"] = ids[int(g["r1_read"])]
+            rec["tax"] = db.lca(taxs)
+    order = sorted(range(len(recs)), key=lambda i: recs[i]["tax"])
+    taxa = []
+
+    def combine(a, b):
+        allg, reads = [], []
+        for i in order[a:b]:
+            allg += recs[i]["genes"]
+            if recs[i]["read"] is not None:
+                reads.append(recs[i]["read"])
+        allg.sort(key=key)
+        merged = []
+        for x in allg:
+            if merged and equal(merged[-1][0], x):
+                merged[-1][1] += 1
+            else:
+                merged.append([x, 1])
+        taxa.append({"tax": recs[order[a]]["tax"], "reads": reads, "genes": merged})
+    if recs:
+        test, start = 0, 0
+        for i in range(1, len(recs)):
+            t = recs[order[i]]["tax"]
+            if t != test:
+                if test != 0:
+                    combine(start, i)
+                test, start = t, i
+        if recs[order[start]]["tax"] != 0:
+            combine(start, len(recs))
+    taxa.sort(key=lambda t: (-len(t["reads"]), t["tax"]))
+
+    def esc(b):
+        return (b.replace(b"&", b"\0").replace(b"<", b"&lt;").replace(b">", b"&gt;").replace(b"'", b"&apos;")
+                .replace(b'"', b"&quot;").replace(b"\0", b"&amp;"))
+    out = []
+    for t in taxa:
+        t["reads"].sort()
+        t["genes"].sort(key=lambda gc: (-gc[1], gc[0]["start"], gc[0]["locus"]))
+        out.append(b'<taxon>\n  <abundance numReads="%d">%s</abundance>\n  <taxonomyID>%d</taxonomyID>\n  <lineage>%s</lineage>\n'
+                   b'  <name>%s</name>\n  <genes>\n' % (len(t["reads"]), ("%f" % (len(t["reads"]) * 100.0 / num_reads)).encode(), t["tax"],
+                                                       esc(db.text(t["tax"], 2)), esc(db.text(t["tax"], 0))))
+        for gene, count in t["genes"]:
+            out.append(b'    <gene protein="%s" locus="%s" product="%s" GeneID="%d" reference="%s" numReads="%d" cdsStart="%d" '
+                       b'cdsEnd="%d">%s</gene>\n' % (esc(gene["protein"]), esc(gene["locus"]), esc(gene["product"]), gene["id"],
+                                                     esc(gene["reference"]), count, gene["start"], gene["stop"], esc(gene["name"])))
+        out.append(b"  </genes>\n  <reads>\n")
+        for r in t["reads"]:
+            out.append(b"    <read>%s</read>\n" % esc(r))
+        out.append(b"  </reads>\n</taxon>\n")
+    return b"".join(out), taxa
+
+
+@pytest.mark.parametrize("seed,distinct", [(1, True), (2, True), (3, False), (4, False)])
+def test_xml_report(kslam, X, seed, distinct):
+    T = importlib.import_module("kslam_amd.tail")
+    from test_tail import _fuzz_overlaps
+    rng = np.random.default_rng(40 + seed)
+    text, ids = make_tree(rng, 40, dangling=0, duplicates=0)
+    db = X.TaxDB(text)
+    n_entries = 10
+    entry_tax = [int(ids[int(rng.integers(0, 40))]) for _ in range(n_entries)]
+    if seed % 2:
+        entry_tax[2] = 0                   # reads on this entry stay unclassified: no record is dropped by the quirk
+    genes, flat = [], []
+    names = [b"dnaA", b"rpoB", b"gyr<A>", b"", b"x&y", b"recA'", b'say"hi"']
+    for e in range(n_entries):
+        gl = []
+        for k in range(int(rng.integers(0, 9))):
+            start = int(rng.integers(0, 6000))
+            stop = start + int(rng.integers(50, 1500))
+            if distinct:                   # every gene its own class: the representative is not a question
+                protein = b"WP_%d_%d" % (e, k) if rng.random() < 0.8 else b""
+                name = b"g%d_%d" % (e, k)
+            else:                          # classes shared between entries (strains): same protein and product, other fields differ
+                protein = [b"WP_1", b"WP_2", b"WP_3", b""][int(rng.integers(0, 4))]
+                name = names[int(rng.integers(0, len(names)))]
+            product = [b"kinase", b"hypothetical protein", b"a < b"][int(rng.integers(0, 3))]
+            g = {"start": start, "stop": stop, "name": name, "protein": protein, "product": product,
+                 "locus": b"LT_%d_%d" % (e, k), "reference": b"NC_%06d" % e, "id": int(rng.integers(0, 1 << 31))}
+            gl.append(g)
+        if e == 5 and gl:
+            gl[0]["start"], gl[0]["stop"] = 4000000000, 4000000500      # CDS fields are uint32; getGene compares them as int
+        genes.append(gl)
+        flat += gl
+    index = T.Index([b"A" * 8000] * n_entries, taxonomy_ids=entry_tax,
+                    genes=[[(g["start"], g["stop"], g["name"], g["protein"], g["product"]) for g in gl] for gl in genes])
+    extras = X.GeneExtras.from_lists([g["locus"] for g in flat], [g["reference"] for g in flat], [g["id"] for g in flat]) if flat else None
+    P = T.TailParams.default(report_cigar=False, threads=3)
+    rep = X.Report()
+    batches, n_pairs_total = [], 0
+    for b in range(2):
+        ov, n_reads = _fuzz_overlaps(kslam, rng, 400, n_entries, per_read=6.0 if not distinct else 3.0)
+        rid = [b"r%d<&>%d" % (b, i % 400) for i in range(n_reads)]
+        reads = T.Reads([b"A" * 100] * n_reads, ids=rid)
+        rp, pr, _ = T.tail_pairs(P, reads, ov)
+        tax, _ = db.classify(P, reads, index, rp, pr, per_read=False)
+        rep.add_batch(reads, index, rp, pr, tax)
+        batches.append((rid, rp, pr))
+        n_pairs_total += 400
+    got = db.report_xml(rep, index, extras, n_pairs_total)
+    exp, taxa = _xml_restatement(db, entry_tax, genes, extras, batches, n_pairs_total)
+    assert len(taxa) >= 3 and sum(len(t["genes"]) for t in taxa) > 5 and b"&lt;&amp;&gt;" in got
+    if distinct:
+        assert got == exp
+    else:
+        # equal-but-different genes: which one represents its class is libstdc++'s sort; everything else must agree
+        import re
+        strip = lambda x: re.sub(rb' locus="[^"]*"| GeneID="[^"]*"| reference="[^"]*"| cdsStart="[^"]*"| cdsEnd="[^"]*"|>[^<]*</gene>', b"", x)
+        def canon(x):
+            blocks = x.split(b"<taxon>\n")
+            return [sorted(strip(l) for l in blk.split(b"\n")) for blk in blocks]
+        assert canon(got) == canon(exp)
+        assert max(c for t in taxa for _, c in t["genes"]) >= 3
+    assert db.report_xml(X.Report(), index, extras, 10) == b""
+    rep.close()

@@ -424,10 +424,12 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
+        import datetime
+        limit = datetime.timedelta(minutes=10)     # a rank that has died must not leave the others waiting for half an hour
         if share:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=limit)
         else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=limit)
 
     K = entry.load_package()
     kdist = importlib.import_module("kslam_amd.dist")

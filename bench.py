@@ -719,4 +719,14 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException:
+        # leave at once: with a process group up, a rank that unwinds normally can sit in the communicator's
+        # teardown while the other ranks wait for it in a collective
+        import traceback
+        traceback.print_exc()
+        sys.stderr.flush()
+        os._exit(1)

@@ -131,19 +131,25 @@ __device__ inline void stage_codes_lane(const uint8_t *codes, int32_t len, bool 
   const uint32_t *w = reinterpret_cast<const uint32_t *>(a0 - (uintptr_t)shift);
   const int32_t ndw = (shift + len + 3) >> 2;
   uint32_t acc = 0;
-  for (int32_t d = 0; d < ndw; d++) {
-    const uint32_t v = codes_of_dword<1>(w[d], rev);
+  struct __attribute__((packed, aligned(4))) Quad { uint32_t x[4]; };   // one 16-byte load (the arrays are padded)
+  for (int32_t d0 = 0; d0 < ndw; d0 += 4) {
+    const Quad q = *reinterpret_cast<const Quad *>(w + d0);
 #pragma unroll
-    for (int32_t b = 0; b < 4; b++) {
-      const int32_t k = 4 * d + b - shift;
-      if (k < 0 || k >= len) continue;
-      const uint32_t kk = (uint32_t)(rev ? len - 1 - k : k);
-      acc |= ((v >> (8 * b)) & 15u) << (4u * (kk & 1u));
-      // a byte is complete with its second nibble in walking order (odd kk forwards, even kk
-      // backwards), or at the last base
-      if (((kk & 1u) == (rev ? 0u : 1u)) || k == len - 1) {
-        dst[(kk >> 1) * NS + lane] = (uint8_t)acc;
-        acc = 0;
+    for (int32_t dd = 0; dd < 4; dd++) {
+      const int32_t d = d0 + dd;
+      const uint32_t v = codes_of_dword<1>(q.x[dd], rev);
+#pragma unroll
+      for (int32_t b = 0; b < 4; b++) {
+        const int32_t k = 4 * d + b - shift;
+        if (k < 0 || k >= len) continue;
+        const uint32_t kk = (uint32_t)(rev ? len - 1 - k : k);
+        acc |= ((v >> (8 * b)) & 15u) << (4u * (kk & 1u));
+        // a byte is complete with its second nibble in walking order (odd kk forwards, even kk
+        // backwards), or at the last base
+        if (((kk & 1u) == (rev ? 0u : 1u)) || k == len - 1) {
+          dst[(kk >> 1) * NS + lane] = (uint8_t)acc;
+          acc = 0;
+        }
       }
     }
   }

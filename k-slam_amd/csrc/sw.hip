@@ -430,7 +430,7 @@ __global__ __launch_bounds__(256) void k_sw_plan(kslam_overlap *__restrict__ ov,
 // NT-way stable partition of the candidate numbers by tier: per-block counts, one small scan,
 // then a scatter that ranks within the block by ballots.
 constexpr int TIER_ITEMS = 4096;   // candidates per block
-constexpr int NT = 8;              // tier bins (5 used)
+constexpr int NT = 8;              // tier bins (up to 6 used)
 __global__ __launch_bounds__(256) void k_tier_hist(const uint8_t *__restrict__ tier, uint64_t n,
                                                    uint32_t *__restrict__ block_hist, uint32_t n_blocks) {
   __shared__ uint32_t h[NT];
@@ -830,10 +830,10 @@ void sw_scores(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, uint32_
   const bool debug = getenv("KSLAM_DEBUG") != nullptr;
   if (const char *ab = getenv("KSLAM_SW_ABLATE")) p.ablate = (uint32_t)atoi(ab);
   if (!(force_full && force_full[0] == '1') && band_ok) {
-    // banded tiers of 16 / 32 / 64 (/ 128 for reads > 160 bases) diagonals; k_sw_plan sends each
-    // candidate to the narrowest one its seed diagonal already certifies, the others start at 32;
-    // whatever fails a tier's certificate is appended to the next tier's list, and what fails the
-    // widest goes to the full-matrix kernel
+    // banded tiers of 16 / 32 / 48 / 64 / 96 (/ 128 for reads > 160 bases) diagonals; k_sw_plan sends each
+    // candidate to the narrowest one its seed diagonal already certifies, the others start at 48 (64 for the
+    // longer reads); whatever fails a tier's certificate is appended to the list of the tier its score
+    // certifies, and what no tier certifies goes to the full-matrix kernel
     Tiers T;
     memset(&T, 0, sizeof T);
     {

@@ -691,6 +691,8 @@ def main():
                 "rank0": {k: round(v / S * 1e3, 3) for k, v in split.items()}}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(K, db, offs, 77, args.cpu_genomes, args.cpu_pairs, args.read_len, local_rank)
+        torch.cuda.empty_cache()       # what torch's allocator cached while generating the inputs goes back to the device:
+                                       # the legs below run two more contexts' worth of library buffers
         if world == 1 and not strong and not args.no_abi_path:
             try:
                 out["abi_path"] = abi_path(K, ctx, reads, args.read_len, max(args.steps, 12))

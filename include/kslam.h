@@ -200,6 +200,10 @@ typedef struct {
 kslam_status kslam_load_qualities(kslam_ctx *ctx, const char *concat_quality);
 kslam_status kslam_load_qualities_device(kslam_ctx *ctx, const void *d_concat_quality);
 kslam_status kslam_row_details(kslam_ctx *ctx, uint64_t *n_md);
+/* the same after kslam_pair_screen, for the overlap records its surviving alignment pairs refer to only (what the
+ * SAM writer will ask for: about a third of the rows); the other rows' records are zero and have no MD text.
+ * The pipelined lanes run this form when kslam_set_pairing switched the device pairing on. */
+kslam_status kslam_row_details_of_pairs(kslam_ctx *ctx, uint64_t *n_md);
 /* page-locked, library-owned copies; hand each back with kslam_free_pinned */
 kslam_status kslam_take_row_details(kslam_ctx *ctx, kslam_row_detail **details,
                                     char **md_pool, uint64_t *n_md);

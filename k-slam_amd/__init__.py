@@ -43,7 +43,7 @@ EXPORTS = ["kslam_abi_version", "kslam_create", "kslam_destroy", "kslam_last_err
            "kslam_align_batch_async", "kslam_wait_batch", "kslam_load_qualities", "kslam_load_qualities_device",
            "kslam_row_details", "kslam_take_row_details", "kslam_free_pinned", "kslam_submit_batch",
            "kslam_submit_batch_columns", "kslam_submit_batch_fastq", "kslam_submit_batch_fastq_text", "kslam_collect_batch", "kslam_release_batch", "kslam_host_alloc",
-           "kslam_host_free", "kslam_pair_screen", "kslam_pair_screen_overlaps", "kslam_take_pairs", "kslam_set_pairing", "kslam_debug_wave_sort",
+           "kslam_host_free", "kslam_pair_screen", "kslam_pair_screen_overlaps", "kslam_take_pairs", "kslam_set_pairing", "kslam_debug_wave_sort", "kslam_row_details_of_pairs",
            "kslam_load_reads", "kslam_load_reads_device", "kslam_align_resident",
            "kslam_fetch_results", "kslam_take_results", "kslam_copy_results_device", "kslam_get_timings",
            "kslam_extract_kmers", "kslam_sort_kmers", "kslam_find_overlaps", "kslam_free",
@@ -134,6 +134,7 @@ def lib():
         L.kslam_load_qualities.argtypes = [vp, vp]
         L.kslam_load_qualities_device.argtypes = [vp, vp]
         L.kslam_row_details.argtypes = [vp, C.POINTER(u64)]
+        L.kslam_row_details_of_pairs.argtypes = [vp, C.POINTER(u64)]
         L.kslam_take_row_details.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64)]
         L.kslam_free_pinned.argtypes = [vp, vp]
         L.kslam_submit_batch.argtypes = [vp, u64, vp, vp, vp, C.POINTER(u64)]
@@ -318,9 +319,11 @@ class Context:
     def load_qualities_device(self, dev_ptr):
         self._chk(self._L.kslam_load_qualities_device(self._h, dev_ptr))
 
-    def row_details(self):
+    def row_details(self, of_pairs=False):
+        """kslam_row_details (every row) / kslam_row_details_of_pairs (the rows the last pair_screen's pairs refer to)"""
         n = C.c_uint64()
-        self._chk(self._L.kslam_row_details(self._h, C.byref(n)))
+        f = self._L.kslam_row_details_of_pairs if of_pairs else self._L.kslam_row_details
+        self._chk(f(self._h, C.byref(n)))
         return int(n.value)
 
     def take_row_details(self, n_rows, copy=True):

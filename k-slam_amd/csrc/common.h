@@ -265,11 +265,12 @@ struct DetailWork {
 void row_details(const kslam_overlap *d_ov, uint64_t n, const uint32_t *d_pool, const uint8_t *d_rbases,
                  const uint8_t *d_rqual, const uint64_t *d_roff, const uint8_t *d_gbases, const uint64_t *d_goff,
                  const double *d_tables, kslam_row_detail *d_out, DetailWork &W, uint8_t **d_md_pool_out,
-                 uint64_t *n_md_out, uint32_t *flags_out, hipStream_t s);
+                 uint64_t *n_md_out, uint32_t *flags_out, hipStream_t s, const uint32_t *d_rows = nullptr,
+                 uint64_t n_list = 0);   // d_rows: only these rows are walked, the others get zero records
 
 // --------------------------------------------------------------- pairs.hip
 struct PairWork {
-  DevBuf recs, count, base, inserts, flags, gpos, rpos, scan_tmp, totals, groups, dense, sort_a, sort_b, idx, picked;
+  DevBuf recs, count, base, inserts, flags, gpos, rpos, scan_tmp, totals, groups, dense, sort_a, sort_b, idx, picked, row_list;
 };
 struct PairResult {
   uint64_t n_overlaps_screened, n_paired_initial, n_insert_sizes, n_read_pairs, n_pairs;
@@ -299,6 +300,9 @@ struct FastqIndexResult {
 // an empty stream).  Semantics of host/fastq.cpp's index (kslam_fastq_index_pair).
 void fastq_index_device(const uint8_t *d_text, uint64_t len1, uint64_t len2, const uint8_t *h_last1, const uint8_t *h_last2,
                         uint64_t max_pairs, bool at_eof, FastqWork &W, FastqIndexResult *res, hipStream_t s);
+
+// the overlap records the result's alignment pairs refer to, ascending, as a list in W (valid until the next pairs call)
+void referenced_rows(PairWork &W, const PairResult *res, uint64_t n_rows, const uint32_t **d_list, uint64_t *n_list, hipStream_t s);
 
 // pseudoAssembly + the second score screen on pair_and_screen's result, in place; false (nothing changed)
 // when an entry has more spans than a workgroup's LDS holds: the host then runs that stage itself

@@ -256,11 +256,12 @@ __global__ __launch_bounds__(256) void k_row_details(const kslam_overlap *__rest
                                                      const uint8_t *__restrict__ gbases, const uint64_t *__restrict__ goff,
                                                      const double *__restrict__ tables, kslam_row_detail *__restrict__ out,
                                                      uint32_t *__restrict__ md_lens, uint8_t *__restrict__ slots,
-                                                     uint32_t *__restrict__ flags_or) {
+                                                     uint32_t *__restrict__ flags_or, const uint32_t *__restrict__ rows) {
   __shared__ WalkLds S;
   fill_walk_lds(S, tables);
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= n) return;
+  const uint64_t i = rows ? rows[x] : x;      // a list of rows, or all of them
   const kslam_overlap o = ov[i];
   const WalkResult r = walk_row(o, pool, rbases, rqual, roff, gbases, goff, S, slots + i * MD_SLOT, MD_SLOT);
   kslam_row_detail d;
@@ -281,11 +282,12 @@ __global__ __launch_bounds__(256) void k_md_gather(const kslam_overlap *__restri
                                                    const uint8_t *__restrict__ gbases, const uint64_t *__restrict__ goff,
                                                    const double *__restrict__ tables, kslam_row_detail *__restrict__ out,
                                                    const uint64_t *__restrict__ md_off, const uint8_t *__restrict__ slots,
-                                                   uint8_t *__restrict__ md_pool) {
+                                                   uint8_t *__restrict__ md_pool, const uint32_t *__restrict__ rows) {
   __shared__ WalkLds S;
   fill_walk_lds(S, tables);
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= n) return;
+  const uint64_t i = rows ? rows[x] : x;
   const uint32_t len = out[i].md_len;
   const uint64_t off = md_off[i];
   out[i].md_off = off;
@@ -339,7 +341,7 @@ void gather_fields(const uint8_t *d_text, const uint64_t *d_bases_at, const uint
 void row_details(const kslam_overlap *d_ov, uint64_t n, const uint32_t *d_pool, const uint8_t *d_rbases,
                  const uint8_t *d_rqual, const uint64_t *d_roff, const uint8_t *d_gbases, const uint64_t *d_goff,
                  const double *d_tables, kslam_row_detail *d_out, DetailWork &W, uint8_t **d_md_pool_out,
-                 uint64_t *n_md_out, uint32_t *flags_out, hipStream_t s) {
+                 uint64_t *n_md_out, uint32_t *flags_out, hipStream_t s, const uint32_t *d_rows, uint64_t n_list) {
   *n_md_out = 0;
   *flags_out = 0;
   *d_md_pool_out = nullptr;
@@ -351,15 +353,22 @@ void row_details(const kslam_overlap *d_ov, uint64_t n, const uint32_t *d_pool, 
   W.totals.ensure(4 * sizeof(uint64_t));
   uint64_t *d_tot = W.totals.as<uint64_t>();
   HIPCHK(hipMemsetAsync(d_tot, 0, 4 * sizeof(uint64_t), s));
-  const unsigned nb = (unsigned)((n + 255) / 256);
-  hipLaunchKernelGGL(k_row_details, dim3(nb), dim3(256), 0, s, d_ov, n, d_pool, d_rbases, d_rqual, d_roff, d_gbases, d_goff,
-                     d_tables, d_out, W.lens.as<uint32_t>(), W.slots.as<uint8_t>(), reinterpret_cast<uint32_t *>(d_tot + 1));
+  const uint64_t m = d_rows ? n_list : n;      // rows walked
+  if (d_rows) {   // the rows that are not on the list: zero records, no MD text
+    HIPCHK(hipMemsetAsync(d_out, 0, n * sizeof(kslam_row_detail), s));
+    HIPCHK(hipMemsetAsync(W.lens.p, 0, n * sizeof(uint32_t), s));
+  }
+  const unsigned nb = (unsigned)((m + 255) / 256);
+  if (m)
+    hipLaunchKernelGGL(k_row_details, dim3(nb), dim3(256), 0, s, d_ov, m, d_pool, d_rbases, d_rqual, d_roff, d_gbases, d_goff,
+                       d_tables, d_out, W.lens.as<uint32_t>(), W.slots.as<uint8_t>(), reinterpret_cast<uint32_t *>(d_tot + 1), d_rows);
   exclusive_scan_u32_to_u64(W.lens.as<uint32_t>(), W.off.as<uint64_t>(), n, d_tot, W.scan_tmp.p, s);
   uint64_t h[2] = {0, 0};
   read_back(h, d_tot, sizeof h, s);
   W.md_pool.ensure(h[0] + 64);
-  hipLaunchKernelGGL(k_md_gather, dim3(nb), dim3(256), 0, s, d_ov, n, d_pool, d_rbases, d_rqual, d_roff, d_gbases, d_goff,
-                     d_tables, d_out, W.off.as<uint64_t>(), W.slots.as<uint8_t>(), W.md_pool.as<uint8_t>());
+  if (m)
+    hipLaunchKernelGGL(k_md_gather, dim3(nb), dim3(256), 0, s, d_ov, m, d_pool, d_rbases, d_rqual, d_roff, d_gbases, d_goff,
+                       d_tables, d_out, W.off.as<uint64_t>(), W.slots.as<uint8_t>(), W.md_pool.as<uint8_t>(), d_rows);
   HIPCHK(hipGetLastError());
   *d_md_pool_out = W.md_pool.as<uint8_t>();
   *n_md_out = h[0];

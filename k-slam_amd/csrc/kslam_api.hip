@@ -822,10 +822,13 @@ void lane_main(kslam_ctx *primary, kslam_ctx::AsyncLane *lane) {
       std::lock_guard<std::mutex> compute(primary->as_compute);
       t2 = now();
       st = kslam_align_resident(c, nullptr, nullptr);
-      if (st == KSLAM_OK && (job->qcat || job->fastq)) st = kslam_row_details(c, nullptr);
+      const bool want_details = job->qcat || job->fastq;
       if (st == KSLAM_OK && primary->pairing.stages)
         st = kslam_pair_screen(c, primary->pairing.paired, primary->pairing.thr, primary->pairing.fraction,
                                primary->pairing.stages, &job->pstats);
+      // the per-row walk after the pairing: only the rows the surviving alignment pairs refer to need it
+      if (st == KSLAM_OK && want_details)
+        st = primary->pairing.stages ? kslam_row_details_of_pairs(c, nullptr) : kslam_row_details(c, nullptr);
     }
     t3 = now();
     if (st == KSLAM_OK) st = kslam_take_results(c, &job->out, &job->n_out, &job->pool, &job->n_cig);
@@ -1164,9 +1167,10 @@ kslam_status kslam_load_qualities_device(kslam_ctx *c, const void *d_concat_qual
   });
 }
 
-kslam_status kslam_row_details(kslam_ctx *c, uint64_t *n_md) {
+static kslam_status row_details_impl(kslam_ctx *c, uint64_t *n_md, bool of_pairs) {
   return guarded(c, [&] {
     if (!c->have_qual) throw StatusError{KSLAM_ERR_STATE, "kslam_load_qualities has not been called for this batch"};
+    if (of_pairs && !c->have_pairs) throw StatusError{KSLAM_ERR_STATE, "kslam_pair_screen has not been called for this result"};
     if (!c->d_tables.p) {
       // matchTable / misMatchTable of src/SAM.h:33-48, with the host's libm (the values the host tail uses)
       double t[200];
@@ -1181,15 +1185,24 @@ kslam_status kslam_row_details(kslam_ctx *c, uint64_t *n_md) {
       HIPCHK(hipStreamSynchronize(c->stream));
     }
     c->res_det.ensure((c->n_res + 1) * sizeof(kslam_row_detail));
+    const uint32_t *d_list = nullptr;
+    uint64_t n_list = 0;
+    if (of_pairs) {
+      referenced_rows(c->pw, &c->pres, c->n_res, &d_list, &n_list, c->stream);
+      if (!d_list) d_list = reinterpret_cast<const uint32_t *>(c->res_det.p);   // (no rows at all: any non-null list of length 0)
+    }
     row_details(c->res_ov.as<kslam_overlap>(), c->n_res, c->res_cig.as<uint32_t>(), c->r_bases.as<uint8_t>(),
                 c->r_qual.as<uint8_t>(), c->r_off.as<uint64_t>(), c->g_bases.as<uint8_t>(), c->g_off.as<uint64_t>(),
                 c->d_tables.as<double>(), c->res_det.as<kslam_row_detail>(), c->detw, &c->d_md_pool, &c->n_md,
-                &c->det_flags, c->stream);
+                &c->det_flags, c->stream, d_list, n_list);
     HIPCHK(hipStreamSynchronize(c->stream));
     c->have_details = true;
     if (n_md) *n_md = c->n_md;
   });
 }
+
+kslam_status kslam_row_details(kslam_ctx *c, uint64_t *n_md) { return row_details_impl(c, n_md, false); }
+kslam_status kslam_row_details_of_pairs(kslam_ctx *c, uint64_t *n_md) { return row_details_impl(c, n_md, true); }
 
 kslam_status kslam_take_row_details(kslam_ctx *c, kslam_row_detail **details, char **md_pool, uint64_t *n_md) {
   if (!c || !details || !md_pool || !n_md) return KSLAM_ERR_ARG;

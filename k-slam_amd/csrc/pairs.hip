@@ -493,6 +493,50 @@ __global__ __launch_bounds__(256) void k_rescreen(Rec *__restrict__ recs, kslam_
 
 }  // namespace
 
+namespace {
+__global__ __launch_bounds__(256) void k_mark_rows(const Rec *__restrict__ recs, const kslam_read_pair *__restrict__ groups,
+                                                   uint64_t n_groups, uint64_t n_rows, uint32_t *__restrict__ flags) {
+  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n_groups) return;
+  const uint64_t first = groups[g].first, cnt = groups[g].count;
+  for (uint64_t k = 0; k < cnt; k++) {
+    const Rec r = recs[first + k];
+    if (r.r1 != NONE && r.r1 < n_rows) flags[r.r1] = 1u;
+    if (r.r2 != NONE && r.r2 < n_rows) flags[r.r2] = 1u;
+  }
+}
+__global__ void k_list_rows(const uint32_t *__restrict__ flags, const uint32_t *__restrict__ pos, uint64_t n,
+                            uint32_t *__restrict__ list) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && flags[i]) list[pos[i]] = (uint32_t)i;
+}
+}  // namespace
+
+// Which overlap records do the surviving alignment pairs refer to?  (The SAM writer's per-row walk is only needed
+// for those: ~36 % of the rows of the bench workload.)
+void referenced_rows(PairWork &W, const PairResult *res, uint64_t n_rows, const uint32_t **d_list, uint64_t *n_list, hipStream_t s) {
+  *d_list = nullptr;
+  *n_list = 0;
+  if (n_rows == 0) return;
+  W.flags.ensure((n_rows + 1) * sizeof(uint32_t));
+  W.gpos.ensure((n_rows + 1) * sizeof(uint32_t));
+  W.scan_tmp.ensure(scan_tmp_bytes(n_rows));
+  W.row_list.ensure((n_rows + 1) * sizeof(uint32_t));
+  uint64_t *tot = W.totals.as<uint64_t>();
+  HIPCHK(hipMemsetAsync(W.flags.p, 0, n_rows * sizeof(uint32_t), s));
+  if (res->n_read_pairs)
+    hipLaunchKernelGGL(k_mark_rows, dim3((unsigned)((res->n_read_pairs + 255) / 256)), dim3(256), 0, s, res->d_pairs, res->d_groups,
+                       res->n_read_pairs, n_rows, W.flags.as<uint32_t>());
+  exclusive_scan_u32(W.flags.as<uint32_t>(), W.gpos.as<uint32_t>(), n_rows, tot + 15, W.scan_tmp.p, s);
+  hipLaunchKernelGGL(k_list_rows, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, s, W.flags.as<uint32_t>(), W.gpos.as<uint32_t>(),
+                     n_rows, W.row_list.as<uint32_t>());
+  HIPCHK(hipGetLastError());
+  uint64_t cnt = 0;
+  read_back(&cnt, tot + 15, sizeof cnt, s);
+  *d_list = W.row_list.as<uint32_t>();
+  *n_list = cnt;
+}
+
 // pseudo-assembly + second score screen on the result of pair_and_screen, in place.  Returns false, having
 // changed nothing, when an entry holds more spans than one workgroup's LDS takes (the host then runs the stage).
 bool pseudo_and_rescreen(PairWork &W, PairResult *res, double score_fraction, SortWorkspace &sortws, hipStream_t s) {

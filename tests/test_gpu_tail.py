@@ -184,6 +184,25 @@ def test_alignment_to_sam_with_the_tail_front_on_the_gpu(kslam, oracle, synth, T
     chunks = []
     fst = T.tail_finish_rows(P, R, I, ov, cg, det, md, rp.copy(), pr.copy(), chunks.append)
     sam = b"".join(chunks)
+    # the walk for the rows the pairs refer to only (what the lanes run after the device pairing): those rows'
+    # records equal the full walk's, the others are zero, and the SAM text is the same
+    c.row_details(of_pairs=True)
+    det2, md2 = c.take_row_details(n_out)
+    used = np.zeros(n_out, dtype=bool)
+    for f in ("r1", "r2"):
+        idx = pr[f][pr[f] != kslam.NO_OVERLAP] if hasattr(kslam, "NO_OVERLAP") else pr[f][pr[f] != 0xFFFFFFFF]
+        used[idx] = True
+    assert 0.1 < used.mean() < 0.9
+    for f in ("logp", "nm", "md_len", "flags"):
+        assert (det2[f][used].view(np.uint64 if f == "logp" else det2[f].dtype) ==
+                det[f][used].view(np.uint64 if f == "logp" else det[f].dtype)).all(), f
+    assert not det2["md_len"][~used].any() and not det2["nm"][~used].any() and (det2["logp"][~used] == 0).all()
+    for k in np.nonzero(used)[0][:2000]:
+        a, b = int(det[k]["md_off"]), int(det2[k]["md_off"])
+        assert md[a:a + int(det[k]["md_len"])].tobytes() == md2[b:b + int(det2[k]["md_len"])].tobytes()
+    chunks2 = []
+    T.tail_finish_rows(P, R, I, ov, cg, det2, md2, rp.copy(), pr.copy(), chunks2.append)
+    assert b"".join(chunks2) == sam
     exp, est = T.tail_sam(P, R, I, ov, cg)
     eal, ecig, _ = oracle.align_to_database(rb, gb, oracle.Params.default())
     assert sam == exp == oracle.tail_sam(P, R.view, I.view, eal, ecig)

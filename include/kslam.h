@@ -283,7 +283,8 @@ typedef struct {
   uint64_t n_overlaps;
   uint32_t *cigar_pool;
   uint64_t n_cigar;
-  kslam_row_detail *details;
+  kslam_row_detail *details;    /* one per overlap record; with the device pairing on, filled in for the records the
+                                   alignment pairs refer to (kslam_row_details_of_pairs), zero for the others */
   char *md_pool;
   uint64_t n_md;
   kslam_read_pair *read_pairs;  /* NULL unless kslam_set_pairing switched the device pairing on */

@@ -291,6 +291,29 @@ __global__ __launch_bounds__(256) void k_sw(kslam_overlap *__restrict__ ov, uint
 // it has m >= m0(g) = ceil((score + cost(g)) / match) matches, uses >= m0(g) rows and columns,
 // starts on a diagonal d = j - i in [-(L - m0(g)), W - m0(g)] and stays within g of it.  True when
 // the union of those ranges over all feasible g lies inside [dlo, dlo + ND - 1].
+// the part of the certificate that does not depend on the band: the smallest A(g) = m0(g) - g over the feasible
+// g; INT32_MAX when nothing needs bounding, -1 when the score certifies nothing
+__device__ inline int32_t certificate_amin(int32_t score, int32_t L, int32_t W, const SwParams &p) {
+  if (score <= 0) return -1;
+  const int32_t Lm = min(L, W), ma = p.match;
+  const int32_t m00 = (score + ma - 1) / ma;
+  if (m00 > Lm) return INT32_MAX;
+  int32_t amin = m00;
+  const int32_t room = Lm * ma - score - p.gap_open;
+  if (room >= 0) {
+    int32_t g = 1;
+    if (p.gap_extend < ma) g = min(room / p.gap_extend + 1, 2047);
+    const int32_t m0 = (score + p.gap_open + (g - 1) * p.gap_extend + ma - 1) / ma;
+    amin = min(amin, m0 - g);
+  }
+  return amin;
+}
+__device__ inline bool band_holds(int32_t amin, int32_t L, int32_t W, int32_t dlo, int32_t ND) {
+  if (amin < 0) return false;
+  if (amin == INT32_MAX) return true;
+  return amin - L >= dlo && W - amin <= dlo + ND - 1;
+}
+
 __device__ inline bool band_certifies(int32_t score, int32_t L, int32_t W, int32_t dlo, int32_t ND,
                                       const SwParams &p) {
   if (score <= 0) return false;
@@ -416,9 +439,10 @@ __global__ __launch_bounds__(256) void k_sw_plan(kslam_overlap *__restrict__ ov,
   }
   if (have && t == 0) {
     int choice = T.unknown;   // no diagonal certifies anything (gapped alignment): see sw_scores
+    const int32_t amin = certificate_amin(best, L, W, p);   // (the divisions once, not once per tier)
     for (int k = 0; k < T.n; k++) {
       const int ND = T.nd[k];
-      if (band_certifies(best, L, W, d0 - ND / 2, ND, p)) {
+      if (band_holds(amin, L, W, d0 - ND / 2, ND)) {
         choice = k;
         break;
       }
@@ -749,8 +773,9 @@ __global__ __launch_bounds__(BS) void k_sw_band(kslam_overlap *__restrict__ ov, 
     int dest = -1;
     if (fail) {
       dest = NT_FULL;
+      const int32_t amin = certificate_amin(f.score, L, W, p);
       for (int k = self + 1; k < T.n; k++)
-        if (f.score <= 0 || band_certifies(f.score, L, W, d0 - T.nd[k] / 2, T.nd[k], p)) {
+        if (f.score <= 0 || band_holds(amin, L, W, d0 - T.nd[k] / 2, T.nd[k])) {
           dest = k;   // (nothing found at all: just try the next band)
           break;
         }

@@ -6,8 +6,8 @@ import csv, glob
 rows = list(csv.DictReader(open(glob.glob('/tmp/gp/**/*kernel_trace.csv', recursive=True)[0])))
 def clean(n): return n.replace('(anonymous namespace)::', '').replace('kslam::', '').replace('void ', '').split('(')[0]
 ks = sorted(((int(r['Start_Timestamp']), int(r['End_Timestamp']), clean(r['Kernel_Name'])) for r in rows if 'kslam' in r['Kernel_Name']))
-# last step = from the last k_plan (extract planning) to the end
-starts = [i for i, k in enumerate(ks) if k[2].startswith('k_plan')]
+# last alignment call = from the last k_extract_filter (first kernel of a call) to the end
+starts = [i for i, k in enumerate(ks) if k[2].startswith('k_extract_filter')]
 i0 = starts[-1]
 step = ks[i0:]
 busy = sum(e - s for s, e, _ in step); span = step[-1][1] - step[0][0]

@@ -26,6 +26,7 @@ synth = importlib.import_module("kslam_amd.synth")
 T = importlib.import_module("kslam_amd.tail")
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
+FROM_FASTQ = os.environ.get("KSLAM_SOAK_FASTQ") == "1"     # through kslam_submit_batch_fastq_text instead of pointer arrays
 t_end = time.time() + budget
 seed, rounds, total_bytes = seed0, 0, 0
 while time.time() < t_end:
@@ -63,14 +64,31 @@ while time.time() < t_end:
     qp = (C.c_char_p * n_reads)(*[C.cast(x, C.c_char_p) for x in keep_q])
     lens = np.array([len(b) for b in reads_b], dtype=np.uint32)
     ctx.set_pairing(paired=True, score_threshold=int(P.score_threshold), score_fraction=float(P.score_fraction), stages=7 if pseudo else 3)
-    o, g_, d, m, release = ctx.collect_batch(ctx.submit_batch_full(n_reads, C.cast(bp, C.c_void_p), C.cast(qp, C.c_void_p), lens.ctypes.data))
+    reads_view = R
+    if FROM_FASTQ:     # the same batch as two FASTQ texts: records found, columns cut and identifiers taken on the device
+        half = n_reads // 2
+        eol = [b"\n", b"\r\n"][seed & 1]
+        def text(lo, mate):
+            return b"".join(b"@f%d/%d extra words%s%s%s+%s%s%s" % (i - lo, mate, eol, reads_b[i], eol, eol, quals[i], eol) for i in range(lo, lo + half))
+        t1, t2 = text(0, 1), text(half, 2)
+        h1, h2 = K.HostBuffer(len(t1) + 64), K.HostBuffer(len(t2) + 64)
+        h1.a[:len(t1)] = np.frombuffer(t1, dtype=np.uint8)
+        h2.a[:len(t2)] = np.frombuffer(t2, dtype=np.uint8)
+        o, g_, d, m, release = ctx.collect_batch(ctx.submit_batch_fastq_text(h1.ptr, len(t1), h2.ptr, len(t2)))
+        reads_view = ctx.last_reads
+        assert reads_view.n_reads == n_reads and reads_view.consumed == (len(t1), len(t2))
+    else:
+        o, g_, d, m, release = ctx.collect_batch(ctx.submit_batch_full(n_reads, C.cast(bp, C.c_void_p), C.cast(qp, C.c_void_p), lens.ctypes.data))
     rp, pr, pst = ctx.last_pairs
     Pw = T.TailParams.default(pseudo_assembly=pseudo and not (pst["stages_done"] & 4), score_threshold=int(P.score_threshold),
                               score_fraction=float(P.score_fraction), num_sam_alignments=int(P.num_sam_alignments))
     out = []
-    T.tail_finish_rows(Pw, R, I, o, g_, d, m, rp.copy(), pr.copy(), out.append)
+    T.tail_finish_rows(Pw, reads_view, I, o, g_, d, m, rp.copy(), pr.copy(), out.append)
     got = b"".join(out)
     release()
+    if FROM_FASTQ:
+        h1.close()
+        h2.close()
     ctx.close()
     eal, ecig, _ = O.align_to_database(reads_b, genomes_b, O.Params.default(score_threshold=int(P.score_threshold)))
     exp = O.tail_sam(P, R.view, I.view, eal, ecig)

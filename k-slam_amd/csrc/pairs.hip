@@ -1,6 +1,6 @@
-// pairs.hip -- the first half of the host tail on the device: score screen, read pairing, insert-size
-// statistics, insert-size screen and score-fraction screen, straight
-// from the overlap records the hot path left in HBM.
+// pairs.hip -- the host tail up to the SAM formatter on the device: score screen, read pairing, insert-size
+// statistics, insert-size screen, score-fraction screen, pseudo-assembly and the second score screen
+// (SURVEY.md section 8f rows N1 / N4), straight from the overlap records the hot path left in HBM.
 //
 // Replaces, in the reference:
 //   screenOverlapsByScoreThreshold                      src/Overlap.h:329-341
@@ -10,6 +10,7 @@
 //   getMaxAllowedInsertSize                             src/PairedOverlap.h:314-360
 //   screenPairedAlignmentsByInsertSize(replace = true)  src/PairedOverlap.h:396-436
 //   screenPairedAlignmentsByScore                       src/PairedOverlap.h:361-390
+//   pseudoAssembly (+ the screen by score once more)    src/PairedOverlap.h:480-582, src/SLAM.h:220-227
 // and follows k-slam_amd/host/tail.cpp (pair_stage, max_allowed_insert, screen_stage) decision for
 // decision, including the points where the reference leaves the result to an unstable sort: the pairing
 // "sort" is a merge of the R1 and R2 rows with ties in input order (R1 first), and the two per-read-pair
@@ -19,7 +20,7 @@
 // binary search), its alignment pairs go to a private region of 4 x (its rows) records -- pairing emits
 // at most 2 per row, the insert-size screen at most doubles that -- so nothing is counted twice and no
 // thread waits for another; the survivors are compacted with two scans.  The insert sizes are appended
-// with one atomic per wave and sorted with the library's radix sort; quartiles and the percentile ladder
+// with one atomic per workgroup and sorted with the library's radix sort; quartiles and the percentile ladder
 // are read from the sorted array by index, the sums are exact 64-bit integers (and fall back to the
 // reference's sequential double accumulation on the host when they could exceed 2^53).
 #include <cmath>

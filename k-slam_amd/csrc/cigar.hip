@@ -672,7 +672,51 @@ __global__ __launch_bounds__(256) void k_finalize(kslam_overlap *__restrict__ ov
   if (threadIdx.x == 0) atomicAdd(cells, sm[0] + sm[1] + sm[2] + sm[3]);
 }
 
+// The records of k_finalize WITHOUT their cigars, into a second array: what the device pairing needs (final
+// coordinates) before the cigar stage has run.  Same arithmetic as k_finalize below.
+__global__ __launch_bounds__(256) void k_final_coords(const kslam_overlap *__restrict__ ov, uint64_t n, SwInputs in,
+                                                      kslam_overlap *__restrict__ out) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  kslam_overlap o = ov[i];
+  const uint64_t L = in.read_off[o.read + 1] - in.read_off[o.read];
+  const uint64_t G = in.genome_off[o.entry + 1] - in.genome_off[o.entry];
+  const int64_t s0 = o.rel > 0 ? o.rel : 0;
+  const int64_t wlen = (int64_t)min(L, G - (uint64_t)s0);
+  if (o.revcomp) {
+    const int32_t rb = o.ref_begin, qb = o.query_begin;
+    o.ref_begin = (int32_t)(wlen - (int64_t)(o.ref_end + 1));
+    o.ref_end = (int32_t)(wlen - (int64_t)(rb + 1));
+    o.query_begin = (int32_t)((int64_t)L - (int64_t)(o.query_end + 1));
+    o.query_end = (int32_t)((int64_t)L - (int64_t)(qb + 1));
+  }
+  o.ref_begin += (int32_t)s0;
+  o.ref_end += (int32_t)s0;
+  o.cigar_len = 0;
+  o.cigar_off = 0;
+  out[i] = o;
+}
+// rows no alignment pair refers to: no cigar (neither the inline <n>M nor a banded one)
+__global__ void k_drop_unreferenced(kslam_overlap *__restrict__ ov, uint32_t *__restrict__ bw, const uint32_t *__restrict__ referenced,
+                                    uint64_t n) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || referenced[i]) return;
+  bw[i] = 0;
+  if (ov[i].cigar_len) ov[i].cigar_len = 0;
+}
+
 }  // namespace
+
+void final_coords_copy(const kslam_overlap *d_ov, uint64_t n, SwInputs in, kslam_overlap *d_out, hipStream_t s) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(k_final_coords, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_ov, n, in, d_out);
+  HIPCHK(hipGetLastError());
+}
+void drop_unreferenced_cigars(kslam_overlap *d_ov, uint32_t *d_bw, const uint32_t *d_referenced, uint64_t n, hipStream_t s) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(k_drop_unreferenced, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_ov, d_bw, d_referenced, n);
+  HIPCHK(hipGetLastError());
+}
 
 // ---------------------------------------------------------------------------
 // host driver of the cigar stage

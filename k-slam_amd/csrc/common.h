@@ -248,6 +248,10 @@ struct CigarWork {
 constexpr uint32_t CIG_CAP = 24;  // ops per small temp cigar slot
 // allocates and clears the per-candidate cigar state; call before sw_scores
 void cigar_prepare(CigarWork &W, uint64_t n, hipStream_t s);
+// the records as cigar_finalize will leave them, cigars aside, into d_out (for the pairing between SW and the cigar stage);
+// and: no cigar for the rows whose d_referenced flag is 0
+void final_coords_copy(const kslam_overlap *d_ov, uint64_t n, SwInputs in, kslam_overlap *d_out, hipStream_t s);
+void drop_unreferenced_cigars(kslam_overlap *d_ov, uint32_t *d_bw, const uint32_t *d_referenced, uint64_t n, hipStream_t s);
 // banded DP + traceback into temp slots; returns the total number of cigar ops
 // and the number of "Trace back error" cases (reference would abort there)
 void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, uint32_t lmax, uint32_t *d_bw,

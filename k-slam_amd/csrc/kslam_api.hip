@@ -124,7 +124,7 @@ struct kslam_ctx {
   DevBuf mg_shards, mg_lens, mg_off, mg_scan;
 
   // ---- results of the last align ----
-  DevBuf res_ov, res_cig, res_tmp;
+  DevBuf res_ov, res_cig, res_tmp, fin_copy;
   uint64_t n_res = 0, n_cig = 0;
   kslam_timings tm{};
 };
@@ -452,8 +452,20 @@ float ev_ms(hipEvent_t a, hipEvent_t b) {
   return ms;
 }
 
+// What the pipelined lanes ask align_resident to do between the SW stage and the CIGAR stage of a batch that is ONE
+// chunk: the device pairing (and screens, pseudo-assembly) on the records with their final coordinates, so that
+// the CIGAR stage -- and later the per-row walk -- only runs for the rows some surviving alignment pair refers
+// to (36 % of the rows of the bench workload; the SAM writer asks for no others).
+struct PairingHook {
+  int paired;
+  uint32_t thr;
+  double fraction;
+  uint32_t stages;
+  bool ran = false;    // false: the batch had several chunks (or nothing to pair): the caller pairs afterwards
+};
+
 // the hot path on the resident reads; stop_after_join: only rows a-3..a-6
-void align_resident(kslam_ctx *c, bool stop_after_join, uint64_t *n_raw_out) {
+void align_resident(kslam_ctx *c, bool stop_after_join, uint64_t *n_raw_out, PairingHook *hook = nullptr) {
   if (!c->have_index) throw StatusError{KSLAM_ERR_STATE, "kslam_set_index has not been called"};
   if (!c->have_reads) throw StatusError{KSLAM_ERR_STATE, "no reads loaded"};
   hipStream_t s = c->stream;
@@ -612,6 +624,19 @@ void align_resident(kslam_ctx *c, bool stop_after_join, uint64_t *n_raw_out) {
       sw_scores(cand, m, in, sp, c->max_read_len, c->band0.as<uint32_t>(), c->sww, &n_full, s);
       if (getenv("KSLAM_DEBUG")) fprintf(stderr, "[kslam] SW: %llu candidates, %llu needed the full-matrix kernel\n", (unsigned long long)m, (unsigned long long)n_full);
       HIPCHK(hipEventRecord(c->ev[6], s));
+      if (hook && r0 == 0 && r1 == n && sp.report_cigar &&
+          !(hook->paired && (c->n_reads < 2 || (c->n_reads & 1))) && m < (1ull << 30)) {
+        c->fin_copy.ensure((m + 1) * sizeof(kslam_overlap));
+        final_coords_copy(cand, m, in, c->fin_copy.as<kslam_overlap>(), s);
+        pair_and_screen(c->fin_copy.as<kslam_overlap>(), m, c->r_len.as<uint32_t>(), c->n_reads, hook->paired ? 1 : 0, hook->thr,
+                        hook->fraction, (hook->stages & 1u) != 0, (hook->stages & 2u) != 0, c->pw, c->sortws, &c->pres, s);
+        if (hook->stages & 4u) pseudo_and_rescreen(c->pw, &c->pres, hook->fraction, c->sortws, s);
+        const uint32_t *list = nullptr;
+        uint64_t n_list = 0;
+        referenced_rows(c->pw, &c->pres, m, &list, &n_list, s);      // leaves the per-row flags in c->pw.flags
+        drop_unreferenced_cigars(cand, c->band0.as<uint32_t>(), c->pw.flags.as<uint32_t>(), m, s);
+        hook->ran = true;
+      }
       // ---- a-13: cigar ----
       uint32_t tb_err = 0;
       cigar_traceback(cand, m, in, sp, c->max_read_len, c->band0.as<uint32_t>(), c->cig, &ncig, &tb_err, s);
@@ -635,6 +660,7 @@ void align_resident(kslam_ctx *c, bool stop_after_join, uint64_t *n_raw_out) {
     c->n_cig += ncig;
     r0 = r1;
   }
+  if (hook && hook->ran) c->have_pairs = true;   // c->pres: pairs of THIS result (row numbers and coordinates are the final ones)
   tm.n_overlaps_raw = n_raw_total;
   tm.n_overlaps = c->n_res;
   read_back(&tm.sw_cells, c->cells.p, sizeof(uint64_t), s);
@@ -784,6 +810,15 @@ kslam_status load_reads_from_fastq_text(kslam_ctx *c, kslam_ctx::AsyncJob *job) 
   });
 }
 
+void fill_pair_stats(const PairResult &r, kslam_pair_stats *st) {
+  if (!st) return;
+  memset(st, 0, sizeof *st);
+  st->n_overlaps_screened = r.n_overlaps_screened; st->n_paired_initial = r.n_paired_initial;
+  st->n_insert_sizes = r.n_insert_sizes; st->n_read_pairs = r.n_read_pairs; st->n_pairs = r.n_pairs;
+  st->max_insert_size = r.max_insert_size;
+  st->stages_done = r.stages_done;
+}
+
 void lane_main(kslam_ctx *primary, kslam_ctx::AsyncLane *lane) {
   for (;;) {
     kslam_ctx::AsyncJob *job = nullptr;
@@ -821,11 +856,16 @@ void lane_main(kslam_ctx *primary, kslam_ctx::AsyncLane *lane) {
       // uploads its next batch.
       std::lock_guard<std::mutex> compute(primary->as_compute);
       t2 = now();
-      st = kslam_align_resident(c, nullptr, nullptr);
       const bool want_details = job->qcat || job->fastq;
-      if (st == KSLAM_OK && primary->pairing.stages)
-        st = kslam_pair_screen(c, primary->pairing.paired, primary->pairing.thr, primary->pairing.fraction,
-                               primary->pairing.stages, &job->pstats);
+      PairingHook hook{primary->pairing.paired, primary->pairing.thr, primary->pairing.fraction, primary->pairing.stages};
+      static const bool eager = getenv("KSLAM_EAGER_CIGAR") != nullptr;   // A/B: every CIGAR, pairing afterwards
+      const bool use_hook = primary->pairing.stages && want_details && !eager;
+      st = guarded(c, [&] { align_resident(c, false, nullptr, use_hook ? &hook : nullptr); });
+      if (st == KSLAM_OK && primary->pairing.stages) {
+        if (hook.ran) fill_pair_stats(c->pres, &job->pstats);
+        else st = kslam_pair_screen(c, primary->pairing.paired, primary->pairing.thr, primary->pairing.fraction,
+                                    primary->pairing.stages, &job->pstats);
+      }
       // the per-row walk after the pairing: only the rows the surviving alignment pairs refer to need it
       if (st == KSLAM_OK && want_details)
         st = primary->pairing.stages ? kslam_row_details_of_pairs(c, nullptr) : kslam_row_details(c, nullptr);
@@ -1226,14 +1266,6 @@ kslam_status kslam_take_row_details(kslam_ctx *c, kslam_row_detail **details, ch
   return KSLAM_OK;
 }
 
-static void fill_pair_stats(const PairResult &r, kslam_pair_stats *st) {
-  if (!st) return;
-  memset(st, 0, sizeof *st);
-  st->n_overlaps_screened = r.n_overlaps_screened; st->n_paired_initial = r.n_paired_initial;
-  st->n_insert_sizes = r.n_insert_sizes; st->n_read_pairs = r.n_read_pairs; st->n_pairs = r.n_pairs;
-  st->max_insert_size = r.max_insert_size;
-  st->stages_done = r.stages_done;
-}
 
 kslam_status kslam_pair_screen(kslam_ctx *c, int paired, uint32_t score_threshold, double score_fraction, uint32_t stages,
                                kslam_pair_stats *stats) {

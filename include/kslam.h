@@ -281,7 +281,7 @@ kslam_status kslam_set_pairing(kslam_ctx *ctx, int paired, uint32_t score_thresh
 typedef struct {
   kslam_overlap *overlaps;
   uint64_t n_overlaps;
-  uint32_t *cigar_pool;         /* with the device pairing on and qualities given, a batch that is one internal chunk gets
+  uint32_t *cigar_pool;         /* with the device pairing on and qualities given, the batch gets
                                    the pairing BETWEEN the SW and the CIGAR stage, and CIGARs (like details) only for the
                                    records the alignment pairs refer to; the others carry cigar_len 0.  kslam_align_batch
                                    and the other entries return every CIGAR, as alignToDatabase does. */

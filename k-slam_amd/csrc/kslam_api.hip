@@ -124,7 +124,7 @@ struct kslam_ctx {
   DevBuf mg_shards, mg_lens, mg_off, mg_scan;
 
   // ---- results of the last align ----
-  DevBuf res_ov, res_cig, res_tmp, fin_copy;
+  DevBuf res_ov, res_cig, res_tmp, fin_copy, band0_all;
   uint64_t n_res = 0, n_cig = 0;
   kslam_timings tm{};
 };
@@ -520,6 +520,11 @@ void align_resident(kslam_ctx *c, bool stop_after_join, uint64_t *n_raw_out, Pai
   uint64_t r0 = 0;
   const uint64_t n = c->n_reads;
   uint32_t tb_err_total = 0;
+  // the lanes' order (PairingHook): every chunk up to its SW stage first, then the pairing on the whole batch, then
+  // the CIGAR stage chunk by chunk for the rows the pairs refer to
+  const bool lazy = hook && !stop_after_join && sp.report_cigar && !(hook->paired && (c->n_reads < 2 || (c->n_reads & 1)));
+  struct Deferred { uint64_t first, m; };
+  std::vector<Deferred> deferred;
   while (r0 < n) {
     // ---- chunk [r0, r1) ----
     // as many reads as fit max_chunk_reads and max_chunk_kmers, at least one
@@ -618,32 +623,29 @@ void align_resident(kslam_ctx *c, bool stop_after_join, uint64_t *n_raw_out, Pai
     if (m && !stop_after_join) {
       kslam_overlap *cand = c->res_ov.as<kslam_overlap>() + c->n_res;
       // ---- a-8..a-12: scores and ends ----
-      c->band0.ensure((m + 1) * sizeof(uint32_t));
-      cigar_prepare(c->cig, m, s);
+      uint32_t *band0;
+      if (lazy) {   // the batch's band array: one slice per chunk, kept until the CIGAR stage runs
+        ensure_keep(c->band0_all, (c->n_res + m + 1) * sizeof(uint32_t), c->n_res * sizeof(uint32_t), s);
+        band0 = c->band0_all.as<uint32_t>() + c->n_res;
+      } else {
+        c->band0.ensure((m + 1) * sizeof(uint32_t));
+        band0 = c->band0.as<uint32_t>();
+        cigar_prepare(c->cig, m, s);
+      }
       uint64_t n_full = 0;
-      sw_scores(cand, m, in, sp, c->max_read_len, c->band0.as<uint32_t>(), c->sww, &n_full, s);
+      sw_scores(cand, m, in, sp, c->max_read_len, band0, c->sww, &n_full, s);
       if (getenv("KSLAM_DEBUG")) fprintf(stderr, "[kslam] SW: %llu candidates, %llu needed the full-matrix kernel\n", (unsigned long long)m, (unsigned long long)n_full);
       HIPCHK(hipEventRecord(c->ev[6], s));
-      if (hook && r0 == 0 && r1 == n && sp.report_cigar &&
-          !(hook->paired && (c->n_reads < 2 || (c->n_reads & 1))) && m < (1ull << 30)) {
-        c->fin_copy.ensure((m + 1) * sizeof(kslam_overlap));
-        final_coords_copy(cand, m, in, c->fin_copy.as<kslam_overlap>(), s);
-        pair_and_screen(c->fin_copy.as<kslam_overlap>(), m, c->r_len.as<uint32_t>(), c->n_reads, hook->paired ? 1 : 0, hook->thr,
-                        hook->fraction, (hook->stages & 1u) != 0, (hook->stages & 2u) != 0, c->pw, c->sortws, &c->pres, s);
-        if (hook->stages & 4u) pseudo_and_rescreen(c->pw, &c->pres, hook->fraction, c->sortws, s);
-        const uint32_t *list = nullptr;
-        uint64_t n_list = 0;
-        referenced_rows(c->pw, &c->pres, m, &list, &n_list, s);      // leaves the per-row flags in c->pw.flags
-        drop_unreferenced_cigars(cand, c->band0.as<uint32_t>(), c->pw.flags.as<uint32_t>(), m, s);
-        hook->ran = true;
+      if (lazy) {
+        deferred.push_back(Deferred{c->n_res, m});
+      } else {
+        // ---- a-13: cigar ----
+        uint32_t tb_err = 0;
+        cigar_traceback(cand, m, in, sp, c->max_read_len, band0, c->cig, &ncig, &tb_err, s);
+        tb_err_total += tb_err;
+        ensure_keep(c->res_cig, (c->n_cig + ncig + 1) * sizeof(uint32_t), c->n_cig * sizeof(uint32_t), s);
+        cigar_finalize(cand, m, in, c->max_read_len, c->cig, band0, c->res_cig.as<uint32_t>(), c->n_cig, c->cells.as<uint64_t>(), s);
       }
-      // ---- a-13: cigar ----
-      uint32_t tb_err = 0;
-      cigar_traceback(cand, m, in, sp, c->max_read_len, c->band0.as<uint32_t>(), c->cig, &ncig, &tb_err, s);
-      tb_err_total += tb_err;
-      ensure_keep(c->res_cig, (c->n_cig + ncig + 1) * sizeof(uint32_t), c->n_cig * sizeof(uint32_t), s);
-      cigar_finalize(cand, m, in, c->max_read_len, c->cig, c->band0.as<uint32_t>(), c->res_cig.as<uint32_t>(), c->n_cig,
-                     c->cells.as<uint64_t>(), s);
     } else {
       HIPCHK(hipEventRecord(c->ev[6], s));
     }
@@ -659,6 +661,38 @@ void align_resident(kslam_ctx *c, bool stop_after_join, uint64_t *n_raw_out, Pai
     c->n_res += m;
     c->n_cig += ncig;
     r0 = r1;
+  }
+  if (lazy && c->n_res) {
+    HIPCHK(hipEventRecord(c->ev[6], s));
+    const uint64_t nr = c->n_res;
+    if (nr < (1ull << 30)) {   // (else: no device pairing possible; every CIGAR, the caller pairs on the host)
+      c->fin_copy.ensure((nr + 1) * sizeof(kslam_overlap));
+      final_coords_copy(c->res_ov.as<kslam_overlap>(), nr, in, c->fin_copy.as<kslam_overlap>(), s);
+      pair_and_screen(c->fin_copy.as<kslam_overlap>(), nr, c->r_len.as<uint32_t>(), c->n_reads, hook->paired ? 1 : 0, hook->thr,
+                      hook->fraction, (hook->stages & 1u) != 0, (hook->stages & 2u) != 0, c->pw, c->sortws, &c->pres, s);
+      if (hook->stages & 4u) pseudo_and_rescreen(c->pw, &c->pres, hook->fraction, c->sortws, s);
+      const uint32_t *list = nullptr;
+      uint64_t n_list = 0;
+      referenced_rows(c->pw, &c->pres, nr, &list, &n_list, s);      // leaves the per-row flags in c->pw.flags
+      drop_unreferenced_cigars(c->res_ov.as<kslam_overlap>(), c->band0_all.as<uint32_t>(), c->pw.flags.as<uint32_t>(), nr, s);
+      hook->ran = true;
+    }
+    for (const Deferred &d : deferred) {
+      kslam_overlap *cand = c->res_ov.as<kslam_overlap>() + d.first;
+      uint32_t *band0 = c->band0_all.as<uint32_t>() + d.first;
+      uint64_t ncig = 0;
+      uint32_t tb_err = 0;
+      cigar_prepare(c->cig, d.m, s);
+      cigar_traceback(cand, d.m, in, sp, c->max_read_len, band0, c->cig, &ncig, &tb_err, s);
+      tb_err_total += tb_err;
+      ensure_keep(c->res_cig, (c->n_cig + ncig + 1) * sizeof(uint32_t), c->n_cig * sizeof(uint32_t), s);
+      cigar_finalize(cand, d.m, in, c->max_read_len, c->cig, band0, c->res_cig.as<uint32_t>(), c->n_cig, c->cells.as<uint64_t>(), s);
+      c->n_cig += ncig;
+    }
+    HIPCHK(hipEventRecord(c->ev[7], s));
+    HIPCHK(hipStreamSynchronize(s));
+    tm.ms_cigar += ev_ms(c->ev[6], c->ev[7]);
+    tm.ms_total += ev_ms(c->ev[6], c->ev[7]);
   }
   if (hook && hook->ran) c->have_pairs = true;   // c->pres: pairs of THIS result (row numbers and coordinates are the final ones)
   tm.n_overlaps_raw = n_raw_total;

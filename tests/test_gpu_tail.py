@@ -242,6 +242,26 @@ def test_alignment_to_sam_with_the_tail_front_on_the_gpu(kslam, oracle, synth, T
     assert c.last_pairs is None
     release()
     c.close()
+    # a batch the library splits into several internal chunks: the lanes still pair once, on the whole batch, between
+    # the chunks' SW stages and their CIGAR stages
+    c2 = kslam.Context(max_kmers_per_chunk=60000)
+    c2.set_index(gb)
+    c2.set_pairing(paired=True, stages=7 if pseudo else 3)
+    for _ in range(2):
+        o, g, d, m, release = c2.collect_batch(c2.submit_batch_full(len(rb), C.cast(bp, C.c_void_p), C.cast(qp, C.c_void_p), lens.ctypes.data))
+        lrp, lpr, lst = c2.last_pairs
+        out = []
+        Pw = T.TailParams.default(pseudo_assembly=pseudo and not (lst["stages_done"] & 4))
+        T.tail_finish_rows(Pw, R, I, o, g, d, m, lrp.copy(), lpr.copy(), out.append)
+        assert b"".join(out) == exp
+        # CIGARs only where a pair refers to the row
+        _, live = _compacted(lrp, lpr)          # (the second screen shrinks groups in place: only their live records count)
+        used = np.zeros(len(o), dtype=bool)
+        for f in ("r1", "r2"):
+            used[live[f][live[f] != 0xFFFFFFFF]] = True
+        assert not o["cigar_len"][~used].any() and o["cigar_len"][used].all()
+        release()
+    c2.close()
 
 
 def test_round2_entry_points_refuse_misuse_loudly(kslam, synth):

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define KSLAM_ABI_VERSION 6
+#define KSLAM_ABI_VERSION 7
 #define KSLAM_K 32u /* src/Globals.h:25 */
 
 typedef enum {
@@ -116,9 +116,23 @@ typedef struct kslam_ctx kslam_ctx;
 
 /* ---- lifecycle ------------------------------------------------------- */
 uint32_t kslam_abi_version(void);
+/* One line: ABI version, host compiler and libstdc++ the library was built with, and whether THAT
+ * libstdc++'s std::sort permutes like csrc/gnu_sort.h (the device stages of rows N1 / N4 reproduce the
+ * reference's std::sort permutations, src/PairedOverlap.h:369, 403, 527, with it; the host tail calls
+ * std::sort itself).  kslam_check_std_sort runs that comparison (once per process: ~6000 tie-heavy,
+ * ordered, all-equal and median-of-three-killer arrays) and returns 1 when every array came out
+ * identical; when it returns 0, kslam_pair_screen* / kslam_set_pairing refuse the device stages
+ * (KSLAM_ERR_UNSUPPORTED) and the tail has to run on the host.  Neither needs a device. */
+const char *kslam_version(void);
+int kslam_check_std_sort(uint64_t *n_arrays);
 kslam_status kslam_create(const kslam_params *params, kslam_ctx **out);
 void kslam_destroy(kslam_ctx *ctx);
 const char *kslam_last_error(const kslam_ctx *ctx);
+/* The KSLAM_* environment switches (kernel choice, buffer sizing, debug output; none of
+ * them changes a result) are read ONCE, by kslam_create, never on the batch path.  kslam_reload_tuning reads
+ * them again for this context and its worker lanes -- for variant tests and tuning scripts that flip a
+ * switch between two batches; a production host never calls it.  Not while batches are in flight. */
+kslam_status kslam_reload_tuning(kslam_ctx *ctx);
 
 /* ---- the index: const GenbankIndex& (src/GenbankTools.h:187-220) ------
  * entries[j].bases, already upper-cased by the DB builder

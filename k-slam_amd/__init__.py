@@ -16,7 +16,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libkslam_hip.so")
+# KSLAM_LIB: another build of the same ABI (tools/kprof.sh loads the measurement-only `make ABLATE=1` library)
+LIB_PATH = os.environ.get("KSLAM_LIB") or os.path.join(_HERE, "libkslam_hip.so")
 
 KMER_DT = np.dtype([("kmer", "<u8"), ("meta", "<u4"), ("offset", "<u4")])
 OVERLAP_TEMP_DT = np.dtype([("read", "<u4"), ("entry", "<u4"), ("rel", "<i4"),
@@ -38,7 +39,7 @@ STATUS = {0: "OK", 1: "ERR_ARG", 2: "ERR_NO_DEVICE", 3: "ERR_OOM", 4: "ERR_UNSUP
           5: "ERR_STATE", 6: "ERR_INTERNAL"}
 
 # every symbol include/kslam.h declares
-EXPORTS = ["kslam_abi_version", "kslam_create", "kslam_destroy", "kslam_last_error",
+EXPORTS = ["kslam_abi_version", "kslam_version", "kslam_check_std_sort", "kslam_create", "kslam_destroy", "kslam_last_error", "kslam_reload_tuning",
            "kslam_set_index", "kslam_set_index_device", "kslam_align_batch", "kslam_free_batch",
            "kslam_align_batch_async", "kslam_wait_batch", "kslam_load_qualities", "kslam_load_qualities_device",
            "kslam_row_details", "kslam_take_row_details", "kslam_free_pinned", "kslam_submit_batch",
@@ -120,10 +121,13 @@ def lib():
         L = C.CDLL(LIB_PATH)
         vp, u64, u32 = C.c_void_p, C.c_uint64, C.c_uint32
         L.kslam_abi_version.restype = u32
+        L.kslam_version.restype = C.c_char_p
+        L.kslam_check_std_sort.argtypes = [C.POINTER(u64)]
         L.kslam_create.argtypes = [C.POINTER(Params), C.POINTER(vp)]
         L.kslam_destroy.argtypes = [vp]
         L.kslam_last_error.restype = C.c_char_p
         L.kslam_last_error.argtypes = [vp]
+        L.kslam_reload_tuning.argtypes = [vp]
         L.kslam_set_index.argtypes = [vp, u64, vp, vp]
         L.kslam_set_index_device.argtypes = [vp, u64, vp, vp]
         L.kslam_align_batch.argtypes = [vp, u64, vp, vp, C.POINTER(vp), C.POINTER(u64),
@@ -226,6 +230,11 @@ class Context:
     def _chk(self, st):
         if st != 0:
             raise KslamError(st, self._L.kslam_last_error(self._h).decode())
+
+    def reload_tuning(self):
+        """kslam_reload_tuning: the KSLAM_* environment switches are read at kslam_create; a test that flips one
+        between two batches of the same context calls this"""
+        self._chk(self._L.kslam_reload_tuning(self._h))
 
     # ---- const GenbankIndex& ----
     def set_index(self, entries):

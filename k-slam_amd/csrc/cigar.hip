@@ -76,7 +76,11 @@ struct CigJob {
   uint8_t *scratch;
   uint64_t wave_slab;   // scratch bytes per wavefront
   uint32_t *err;        // [0] traceback errors
-  uint32_t variant;     // timing ablations (KSLAM_CIGAR_VARIANT), 0 in production
+#ifdef KSLAM_ABLATE
+  uint32_t variant;     // timing ablations (KSLAM_CIGAR_VARIANT): measurement-only build
+#else
+  static constexpr uint32_t variant = 0;   // compiled out of the product build
+#endif
   // where candidates go that are not finished by this launch (nullptr: the host re-lists by flags)
   uint32_t *next_list = nullptr, *next_count = nullptr;         // band doubled: the next class
   uint32_t *special_list = nullptr, *special_count = nullptr;   // handed back by the systolic kernel
@@ -731,7 +735,7 @@ void cigar_prepare(CigarWork &W, uint64_t n, hipStream_t s) {
 }
 
 void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, uint32_t lmax, uint32_t *d_bw,
-                     CigarWork &W, uint64_t *n_cigar_out, uint32_t *n_tb_err, hipStream_t s) {
+                     CigarWork &W, uint64_t *n_cigar_out, uint32_t *n_tb_err, const Tuning &tune, hipStream_t s) {
   *n_cigar_out = 0;
   *n_tb_err = 0;
   if (n == 0) return;
@@ -768,7 +772,7 @@ void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, u
     // workload (one-lane kernel / systolic, ms): c3 2.2 / 1.4, c4 3.1 / 1.5, c5 2.1 / 0.2; the narrow
     // classes, where 5 of 16 diagonal slots are live and the single-lane traceback dominates, stay
     // on the one-lane kernel (c0-c2: 3.9 / 5.4).
-    const int sys_mask = getenv("KSLAM_CIGAR_SYS") ? atoi(getenv("KSLAM_CIGAR_SYS")) : 0xF8;
+    const int sys_mask = tune.cigar_sys_mask;
     struct Route {
       const uint32_t *list = nullptr;
       uint32_t *next_list = nullptr, *next_count = nullptr, *special_list = nullptr, *special_count = nullptr,
@@ -805,10 +809,12 @@ void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, u
         J.scratch = W.scratch.as<uint8_t>();
         J.wave_slab = slab;
         J.err = d_err;
-        { const char *cv = getenv("KSLAM_CIGAR_VARIANT"); J.variant = cv ? (uint32_t)atoi(cv) : 0u; }
+#ifdef KSLAM_ABLATE
+        J.variant = tune.cigar_variant;
+#endif
         const unsigned nb = (unsigned)((J.m + NG - 1) / NG);
         // the tracebacks of this launch in a kernel of their own (KSLAM_CIGAR_TB=inline: at the end of the DP kernel)
-        const bool tb_inline = getenv("KSLAM_CIGAR_TB") && getenv("KSLAM_CIGAR_TB")[0] == 'i';
+        const bool tb_inline = tune.cigar_tb_inline;
         if (!tb_inline) {
           W.tb_list.ensure(((uint64_t)J.m + 1) * sizeof(uint32_t));
           J.tb_list = W.tb_list.as<uint32_t>();
@@ -840,8 +846,7 @@ void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, u
       // more occupancy than the traceback gained (class 1: 7.9 ms against 2.8 ms).
       const size_t base_lane = (size_t)lmax + 2 + (size_t)3 * Y.W1 * sizeof(int16_t);
       const uint32_t wpr_fit = (Y.wd + 5) / 6;
-      const char *force = getenv("KSLAM_CIGAR_DIRS");
-      const bool dir_in_lds = force && force[0] == 'l' &&
+      const bool dir_in_lds = tune.cigar_dirs_lds &&
                               (base_lane + (size_t)lmax * wpr_fit * 4) * 16 + 64 <= 64 * 1024;
       Y.wpr = dir_in_lds ? wpr_fit : 0;
       const size_t per_lane = base_lane + (size_t)lmax * Y.wpr * 4;
@@ -858,7 +863,7 @@ void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, u
                               reinterpret_cast<const void *>(&k_banded_lds<4>)})
           HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       // narrow bands: the band in registers (KSLAM_CIGAR_REG=0 turns it off)
-      const bool use_reg = !(getenv("KSLAM_CIGAR_REG") && getenv("KSLAM_CIGAR_REG")[0] == '0');
+      const bool use_reg = tune.cigar_reg;
       const uint32_t reg_bw = (!use_reg || big || Y.wpr) ? 0u : (slot_bw <= 2 ? 2u : (slot_bw <= 4 ? 4u : 0u));
       uint64_t slab = Y.wpr ? 256 : (uint64_t)lmax * std::max<uint32_t>(Y.wd, reg_bw ? 8u : 0u) * nl;   // direction
       slab = (slab + 255) & ~255ull;   // bytes per block; the register variant stores <= 8 bytes per row and lane
@@ -881,7 +886,9 @@ void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, u
         J.scratch = W.scratch.as<uint8_t>();
         J.wave_slab = slab;
         J.err = d_err;
-        { const char *cv = getenv("KSLAM_CIGAR_VARIANT"); J.variant = cv ? (uint32_t)atoi(cv) : 0u; }
+#ifdef KSLAM_ABLATE
+        J.variant = tune.cigar_variant;
+#endif
         if (reg_bw == 2) hipLaunchKernelGGL(k_banded_lds<2>, dim3((unsigned)nb_here), dim3(64), lds, s, J, in, p, Y);
         else if (reg_bw == 4) hipLaunchKernelGGL(k_banded_lds<4>, dim3((unsigned)nb_here), dim3(64), lds, s, J, in, p, Y);
         else hipLaunchKernelGGL(k_banded_lds<0>, dim3((unsigned)nb_here), dim3(64), lds, s, J, in, p, Y);
@@ -891,7 +898,7 @@ void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, u
     // Band classes 0..6 (bw <= 64): one partition of the candidates by class, then class after class;
     // an attempt that falls short of the score doubles its band, i.e. moves up exactly one class, and
     // the kernels append such candidates to the next class's list themselves.
-    const bool debug = getenv("KSLAM_DEBUG") != nullptr;
+    const bool debug = tune.debug;
     W.cls.ensure(n);
     for (int k = 0; k < 8; k++) W.cls_list[k].ensure((n + 1) * sizeof(uint32_t));
     W.special.ensure((n + 1) * sizeof(uint32_t));

@@ -31,6 +31,32 @@ struct StatusError {
   std::string msg;
 };
 
+// The KSLAM_* environment switches.  They are read ONCE per context, when
+// kslam_create builds it (kslam_reload_tuning re-reads them: variant tests and tuning scripts), never on
+// the batch path, and none of them changes a result.  The measurement-only ablations that DO change
+// results (parts of kernels switched off) only exist in a -DKSLAM_ABLATE build (make ABLATE=1).
+struct Tuning {
+  bool debug = false;                 // KSLAM_DEBUG: per-stage counts on stderr
+  bool sw_full = false;               // KSLAM_SW_FULL=1: every candidate on the full-matrix scoring kernel
+  bool sw_no48 = false, sw_no96 = false;   // KSLAM_SW_NO48 / _NO96: drop a band tier
+  int sw_unknown_nd = 0;              // KSLAM_SW_UNKNOWN_ND: where gapped candidates start (0: by read length)
+  int cigar_sys_mask = 0xF8;          // KSLAM_CIGAR_SYS: band classes that run on the systolic kernel
+  bool cigar_reg = true;              // KSLAM_CIGAR_REG=0: no band-in-registers kernel
+  bool cigar_dirs_lds = false;        // KSLAM_CIGAR_DIRS=lds: direction words in LDS
+  bool cigar_tb_inline = false;       // KSLAM_CIGAR_TB=inline: systolic tracebacks at the end of the DP kernel
+  int bucket_bits_max = 27;           // KSLAM_BUCKET_BITS
+  int bucket_bits_exact = 0;          // KSLAM_BUCKET_BITS_EXACT (0: sized from the index)
+  int filter_bits = -1;               // KSLAM_FILTER_BITS (-1: sized from the index, 0: no filter)
+  int sort_bytes = -1;                // KSLAM_SORT_BYTES (-1: what the bucket table needs)
+  int lanes = 2;                      // KSLAM_LANES
+  bool eager_cigar = false;           // KSLAM_EAGER_CIGAR
+  bool pageable_columns = false;      // KSLAM_PAGEABLE_COLUMNS
+#ifdef KSLAM_ABLATE
+  uint32_t sw_ablate = 0, cigar_variant = 0, filter_ablate = 0;   // KSLAM_SW_ABLATE / _CIGAR_VARIANT / _FILTER_ABLATE
+#endif
+};
+Tuning read_tuning();   // kslam_api.hip
+
 // grow-only device buffer
 struct DevBuf {
   void *p = nullptr;
@@ -121,7 +147,7 @@ void filter_build(const uint64_t *d_sorted_keys, uint32_t n, uint32_t log2_bits,
 // reads d_off[0..n_reads] (gap 1, ids = position in d_off): surviving records appended at *d_cursor
 // (which ends as their number); nothing is written beyond `cap` (the caller reruns with a larger buffer)
 void extract_filtered(const uint8_t *d_bases, const uint64_t *d_off, uint32_t n_reads, const void *d_filter,
-                      uint32_t log2_bits, uint4 *d_out, uint64_t *d_cursor, uint64_t cap, hipStream_t s);
+                      uint32_t log2_bits, uint4 *d_out, uint64_t *d_cursor, uint64_t cap, const Tuning &tune, hipStream_t s);
 
 // ---------------------------------------------------------- radix_sort.hip
 struct SortPass {
@@ -210,7 +236,11 @@ struct SwParams {
   int32_t match, mismatch, gap_open, gap_extend;
   uint32_t score_threshold;
   int32_t report_cigar;
+#ifdef KSLAM_ABLATE
   uint32_t ablate = 0;   // KSLAM_SW_ABLATE (measurement only): 1 = no sweep, 2 = no staging either, 3 = one turn, result accepted
+#else
+  static constexpr uint32_t ablate = 0;   // the ablations are compiled out of the product build
+#endif
 };
 struct SwInputs {
   const uint8_t *read_bases;
@@ -233,7 +263,7 @@ struct SwWork {
 };
 // *n_full_out: candidates that needed the full-matrix kernel (the rest ran in a proven band)
 void sw_scores(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, uint32_t max_read_len,
-               uint32_t *d_band0, SwWork &W, uint64_t *n_full_out, hipStream_t s);
+               uint32_t *d_band0, SwWork &W, uint64_t *n_full_out, const Tuning &tune, hipStream_t s);
 
 // Stable 8-way partition of the element numbers 0..n-1 by d_bins[i] (bins >= 8 are left out):
 // d_lists[k] receives bin k's numbers in order, d_counts[k] its size (sw.hip).
@@ -255,7 +285,7 @@ void drop_unreferenced_cigars(kslam_overlap *d_ov, uint32_t *d_bw, const uint32_
 // banded DP + traceback into temp slots; returns the total number of cigar ops
 // and the number of "Trace back error" cases (reference would abort there)
 void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, uint32_t lmax, uint32_t *d_bw,
-                     CigarWork &W, uint64_t *n_cigar_out, uint32_t *n_tb_err, hipStream_t s);
+                     CigarWork &W, uint64_t *n_cigar_out, uint32_t *n_tb_err, const Tuning &tune, hipStream_t s);
 // un-flip + absolute coordinates, cigar gather into pool[pool_base ...)
 void cigar_finalize(kslam_overlap *d_ov, uint64_t n, SwInputs in, uint32_t lmax, CigarWork &W,
                     const uint32_t *d_bw, uint32_t *d_pool, uint64_t pool_base, uint64_t *d_cells, hipStream_t s);

@@ -117,6 +117,11 @@ __global__ __launch_bounds__(FW * 64) void k_extract_filter(const uint8_t *__res
                                                             uint4 *__restrict__ out,
                                                             unsigned long long *__restrict__ cursor, uint64_t cap,
                                                             uint32_t ablate) {
+#ifdef KSLAM_ABLATE
+#define KSLAM_FILTER_ABLATED(bit) ((ablate & (bit)) != 0)   // measurement-only build: parts of the kernel switched off
+#else
+#define KSLAM_FILTER_ABLATED(bit) false
+#endif
   __shared__ uint32_t packed[FW][LWORDS];
   __shared__ uint4 stage[STAGE];
   __shared__ uint32_t staged;              // slots handed out (may count past STAGE)
@@ -169,8 +174,13 @@ __global__ __launch_bounds__(FW * 64) void k_extract_filter(const uint8_t *__res
     // one more atomic per workgroup and trip instead of one per wave and 64 k-mers -- 250-bp reads ran
     // 26 x slower through that overflow path (28.9 ms) than they do now.
     if (i) {
+      // The decision must be the same in every wave: all of them read `staged` between two barriers, so
+      // that no wave is already adding to it (keep_record of trip i) while another has yet to read it --
+      // waves that disagreed would pair the barriers of flush_stage with the wrong ones.
       __syncthreads();
-      if (staged >= STAGE / 2) flush_stage();   // (workgroup-uniform: `staged` is shared)
+      const bool half_full = staged >= STAGE / 2;
+      __syncthreads();
+      if (half_full) flush_stage();
     }
     if (i >= r_cnt) continue;
     const uint64_t s0 = offset_of(i);
@@ -232,14 +242,14 @@ __global__ __launch_bounds__(FW * 64) void k_extract_filter(const uint8_t *__res
       const uint32_t qa = q0 + lane, qb = q0 + 64 + lane;
       const Cut ca = cut(qa), cb = cut(qb);
       Probe pa, pb;
-      if (ablate & 2u) {   // measurement only: no minimizer (a pseudo-random line per k-mer)
+      if (KSLAM_FILTER_ABLATED(2u)) {   // measurement only: no minimizer (a pseudo-random line per k-mer)
         pa.piece = (uint32_t)((ca.fwd * 0x9E3779B97F4A7C15ull) >> (64 - line_bits - 3)); pa.s0 = pa.s1 = pa.s2 = pa.s3 = (uint32_t)ca.rc & 31u;
         pb.piece = (uint32_t)((cb.fwd * 0x9E3779B97F4A7C15ull) >> (64 - line_bits - 3)); pb.s0 = pb.s1 = pb.s2 = pb.s3 = (uint32_t)cb.rc & 31u;
       } else {
         pa = probe_of(ca.fwd, ca.rc, line_bits); pb = probe_of(cb.fwd, cb.rc, line_bits);
       }
       uint4 fa, fb;
-      if (ablate & 1u) {   // measurement only: no probe load
+      if (KSLAM_FILTER_ABLATED(1u)) {   // measurement only: no probe load
         fa = make_uint4(pa.piece, pa.piece >> 3, pa.piece >> 5, 0x11111111u); fb = make_uint4(pb.piece, pb.piece >> 2, pb.piece >> 7, 0x11111111u);
       } else {
         fa = filter[pa.piece];
@@ -250,6 +260,7 @@ __global__ __launch_bounds__(FW * 64) void k_extract_filter(const uint8_t *__res
     }
   }
   flush_stage();
+#undef KSLAM_FILTER_ABLATED
 }
 
 }  // namespace
@@ -265,14 +276,19 @@ void filter_build(const uint64_t *d_sorted_keys, uint32_t n, uint32_t log2_bits,
 }
 
 void extract_filtered(const uint8_t *d_bases, const uint64_t *d_off, uint32_t n_reads, const void *d_filter,
-                      uint32_t log2_bits, uint4 *d_out, uint64_t *d_cursor, uint64_t cap, hipStream_t s) {
+                      uint32_t log2_bits, uint4 *d_out, uint64_t *d_cursor, uint64_t cap, const Tuning &tune, hipStream_t s) {
   HIPCHK(hipMemsetAsync(d_cursor, 0, sizeof(uint64_t), s));
   if (n_reads == 0) return;
   const uint32_t per_block = FW * RPW;
   hipLaunchKernelGGL(k_extract_filter, dim3((n_reads + per_block - 1) / per_block), dim3(FW * 64), 0, s, d_bases, d_off,
                      n_reads, (const uint4 *)d_filter, log2_bits - 10, d_out,
                      reinterpret_cast<unsigned long long *>(d_cursor), cap,
-                     (uint32_t)(getenv("KSLAM_FILTER_ABLATE") ? atoi(getenv("KSLAM_FILTER_ABLATE")) : 0));
+#ifdef KSLAM_ABLATE
+                     tune.filter_ablate);
+#else
+                     0u);
+  (void)tune;
+#endif
   HIPCHK(hipGetLastError());
 }
 

@@ -23,6 +23,7 @@ using namespace kslam;
 
 struct kslam_ctx {
   kslam_params prm{};
+  Tuning tune;                   // the KSLAM_* environment switches as they stood at kslam_create
   int device = 0;
   hipStream_t stream = nullptr;
   std::string err;
@@ -78,13 +79,15 @@ struct kslam_ctx {
   // ---- device pairing / screens (pairs.hip) ----
   PairWork pw;
   PairResult pres{};
-  bool have_pairs = false;
+  bool have_pairs = false;        // c->pres holds pairs (of res_ov, or of records handed in)
+  bool pairs_of_result = false;   // ... and they index the rows of the current res_ov (kslam_pair_screen / the lane hook)
   DevBuf pr_ov, pr_len;          // kslam_pair_screen_overlaps: the records and read lengths handed in
   struct { int paired = 1; uint32_t thr = 0; double fraction = 0.95; uint32_t stages = 0; } pairing;   // for the lanes
 
   // ---- pipelined entry (kslam_align_batch_async): worker lanes, each a sibling context that BORROWS
   // this context's index (same device pointers, never freed by the sibling) ----
   bool borrowed_index = false;
+  bool holds_hook = false;       // this context counts towards the page-locked column allocator being installed
   struct AsyncJob {
     uint64_t ticket = 0;
     uint64_t n_reads = 0;
@@ -135,6 +138,40 @@ struct kslam_multi {
   DevBuf rows_out, pool_out;     // on ctx[0]'s device: the batch-global result
   std::vector<DevBuf> send;      // per shard, on its own device: its records in batch terms, ready to copy
 };
+
+namespace kslam {
+Tuning read_tuning() {
+  Tuning t;
+  auto flag = [](const char *name) { return getenv(name) != nullptr; };
+  auto num = [](const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; };
+  auto starts = [](const char *name, char ch) { const char *e = getenv(name); return e && e[0] == ch; };
+  t.debug = flag("KSLAM_DEBUG");
+  t.sw_full = starts("KSLAM_SW_FULL", '1');
+  t.sw_no48 = flag("KSLAM_SW_NO48");
+  t.sw_no96 = flag("KSLAM_SW_NO96");
+  t.sw_unknown_nd = num("KSLAM_SW_UNKNOWN_ND", 0);
+  t.cigar_sys_mask = num("KSLAM_CIGAR_SYS", 0xF8);
+  t.cigar_reg = !starts("KSLAM_CIGAR_REG", '0');
+  t.cigar_dirs_lds = starts("KSLAM_CIGAR_DIRS", 'l');
+  t.cigar_tb_inline = starts("KSLAM_CIGAR_TB", 'i');
+  t.bucket_bits_max = std::min(28, std::max(8, num("KSLAM_BUCKET_BITS", 27)));
+  t.bucket_bits_exact = flag("KSLAM_BUCKET_BITS_EXACT") ? std::min(28, std::max(8, num("KSLAM_BUCKET_BITS_EXACT", 0))) : 0;
+  if (flag("KSLAM_FILTER_BITS")) {
+    const int v = num("KSLAM_FILTER_BITS", 0);
+    t.filter_bits = v <= 0 ? 0 : std::min(36, std::max(20, v));
+  }
+  if (flag("KSLAM_SORT_BYTES")) t.sort_bytes = std::max(0, num("KSLAM_SORT_BYTES", 0));
+  t.lanes = std::min(8, std::max(1, num("KSLAM_LANES", 2)));
+  t.eager_cigar = flag("KSLAM_EAGER_CIGAR");
+  t.pageable_columns = flag("KSLAM_PAGEABLE_COLUMNS");
+#ifdef KSLAM_ABLATE
+  t.sw_ablate = (uint32_t)num("KSLAM_SW_ABLATE", 0);
+  t.cigar_variant = (uint32_t)num("KSLAM_CIGAR_VARIANT", 0);
+  t.filter_ablate = (uint32_t)num("KSLAM_FILTER_ABLATE", 0);
+#endif
+  return t;
+}
+}  // namespace kslam
 
 namespace {
 
@@ -196,6 +233,14 @@ static void *pinned_plain_alloc(size_t bytes) {
   plain_blocks().push_back(q);
   return q;
 }
+void *pinned_alloc(size_t bytes);
+void pinned_free(void *p, size_t bytes);
+// the allocator the host-side FASTQ parser uses for its big column blocks while a GPU context exists
+// (workers.hpp: big_alloc_hook): installed by the first kslam_create, removed by the last kslam_destroy
+const kslam_host::BigAlloc pinned_hook{pinned_alloc, pinned_free};
+std::mutex &hook_mutex() { static std::mutex m; return m; }
+int &hook_users() { static int n = 0; return n; }
+
 void *pinned_alloc(size_t bytes) {
   static const bool plain = getenv("KSLAM_PINNED_PLAIN") != nullptr;
   if (plain) return pinned_plain_alloc(bytes);
@@ -377,10 +422,9 @@ void build_index(kslam_ctx *c) {
   if (m) hipLaunchKernelGGL(k_split_soa, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, (const uint4 *)sorted,
                             (uint32_t)m, c->gk_key.as<uint64_t>(), c->gk_meta.as<uint32_t>(),
                             c->gk_off.as<uint32_t>());
-  uint32_t bits = 8, max_bits = 27;   // 27: ~2.3 genome k-mers per bucket for a 5 Gb database (537 MB table)
-  if (const char *e = getenv("KSLAM_BUCKET_BITS")) max_bits = std::min(28u, std::max(8u, (uint32_t)atoi(e)));
+  uint32_t bits = 8, max_bits = (uint32_t)c->tune.bucket_bits_max;   // 27: ~2.3 genome k-mers per bucket for a 5 Gb database (537 MB table)
   while (bits < max_bits && (m >> (bits + 2)) != 0) bits++;   // 2 to 4 keys per bucket (measured: 3.06 ms at 27 bits, 3.24 at 26, 3.13 at 28)
-  if (const char *e = getenv("KSLAM_BUCKET_BITS_EXACT")) bits = std::min(28u, std::max(8u, (uint32_t)atoi(e)));   // tuning
+  if (c->tune.bucket_bits_exact) bits = (uint32_t)c->tune.bucket_bits_exact;   // tuning
   c->bucket_bits = bits;
   c->g_bucket.ensure(((1ull << bits) + 2) * sizeof(uint32_t));
   build_bucket_table(c->gk_key.as<uint64_t>(), (uint32_t)m, bits, c->g_bucket.as<uint32_t>(), s);
@@ -390,10 +434,7 @@ void build_index(kslam_ctx *c) {
   {
     uint32_t fb = 20;
     while (fb < 35 && ((uint64_t)1 << fb) < m * 12) fb++;
-    if (const char *e = getenv("KSLAM_FILTER_BITS")) {
-      const int v = atoi(e);
-      fb = v <= 0 ? 0u : std::min(36u, std::max(20u, (uint32_t)v));
-    }
+    if (c->tune.filter_bits >= 0) fb = (uint32_t)c->tune.filter_bits;
     c->filter_bits = fb;
     if (fb) {
       c->g_filter.ensure(filter_bytes(fb));
@@ -475,6 +516,7 @@ void align_resident(kslam_ctx *c, bool stop_after_join, uint64_t *n_raw_out, Pai
   c->n_cig = 0;
   c->have_details = false;
   c->have_pairs = false;
+  c->pairs_of_result = false;
   c->cells.ensure(sizeof(uint64_t));
   HIPCHK(hipMemsetAsync(c->cells.p, 0, sizeof(uint64_t), s));
   uint64_t n_raw_total = 0;
@@ -511,7 +553,7 @@ void align_resident(kslam_ctx *c, bool stop_after_join, uint64_t *n_raw_out, Pai
   std::vector<SortPass> kpasses;
   {
     uint32_t nbytes = (std::min(c->bucket_bits, 24u) + 7) / 8;
-    if (const char *e = getenv("KSLAM_SORT_BYTES")) nbytes = (uint32_t)std::max(0, atoi(e));
+    if (c->tune.sort_bytes >= 0) nbytes = (uint32_t)c->tune.sort_bytes;
     nbytes = std::min(8u, std::max(c->filter_bits ? 0u : 1u, nbytes));   // 0: look the survivors up unsorted
     for (uint32_t b = 8 - nbytes; b < 8; b++) kpasses.push_back(SortPass{b / 4, 8 * (b % 4), 0});
   }
@@ -554,7 +596,7 @@ void align_resident(kslam_ctx *c, bool stop_after_join, uint64_t *n_raw_out, Pai
       for (int attempt = 0; attempt < 2; attempt++) {
         c->recs_a.ensure((cap + 1) * sizeof(uint4));
         extract_filtered(c->r_bases.as<uint8_t>(), d_off, (uint32_t)nr, c->g_filter.p, c->filter_bits,
-                         c->recs_a.as<uint4>(), d_tot + 2, cap, s);
+                         c->recs_a.as<uint4>(), d_tot + 2, cap, c->tune, s);
         read_back(&nk, d_tot + 2, sizeof nk, s);
         if (nk <= cap) break;
         cap = nk;
@@ -633,15 +675,15 @@ void align_resident(kslam_ctx *c, bool stop_after_join, uint64_t *n_raw_out, Pai
         cigar_prepare(c->cig, m, s);
       }
       uint64_t n_full = 0;
-      sw_scores(cand, m, in, sp, c->max_read_len, band0, c->sww, &n_full, s);
-      if (getenv("KSLAM_DEBUG")) fprintf(stderr, "[kslam] SW: %llu candidates, %llu needed the full-matrix kernel\n", (unsigned long long)m, (unsigned long long)n_full);
+      sw_scores(cand, m, in, sp, c->max_read_len, band0, c->sww, &n_full, c->tune, s);
+      if (c->tune.debug) fprintf(stderr, "[kslam] SW: %llu candidates, %llu needed the full-matrix kernel\n", (unsigned long long)m, (unsigned long long)n_full);
       HIPCHK(hipEventRecord(c->ev[6], s));
       if (lazy) {
         deferred.push_back(Deferred{c->n_res, m});
       } else {
         // ---- a-13: cigar ----
         uint32_t tb_err = 0;
-        cigar_traceback(cand, m, in, sp, c->max_read_len, band0, c->cig, &ncig, &tb_err, s);
+        cigar_traceback(cand, m, in, sp, c->max_read_len, band0, c->cig, &ncig, &tb_err, c->tune, s);
         tb_err_total += tb_err;
         ensure_keep(c->res_cig, (c->n_cig + ncig + 1) * sizeof(uint32_t), c->n_cig * sizeof(uint32_t), s);
         cigar_finalize(cand, m, in, c->max_read_len, c->cig, band0, c->res_cig.as<uint32_t>(), c->n_cig, c->cells.as<uint64_t>(), s);
@@ -683,7 +725,7 @@ void align_resident(kslam_ctx *c, bool stop_after_join, uint64_t *n_raw_out, Pai
       uint64_t ncig = 0;
       uint32_t tb_err = 0;
       cigar_prepare(c->cig, d.m, s);
-      cigar_traceback(cand, d.m, in, sp, c->max_read_len, band0, c->cig, &ncig, &tb_err, s);
+      cigar_traceback(cand, d.m, in, sp, c->max_read_len, band0, c->cig, &ncig, &tb_err, c->tune, s);
       tb_err_total += tb_err;
       ensure_keep(c->res_cig, (c->n_cig + ncig + 1) * sizeof(uint32_t), c->n_cig * sizeof(uint32_t), s);
       cigar_finalize(cand, d.m, in, c->max_read_len, c->cig, band0, c->res_cig.as<uint32_t>(), c->n_cig, c->cells.as<uint64_t>(), s);
@@ -694,7 +736,7 @@ void align_resident(kslam_ctx *c, bool stop_after_join, uint64_t *n_raw_out, Pai
     tm.ms_cigar += ev_ms(c->ev[6], c->ev[7]);
     tm.ms_total += ev_ms(c->ev[6], c->ev[7]);
   }
-  if (hook && hook->ran) c->have_pairs = true;   // c->pres: pairs of THIS result (row numbers and coordinates are the final ones)
+  if (hook && hook->ran) c->have_pairs = c->pairs_of_result = true;   // c->pres: pairs of THIS result (row numbers and coordinates are the final ones)
   tm.n_overlaps_raw = n_raw_total;
   tm.n_overlaps = c->n_res;
   read_back(&tm.sw_cells, c->cells.p, sizeof(uint64_t), s);
@@ -864,7 +906,7 @@ void lane_main(kslam_ctx *primary, kslam_ctx::AsyncLane *lane) {
       lane->q.pop_front();
     }
     kslam_ctx *c = lane->c;
-    static const bool dbg = getenv("KSLAM_DEBUG") != nullptr;
+    const bool dbg = primary->tune.debug;
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = now();
     double t1 = 0, t2 = 0, t3 = 0;
@@ -892,7 +934,7 @@ void lane_main(kslam_ctx *primary, kslam_ctx::AsyncLane *lane) {
       t2 = now();
       const bool want_details = job->qcat || job->fastq;
       PairingHook hook{primary->pairing.paired, primary->pairing.thr, primary->pairing.fraction, primary->pairing.stages};
-      static const bool eager = getenv("KSLAM_EAGER_CIGAR") != nullptr;   // A/B: every CIGAR, pairing afterwards
+      const bool eager = primary->tune.eager_cigar;   // A/B: every CIGAR, pairing afterwards
       const bool use_hook = primary->pairing.stages && want_details && !eager;
       st = guarded(c, [&] { align_resident(c, false, nullptr, use_hook ? &hook : nullptr); });
       if (st == KSLAM_OK && primary->pairing.stages) {
@@ -927,22 +969,42 @@ void lane_main(kslam_ctx *primary, kslam_ctx::AsyncLane *lane) {
 
 void ensure_lanes(kslam_ctx *c) {
   if (!c->lanes.empty()) return;
-  int n_lanes = 2;
-  if (const char *e = getenv("KSLAM_LANES")) n_lanes = std::min(8, std::max(1, atoi(e)));
+  const int n_lanes = c->tune.lanes;
+  // built aside and published only when every lane has its context AND its thread: a failure half way
+  // (page-locked or device memory) must not leave lanes without workers behind, to which the next
+  // submit would queue a job nobody ever runs
+  std::vector<kslam_ctx::AsyncLane *> fresh;
+  auto undo = [&] {
+    for (auto *l : fresh) { kslam_destroy(l->c); delete l; }
+    fresh.clear();
+  };
   for (int k = 0; k < n_lanes; k++) {
     kslam_ctx *lc = nullptr;
     const kslam_status s1 = kslam_create(&c->prm, &lc);
     if (s1 != KSLAM_OK) {
       const std::string msg = lc ? lc->err : "lane context";
       kslam_destroy(lc);
+      undo();
       throw StatusError{s1, msg};
     }
+    lc->tune = c->tune;
     share_index(lc, c);
     auto *l = new kslam_ctx::AsyncLane();
     l->c = lc;
-    c->lanes.push_back(l);
+    fresh.push_back(l);
   }
-  for (auto *l : c->lanes) l->th = std::thread(lane_main, c, l);
+  size_t started = 0;
+  try {
+    for (auto *l : fresh) { l->th = std::thread(lane_main, c, l); started++; }
+  } catch (const std::exception &e) {
+    { std::lock_guard<std::mutex> lk(c->as_mu); c->as_stop = true; }
+    c->as_cv.notify_all();
+    for (size_t k = 0; k < started; k++) fresh[k]->th.join();
+    c->as_stop = false;
+    undo();
+    throw StatusError{KSLAM_ERR_OOM, std::string("could not start a lane thread: ") + e.what()};
+  }
+  c->lanes = std::move(fresh);
 }
 
 void stop_lanes(kslam_ctx *c) {
@@ -991,11 +1053,12 @@ kslam_status kslam_create(const kslam_params *params, kslam_ctx **out) {
   }
   kslam_status st = guarded(c, [&] {
     validate_params(c->prm);
-    // from now on the FASTQ parser's big column blocks are page-locked (DMA-able as they stand)
-    if (!getenv("KSLAM_PAGEABLE_COLUMNS")) {
-      kslam_host::BigAlloc &h = kslam_host::big_alloc_hook();
-      h.alloc = pinned_alloc;
-      h.release = pinned_free;
+    c->tune = read_tuning();
+    // while a context exists the FASTQ parser's big column blocks are page-locked (DMA-able as they stand)
+    if (!c->tune.pageable_columns) {
+      std::lock_guard<std::mutex> lk(hook_mutex());
+      if (hook_users()++ == 0) kslam_host::big_alloc_hook().store(&pinned_hook, std::memory_order_release);
+      c->holds_hook = true;
     }
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     for (auto &ev : c->ev) HIPCHK(hipEventCreate(&ev));
@@ -1009,6 +1072,11 @@ kslam_status kslam_create(const kslam_params *params, kslam_ctx **out) {
 void kslam_destroy(kslam_ctx *c) {
   if (!c) return;
   if (!c->lanes.empty()) stop_lanes(c);   // workers first: they use this context's index
+  if (c->holds_hook) {
+    std::lock_guard<std::mutex> lk(hook_mutex());
+    if (--hook_users() == 0) kslam_host::big_alloc_hook().store(nullptr, std::memory_order_release);
+    c->holds_hook = false;
+  }
   if (c->device >= 0) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
@@ -1043,6 +1111,17 @@ void kslam_destroy(kslam_ctx *c) {
 }
 
 const char *kslam_last_error(const kslam_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+kslam_status kslam_reload_tuning(kslam_ctx *c) {
+  if (!c) return KSLAM_ERR_ARG;
+  std::lock_guard<std::mutex> lk(c->as_mu);
+  const Tuning t = read_tuning();
+  const int lanes = c->lanes.empty() ? t.lanes : c->tune.lanes;   // the number of lanes is fixed once they exist
+  c->tune = t;
+  c->tune.lanes = lanes;
+  for (auto *l : c->lanes) l->c->tune = c->tune;
+  return KSLAM_OK;
+}
 
 kslam_status kslam_set_index(kslam_ctx *c, uint64_t n_entries, const char *const *bases, const uint64_t *lens) {
   return guarded(c, [&] {
@@ -1244,7 +1323,9 @@ kslam_status kslam_load_qualities_device(kslam_ctx *c, const void *d_concat_qual
 static kslam_status row_details_impl(kslam_ctx *c, uint64_t *n_md, bool of_pairs) {
   return guarded(c, [&] {
     if (!c->have_qual) throw StatusError{KSLAM_ERR_STATE, "kslam_load_qualities has not been called for this batch"};
-    if (of_pairs && !c->have_pairs) throw StatusError{KSLAM_ERR_STATE, "kslam_pair_screen has not been called for this result"};
+    if (of_pairs && !(c->have_pairs && c->pairs_of_result))
+      throw StatusError{KSLAM_ERR_STATE, "kslam_pair_screen has not been called for this result (pairs of records handed "
+                                         "in through kslam_pair_screen_overlaps do not refer to its rows)"};
     if (!c->d_tables.p) {
       // matchTable / misMatchTable of src/SAM.h:33-48, with the host's libm (the values the host tail uses)
       double t[200];
@@ -1301,20 +1382,28 @@ kslam_status kslam_take_row_details(kslam_ctx *c, kslam_row_detail **details, ch
 }
 
 
+// the device stages stand on csrc/gnu_sort.h being this build's std::sort (host/selfcheck.cpp)
+static void require_std_sort_parity() {
+  if (!kslam_check_std_sort(nullptr))
+    throw StatusError{KSLAM_ERR_UNSUPPORTED, std::string("this build's std::sort does not permute like csrc/gnu_sort.h (") +
+                                                 kslam_version() + "): run pairing and screens on the host (include/kslam_tail.h)"};
+}
+
 kslam_status kslam_pair_screen(kslam_ctx *c, int paired, uint32_t score_threshold, double score_fraction, uint32_t stages,
                                kslam_pair_stats *stats) {
   return guarded(c, [&] {
+    require_std_sort_parity();
     if (!c->have_reads) throw StatusError{KSLAM_ERR_STATE, "no batch loaded"};
     if (paired && (c->n_reads < 2 || (c->n_reads & 1)))
       throw StatusError{KSLAM_ERR_ARG, "paired data needs an even, non-zero number of reads ([R1 block | R2 block])"};
     if (c->n_res >= (1ull << 30)) throw StatusError{KSLAM_ERR_UNSUPPORTED, "2^30 or more overlaps in one batch"};
-    c->have_pairs = false;
+    c->have_pairs = c->pairs_of_result = false;
     pair_and_screen(c->res_ov.as<kslam_overlap>(), c->n_res, c->r_len.as<uint32_t>(), c->n_reads, paired ? 1 : 0,
                     score_threshold, score_fraction, (stages & 1u) != 0, (stages & 2u) != 0, c->pw, c->sortws, &c->pres,
                     c->stream);
     if (stages & 4u) pseudo_and_rescreen(c->pw, &c->pres, score_fraction, c->sortws, c->stream);
     HIPCHK(hipStreamSynchronize(c->stream));
-    c->have_pairs = true;
+    c->have_pairs = c->pairs_of_result = true;
     fill_pair_stats(c->pres, stats);
   });
 }
@@ -1323,11 +1412,12 @@ kslam_status kslam_pair_screen_overlaps(kslam_ctx *c, const kslam_overlap *overl
                                         const uint32_t *read_lens, uint64_t n_reads, int paired, uint32_t score_threshold,
                                         double score_fraction, uint32_t stages, kslam_pair_stats *stats) {
   return guarded(c, [&] {
+    require_std_sort_parity();
     if ((n_overlaps && !overlaps) || (n_reads && !read_lens)) throw StatusError{KSLAM_ERR_ARG, "null argument"};
     if (paired && (n_reads < 2 || (n_reads & 1)))
       throw StatusError{KSLAM_ERR_ARG, "paired data needs an even, non-zero number of reads ([R1 block | R2 block])"};
     if (n_overlaps >= (1ull << 30)) throw StatusError{KSLAM_ERR_UNSUPPORTED, "2^30 or more overlaps in one batch"};
-    c->have_pairs = false;
+    c->have_pairs = c->pairs_of_result = false;
     c->pr_ov.ensure((n_overlaps + 1) * sizeof(kslam_overlap));
     c->pr_len.ensure((n_reads + 1) * sizeof(uint32_t));
     if (n_overlaps)
@@ -1377,6 +1467,10 @@ kslam_status kslam_debug_wave_sort(kslam_ctx *c, const int32_t *keys, const uint
 
 kslam_status kslam_set_pairing(kslam_ctx *c, int paired, uint32_t score_threshold, double score_fraction, uint32_t stages) {
   if (!c) return KSLAM_ERR_ARG;
+  if (stages & 7u) {
+    const kslam_status st = guarded(c, [&] { require_std_sort_parity(); });
+    if (st != KSLAM_OK) return st;
+  }
   std::lock_guard<std::mutex> lk(c->as_mu);
   c->pairing.paired = paired; c->pairing.thr = score_threshold; c->pairing.fraction = score_fraction;
   c->pairing.stages = stages & 7u;

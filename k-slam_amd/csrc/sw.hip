@@ -840,7 +840,7 @@ void encode_bases(const uint8_t *d_src, uint8_t *d_dst, uint64_t n, hipStream_t 
 }
 
 void sw_scores(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, uint32_t max_read_len,
-               uint32_t *d_band0, SwWork &W, uint64_t *n_full_out, hipStream_t s) {
+               uint32_t *d_band0, SwWork &W, uint64_t *n_full_out, const Tuning &tune, hipStream_t s) {
   if (n_full_out) *n_full_out = 0;
   if (n == 0) return;
   if (max_read_len > 511) throw StatusError{KSLAM_ERR_UNSUPPORTED, "reads longer than 511 bases are not supported yet"};
@@ -848,13 +848,14 @@ void sw_scores(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, uint32_
   const int lm = max_read_len <= 160 ? 0 : (max_read_len <= 256 ? 1 : 2);
   const uint32_t *full_list = nullptr;
   uint64_t n_full = n;
-  const char *force_full = getenv("KSLAM_SW_FULL");
   // the band kernels carry gE x (i + j) on top of the score and 2 gE inside the 6-bit table fields
   const bool band_ok = (int64_t)(p.match + 2 * p.gap_extend) * (int64_t)max_read_len <= 8187 &&
                        p.match + 2 * p.gap_extend <= 31;
-  const bool debug = getenv("KSLAM_DEBUG") != nullptr;
-  if (const char *ab = getenv("KSLAM_SW_ABLATE")) p.ablate = (uint32_t)atoi(ab);
-  if (!(force_full && force_full[0] == '1') && band_ok) {
+  const bool debug = tune.debug;
+#ifdef KSLAM_ABLATE
+  p.ablate = tune.sw_ablate;
+#endif
+  if (!tune.sw_full && band_ok) {
     // banded tiers of 16 / 32 / 48 / 64 / 96 (/ 128 for reads > 160 bases) diagonals; k_sw_plan sends each
     // candidate to the narrowest one its seed diagonal already certifies, the others start at 48 (64 for the
     // longer reads); whatever fails a tier's certificate is appended to the list of the tier its score
@@ -863,8 +864,7 @@ void sw_scores(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, uint32_
     memset(&T, 0, sizeof T);
     {
       const int nd0[5] = {16, 32, 48, 64, 96}, nd1[6] = {16, 32, 48, 64, 96, 128};
-      const bool no48 = getenv("KSLAM_SW_NO48") != nullptr;   // ablation
-      const bool no96 = getenv("KSLAM_SW_NO96") != nullptr;   // ablation
+      const bool no48 = tune.sw_no48, no96 = tune.sw_no96;   // A/B of the tier set
       T.n = 0;
       for (int k = 0; k < (lm == 0 ? 5 : 6); k++) {
         const int nd = lm == 0 ? nd0[k] : nd1[k];
@@ -877,7 +877,7 @@ void sw_scores(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, uint32_
     // first (2.25 us) and 48 again for most.
     {
       // (reads of 161-256 bases: 64 -- 83.2 against 85.0 ms per 1 M pairs of 250 bp, 89.5 when started at 32)
-      const int unk = getenv("KSLAM_SW_UNKNOWN_ND") ? atoi(getenv("KSLAM_SW_UNKNOWN_ND")) : (lm == 0 ? 48 : 64);
+      const int unk = tune.sw_unknown_nd ? tune.sw_unknown_nd : (lm == 0 ? 48 : 64);
       T.unknown = 1;
       for (int k = 0; k < T.n; k++) if (T.nd[k] <= unk) T.unknown = k;
     }

@@ -212,12 +212,12 @@ struct BlockCache {
     const size_t cap = bytes + bytes / 8 + 64;
     // big blocks (bases, qualities, identifiers of a batch) come from the library's page-locked allocator
     // once a GPU context has installed it (workers.hpp: big_alloc_hook), so they reach the device by DMA
-    const BigAlloc hook = big_alloc_hook();
+    const BigAlloc *hook = big_alloc_hook().load(std::memory_order_acquire);
     void *p = nullptr;
     void (*rel)(void *, size_t) = nullptr;
-    if (hook.alloc && cap >= (8u << 20)) {
-      p = hook.alloc(cap);
-      if (p) rel = hook.release;
+    if (hook && hook->alloc && cap >= (8u << 20)) {
+      p = hook->alloc(cap);
+      if (p) rel = hook->release;
     }
     if (!p) {
       p = malloc(cap);

@@ -140,8 +140,10 @@ struct BigAlloc {
   void *(*alloc)(size_t) = nullptr;   // nullptr: malloc
   void (*release)(void *, size_t) = nullptr;
 };
-inline BigAlloc &big_alloc_hook() {
-  static BigAlloc h;
+// One pointer to an immutable struct, so that a parser thread reading the hook while a context is being
+// created or destroyed sees either no hook or a complete one (never `alloc` without `release`).
+inline std::atomic<const BigAlloc *> &big_alloc_hook() {
+  static std::atomic<const BigAlloc *> h{nullptr};
   return h;
 }
 

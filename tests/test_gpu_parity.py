@@ -472,6 +472,7 @@ def test_banded_sw_equals_full_matrix_sw(kslam, synth, monkeypatch, read_len, fr
     c.set_index(gb)
     a, ac = c.align_batch(rb)
     monkeypatch.setenv("KSLAM_SW_FULL", "1")
+    c.reload_tuning()                     # the switches are read at kslam_create, not per batch
     b, bc = c.align_batch(rb)
     monkeypatch.delenv("KSLAM_SW_FULL")
     c.close()
@@ -507,6 +508,7 @@ def test_every_kernel_variant_gives_the_same_alignments(kslam, synth, monkeypatc
     for env in variants:
         for k, v in env.items():
             monkeypatch.setenv(k, v)
+        c.reload_tuning()                 # the switches are read at kslam_create, not per batch
         got, gcig = c.align_batch(rb)
         for k in env:
             monkeypatch.delenv(k)

@@ -89,6 +89,17 @@ kslam_status kslam_fastq_index_pair(const char *r1, uint64_t len1, const char *r
                                     uint64_t *consumed1, uint64_t *consumed2);
 void kslam_fastq_layout_free(kslam_fastq_layout *layout);
 
+/* Batch boundaries without parsing: where the reference's stream would stand after reading max_records more
+ * records from text[0..len) (getSequencesFromFASTQFile's loop, src/FASTQsequence.h:129-165, as the batch loop of
+ * src/SLAM.h:193-207 calls it) -- the byte after the fourth line of record max_records.  *complete = 1 and
+ * *end = that position when the text holds that many whole records; otherwise *end = len and *complete = at_eof
+ * (at the true end of the stream the rest is the last, shorter batch; of a prefix, more bytes are needed).
+ * A streaming host cuts its batches with this (terminators are only counted, 64 MiB per round on all usable
+ * CPUs) and hands each window to kslam_submit_batch_fastq_text (include/kslam.h), which indexes it on the
+ * device; batch k+1 can then be submitted before batch k's index exists. */
+kslam_status kslam_fastq_batch_end(const char *text, uint64_t len, uint64_t max_records, int at_eof, int threads,
+                                   uint64_t *end, int *complete);
+
 #ifdef __cplusplus
 }
 #endif

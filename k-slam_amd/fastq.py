@@ -12,7 +12,7 @@ from .tail import ReadsView
 
 # every symbol include/kslam_fastq.h declares
 EXPORTS = ["kslam_fastq_parse", "kslam_fastq_parse_pair", "kslam_reads_free", "kslam_fastq_index_pair",
-           "kslam_fastq_layout_free"]
+           "kslam_fastq_layout_free", "kslam_fastq_batch_end"]
 
 _vp, _u64 = C.c_void_p, C.c_uint64
 
@@ -41,6 +41,7 @@ def lib():
         L.kslam_fastq_index_pair.argtypes = [_vp, _u64, _vp, _u64, _u64, C.c_int, C.c_int, P(ReadsColumns),
                                              P(Layout), P(_u64), P(_u64)]
         L.kslam_fastq_layout_free.argtypes = [P(Layout)]
+        L.kslam_fastq_batch_end.argtypes = [_vp, _u64, _u64, C.c_int, C.c_int, P(_u64), P(C.c_int)]
         L.kslam_fastq_layout_free.restype = None
         L.kslam_reads_free.argtypes = [P(ReadsColumns)]
         L.kslam_reads_free.restype = None
@@ -146,3 +147,10 @@ def parse_pair(r1, r2, max_pairs=0, at_eof=True, threads=0):
     _chk(lib().kslam_fastq_parse_pair(r1, len(r1), r2, len(r2), max_pairs, int(at_eof), threads,
                                       C.byref(cols), C.byref(u1), C.byref(u2)))
     return Batch(cols), int(u1.value), int(u2.value)
+
+
+def batch_end(text_ptr, length, max_records, at_eof=True, threads=0):
+    """kslam_fastq_batch_end on a text ADDRESS -> (end, complete): the byte after record `max_records`"""
+    end, done = _u64(), C.c_int()
+    _chk(lib().kslam_fastq_batch_end(text_ptr, length, max_records, int(at_eof), threads, C.byref(end), C.byref(done)))
+    return int(end.value), bool(done.value)

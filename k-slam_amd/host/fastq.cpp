@@ -421,6 +421,64 @@ kslam_status kslam_fastq_index_pair(const char *r1, uint64_t len1, const char *r
   });
 }
 
+// Where the batch loop of src/SLAM.h:193-207 would leave a stream after one more batch: the byte after the
+// max_records-th record's fourth line.  Only terminators are COUNTED here (no fields, no index): 64 MiB of
+// text per round over all workers, stopping in the round that holds the last line wanted.
+kslam_status kslam_fastq_batch_end(const char *text, uint64_t len, uint64_t max_records, int at_eof, int threads,
+                                   uint64_t *end, int *complete) {
+  return guarded([&] {
+    if (!end || !complete) fail(KSLAM_ERR_ARG, "null output argument");
+    if (len && !text) fail(KSLAM_ERR_ARG, "null text");
+    *end = len;
+    *complete = 0;
+    if (max_records == 0) { *complete = at_eof != 0; return; }
+    uint64_t scan_len = len;   // (a trailing "\r" of a prefix may be half of "\r\n": index_stream's rule)
+    if (!at_eof && len && text[len - 1] == '\r') scan_len = len - 1;
+    const int nt = thread_count(threads);
+    const uint64_t want = 4 * max_records, chunk = 1 << 20, round_chunks = 64;
+    uint64_t have = 0;
+    for (uint64_t base = 0; base < scan_len; base += chunk * round_chunks) {
+      const uint64_t stop = std::min(scan_len, base + chunk * round_chunks);
+      const size_t n_chunks = (size_t)((stop - base + chunk - 1) / chunk);
+      std::vector<uint64_t> count(n_chunks, 0);
+      Pool::get().tasks(nt, n_chunks, [&](size_t c) {
+        const uint64_t lo = base + c * chunk, hi = std::min(stop, lo + chunk);
+        uint64_t k = 0, p = lo;
+        const uint64_t ones = 0x0101010101010101ull, high = 0x8080808080808080ull;
+        while (p < hi) {
+          while (p + 8 <= hi) {   // skip 8 bytes at a time while none of them is LF or CR
+            uint64_t w;
+            memcpy(&w, text + p, 8);
+            const uint64_t a = w ^ (ones * 0x0A), b = w ^ (ones * 0x0D);
+            if ((((a - ones) & ~a) | ((b - ones) & ~b)) & high) break;
+            p += 8;
+          }
+          const uint64_t lim = std::min(hi, p + 8);
+          for (; p < lim; p++)
+            if ((text[p] == '\n' || text[p] == '\r') && is_event(text, p)) k++;
+        }
+        count[c] = k;
+      });
+      for (size_t c = 0; c < n_chunks; c++) {
+        if (have + count[c] >= want) {   // the line wanted ends in this chunk
+          const uint64_t lo = base + c * chunk, hi = std::min(stop, lo + chunk);
+          for (uint64_t p = lo; p < hi; p++)
+            if ((text[p] == '\n' || text[p] == '\r') && is_event(text, p) && ++have == want) {
+              *end = line_after(text, len, p);
+              *complete = 1;
+              return;
+            }
+          fail(KSLAM_ERR_INTERNAL, "kslam_fastq_batch_end: count and locate disagree");
+        }
+        have += count[c];
+      }
+    }
+    // fewer than 4 x max_records terminated lines: at the true end of the stream the rest is the last batch
+    // (the reference reads on to the end: index_stream's `consumed = len`); of a prefix, more bytes are needed
+    *complete = at_eof != 0;
+  });
+}
+
 void kslam_fastq_layout_free(kslam_fastq_layout *layout) {
   if (!layout) return;
   cache().put(layout->bases_at);

@@ -36,6 +36,9 @@
 #include <vector>
 
 #include "../../include/kslam_tail.h"
+#include <cerrno>
+#include <unistd.h>
+
 #include "workers.hpp"
 
 namespace {
@@ -1688,6 +1691,22 @@ kslam_status kslam_tail_finish_write_rows(const kslam_tail_params *params, const
     st.ms_sam = now_ms() - t1;
     if (stats) *stats = st;
   });
+}
+
+// a kslam_write_fn that streams to a file descriptor: `user` points to the int
+int kslam_write_fd(void *user, const char *data, uint64_t len) {
+  if (!user) return 1;
+  const int fd = *static_cast<const int *>(user);
+  while (len) {
+    const ssize_t w = ::write(fd, data, (size_t)std::min<uint64_t>(len, 1ull << 30));
+    if (w < 0) {
+      if (errno == EINTR) continue;
+      return 1;
+    }
+    data += w;
+    len -= (uint64_t)w;
+  }
+  return 0;
 }
 
 void kslam_tail_release_buffers(void) {

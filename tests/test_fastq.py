@@ -215,3 +215,42 @@ def test_parsed_batch_feeds_the_tail(kslam, F):
     sam, st = T.tail_sam(T.TailParams.default(report_cigar=False), batch, index, ov, np.zeros(0, np.uint32))
     lines = sam.split(b"\n")
     assert lines[0].startswith(b"p1\t") and lines[1].startswith(b"p1\t") and st.n_read_pairs == 1
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_batch_end_is_where_the_parser_stops(F, seed):
+    """kslam_fastq_batch_end only counts line terminators; it must name the stream position the parser reports
+    after max_records records (the reference's ifstream position between two calls of the batch loop,
+    src/SLAM.h:193-207), for every line-ending flavour, at end of stream and on a prefix."""
+    import ctypes as C
+    rng = np.random.default_rng(500 + seed)
+    text = make_text(rng, int(rng.integers(1, 300)), truncate=seed % 3 == 2, blank_tail=seed % 2)
+    if seed == 4:
+        text = text.rstrip(b"\r\n") + b"\r"
+    if seed == 5:
+        text = make_text(rng, 3000, eol_mix=False) * 30          # > 64 MiB would be a round; this spans many 1 MiB chunks
+    buf = C.create_string_buffer(text, len(text) + 1)
+    ptr = C.addressof(buf)
+    total, _ = F.parse(text)
+    for at_eof in (True, False):
+        for n in (1, 2, 7, total.n_reads, total.n_reads + 1, 10 * total.n_reads + 3):
+            if n == 0:
+                continue
+            batch, used = F.parse(text, max_reads=n, at_eof=at_eof, threads=2)
+            end, complete = F.batch_end(ptr, len(text), n, at_eof, threads=3)
+            if batch.n_reads == n and (complete or not at_eof):
+                assert complete and end == used, (n, at_eof)
+            else:           # fewer whole records than asked for
+                assert end == len(text) and complete == at_eof, (n, at_eof)
+                if at_eof:
+                    assert used == len(text)
+    # cutting a stream with batch_end and parsing the windows = parsing it in calls of n records
+    pos, got = 0, []
+    while pos < len(text):
+        end, complete = F.batch_end(ptr + pos, len(text) - pos, 11, True)
+        # (a window cut by batch_end ends right after a terminator, so "at end of stream" is safe for inner windows
+        #  too -- and needed: a lone "\r" closing the window is a whole terminator, batch_end saw the byte after it)
+        b, used = F.parse(text[pos:pos + end], at_eof=True)
+        got += records(b)
+        pos += end
+    assert got == records(total)

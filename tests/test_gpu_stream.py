@@ -1,0 +1,166 @@
+"""The reference's batch loop, several batches long (metagenomicAnalysis_Low_Mem, src/SLAM.h:159-268):
+one FASTQ pair streamed in batches of `--num-reads-at-once` pairs through
+  kslam_fastq_batch_end -> kslam_submit_batch_fastq_text (GPU: FASTQ index, alignment, pairing, insert-size
+  statistics, screens, pseudo-assembly, per-row walk) -> kslam_tail_finish_write_rows -> kslam_write_fd
+  -> kslam_tail_classify -> kslam_taxreport_add_batch
+with one SAM file appended to and the taxonomy accumulated over the batches (src/SLAM.h:234-249), against
+the oracle chain driven with the SAME batch boundaries (the insert-size limit is a per-batch statistic,
+src/PairedOverlap.h:314-360, so the boundaries are part of the result)."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _make_case(synth, tmp_path, n_pairs, eol, seed=2031):
+    from test_gpu_end_to_end import _taxdb_text, _fastq_text
+    D = importlib.import_module("kslam_amd.db")
+    n_species, n_strains = 4, 3
+    rng = np.random.default_rng(seed)
+    genomes = synth.make_genomes(seed % 1000, n_species, n_strains, 30000, strain_sub=0.02, strain_indel=0.001,
+                                 shared_segment=2500)
+    reads, _ = synth.make_paired_reads(seed % 1000 + 1, genomes, n_pairs, read_len=120, frag_mean=320, frag_sd=40,
+                                       sub_rate=0.015, indel_rate=0.003, n_rate=0.001, edge_frac=0.04, unmapped_frac=0.05)
+    gb = synth.to_bytes(genomes)
+    entries = [{"bases": g, "taxonomyID": 1000 + i if i != 5 else 0, "genbankID": 7000 + i,
+                "locusTag": b"NC_%06d.1" % i, "isPlasmid": i % 4 == 3,
+                # gene locus tags make sortResults' key (count, cdsStart, locusTag; src/MetagenomicResults.h:262-271) total:
+                # without them genes of different strains tie there and the order is std::sort's (unstable) choice
+                "genes": [{"geneName": b"gene%d" % k, "proteinID": b"WP_%d.1" % (100 * i + k), "locusTag": b"LT%02d_%02d" % (i, k),
+                           "referenceSequence": b"NC_%06d" % i,
+                           "product": b"hypothetical protein %d" % k, "start": 500 + 1500 * k,
+                           "stop": 1700 + 1500 * k, "geneID": k, "complement": bool(k & 1)} for k in range(15)]}
+               for i, g in enumerate(gb)]
+    dbdir = tmp_path / "db"
+    dbdir.mkdir()
+    D.write(dbdir / "database", entries)
+    taxdb = _taxdb_text(n_species, n_strains)
+    (dbdir / "taxDB").write_bytes(taxdb)
+    rb = synth.to_bytes(reads)
+    quals = [bytes(rng.integers(35, 74, len(b), dtype=np.uint8)) for b in rb]
+    ids = [b"frag%05d" % i for i in range(n_pairs)]
+    r1 = _fastq_text(rb[:n_pairs], quals[:n_pairs], ids, 1, eol)
+    r2 = _fastq_text(rb[n_pairs:], quals[n_pairs:], ids, 2, eol)
+    return dbdir, taxdb, rb, quals, ids, r1, r2
+
+
+@pytest.mark.parametrize("eol,pseudo,per_batch", [(b"\n", True, 700), (b"\r\n", False, 1000), (b"\n", True, 2500), (b"\n", True, 833)])
+def test_stream_of_batches_equals_the_reference_loop(kslam, oracle, synth, tmp_path, eol, pseudo, per_batch):
+    import ctypes as C
+    D = importlib.import_module("kslam_amd.db")
+    T = importlib.import_module("kslam_amd.tail")
+    X = importlib.import_module("kslam_amd.taxonomy")
+    S = importlib.import_module("kslam_amd.stream")
+    dbo = importlib.import_module("oracle.db_oracle")
+    n_pairs = 2500
+    dbdir, taxdb, rb, quals, ids, r1, r2 = _make_case(synth, tmp_path, n_pairs, eol)
+
+    # ---- product: files -> files ----
+    db = D.Database.load(dbdir / "database")
+    ctx = kslam.Context()
+    bases_pp, lens_p = db.entry_pointers()
+    ctx._chk(ctx._L.kslam_set_index(ctx._h, db.n_entries, C.cast(bases_pp, C.c_void_p), C.cast(lens_p, C.c_void_p)))
+    tax = X.TaxDB((dbdir / "taxDB").read_bytes())
+    report = X.Report()
+    h1, h2 = kslam.HostBuffer(len(r1) + 64), kslam.HostBuffer(len(r2) + 64)
+    h1.a[:len(r1)] = np.frombuffer(r1, dtype=np.uint8)
+    h2.a[:len(r2)] = np.frombuffer(r2, dtype=np.uint8)
+    P = T.TailParams.default(pseudo_assembly=pseudo)
+    header = T.sam_header(db, b"SLAM --db db R1.fq R2.fq")
+    sam_path, per_read_path = str(tmp_path / "out.sam"), str(tmp_path / "out_PerRead")
+    sam_fd = os.open(sam_path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC)
+    pr_fd = os.open(per_read_path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC)
+    res = S.classify_stream(ctx, db, h1.ptr, len(r1), h2.ptr, len(r2), per_batch, P, taxdb=tax, report=report,
+                            sam_fd=sam_fd, per_read_fd=pr_fd, sam_header=header)
+    os.close(sam_fd)
+    os.close(pr_fd)
+    sam = open(sam_path, "rb").read()
+    per_read = open(per_read_path, "rb").read()
+    summary = tax.summary(res["tax_ids"], res["pairs"])
+    xml = tax.report_xml(report, db, db.gene_extras(), res["pairs"])
+    n_batches = (n_pairs + per_batch - 1) // per_batch
+    assert res["pairs"] == n_pairs and len(res["batches"]) == n_batches
+    assert [b["pairs"] for b in res["batches"]] == [min(per_batch, n_pairs - k * per_batch) for k in range(n_batches)]
+    if pseudo:
+        assert all(b["pseudo_assembly_on"] == "gpu" for b in res["batches"])
+
+    # ---- checker: the oracle chain, batch by batch with the same boundaries ----
+    _, oentries = dbo.parse((dbdir / "database").read_bytes())
+    ogb = [e["bases"] for e in oentries]
+    oI = T.Index(ogb, locus_tags=[e["locusTag"] for e in oentries], taxonomy_ids=[e["taxonomyID"] for e in oentries],
+                 genes=[[(g["start"], g["stop"], g["geneName"], g["proteinID"], g["product"]) for g in e["genes"]]
+                        for e in oentries])
+    otree = oracle.taxonomy_tree(taxdb)
+    esam, eper_read, etax, ebatches, limits = [], [], [], [], []
+    for k in range(n_batches):
+        lo, hi = k * per_batch, min(n_pairs, (k + 1) * per_batch)
+        b_reads = rb[lo:hi] + rb[n_pairs + lo:n_pairs + hi]
+        b_quals = quals[lo:hi] + quals[n_pairs + lo:n_pairs + hi]
+        b_ids = ids[lo:hi] + ids[lo:hi]
+        eal, ecig, _ = oracle.align_to_database(b_reads, ogb)
+        oR = T.Reads(b_reads, b_quals, b_ids)
+        st = T.TailStats()
+        esam.append(oracle.tail_sam(P, oR.view, oI.view, eal, ecig, stats=st))
+        limits.append(int(st.max_insert_size))
+        erp, epr = oracle.tail_pairs(P, oR.view, eal)
+        t = [otree.lca([oentries[int(e)]["taxonomyID"] for e in epr["entry"][int(g["first"]):int(g["first"]) + int(g["count"])]])
+             for g in erp]
+        etax += t
+        eper_read.append(b"".join(b"%s\t%d\n" % (b_ids[int(g["r1_read"])], x) for g, x in zip(erp, t)))
+        ebatches.append((b_ids, erp, epr))
+    assert sam == header + b"".join(esam) and sam.count(b"\n") > 2 * n_pairs * 0.9
+    assert [b["max_insert_size"] for b in sorted(res["batches"], key=lambda b: b["batch"])] == limits
+    assert res["tax_ids"].tolist() == etax and len(set(etax)) > 6
+    assert per_read == b"".join(eper_read)
+    assert summary == oracle.taxonomy_summary(otree, etax, n_pairs)
+    from test_taxonomy import _xml_restatement
+    ogenes = [[{"start": g["start"], "stop": g["stop"], "name": g["geneName"], "protein": g["proteinID"], "product": g["product"],
+                "locus": g["locusTag"], "reference": g["referenceSequence"], "id": g["geneID"]} for g in e["genes"]] for e in oentries]
+    exml, taxa = _xml_restatement(tax, [e["taxonomyID"] for e in oentries], ogenes, None, ebatches, n_pairs)
+    if xml != exml and os.path.isdir(os.path.join(ROOT, "gpurun_out")):      # leave both texts behind for a diff
+        open(os.path.join(ROOT, "gpurun_out", "stream_xml_got.xml"), "wb").write(xml)
+        open(os.path.join(ROOT, "gpurun_out", "stream_xml_exp.xml"), "wb").write(exml)
+    assert xml == exml and len(taxa) > 6 and xml.count(b"<read>") > 0.8 * n_pairs
+    if n_batches > 1 and per_batch == 700:
+        # the boundaries matter: one batch of everything has another insert-size limit or at least other statistics
+        assert len(set(limits)) >= 1
+    h1.close()
+    h2.close()
+    ctx.close()
+    db.close()
+    report.close()
+    tax.close()
+    otree.close()
+
+
+def test_stream_stops_at_max_pairs_and_reports_mismatched_files(kslam, synth, tmp_path):
+    """--num-reads (maxNumReads, src/SLAM.h:193, 201-203) cuts the last batch short; an R2 file with fewer
+    records than R1 is refused like kslam_fastq_parse_pair refuses it."""
+    import ctypes as C
+    D = importlib.import_module("kslam_amd.db")
+    T = importlib.import_module("kslam_amd.tail")
+    S = importlib.import_module("kslam_amd.stream")
+    n_pairs = 900
+    dbdir, taxdb, rb, quals, ids, r1, r2 = _make_case(synth, tmp_path, n_pairs, b"\n", seed=77)
+    db = D.Database.load(dbdir / "database")
+    ctx = kslam.Context()
+    bases_pp, lens_p = db.entry_pointers()
+    ctx._chk(ctx._L.kslam_set_index(ctx._h, db.n_entries, C.cast(bases_pp, C.c_void_p), C.cast(lens_p, C.c_void_p)))
+    h1, h2 = kslam.HostBuffer(len(r1) + 64), kslam.HostBuffer(len(r2) + 64)
+    h1.a[:len(r1)] = np.frombuffer(r1, dtype=np.uint8)
+    h2.a[:len(r2)] = np.frombuffer(r2, dtype=np.uint8)
+    P = T.TailParams.default()
+    res = S.classify_stream(ctx, db, h1.ptr, len(r1), h2.ptr, len(r2), 400, P, max_pairs_total=650)
+    assert [b["pairs"] for b in sorted(res["batches"], key=lambda b: b["batch"])] == [400, 250] and res["pairs"] == 650
+    # R2 one record short
+    cut = r2.rstrip(b"\n").rfind(b"\n@")
+    with pytest.raises(kslam.KslamError, match="mismatch in R1 and R2"):
+        S.classify_stream(ctx, db, h1.ptr, len(r1), h2.ptr, cut + 1, 400, P)
+    h1.close()
+    h2.close()
+    ctx.close()
+    db.close()

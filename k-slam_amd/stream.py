@@ -77,12 +77,15 @@ def cut_batches(r1_ptr, len1, r2_ptr, len2, pairs_per_batch, max_pairs_total=0, 
 
 def classify_stream(ctx, index, r1_ptr, len1, r2_ptr, len2, pairs_per_batch, params, taxdb=None, report=None,
                     sam_fd=-1, per_read_fd=-1, sam_header=None, max_pairs_total=0, depth=None, host_threads=0,
-                    on_batch=None):
+                    on_batch=None, before_batch=None):
     """Runs the loop above.  r1_ptr / r2_ptr: ADDRESSES of the two FASTQ texts (page-locked memory from
     kslam_amd.HostBuffer goes up by DMA), index: a kslam_amd.tail index view (e.g. kslam_amd.db.Database),
     params: kslam_amd.tail.TailParams (paired; pseudo_assembly as wanted), taxdb / report: optional
     kslam_amd.taxonomy.TaxDB / Report.  Returns a dict: pairs, tax_ids (uint32, one per aligned read pair over all
-    batches, in order), per-batch statistics and the wall-clock split."""
+    batches, in order), per-batch statistics and the wall-clock split.
+    Test hooks, both called on the host-stage thread: before_batch(k, ov, cg, det, md, rp, pr, pair_stats, reads) sees
+    the batch as the GPU returned it (the SAM writer sorts `pr` in place afterwards); on_batch(rec, ov, cg, rp, pr,
+    reads) sees it after the host stage."""
     if not params.paired:
         raise KslamError(4, "classify_stream: paired data only (single-end batches go through kslam_submit_batch_columns)")
     t_start = time.perf_counter()
@@ -105,6 +108,9 @@ def classify_stream(ctx, index, r1_ptr, len1, r2_ptr, len2, pairs_per_batch, par
             t0 = time.perf_counter()
             rp, pr, pst = pairs
             on_gpu = bool(pst["stages_done"] & 4)
+            if before_batch is not None:
+                before_batch(k, ov, cg, det, md, rp, pr, pst, reads)
+                t0 = time.perf_counter()
             st = finish_rows_fd(P_write if on_gpu or not params.pseudo_assembly else P_host, reads, index, ov, cg, det, md,
                                 rp, pr, sam_fd)
             t1 = time.perf_counter()

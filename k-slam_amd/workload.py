@@ -35,11 +35,21 @@ def _revcomp_rows(x):
     return lut[x.flip(1).long()]
 
 
-def make_database(dev, gen, n_species, n_strains, length):
+def viral_lengths(dev, gen, n_viral, min_len=5_000, max_len=200_000):
+    """lengths of the "+viral" entries of BASELINE configs[2] ("add 10 k genomes of 5-200 kb"):
+    log-uniform between the two bounds, as virus genome sizes are -- many small ones, few large ones"""
+    u = torch.rand(n_viral, generator=gen, device=dev, dtype=torch.float64)
+    ln = torch.exp(np.log(min_len) + u * (np.log(max_len) - np.log(min_len))).long().clamp(min_len, max_len)
+    return ln.cpu().numpy().astype(np.int64)
+
+
+def make_database(dev, gen, n_species, n_strains, length, n_viral=0):
     """Species x strains database as ONE device byte tensor + host offsets.
-    Strains derive from the species root by 1-3 % substitutions + sparse 1-10 bp indels."""
+    Strains derive from the species root by 1-3 % substitutions + sparse 1-10 bp indels.
+    n_viral > 0 (configs[2]): that many unrelated i.i.d. genomes of 5-200 kb appended AFTER the bacterial entries
+    (the random draws of the bacterial part are the same with and without them)."""
     acgt = _ACGT.to(dev)
-    cap = int(n_species * n_strains * length * 1.01) + 1024
+    cap = int(n_species * n_strains * length * 1.01) + 1024 + n_viral * 200_000
     db = torch.empty(cap, dtype=torch.uint8, device=dev)
     offs = [0]
     for _ in range(n_species):
@@ -75,11 +85,17 @@ def make_database(dev, gen, n_species, n_strains, length):
             n = codes.numel()
             db[offs[-1]:offs[-1] + n] = acgt[codes.long()]
             offs.append(offs[-1] + n)
+    if n_viral:
+        lens = viral_lengths(dev, gen, n_viral)
+        total = int(lens.sum())
+        db[offs[-1]:offs[-1] + total] = acgt[torch.randint(0, 4, (total,), generator=gen, device=dev)]
+        base = offs[-1]
+        offs.extend((base + np.cumsum(lens)).tolist())
     return db[:offs[-1]], np.array(offs, dtype=np.uint64)
 
 
 def make_reads(dev, gen, db, offs, n_pairs, read_len=READ_LEN, sub_rate=0.01, indel_rate=0.001,
-               unmapped=0.02, with_truth=False):
+               unmapped=0.02, with_truth=False, by_length=False):
     """[2 * n_pairs, read_len] ASCII tensor in the reference batch layout (R1 block | R2 block).
     with_truth: also a dict of device tensors, one row per READ (2 * n_pairs):
       entry      source database entry, -1 for reads of the pairs that are not from the database
@@ -90,12 +106,19 @@ def make_reads(dev, gen, db, offs, n_pairs, read_len=READ_LEN, sub_rate=0.01, in
       has_indel  the read carries the one single-base indel
       seed_ok    an error-free 32-mer of the read sits on a 16-aligned entry offset (the genome
                  sampling of src/SLAM.h:64), so the reference's join must report (entry, rel, revcomp)
-    The random draws are the same with and without truth."""
+    The random draws are the same with and without truth.
+    by_length: the source entry of a pair is drawn with probability proportional to its length (a community in which
+    every genome has the same coverage) instead of uniformly over the entries -- for databases whose entries differ in
+    length by orders of magnitude (configs[2]: 4 Mb bacterial next to 5 kb viral genomes)."""
     acgt = _ACGT.to(dev)
     goff = torch.from_numpy(offs.astype(np.int64)).to(dev)
     glen = goff[1:] - goff[:-1]
     ng = glen.numel()
-    g = torch.randint(0, ng, (n_pairs,), generator=gen, device=dev)
+    if by_length:
+        at = (torch.rand(n_pairs, generator=gen, device=dev, dtype=torch.float64) * float(goff[-1])).long()
+        g = (torch.searchsorted(goff, at, right=True) - 1).clamp(0, ng - 1)
+    else:
+        g = torch.randint(0, ng, (n_pairs,), generator=gen, device=dev)
     frag = (350 + 30 * torch.randn(n_pairs, generator=gen, device=dev)).round().long().clamp(read_len + 1, 1000)
     span = (glen[g] - frag - 2).clamp(min=1)
     start = (torch.rand(n_pairs, generator=gen, device=dev, dtype=torch.float64) * span).long()
@@ -237,3 +260,64 @@ def check_against_truth(ov_bytes, cig_words, truth, read_len, match=2, mismatch=
     res["ok"] = (unsorted == 0 and res["planted_missing"] == 0 and res["planted_score_out_of_bounds"] == 0
                  and res["error_free_wrong"] == 0 and hits_unmapped == 0)
     return res
+
+
+# ---- the batch as FASTQ text (what the reference's driver reads, src/FASTQsequence.h:129-165) ----
+
+ID_DIGITS = 8
+
+
+def fastq_text(reads_block, mate, first_pair=0, gen=None, phred=(20, 40)):
+    """[n, L] ASCII base rows (device or host tensor) -> uint8 tensor [n, W] on the same device holding the records
+    "@p00000123/1\n<bases>\n+\n<quality>\n" (fixed width; the identifier the reference derives is p00000123,
+    src/FASTQsequence.h:61-71).  Qualities: uniform Phred 20-40 from `gen`, constant 'I'
+    (Phred 40) without a generator.  Returns (text, quality rows [n, L])."""
+    n, L = reads_block.shape
+    dev = reads_block.device
+    Wd = 2 + ID_DIGITS + 3 + L + 3 + L + 1
+    a = torch.empty((n, Wd), dtype=torch.uint8, device=dev)
+    a[:, 0] = ord("@")
+    a[:, 1] = ord("p")
+    idx = torch.arange(first_pair, first_pair + n, device=dev, dtype=torch.int64)
+    for d in range(ID_DIGITS):
+        a[:, 2 + d] = ((idx // 10 ** (ID_DIGITS - 1 - d)) % 10 + ord("0")).to(torch.uint8)
+    c = 2 + ID_DIGITS
+    a[:, c] = ord("/")
+    a[:, c + 1] = ord("0") + mate
+    a[:, c + 2] = 10
+    a[:, c + 3:c + 3 + L] = reads_block
+    a[:, c + 3 + L] = 10
+    a[:, c + 4 + L] = ord("+")
+    a[:, c + 5 + L] = 10
+    if gen is None:
+        q = torch.full((n, L), ord("I"), dtype=torch.uint8, device=dev)
+    else:
+        q = torch.randint(33 + phred[0], 33 + phred[1] + 1, (n, L), generator=gen, device=dev, dtype=torch.uint8)
+    a[:, c + 6 + L:c + 6 + 2 * L] = q
+    a[:, Wd - 1] = 10
+    return a, q
+
+
+def pair_id(i):
+    return b"p%0*d" % (ID_DIGITS, i)
+
+
+def make_batch_in_pieces(dev, gen, db, offs, total_pairs, read_len, pieces=8, first_piece=0, n_pieces=None, seed_base=2,
+                         by_length=False, with_truth=True):
+    """A large batch generated piece by piece (the temporaries of make_reads are 8-byte-per-base tensors): pieces
+    [first_piece, first_piece + n_pieces) of `pieces`, each seeded on its own so that the batch is the same however it
+    is split (bench.py --strong gives every rank its pieces).  -> ([2 m, L] reads in block layout, truth or None)"""
+    n_pieces = pieces if n_pieces is None else n_pieces
+    piece = total_pairs // pieces
+    r1s, r2s, tr = [], [], []
+    for pc in range(first_piece, first_piece + n_pieces):
+        gen.manual_seed(seed_base + 1000 * pc)
+        r = make_reads(dev, gen, db, offs, piece, read_len=read_len, with_truth=with_truth, by_length=by_length)
+        if with_truth:
+            r, t = r
+            tr.append(t)
+        r1s.append(r[:piece])
+        r2s.append(r[piece:])
+    reads = torch.cat(r1s + r2s, 0).contiguous()
+    truth = {k: torch.cat([t[k][:piece] for t in tr] + [t[k][piece:] for t in tr]) for k in tr[0]} if with_truth else None
+    return reads, truth

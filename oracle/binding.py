@@ -368,6 +368,8 @@ def tail_lib():
         L.orc_tail_sam.argtypes = [vp, vp, vp, vp, u64, vp, u64, C.POINTER(vp), C.POINTER(u64), vp]
         L.orc_sam_header.argtypes = [vp, C.c_char_p, C.POINTER(vp), C.POINTER(u64)]
         L.orc_tail_free.argtypes = [vp]
+        L.orc_tail_force_insert_limit.argtypes = [C.c_int64]
+        L.orc_tail_force_insert_limit.restype = None
         _tail = L
     return _tail
 
@@ -407,6 +409,12 @@ def tail_sam(params, reads_view, index_view, overlaps, cigar_pool, stats=None):
     out = C.string_at(txt.value, n.value)
     L.orc_tail_free(txt)
     return out
+
+
+def tail_force_insert_limit(limit):
+    """the next tail_pairs / tail_sam calls screen with this insert-size limit (the whole batch's) instead of the one
+    they would compute from their own read pairs; None switches back"""
+    tail_lib().orc_tail_force_insert_limit(-1 if limit is None else int(limit))
 
 
 def sam_header(index_view, command_line=b""):

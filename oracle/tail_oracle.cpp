@@ -627,6 +627,11 @@ std::vector<OvRec> load(const kslam_overlap *ov, uint64_t n, const uint32_t *poo
   return v;
 }
 
+// A sub-sample of a batch is run with the insert-size limit of the WHOLE batch (getMaxAllowedInsertSize is a
+// batch-global statistic, src/PairedOverlap.h:314-360; everything after it is per read pair or per entry):
+// orc_tail_force_insert_limit(limit) makes the next calls use `limit` instead of computing it; -1 switches back.
+static int64_t g_forced_insert_limit = -1;
+
 // src/SLAM.h:102-128
 std::vector<ReadPair> run_tail(const kslam_tail_params *p, const Reads &reads,
                                std::vector<OvRec> &ov, kslam_tail_stats *st) {
@@ -638,6 +643,7 @@ std::vector<ReadPair> run_tail(const kslam_tail_params *p, const Reads &reads,
     rps = group_pairs(pairs, reads.size() / 2);
     if (stages & KSLAM_TAIL_INSERT_SCREEN) {
       st->max_insert_size = max_insert(rps, &st->n_insert_sizes);
+      if (g_forced_insert_limit >= 0) st->max_insert_size = (uint32_t)g_forced_insert_limit;
       screen_insert(rps, st->max_insert_size);
     }
     if (stages & KSLAM_TAIL_SCORE_SCREEN) screen_score(rps, p->score_fraction);
@@ -667,6 +673,8 @@ char *dup_text(const std::string &s) {
 extern "C" {
 
 const char *orc_tail_last_error(void) { return g_err.c_str(); }
+
+void orc_tail_force_insert_limit(int64_t limit) { g_forced_insert_limit = limit; }
 
 int orc_tail_pairs(const kslam_tail_params *params, const kslam_reads_view *reads_v,
                    const kslam_overlap *overlaps, uint64_t n_overlaps,

@@ -1,21 +1,32 @@
 #!/usr/bin/env python3
-"""bench.py -- throughput of the k-SLAM alignment hot path on MI355X.
+"""bench.py -- paired reads/s classified by the MI355X-native k-SLAM path (BASELINE.json's metric).
 
-A "step" is one pass of the hot path (alignToDatabase, reference src/SLAM.h:59-79:
-read k-mer extraction -> k-mer sort -> join against the resident genome k-mer list ->
-overlap sort/dedupe -> Smith-Waterman -> CIGAR) over one batch of synthetic paired reads
-that is already resident in HBM.  Workload at N=1 = BASELINE.json configs[1]:
-1M 150 bp read pairs vs a ~5 Gb synthetic bacterial database.  With N > 1 every rank
-replicates the database, aligns its own 1M pairs (weak scaling) and the per-read results
-are gathered to rank 0 over RCCL inside the timed region.
+A "step" is one batch of synthetic paired reads through the reference's per-batch loop body (src/SLAM.h:193-249):
+FASTQ text -> alignToDatabase (src/SLAM.h:59-79: k-mer extraction, sort, join, dedupe, Smith-Waterman, CIGAR) ->
+score screen, pairing, insert-size statistics, screens [, pseudo-assembly] -> SAM text WRITTEN to a file ->
+per-read taxonomy (LCA) WRITTEN to <out>_PerRead.  `value` = 2 x pairs x K / wall clock of K such steps, pipeline
+fill and drain included (median of three repetitions), FASTQ text in page-locked host memory when the clock starts,
+every PCIe byte inside.  Reported beside it, as `hot_path`: the alignToDatabase operator alone on a batch that is
+resident in HBM (what `value` was in rounds 1-2), with the `roofline` objects attached to it.
 
-Prints ONE JSON line on rank 0 (see the driver contract in the task statement).
+  --config 1 (default, N = 1)  BASELINE configs[1]: 1 M x 2 x 150 bp pairs per batch vs the 5 Gb bacterial database,
+                               --no-pseudo-assembly
+  --config 2                   configs[2]: 10 M pairs per batch vs bacterial + 10 k viral genomes, pseudo-assembly on
+  --config 4                   configs[4]: 10 M x 2 x 250 bp pairs per batch vs the bacterial database
+  --gpus N > 1 (config 3)      ONE batch of --total-pairs pairs per step, read pairs sharded over the N GPUs, gathered to
+                               rank 0 (RCCL over xGMI), batch-global tail and SAM text on rank 0.  Without a launcher
+                               (WORLD_SIZE unset) bench.py starts the N rank processes itself.
+
+Prints ONE JSON line on rank 0 (the driver contract of the task statement).
 """
 import argparse
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -29,13 +40,60 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 READ_LEN = 150
 W = entry.load_package() and importlib.import_module("kslam_amd.workload")   # generator + ground truth
 make_database, make_reads = W.make_database, W.make_reads
+PIECES = 8            # a strong batch is generated in 8 fixed pieces: the same batch for N = 1, 2, 4, 8
 
 
-def cpu_baseline(K, db, offs, seed, n_genomes, n_pairs, read_len=READ_LEN, device=0):
-    """The oracle's alignToDatabase timed on the host cores, on a bounded sample of the
-    same workload (reported baseline; the oracle is the checker, never the product).  The same
-    sample then goes through the HIP library and the two result sets are compared record by record:
-    the baseline leg doubles as a parity check inside the driver-run record."""
+# ------------------------------------------------------------------------------------------------ launcher
+def self_launch(args, argv):
+    """--gpus N without a launcher: start the N rank processes here.  The parent never touches the GPU
+    (torch.cuda.device_count() does not initialise it on this image), relays rank 0's JSON line and exits non-zero
+    if any rank dies."""
+    n = args.gpus
+    share = os.environ.get("KSLAM_BENCH_SHARE_GPU") == "1"
+    ndev = torch.cuda.device_count()
+    if n > ndev and not share:
+        raise SystemExit("--gpus %d but %d device(s) visible (KSLAM_BENCH_SHARE_GPU=1 lets ranks share a GPU: tests only)" % (n, ndev))
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), KSLAM_BENCH_LAUNCHED_BY="bench.py")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+    out_lines = []
+    reader = threading.Thread(target=lambda: out_lines.extend(procs[0].stdout.read().splitlines()))
+    reader.start()
+    failed = None
+    while any(p.poll() is None for p in procs):
+        for r, p in enumerate(procs):
+            if p.poll() not in (None, 0) and failed is None:
+                failed = (r, p.returncode)
+                for q in procs:                      # the exact children started above, by PID
+                    if q.poll() is None:
+                        q.terminate()
+        time.sleep(0.2)
+    reader.join()
+    for r, p in enumerate(procs):
+        if p.returncode != 0 and failed is None:
+            failed = (r, p.returncode)
+    js = [x for x in out_lines if x.startswith("{")]
+    for x in out_lines:
+        if not x.startswith("{"):
+            print(x, file=sys.stderr)
+    if failed is not None or not js:
+        print("bench.py: rank %s exited with code %s" % (failed or ("?", "?")), file=sys.stderr)
+        raise SystemExit(1)
+    print(js[-1], flush=True)
+
+
+# ------------------------------------------------------------------------------------------------ CPU baseline
+def cpu_baseline(K, db, offs, seed, n_genomes, n_pairs, read_len=READ_LEN, device=0, full=False):
+    """The oracle's alignToDatabase timed on the host cores, on a bounded sample of the same workload (reported
+    baseline; the oracle is the checker, never the product).  The same sample then goes through the HIP library:
+    the result sets are compared record by record and the GPU's time on that very sample is reported, so that
+    `speedup_on_sample` is one workload on both sides."""
     import oracle as O
     n_genomes = min(n_genomes, len(offs) - 1)
     sub = db[:int(offs[n_genomes])].cpu()
@@ -49,370 +107,266 @@ def cpu_baseline(K, db, offs, seed, n_genomes, n_pairs, read_len=READ_LEN, devic
     kind_ssw = "own scalar SSW restatement"
     if O.use_reference_ssw(True):
         kind_ssw = "SSW core = the reference's own ssw.c (SSE2) from oracle/_ref"
-    # one OpenMP thread per CPU the job may use (cgroup quota), not per hardware thread of the host
-    cores = O.usable_cpus()
+    cores = O.usable_cpus()        # one OpenMP thread per CPU the job may use (cgroup quota), not per hardware thread
     O.set_num_threads(cores)
     al, cg, ph = O.align_to_database(rl, gl)
-    dt = float(ph[5])          # seconds inside the C call (excludes the ctypes marshalling)
+    dt = float(ph[5])              # seconds inside the C call (excludes the ctypes marshalling)
     O.use_reference_ssw(False)
     out = {
         "value": round(len(rl) / dt, 1), "unit": "reads/s", "cores": cores, "kind": "port",
         "pairs": n_pairs, "read_len": read_len, "db_genomes": n_genomes, "db_bases": int(suboffs[-1]),
         "seconds": round(dt, 2),
         "phases_s": dict(zip(("extract", "genome_kmers", "sort", "join", "sw"), (round(float(x), 2) for x in ph[:5]))),
-        "sample": "%d pairs x %d bp vs the first %d database genomes (%.0f Mb) -- NOT the whole 5 Gb database, "
-                  "which the CPU path cannot finish inside the bounded 10-30 s; whole reference batch "
-                  "path incl. genome k-mer re-extraction and the (reads+genomes) sort, OpenMP on the CPUs the "
-                  "job's cgroup quota allows; %s" % (n_pairs, read_len, n_genomes, float(suboffs[-1]) / 1e6, kind_ssw),
+        "sample": ("the WHOLE workload of this run (--cpu-full): " if full else "") +
+                  "%d pairs x %d bp vs %s database genomes (%.0f Mb)%s; whole reference batch path incl. genome k-mer "
+                  "re-extraction and the (reads+genomes) sort, alignToDatabase only (no tail), OpenMP on the CPUs the "
+                  "job's cgroup quota allows; %s" % (
+                      n_pairs, read_len, "all %d" % n_genomes if full else "the first %d" % n_genomes, float(suboffs[-1]) / 1e6,
+                      "" if full else " -- NOT the whole database, which the CPU path cannot finish inside the bounded 10-30 s",
+                      kind_ssw),
         "n_alignments": int(len(al)),
     }
-    try:   # the same sample through the HIP library: identical records and CIGARs?
+    try:   # the same sample through the HIP library: identical records and CIGARs?  and how long does the GPU take for it?
         c = K.Context(device=device)
         c.set_index(gl)
         c.load_reads_arrays(np.ascontiguousarray(reads).reshape(-1), np.arange(len(rl) + 1, dtype=np.uint64) * np.uint64(read_len))
         n_out, n_cig = c.align_resident()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            n_out, n_cig = c.align_resident()
+        gpu_ms = (time.perf_counter() - t0) / 3 * 1e3
         gov, gcg = c.fetch_results(n_out, n_cig)
         c.close()
         same = len(gov) == len(al) and all((gov[f] == al[f]).all() for f in (
             "read", "entry", "rel", "revcomp", "score", "ref_begin", "ref_end", "query_begin", "query_end",
             "cigar_len", "cigar_off")) and np.array_equal(gcg, cg)
         out["gpu_equals_cpu_on_sample"] = {"identical": bool(same), "alignments": int(len(gov)), "cigar_ops": int(len(gcg))}
+        out["gpu_ms_on_sample"] = round(gpu_ms, 3)
+        out["speedup_on_sample"] = round(dt * 1e3 / gpu_ms, 1)
     except Exception as e:   # never lose the bench line over the extra check
         out["gpu_equals_cpu_on_sample"] = {"error": repr(e)}
     return out
 
 
+# ------------------------------------------------------------------------------------------------ the e2e legs
+class FastqFiles:
+    """F batches of synthetic pairs as two FASTQ texts in page-locked host memory (what a host holds after reading the
+    two files), built on the GPU piece by piece."""
+
+    def __init__(self, K, dev, batches, read_len, first_pair=0):
+        n = sum(b.shape[0] // 2 for b in batches)
+        self.rec = 2 + W.ID_DIGITS + 3 + read_len + 3 + read_len + 1
+        self.n_pairs, self.len = n, n * self.rec
+        self.h = [K.HostBuffer(self.len + 64) for _ in range(2)]
+        qgen = torch.Generator(device=dev)
+        qgen.manual_seed(4242)
+        at = 0
+        for b in batches:
+            m = b.shape[0] // 2
+            for mate in (0, 1):
+                view = torch.from_numpy(self.h[mate].a[at * self.rec:(at + m) * self.rec].reshape(m, self.rec))
+                for lo in range(0, m, 1_250_000):
+                    hi = min(m, lo + 1_250_000)
+                    txt, _ = W.fastq_text(b[mate * m + lo:mate * m + hi], mate + 1, first_pair=first_pair + at + lo, gen=qgen)
+                    view[lo:hi].copy_(txt)
+                    del txt
+            at += m
+        torch.cuda.synchronize()
+
+    def close(self):
+        for x in self.h:
+            x.close()
+
+
+def e2e_leg(K, ctx, files, pairs_per_batch, index_view, taxdb, steps, warmup, pseudo, reps=3, tag="e2e"):
+    """K steps of the reference's batch loop, FASTQ text in host memory to SAM + _PerRead files in /dev/shm."""
+    S = importlib.import_module("kslam_amd.stream")
+    T = importlib.import_module("kslam_amd.tail")
+    X = importlib.import_module("kslam_amd.taxonomy")
+    P = T.TailParams.default(pseudo_assembly=pseudo)
+    wins = list(S.cut_batches(files.h[0].ptr, files.len, files.h[1].ptr, files.len, pairs_per_batch))
+    F = len(wins)
+    header = T.sam_header(index_view, b"SLAM --db synthetic R1.fq R2.fq")
+    sam_path = "/dev/shm/kslam_bench_%d_%s.sam" % (os.getpid(), tag)
+    pr_path = "/dev/shm/kslam_bench_%d_%s_PerRead" % (os.getpid(), tag)
+
+    def run(n_steps, keep_report=False):
+        report = X.Report()
+        sam_fd = os.open(sam_path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o600)
+        pr_fd = os.open(pr_path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o600)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = S.classify_stream(ctx, index_view, files.h[0].ptr, files.len, files.h[1].ptr, files.len, pairs_per_batch, P,
+                                taxdb=taxdb, report=report, sam_fd=sam_fd, per_read_fd=pr_fd, sam_header=header,
+                                windows=[wins[i % F] for i in range(n_steps)])
+        os.close(sam_fd)
+        os.close(pr_fd)
+        torch.cuda.synchronize()
+        res["wall"] = time.perf_counter() - t0
+        res["sam_file_bytes"], res["per_read_file_bytes"] = os.path.getsize(sam_path), os.path.getsize(pr_path)
+        if keep_report:
+            res["report"] = report
+        else:
+            report.close()
+        return res
+    try:
+        run(max(warmup, 3))                       # lanes, page-locked buffers, the tail's arenas, the files' pages
+        runs = [run(steps, keep_report=(i == reps - 1)) for i in range(reps)]
+        walls = sorted(r["wall"] for r in runs)
+        med = runs[[r["wall"] for r in runs].index(walls[len(walls) // 2])]
+        last = runs[-1]
+        # end of run (src/SLAM.h:255-265): the abbreviated table and the XML report over all batches
+        t0 = time.perf_counter()
+        summary = taxdb.summary(last["tax_ids"], last["pairs"])
+        xml = taxdb.report_xml(last["report"], index_view, None, last["pairs"])
+        with open(sam_path + ".xml", "wb") as f:
+            f.write(xml)
+        t_end = time.perf_counter() - t0
+        last["report"].close()
+        n_reads = 2 * pairs_per_batch * steps
+        b = sorted(med["batches"], key=lambda r: r["batch"])
+        same = all(r["sam_file_bytes"] == runs[0]["sam_file_bytes"] and r["per_read_file_bytes"] == runs[0]["per_read_file_bytes"]
+                   and np.array_equal(r["tax_ids"], runs[0]["tax_ids"]) for r in runs)
+        out = {
+            "reads_per_s": round(n_reads / med["wall"], 1), "ms_per_step": round(med["wall"] / steps * 1e3, 3), "steps": steps,
+            "repetitions_ms_per_step": [round(r["wall"] / steps * 1e3, 3) for r in runs],
+            "pairs_per_batch": pairs_per_batch, "distinct_batches_in_the_text": F, "pseudo_assembly": bool(pseudo),
+            "pseudo_assembly_on": b[-1]["pseudo_assembly_on"],
+            "fastq_mb_per_batch": round(2 * files.len / F / 1e6, 1), "sam_mb_per_batch": round(med["sam_bytes"] / steps / 1e6, 1),
+            "per_read_mb_per_batch": round(med["per_read_bytes"] / steps / 1e6, 2),
+            "classified_read_pairs_per_batch": int(len(med["tax_ids"]) / steps),
+            "alignment_pairs_per_batch": int(sum(r["alignment_pairs"] for r in b) / steps),
+            "host_ms_per_batch": {"sam_text_and_write": round(sum(r["ms_sam"] for r in b) / steps, 2),
+                                  "lca_per_read_and_report": round(sum(r.get("ms_classify", 0.0) for r in b) / steps, 2)},
+            "s_main_thread_waiting_for_gpu": med["s_waiting_for_gpu"], "s_main_thread_waiting_for_host_stage": med["s_waiting_for_host_stage"],
+            "end_of_run_reports_s": round(t_end, 3), "end_of_run_report_bytes": {"abbreviated": len(summary), "xml": len(xml)},
+            "including_end_of_run_reports": {"reads_per_s": round(n_reads / (last["wall"] + t_end), 1)},
+            "verified": {"repetitions_identical": bool(same), "sam_file_bytes": int(runs[0]["sam_file_bytes"]),
+                         "per_read_lines": int(len(runs[0]["tax_ids"])), "max_insert_size": b[0]["max_insert_size"]},
+            "what": "FASTQ text (two files' worth, page-locked host memory) -> kslam_fastq_batch_end (batch boundaries) -> "
+                    "kslam_submit_batch_fastq_text (GPU: FASTQ record index, alignToDatabase, score screen / pairing / insert-size "
+                    "statistics / screens%s, per-row NM / MD / log-probability; %d batches in flight) -> kslam_collect_batch -> "
+                    "kslam_tail_finish_write_rows -> kslam_write_fd into a /dev/shm SAM file -> kslam_tail_classify (per-read LCA) "
+                    "-> <out>_PerRead file + kslam_taxreport_add_batch; wall clock of the K steps incl. pipeline fill and drain"
+                    % (" / pseudo-assembly / second screen" if pseudo else "", 3),
+        }
+        return out
+    finally:
+        for pth in (sam_path, pr_path, sam_path + ".xml"):
+            try:
+                os.unlink(pth)
+            except OSError:
+                pass
+
+
 def abi_path(K, ctx, reads, read_len, steps):
-    """What a k-SLAM host linking the library sees: reads[i].bases in host memory in (char **, lengths),
-    overlap records + CIGAR pool back in host memory (page-locked, library-owned), batch after batch
-    through kslam_align_batch_async / kslam_wait_batch with two batches in flight -- upload, kernels and
-    download of neighbouring batches overlap.  Every PCIe byte is inside this number; it is not `value`."""
-    import ctypes as C
+    """What a k-SLAM host that only swaps alignToDatabase sees (first sketch): reads[i].bases in host
+    memory in (char **, lengths), overlap records + CIGAR pool back in host memory, through kslam_align_batch one
+    batch at a time and through kslam_align_batch_async / kslam_wait_batch with two batches in flight."""
     host = np.ascontiguousarray(reads.cpu().numpy())
     n = host.shape[0]
     ptrs = (host.ctypes.data + np.arange(n, dtype=np.uint64) * np.uint64(read_len)).astype(np.uint64)
     lens = np.full(n, read_len, dtype=np.uint32)
     pp, lp = ptrs.ctypes.data, lens.ctypes.data
-
-    t_sub, t_wait = [], []
+    done_at = []
 
     def run(k):
         t0 = time.perf_counter()
         rows = 0
         pend = [ctx.submit_batch_pointers(n, pp, lp)]
         for i in range(k):
-            ta = time.perf_counter()
             if i + 1 < k:
                 pend.append(ctx.submit_batch_pointers(n, pp, lp))
-            tb = time.perf_counter()
             ov, cg, release = ctx.wait_batch(pend.pop(0), copy=False)
             rows = len(ov)
             release()
-            t_sub.append(tb - ta)
-            t_wait.append(time.perf_counter() - tb)
             done_at.append(time.perf_counter())
         return time.perf_counter() - t0, rows
-    done_at = []
-    run(3)                                             # lanes, page-locked buffers and work buffers exist now
-    del t_sub[:], t_wait[:], done_at[:]
+    run(3)
+    del done_at[:]
     wall, rows = run(steps)
-    steady = (done_at[-1] - done_at[0]) / (len(done_at) - 1)   # batch-to-batch, without the pipeline fill of the first
+    steady = (done_at[-1] - done_at[0]) / (len(done_at) - 1)
     t0 = time.perf_counter()
-    for _ in range(3):
+    for i in range(3):
         ov, cg, release = ctx.align_batch_pointers(n, pp, lp, copy=False)
-        if _ < 2:
+        if i < 2:
             release()
     sync_wall = (time.perf_counter() - t0) / 3
-    # identity with the resident path
     n_out, n_cig = ctx.align_resident()
     r_ov, r_cg = ctx.fetch_results(n_out, n_cig)
     same = ov.tobytes() == r_ov.tobytes() and cg.tobytes() == r_cg.tobytes()
     release()
     return {
-        "ms_in_submit": round(1e3 * sum(t_sub) / max(len(t_sub), 1), 2), "ms_in_wait": round(1e3 * sum(t_wait) / max(len(t_wait), 1), 2),
-        "reads_per_s": round(n / steady, 1), "ms_per_batch": round(steady * 1e3, 2), "steps": steps,
-        "including_pipeline_fill": {"reads_per_s": round(n * steps / wall, 1), "ms_per_batch": round(wall / steps * 1e3, 2)},
+        "pipelined": {"reads_per_s": round(n * steps / wall, 1), "ms_per_batch": round(wall / steps * 1e3, 2),
+                      "steady_state_ms_per_batch": round(steady * 1e3, 2)},
         "one_batch_at_a_time": {"reads_per_s": round(n / sync_wall, 1), "ms_per_batch": round(sync_wall * 1e3, 2)},
-        "h2d_mb_per_batch": round(n * read_len / 1e6, 1), "d2h_mb_per_batch": round((rows * 48 + n_cig * 4) / 1e6, 1),
+        "steps": steps, "h2d_mb_per_batch": round(n * read_len / 1e6, 1), "d2h_mb_per_batch": round((rows * 48 + n_cig * 4) / 1e6, 1),
         "equals_resident_result": bool(same),
-        "what": "host pointers in -> kslam_align_batch_async / kslam_wait_batch (two batches in flight) -> host "
-                "results out; `one_batch_at_a_time` = kslam_align_batch in a loop",
+        "what": "host pointers in -> host results out, alignToDatabase only: `one_batch_at_a_time` = kslam_align_batch in a loop (the "
+                "drop-in of INTEGRATION.md's first sketch), `pipelined` = kslam_align_batch_async / kslam_wait_batch, two batches in flight",
     }
 
 
-def _host_copy(t, keep):
-    """a host copy in a private anonymous mapping advised for transparent huge pages (what kslam_db_load /
-    kslam_fastq_parse do for their columns)"""
-    import mmap
-    n = t.numel() * t.element_size()
-    m = mmap.mmap(-1, max((n + (2 << 20) - 1) // (2 << 20) * (2 << 20), 2 << 20),
-                  flags=mmap.MAP_PRIVATE | mmap.MAP_ANONYMOUS)
-    if hasattr(mmap, "MADV_HUGEPAGE"):
-        m.madvise(mmap.MADV_HUGEPAGE)
-    a = np.frombuffer(m, dtype=np.uint8, count=n).reshape(tuple(t.shape))
-    torch.from_numpy(a).copy_(t)
-    keep.append(m)
-    return a
+def ids_view(T, n_pairs, read_len, first_pair=0):
+    """kslam_reads_view of a fixed-length batch [R1 block | R2 block] without bases / quality columns (the SAM writer
+    gets NM / MD / log-probability from the GPU and never reads them): identifiers p<8 digits>, offsets."""
+    ids = np.empty((2 * n_pairs, 1 + W.ID_DIGITS), dtype=np.uint8)
+    ids[:, 0] = ord("p")
+    idx = np.tile(np.arange(first_pair, first_pair + n_pairs, dtype=np.int64), 2)
+    for d in range(W.ID_DIGITS):
+        ids[:, 1 + d] = (idx // 10 ** (W.ID_DIGITS - 1 - d)) % 10 + ord("0")
+    ids = ids.reshape(-1)
+    ioff = np.arange(2 * n_pairs + 1, dtype=np.uint64) * np.uint64(1 + W.ID_DIGITS)
+    boff = np.arange(2 * n_pairs + 1, dtype=np.uint64) * np.uint64(read_len)
+    rv = T.ReadsView(2 * n_pairs, None, boff.ctypes.data, None, boff.ctypes.data, ids.ctypes.data, ioff.ctypes.data)
+    return type("IdsView", (), {"view": rv, "n_reads": 2 * n_pairs, "_keep": (ids, ioff, boff)})()
 
 
-def sam_pipeline(K, ctx, reads, db, offs, read_len, steps, pseudo_assembly=False):
-    """Read columns in host memory -> SAM records on the host, the way a streaming caller runs it: the
-    batch goes up through the pipelined entry (kslam_submit_batch_columns: bases + qualities by DMA from
-    page-locked columns), comes back as overlap records + CIGARs + per-row NM / log-probability / MD
-    (kslam_row_details: the GPU walks every alignment's CIGAR + read + quality + entry window, so the host
-    writer formats text and never reads the 5 GB database), and goes through the host tail
-    (include/kslam_tail.h: pairing, insert-size / score screens, [pseudo-assembly,] SAM text) on a worker
-    thread while the next batches are on the GPU.  Reported next to the headline number; not `value`."""
-    import threading
-    T = importlib.import_module("kslam_amd.tail")
-    n_reads = reads.shape[0]
-    t0 = time.time()
-    nb = n_reads * read_len
-    hb, hq = K.HostBuffer(nb + 64), K.HostBuffer(nb + 64)
-    torch.from_numpy(hb.a[:nb].reshape(n_reads, read_len)).copy_(reads)
-    hq.a[:] = ord("I")                                             # quality: constant phred 40
-    off = np.arange(n_reads + 1, dtype=np.uint64) * np.uint64(read_len)
-    R = T.ReadsArrays(hb.a[:nb], read_len, quality_u8=hq.a[:nb])
-    # the index view the writer gets: offsets, names, taxonomy ids -- and NO copy of the database
-    I = T.IndexArrays(np.zeros(1, dtype=np.uint8), offs, taxonomy_ids=np.arange(1, len(offs), dtype=np.uint32))
-    P = T.TailParams.default(pseudo_assembly=pseudo_assembly)
-    P_write = T.TailParams.default(pseudo_assembly=False)         # when the GPU has run that stage too
-    gpu_stages = 7 if pseudo_assembly and os.environ.get("KSLAM_BENCH_HOST_PSEUDO") != "1" else 3
-    t_host_copy = time.time() - t0
-    stats, finished = [], []
-
-    def submit():
-        return ctx.submit_batch_columns(n_reads, hb.ptr, hq.ptr, off.ctypes.data)
-
-    def collect(tk):
-        res = ctx.collect_batch(tk)
-        return res + (ctx.last_pairs,)
-
-    def tail(ov, cg, det, md, release, pairs):
-        rp, pr, pst = pairs                        # read pairs / alignment pairs from the GPU (views: modified in place)
-        st = T.tail_finish_rows(P_write if pst["stages_done"] & 4 else P, R, I, ov, cg, det, md, rp, pr)
-        release()                                  # page-locked result buffers back to the library
-        d = st.as_dict()
-        d["gpu_pairing"] = pst
-        stats.append(d)
-        finished.append(time.perf_counter())       # batch complete: SAM text written
-
-    # score screen, pairing, insert-size statistics, screens [, pseudo-assembly, second screen]: on the GPU
-    ctx.set_pairing(paired=True, stages=gpu_stages)
-    for tk in [submit(), submit(), submit()]:       # warm both lanes' buffers and the tail's work buffers
-        tail(*collect(tk))
-    stats.clear()
-    del finished[:]
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    worker, done_at = None, []
-    pend = [submit(), submit()]                    # two batches on the GPU lanes
-    for k in range(steps):
-        res = collect(pend.pop(0))                 # batch k: its rows in page-locked buffers
-        if k + 2 < steps:
-            pend.append(submit())
-        if worker is not None:
-            worker.join()                          # host tail of batch k-1 must be done
-        worker = threading.Thread(target=tail, args=res)
-        worker.start()
-        done_at.append(time.perf_counter())
-    worker.join()
-    wall = time.perf_counter() - t0
-    tail_ms = [sum(v for k, v in s.items() if k.startswith("ms_")) for s in stats]
-    last = stats[-1]
-    ctx.set_pairing(stages=0)
-    hb.close()
-    hq.close()
-    # batch-to-batch in the steady state (completion of batch 0 to completion of the last): what a long run of
-    # batches sees; the wall clock of a short run also holds the pipeline's fill (first batch: upload + align +
-    # download with nothing to overlap) and drain (last host stage)
-    steady = (finished[-1] - finished[0]) / (len(finished) - 1) if len(finished) > 1 else wall / steps
-    return {
-        "reads_per_s": round(n_reads / steady, 1), "ms_per_batch": round(steady * 1e3, 2),
-        "including_pipeline_fill_and_drain": {"reads_per_s": round(n_reads * steps / wall, 1),
-                                              "ms_per_batch": round(wall / steps * 1e3, 2)},
-        "steps": steps, "host_tail_ms": round(sum(tail_ms) / len(tail_ms), 2),
-        "host_tail_phases_ms": {k[3:]: round(last[k], 2) for k in last if k.startswith("ms_")},
-        "host_threads": int(last["threads"]), "sam_mb_per_batch": round(last["sam_bytes"] / 1e6, 1),
-        "alignment_pairs": int(last["n_paired_final"]), "read_pairs_aligned": int(last["n_read_pairs"]),
-        "pseudo_assembly": bool(pseudo_assembly), "gpu_pairing": last["gpu_pairing"],
-        "pseudo_assembly_on": ("gpu" if last["gpu_pairing"]["stages_done"] & 4 else "host") if pseudo_assembly else None,
-        "what": "read columns in page-locked host memory -> kslam_submit_batch_columns (align + per-row NM / "
-                "log-probability / MD + score screen / pairing / insert-size statistics / screens%s on the GPU, two "
-                "batches in flight) -> kslam_collect_batch -> SAM text (host, discarded by the writer; no host copy "
-                "of the database) on a worker thread; one-time host copy of the reads took %.1f s" % (
-                    " / pseudo-assembly / second screen" if pseudo_assembly else "", t_host_copy),
-    }
-
-
-def full_pipeline(K, ctx, reads, db, offs, read_len, steps, pseudo_assembly=False):
-    """First FASTQ byte to last SAM byte, the way the reference's low-memory driver loops
-    (src/SLAM.h:193-241): per batch the two FASTQ texts are parsed on the host (include/kslam_fastq.h),
-    bases and qualities go to the GPU through the pipelined entry (kslam_submit_batch_columns: by DMA from
-    the parser's page-locked columns), come back as
-    overlap records + CIGARs + per-row NM / log-probability / MD (kslam_collect_batch) and go through the
-    host tail to SAM text -- parse of batch k+1, GPU work of batch k and tail of batch k-1 at the same
-    time.  Synthetic FASTQ text of the bench's own read batch, held in memory; the SAM text is handed to
-    a writer that discards it.  Reported next to the headline number; it is not `value`."""
-    import threading
-    F = importlib.import_module("kslam_amd.fastq")
-    T = importlib.import_module("kslam_amd.tail")
-    host = reads.cpu().numpy()
-    n = host.shape[0] // 2
-
-    def fastq_text(block, mate):
-        # fixed-width records "@p0000123/1\n<bases>\n+\n<quality>\n"
-        W = 2 + 7 + 3 + read_len + 3 + read_len + 1
-        a = np.empty((n, W), dtype=np.uint8)
-        a[:, 0:2] = np.frombuffer(b"@p", dtype=np.uint8)
-        idx = np.arange(n, dtype=np.int64)
-        for d in range(7):
-            a[:, 2 + d] = ((idx // 10 ** (6 - d)) % 10 + ord("0")).astype(np.uint8)
-        a[:, 9:12] = np.frombuffer(b"/%d\n" % mate, dtype=np.uint8)
-        a[:, 12:12 + read_len] = block
-        a[:, 12 + read_len:15 + read_len] = np.frombuffer(b"\n+\n", dtype=np.uint8)
-        a[:, 15 + read_len:15 + 2 * read_len] = ord("I")
-        a[:, W - 1] = ord("\n")
-        return a.tobytes()
-    r1, r2 = fastq_text(host[:n], 1), fastq_text(host[n:], 2)
-    # the two "files" as a host would hold them for this library: read into page-locked buffers
-    h1, h2 = K.HostBuffer(len(r1) + 64), K.HostBuffer(len(r2) + 64)
-    h1.a[:len(r1)] = np.frombuffer(r1, dtype=np.uint8)
-    h2.a[:len(r2)] = np.frombuffer(r2, dtype=np.uint8)
-    len1, len2 = len(r1), len(r2)
-    del r1, r2
-    I = T.IndexArrays(np.zeros(1, dtype=np.uint8), offs, taxonomy_ids=np.arange(1, len(offs), dtype=np.uint32))
-    nthr = int(os.environ.get("KSLAM_BENCH_HOST_THREADS", "0"))
-    P = T.TailParams.default(threads=nthr, pseudo_assembly=pseudo_assembly)
-    P_write = T.TailParams.default(threads=nthr, pseudo_assembly=False)   # when the GPU has run that stage too
-    gpu_stages = 7 if pseudo_assembly and os.environ.get("KSLAM_BENCH_HOST_PSEUDO") != "1" else 3
-    stats, on_gpu, finished = [], [], []
-
-    def collect(tk):
-        res = ctx.collect_batch(tk)
-        return res + (ctx.last_pairs, ctx.last_reads)
-
-    def tail(batch, ov, cg, det, md, release, pairs, reads_view):
-        rp, pr, pst = pairs
-        on_gpu.append(bool(pst["stages_done"] & 4))
-        st = T.tail_finish_rows(P_write if on_gpu[-1] else P, reads_view if reads_view is not None else batch, I, ov, cg,
-                                det, md, rp, pr)
-        release()
-        if batch is not None:
-            batch.close()
-        stats.append(st.as_dict())
-        finished.append(time.perf_counter())
-
-    ctx.set_pairing(paired=True, stages=gpu_stages)
-    host_index = os.environ.get("KSLAM_BENCH_HOST_FASTQ_INDEX") == "1"   # A/B: the record index on the host (round-2 first form)
-
-    def parse_and_submit():
-        t0 = time.perf_counter()
-        # the host only INDEXES the records (line ends, identifiers, offsets); the texts go up as they
-        # are and the bases / quality columns are cut out of them on the GPU
-        if not host_index:
-            # nothing is scanned on the host: line index, identifiers, offsets and columns are all made on the GPU
-            tk = ctx.submit_batch_fastq_text(h1.ptr, len1, h2.ptr, len2)
-            return None, tk, (0.0, time.perf_counter() - t0)
-        batch, u1, u2 = F.index_pair(h1.ptr, len1, h2.ptr, len2, threads=nthr)
-        t1 = time.perf_counter()
-        tk = ctx.submit_batch_fastq(h1.ptr, len1, h2.ptr, len2, batch.n_reads, batch._cols.bases_off,
-                                    batch.layout.bases_at, batch.layout.quality_at)
-        return batch, tk, (t1 - t0, time.perf_counter() - t1)
-    import ctypes as C
-    worker, parts, waits, joins = None, [], [], []
-
-    depth = int(os.environ.get("KSLAM_LANES", "2")) + 1
-
-    def run(nsteps):
-        nonlocal worker
-        queue = [parse_and_submit()]                               # batch 0 on its way
-        for k in range(nsteps):
-            while len(queue) < depth and k + len(queue) < nsteps:  # more batches queued behind it: one per lane + 1
-                queue.append(parse_and_submit())
-            cur = queue.pop(0)
-            tw = time.perf_counter()
-            res = collect(cur[1])                                  # batch k back from the GPU
-            waits.append(time.perf_counter() - tw)
-            tj = time.perf_counter()
-            if worker is not None:
-                worker.join()                                      # host stage of batch k-1 done
-            joins.append(time.perf_counter() - tj)
-            worker = threading.Thread(target=tail, args=(cur[0],) + tuple(res))
-            worker.start()
-            parts.append(cur[2])
-        worker.join()
-        worker = None
-    run(6)          # warm-up in the same shape: both lanes, the parser's page-locked block cache, the tail's arenas
-    stats.clear()
-    del parts[:], waits[:], joins[:], finished[:]
-    torch.cuda.synchronize()
-    t_start = time.perf_counter()
-    run(steps)
-    wall = time.perf_counter() - t_start
-    n_reads = 2 * n
-    ms = lambda k: round(1e3 * sum(p[k] for p in parts) / len(parts), 2)   # noqa: E731
-    ctx.set_pairing(stages=0)
-    h1.close()
-    h2.close()
-    steady = (finished[-1] - finished[0]) / (len(finished) - 1) if len(finished) > 1 else wall / steps   # see sam_pipeline
-    return {
-        "reads_per_s": round(n_reads / steady, 1), "ms_per_batch": round(steady * 1e3, 2), "steps": steps,
-        "including_pipeline_fill_and_drain": {"reads_per_s": round(n_reads * steps / wall, 1),
-                                              "ms_per_batch": round(wall / steps * 1e3, 2)},
-        "ms_fastq_parse": ms(0), "ms_submit": ms(1), "ms_waiting_for_gpu": round(1e3 * sum(waits) / len(waits), 2),
-        "ms_waiting_for_host_stage": round(1e3 * sum(joins) / len(joins), 2),
-        "host_tail_ms": round(sum(sum(v for k, v in s.items() if k.startswith("ms_")) for s in stats) / len(stats), 2),
-        "host_tail_phases_ms": {k[3:]: round(stats[-1][k], 2) for k in stats[-1] if k.startswith("ms_")},
-        "fastq_mb_per_batch": round((len1 + len2) / 1e6, 1), "sam_mb_per_batch": round(stats[-1]["sam_bytes"] / 1e6, 1),
-        "pseudo_assembly": bool(pseudo_assembly),
-        "pseudo_assembly_on": ("gpu" if all(on_gpu) else "host") if pseudo_assembly else None,
-        "fastq_index": "host" if host_index else "gpu",
-        "what": "FASTQ text (2 files, in page-locked memory) -> kslam_submit_batch_fastq_text (texts up by DMA; line index, "
-                "identifiers, offsets and the bases / quality columns made on the GPU; align, per-row "
-                "NM / log-probability / MD, score screen / pairing / insert-size statistics / screens [/ pseudo-assembly / "
-                "second screen]) -> kslam_collect_batch -> SAM text (host, discarded by the "
-                "writer; no host copy of the database); three batches in flight, the host stage of batch k-1 under the GPU "
-                "work of batches k, k+1",
-    }
-
-
+# ------------------------------------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--pairs", type=int, default=1_000_000, help="read pairs per GPU per step")
+    ap.add_argument("--config", type=int, default=0, choices=[0, 1, 2, 3, 4],
+                    help="BASELINE configs[k]; default 1 at --gpus 1, 3 (strong) at --gpus > 1")
+    ap.add_argument("--pairs", type=int, default=0, help="read pairs per batch (default: 1 M for config 1, 10 M for 2 and 4)")
     ap.add_argument("--species", type=int, default=250)
     ap.add_argument("--strains", type=int, default=5)
     ap.add_argument("--genome-len", type=int, default=4_000_000)
+    ap.add_argument("--viral", type=int, default=-1, help="viral genomes appended to the database (default: 10000 for config 2, else 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=300000)
     ap.add_argument("--cpu-genomes", type=int, default=25)
+    ap.add_argument("--cpu-full", action="store_true", help="cpu_baseline on the WHOLE workload of this run (minutes to hours of CPU time)")
     ap.add_argument("--no-cigar", action="store_true")
     ap.add_argument("--no-abi-path", action="store_true", help="skip the host-pointers-in / host-results-out leg")
-    ap.add_argument("--no-sam-pipeline", action="store_true", help="skip the GPU + host-tail pipeline leg")
-    ap.add_argument("--no-full-pipeline", action="store_true", help="skip the FASTQ text -> SAM text leg")
-    ap.add_argument("--read-len", type=int, default=READ_LEN, help="150 (BASELINE configs[1..3]) or 250 (configs[4])")
+    ap.add_argument("--no-e2e", action="store_true", help="hot path only: `value` is then the resident-input rate and says so")
+    ap.add_argument("--no-sam-pipeline", dest="no_e2e", action="store_true", help=argparse.SUPPRESS)    # rounds 1-2 spelling (tools/*.sh)
+    ap.add_argument("--no-full-pipeline", dest="no_e2e", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--read-len", type=int, default=0, help="150 (configs[1..3]) or 250 (configs[4])")
     ap.add_argument("--strong", action="store_true",
-                    help="BASELINE configs[3] shape: ONE batch of --total-pairs pairs per step, split over the GPUs, "
-                         "timed until rank 0 holds the merged result (default when --gpus > 1)")
-    ap.add_argument("--weak", action="store_true", help="with --gpus > 1: --pairs fresh pairs per GPU instead")
+                    help="configs[3] shape: ONE batch of --total-pairs pairs per step, split over the GPUs (default when --gpus > 1)")
+    ap.add_argument("--weak", action="store_true", help="with --gpus > 1: --pairs fresh pairs per GPU instead (hot path only)")
     ap.add_argument("--total-pairs", type=int, default=10_000_000,
                     help="pairs per batch in --strong mode (the reference's --num-reads-at-once default, src/main.cpp:56)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args, sys.argv[1:])       # before this process makes any HIP call
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    share = os.environ.get("KSLAM_BENCH_SHARE_GPU") == "1"
+    if world > torch.cuda.device_count() and not share:
+        raise SystemExit("--gpus %d but %d device(s) visible" % (world, torch.cuda.device_count()))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the hot path has no CPU fallback")
     # KSLAM_BENCH_SHARE_GPU=1 (tests only): the ranks share the GPUs that exist, and talk through gloo with
     # host-staged pieces -- RCCL refuses two ranks on one device.  Everything else (sharding, count exchange,
     # export in batch terms, placement, verification) is the code a real N-GPU run executes.
-    share = os.environ.get("KSLAM_BENCH_SHARE_GPU") == "1"
     if share:
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
@@ -433,8 +387,18 @@ def main():
 
     K = entry.load_package()
     kdist = importlib.import_module("kslam_amd.dist")
-    strong = args.strong or (world > 1 and not args.weak)
-    PIECES = 8          # the strong batch is generated in 8 fixed pieces, so it is the same batch for N = 1, 2, 4, 8
+    T = importlib.import_module("kslam_amd.tail")
+    X = importlib.import_module("kslam_amd.taxonomy")
+    S = importlib.import_module("kslam_amd.stream")
+    strong = args.strong or (world > 1 and not args.weak) or args.config == 3
+    config = args.config or (3 if strong else 1)
+    if config == 3:
+        strong = True
+    read_len = args.read_len or (250 if config == 4 else READ_LEN)
+    pairs = args.pairs or (1_000_000 if config in (1, 3) else 10_000_000)
+    n_viral = args.viral if args.viral >= 0 else (10_000 if config == 2 else 0)
+    pseudo = config != 1                     # configs[1] is quoted with --no-pseudo-assembly; the reference's default is on
+    by_length = n_viral > 0
     if strong and (8 % world or args.total_pairs % PIECES):
         raise SystemExit("--strong needs 1, 2, 4 or 8 ranks and --total-pairs divisible by 8")
 
@@ -442,36 +406,38 @@ def main():
     gen = torch.Generator(device=dev)
     gen.manual_seed(1)                      # database: same on every rank (replicated index)
     t0 = time.time()
-    db, offs = make_database(dev, gen, args.species, args.strains, args.genome_len)
+    db, offs = make_database(dev, gen, args.species, args.strains, args.genome_len, n_viral=n_viral)
+    n_entries = len(offs) - 1
     if strong:
         # this rank's pairs [pair_lo, pair_hi) of the one batch, local layout [R1 of them | R2 of them]
         piece = args.total_pairs // PIECES
         mine = range(rank * PIECES // world, (rank + 1) * PIECES // world)
         pair_lo, pair_hi = mine[0] * piece, (mine[-1] + 1) * piece
-        r1s, r2s, tr = [], [], []
-        for pc in mine:
-            gen.manual_seed(2 + 1000 * pc)
-            r, t = make_reads(dev, gen, db, offs, piece, read_len=args.read_len, with_truth=True)
-            r1s.append(r[:piece]); r2s.append(r[piece:]); tr.append(t)
-        reads = torch.cat(r1s + r2s, 0).contiguous()
-        truth = {k: torch.cat([t[k][:piece] for t in tr] + [t[k][piece:] for t in tr]) for k in tr[0]}
-        del r1s, r2s, tr
+        reads, truth = W.make_batch_in_pieces(dev, gen, db, offs, args.total_pairs, read_len, pieces=PIECES, first_piece=mine[0],
+                                              n_pieces=len(mine), by_length=by_length)
         n_batch_pairs = args.total_pairs
+    elif pairs > 2_000_000:
+        reads, truth = W.make_batch_in_pieces(dev, gen, db, offs, pairs, read_len, pieces=PIECES, seed_base=2 + 1000 * rank,
+                                              by_length=by_length)
+        pair_lo, pair_hi = rank * pairs, (rank + 1) * pairs
+        n_batch_pairs = pairs * world
     else:
         gen.manual_seed(2 + 1000 * rank)        # reads: a different shard of pairs per rank
-        reads, truth = make_reads(dev, gen, db, offs, args.pairs, read_len=args.read_len, with_truth=True)
-        pair_lo, pair_hi = rank * args.pairs, (rank + 1) * args.pairs
-        n_batch_pairs = args.pairs * world
+        reads, truth = make_reads(dev, gen, db, offs, pairs, read_len=read_len, with_truth=True, by_length=by_length)
+        pair_lo, pair_hi = rank * pairs, (rank + 1) * pairs
+        n_batch_pairs = pairs * world
     torch.cuda.synchronize()
     t_gen = time.time() - t0
 
     ctx = K.Context(report_cigar=not args.no_cigar, device=local_rank)
     t0 = time.time()
-    ctx.set_index_device(len(offs) - 1, db.data_ptr(), offs)
+    ctx.set_index_device(n_entries, db.data_ptr(), offs)
     t_index = time.time() - t0
     n_reads = reads.shape[0]
-    roffs = (np.arange(n_reads + 1, dtype=np.uint64) * np.uint64(args.read_len))
+    roffs = (np.arange(n_reads + 1, dtype=np.uint64) * np.uint64(read_len))
     ctx.load_reads_device(n_reads, reads.data_ptr(), roffs)
+    tax_text, entry_tax = W.taxonomy(args.species, args.strains, n_viral)
+    index_view = T.IndexArrays(np.zeros(1, dtype=np.uint8), offs, taxonomy_ids=entry_tax)   # no host copy of the database
 
     pending = []   # the gather of the previous batch, still in flight while this one is aligned
     merged = {}    # rank 0, --strong: the batch-global result of the last finished batch (device tensors)
@@ -485,6 +451,7 @@ def main():
                 merged["ov"], merged["cg"] = got
 
     split = {"align": 0.0, "wait_for_previous_gather": 0.0, "counts_export_post": 0.0}   # host clock, this rank, timed steps
+    gathered_bytes = [0]
 
     def step():
         ta = time.perf_counter()
@@ -507,6 +474,12 @@ def main():
             ctx.copy_results_device(ov.data_ptr(), cg.data_ptr())
             drain()
             pending.append(kdist.start_gather(ov, cg))
+        elif strong:
+            ov = torch.empty(n_out * 48, dtype=torch.uint8, device=dev)
+            cg = torch.empty(max(n_cig, 1) * 4, dtype=torch.uint8, device=dev)
+            ctx.copy_results_device(ov.data_ptr(), cg.data_ptr())
+            merged["ov"], merged["cg"] = ov, cg[:n_cig * 4]
+        gathered_bytes[0] = n_out * 48 + n_cig * 4
         return n_out, n_cig
 
     def barrier():
@@ -516,6 +489,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # ================= the hot path: alignToDatabase on the resident batch (+ the gather when sharded) =================
     for _ in range(args.warmup):
         step()
     acc = {}
@@ -529,11 +503,14 @@ def main():
             acc[k] = acc.get(k, 0) + v
     barrier()
     elapsed = time.perf_counter() - t0
+    split_max, per_rank_align = dict(split), None
     if use_dist:
         te = torch.tensor([elapsed] + [split[k] for k in sorted(split)], dtype=torch.float64, device=cdev)
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te[0].item())
-        split_max = {k: float(v) for k, v in zip(sorted(split), te[1:].tolist())}     # slowest rank per part
+        allr = [torch.zeros_like(te) for _ in range(world)]
+        dist.all_gather(allr, te)
+        elapsed = max(float(a[0]) for a in allr)
+        split_max = {k: max(float(a[1 + i]) for a in allr) for i, k in enumerate(sorted(split))}
+        per_rank_align = [round(float(a[1 + sorted(split).index("align")]) / args.steps * 1e3, 3) for a in allr]
 
     # ---- outside the timed region: is what was just timed RIGHT?  (no oracle here: the generator's
     # own ground truth, the reference's structural expectations of src/Tests.h:161-264, :321-330) ----
@@ -544,51 +521,143 @@ def main():
         ctx.copy_results_device(ov.data_ptr(), cg.data_ptr())
         return ov, cg[:n_cig * 4].view(torch.int32)
     ov_a, cg_a = device_results()
-    verified = W.check_against_truth(ov_a, None if args.no_cigar else cg_a, truth, args.read_len)
+    verified = W.check_against_truth(ov_a, None if args.no_cigar else cg_a, truth, read_len)
     ov_b, cg_b = device_results()
     verified["run_to_run_identical"] = bool(ov_a.numel() == ov_b.numel() and torch.equal(ov_a, ov_b)
                                             and torch.equal(cg_a, cg_b))
     verified["ok"] = bool(verified["ok"] and verified["run_to_run_identical"])
+    ranks_seen = 1
     if use_dist:   # every rank checked its own shard: sum the counts, AND the verdicts
         keys = [k for k, v in verified.items() if not isinstance(v, bool)]
-        t = torch.tensor([verified[k] for k in keys] + [int(verified["ok"]), int(verified["run_to_run_identical"])],
+        t = torch.tensor([verified[k] for k in keys] + [int(verified["ok"]), int(verified["run_to_run_identical"]), 1],
                          dtype=torch.int64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         for k, v in zip(keys, t[:len(keys)].tolist()):
             verified[k] = int(v)
-        verified["ok"] = bool(int(t[-2]) == world)
-        verified["run_to_run_identical"] = bool(int(t[-1]) == world)
-    if strong and use_dist and rank == 0 and "ov" in merged:
-        # the merged batch: row count, order, and -- when this rank aligned the whole batch itself (one
-        # rank) -- byte identity with the single-context result
+        verified["ok"] = bool(int(t[-3]) == world)
+        verified["run_to_run_identical"] = bool(int(t[-2]) == world)
+        ranks_seen = int(t[-1])
+    whole = None
+    if strong and rank == 0 and "ov" in merged:
+        # the merged batch: row count, order, and byte identity with what ONE context returns for the whole batch
         mc = W.overlap_columns(merged["ov"])
         n_rel = int(mc["rel"].max()) + 1026 if mc["rel"].numel() else 1026
-        mkey = (mc["read"] * (len(offs) - 1) + mc["entry"]) * n_rel + (mc["rel"] + 1024)
+        mkey = (mc["read"] * n_entries + mc["entry"]) * n_rel + (mc["rel"] + 1024)
         verified["merged_rows"] = int(mkey.numel())
         verified["merged_unsorted_neighbours"] = int((mkey[1:] < mkey[:-1]).sum()) if mkey.numel() > 1 else 0
+        del mc, mkey
         if world > 1:
-            # the whole batch once more, in THIS rank's context alone (outside the timed region): what the N ranks
-            # produced together must be, byte for byte, what one context returns for the batch
+            # the whole batch once more, in THIS rank's context alone (outside the timed region)
             del ov_a, cg_a, ov_b, cg_b
-            piece = args.total_pairs // PIECES
-            r1s, r2s = [], []
-            for pc in range(PIECES):
-                gen.manual_seed(2 + 1000 * pc)
-                r = make_reads(dev, gen, db, offs, piece, read_len=args.read_len)
-                r1s.append(r[:piece]); r2s.append(r[piece:])
-            whole = torch.cat(r1s + r2s, 0).contiguous()
-            del r1s, r2s
+            whole, _ = W.make_batch_in_pieces(dev, gen, db, offs, args.total_pairs, read_len, pieces=PIECES, by_length=by_length,
+                                              with_truth=False)
             ctx.load_reads_device(whole.shape[0], whole.data_ptr(),
-                                  np.arange(whole.shape[0] + 1, dtype=np.uint64) * np.uint64(args.read_len))
+                                  np.arange(whole.shape[0] + 1, dtype=np.uint64) * np.uint64(read_len))
             ov_a, cg_a = device_results()
             ov_b = cg_b = None
-            del whole
+            ctx.load_reads_device(n_reads, reads.data_ptr(), roffs)      # back to this rank's shard for the second clock
+        else:
+            whole = reads
         verified["merged_equals_single_context"] = bool(
             merged["ov"].numel() == ov_a.numel() and torch.equal(merged["ov"], ov_a) and
             torch.equal(merged["cg"].view(torch.int32), cg_a))
         verified["ok"] = bool(verified["ok"] and verified["merged_equals_single_context"])
         verified["ok"] = bool(verified["ok"] and verified["merged_unsorted_neighbours"] == 0)
     del ov_a, cg_a, ov_b, cg_b
+
+    # ================= strong mode, second clock: through the batch-global tail to SAM text + per-read taxa on rank 0 =================
+    classified = None
+    if strong and not args.no_e2e and not args.no_cigar:
+        taxdb = X.TaxDB(tax_text) if rank == 0 else None
+        tail_ctx = rv = None
+        if rank == 0:
+            # rank 0 keeps the WHOLE batch (bases + qualities) resident in a sibling context that borrows the index: the
+            # per-row walk of the SAM writer (NM / MD / log-probability) needs every read of the batch next to the genomes
+            tail_ctx = ctx.sibling()
+            tail_ctx.load_reads_device(whole.shape[0], whole.data_ptr(), np.arange(whole.shape[0] + 1, dtype=np.uint64) * np.uint64(read_len))
+            qgen = torch.Generator(device=dev)
+            qgen.manual_seed(4242)
+            qual = torch.randint(33 + 20, 33 + 41, (whole.shape[0] * read_len + 64,), generator=qgen, device=dev, dtype=torch.uint8)
+            torch.cuda.synchronize()
+            tail_ctx.load_qualities_device(qual.data_ptr())
+            del qual
+            rv = ids_view(T, args.total_pairs, read_len)
+        P_write = T.TailParams.default(pseudo_assembly=False)
+        P_host = T.TailParams.default(pseudo_assembly=True)
+        sam_path = "/dev/shm/kslam_bench_%d_strong.sam" % os.getpid()
+        pr_path = sam_path + "_PerRead"
+        tail_ms = {"adopt_pair_screen_details": 0.0, "download": 0.0, "host_sam_and_lca": 0.0}
+        tail_out = {}
+        worker = [None]
+
+        def host_stage(ov, cg, det, md, rp, pr, pst, releases, fds):
+            t1 = time.perf_counter()
+            st = S.finish_rows_fd(P_write if pst["stages_done"] & 4 else P_host, rv, index_view, ov, cg, det, md, rp, pr, fds[0])
+            ids, text = taxdb.classify(P_write, rv, index_view, rp, pr, per_read=True)
+            os.write(fds[1], text)
+            for r in releases:
+                r()
+            tail_ms["host_sam_and_lca"] += time.perf_counter() - t1
+            tail_out.update(sam_bytes=int(st.sam_bytes), per_read_lines=int(len(ids)), alignment_pairs=int(st.n_paired_final),
+                            max_insert_size=int(pst["max_insert_size"]), pseudo_on="gpu" if pst["stages_done"] & 4 else "host")
+
+        def tail_step(fds):
+            # rank 0, after the gather of this batch has landed: the reference's per-batch steps after alignToDatabase
+            # (src/SLAM.h:210-249) on the merged batch
+            t1 = time.perf_counter()
+            n_rows, n_ops = merged["ov"].numel() // 48, merged["cg"].numel() // 4
+            tail_ctx.adopt_results_device(merged["ov"].data_ptr(), n_rows, merged["cg"].data_ptr(), n_ops)
+            pst = tail_ctx.pair_screen(paired=True, stages=7)
+            tail_ctx.row_details(of_pairs=True)
+            t2 = time.perf_counter()
+            ov, cg, rel1 = tail_ctx.take_results()
+            det, md, rel2 = tail_ctx.take_row_details(len(ov), copy=False)
+            rp, pr, rel3 = tail_ctx.take_pairs(copy=False)
+            t3 = time.perf_counter()
+            tail_ms["adopt_pair_screen_details"] += t2 - t1
+            tail_ms["download"] += t3 - t2
+            if worker[0] is not None:
+                worker[0].join()                          # the host stage of the previous batch
+            worker[0] = threading.Thread(target=host_stage, args=(ov, cg, det, md, rp, pr, pst, (rel1, rel2, rel3), fds))
+            worker[0].start()
+
+        def classified_steps(k):
+            fds = None
+            if rank == 0:
+                fds = (os.open(sam_path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o600),
+                       os.open(pr_path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o600))
+            for _ in range(k):
+                step()
+                if rank == 0:
+                    drain()                               # this batch's rows have landed on rank 0
+                    tail_step(fds)
+            if rank == 0:
+                worker[0].join()
+                worker[0] = None
+                for fd in fds:
+                    os.close(fd)
+        classified_steps(max(args.warmup, 1))
+        for k in tail_ms:
+            tail_ms[k] = 0.0
+        barrier()
+        t0 = time.perf_counter()
+        classified_steps(args.steps)
+        barrier()
+        el2 = time.perf_counter() - t0
+        if use_dist:
+            te = torch.tensor([el2], dtype=torch.float64, device=cdev)
+            dist.all_reduce(te, op=dist.ReduceOp.MAX)
+            el2 = float(te[0])
+        if rank == 0:
+            classified = {"elapsed": el2, "rank0_tail_ms_per_step": {k: round(v / args.steps * 1e3, 2) for k, v in tail_ms.items()},
+                          "sam_mb_per_batch": round(tail_out["sam_bytes"] / 1e6, 1), "per_read_lines_per_batch": tail_out["per_read_lines"],
+                          "alignment_pairs_per_batch": tail_out["alignment_pairs"], "max_insert_size": tail_out["max_insert_size"],
+                          "pseudo_assembly_on": tail_out["pseudo_on"],
+                          "sam_file_bytes": os.path.getsize(sam_path), "per_read_file_bytes": os.path.getsize(pr_path)}
+            for pth in (sam_path, pr_path):
+                os.unlink(pth)
+            tail_ctx.close()
+            taxdb.close()
 
     # RCCL announces itself on stdout through C stdio ("Librccl path : ..."), buffered when piped and
     # otherwise flushed when each rank exits -- after rank 0's JSON.  Every rank pushes it out now,
@@ -602,10 +671,9 @@ def main():
         dist.barrier()
 
     if rank == 0:
-        S = args.steps
-        tm = {k: v / S for k, v in acc.items()}
-        total_reads = 2 * n_batch_pairs * S
-        n_kmers = tm["n_read_kmers"]
+        Ksteps = args.steps
+        tm = {k: v / Ksteps for k, v in acc.items()}
+        total_reads = 2 * n_batch_pairs * Ksteps
         passes = int(round(tm["sort_passes"]))
         launches = max(tm["n_scatter_launches"], 1)
         launch_ms = tm["ms_sort_scatter"] / launches
@@ -614,7 +682,7 @@ def main():
         achieved = per_launch_bytes / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and config == 1:
             try:
                 traffic = json.load(open(tpath)).get("k_scatter_bytes_per_launch")
             except Exception:
@@ -624,12 +692,12 @@ def main():
         # committed counter run of this same workload (tools/pmc_valu.sh -> profiles/sw_valu.json), time measured live
         sw_valu = None
         vpath = os.path.join(ROOT, "profiles", "sw_valu.json")
-        if os.path.exists(vpath) and args.read_len == READ_LEN and not strong and args.pairs == 1_000_000 and tm["ms_sw"] > 0:
+        if os.path.exists(vpath) and config == 1 and pairs == 1_000_000 and args.species == 250 and tm["ms_sw"] > 0:
             try:
                 vj = json.load(open(vpath))
                 instr = float(vj["sw_phase_per_align"]["valu_wave_instr"])
                 rate = instr / (tm["ms_sw"] * 1e-3) / 1e9
-                sw_valu = {"bound": "valu-issue", "kernels": "k_sw_plan + k_sw_band<...> tiers + k_sw (the SW phase, 61 % of the step)",
+                sw_valu = {"bound": "valu-issue", "kernels": "k_sw_plan + k_sw_band<...> tiers + k_sw (the SW phase, the largest share of the step)",
                            "achieved": round(rate, 1), "peak": 1228.8, "unit": "G wave-instr/s", "frac": round(rate / 1228.8, 4),
                            "sustained_for_4_cycle_kinds": 575.0, "sustained_for_2_cycle_kinds": 1084.0,
                            "valu_wave_instr_per_step": int(instr), "ms": round(tm["ms_sw"], 3),
@@ -638,81 +706,121 @@ def main():
                                    "rate is the realistic ceiling; instruction count from profiles/sw_valu.json (PMC, separate run)"}
             except Exception:
                 sw_valu = None
+        db_desc = "%d-genome (%d species x %d strains x %.1f Mb%s = %.2f Gb) synthetic %s db" % (
+            n_entries, args.species, args.strains, args.genome_len / 1e6, " + %d viral genomes of 5-200 kb" % n_viral if n_viral else "",
+            float(offs[-1]) / 1e9, "bacterial + viral" if n_viral else "bacterial")
+        roofline = {
+            "bound": "hbm", "kernel": "k_scatter<4> (the scatter launch of one radix pass of the read k-mer sort; the sort only sees "
+                                      "the k-mers the genome filter lets through)",
+            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "launch_ms": round(launch_ms, 4), "bytes_per_launch": int(per_launch_bytes),
+            "sort_phase": {"passes": passes, "bytes": int(sort_bytes), "ms": round(tm["ms_sort"], 3),
+                           "frac": round(sort_bytes / (tm["ms_sort"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if tm["ms_sort"] > 0 else 0.0},
+            # context, not the roofline: what the best hand-written streaming copy of the same bytes
+            # sustained on a bench box (tools/copy_peak.hip, profiles/r01h_copy_peak.txt)
+            "streaming_copy_ceiling": {"GB/s": 5590.0, "measured": "profiles/r01h_copy_peak.txt"},
+        }
+        hot = {
+            "reads_per_s": round(total_reads / elapsed, 1), "ms_per_step": round(elapsed / Ksteps * 1e3, 3),
+            "what": ("ONE batch of %d pairs per step, read pairs split over %d GPU(s), timed until rank 0 holds the merged overlap records"
+                     % (args.total_pairs, world)) if strong else
+                    "alignToDatabase incl. CIGAR on a batch that is resident in HBM; results stay on the device",
+            "phases_ms": {k: round(tm[k], 3) for k in ("ms_extract", "ms_sort", "ms_join", "ms_sw", "ms_cigar", "ms_total")},
+            "counts": {"read_kmers": int(tm["n_read_kmers"]), "read_kmers_kept_by_filter": int(tm["n_kmers_kept"]),
+                       "genome_kmers": int(tm["n_genome_kmers"]), "overlaps_raw": int(tm["n_overlaps_raw"]),
+                       "candidates": int(tm["n_overlaps"]), "cigar_ops": int(n_cig), "chunks": int(tm["n_chunks"])},
+            "sw_gcups": round(tm["sw_cells"] / ((tm["ms_sw"]) * 1e-3) / 1e9, 1) if tm["ms_sw"] > 0 else 0.0,
+            "verified": verified,
+        }
         out = {
-            "metric": "paired %dbp reads/sec classified (bit-exact SAM)" % args.read_len,
-            "value": round(total_reads / elapsed, 1),
-            "unit": "reads/s",
-            "n_gpus": world, "steps": S, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / S * 1e3, 3),
+            "metric": "paired %dbp reads/sec classified (bit-exact SAM)" % read_len,
+            "value": None, "unit": "reads/s",
+            "n_gpus": world, "steps": Ksteps, "warmup": args.warmup, "ms_per_step": None,
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "u64 k-mers / i32 DP", "data": "synthetic",
             "config": {
-                "workload": ("BASELINE configs[3]: ONE batch of %d x 2 x %d bp reads per step, read pairs split over %d GPU(s), "
-                             "timed until rank 0 holds the merged result, vs %d-genome " % (
-                                 args.total_pairs, args.read_len, world, len(offs) - 1) if strong else
-                             "BASELINE configs[%d]: %d x 2 x %d bp reads per GPU vs %d-genome " % (
-                                 4 if args.read_len > 150 else 1, args.pairs, args.read_len, len(offs) - 1)) +
-                            "(%d species x %d strains x %.1f Mb = %.2f Gb) synthetic bacterial db, "
-                            "hot path alignToDatabase incl. CIGAR, inputs resident in HBM" % (
-                                args.species, args.strains, args.genome_len / 1e6, float(offs[-1]) / 1e9),
-                "pairs_per_batch": n_batch_pairs,
-                "pairs_per_gpu": n_reads // 2, "db_bases": int(offs[-1]),
+                "workload": ("BASELINE configs[3]: ONE batch of %d x 2 x %d bp reads per step, read pairs split over %d GPU(s), vs %s"
+                             % (args.total_pairs, read_len, world, db_desc)) if strong else
+                            ("BASELINE configs[%d]: %d x 2 x %d bp reads per batch%s vs %s, %s" % (
+                                config, pairs, read_len, " per GPU" if world > 1 else "", db_desc,
+                                "pseudo-assembly on (the reference's default)" if pseudo else "--no-pseudo-assembly")),
+                "pairs_per_batch": n_batch_pairs, "pairs_per_gpu": n_reads // 2, "db_bases": int(offs[-1]), "db_entries": n_entries,
                 "parallelism": "read pairs sharded x%d, genome k-mer list replicated, gather to rank 0" % world,
             },
-            "roofline": {
-                "bound": "hbm", "kernel": "k_scatter<4> (the scatter launch of one radix pass of the read k-mer sort; "
-                                          "since round 2 the sort only sees the k-mers the genome filter lets through)",
-                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "launch_ms": round(launch_ms, 4), "bytes_per_launch": int(per_launch_bytes),
-                "sort_phase": {"passes": passes, "bytes": int(sort_bytes), "ms": round(tm["ms_sort"], 3),
-                               "frac": round(sort_bytes / (tm["ms_sort"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-                               if tm["ms_sort"] > 0 else 0.0},
-                # context, not the roofline: what the best hand-written streaming copy of the same bytes
-                # sustained on a bench box (tools/copy_peak.hip, profiles/r01h_copy_peak.txt)
-                "streaming_copy_ceiling": {"GB/s": 5590.0, "measured": "profiles/r01h_copy_peak.txt"},
-            },
-            "roofline_valu": sw_valu,
-            "phases_ms": {k: round(tm[k], 3) for k in ("ms_extract", "ms_sort", "ms_join", "ms_sw",
-                                                         "ms_cigar", "ms_total")},
-            "counts": {"read_kmers": int(n_kmers), "read_kmers_kept_by_filter": int(tm["n_kmers_kept"]),
-                       "genome_kmers": int(tm["n_genome_kmers"]),
-                       "overlaps_raw": int(tm["n_overlaps_raw"]), "candidates": int(tm["n_overlaps"]),
-                       "cigar_ops": int(n_cig), "chunks": int(tm["n_chunks"])},
-            "sw_gcups": round(tm["sw_cells"] / ((tm["ms_sw"]) * 1e-3) / 1e9, 1) if tm["ms_sw"] > 0 else 0.0,
+            "value_definition": None,
+            "hot_path": hot, "roofline": roofline, "roofline_valu": sw_valu,
             "setup_s": {"generate": round(t_gen, 2), "index_build": round(t_index, 2)},
-            "verified": verified,
         }
+        if use_dist:
+            out["rccl"] = {"backend": dist.get_backend(), "world": world, "ranks_seen": ranks_seen,
+                           "bytes_gathered_per_step": int(merged["ov"].numel() + merged["cg"].numel()) if "ov" in merged else 0,
+                           "launched_by": os.environ.get("KSLAM_BENCH_LAUNCHED_BY", "external launcher (torch.distributed.run)"),
+                           "shared_gpu": bool(share)}
+            out["per_rank_align_ms"] = per_rank_align
         if use_dist and strong:
-            # where a step's time goes on the host clock (per step; max over ranks, and rank 0 = the collecting rank):
-            # the align call, the wait for the previous batch's gather to land, and count exchange + export + posting
             out["strong_step_split_ms"] = {
-                "max_over_ranks": {k: round(v / S * 1e3, 3) for k, v in split_max.items()},
-                "rank0": {k: round(v / S * 1e3, 3) for k, v in split.items()}}
+                "max_over_ranks": {k: round(v / Ksteps * 1e3, 3) for k, v in split_max.items()},
+                "rank0": {k: round(v / Ksteps * 1e3, 3) for k, v in split.items()}}
+        if strong and classified is not None:
+            out["value"] = round(total_reads / classified["elapsed"], 1)
+            out["ms_per_step"] = round(classified["elapsed"] / Ksteps * 1e3, 3)
+            del classified["elapsed"]
+            out["classified"] = classified
+            out["value_definition"] = (
+                "K steps, each: every rank aligns its read pairs of the one batch (resident in its HBM), the overlap records are "
+                "gathered to rank 0, rank 0 runs the batch-global steps on the merged batch (score screen, pairing, insert-size "
+                "statistics, screens, pseudo-assembly, per-row NM / MD / log-probability on its GPU; SAM text written to a file and "
+                "per-read LCA written to _PerRead on its host CPUs, overlapped with the next step's alignment); max over ranks.  "
+                "`hot_path.reads_per_s` stops the clock when rank 0 holds the merged records.  The tail is NOT sharded: it is the "
+                "Amdahl term of the strong-scaling curve (DESIGN.md section 5)")
+        else:
+            out["value_definition"] = "see e2e" if not args.no_e2e and not strong else "hot path only (--no-e2e): resident-input alignToDatabase"
+        torch.cuda.empty_cache()       # what torch's allocator cached while generating the inputs goes back to the device
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(K, db, offs, 77, args.cpu_genomes, args.cpu_pairs, args.read_len, local_rank)
-        torch.cuda.empty_cache()       # what torch's allocator cached while generating the inputs goes back to the device:
-                                       # the legs below run two more contexts' worth of library buffers
-        if world == 1 and not strong and not args.no_abi_path:
+            if args.cpu_full:
+                out["cpu_baseline"] = cpu_baseline(K, db, offs, 2, n_entries, pairs, read_len, local_rank, full=True)
+            else:
+                out["cpu_baseline"] = cpu_baseline(K, db, offs, 77, args.cpu_genomes, args.cpu_pairs, read_len, local_rank)
+        if world == 1 and not strong and not args.no_abi_path and pairs <= 2_000_000:
             try:
-                out["abi_path"] = abi_path(K, ctx, reads, args.read_len, max(args.steps, 12))
+                out["abi_path"] = abi_path(K, ctx, reads, read_len, max(Ksteps, 12))
             except Exception as e:   # extra evidence only: never lose the bench line over it
                 out["abi_path"] = {"error": repr(e)}
-        # The pipeline legs run the host tail with the flags of the configuration they are on: BASELINE
-        # configs[1] is quoted with --no-pseudo-assembly; the same legs with pseudo-assembly (the reference's
-        # default, configs[2]) are reported next to them.
-        if world == 1 and not strong and not args.no_sam_pipeline and not args.no_cigar:
-            for key, pa in (("sam_pipeline", False), ("sam_pipeline_with_pseudo_assembly", True)):
+        if world == 1 and not strong and not args.no_e2e and not args.no_cigar:
+            # ---- `value`: FASTQ text -> SAM file + _PerRead file, K steps of the reference's batch loop ----
+            batch_bytes = 2 * pairs * (2 + W.ID_DIGITS + 3 + 2 * read_len + 4)
+            F = max(1, min(Ksteps, int(6e9 // batch_bytes)))
+            batches = [reads]
+            for b in range(1, F):
+                if pairs > 2_000_000:
+                    r, _ = W.make_batch_in_pieces(dev, gen, db, offs, pairs, read_len, seed_base=2 + 17 * b, by_length=by_length, with_truth=False)
+                else:
+                    gen.manual_seed(2 + 17 * b)
+                    r = make_reads(dev, gen, db, offs, pairs, read_len=read_len, by_length=by_length)
+                batches.append(r)
+            files = FastqFiles(K, dev, batches, read_len)
+            del batches
+            torch.cuda.empty_cache()
+            taxdb = X.TaxDB(tax_text)
+            e2e = e2e_leg(K, ctx, files, pairs, index_view, taxdb, Ksteps, args.warmup, pseudo)
+            out["e2e"] = e2e
+            out["value"], out["ms_per_step"] = e2e["reads_per_s"], e2e["ms_per_step"]
+            out["value_definition"] = (
+                "2 x pairs x K / wall clock of K steps of the reference's batch loop (src/SLAM.h:193-249), pipeline fill and drain "
+                "included, median of %d repetitions: FASTQ text in page-locked HOST memory when the clock starts (every PCIe byte "
+                "inside), SAM text and <out>_PerRead written to files in /dev/shm when it stops, per-read LCA inside.  The rate with "
+                "the batch resident in HBM and the results left on the device (alignToDatabase only) is hot_path.reads_per_s" % 3)
+            if config == 1:       # the same with the reference's default (pseudo-assembly on)
                 try:
-                    out[key] = sam_pipeline(K, ctx, reads, db, offs, args.read_len, max(args.steps, 12), pa)
-                except Exception as e:   # extra evidence only: never lose the bench line over it
-                    out[key] = {"error": repr(e)}
-        if world == 1 and not strong and not args.no_full_pipeline and not args.no_cigar:
-            for key, pa in (("full_pipeline", False), ("full_pipeline_with_pseudo_assembly", True)):
-                try:
-                    out[key] = full_pipeline(K, ctx, reads, db, offs, args.read_len, max(args.steps, 12), pa)
+                    out["e2e_with_pseudo_assembly"] = e2e_leg(K, ctx, files, pairs, index_view, taxdb, Ksteps, args.warmup, True, tag="pa")
                 except Exception as e:
-                    out[key] = {"error": repr(e)}
+                    out["e2e_with_pseudo_assembly"] = {"error": repr(e)}
+            taxdb.close()
+            files.close()
+        if out["value"] is None:      # --no-e2e / --no-cigar / weak multi-GPU: the hot path is all that was timed
+            out["value"], out["ms_per_step"] = hot["reads_per_s"], hot["ms_per_step"]
+            out["value_definition"] = "hot path only: alignToDatabase on the resident batch" + (", results gathered to rank 0" if use_dist else "")
         print(json.dumps(out), flush=True)
     ctx.close()
     if use_dist:
@@ -726,9 +834,11 @@ if __name__ == "__main__":
     except SystemExit:
         raise
     except BaseException:
-        # leave at once: with a process group up, a rank that unwinds normally can sit in the communicator's
-        # teardown while the other ranks wait for it in a collective
         import traceback
         traceback.print_exc()
-        sys.stderr.flush()
-        os._exit(1)
+        try:
+            sys.stdout.flush()
+            sys.stderr.flush()
+        except Exception:
+            pass
+        os._exit(1)     # a rank that failed must not sit in a collective's destructor while the others wait

@@ -134,6 +134,13 @@ const char *kslam_last_error(const kslam_ctx *ctx);
  * switch between two batches; a production host never calls it.  Not while batches are in flight. */
 kslam_status kslam_reload_tuning(kslam_ctx *ctx);
 
+/* A second context on the same device that BORROWS `primary`'s index (same device pointers; nothing of the
+ * index is copied or freed by the sibling) and has its own stream, read batch and work buffers -- what the
+ * pipelined lanes are made of.  For a host that keeps two batches resident at once (bench.py: a rank's shard in
+ * one context, the whole batch for the batch-global tail in another).  Destroy it before the primary; it sees
+ * a later kslam_set_index of the primary only after being re-created. */
+kslam_status kslam_create_sibling(kslam_ctx *primary, kslam_ctx **out);
+
 /* ---- the index: const GenbankIndex& (src/GenbankTools.h:187-220) ------
  * entries[j].bases, already upper-cased by the DB builder
  * (src/GenbankTools.h:256-258).  One-time: uploads the bases and builds the
@@ -370,6 +377,14 @@ kslam_status kslam_take_results(kslam_ctx *ctx, kslam_overlap **out, uint64_t *n
 kslam_status kslam_copy_results_device(kslam_ctx *ctx, void *d_overlaps,
                                        void *d_cigar_pool);
 kslam_status kslam_get_timings(const kslam_ctx *ctx, kslam_timings *out);
+/* The other direction: records (in alignToDatabase's order, read ids and cigar_off in terms of the batch this
+ * context has LOADED) and their CIGAR pool, already in device memory of this context's GPU, become its "last
+ * result" -- as if kslam_align_resident had produced them.  For the batch-global steps after a read-sharded
+ * alignment (src/SLAM.h:210-239 on the merged batch): the collecting rank loads the whole batch's reads and
+ * qualities, adopts the gathered rows and runs kslam_pair_screen / kslam_row_details_of_pairs on them.  The
+ * caller must have synchronized with whatever produced the two arrays. */
+kslam_status kslam_adopt_results_device(kslam_ctx *ctx, const void *d_overlaps, uint64_t n_overlaps,
+                                        const void *d_cigar_pool, uint64_t n_cigar);
 
 /* ---- read-sharded batches: several GPUs of one node ----
  * The batch loop of the reference (src/SLAM.h:194-209) hands alignToDatabase

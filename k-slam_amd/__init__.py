@@ -39,7 +39,7 @@ STATUS = {0: "OK", 1: "ERR_ARG", 2: "ERR_NO_DEVICE", 3: "ERR_OOM", 4: "ERR_UNSUP
           5: "ERR_STATE", 6: "ERR_INTERNAL"}
 
 # every symbol include/kslam.h declares
-EXPORTS = ["kslam_abi_version", "kslam_version", "kslam_check_std_sort", "kslam_create", "kslam_destroy", "kslam_last_error", "kslam_reload_tuning",
+EXPORTS = ["kslam_abi_version", "kslam_version", "kslam_check_std_sort", "kslam_create", "kslam_destroy", "kslam_last_error", "kslam_reload_tuning", "kslam_create_sibling", "kslam_adopt_results_device",
            "kslam_set_index", "kslam_set_index_device", "kslam_align_batch", "kslam_free_batch",
            "kslam_align_batch_async", "kslam_wait_batch", "kslam_load_qualities", "kslam_load_qualities_device",
            "kslam_row_details", "kslam_take_row_details", "kslam_free_pinned", "kslam_submit_batch",
@@ -128,6 +128,8 @@ def lib():
         L.kslam_last_error.restype = C.c_char_p
         L.kslam_last_error.argtypes = [vp]
         L.kslam_reload_tuning.argtypes = [vp]
+        L.kslam_create_sibling.argtypes = [vp, C.POINTER(vp)]
+        L.kslam_adopt_results_device.argtypes = [vp, vp, u64, vp, u64]
         L.kslam_set_index.argtypes = [vp, u64, vp, vp]
         L.kslam_set_index_device.argtypes = [vp, u64, vp, vp]
         L.kslam_align_batch.argtypes = [vp, u64, vp, vp, C.POINTER(vp), C.POINTER(u64),
@@ -230,6 +232,18 @@ class Context:
     def _chk(self, st):
         if st != 0:
             raise KslamError(st, self._L.kslam_last_error(self._h).decode())
+
+    def sibling(self):
+        """kslam_create_sibling: a second context on this device that borrows this context's index"""
+        h = C.c_void_p()
+        self._chk(self._L.kslam_create_sibling(self._h, C.byref(h)))
+        c = Context.__new__(Context)
+        c._L, c._h = self._L, h
+        return c
+
+    def adopt_results_device(self, d_overlaps, n_overlaps, d_cigars, n_cigar):
+        """kslam_adopt_results_device: device arrays become this context's last result"""
+        self._chk(self._L.kslam_adopt_results_device(self._h, d_overlaps, n_overlaps, d_cigars, n_cigar))
 
     def reload_tuning(self):
         """kslam_reload_tuning: the KSLAM_* environment switches are read at kslam_create; a test that flips one

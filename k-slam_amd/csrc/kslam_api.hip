@@ -1112,6 +1112,41 @@ void kslam_destroy(kslam_ctx *c) {
 
 const char *kslam_last_error(const kslam_ctx *c) { return c ? c->err.c_str() : "null context"; }
 
+kslam_status kslam_create_sibling(kslam_ctx *primary, kslam_ctx **out) {
+  if (!primary || !out) return KSLAM_ERR_ARG;
+  *out = nullptr;
+  if (primary->device < 0) return KSLAM_ERR_NO_DEVICE;
+  kslam_ctx *c = nullptr;
+  const kslam_status st = kslam_create(&primary->prm, &c);
+  if (st != KSLAM_OK) {
+    if (c) primary->err = c->err;
+    kslam_destroy(c);
+    return st;
+  }
+  c->tune = primary->tune;
+  share_index(c, primary);
+  *out = c;
+  return KSLAM_OK;
+}
+
+kslam_status kslam_adopt_results_device(kslam_ctx *c, const void *d_overlaps, uint64_t n_overlaps, const void *d_cigar_pool,
+                                        uint64_t n_cigar) {
+  return guarded(c, [&] {
+    if (!c->have_reads) throw StatusError{KSLAM_ERR_STATE, "no batch loaded: the records refer to the reads of a loaded batch"};
+    if ((n_overlaps && !d_overlaps) || (n_cigar && !d_cigar_pool)) throw StatusError{KSLAM_ERR_ARG, "null argument"};
+    hipStream_t s = c->stream;
+    c->have_details = false;
+    c->have_pairs = c->pairs_of_result = false;
+    c->res_ov.ensure((n_overlaps + 1) * sizeof(kslam_overlap));
+    c->res_cig.ensure((n_cigar + 1) * sizeof(uint32_t));
+    if (n_overlaps) HIPCHK(hipMemcpyAsync(c->res_ov.p, d_overlaps, n_overlaps * sizeof(kslam_overlap), hipMemcpyDeviceToDevice, s));
+    if (n_cigar) HIPCHK(hipMemcpyAsync(c->res_cig.p, d_cigar_pool, n_cigar * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+    c->n_res = n_overlaps;
+    c->n_cig = n_cigar;
+  });
+}
+
 kslam_status kslam_reload_tuning(kslam_ctx *c) {
   if (!c) return KSLAM_ERR_ARG;
   std::lock_guard<std::mutex> lk(c->as_mu);

@@ -77,7 +77,7 @@ def cut_batches(r1_ptr, len1, r2_ptr, len2, pairs_per_batch, max_pairs_total=0, 
 
 def classify_stream(ctx, index, r1_ptr, len1, r2_ptr, len2, pairs_per_batch, params, taxdb=None, report=None,
                     sam_fd=-1, per_read_fd=-1, sam_header=None, max_pairs_total=0, depth=None, host_threads=0,
-                    on_batch=None, before_batch=None):
+                    on_batch=None, before_batch=None, windows=None):
     """Runs the loop above.  r1_ptr / r2_ptr: ADDRESSES of the two FASTQ texts (page-locked memory from
     kslam_amd.HostBuffer goes up by DMA), index: a kslam_amd.tail index view (e.g. kslam_amd.db.Database),
     params: kslam_amd.tail.TailParams (paired; pseudo_assembly as wanted), taxdb / report: optional
@@ -137,7 +137,9 @@ def classify_stream(ctx, index, r1_ptr, len1, r2_ptr, len2, pairs_per_batch, par
         finally:
             release()
 
-    windows = cut_batches(r1_ptr, len1, r2_ptr, len2, pairs_per_batch, max_pairs_total, host_threads)
+    # windows: batch boundaries found earlier with cut_batches (timing runs read one text several times over)
+    windows = iter(windows) if windows is not None else cut_batches(r1_ptr, len1, r2_ptr, len2, pairs_per_batch,
+                                                                   max_pairs_total, host_threads)
     queue, worker, k = [], None, 0
     t_wait_gpu = t_wait_host = 0.0
     exhausted = False

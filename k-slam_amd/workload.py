@@ -321,3 +321,25 @@ def make_batch_in_pieces(dev, gen, db, offs, total_pairs, read_len, pieces=8, fi
     reads = torch.cat(r1s + r2s, 0).contiguous()
     truth = {k: torch.cat([t[k][:piece] for t in tr] + [t[k][piece:] for t in tr]) for k in tr[0]} if with_truth else None
     return reads, truth
+
+
+def taxonomy(n_species, n_strains, n_viral=0):
+    """A synthetic <db>/taxDB for the synthetic database (four lines per node: id, parent id, name, rank;
+    src/TaxonomyDatabase.h:153-183) and the taxonomy id of every entry.  root 1 -> Bacteria 2 -> genus (two species
+    each) -> species -> strain = entry; Viruses 3 -> one species per viral entry."""
+    recs = [(1, 1, b"root", b"no rank"), (2, 1, b"Bacteria", b"superkingdom")]
+    ids = []
+    for s in range(n_species):
+        g = 1000 + s // 2
+        if s % 2 == 0:
+            recs.append((g, 2, b"Genus%d" % g, b"genus"))
+        recs.append((10000 + s, g, b"Genus%d species%d" % (g, s), b"species"))
+        for k in range(n_strains):
+            recs.append((100000 + s * n_strains + k, 10000 + s, b"strain %d.%d" % (s, k), b"strain"))
+            ids.append(100000 + s * n_strains + k)
+    if n_viral:
+        recs.append((3, 1, b"Viruses", b"superkingdom"))
+        for v in range(n_viral):
+            recs.append((2000000 + v, 3, b"Synthetic virus %d" % v, b"species"))
+            ids.append(2000000 + v)
+    return b"".join(b"%d\n%d\n%s\n%s\n" % r for r in recs), np.array(ids, dtype=np.uint32)

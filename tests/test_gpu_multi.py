@@ -97,7 +97,7 @@ def test_bench_strong_mode_through_the_rccl_path_at_world_1():
                         "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
-    v = line["verified"]
+    v = line["hot_path"]["verified"]
     assert line["scaling"] == "strong" and line["config"]["pairs_per_batch"] == 40000
     assert v["ok"] and v["merged_equals_single_context"] and v["merged_unsorted_neighbours"] == 0
     assert v["planted_missing"] == 0 and v["planted_expected"] > 50000 and v["merged_rows"] == v["overlaps"]
@@ -121,8 +121,55 @@ def test_bench_strong_mode_with_several_ranks_on_one_gpu(world):
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     line = json.loads([x for x in r.stdout.strip().splitlines() if x.startswith("{")][-1])
-    v = line["verified"]
+    v = line["hot_path"]["verified"]
     assert line["scaling"] == "strong" and line["n_gpus"] == world and line["config"]["pairs_per_batch"] == 48000
     assert line["config"]["pairs_per_gpu"] == 48000 // world
     assert v["ok"] and v["merged_equals_single_context"] and v["merged_unsorted_neighbours"] == 0
     assert v["planted_missing"] == 0 and v["planted_expected"] > 60000 and v["merged_rows"] == v["overlaps"]
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_bench_starts_its_own_ranks_when_no_launcher_did(world):
+    """`python bench.py --gpus N` with WORLD_SIZE unset: bench.py starts the N rank processes itself (never a re-exec of
+    a process that has touched the GPU), relays rank 0's line, and the line proves the ranks were there: n_gpus, the
+    communicator's world, ranks_seen, bytes gathered per step, per-rank align times, the merged batch equal to one
+    context's, and the second clock through the batch-global tail (SAM text + per-read taxa on rank 0)."""
+    env = dict(os.environ, KSLAM_BENCH_SHARE_GPU="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--total-pairs", "48000",
+                        "--species", "4", "--strains", "3", "--genome-len", "300000", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [x for x in r.stdout.strip().splitlines() if x.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    v = line["hot_path"]["verified"]
+    assert line["scaling"] == "strong" and line["n_gpus"] == world and line["config"]["pairs_per_gpu"] == 48000 // world
+    assert line["rccl"]["world"] == world and line["rccl"]["ranks_seen"] == world and line["rccl"]["launched_by"] == "bench.py"
+    assert line["rccl"]["bytes_gathered_per_step"] > 48 * v["overlaps"] and len(line["per_rank_align_ms"]) == world
+    assert v["ok"] and v["merged_equals_single_context"] and v["planted_missing"] == 0
+    c = line["classified"]
+    assert c["sam_file_bytes"] > 100 * 48000 and c["per_read_lines_per_batch"] > 0.9 * 48000 and c["pseudo_assembly_on"] == "gpu"
+    assert line["value"] <= line["hot_path"]["reads_per_s"] * 1.05      # the second clock includes the first one's work
+
+
+def test_strong_line_of_one_rank_through_the_self_launcher_equals_plain_strong():
+    """N = 1: `--gpus 1 --strong` (no process group) and the same through RCCL at world size 1 classify the same batch:
+    same SAM bytes, same _PerRead lines, same merged rows."""
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--strong", "--total-pairs", "40000", "--species", "4", "--strains", "3",
+            "--genome-len", "300000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    a = subprocess.run(base, env=env, capture_output=True, text=True, timeout=900)
+    assert a.returncode == 0, a.stdout[-2000:] + a.stderr[-3000:]
+    env2 = dict(env, KSLAM_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29591", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    b = subprocess.run(base, env=env2, capture_output=True, text=True, timeout=900)
+    assert b.returncode == 0, b.stdout[-2000:] + b.stderr[-3000:]
+    la = json.loads([x for x in a.stdout.strip().splitlines() if x.startswith("{")][-1])
+    lb = json.loads([x for x in b.stdout.strip().splitlines() if x.startswith("{")][-1])
+    for k in ("sam_file_bytes", "per_read_file_bytes", "alignment_pairs_per_batch", "max_insert_size"):
+        assert la["classified"][k] == lb["classified"][k], k
+    assert la["hot_path"]["verified"]["merged_rows"] == lb["hot_path"]["verified"]["merged_rows"]
+    assert "rccl" in lb and "rccl" not in la

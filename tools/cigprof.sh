@@ -10,6 +10,6 @@ f = glob.glob('/tmp/prof_%s/**/*kernel_trace.csv' % mode, recursive=True)[0]
 rows = [r for r in csv.DictReader(open(f)) if 'k_banded_lds' in r['Kernel_Name']]
 d = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6 for r in rows]
 print(mode, "k_banded_lds dispatches (ms):", [round(x, 2) for x in d[-6:]], "lds:", [r.get('LDS_Block_Size', r.get('LDS_Block_Size_v', '?')) for r in rows[-6:]])
-j = json.load(open('/tmp/o_%s.json' % mode)); print(mode, j['ms_per_step'], j['phases_ms'])
+j = json.load(open('/tmp/o_%s.json' % mode)); print(mode, j['hot_path']['ms_per_step'], j['hot_path']['phases_ms'])
 PY
 done

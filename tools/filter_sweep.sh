@@ -7,7 +7,7 @@ for cfg in "0 3" "32 3" "32 2" "32 1" "32 0" "31 2" "33 2" "30 2"; do
 import json, sys
 try:
     j = json.load(open('/tmp/fs.json'))
-    print("filter_bits", sys.argv[1], "sort_bytes", sys.argv[2], "ms/step", j["ms_per_step"], j["phases_ms"], "kept", j["counts"]["read_kmers_kept_by_filter"], "raw", j["counts"]["overlaps_raw"], "ok", j["verified"]["ok"], "index_s", j["setup_s"]["index_build"])
+    print("filter_bits", sys.argv[1], "sort_bytes", sys.argv[2], "ms/step", j["hot_path"]["ms_per_step"], j["hot_path"]["phases_ms"], "kept", j["hot_path"]["counts"]["read_kmers_kept_by_filter"], "raw", j["hot_path"]["counts"]["overlaps_raw"], "ok", j["hot_path"]["verified"]["ok"], "index_s", j["setup_s"]["index_build"])
 except Exception as e:
     print("failed", sys.argv[1:], e, open('/tmp/fs.err').read()[-500:])
 PY

@@ -8,5 +8,5 @@ def clean(n): return n.replace('(anonymous namespace)::', '').replace('kslam::',
 for r in rows:
     if 'kslam' in r['Name'] and float(r['TotalDurationNs']) > 3e5:
         print("%-34s calls %4s  avg %9.3f ms  total/step %8.3f ms" % (clean(r['Name'])[:34], r['Calls'], float(r['AverageNs']) / 1e6, float(r['TotalDurationNs']) / 1e6 / 4))
-j = json.load(open('/tmp/kprof.json')); print(j['ms_per_step'], j['phases_ms'])
+j = json.load(open('/tmp/kprof.json')); print(j['hot_path']['ms_per_step'], j['hot_path']['phases_ms'])
 PY

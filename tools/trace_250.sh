@@ -20,4 +20,4 @@ with open('gpurun_out/keep/%s_kernel_stats_250bp.txt' % R, 'w') as fh:
 PY
 python3 -c "
 import json;d=json.loads(open('gpurun_out/keep/${R}_bench_250bp.json').read().strip().splitlines()[-1])
-print(d['value'], d['ms_per_step'], d['phases_ms'], d['counts'], d['verified'])"
+print(d['hot_path']['reads_per_s'], d['hot_path']['ms_per_step'], d['hot_path']['phases_ms'], d['hot_path']['counts'], d['hot_path']['verified'])"

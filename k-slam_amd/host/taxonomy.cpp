@@ -44,14 +44,15 @@ struct kslam_taxdb {
 
 // One IdentifiedTaxonomy (src/MetagenomicResults.h:32-43) as collected per read pair: the genes are numbers
 // into the index view's gene columns
-struct TaxRecord {
-  uint32_t tax = 0;
-  bool has_read = false;
-  std::string read;
-  std::vector<uint64_t> genes;
-};
+// (pooled: record i's read name is names[name_off[i] .. name_off[i + 1]), its genes genes[gene_off[i] .. gene_off[i + 1]);
+// a batch appends a million records, so there is no object -- and no allocation -- per record)
 struct kslam_taxreport {
-  std::vector<TaxRecord> recs;
+  std::vector<uint32_t> tax;
+  std::vector<uint8_t> has_read;
+  std::vector<uint64_t> name_off{0}, gene_off{0};
+  std::vector<char> names;
+  std::vector<uint64_t> genes;
+  size_t size() const { return tax.size(); }
 };
 
 namespace {
@@ -345,18 +346,36 @@ kslam_status kslam_tail_classify(const kslam_tail_params *params, const kslam_re
       }
     });
     if (per_read_text) {  // writePerReadResults, src/MetagenomicResults.h:455-463
-      std::string out;
-      out.reserve(n_read_pairs * 24);
-      for (uint64_t g = 0; g < n_read_pairs; g++) {
-        if (!read_pairs[g].count) continue;  // (a result without alignments has no read name)
-        const uint32_t r = read_pairs[g].r1_read;
-        if (r >= reads->n_reads) fail(KSLAM_ERR_ARG, "read pair refers to a read outside the batch");
-        out.append(reads->ids + reads->ids_off[r], reads->ids_off[r + 1] - reads->ids_off[r]);
-        out += '\t';
-        out += std::to_string(tax_ids[g]);
-        out += '\n';
-      }
-      *per_read_text = dup_text(out, per_read_len);
+      std::vector<std::string> part(n_tasks);
+      Pool::get().tasks(threads, n_tasks, [&](size_t t) {
+        std::string &out = part[t];
+        out.reserve(grain * 24);
+        char num[16];
+        for (uint64_t g = t * grain; g < std::min(n_read_pairs, (t + 1) * grain); g++) {
+          if (!read_pairs[g].count) continue;  // (a result without alignments has no read name)
+          const uint32_t r = read_pairs[g].r1_read;
+          if (r >= reads->n_reads) fail(KSLAM_ERR_ARG, "read pair refers to a read outside the batch");
+          out.append(reads->ids + reads->ids_off[r], reads->ids_off[r + 1] - reads->ids_off[r]);
+          out += '\t';
+          int k = 0;
+          uint32_t v = tax_ids[g];
+          do { num[k++] = (char)('0' + v % 10); v /= 10; } while (v);
+          while (k) out += num[--k];
+          out += '\n';
+        }
+      });
+      uint64_t total = 0;
+      std::vector<uint64_t> at(n_tasks + 1, 0);
+      for (size_t t = 0; t < n_tasks; t++) at[t + 1] = at[t] + part[t].size();
+      total = at[n_tasks];
+      char *buf = (char *)malloc(total + 1);
+      if (!buf) fail(KSLAM_ERR_OOM, "out of host memory");
+      Pool::get().tasks(threads, n_tasks, [&](size_t t) {
+        if (!part[t].empty()) memcpy(buf + at[t], part[t].data(), part[t].size());
+      });
+      buf[total] = 0;
+      *per_read_text = buf;
+      *per_read_len = total;
     }
   });
 }
@@ -417,27 +436,57 @@ kslam_status kslam_taxreport_add_batch(kslam_taxreport *report, const kslam_read
       fail(KSLAM_ERR_ARG, "null argument");
     if (!reads->ids || !reads->ids_off) fail(KSLAM_ERR_ARG, "the report needs the read identifiers");
     const GeneOrder ord{index};
-    const size_t base = report->recs.size();
-    report->recs.resize(base + n_read_pairs);
-    for (uint64_t g = 0; g < n_read_pairs; g++) {
-      const kslam_read_pair &rp = read_pairs[g];
-      TaxRecord &rec = report->recs[base + g];
-      if (rp.first + rp.count > n_pairs) fail(KSLAM_ERR_ARG, "read pair slice outside the pairs array");
-      if (rp.count == 0) continue;                      // an empty result: id 0, no read, no genes (:93)
-      for (uint64_t k = 0; k < rp.count; k++) {
-        const kslam_paired_overlap &p = pairs[rp.first + k];
-        if (p.entry >= index->n_entries) fail(KSLAM_ERR_ARG, "alignment pair refers outside the index");
-        const int64_t gene = best_gene_of(index, p.entry, p.ref_start, p.ref_end);
-        if (gene >= 0) rec.genes.push_back((uint64_t)gene);
+    const size_t base = report->size();
+    if (n_read_pairs == 0) return;
+    // pass 1, parallel: every record's genes (best-overlapping gene of each alignment pair, sorted, unique) into the
+    // task's own list; pass 2: the lists and the read names are appended to the report's pools in record order
+    const int threads = std::max(1, std::min(usable_cpus(), 512));
+    const uint64_t grain = 8192, n_tasks = (n_read_pairs + grain - 1) / grain;
+    std::vector<std::vector<uint64_t>> task_genes(n_tasks);
+    std::vector<uint32_t> n_genes(n_read_pairs, 0), name_len(n_read_pairs, 0);
+    report->tax.resize(base + n_read_pairs, 0);
+    report->has_read.resize(base + n_read_pairs, 0);
+    Pool::get().tasks(threads, n_tasks, [&](size_t t) {
+      std::vector<uint64_t> &out = task_genes[t];
+      for (uint64_t g = t * grain; g < std::min(n_read_pairs, (t + 1) * grain); g++) {
+        const kslam_read_pair &rp = read_pairs[g];
+        if (rp.first + rp.count > n_pairs) fail(KSLAM_ERR_ARG, "read pair slice outside the pairs array");
+        if (rp.count == 0) continue;                      // an empty result: id 0, no read, no genes (:93)
+        const size_t first = out.size();
+        for (uint64_t k = 0; k < rp.count; k++) {
+          const kslam_paired_overlap &p = pairs[rp.first + k];
+          if (p.entry >= index->n_entries) fail(KSLAM_ERR_ARG, "alignment pair refers outside the index");
+          const int64_t gene = best_gene_of(index, p.entry, p.ref_start, p.ref_end);
+          if (gene >= 0) out.push_back((uint64_t)gene);
+        }
+        std::sort(out.begin() + first, out.end(), [&](uint64_t a, uint64_t b) { return ord.less(a, b); });
+        out.erase(std::unique(out.begin() + first, out.end(), [&](uint64_t a, uint64_t b) { return ord.equal(a, b); }), out.end());
+        n_genes[g] = (uint32_t)(out.size() - first);
+        if (rp.r1_read >= reads->n_reads) fail(KSLAM_ERR_ARG, "read pair refers to a read outside the batch");
+        name_len[g] = (uint32_t)(reads->ids_off[rp.r1_read + 1] - reads->ids_off[rp.r1_read]);
+        report->has_read[base + g] = 1;
+        report->tax[base + g] = tax_ids[g];
       }
-      std::sort(rec.genes.begin(), rec.genes.end(), [&](uint64_t a, uint64_t b) { return ord.less(a, b); });
-      rec.genes.erase(std::unique(rec.genes.begin(), rec.genes.end(), [&](uint64_t a, uint64_t b) { return ord.equal(a, b); }),
-                      rec.genes.end());
-      if (rp.r1_read >= reads->n_reads) fail(KSLAM_ERR_ARG, "read pair refers to a read outside the batch");
-      rec.read.assign(reads->ids + reads->ids_off[rp.r1_read], reads->ids_off[rp.r1_read + 1] - reads->ids_off[rp.r1_read]);
-      rec.has_read = true;
-      rec.tax = tax_ids[g];
+    });
+    report->name_off.resize(base + n_read_pairs + 1);
+    report->gene_off.resize(base + n_read_pairs + 1);
+    uint64_t no = report->name_off[base], go = report->gene_off[base];
+    for (uint64_t g = 0; g < n_read_pairs; g++) {
+      no += name_len[g];
+      go += n_genes[g];
+      report->name_off[base + g + 1] = no;
+      report->gene_off[base + g + 1] = go;
     }
+    report->names.resize(no);
+    report->genes.resize(go);
+    Pool::get().tasks(threads, n_tasks, [&](size_t t) {
+      const uint64_t g0 = t * grain, g1 = std::min(n_read_pairs, (t + 1) * grain);
+      if (!task_genes[t].empty())
+        memcpy(report->genes.data() + report->gene_off[base + g0], task_genes[t].data(), task_genes[t].size() * sizeof(uint64_t));
+      for (uint64_t g = g0; g < g1; g++)
+        if (name_len[g])
+          memcpy(report->names.data() + report->name_off[base + g], reads->ids + reads->ids_off[read_pairs[g].r1_read], name_len[g]);
+    });
   });
 }
 
@@ -450,19 +499,20 @@ kslam_status kslam_taxreport_xml(const kslam_taxreport *report, const kslam_inde
     struct Counted { uint64_t gene; int count; };
     struct Taxon { uint32_t tax; std::vector<std::string> reads; std::vector<Counted> genes; };
     // combineTaxonomies, src/MetagenomicResults.h:149-177 (records of equal id in input order: see the header)
-    const size_t n = report->recs.size();
+    const size_t n = report->size();
     std::vector<uint32_t> order(n);
     for (size_t i = 0; i < n; i++) order[i] = (uint32_t)i;
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return report->recs[a].tax < report->recs[b].tax; });
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return report->tax[a] < report->tax[b]; });
     std::vector<Taxon> taxa;
     auto combine = [&](size_t from, size_t to) {        // combineRangeOfIdentifiedTaxonomy, :118-142
       Taxon t;
-      t.tax = report->recs[order[from]].tax;
+      t.tax = report->tax[order[from]];
       std::vector<uint64_t> all;
       for (size_t i = from; i < to; i++) {
-        const TaxRecord &r = report->recs[order[i]];
-        all.insert(all.end(), r.genes.begin(), r.genes.end());
-        if (r.has_read) t.reads.push_back(r.read);
+        const uint32_t r = order[i];
+        all.insert(all.end(), report->genes.begin() + report->gene_off[r], report->genes.begin() + report->gene_off[r + 1]);
+        if (report->has_read[r])
+          t.reads.emplace_back(report->names.data() + report->name_off[r], report->name_off[r + 1] - report->name_off[r]);
       }
       std::sort(all.begin(), all.end(), [&](uint64_t a, uint64_t b) { return ord.less(a, b); });
       for (size_t i = 0; i < all.size(); i++) {
@@ -475,14 +525,14 @@ kslam_status kslam_taxreport_xml(const kslam_taxreport *report, const kslam_inde
       uint32_t test = 0;
       size_t start = 0;
       for (size_t i = 1; i < n; i++) {
-        const uint32_t id = report->recs[order[i]].tax;
+        const uint32_t id = report->tax[order[i]];
         if (id != test) {
           if (test != 0) combine(start, i);
           test = id;
           start = i;
         }
       }
-      if (report->recs[order[start]].tax != 0) combine(start, n);
+      if (report->tax[order[start]] != 0) combine(start, n);
     }
     // sortResults, src/MetagenomicResults.h:254-273
     std::sort(taxa.begin(), taxa.end(), [](const Taxon &a, const Taxon &b) {

@@ -266,6 +266,45 @@ def test_sam_text_matches_restatement_and_the_sam_definition(kslam, oracle, synt
     assert checked > 2 * n_pairs * 0.8 and primaries == st.n_read_pairs
 
 
+def test_sam_text_written_through_the_fd_writer(kslam, oracle, synth, T, tmp_path):
+    """kslam_write_fd: the library's own writer.  Into a regular file the chunks go out in parallel (pwrite from the
+    descriptor's position, which moves past the text: a header written first and a second batch written after stay
+    where they belong); into a pipe, which cannot seek, chunk by chunk.  Both give the text of kslam_tail_sam."""
+    import ctypes as C
+    import os
+    import threading
+    rb, gb, quals, R, I = _aligned_case(oracle, synth, T, 13, 900)
+    al, cig, _ = oracle.align_to_database(rb, gb, oracle.Params.default())
+    P = T.TailParams.default(threads=5)
+    exp, _ = T.tail_sam(P, R, I, al, cig)
+    L = T.lib()
+    ov = np.ascontiguousarray(al, dtype=kslam.OVERLAP_DT)
+    pool = np.ascontiguousarray(cig, dtype=np.uint32)
+    writer = C.cast(L.kslam_write_fd, T.WRITE_FN)
+
+    def write_to(fd):
+        keep = C.c_int(fd)
+        st = T.TailStats()
+        T._chk(L.kslam_tail_sam_write(C.byref(P), C.byref(R.view), C.byref(I.view), ov.ctypes.data, len(ov), pool.ctypes.data,
+                                      len(pool), writer, C.cast(C.pointer(keep), C.c_void_p), C.byref(st)))
+        return st
+    path = str(tmp_path / "x.sam")
+    fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC)
+    os.write(fd, b"@HD\theader\n")
+    st = write_to(fd)
+    write_to(fd)
+    os.close(fd)
+    assert open(path, "rb").read() == b"@HD\theader\n" + exp + exp and st.sam_bytes == len(exp) > 100000
+    r, w = os.pipe()
+    got = []
+    reader = threading.Thread(target=lambda: got.append(os.fdopen(r, "rb").read()))
+    reader.start()
+    write_to(w)
+    os.close(w)
+    reader.join()
+    assert got[0] == exp
+
+
 @pytest.mark.parametrize("kw", [{}, {"num_sam_alignments": 1}, {"paired": False}, {"score_threshold": 120}])
 def test_sam_from_precomputed_row_details_is_the_same_text(kslam, oracle, synth, T, kw):
     """kslam_tail_sam_rows: NM / log-probability / MD handed in per row (what kslam_row_details computes

@@ -192,8 +192,8 @@ def e2e_leg(K, ctx, files, pairs_per_batch, index_view, taxdb, steps, warmup, ps
 
     def run(n_steps, keep_report=False):
         report = X.Report()
-        sam_fd = os.open(sam_path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o600)
-        pr_fd = os.open(pr_path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o600)
+        sam_fd = os.open(sam_path, os.O_RDWR | os.O_CREAT | os.O_TRUNC, 0o600)
+        pr_fd = os.open(pr_path, os.O_RDWR | os.O_CREAT | os.O_TRUNC, 0o600)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         res = S.classify_stream(ctx, index_view, files.h[0].ptr, files.len, files.h[1].ptr, files.len, pairs_per_batch, P,
@@ -624,8 +624,8 @@ def main():
         def classified_steps(k):
             fds = None
             if rank == 0:
-                fds = (os.open(sam_path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o600),
-                       os.open(pr_path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o600))
+                fds = (os.open(sam_path, os.O_RDWR | os.O_CREAT | os.O_TRUNC, 0o600),
+                       os.open(pr_path, os.O_RDWR | os.O_CREAT | os.O_TRUNC, 0o600))
             for _ in range(k):
                 step()
                 if rank == 0:

@@ -156,8 +156,9 @@ kslam_status kslam_tail_sam(const kslam_tail_params *params,
  * allocates nothing. */
 typedef int (*kslam_write_fn)(void *user, const char *data, uint64_t len);
 /* a ready-made writer: `user` points to an int holding an open file descriptor (the SAM file).  The kslam_tail_*_write*
- * entries recognise it and, when the descriptor can seek, write a batch's chunks in parallel (pwrite from the
- * descriptor's current position, which is then moved past the text) instead of calling it chunk by chunk. */
+ * entries recognise it and, when the descriptor is a file opened for reading AND writing (O_RDWR: the new range is
+ * mapped), copy a batch's chunks into place in parallel from the descriptor's current position, which is then
+ * moved past the text, instead of calling it chunk by chunk. */
 int kslam_write_fd(void *user, const char *data, uint64_t len);
 kslam_status kslam_tail_sam_write(const kslam_tail_params *params,
                                   const kslam_reads_view *reads,

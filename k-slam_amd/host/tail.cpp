@@ -1458,33 +1458,28 @@ void sam_stage(const SamInput &in, Arena &A, int threads, const Group *groups, s
   std::vector<size_t> at(n_tasks + 1, 0);
   for (size_t t = 0; t < n_tasks; t++) at[t + 1] = at[t] + parts[t].n;
   *bytes = at.back();
-  if (sink.write == &kslam_write_fd && sink.user) {
-    // the library's own file writer: the chunks' places in the file are known, so they go out in parallel (pwrite at
-    // the descriptor's current position; on tmpfs / page cache the cost is allocating and copying pages, which one
-    // thread does at ~5 GB/s and sixteen do at several times that).  A descriptor that cannot seek (a pipe) is
-    // written serially below.
+  if (sink.write == &kslam_write_fd && sink.user && at.back()) {
+    // The library's own file writer: the chunks' places in the file are known, so the file is grown, its new range is
+    // mapped and the chunks are copied in by all workers at once.  (write() / pwrite() on ONE file serialise on the
+    // inode lock, whatever the number of callers: measured 5 GB/s into tmpfs, 80 ms for a batch's 400 MB of SAM text,
+    // three times the formatting itself; page faults on a shared mapping do not.)  A descriptor that cannot seek or
+    // be mapped (a pipe) is written chunk by chunk below.
     const int fd = *static_cast<const int *>(sink.user);
     const off_t base = lseek(fd, 0, SEEK_CUR);
-    if (base >= 0) {
-      std::atomic<int> bad(0);
-      Pool::get().tasks(threads, n_tasks, [&](size_t t) {
-        const char *p = parts[t].p;
-        size_t left = parts[t].n;
-        off_t at_file = base + (off_t)at[t];
-        while (left) {
-          const ssize_t w = pwrite(fd, p, std::min<size_t>(left, (size_t)1 << 30), at_file);
-          if (w < 0) {
-            if (errno == EINTR) continue;
-            bad = 1;
-            return;
-          }
-          p += w;
-          left -= (size_t)w;
-          at_file += w;
-        }
-      });
-      if (bad || lseek(fd, base + (off_t)at.back(), SEEK_SET) < 0) fail(KSLAM_ERR_ARG, "writing the SAM text failed");
-      return;
+    const uint64_t total = at.back();
+    if (base >= 0 && ftruncate(fd, base + (off_t)total) == 0) {
+      const uint64_t page = 4096, lo = (uint64_t)base & ~(page - 1), span = (uint64_t)base - lo + total;
+      void *m = mmap(nullptr, span, PROT_READ | PROT_WRITE, MAP_SHARED, fd, (off_t)lo);
+      if (m != MAP_FAILED) {
+        char *dst = static_cast<char *>(m) + ((uint64_t)base - lo);
+        Pool::get().tasks(threads, n_tasks, [&](size_t t) {
+          if (parts[t].n) memcpy(dst + at[t], parts[t].p, parts[t].n);
+        });
+        munmap(m, span);
+        if (lseek(fd, base + (off_t)total, SEEK_SET) < 0) fail(KSLAM_ERR_ARG, "writing the SAM text failed");
+        return;
+      }
+      if (ftruncate(fd, base) != 0) fail(KSLAM_ERR_ARG, "writing the SAM text failed");   // not mappable: undo, write serially
     }
   }
   if (sink.write) {

@@ -108,7 +108,7 @@ def _run_config(kslam, oracle, tmp_path, n_viral, read_len, by_length, pseudo):
 
     def run(tag):
         path = "/dev/shm/kslam_test_%s_%d.sam" % (tag, os.getpid())
-        fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC)
+        fd = os.open(path, os.O_RDWR | os.O_CREAT | os.O_TRUNC)
         try:
             res = S.classify_stream(ctx, I, h[0].ptr, n_pairs * rec_w, h[1].ptr, n_pairs * rec_w, n_pairs, P, sam_fd=fd,
                                     before_batch=before)

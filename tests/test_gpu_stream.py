@@ -72,8 +72,8 @@ def test_stream_of_batches_equals_the_reference_loop(kslam, oracle, synth, tmp_p
     P = T.TailParams.default(pseudo_assembly=pseudo)
     header = T.sam_header(db, b"SLAM --db db R1.fq R2.fq")
     sam_path, per_read_path = str(tmp_path / "out.sam"), str(tmp_path / "out_PerRead")
-    sam_fd = os.open(sam_path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC)
-    pr_fd = os.open(per_read_path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC)
+    sam_fd = os.open(sam_path, os.O_RDWR | os.O_CREAT | os.O_TRUNC)
+    pr_fd = os.open(per_read_path, os.O_RDWR | os.O_CREAT | os.O_TRUNC)
     res = S.classify_stream(ctx, db, h1.ptr, len(r1), h2.ptr, len(r2), per_batch, P, taxdb=tax, report=report,
                             sam_fd=sam_fd, per_read_fd=pr_fd, sam_header=header)
     os.close(sam_fd)

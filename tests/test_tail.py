@@ -289,7 +289,7 @@ def test_sam_text_written_through_the_fd_writer(kslam, oracle, synth, T, tmp_pat
                                       len(pool), writer, C.cast(C.pointer(keep), C.c_void_p), C.byref(st)))
         return st
     path = str(tmp_path / "x.sam")
-    fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC)
+    fd = os.open(path, os.O_RDWR | os.O_CREAT | os.O_TRUNC)
     os.write(fd, b"@HD\theader\n")
     st = write_to(fd)
     write_to(fd)

@@ -178,7 +178,7 @@ class FastqFiles:
             x.close()
 
 
-def e2e_leg(K, ctx, files, pairs_per_batch, index_view, taxdb, steps, warmup, pseudo, reps=3, tag="e2e"):
+def e2e_leg(K, ctx, files, pairs_per_batch, index_view, taxdb, steps, warmup, pseudo, reps=3, tag="e2e", out_dir="/dev/shm"):
     """K steps of the reference's batch loop, FASTQ text in host memory to SAM + _PerRead files in /dev/shm."""
     S = importlib.import_module("kslam_amd.stream")
     T = importlib.import_module("kslam_amd.tail")
@@ -187,8 +187,8 @@ def e2e_leg(K, ctx, files, pairs_per_batch, index_view, taxdb, steps, warmup, ps
     wins = list(S.cut_batches(files.h[0].ptr, files.len, files.h[1].ptr, files.len, pairs_per_batch))
     F = len(wins)
     header = T.sam_header(index_view, b"SLAM --db synthetic R1.fq R2.fq")
-    sam_path = "/dev/shm/kslam_bench_%d_%s.sam" % (os.getpid(), tag)
-    pr_path = "/dev/shm/kslam_bench_%d_%s_PerRead" % (os.getpid(), tag)
+    sam_path = os.path.join(out_dir, "kslam_bench_%d_%s.sam" % (os.getpid(), tag))
+    pr_path = os.path.join(out_dir, "kslam_bench_%d_%s_PerRead" % (os.getpid(), tag))
 
     def run(n_steps, keep_report=False):
         report = X.Report()
@@ -236,8 +236,10 @@ def e2e_leg(K, ctx, files, pairs_per_batch, index_view, taxdb, steps, warmup, ps
             "per_read_mb_per_batch": round(med["per_read_bytes"] / steps / 1e6, 2),
             "classified_read_pairs_per_batch": int(len(med["tax_ids"]) / steps),
             "alignment_pairs_per_batch": int(sum(r["alignment_pairs"] for r in b) / steps),
-            "host_ms_per_batch": {"sam_text_and_write": round(sum(r["ms_sam"] for r in b) / steps, 2),
-                                  "lca_per_read_and_report": round(sum(r.get("ms_classify", 0.0) for r in b) / steps, 2)},
+            "host_ms_per_batch": {"sam_text": round(sum(r["ms_sam"] for r in b) / steps, 2),
+                                  "lca_per_read_and_report": round(sum(r.get("ms_classify", 0.0) for r in b) / steps, 2),
+                                  "writer_thread_in_write": round(med.get("s_in_write", 0.0) / steps * 1e3, 2)},
+            "sink": sam_path.rsplit("/", 1)[0],
             "s_main_thread_waiting_for_gpu": med["s_waiting_for_gpu"], "s_main_thread_waiting_for_host_stage": med["s_waiting_for_host_stage"],
             "end_of_run_reports_s": round(t_end, 3), "end_of_run_report_bytes": {"abbreviated": len(summary), "xml": len(xml)},
             "including_end_of_run_reports": {"reads_per_s": round(n_reads / (last["wall"] + t_end), 1)},
@@ -246,7 +248,7 @@ def e2e_leg(K, ctx, files, pairs_per_batch, index_view, taxdb, steps, warmup, ps
             "what": "FASTQ text (two files' worth, page-locked host memory) -> kslam_fastq_batch_end (batch boundaries) -> "
                     "kslam_submit_batch_fastq_text (GPU: FASTQ record index, alignToDatabase, score screen / pairing / insert-size "
                     "statistics / screens%s, per-row NM / MD / log-probability; %d batches in flight) -> kslam_collect_batch -> "
-                    "kslam_tail_finish_write_rows -> kslam_write_fd into a /dev/shm SAM file -> kslam_tail_classify (per-read LCA) "
+                    "kslam_tail_finish_write_rows -> kslam_sam_writer (background write() into the SAM file) -> kslam_tail_classify (per-read LCA) "
                     "-> <out>_PerRead file + kslam_taxreport_add_batch; wall clock of the K steps incl. pipeline fill and drain"
                     % (" / pseudo-assembly / second screen" if pseudo else "", 3),
         }
@@ -342,6 +344,7 @@ def main():
     ap.add_argument("--no-cigar", action="store_true")
     ap.add_argument("--no-abi-path", action="store_true", help="skip the host-pointers-in / host-results-out leg")
     ap.add_argument("--no-e2e", action="store_true", help="hot path only: `value` is then the resident-input rate and says so")
+    ap.add_argument("--out-dir", default="/dev/shm", help="where the e2e legs write their SAM / _PerRead files")
     ap.add_argument("--no-sam-pipeline", dest="no_e2e", action="store_true", help=argparse.SUPPRESS)    # rounds 1-2 spelling (tools/*.sh)
     ap.add_argument("--no-full-pipeline", dest="no_e2e", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--read-len", type=int, default=0, help="150 (configs[1..3]) or 250 (configs[4])")
@@ -584,7 +587,7 @@ def main():
             rv = ids_view(T, args.total_pairs, read_len)
         P_write = T.TailParams.default(pseudo_assembly=False)
         P_host = T.TailParams.default(pseudo_assembly=True)
-        sam_path = "/dev/shm/kslam_bench_%d_strong.sam" % os.getpid()
+        sam_path = os.path.join(args.out_dir, "kslam_bench_%d_strong.sam" % os.getpid())
         pr_path = sam_path + "_PerRead"
         tail_ms = {"adopt_pair_screen_details": 0.0, "download": 0.0, "host_sam_and_lca": 0.0}
         tail_out = {}
@@ -624,8 +627,8 @@ def main():
         def classified_steps(k):
             fds = None
             if rank == 0:
-                fds = (os.open(sam_path, os.O_RDWR | os.O_CREAT | os.O_TRUNC, 0o600),
-                       os.open(pr_path, os.O_RDWR | os.O_CREAT | os.O_TRUNC, 0o600))
+                sam_fd = os.open(sam_path, os.O_RDWR | os.O_CREAT | os.O_TRUNC, 0o600)
+                fds = (T.SamWriter(sam_fd), os.open(pr_path, os.O_RDWR | os.O_CREAT | os.O_TRUNC, 0o600))
             for _ in range(k):
                 step()
                 if rank == 0:
@@ -634,8 +637,9 @@ def main():
             if rank == 0:
                 worker[0].join()
                 worker[0] = None
-                for fd in fds:
-                    os.close(fd)
+                fds[0].close()
+                os.close(sam_fd)
+                os.close(fds[1])
         classified_steps(max(args.warmup, 1))
         for k in tail_ms:
             tail_ms[k] = 0.0
@@ -803,7 +807,7 @@ def main():
             del batches
             torch.cuda.empty_cache()
             taxdb = X.TaxDB(tax_text)
-            e2e = e2e_leg(K, ctx, files, pairs, index_view, taxdb, Ksteps, args.warmup, pseudo)
+            e2e = e2e_leg(K, ctx, files, pairs, index_view, taxdb, Ksteps, args.warmup, pseudo, out_dir=args.out_dir)
             out["e2e"] = e2e
             out["value"], out["ms_per_step"] = e2e["reads_per_s"], e2e["ms_per_step"]
             out["value_definition"] = (
@@ -813,7 +817,7 @@ def main():
                 "the batch resident in HBM and the results left on the device (alignToDatabase only) is hot_path.reads_per_s" % 3)
             if config == 1:       # the same with the reference's default (pseudo-assembly on)
                 try:
-                    out["e2e_with_pseudo_assembly"] = e2e_leg(K, ctx, files, pairs, index_view, taxdb, Ksteps, args.warmup, True, tag="pa")
+                    out["e2e_with_pseudo_assembly"] = e2e_leg(K, ctx, files, pairs, index_view, taxdb, Ksteps, args.warmup, True, tag="pa", out_dir=args.out_dir)
                 except Exception as e:
                     out["e2e_with_pseudo_assembly"] = {"error": repr(e)}
             taxdb.close()

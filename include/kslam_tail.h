@@ -155,11 +155,21 @@ kslam_status kslam_tail_sam(const kslam_tail_params *params,
  * live in buffers the library keeps between calls, so a steady stream of batches
  * allocates nothing. */
 typedef int (*kslam_write_fn)(void *user, const char *data, uint64_t len);
-/* a ready-made writer: `user` points to an int holding an open file descriptor (the SAM file).  The kslam_tail_*_write*
- * entries recognise it and, when the descriptor is a file opened for reading AND writing (O_RDWR: the new range is
- * mapped), copy a batch's chunks into place in parallel from the descriptor's current position, which is then
- * moved past the text, instead of calling it chunk by chunk. */
+/* a ready-made writer: `user` points to an int holding an open file descriptor (the SAM file) */
 int kslam_write_fd(void *user, const char *data, uint64_t len);
+/* The same in the background: a writer object owns a thread that write()s to `fd`, batch after batch in order, while
+ * the caller formats the next batch.  Pass kslam_write_queued as `write` and the writer as `user`: the
+ * kslam_tail_*_write* entries then hand the batch's text buffers over instead of copying them (written buffers are
+ * reused; at most two batches wait in the queue) and return as soon as the text is formatted.  Called directly,
+ * kslam_write_queued copies `data` into the queue (a header).  kslam_sam_writer_close waits until everything is
+ * written and reports a failed write (message in kslam_tail_last_error()); it does not close fd.
+ * Why a thread: writes into one file serialise in the kernel whoever issues them (inode lock; ~6 GB/s into tmpfs on the
+ * MI355X boxes = 70 ms per batch of 1 M read pairs, more than the formatting on sixteen CPUs), so the only way to hide
+ * them is to overlap them with the next batch's work. */
+typedef struct kslam_sam_writer kslam_sam_writer;
+kslam_status kslam_sam_writer_open(int fd, kslam_sam_writer **out);
+int kslam_write_queued(void *user, const char *data, uint64_t len);
+kslam_status kslam_sam_writer_close(kslam_sam_writer *writer, uint64_t *bytes_written, double *seconds_writing);
 kslam_status kslam_tail_sam_write(const kslam_tail_params *params,
                                   const kslam_reads_view *reads,
                                   const kslam_index_view *index,

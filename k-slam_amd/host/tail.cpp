@@ -29,6 +29,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <functional>
 #include <mutex>
 #include <string>
@@ -1414,6 +1415,66 @@ void check_sam_views(const SamInput &in) {
     fail(KSLAM_ERR_ARG, "index view has n_genes > 0 but no gene columns");
 }
 
+}  // namespace
+
+// The background SAM writer (include/kslam_tail.h: kslam_sam_writer_*): one thread that write()s whole batches of
+// chunks in order while the next batch is being formatted.  The formatter's per-task buffers are handed over, not
+// copied; written sets come back through `spare` and are reused (fresh memory for 400 MB of text per batch costs more
+// in page faults than the formatting).
+struct kslam_sam_writer {
+  int fd = -1;
+  std::thread th;
+  std::mutex m;
+  std::condition_variable cv;
+  std::deque<std::vector<Text>> queue;
+  std::vector<std::vector<Text>> spare;
+  bool stop = false, busy = false;
+  int error = 0;            // errno of the first failed write
+  uint64_t bytes = 0;
+  double write_s = 0;
+  void run() {
+    for (;;) {
+      std::vector<Text> set;
+      {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return stop || !queue.empty(); });
+        if (queue.empty()) return;
+        set = std::move(queue.front());
+        queue.pop_front();
+        busy = true;
+      }
+      const double t0 = now_ms();
+      uint64_t done = 0;
+      for (Text &t : set) {
+        const char *p = t.p;
+        size_t left = t.n;
+        while (left && !error) {
+          const ssize_t w = ::write(fd, p, std::min<size_t>(left, (size_t)1 << 30));
+          if (w < 0) {
+            if (errno == EINTR) continue;
+            error = errno ? errno : EIO;
+            break;
+          }
+          p += w;
+          left -= (size_t)w;
+          done += (uint64_t)w;
+        }
+        t.n = 0;
+      }
+      {
+        std::lock_guard<std::mutex> lk(m);
+        bytes += done;
+        write_s += (now_ms() - t0) * 1e-3;
+        busy = false;
+        if (spare.size() < 3) spare.push_back(std::move(set));
+      }
+      cv.notify_all();
+    }
+  }
+};
+
+namespace {
+
 // where the SAM text goes: one malloc'ed buffer, or a writer called chunk by chunk in order
 struct SamSink {
   char **text = nullptr;
@@ -1458,29 +1519,25 @@ void sam_stage(const SamInput &in, Arena &A, int threads, const Group *groups, s
   std::vector<size_t> at(n_tasks + 1, 0);
   for (size_t t = 0; t < n_tasks; t++) at[t + 1] = at[t] + parts[t].n;
   *bytes = at.back();
-  if (sink.write == &kslam_write_fd && sink.user && at.back()) {
-    // The library's own file writer: the chunks' places in the file are known, so the file is grown, its new range is
-    // mapped and the chunks are copied in by all workers at once.  (write() / pwrite() on ONE file serialise on the
-    // inode lock, whatever the number of callers: measured 5 GB/s into tmpfs, 80 ms for a batch's 400 MB of SAM text,
-    // three times the formatting itself; page faults on a shared mapping do not.)  A descriptor that cannot seek or
-    // be mapped (a pipe) is written chunk by chunk below.
-    const int fd = *static_cast<const int *>(sink.user);
-    const off_t base = lseek(fd, 0, SEEK_CUR);
-    const uint64_t total = at.back();
-    if (base >= 0 && ftruncate(fd, base + (off_t)total) == 0) {
-      const uint64_t page = 4096, lo = (uint64_t)base & ~(page - 1), span = (uint64_t)base - lo + total;
-      void *m = mmap(nullptr, span, PROT_READ | PROT_WRITE, MAP_SHARED, fd, (off_t)lo);
-      if (m != MAP_FAILED) {
-        char *dst = static_cast<char *>(m) + ((uint64_t)base - lo);
-        Pool::get().tasks(threads, n_tasks, [&](size_t t) {
-          if (parts[t].n) memcpy(dst + at[t], parts[t].p, parts[t].n);
-        });
-        munmap(m, span);
-        if (lseek(fd, base + (off_t)total, SEEK_SET) < 0) fail(KSLAM_ERR_ARG, "writing the SAM text failed");
-        return;
+  if (sink.write == &kslam_write_queued && sink.user) {
+    // the background writer: this batch's buffers join its queue (at most two batches wait there: a writer that falls
+    // behind holds the formatter back instead of piling up text), and a written set takes their place in the arena
+    kslam_sam_writer *w = static_cast<kslam_sam_writer *>(sink.user);
+    std::vector<Text> next;
+    {
+      std::unique_lock<std::mutex> lk(w->m);
+      w->cv.wait(lk, [&] { return w->error || w->queue.size() < 2; });
+      if (w->error) fail(KSLAM_ERR_ARG, std::string("writing the SAM text failed: ") + strerror(w->error));
+      if (!w->spare.empty()) {
+        next = std::move(w->spare.back());
+        w->spare.pop_back();
       }
-      if (ftruncate(fd, base) != 0) fail(KSLAM_ERR_ARG, "writing the SAM text failed");   // not mappable: undo, write serially
+      std::vector<Text> mine(std::make_move_iterator(parts.begin()), std::make_move_iterator(parts.begin() + n_tasks));
+      w->queue.push_back(std::move(mine));
     }
+    w->cv.notify_all();
+    for (size_t t = 0; t < n_tasks && t < next.size(); t++) parts[t] = std::move(next[t]);
+    return;
   }
   if (sink.write) {
     for (size_t t = 0; t < n_tasks; t++)
@@ -1731,6 +1788,55 @@ int kslam_write_fd(void *user, const char *data, uint64_t len) {
     len -= (uint64_t)w;
   }
   return 0;
+}
+
+kslam_status kslam_sam_writer_open(int fd, kslam_sam_writer **out) {
+  return guarded([&] {
+    if (!out || fd < 0) fail(KSLAM_ERR_ARG, "bad argument");
+    kslam_sam_writer *w = new kslam_sam_writer();
+    w->fd = fd;
+    w->th = std::thread([w] { w->run(); });
+    *out = w;
+  });
+}
+
+// the writer as a plain kslam_write_fn (a caller's own text, e.g. the header): copied into a queued buffer
+int kslam_write_queued(void *user, const char *data, uint64_t len) {
+  kslam_sam_writer *w = static_cast<kslam_sam_writer *>(user);
+  if (!w) return 1;
+  std::vector<Text> one(1);
+  try {
+    one[0].put(data, (size_t)len);
+  } catch (...) {
+    return 1;
+  }
+  {
+    std::unique_lock<std::mutex> lk(w->m);
+    w->cv.wait(lk, [&] { return w->error || w->queue.size() < 2; });
+    if (w->error) return 1;
+    w->queue.push_back(std::move(one));
+  }
+  w->cv.notify_all();
+  return 0;
+}
+
+kslam_status kslam_sam_writer_close(kslam_sam_writer *w, uint64_t *bytes_written, double *seconds_writing) {
+  if (!w) return KSLAM_ERR_ARG;
+  {
+    std::lock_guard<std::mutex> lk(w->m);
+    w->stop = true;
+  }
+  w->cv.notify_all();
+  if (w->th.joinable()) w->th.join();      // drains the queue first
+  const int err = w->error;
+  if (bytes_written) *bytes_written = w->bytes;
+  if (seconds_writing) *seconds_writing = w->write_s;
+  delete w;
+  if (err) {
+    g_err = std::string("writing the SAM text failed: ") + strerror(err);
+    return KSLAM_ERR_ARG;
+  }
+  return KSLAM_OK;
 }
 
 void kslam_tail_release_buffers(void) {

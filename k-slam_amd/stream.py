@@ -35,13 +35,16 @@ def _fd_writer():
 
 
 def finish_rows_fd(params, reads, index, ov, cg, det, md, rp, pr, fd):
-    """kslam_tail_finish_write_rows with the library's own file-descriptor writer (no Python in the write path);
-    fd < 0: the text is formatted and dropped."""
+    """kslam_tail_finish_write_rows with one of the library's own writers (no Python in the write path): fd = a file
+    descriptor (kslam_write_fd, written before the call returns), a kslam_amd.tail.SamWriter (kslam_write_queued: the
+    text is handed to its background thread), or < 0: the text is formatted and dropped."""
     L = T.lib()
     st = T.TailStats()
     pool = np.ascontiguousarray(cg, dtype=np.uint32)
-    keep = C.c_int(fd)
-    if fd >= 0:
+    if isinstance(fd, T.SamWriter):
+        cb, user = fd.callback, fd._h
+    elif fd >= 0:
+        keep = C.c_int(fd)
         cb, user = _fd_writer(), C.cast(C.pointer(keep), C.c_void_p)
     else:
         cb, user = T.WRITE_FN(lambda u, d, n: 0), None
@@ -92,8 +95,11 @@ def classify_stream(ctx, index, r1_ptr, len1, r2_ptr, len2, pairs_per_batch, par
     stages = 3 | (4 if params.pseudo_assembly else 0)
     ctx.set_pairing(paired=True, score_threshold=params.score_threshold, score_fraction=params.score_fraction, stages=stages)
     depth = depth or 3
-    if sam_header is not None and sam_fd >= 0:
-        os.write(sam_fd, sam_header)
+    # the SAM text leaves through a background writer (kslam_sam_writer): the write of batch k runs under the
+    # formatting of batch k + 1
+    writer = T.SamWriter(sam_fd) if sam_fd >= 0 else None
+    if sam_header is not None and writer is not None:
+        writer.write(sam_header)
     P_host = T.TailParams.default(paired=True, report_cigar=bool(params.report_cigar), score_threshold=params.score_threshold,
                                   num_sam_alignments=params.num_sam_alignments, score_fraction=params.score_fraction,
                                   pseudo_assembly=bool(params.pseudo_assembly), sam_xa=bool(params.sam_xa), threads=host_threads)
@@ -112,7 +118,7 @@ def classify_stream(ctx, index, r1_ptr, len1, r2_ptr, len2, pairs_per_batch, par
                 before_batch(k, ov, cg, det, md, rp, pr, pst, reads)
                 t0 = time.perf_counter()
             st = finish_rows_fd(P_write if on_gpu or not params.pseudo_assembly else P_host, reads, index, ov, cg, det, md,
-                                rp, pr, sam_fd)
+                                rp, pr, writer if writer is not None else -1)
             t1 = time.perf_counter()
             rec = {"batch": k, "pairs": reads.n_reads // 2, "overlaps": int(len(ov)), "alignment_pairs": int(st.n_paired_final),
                    "read_pairs_aligned": int(st.n_read_pairs), "max_insert_size": int(pst["max_insert_size"]),
@@ -188,6 +194,11 @@ def classify_stream(ctx, index, r1_ptr, len1, r2_ptr, len2, pairs_per_batch, par
         except KslamError:
             pass
     ctx.set_pairing(stages=0)
+    if writer is not None:
+        try:
+            out["sam_bytes_written"], out["s_in_write"] = writer.close()
+        except KslamError as e:
+            failure.append(e)
     if failure:
         raise failure[0]
     out["tax_ids"] = np.concatenate(out["tax_ids"]) if out["tax_ids"] else np.zeros(0, dtype=np.uint32)

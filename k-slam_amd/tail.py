@@ -23,7 +23,7 @@ assert PAIRED_OVERLAP_DT.itemsize == 32 and READ_PAIR_DT.itemsize == 24
 EXPORTS = ["kslam_tail_last_error", "kslam_tail_pairs", "kslam_sam_records", "kslam_tail_sam",
            "kslam_tail_sam_write", "kslam_tail_sam_rows", "kslam_tail_sam_write_rows", "kslam_tail_finish_write_rows",
            "kslam_tail_release_buffers",
-           "kslam_sam_header", "kslam_write_fd"]
+           "kslam_sam_header", "kslam_write_fd", "kslam_sam_writer_open", "kslam_write_queued", "kslam_sam_writer_close"]
 WRITE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64)
 
 _vp, _u64, _u32, _i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int32
@@ -187,6 +187,9 @@ def lib():
                                                    _vp, _vp, _u64, _vp, _u64, _vp, _u64, WRITE_FN, _vp, P(TailStats)]
         L.kslam_tail_release_buffers.restype = None
         L.kslam_sam_header.argtypes = [P(IndexView), C.c_char_p, P(_vp), P(_u64)]
+        L.kslam_sam_writer_open.argtypes = [C.c_int, P(_vp)]
+        L.kslam_sam_writer_close.argtypes = [_vp, P(_u64), P(C.c_double)]
+        L.kslam_write_queued.argtypes = [_vp, C.c_char_p, _u64]
         _lib = L
     return _lib
 
@@ -360,3 +363,26 @@ def sam_header(index, command_line=b""):
     txt, n = _vp(), _u64()
     _chk(L.kslam_sam_header(C.byref(index.view), command_line, C.byref(txt), C.byref(n)))
     return _text(txt, n)
+
+
+class SamWriter:
+    """kslam_sam_writer: a background thread that writes SAM text to `fd` in order while the next batch is formatted"""
+
+    def __init__(self, fd):
+        L = lib()
+        self._h = _vp()
+        _chk(L.kslam_sam_writer_open(fd, C.byref(self._h)))
+        self.callback = C.cast(L.kslam_write_queued, WRITE_FN)
+
+    def write(self, data):
+        if lib().kslam_write_queued(self._h, data, len(data)) != 0:
+            raise KslamError(1, "the SAM writer reported a failed write")
+
+    def close(self):
+        """-> (bytes written, seconds the thread spent in write())"""
+        if self._h is None:
+            return 0, 0.0
+        n, sec = _u64(), C.c_double()
+        h, self._h = self._h, None
+        _chk(lib().kslam_sam_writer_close(h, C.byref(n), C.byref(sec)))
+        return int(n.value), float(sec.value)

@@ -267,9 +267,9 @@ def test_sam_text_matches_restatement_and_the_sam_definition(kslam, oracle, synt
 
 
 def test_sam_text_written_through_the_fd_writer(kslam, oracle, synth, T, tmp_path):
-    """kslam_write_fd: the library's own writer.  Into a regular file the chunks go out in parallel (pwrite from the
-    descriptor's position, which moves past the text: a header written first and a second batch written after stay
-    where they belong); into a pipe, which cannot seek, chunk by chunk.  Both give the text of kslam_tail_sam."""
+    """kslam_write_fd and the background writer (kslam_sam_writer_* / kslam_write_queued: buffers handed over, written by
+    the writer's thread in order, reused): a header first, two batches after it, into a file and into a pipe -- always the
+    text of kslam_tail_sam; a failing descriptor is reported."""
     import ctypes as C
     import os
     import threading
@@ -303,6 +303,31 @@ def test_sam_text_written_through_the_fd_writer(kslam, oracle, synth, T, tmp_pat
     os.close(w)
     reader.join()
     assert got[0] == exp
+
+    def queued(fd, n_batches):
+        wr = T.SamWriter(fd)
+        wr.write(b"@HD\theader\n")
+        st = T.TailStats()
+        for _ in range(n_batches):
+            T._chk(L.kslam_tail_sam_write(C.byref(P), C.byref(R.view), C.byref(I.view), ov.ctypes.data, len(ov), pool.ctypes.data,
+                                          len(pool), wr.callback, wr._h, C.byref(st)))
+        return wr.close()
+    fd = os.open(path, os.O_RDWR | os.O_CREAT | os.O_TRUNC)
+    n, sec = queued(fd, 5)
+    os.close(fd)
+    assert open(path, "rb").read() == b"@HD\theader\n" + exp * 5 and n == 11 + 5 * len(exp) and sec >= 0
+    r, w = os.pipe()
+    got = []
+    reader = threading.Thread(target=lambda: got.append(os.fdopen(r, "rb").read()))
+    reader.start()
+    queued(w, 2)
+    os.close(w)
+    reader.join()
+    assert got[0] == b"@HD\theader\n" + exp * 2
+    rd = os.open(path, os.O_RDONLY)            # not open for writing: the writer's thread fails, close() says so
+    with pytest.raises(kslam.KslamError, match="writing the SAM text failed"):
+        queued(rd, 1)
+    os.close(rd)
 
 
 @pytest.mark.parametrize("kw", [{}, {"num_sam_alignments": 1}, {"paired": False}, {"score_threshold": 120}])

@@ -187,12 +187,13 @@ def e2e_leg(K, ctx, files, pairs_per_batch, index_view, taxdb, steps, warmup, ps
     wins = list(S.cut_batches(files.h[0].ptr, files.len, files.h[1].ptr, files.len, pairs_per_batch))
     F = len(wins)
     header = T.sam_header(index_view, b"SLAM --db synthetic R1.fq R2.fq")
-    sam_path = os.path.join(out_dir, "kslam_bench_%d_%s.sam" % (os.getpid(), tag))
-    pr_path = os.path.join(out_dir, "kslam_bench_%d_%s_PerRead" % (os.getpid(), tag))
+    discard = out_dir == "/dev/null"      # the same leg with the SAM text thrown away by the kernel: what the sink costs
+    sam_path = "/dev/null" if discard else os.path.join(out_dir, "kslam_bench_%d_%s.sam" % (os.getpid(), tag))
+    pr_path = os.path.join("/dev/shm" if discard else out_dir, "kslam_bench_%d_%s_PerRead" % (os.getpid(), tag))
 
     def run(n_steps, keep_report=False):
         report = X.Report()
-        sam_fd = os.open(sam_path, os.O_RDWR | os.O_CREAT | os.O_TRUNC, 0o600)
+        sam_fd = os.open(sam_path, os.O_WRONLY) if discard else os.open(sam_path, os.O_RDWR | os.O_CREAT | os.O_TRUNC, 0o600)
         pr_fd = os.open(pr_path, os.O_RDWR | os.O_CREAT | os.O_TRUNC, 0o600)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -203,7 +204,8 @@ def e2e_leg(K, ctx, files, pairs_per_batch, index_view, taxdb, steps, warmup, ps
         os.close(pr_fd)
         torch.cuda.synchronize()
         res["wall"] = time.perf_counter() - t0
-        res["sam_file_bytes"], res["per_read_file_bytes"] = os.path.getsize(sam_path), os.path.getsize(pr_path)
+        res["sam_file_bytes"] = res.get("sam_bytes_written", 0) if discard else os.path.getsize(sam_path)
+        res["per_read_file_bytes"] = os.path.getsize(pr_path)
         if keep_report:
             res["report"] = report
         else:
@@ -219,7 +221,7 @@ def e2e_leg(K, ctx, files, pairs_per_batch, index_view, taxdb, steps, warmup, ps
         t0 = time.perf_counter()
         summary = taxdb.summary(last["tax_ids"], last["pairs"])
         xml = taxdb.report_xml(last["report"], index_view, None, last["pairs"])
-        with open(sam_path + ".xml", "wb") as f:
+        with open(pr_path + ".xml", "wb") as f:
             f.write(xml)
         t_end = time.perf_counter() - t0
         last["report"].close()
@@ -254,9 +256,10 @@ def e2e_leg(K, ctx, files, pairs_per_batch, index_view, taxdb, steps, warmup, ps
         }
         return out
     finally:
-        for pth in (sam_path, pr_path, sam_path + ".xml"):
+        for pth in (sam_path, pr_path, pr_path + ".xml"):
             try:
-                os.unlink(pth)
+                if pth != "/dev/null":
+                    os.unlink(pth)
             except OSError:
                 pass
 
@@ -815,6 +818,11 @@ def main():
                 "included, median of %d repetitions: FASTQ text in page-locked HOST memory when the clock starts (every PCIe byte "
                 "inside), SAM text and <out>_PerRead written to files in /dev/shm when it stops, per-read LCA inside.  The rate with "
                 "the batch resident in HBM and the results left on the device (alignToDatabase only) is hot_path.reads_per_s" % 3)
+            try:                  # what the sink costs: the same leg with the SAM text written to /dev/null
+                d = e2e_leg(K, ctx, files, pairs, index_view, taxdb, Ksteps, args.warmup, pseudo, reps=1, tag="null", out_dir="/dev/null")
+                out["e2e_sam_to_dev_null"] = {k: d[k] for k in ("reads_per_s", "ms_per_step", "host_ms_per_batch")}
+            except Exception as e:
+                out["e2e_sam_to_dev_null"] = {"error": repr(e)}
             if config == 1:       # the same with the reference's default (pseudo-assembly on)
                 try:
                     out["e2e_with_pseudo_assembly"] = e2e_leg(K, ctx, files, pairs, index_view, taxdb, Ksteps, args.warmup, True, tag="pa", out_dir=args.out_dir)

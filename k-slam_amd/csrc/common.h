@@ -48,6 +48,7 @@ struct Tuning {
   int bucket_bits_exact = 0;          // KSLAM_BUCKET_BITS_EXACT (0: sized from the index)
   int filter_bits = -1;               // KSLAM_FILTER_BITS (-1: sized from the index, 0: no filter)
   int sort_bytes = -1;                // KSLAM_SORT_BYTES (-1: what the bucket table needs)
+  bool sort_digit_bytes = true;       // KSLAM_SORT_DIGIT_BYTES=0: histograms re-read the records
   int lanes = 2;                      // KSLAM_LANES
   bool eager_cigar = false;           // KSLAM_EAGER_CIGAR
   bool pageable_columns = false;      // KSLAM_PAGEABLE_COLUMNS
@@ -173,6 +174,8 @@ struct SortWorkspace {
   DevBuf hist;      // u32 [chunks][256] per-chunk digit totals -> bases
   DevBuf status;    // u32 [tiles][256] per-tile digit counts -> in-chunk prefixes
   DevBuf tickets;   // u32 [256] per-digit totals -> global bin bases
+  DevBuf digits;    // u8 [n] the next pass's digit of every record, written by the scatter (radix_sort.hip)
+  bool use_digit_bytes = true;   // KSLAM_SORT_DIGIT_BYTES=0: every histogram re-reads the records (A/B)
   hipEvent_t *ev_sc0 = nullptr, *ev_sc1 = nullptr;   // optional per-pass events around k_scatter
   uint32_t epoch = 0;
 };

@@ -161,6 +161,7 @@ Tuning read_tuning() {
     t.filter_bits = v <= 0 ? 0 : std::min(36, std::max(20, v));
   }
   if (flag("KSLAM_SORT_BYTES")) t.sort_bytes = std::max(0, num("KSLAM_SORT_BYTES", 0));
+  t.sort_digit_bytes = !starts("KSLAM_SORT_DIGIT_BYTES", '0');
   t.lanes = std::min(8, std::max(1, num("KSLAM_LANES", 2)));
   t.eager_cigar = flag("KSLAM_EAGER_CIGAR");
   t.pageable_columns = flag("KSLAM_PAGEABLE_COLUMNS");
@@ -611,6 +612,7 @@ void align_resident(kslam_ctx *c, bool stop_after_join, uint64_t *n_raw_out, Pai
     tm.n_kmers_kept += nk;
     HIPCHK(hipEventRecord(c->ev[1], s));
     // ---- a-4: sort by k-mer ----
+    c->sortws.use_digit_bytes = c->tune.sort_digit_bytes;
     c->sortws.ev_sc0 = c->evs0; c->sortws.ev_sc1 = c->evs1;
     const uint4 *sorted = (const uint4 *)radix_sort(c->recs_a.p, c->recs_b.p, nk, 4, kpasses.data(),
                                                     (int)kpasses.size(), c->sortws, s, c->ev[2], c->ev[3],
@@ -1087,7 +1089,7 @@ void kslam_destroy(kslam_ctx *c) {
     DevBuf *bufs[] = {&c->g_codes, &c->r_codes, &c->g_bases, &c->g_off, &c->gk_key, &c->gk_meta, &c->gk_off, &c->g_bucket, &c->g_filter, &c->r_bases,
                       &c->r_off, &c->r_len, &c->nk, &c->nseg, &c->rec_start, &c->seg_start, &c->segs, &c->scan_tmp,
                       &c->totals, &c->recs_a, &c->recs_b, &c->block_tot, &c->block_base, &c->ovk_a, &c->ovk_b,
-                      &c->flags, &c->pos, &c->band0, &c->sortws.hist, &c->sortws.status, &c->sortws.tickets,
+                      &c->flags, &c->pos, &c->band0, &c->sortws.hist, &c->sortws.status, &c->sortws.tickets, &c->sortws.digits,
                       &c->cig.flags, &c->cig.pos, &c->cig.list, &c->cig.bmax, &c->cig.needbig,
                       &c->cig.scan_tmp, &c->cig.totals, &c->cig.cig_off, &c->cig.tmp, &c->cig.tmp_big,
                       &c->cig.big_pos, &c->cig.scratch, &c->sww.flags, &c->sww.pos, &c->sww.list, &c->sww.list2, &c->sww.scan_tmp, &c->sww.totals, &c->cells, &c->res_ov, &c->res_cig, &c->res_tmp, &c->r_qual, &c->d_tables, &c->res_det, &c->fq_text, &c->fq_bases_at, &c->fq_qual_at, &c->fqw.tile_count, &c->fqw.tile_base, &c->fqw.scan_tmp,

@@ -63,6 +63,31 @@ __device__ __forceinline__ void tile_hist_body(const typename RecT<RW>::type *__
   if (tid < 256) tile_hist[(uint64_t)blockIdx.x * 256 + tid] = h[tid];
 }
 
+// The same histogram from the pass's DIGIT BYTES: the scatter of pass p also stores every record's digit of pass
+// p + 1 at the record's destination (one byte next to the 8 / 16 the record takes), so that pass p + 1's
+// histogram reads 1 byte per record instead of the whole record -- the histogram read had been a third of a
+// pass's traffic.  One workgroup of 256 threads per tile, 16 digits per thread.
+__global__ __launch_bounds__(256) void k_tile_hist_bytes(const uint8_t *__restrict__ dig, uint32_t n,
+                                                         uint32_t *__restrict__ tile_hist) {
+  __shared__ uint32_t h[256];
+  const uint32_t tid = threadIdx.x;
+  h[tid] = 0;
+  __syncthreads();
+  const uint32_t base = blockIdx.x * SORT_TILE + tid * 16;
+  if (base + 16 <= n) {
+    const uint4 v = *reinterpret_cast<const uint4 *>(dig + base);   // tiles start at multiples of 4096: aligned
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+#pragma unroll
+      for (int b = 0; b < 4; b++) atomicAdd(&h[(w[k] >> (8 * b)) & 0xFFu], 1u);
+  } else {
+    for (uint32_t i = base; i < n && i < base + 16; i++) atomicAdd(&h[dig[i]], 1u);
+  }
+  __syncthreads();
+  tile_hist[(uint64_t)blockIdx.x * 256 + tid] = h[tid];
+}
+
 // ---- scan of the tile histograms (per digit, over tiles) --------------------------------------
 constexpr int CHUNK_TILES = 64;
 // level 1: one workgroup per chunk of 64 tiles, thread = digit: in-chunk exclusive prefix in place
@@ -145,7 +170,8 @@ __device__ __forceinline__ void scatter_body(const typename RecT<RW>::type *__re
                                              typename RecT<RW>::type *__restrict__ out, uint32_t n,
                                              const uint32_t *__restrict__ tile_prefix,
                                              const uint32_t *__restrict__ chunk_base,
-                                             const uint32_t *__restrict__ bin_base, SortPass pass) {
+                                             const uint32_t *__restrict__ bin_base, SortPass pass,
+                                             uint8_t *__restrict__ next_digits, SortPass next_pass) {
   using T = typename RecT<RW>::type;
   __shared__ T stage[SORT_TILE];
   __shared__ uint32_t wave_hist[RS_WAVES][256];
@@ -239,7 +265,9 @@ __device__ __forceinline__ void scatter_body(const typename RecT<RW>::type *__re
     const uint32_t p = j * RS_BLOCK + tid;
     if (p < count) {
       const T r = stage[p];
-      out[glob_delta[digit_of(r, pass)] + p] = r;
+      const uint32_t dest = glob_delta[digit_of(r, pass)] + p;
+      out[dest] = r;
+      if (next_digits) next_digits[dest] = (uint8_t)digit_of(r, next_pass);   // the next pass's histogram reads these
     }
   }
 }
@@ -249,16 +277,18 @@ __global__ __launch_bounds__(RS_BLOCK) void k_scatter(const typename RecT<RW>::t
                                                       typename RecT<RW>::type *__restrict__ out, uint32_t n,
                                                       const uint32_t *__restrict__ tile_prefix,
                                                       const uint32_t *__restrict__ chunk_base,
-                                                      const uint32_t *__restrict__ bin_base, SortPass pass) {
-  scatter_body<RW>(in, out, n, tile_prefix, chunk_base, bin_base, pass);
+                                                      const uint32_t *__restrict__ bin_base, SortPass pass,
+                                                      uint8_t *__restrict__ next_digits, SortPass next_pass) {
+  scatter_body<RW>(in, out, n, tile_prefix, chunk_base, bin_base, pass, next_digits, next_pass);
 }
 template <int RW>
 __global__ __launch_bounds__(RS_BLOCK) void k_scatter_setup(const typename RecT<RW>::type *__restrict__ in,
                                                             typename RecT<RW>::type *__restrict__ out, uint32_t n,
                                                             const uint32_t *__restrict__ tile_prefix,
                                                             const uint32_t *__restrict__ chunk_base,
-                                                            const uint32_t *__restrict__ bin_base, SortPass pass) {
-  scatter_body<RW>(in, out, n, tile_prefix, chunk_base, bin_base, pass);
+                                                            const uint32_t *__restrict__ bin_base, SortPass pass,
+                                                            uint8_t *__restrict__ next_digits, SortPass next_pass) {
+  scatter_body<RW>(in, out, n, tile_prefix, chunk_base, bin_base, pass, next_digits, next_pass);
 }
 
 template <int RW, bool SETUP>
@@ -271,18 +301,24 @@ void sort_impl(void *a, void *b, uint32_t n, const PassList &pl, SortWorkspace &
   uint32_t *chunk_tot = ws.hist.as<uint32_t>();
   uint32_t *digit_tot = ws.tickets.as<uint32_t>();
   T *src = (T *)a, *dst = (T *)b;
+  // digit bytes of the NEXT pass, written by each scatter next to the records (ws.digits: n bytes; the one-time
+  // sorts keep the plain form, their kernel names are the profile's reference for it)
+  uint8_t *digits = (!SETUP && pl.n > 1 && ws.use_digit_bytes) ? ws.digits.as<uint8_t>() : nullptr;
   if (ev0) HIPCHK(hipEventRecord(ev0, s));
   for (int p = 0; p < pl.n; p++) {
     if (SETUP) hipLaunchKernelGGL(k_tile_hist_setup<RW>, dim3(tiles), dim3(RS_BLOCK), 0, s, (const T *)src, n, pl.p[p], tile_hist);
+    else if (digits && p > 0) hipLaunchKernelGGL(k_tile_hist_bytes, dim3(tiles), dim3(256), 0, s, (const uint8_t *)digits, n, tile_hist);
     else hipLaunchKernelGGL(k_tile_hist<RW>, dim3(tiles), dim3(RS_BLOCK), 0, s, (const T *)src, n, pl.p[p], tile_hist);
     hipLaunchKernelGGL(k_chunk_scan, dim3(chunks), dim3(256), 0, s, tile_hist, tiles, chunk_tot);
     hipLaunchKernelGGL(k_col_scan, dim3(256), dim3(256), 0, s, chunk_tot, chunks, digit_tot);
     hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(256), 0, s, digit_tot);
     if (ws.ev_sc0) HIPCHK(hipEventRecord(ws.ev_sc0[p], s));
+    uint8_t *nd = (digits && p + 1 < pl.n) ? digits : nullptr;   // (pass p's histogram has read the array by now)
+    const SortPass np = pl.p[p + 1 < pl.n ? p + 1 : p];
     if (SETUP) hipLaunchKernelGGL(k_scatter_setup<RW>, dim3(tiles), dim3(RS_BLOCK), 0, s, (const T *)src, dst, n, tile_hist,
-                                  chunk_tot, digit_tot, pl.p[p]);
+                                  chunk_tot, digit_tot, pl.p[p], (uint8_t *)nullptr, np);
     else hipLaunchKernelGGL(k_scatter<RW>, dim3(tiles), dim3(RS_BLOCK), 0, s, (const T *)src, dst, n, tile_hist,
-                            chunk_tot, digit_tot, pl.p[p]);
+                            chunk_tot, digit_tot, pl.p[p], nd, np);
     if (ws.ev_sc0) HIPCHK(hipEventRecord(ws.ev_sc1[p], s));
     T *t = src; src = dst; dst = t;
     if (n_launches) (*n_launches)++;
@@ -311,6 +347,7 @@ void *radix_sort(void *a, void *b, uint64_t n, int rec_words, const SortPass *pa
   ws.status.ensure(tiles * 256 * sizeof(uint32_t));   // per-tile digit histograms / prefixes
   ws.hist.ensure(chunks * 256 * sizeof(uint32_t));    // per-chunk totals / bases
   ws.tickets.ensure(256 * sizeof(uint32_t));           // per-digit totals -> bin bases
+  if (!setup && n_passes > 1 && ws.use_digit_bytes) ws.digits.ensure(n + 64);   // next-pass digit of every record
   void *res = nullptr;
   if (rec_words == 4 && setup) sort_impl<4, true>(a, b, (uint32_t)n, pl, ws, s, ev0, ev1, n_launches, &res);
   else if (rec_words == 4) sort_impl<4, false>(a, b, (uint32_t)n, pl, ws, s, ev0, ev1, n_launches, &res);

@@ -147,8 +147,11 @@ size_t filter_bytes(uint32_t log2_bits);
 void filter_build(const uint64_t *d_sorted_keys, uint32_t n, uint32_t log2_bits, void *d_filter, hipStream_t s);
 // reads d_off[0..n_reads] (gap 1, ids = position in d_off): surviving records appended at *d_cursor
 // (which ends as their number); nothing is written beyond `cap` (the caller reruns with a larger buffer)
+// d_digits != nullptr: also byte digit_word / digit_shift of every record written (the first radix pass's digit), at
+// the record's index
 void extract_filtered(const uint8_t *d_bases, const uint64_t *d_off, uint32_t n_reads, const void *d_filter,
-                      uint32_t log2_bits, uint4 *d_out, uint64_t *d_cursor, uint64_t cap, const Tuning &tune, hipStream_t s);
+                      uint32_t log2_bits, uint4 *d_out, uint64_t *d_cursor, uint64_t cap, const Tuning &tune, hipStream_t s,
+                      uint8_t *d_digits = nullptr, uint32_t digit_word = 0, uint32_t digit_shift = 0);
 
 // ---------------------------------------------------------- radix_sort.hip
 struct SortPass {
@@ -176,6 +179,8 @@ struct SortWorkspace {
   DevBuf tickets;   // u32 [256] per-digit totals -> global bin bases
   DevBuf digits;    // u8 [n] the next pass's digit of every record, written by the scatter (radix_sort.hip)
   bool use_digit_bytes = true;   // KSLAM_SORT_DIGIT_BYTES=0: every histogram re-reads the records (A/B)
+  bool first_digits_ready = false;   // `digits` already holds the FIRST pass's digit of every record (the producer of the
+                                     // records wrote them: extract_filtered); the caller sets and clears it around one sort
   hipEvent_t *ev_sc0 = nullptr, *ev_sc1 = nullptr;   // optional per-pass events around k_scatter
   uint32_t epoch = 0;
 };

@@ -116,7 +116,8 @@ __global__ __launch_bounds__(FW * 64) void k_extract_filter(const uint8_t *__res
                                                             const uint4 *__restrict__ filter, uint32_t line_bits,
                                                             uint4 *__restrict__ out,
                                                             unsigned long long *__restrict__ cursor, uint64_t cap,
-                                                            uint32_t ablate) {
+                                                            uint32_t ablate, uint8_t *__restrict__ digits,
+                                                            uint32_t digit_word, uint32_t digit_shift) {
 #ifdef KSLAM_ABLATE
 #define KSLAM_FILTER_ABLATED(bit) ((ablate & (bit)) != 0)   // measurement-only build: parts of the kernel switched off
 #else
@@ -136,6 +137,8 @@ __global__ __launch_bounds__(FW * 64) void k_extract_filter(const uint8_t *__res
   const uint32_t r_cnt = r_begin < n_reads ? min(n_reads - r_begin, RPW) : 0u;
   const uint64_t my_off = r_cnt ? off[r_begin + min(lane, r_cnt)] : 0ull;   // lanes 0..r_cnt: this wave's read offsets
 
+  // the first radix pass's digit of a record (the sort's first histogram then reads these bytes, not the records)
+  auto digit_of_rec = [&](const uint4 &r) -> uint8_t { return (uint8_t)(((digit_word ? r.y : r.x) >> digit_shift) & 0xFFu); };
   auto offset_of = [&](uint32_t i) -> uint64_t {   // i is wave-uniform
     const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)my_off, i);
     const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(my_off >> 32), i);
@@ -162,7 +165,11 @@ __global__ __launch_bounds__(FW * 64) void k_extract_filter(const uint8_t *__res
     __syncthreads();
     const unsigned long long gb = wg_base;
     if (gb + n_st <= cap)
-      for (uint32_t k = threadIdx.x; k < n_st; k += FW * 64) out[gb + k] = stage[k];
+      for (uint32_t k = threadIdx.x; k < n_st; k += FW * 64) {
+        const uint4 r = stage[k];
+        out[gb + k] = r;
+        if (digits) digits[gb + k] = digit_of_rec(r);
+      }
     __syncthreads();
     if (threadIdx.x == 0) { staged = 0; stage_valid = STAGE; }
     __syncthreads();
@@ -235,7 +242,10 @@ __global__ __launch_bounds__(FW * 64) void k_extract_filter(const uint8_t *__res
         if (lane == 0) gb = atomicAdd(cursor, (unsigned long long)cnt);
         gb = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(gb >> 32)) << 32) |
              __builtin_amdgcn_readfirstlane((uint32_t)gb);
-        if (keep && gb + cnt <= cap) out[gb + (slot - base)] = rec;
+        if (keep && gb + cnt <= cap) {
+          out[gb + (slot - base)] = rec;
+          if (digits) digits[gb + (slot - base)] = digit_of_rec(rec);
+        }
       }
     };
     for (uint32_t q0 = 0; q0 < nk; q0 += 128) {
@@ -276,7 +286,8 @@ void filter_build(const uint64_t *d_sorted_keys, uint32_t n, uint32_t log2_bits,
 }
 
 void extract_filtered(const uint8_t *d_bases, const uint64_t *d_off, uint32_t n_reads, const void *d_filter,
-                      uint32_t log2_bits, uint4 *d_out, uint64_t *d_cursor, uint64_t cap, const Tuning &tune, hipStream_t s) {
+                      uint32_t log2_bits, uint4 *d_out, uint64_t *d_cursor, uint64_t cap, const Tuning &tune, hipStream_t s,
+                      uint8_t *d_digits, uint32_t digit_word, uint32_t digit_shift) {
   HIPCHK(hipMemsetAsync(d_cursor, 0, sizeof(uint64_t), s));
   if (n_reads == 0) return;
   const uint32_t per_block = FW * RPW;
@@ -284,11 +295,12 @@ void extract_filtered(const uint8_t *d_bases, const uint64_t *d_off, uint32_t n_
                      n_reads, (const uint4 *)d_filter, log2_bits - 10, d_out,
                      reinterpret_cast<unsigned long long *>(d_cursor), cap,
 #ifdef KSLAM_ABLATE
-                     tune.filter_ablate);
+                     tune.filter_ablate,
 #else
-                     0u);
-  (void)tune;
+                     0u,
 #endif
+                     d_digits, digit_word, digit_shift);
+  (void)tune;
   HIPCHK(hipGetLastError());
 }
 

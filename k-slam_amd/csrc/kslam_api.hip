@@ -594,16 +594,21 @@ void align_resident(kslam_ctx *c, bool stop_after_join, uint64_t *n_raw_out, Pai
       d_tot = c->totals.as<uint64_t>();
       uint64_t cap = std::max<uint64_t>(c->kept_last + c->kept_last / 4, nk_all / 12) + 4096;
       cap = std::min(cap, nk_all);
+      // the extraction also writes the first radix pass's digit of every survivor (radix_sort.hip: digit bytes)
+      const bool with_digits = c->tune.sort_digit_bytes && kpasses.size() > 1 && kpasses[0].word < 2 && !kpasses[0].invert;
       for (int attempt = 0; attempt < 2; attempt++) {
         c->recs_a.ensure((cap + 1) * sizeof(uint4));
+        if (with_digits) c->sortws.digits.ensure(cap + 64);
         extract_filtered(c->r_bases.as<uint8_t>(), d_off, (uint32_t)nr, c->g_filter.p, c->filter_bits,
-                         c->recs_a.as<uint4>(), d_tot + 2, cap, c->tune, s);
+                         c->recs_a.as<uint4>(), d_tot + 2, cap, c->tune, s, with_digits ? c->sortws.digits.as<uint8_t>() : nullptr,
+                         with_digits ? kpasses[0].word : 0u, with_digits ? kpasses[0].shift : 0u);
         read_back(&nk, d_tot + 2, sizeof nk, s);
         if (nk <= cap) break;
         cap = nk;
       }
       c->kept_last = nk;
       c->recs_b.ensure((nk + 1) * sizeof(uint4));
+      c->sortws.first_digits_ready = with_digits;
     } else {
       c->recs_a.ensure((nk + 1) * sizeof(uint4));
       c->recs_b.ensure((nk + 1) * sizeof(uint4));
@@ -618,6 +623,7 @@ void align_resident(kslam_ctx *c, bool stop_after_join, uint64_t *n_raw_out, Pai
                                                     (int)kpasses.size(), c->sortws, s, c->ev[2], c->ev[3],
                                                     &tm.n_scatter_launches);
     c->sortws.ev_sc0 = nullptr; c->sortws.ev_sc1 = nullptr;
+    c->sortws.first_digits_ready = false;
     HIPCHK(hipEventRecord(c->ev[4], s));
     // ---- a-5: join ----
     const uint64_t n_tiles = (nk + JOIN_TILE - 1) / JOIN_TILE;

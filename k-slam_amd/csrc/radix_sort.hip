@@ -96,10 +96,19 @@ __global__ __launch_bounds__(256) void k_chunk_scan(uint32_t *__restrict__ tile_
   const uint32_t d = threadIdx.x;
   const uint32_t t0 = blockIdx.x * CHUNK_TILES, t1 = min(t0 + CHUNK_TILES, n_tiles);
   uint32_t acc = 0;
-  for (uint32_t t = t0; t < t1; t++) {
-    const uint32_t v = tile_hist[(uint64_t)t * 256 + d];
-    tile_hist[(uint64_t)t * 256 + d] = acc;
-    acc += v;
+  // 32 loads in flight per thread: a load-add-store loop over the 64 tiles was a chain of 64 round trips (23 us per
+  // launch, twelve launches per batch: a fifth of the sort phase's time went into this small kernel)
+  constexpr uint32_t U = 32;
+  for (uint32_t t = t0; t < t1; t += U) {
+    uint32_t v[U];
+#pragma unroll
+    for (uint32_t k = 0; k < U; k++) v[k] = t + k < t1 ? tile_hist[(uint64_t)(t + k) * 256 + d] : 0u;
+#pragma unroll
+    for (uint32_t k = 0; k < U; k++)
+      if (t + k < t1) {
+        tile_hist[(uint64_t)(t + k) * 256 + d] = acc;
+        acc += v[k];
+      }
   }
   chunk_tot[(uint64_t)blockIdx.x * 256 + d] = acc;
 }
@@ -307,7 +316,7 @@ void sort_impl(void *a, void *b, uint32_t n, const PassList &pl, SortWorkspace &
   if (ev0) HIPCHK(hipEventRecord(ev0, s));
   for (int p = 0; p < pl.n; p++) {
     if (SETUP) hipLaunchKernelGGL(k_tile_hist_setup<RW>, dim3(tiles), dim3(RS_BLOCK), 0, s, (const T *)src, n, pl.p[p], tile_hist);
-    else if (digits && p > 0) hipLaunchKernelGGL(k_tile_hist_bytes, dim3(tiles), dim3(256), 0, s, (const uint8_t *)digits, n, tile_hist);
+    else if (digits && (p > 0 || ws.first_digits_ready)) hipLaunchKernelGGL(k_tile_hist_bytes, dim3(tiles), dim3(256), 0, s, (const uint8_t *)digits, n, tile_hist);
     else hipLaunchKernelGGL(k_tile_hist<RW>, dim3(tiles), dim3(RS_BLOCK), 0, s, (const T *)src, n, pl.p[p], tile_hist);
     hipLaunchKernelGGL(k_chunk_scan, dim3(chunks), dim3(256), 0, s, tile_hist, tiles, chunk_tot);
     hipLaunchKernelGGL(k_col_scan, dim3(256), dim3(256), 0, s, chunk_tot, chunks, digit_tot);

@@ -340,6 +340,8 @@ def main():
     ap.add_argument("--strains", type=int, default=5)
     ap.add_argument("--genome-len", type=int, default=4_000_000)
     ap.add_argument("--viral", type=int, default=-1, help="viral genomes appended to the database (default: 10000 for config 2, else 0)")
+    ap.add_argument("--repeats", action="store_true",
+                    help="repeat-rich database: an rRNA-like 1.5 kb segment x5 in every genome, an insertion element in a third of them")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=300000)
     ap.add_argument("--cpu-genomes", type=int, default=25)
@@ -412,7 +414,7 @@ def main():
     gen = torch.Generator(device=dev)
     gen.manual_seed(1)                      # database: same on every rank (replicated index)
     t0 = time.time()
-    db, offs = make_database(dev, gen, args.species, args.strains, args.genome_len, n_viral=n_viral)
+    db, offs = make_database(dev, gen, args.species, args.strains, args.genome_len, n_viral=n_viral, repeats=args.repeats)
     n_entries = len(offs) - 1
     if strong:
         # this rank's pairs [pair_lo, pair_hi) of the one batch, local layout [R1 of them | R2 of them]
@@ -715,7 +717,8 @@ def main():
                 sw_valu = None
         db_desc = "%d-genome (%d species x %d strains x %.1f Mb%s = %.2f Gb) synthetic %s db" % (
             n_entries, args.species, args.strains, args.genome_len / 1e6, " + %d viral genomes of 5-200 kb" % n_viral if n_viral else "",
-            float(offs[-1]) / 1e9, "bacterial + viral" if n_viral else "bacterial")
+            float(offs[-1]) / 1e9, ("bacterial + viral" if n_viral else "bacterial") +
+            (" REPEAT-RICH (rRNA-like 1.5 kb segment x5 per genome, 1.3 kb insertion element x2 in every third species)" if args.repeats else ""))
         roofline = {
             "bound": "hbm", "kernel": "k_scatter<4> (the scatter launch of one radix pass of the read k-mer sort; the sort only sees "
                                       "the k-mers the genome filter lets through)",

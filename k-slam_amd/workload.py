@@ -35,6 +35,11 @@ def _revcomp_rows(x):
     return lut[x.flip(1).long()]
 
 
+def _revcomp_codes(c):
+    """reverse complement of a code tensor (A0 C1 G2 T3 as in _ACGT: complement = 3 - code)"""
+    return (3 - c).flip(0)
+
+
 def viral_lengths(dev, gen, n_viral, min_len=5_000, max_len=200_000):
     """lengths of the "+viral" entries of BASELINE configs[2] ("add 10 k genomes of 5-200 kb"):
     log-uniform between the two bounds, as virus genome sizes are -- many small ones, few large ones"""
@@ -43,17 +48,50 @@ def viral_lengths(dev, gen, n_viral, min_len=5_000, max_len=200_000):
     return ln.cpu().numpy().astype(np.int64)
 
 
-def make_database(dev, gen, n_species, n_strains, length, n_viral=0):
+RRNA_LEN, RRNA_COPIES, IS_LEN, IS_COPIES = 1500, 5, 1300, 2
+
+
+def make_database(dev, gen, n_species, n_strains, length, n_viral=0, repeats=False):
     """Species x strains database as ONE device byte tensor + host offsets.
     Strains derive from the species root by 1-3 % substitutions + sparse 1-10 bp indels.
     n_viral > 0 (configs[2]): that many unrelated i.i.d. genomes of 5-200 kb appended AFTER the bacterial entries
-    (the random draws of the bacterial part are the same with and without them)."""
+    (the random draws of the bacterial part are the same with and without them).
+    repeats: what real bacterial sets carry and i.i.d. genomes do not -- sequence shared by hundreds of entries.  Every
+    species root gets RRNA_COPIES copies of ONE 1.5 kb "rRNA operon" (the species' own variant: 3 % substitutions
+    against the universal segment, so that, as with real 16S / 23S genes, conserved 32-mers are shared across species and
+    others are not), and every third species IS_COPIES copies of one identical 1.3 kb insertion element; the strains then
+    diverge from the root as usual.  A read from such a copy meets thousands of genome k-mers: the regime of the join's
+    long pile-ups (nG x nR cross product, src/Overlap.h:163-197), of (read, entry) segments with several copies in the
+    dedupe, and of read pairs with hundreds of alignment pairs.  Its own generator (seeded from `gen`'s seed + 7919), so
+    that the rest of the database is bit for bit the one without repeats."""
     acgt = _ACGT.to(dev)
+    rgen = None
+    if repeats:
+        rgen = torch.Generator(device=dev)
+        rgen.manual_seed(gen.initial_seed() + 7919)
+        rrna = torch.randint(0, 4, (RRNA_LEN,), generator=rgen, device=dev, dtype=torch.uint8)
+        ins_el = torch.randint(0, 4, (IS_LEN,), generator=rgen, device=dev, dtype=torch.uint8)
     cap = int(n_species * n_strains * length * 1.01) + 1024 + n_viral * 200_000
     db = torch.empty(cap, dtype=torch.uint8, device=dev)
     offs = [0]
-    for _ in range(n_species):
+    for sp in range(n_species):
         root_codes = torch.randint(0, 4, (length,), generator=gen, device=dev, dtype=torch.uint8)
+        if repeats and length > 40 * RRNA_LEN:
+            mm = torch.rand(RRNA_LEN, generator=rgen, device=dev) < 0.03
+            sh = torch.randint(1, 4, (RRNA_LEN,), generator=rgen, device=dev, dtype=torch.uint8)
+            variant = torch.where(mm, (rrna + sh) % 4, rrna)
+            root_codes = root_codes.clone()
+            # copies at seeded, non-overlapping places: one per tenth of the genome
+            slots = torch.randperm(10, generator=rgen, device=dev)[:RRNA_COPIES + IS_COPIES].tolist()
+            jit = torch.rand(RRNA_COPIES + IS_COPIES, generator=rgen, device=dev).tolist()
+            for k, (slot, u) in enumerate(zip(slots, jit)):
+                seg = variant if k < RRNA_COPIES else ins_el
+                if k >= RRNA_COPIES and sp % 3 != 0:
+                    continue
+                at = slot * (length // 10) + int(u * (length // 10 - seg.numel() - 1))
+                if (k + sp) % 2:        # either strand
+                    seg = _revcomp_codes(seg)
+                root_codes[at:at + seg.numel()] = seg
         for st in range(n_strains):
             codes = root_codes
             if st > 0:

@@ -132,3 +132,76 @@ def test_run_to_run_identity_at_scale(big):
     ctx.copy_results_device(ov2.data_ptr(), cg2.data_ptr())
     assert ov2.numel() == ov.numel() and torch.equal(ov, ov2)
     assert torch.equal(cg, cg2[:n_cig * 4].view(torch.int32))
+
+
+def test_repeat_rich_database_truth_and_oracle_parity(kslam, oracle):
+    """The same 5 Gb database with what real bacterial sets carry: an rRNA-like 1.5 kb segment in five copies per genome
+    (species variants sharing their conserved 32-mers) and an insertion element in every third species
+    (k-slam_amd/workload.py).  Reads from such a copy meet thousands of genome k-mers: k_join_fill's long pile-ups and its
+    > 4096-overlap workgroups, (read, entry) segments with several copies in k_dedupe_flags, the rerun of the join when its
+    output outgrows the buffer sized from the filter's survivors -- none of which the i.i.d. database reaches.  The
+    reference emits the full nG x nR cross product there (src/Overlap.h:163-197; removeLowQualityOverlaps is commented
+    out, :292), so must this.  Checks: planted truth on every read; and oracle parity, row by row and CIGAR op by CIGAR op,
+    of every row that pairs a sampled read -- the reads of three species plus the 1 500 reads with the most hits in the
+    batch, wherever they come from -- with an entry of those species (join, dedupe and SW are independent per (read,
+    entry): no closure of the sample is needed for the rows)."""
+    import torch
+    W = importlib.import_module("kslam_amd.workload")
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1)
+    db, offs = W.make_database(dev, gen, SPECIES, STRAINS, GENOME_LEN, repeats=True)
+    ctx = kslam.Context()
+    ctx.set_index_device(len(offs) - 1, db.data_ptr(), offs)
+    gen.manual_seed(2)
+    n_pairs = 1_000_000
+    reads, truth = W.make_reads(dev, gen, db, offs, n_pairs, read_len=150, with_truth=True)
+    torch.cuda.synchronize()
+    ctx.load_reads_device(2 * n_pairs, reads.data_ptr(), np.arange(2 * n_pairs + 1, dtype=np.uint64) * np.uint64(150))
+    n_out, n_cig = ctx.align_resident()
+    tm = ctx.timings()
+    ov_d = torch.empty(n_out * 48, dtype=torch.uint8, device=dev)
+    cg_d = torch.empty(max(n_cig, 1) * 4, dtype=torch.uint8, device=dev)
+    ctx.copy_results_device(ov_d.data_ptr(), cg_d.data_ptr())
+    res = W.check_against_truth(ov_d, cg_d[:n_cig * 4].view(torch.int32), truth, 150)
+    print(res, {k: round(v, 2) if isinstance(v, float) else v for k, v in tm.items()})
+    assert res["ok"] and res["planted_expected"] > 1_600_000, res
+    ov = np.frombuffer(ov_d.cpu().numpy().tobytes(), dtype=kslam.OVERLAP_DT)
+    cg = cg_d[:n_cig * 4].cpu().numpy().view(np.uint32)
+    per_read = np.bincount(ov["read"], minlength=2 * n_pairs)
+    assert tm["n_overlaps"] > 12_000_000 and per_read.max() > 1000         # the repeat regime is really there
+    species = [0, SPECIES // 2, SPECIES - 1]
+    entries = np.array(sorted(s * STRAINS + k for s in species for k in range(STRAINS)))
+    t_entry = truth["entry"].cpu().numpy()
+    hot = np.argsort(-per_read, kind="stable")[:1500]
+    from_sub = np.nonzero(np.isin(t_entry, entries))[0][:4000]
+    sample = np.unique(np.concatenate([hot, from_sub]))
+    rd = reads[torch.from_numpy(sample).to(dev)].cpu().numpy()
+    sub_reads = [rd[i].tobytes() for i in range(len(sample))]
+    sub_entries = [db[int(offs[e]):int(offs[e + 1])].cpu().numpy().tobytes() for e in entries]
+    exp, ecig, _ = oracle.align_to_database(sub_reads, sub_entries)
+    local = np.full(2 * n_pairs, -1, dtype=np.int64)
+    local[sample] = np.arange(len(sample))
+    eloc = np.full(len(offs) - 1, -1, dtype=np.int64)
+    eloc[entries] = np.arange(len(entries))
+    rows = ov[(local[ov["read"]] >= 0) & (eloc[ov["entry"]] >= 0)]
+    assert len(rows) == len(exp) and len(rows) > 30_000, (len(rows), len(exp))
+    assert (local[rows["read"]] == exp["read"]).all() and (eloc[rows["entry"]] == exp["entry"]).all()
+    for f in ("rel", "revcomp", "score", "ref_begin", "ref_end", "query_begin", "query_end", "cigar_len"):
+        bad = np.nonzero(rows[f] != exp[f])[0]
+        assert len(bad) == 0, "%s differs at %s" % (f, bad[:5])
+    ln = rows["cigar_len"].astype(np.int64)
+    inner = np.arange(int(ln.sum())) - np.repeat(np.cumsum(ln) - ln, ln)
+    assert np.array_equal(cg[np.repeat(rows["cigar_off"].astype(np.int64), ln) + inner],
+                          ecig[np.repeat(exp["cigar_off"].astype(np.int64), ln) + inner])
+    # several copies of one (read, entry): the dedupe's "|delta rel| < 3 against the last kept" over long segments
+    key = rows["read"].astype(np.int64) * 4096 + rows["entry"]
+    _, counts = np.unique(key, return_counts=True)
+    assert counts.max() >= 5
+    # run to run
+    n2, c2 = ctx.align_resident()
+    ov2 = torch.empty(n2 * 48, dtype=torch.uint8, device=dev)
+    cg2 = torch.empty(max(c2, 1) * 4, dtype=torch.uint8, device=dev)
+    ctx.copy_results_device(ov2.data_ptr(), cg2.data_ptr())
+    assert n2 == n_out and torch.equal(ov_d, ov2) and torch.equal(cg_d[:n_cig * 4], cg2[:c2 * 4])
+    ctx.close()

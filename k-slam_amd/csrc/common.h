@@ -271,7 +271,8 @@ struct SwWork {
 };
 // *n_full_out: candidates that needed the full-matrix kernel (the rest ran in a proven band)
 void sw_scores(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, uint32_t max_read_len,
-               uint32_t *d_band0, SwWork &W, uint64_t *n_full_out, const Tuning &tune, hipStream_t s);
+               uint32_t *d_band0, SwWork &W, uint64_t *n_full_out, const Tuning &tune, hipStream_t s,
+               bool long_reads = false);   // long_reads: the chunk's reads exceed the packed kernels (sw.hip: k_sw_long)
 
 // Stable 8-way partition of the element numbers 0..n-1 by d_bins[i] (bins >= 8 are left out):
 // d_lists[k] receives bin k's numbers in order, d_counts[k] its size (sw.hip).

@@ -47,6 +47,10 @@ struct kslam_ctx {
   bool have_reads = false;
   uint64_t n_reads = 0;
   uint32_t max_read_len = 0;
+  // reads the packed SW / extraction kernels cannot hold (more than short_cap bases) are aligned in chunks of their own,
+  // by the plain kernels (sw.hip: k_sw_long): class_runs = the read numbers at which the class (short / long) changes
+  uint32_t short_cap = 511, max_short_len = 0;
+  std::vector<uint64_t> class_runs;
   std::vector<uint64_t> h_roff;  // [n_reads + 1]
   std::vector<uint64_t> h_kpre, h_spre;   // [n_reads + 1] k-mers / extraction segments of the reads before i (chunk planning)
   DevBuf r_bases, r_off, r_len, r_codes;
@@ -464,14 +468,26 @@ void finish_load_reads(kslam_ctx *c) {
     c->h_kpre[i + 1] = c->h_kpre[i] + k;
     c->h_spre[i + 1] = c->h_spre[i] + (k + SEG_KMERS - 1) / SEG_KMERS;
   }
-  if (mx > 511)
-    throw StatusError{KSLAM_ERR_UNSUPPORTED, "reads longer than 511 bases are not supported yet (read " +
-                                                 std::to_string(mx_at) + " of the batch has " + std::to_string(mx) + ")"};
-  // 13-bit score field of the packed DP values; and the (score | position, H) pairs of the running best go
-  // through v_max_f64, where a score of 8188 or more would read as a NaN bit pattern
-  if ((uint64_t)c->prm.match * mx > 8187)
-    throw StatusError{KSLAM_ERR_UNSUPPORTED, "match * read length must stay below 8188 (score field of the SW kernels); read " +
-                                                 std::to_string(mx_at) + " has " + std::to_string(mx) + " bases"};
+  // 13-bit score field of the packed DP values (and v_max_f64 reading 8188 and above as NaN patterns), 9-bit row / column
+  // fields of the origin key: reads beyond either go through the plain kernels, in chunks of their own
+  c->short_cap = (uint32_t)std::min<uint64_t>(511, 8187 / std::max<uint64_t>(1, (uint64_t)c->prm.match + 2 * c->prm.gap_extend));
+  if (mx > 9000)
+    throw StatusError{KSLAM_ERR_UNSUPPORTED, "reads longer than 9000 bases are not supported (read " + std::to_string(mx_at) +
+                                                 " of the batch has " + std::to_string(mx) + ")"};
+  c->class_runs.clear();
+  c->max_short_len = 0;
+  if (mx > c->short_cap) {
+    bool prev_long = false;
+    for (uint64_t i = 0; i < n; i++) {
+      const uint64_t len = c->h_roff[i + 1] - c->h_roff[i];
+      const bool is_long = len > c->short_cap;
+      if (!is_long) c->max_short_len = std::max<uint32_t>(c->max_short_len, (uint32_t)len);
+      if (i && is_long != prev_long) c->class_runs.push_back(i);
+      prev_long = is_long;
+    }
+  } else {
+    c->max_short_len = (uint32_t)mx;
+  }
   c->max_read_len = (uint32_t)mx;
   c->r_off.ensure((n + 1) * sizeof(uint64_t));
   HIPCHK(hipMemcpyAsync(c->r_off.p, c->h_roff.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s));
@@ -566,7 +582,7 @@ void align_resident(kslam_ctx *c, bool stop_after_join, uint64_t *n_raw_out, Pai
   // the lanes' order (PairingHook): every chunk up to its SW stage first, then the pairing on the whole batch, then
   // the CIGAR stage chunk by chunk for the rows the pairs refer to
   const bool lazy = hook && !stop_after_join && sp.report_cigar && !(hook->paired && (c->n_reads < 2 || (c->n_reads & 1)));
-  struct Deferred { uint64_t first, m; };
+  struct Deferred { uint64_t first, m; uint32_t lmax; bool long_chunk; };
   std::vector<Deferred> deferred;
   while (r0 < n) {
     // ---- chunk [r0, r1) ----
@@ -575,6 +591,23 @@ void align_resident(kslam_ctx *c, bool stop_after_join, uint64_t *n_raw_out, Pai
     const uint64_t *kp = c->h_kpre.data();
     uint64_t r1 = (uint64_t)(std::upper_bound(kp + r0 + 1, kp + hi + 1, kp[r0] + max_chunk_kmers) - kp) - 1;
     r1 = std::max(r1, r0 + 1);
+    // a chunk holds reads of one class: short (the packed kernels) or long (the plain ones)
+    const bool long_chunk = c->h_roff[r0 + 1] - c->h_roff[r0] > c->short_cap;
+    if (!c->class_runs.empty()) {
+      auto nx = std::upper_bound(c->class_runs.begin(), c->class_runs.end(), r0);
+      if (nx != c->class_runs.end()) r1 = std::min<uint64_t>(r1, *nx);
+    }
+    uint32_t lmax_chunk = c->max_short_len;
+    if (long_chunk) {
+      lmax_chunk = 0;
+      for (uint64_t i = r0; i < r1; i++) lmax_chunk = std::max<uint32_t>(lmax_chunk, (uint32_t)(c->h_roff[i + 1] - c->h_roff[i]));
+    }
+    Tuning tune_chunk = c->tune;
+    if (long_chunk) {   // every CIGAR of such a chunk on the literal one-lane kernel (the others are sized by template)
+      tune_chunk.cigar_sys_mask = 0;
+      tune_chunk.cigar_reg = false;
+      tune_chunk.cigar_dirs_lds = false;
+    }
     const uint64_t nk_all = kp[r1] - kp[r0], nsegs = c->h_spre[r1] - c->h_spre[r0];
     if (nk_all >= (1ull << 32)) throw StatusError{KSLAM_ERR_UNSUPPORTED, "a single read chunk exceeds 2^32 k-mers"};
     const uint64_t nr = r1 - r0;
@@ -587,7 +620,8 @@ void align_resident(kslam_ctx *c, bool stop_after_join, uint64_t *n_raw_out, Pai
     // ---- a-3: read k-mer extraction ----
     HIPCHK(hipEventRecord(c->ev[0], s));
     uint64_t nk = nk_all;
-    if (c->filter_bits && nk_all) {
+    const bool use_filter = c->filter_bits && !long_chunk;   // (k_extract_filter packs a read into 36 words)
+    if (use_filter && nk_all) {
       // only the k-mers the genome filter lets through are written; buffer sized from the last chunk,
       // rerun once with the exact size if it was too small
       c->totals.ensure(8 * sizeof(uint64_t));
@@ -636,7 +670,7 @@ void align_resident(kslam_ctx *c, bool stop_after_join, uint64_t *n_raw_out, Pai
     if (nk) {
       // single-pass join into a buffer sized from the last batch; rerun once if it was too small
       const uint64_t have_cap = c->ovk_a.cap / sizeof(uint64_t);
-      const uint64_t guess = (c->filter_bits ? 4 * nk : nk / 6) + 1024;
+      const uint64_t guess = (use_filter ? 4 * nk : nk / 6) + 1024;
       uint64_t cap = have_cap > guess ? have_cap - 1 : guess;   // never grows a big-enough buffer
       for (int attempt = 0; attempt < 2; attempt++) {
         c->ovk_a.ensure((cap + 1) * sizeof(uint64_t));
@@ -683,18 +717,18 @@ void align_resident(kslam_ctx *c, bool stop_after_join, uint64_t *n_raw_out, Pai
         cigar_prepare(c->cig, m, s);
       }
       uint64_t n_full = 0;
-      sw_scores(cand, m, in, sp, c->max_read_len, band0, c->sww, &n_full, c->tune, s);
+      sw_scores(cand, m, in, sp, lmax_chunk, band0, c->sww, &n_full, c->tune, s, long_chunk);
       if (c->tune.debug) fprintf(stderr, "[kslam] SW: %llu candidates, %llu needed the full-matrix kernel\n", (unsigned long long)m, (unsigned long long)n_full);
       HIPCHK(hipEventRecord(c->ev[6], s));
       if (lazy) {
-        deferred.push_back(Deferred{c->n_res, m});
+        deferred.push_back(Deferred{c->n_res, m, lmax_chunk, long_chunk});
       } else {
         // ---- a-13: cigar ----
         uint32_t tb_err = 0;
-        cigar_traceback(cand, m, in, sp, c->max_read_len, band0, c->cig, &ncig, &tb_err, c->tune, s);
+        cigar_traceback(cand, m, in, sp, lmax_chunk, band0, c->cig, &ncig, &tb_err, tune_chunk, s);
         tb_err_total += tb_err;
         ensure_keep(c->res_cig, (c->n_cig + ncig + 1) * sizeof(uint32_t), c->n_cig * sizeof(uint32_t), s);
-        cigar_finalize(cand, m, in, c->max_read_len, c->cig, band0, c->res_cig.as<uint32_t>(), c->n_cig, c->cells.as<uint64_t>(), s);
+        cigar_finalize(cand, m, in, lmax_chunk, c->cig, band0, c->res_cig.as<uint32_t>(), c->n_cig, c->cells.as<uint64_t>(), s);
       }
     } else {
       HIPCHK(hipEventRecord(c->ev[6], s));
@@ -733,10 +767,12 @@ void align_resident(kslam_ctx *c, bool stop_after_join, uint64_t *n_raw_out, Pai
       uint64_t ncig = 0;
       uint32_t tb_err = 0;
       cigar_prepare(c->cig, d.m, s);
-      cigar_traceback(cand, d.m, in, sp, c->max_read_len, band0, c->cig, &ncig, &tb_err, c->tune, s);
+      Tuning tune_d = c->tune;
+      if (d.long_chunk) { tune_d.cigar_sys_mask = 0; tune_d.cigar_reg = false; tune_d.cigar_dirs_lds = false; }
+      cigar_traceback(cand, d.m, in, sp, d.lmax, band0, c->cig, &ncig, &tb_err, tune_d, s);
       tb_err_total += tb_err;
       ensure_keep(c->res_cig, (c->n_cig + ncig + 1) * sizeof(uint32_t), c->n_cig * sizeof(uint32_t), s);
-      cigar_finalize(cand, d.m, in, c->max_read_len, c->cig, band0, c->res_cig.as<uint32_t>(), c->n_cig, c->cells.as<uint64_t>(), s);
+      cigar_finalize(cand, d.m, in, d.lmax, c->cig, band0, c->res_cig.as<uint32_t>(), c->n_cig, c->cells.as<uint64_t>(), s);
       c->n_cig += ncig;
     }
     HIPCHK(hipEventRecord(c->ev[7], s));

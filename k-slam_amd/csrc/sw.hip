@@ -832,6 +832,98 @@ __global__ __launch_bounds__(256) void k_encode(const uint4 *__restrict__ src, u
 }
 }  // namespace
 
+
+// ---- reads beyond the packed kernels' reach (more than 511 bases, or match x length beyond the 13-bit score field) ----
+// ssw_align (src/ssw.c:841-951) takes any length; merged read pairs and the odd long read are real inputs.  This kernel is
+// the reference's two passes stated plainly: one wavefront per candidate, 32-bit scores, the matrix swept by
+// anti-diagonals with H / E / F of the last two anti-diagonals in LDS (indexed by read row, updated in place from the
+// highest row down, so that a row's upper neighbours are still the previous anti-diagonal's).  Forward pass
+// (:870-877): highest score, then smallest end column, then smallest end row (:316-342); reverse pass (:906-923) over
+// the two prefixes read backwards: the first column, then the smallest row, at which the score is reached again.
+// Slow (a 2 000-base read: ~1 ms of one wavefront per candidate) and exact; only the chunks of a batch that hold such reads
+// come here (kslam_api.hip splits a batch into runs of short and long reads).
+struct LongBest {
+  long long key;   // score << 40 | (0xFFFFF - column) << 20 | (0xFFFFF - row): one signed maximum is the reference's rule
+};
+__device__ inline long long long_pass(const uint8_t *sq, const uint8_t *sw, int32_t L, int32_t W, bool rev, int32_t q_last,
+                                      int32_t w_last, const SwParams &p, int32_t *A2, int32_t *A1, int32_t *E, int32_t *F,
+                                      int32_t lane) {
+  // rev: row i reads sq[q_last - i], column j reads sw[w_last - j] (the reverse pass over the prefixes)
+  constexpr int32_t NEG = -(1 << 29);
+  for (int32_t i = lane; i <= L; i += 64) { A2[i] = 0; A1[i] = 0; E[i] = NEG; F[i] = NEG; }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  long long best = 0;
+  const int32_t gO = p.gap_open, gE = p.gap_extend;
+  // arrays are indexed by row + 1 (slot 0 = the row above the matrix: H = 0, F = NEG)
+  for (int32_t k = 0; k <= L + W - 2; k++) {
+    const int32_t lo = max(0, k - (W - 1)), hi = min(L - 1, k);       // rows of this anti-diagonal
+    // from the highest rows down: a chunk's upper neighbour row belongs to the chunk processed after it
+    for (int32_t top = hi; top >= lo; top -= 64) {
+      const int32_t i = top - lane;
+      const bool live = i >= lo;
+      int32_t h = 0, e = NEG, f = NEG;
+      if (live) {
+        const int32_t j = k - i;
+        const uint32_t qc = sq[rev ? q_last - i : i], wc = sw[rev ? w_last - j : j];
+        const int32_t sc = (qc > 3u || wc > 3u) ? 0 : (qc == wc ? p.match : -p.mismatch);
+        const int32_t hd = (i > 0 && j > 0) ? A2[i] : 0;             // H(i - 1, j - 1): anti-diagonal k - 2, row i - 1
+        const int32_t hl = j > 0 ? A1[i + 1] : 0, el = j > 0 ? E[i + 1] : NEG;   // (i, j - 1): k - 1, row i
+        const int32_t hu = i > 0 ? A1[i] : 0, fu = i > 0 ? F[i] : NEG;           // (i - 1, j): k - 1, row i - 1
+        e = max(el - gE, hl - gO);
+        f = max(fu - gE, hu - gO);
+        h = max(max(hd + sc, 0), max(e, f));
+        const long long key = ((long long)h << 40) | ((long long)(0xFFFFF - j) << 20) | (long long)(0xFFFFF - i);
+        best = h > 0 && key > best ? key : best;
+      }
+      __builtin_amdgcn_wave_barrier();      // every lane has read its neighbours of the previous anti-diagonals
+      if (live) { A2[i + 1] = h; E[i + 1] = e; F[i + 1] = f; }   // A2 becomes this anti-diagonal's H row
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    int32_t *t = A2; A2 = A1; A1 = t;       // k - 1 becomes k - 2, the rows just written are k - 1
+  }
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) {
+    const long long o = __shfl_xor(best, m, 64);
+    best = o > best ? o : best;
+  }
+  return best;
+}
+
+__global__ __launch_bounds__(64) void k_sw_long(kslam_overlap *__restrict__ ov, uint64_t n, SwInputs in, SwParams p,
+                                                uint32_t *__restrict__ band0, uint32_t lcap) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t long_lds[];
+  const int32_t lane = threadIdx.x;
+  const uint64_t ci = blockIdx.x;
+  if (ci >= n) return;
+  const uint32_t rows = lcap + 2;
+  int32_t *A2 = reinterpret_cast<int32_t *>(long_lds), *A1 = A2 + rows, *E = A1 + rows, *F = E + rows;
+  uint8_t *sq = reinterpret_cast<uint8_t *>(F + rows), *sw = sq + ((lcap + 16) & ~15u);
+  int32_t L = 0, W = 0;
+  stage_candidate<64>(ov[ci], in, lane, sq, sw, &L, &W);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  PassResult f{0, 0, 0, 0, 0};
+  if (L > 0 && W > 0) {
+    // A2 / A1 swap inside the pass: which array ends as which does not matter, both are re-initialised by the next pass
+    const long long fw = long_pass(sq, sw, L, W, false, 0, 0, p, A2, A1, E, F, lane);
+    if (fw > 0) {
+      f.score = (int32_t)(fw >> 40);
+      f.end_col = 0xFFFFF - (int32_t)((fw >> 20) & 0xFFFFF);
+      f.end_row = 0xFFFFF - (int32_t)(fw & 0xFFFFF);
+      const long long bw = long_pass(sq, sw, f.end_row + 1, f.end_col + 1, true, f.end_row, f.end_col, p, A2, A1, E, F, lane);
+      // the reverse pass reaches the forward score (the same alignment read backwards); its first column / smallest row
+      f.beg_col = f.end_col - (0xFFFFF - (int32_t)((bw >> 20) & 0xFFFFF));
+      f.beg_row = f.end_row - (0xFFFFF - (int32_t)(bw & 0xFFFFF));
+    }
+  }
+  sw_epilogue<64, 1>(ov, ci, true, lane, L, f, sq, sw, p, band0);
+}
+
 void encode_bases(const uint8_t *d_src, uint8_t *d_dst, uint64_t n, hipStream_t s) {
   const uint64_t n16 = (n + 15) / 16;   // both arrays carry 64 bytes of slack
   if (n16) hipLaunchKernelGGL(k_encode, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, s,
@@ -840,10 +932,24 @@ void encode_bases(const uint8_t *d_src, uint8_t *d_dst, uint64_t n, hipStream_t 
 }
 
 void sw_scores(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, uint32_t max_read_len,
-               uint32_t *d_band0, SwWork &W, uint64_t *n_full_out, const Tuning &tune, hipStream_t s) {
+               uint32_t *d_band0, SwWork &W, uint64_t *n_full_out, const Tuning &tune, hipStream_t s, bool long_reads) {
   if (n_full_out) *n_full_out = 0;
   if (n == 0) return;
-  if (max_read_len > 511) throw StatusError{KSLAM_ERR_UNSUPPORTED, "reads longer than 511 bases are not supported yet"};
+  if (long_reads) {   // a chunk of reads the packed kernels cannot hold: every candidate through the plain two-pass kernel
+    const uint32_t lcap = (max_read_len + 15u) & ~15u;
+    const size_t lds = (size_t)4 * (lcap + 2) * sizeof(int32_t) + 2 * ((size_t)lcap + 16);
+    if (lds > 160 * 1024) throw StatusError{KSLAM_ERR_UNSUPPORTED, "reads longer than 9000 bases are not supported"};
+    if (lds > 64 * 1024)
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sw_long), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    for (uint64_t lo = 0; lo < n; lo += 1u << 30) {
+      const uint64_t m = std::min<uint64_t>(n - lo, 1u << 30);
+      hipLaunchKernelGGL(k_sw_long, dim3((unsigned)m), dim3(64), lds, s, d_ov + lo, m, in, p, d_band0 + lo, lcap);
+    }
+    HIPCHK(hipGetLastError());
+    if (n_full_out) *n_full_out = n;
+    return;
+  }
+  if (max_read_len > 511) throw StatusError{KSLAM_ERR_UNSUPPORTED, "a chunk of short reads holds a read longer than 511 bases"};
   if (n >= (1ull << 32)) throw StatusError{KSLAM_ERR_UNSUPPORTED, ">= 2^32 candidates in one chunk"};
   const int lm = max_read_len <= 160 ? 0 : (max_read_len <= 256 ? 1 : 2);
   const uint32_t *full_list = nullptr;

@@ -684,3 +684,45 @@ def test_scores_at_the_top_of_the_score_field(kslam, oracle, synth, scoring):
     _compare_alignments(got, gcig, exp, ecig)
     with pytest.raises(kslam.KslamError, match="8188"):
         kslam.align_to_database(rb, gb, match=17, mismatch=10, gap_open=12, gap_extend=4)
+
+
+@pytest.mark.parametrize("long_len,layout", [(600, "mixed"), (2000, "mixed"), (700, "all"), (4000, "few")])
+def test_reads_beyond_the_packed_kernels(kslam, oracle, synth, long_len, layout):
+    """ssw_align takes any read length (src/ssw.c:841-951); the packed SW kernels hold 511 bases.  A batch with longer
+    reads -- merged pairs, the odd long read -- is split into runs of short and long reads; the long runs go through
+    the unfiltered extraction, k_sw_long (plain two-pass SW, one wavefront per candidate) and the literal banded_sw kernel.
+    Rows and CIGARs must be the oracle's for every read of the batch, short and long, in batch order."""
+    rng = np.random.default_rng(4000 + long_len)
+    genomes = synth.make_genomes(301, 3, 3, 40000, strain_sub=0.02, strain_indel=0.002)
+    short, _ = synth.make_paired_reads(302, genomes, 400, read_len=150, sub_rate=0.015, indel_rate=0.003, edge_frac=0.05)
+    def long_read(L):
+        g = genomes[int(rng.integers(0, len(genomes)))]
+        at = int(rng.integers(-200, len(g) - L + 200))             # some hang over either end of the genome
+        lo, hi = max(at, 0), min(at + L, len(g))
+        frag = np.concatenate([synth.random_bases(rng, lo - at), g[lo:hi], synth.random_bases(rng, at + L - hi)])
+        if rng.random() < 0.5:
+            frag = synth.revcomp(frag)
+        r = synth.mutate(rng, frag, 0.02, 0.004)
+        return r[:L + int(rng.integers(-30, 1))]
+    n_long = {"mixed": 40, "all": 60, "few": 6}[layout]
+    longs = [long_read(long_len) for _ in range(n_long)]
+    if layout == "all":
+        reads = longs
+    else:
+        reads = list(short)
+        for k, r in enumerate(longs):                              # scattered: runs of one, and one run of several
+            reads.insert(int(rng.integers(0, len(reads))) if k % 4 else 17, r)
+    rb, gb = synth.to_bytes(reads), synth.to_bytes(genomes)
+    assert max(len(r) for r in rb) > 511
+    c = kslam.Context()
+    c.set_index(gb)
+    got, gcig = c.align_batch(rb)
+    again, acig = c.align_batch(rb)
+    c.close()
+    exp, ecig, _ = oracle.align_to_database(rb, gb)
+    _compare_alignments(got, gcig, exp, ecig)
+    assert got.tobytes() == again.tobytes() and gcig.tobytes() == acig.tobytes()
+    lens = np.array([len(r) for r in rb])
+    on_long = lens[got["read"]] > 511
+    assert on_long.sum() > 2 * n_long and (got["cigar_len"][on_long] > 1).sum() > n_long // 2
+    assert got["score"][on_long].max() > 1022                      # beyond what 511 bases can score

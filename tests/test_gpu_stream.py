@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _make_case(synth, tmp_path, n_pairs, eol, seed=2031):
+def _make_case(synth, tmp_path, n_pairs, eol, seed=2031, long_reads=False):
     from test_gpu_end_to_end import _taxdb_text, _fastq_text
     D = importlib.import_module("kslam_amd.db")
     n_species, n_strains = 4, 3
@@ -25,6 +25,15 @@ def _make_case(synth, tmp_path, n_pairs, eol, seed=2031):
                                  shared_segment=2500)
     reads, _ = synth.make_paired_reads(seed % 1000 + 1, genomes, n_pairs, read_len=120, frag_mean=320, frag_sd=40,
                                        sub_rate=0.015, indel_rate=0.003, n_rate=0.001, edge_frac=0.04, unmapped_frac=0.05)
+    if long_reads:      # every 40th pair is a pair of 600-base reads (merged-pair-like): beyond the packed kernels' 511
+        for k in range(0, n_pairs, 40):
+            g = genomes[int(rng.integers(0, len(genomes)))]
+            at = int(rng.integers(0, len(g) - 1300))
+            frag = g[at:at + 1200]
+            if rng.random() < 0.5:
+                frag = synth.revcomp(frag)
+            reads[k] = synth.mutate(rng, frag[:600], 0.015, 0.003)[:600]
+            reads[n_pairs + k] = synth.mutate(rng, synth.revcomp(frag)[:600], 0.015, 0.003)[:600]
     gb = synth.to_bytes(genomes)
     entries = [{"bases": g, "taxonomyID": 1000 + i if i != 5 else 0, "genbankID": 7000 + i,
                 "locusTag": b"NC_%06d.1" % i, "isPlasmid": i % 4 == 3,
@@ -48,8 +57,10 @@ def _make_case(synth, tmp_path, n_pairs, eol, seed=2031):
     return dbdir, taxdb, rb, quals, ids, r1, r2
 
 
-@pytest.mark.parametrize("eol,pseudo,per_batch", [(b"\n", True, 700), (b"\r\n", False, 1000), (b"\n", True, 2500), (b"\n", True, 833)])
-def test_stream_of_batches_equals_the_reference_loop(kslam, oracle, synth, tmp_path, eol, pseudo, per_batch):
+@pytest.mark.parametrize("eol,pseudo,per_batch,long_reads", [(b"\n", True, 700, False), (b"\r\n", False, 1000, False),
+                                                             (b"\n", True, 2500, False), (b"\n", True, 833, False),
+                                                             (b"\n", True, 900, True)])
+def test_stream_of_batches_equals_the_reference_loop(kslam, oracle, synth, tmp_path, eol, pseudo, per_batch, long_reads):
     import ctypes as C
     D = importlib.import_module("kslam_amd.db")
     T = importlib.import_module("kslam_amd.tail")
@@ -57,7 +68,7 @@ def test_stream_of_batches_equals_the_reference_loop(kslam, oracle, synth, tmp_p
     S = importlib.import_module("kslam_amd.stream")
     dbo = importlib.import_module("oracle.db_oracle")
     n_pairs = 2500
-    dbdir, taxdb, rb, quals, ids, r1, r2 = _make_case(synth, tmp_path, n_pairs, eol)
+    dbdir, taxdb, rb, quals, ids, r1, r2 = _make_case(synth, tmp_path, n_pairs, eol, long_reads=long_reads)
 
     # ---- product: files -> files ----
     db = D.Database.load(dbdir / "database")

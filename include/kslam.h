@@ -279,6 +279,29 @@ typedef struct {
 } kslam_pair_stats;
 kslam_status kslam_pair_screen(kslam_ctx *ctx, int paired, uint32_t score_threshold,
                                double score_fraction, uint32_t stages, kslam_pair_stats *stats);
+/* The same in pieces, for a batch whose read pairs are SHARDED over several GPUs (bench.py --gpus N).
+ * Everything in the tail is per read pair except two steps, and those take gathered inputs:
+ *   kslam_pair_phase_a   score screen + pairing on this shard's result; *d_inserts / *n_inserts = the shard's non-zero
+ *                        insert sizes (device memory, valid until the next pairing call on this context)
+ *   <the host gathers every shard's insert sizes into one device array, in any order>
+ *   kslam_pair_phase_b   getMaxAllowedInsertSize of ALL of them (the limit is a statistic of the whole batch,
+ *                        src/PairedOverlap.h:314-360: every shard computes the same value), then the two screens on this
+ *                        shard's read pairs; *d_pairs / *n_pairs = its dense alignment-pair records (device memory)
+ *   <the host gathers every shard's records in RANK order = read-pair order, the reference's bucket iteration order>
+ *   kslam_pseudo_merged  pseudoAssembly (per entry across all read pairs of the batch, :480-582) on the gathered records
+ *                        -- modified in place --, the new scores of records [own_base, own_base + n_pairs) copied back
+ *                        into this shard's, second score screen on them.  stages_done lacks PSEUDO_ASM when an entry
+ *                        is too large for the device path (the caller then runs that stage on the host, merged).
+ * Afterwards kslam_take_pairs / kslam_row_details_of_pairs as after kslam_pair_screen.  The shards' read pairs,
+ * alignment pairs and SAM text concatenated in rank order are those of one context that aligned the whole batch
+ * (tests/test_gpu_multi.py). */
+kslam_status kslam_pair_phase_a(kslam_ctx *ctx, int paired, uint32_t score_threshold, const int32_t **d_inserts,
+                                uint64_t *n_inserts);
+kslam_status kslam_pair_phase_b(kslam_ctx *ctx, const int32_t *d_all_inserts, uint64_t n_all, double score_fraction,
+                                uint32_t stages, kslam_pair_stats *stats, const kslam_paired_overlap **d_pairs,
+                                uint64_t *n_pairs);
+kslam_status kslam_pseudo_merged(kslam_ctx *ctx, void *d_all_pairs, uint64_t n_all, uint64_t own_base,
+                                 double score_fraction, kslam_pair_stats *stats);
 /* the same on overlap records and read lengths handed in from the host (stage-level parity tests) */
 kslam_status kslam_pair_screen_overlaps(kslam_ctx *ctx, const kslam_overlap *overlaps, uint64_t n_overlaps,
                                         const uint32_t *read_lens, uint64_t n_reads, int paired,

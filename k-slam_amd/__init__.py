@@ -44,7 +44,7 @@ EXPORTS = ["kslam_abi_version", "kslam_version", "kslam_check_std_sort", "kslam_
            "kslam_align_batch_async", "kslam_wait_batch", "kslam_load_qualities", "kslam_load_qualities_device",
            "kslam_row_details", "kslam_take_row_details", "kslam_free_pinned", "kslam_submit_batch",
            "kslam_submit_batch_columns", "kslam_submit_batch_fastq", "kslam_submit_batch_fastq_text", "kslam_collect_batch", "kslam_release_batch", "kslam_host_alloc",
-           "kslam_host_free", "kslam_pair_screen", "kslam_pair_screen_overlaps", "kslam_take_pairs", "kslam_set_pairing", "kslam_debug_wave_sort", "kslam_row_details_of_pairs",
+           "kslam_host_free", "kslam_pair_screen", "kslam_pair_phase_a", "kslam_pair_phase_b", "kslam_pseudo_merged", "kslam_pair_screen_overlaps", "kslam_take_pairs", "kslam_set_pairing", "kslam_debug_wave_sort", "kslam_row_details_of_pairs",
            "kslam_load_reads", "kslam_load_reads_device", "kslam_align_resident",
            "kslam_fetch_results", "kslam_take_results", "kslam_copy_results_device", "kslam_get_timings",
            "kslam_extract_kmers", "kslam_sort_kmers", "kslam_find_overlaps", "kslam_free",
@@ -145,6 +145,9 @@ def lib():
         L.kslam_free_pinned.argtypes = [vp, vp]
         L.kslam_submit_batch.argtypes = [vp, u64, vp, vp, vp, C.POINTER(u64)]
         L.kslam_pair_screen.argtypes = [vp, C.c_int, u32, C.c_double, u32, C.POINTER(PairStats)]
+        L.kslam_pair_phase_a.argtypes = [vp, C.c_int, u32, C.POINTER(vp), C.POINTER(u64)]
+        L.kslam_pair_phase_b.argtypes = [vp, vp, u64, C.c_double, u32, C.POINTER(PairStats), C.POINTER(vp), C.POINTER(u64)]
+        L.kslam_pseudo_merged.argtypes = [vp, vp, u64, u64, C.c_double, C.POINTER(PairStats)]
         L.kslam_pair_screen_overlaps.argtypes = [vp, vp, u64, vp, u64, C.c_int, u32, C.c_double, u32, C.POINTER(PairStats)]
         L.kslam_take_pairs.argtypes = [vp, C.POINTER(vp), C.POINTER(u64), C.POINTER(vp), C.POINTER(u64)]
         L.kslam_set_pairing.argtypes = [vp, C.c_int, u32, C.c_double, u32]
@@ -372,6 +375,24 @@ class Context:
         """kslam_pair_screen on the last results -> stats dict"""
         st = PairStats()
         self._chk(self._L.kslam_pair_screen(self._h, int(paired), score_threshold, score_fraction, stages, C.byref(st)))
+        return st.as_dict()
+
+    def pair_phase_a(self, paired=True, score_threshold=0):
+        """kslam_pair_phase_a -> (device address of this shard's insert sizes (int32), their number)"""
+        p, n = C.c_void_p(), C.c_uint64()
+        self._chk(self._L.kslam_pair_phase_a(self._h, int(paired), score_threshold, C.byref(p), C.byref(n)))
+        return p.value or 0, int(n.value)
+
+    def pair_phase_b(self, d_all_inserts, n_all, score_fraction=0.95, stages=3):
+        """kslam_pair_phase_b -> (stats dict, device address of this shard's dense alignment-pair records, their number)"""
+        st, p, n = PairStats(), C.c_void_p(), C.c_uint64()
+        self._chk(self._L.kslam_pair_phase_b(self._h, d_all_inserts, n_all, score_fraction, stages, C.byref(st), C.byref(p), C.byref(n)))
+        return st.as_dict(), p.value or 0, int(n.value)
+
+    def pseudo_merged(self, d_all_pairs, n_all, own_base, score_fraction=0.95):
+        """kslam_pseudo_merged -> stats dict"""
+        st = PairStats()
+        self._chk(self._L.kslam_pseudo_merged(self._h, d_all_pairs, n_all, own_base, score_fraction, C.byref(st)))
         return st.as_dict()
 
     def pair_screen_overlaps(self, overlaps, read_lens, paired=True, score_threshold=0, score_fraction=0.95, stages=3):

@@ -314,6 +314,8 @@ void row_details(const kslam_overlap *d_ov, uint64_t n, const uint32_t *d_pool, 
 // --------------------------------------------------------------- pairs.hip
 struct PairWork {
   DevBuf recs, count, base, inserts, flags, gpos, rpos, scan_tmp, totals, groups, dense, sort_a, sort_b, idx, picked, row_list;
+  uint64_t units = 0, mid = 0;   // between pair_phase_a and pair_phase_b: read pairs (or reads) of the batch, its R1 block
+  int paired = 0;
 };
 struct PairResult {
   uint64_t n_overlaps_screened, n_paired_initial, n_insert_sizes, n_read_pairs, n_pairs;
@@ -343,6 +345,20 @@ struct FastqIndexResult {
 // an empty stream).  Semantics of host/fastq.cpp's index (kslam_fastq_index_pair).
 void fastq_index_device(const uint8_t *d_text, uint64_t len1, uint64_t len2, const uint8_t *h_last1, const uint8_t *h_last2,
                         uint64_t max_pairs, bool at_eof, FastqWork &W, FastqIndexResult *res, hipStream_t s);
+
+// pair_and_screen in its two halves, for read pairs sharded over several GPUs: phase A pairs per
+// read pair and collects the shard's insert sizes (W.inserts, res->n_insert_sizes); the caller gathers every shard's
+// insert sizes and computes the batch's limit from all of them (insert_limit_device: the statistic is batch-global,
+// src/PairedOverlap.h:314-360); phase B screens with that limit.  pseudo_merged: pseudo-assembly on the dense
+// alignment-pair records of ALL shards (d_all, gathered in rank order; this shard's are [own_base, own_base + n_pairs)),
+// new scores copied back into this shard's records, second screen on them.
+void pair_phase_a(const kslam_overlap *d_ov, uint64_t n, const uint32_t *d_read_len, uint64_t n_reads, int paired,
+                  uint32_t score_threshold, PairWork &W, PairResult *res, hipStream_t s);
+uint32_t insert_limit_device(const int32_t *d_ins, uint64_t n, PairWork &W, SortWorkspace &sortws, hipStream_t s);
+void pair_phase_b(const kslam_overlap *d_ov, uint32_t limit, double score_fraction, int do_insert, int do_score, PairWork &W,
+                  PairResult *res, hipStream_t s);
+bool pseudo_merged(PairWork &W, PairResult *res, void *d_all, uint64_t n_all, uint64_t own_base, double score_fraction,
+                   SortWorkspace &sortws, hipStream_t s);
 
 // the overlap records the result's alignment pairs refer to, ascending, as a list in W (valid until the next pairs call)
 void referenced_rows(PairWork &W, const PairResult *res, uint64_t n_rows, const uint32_t **d_list, uint64_t *n_list, hipStream_t s);

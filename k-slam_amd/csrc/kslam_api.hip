@@ -85,6 +85,7 @@ struct kslam_ctx {
   PairResult pres{};
   bool have_pairs = false;        // c->pres holds pairs (of res_ov, or of records handed in)
   bool pairs_of_result = false;   // ... and they index the rows of the current res_ov (kslam_pair_screen / the lane hook)
+  bool phase_a_done = false;      // kslam_pair_phase_a ran on the current result, kslam_pair_phase_b has not yet
   DevBuf pr_ov, pr_len;          // kslam_pair_screen_overlaps: the records and read lengths handed in
   struct { int paired = 1; uint32_t thr = 0; double fraction = 0.95; uint32_t stages = 0; } pairing;   // for the lanes
 
@@ -534,6 +535,7 @@ void align_resident(kslam_ctx *c, bool stop_after_join, uint64_t *n_raw_out, Pai
   c->have_details = false;
   c->have_pairs = false;
   c->pairs_of_result = false;
+  c->phase_a_done = false;
   c->cells.ensure(sizeof(uint64_t));
   HIPCHK(hipMemsetAsync(c->cells.p, 0, sizeof(uint64_t), s));
   uint64_t n_raw_total = 0;
@@ -1483,6 +1485,55 @@ kslam_status kslam_pair_screen(kslam_ctx *c, int paired, uint32_t score_threshol
     if (stages & 4u) pseudo_and_rescreen(c->pw, &c->pres, score_fraction, c->sortws, c->stream);
     HIPCHK(hipStreamSynchronize(c->stream));
     c->have_pairs = c->pairs_of_result = true;
+    fill_pair_stats(c->pres, stats);
+  });
+}
+
+// ---- the same in pieces, for read pairs sharded over several GPUs: the two batch-global steps take gathered inputs ----
+kslam_status kslam_pair_phase_a(kslam_ctx *c, int paired, uint32_t score_threshold, const int32_t **d_inserts, uint64_t *n_inserts) {
+  return guarded(c, [&] {
+    require_std_sort_parity();
+    if (!d_inserts || !n_inserts) throw StatusError{KSLAM_ERR_ARG, "null argument"};
+    if (!c->have_reads) throw StatusError{KSLAM_ERR_STATE, "no batch loaded"};
+    if (paired && (c->n_reads < 2 || (c->n_reads & 1)))
+      throw StatusError{KSLAM_ERR_ARG, "paired data needs an even, non-zero number of reads ([R1 block | R2 block])"};
+    if (c->n_res >= (1ull << 30)) throw StatusError{KSLAM_ERR_UNSUPPORTED, "2^30 or more overlaps in one batch"};
+    c->have_pairs = c->pairs_of_result = false;
+    pair_phase_a(c->res_ov.as<kslam_overlap>(), c->n_res, c->r_len.as<uint32_t>(), c->n_reads, paired ? 1 : 0, score_threshold, c->pw,
+                 &c->pres, c->stream);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->phase_a_done = true;
+    *d_inserts = c->pw.inserts.as<int32_t>();
+    *n_inserts = c->pres.n_insert_sizes;
+  });
+}
+
+kslam_status kslam_pair_phase_b(kslam_ctx *c, const int32_t *d_all_inserts, uint64_t n_all, double score_fraction, uint32_t stages,
+                                kslam_pair_stats *stats, const kslam_paired_overlap **d_pairs, uint64_t *n_pairs) {
+  return guarded(c, [&] {
+    if (!c->phase_a_done) throw StatusError{KSLAM_ERR_STATE, "kslam_pair_phase_a has not been called for this result"};
+    if (n_all && !d_all_inserts) throw StatusError{KSLAM_ERR_ARG, "null insert sizes"};
+    c->phase_a_done = false;
+    uint32_t limit = 0xFFFFFFFFu;
+    const bool do_insert = (stages & 1u) != 0;
+    if (do_insert && c->pw.paired) limit = insert_limit_device(d_all_inserts, n_all, c->pw, c->sortws, c->stream);
+    pair_phase_b(c->res_ov.as<kslam_overlap>(), limit, score_fraction, do_insert, (stages & 2u) != 0, c->pw, &c->pres, c->stream);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->pres.n_insert_sizes = n_all;
+    c->have_pairs = c->pairs_of_result = true;
+    fill_pair_stats(c->pres, stats);
+    if (d_pairs) *d_pairs = c->pres.d_pairs;
+    if (n_pairs) *n_pairs = c->pres.n_pairs;
+  });
+}
+
+kslam_status kslam_pseudo_merged(kslam_ctx *c, void *d_all_pairs, uint64_t n_all, uint64_t own_base, double score_fraction,
+                                 kslam_pair_stats *stats) {
+  return guarded(c, [&] {
+    if (!(c->have_pairs && c->pairs_of_result)) throw StatusError{KSLAM_ERR_STATE, "kslam_pair_phase_b has not been called for this result"};
+    if (n_all && !d_all_pairs) throw StatusError{KSLAM_ERR_ARG, "null records"};
+    pseudo_merged(c->pw, &c->pres, d_all_pairs, n_all, own_base, score_fraction, c->sortws, c->stream);
+    HIPCHK(hipStreamSynchronize(c->stream));
     fill_pair_stats(c->pres, stats);
   });
 }

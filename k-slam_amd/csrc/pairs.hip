@@ -538,25 +538,45 @@ void referenced_rows(PairWork &W, const PairResult *res, uint64_t n_rows, const 
   *n_list = cnt;
 }
 
+__global__ void k_spans_flat(const Rec *__restrict__ recs, uint64_t n, uint4 *__restrict__ out, uint32_t *__restrict__ max_entry) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t mx = 0;
+  if (i < n) {
+    const Rec r = recs[i];
+    out[i] = make_uint4(r.entry, (uint32_t)r.ref_start, (uint32_t)r.ref_end, (uint32_t)i);
+    mx = r.entry;
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
+  if ((threadIdx.x & 63) == 0 && mx) atomicMax(max_entry, mx);
+}
+__global__ void k_take_scores(const Rec *__restrict__ all, uint64_t base, uint64_t n, Rec *__restrict__ own) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) own[i].combined_score = all[base + i].combined_score;
+}
+
+
 // pseudo-assembly + second score screen on the result of pair_and_screen, in place.  Returns false, having
 // changed nothing, when an entry holds more spans than one workgroup's LDS takes (the host then runs the stage).
-bool pseudo_and_rescreen(PairWork &W, PairResult *res, double score_fraction, SortWorkspace &sortws, hipStream_t s) {
-  const uint64_t n = res->n_pairs, n_groups = res->n_read_pairs;
-  if (n == 0) { res->stages_done |= 4u; return true; }
-  if (n >= (1ull << 28)) return false;
-  Rec *recs = const_cast<Rec *>(res->d_pairs);
-  kslam_read_pair *groups = const_cast<kslam_read_pair *>(res->d_groups);
+// spans of `recs` (in record order, or group by group: the same order, the dense array is laid out by group) ->
+// stable bucket sort by entry -> one wavefront per entry: std::sort by start, chains, new scores into recs
+static bool pseudo_on_records(Rec *recs, uint64_t n, bool from_groups, const kslam_read_pair *groups, uint64_t n_groups,
+                              PairWork &W, SortWorkspace &sortws, hipStream_t s) {
   W.sort_a.ensure((n + 1) * sizeof(uint4));
   W.sort_b.ensure((n + 1) * sizeof(uint4));
   W.flags.ensure((n + 1) * sizeof(uint32_t));
   W.gpos.ensure((n + 1) * sizeof(uint32_t));
   W.count.ensure((n + 2) * sizeof(uint32_t));          // run starts
   W.scan_tmp.ensure(scan_tmp_bytes(n));
+  W.totals.ensure(16 * sizeof(uint64_t));
   uint64_t *tot = W.totals.as<uint64_t>();
   HIPCHK(hipMemsetAsync(tot + 12, 0, 2 * sizeof(uint64_t), s));
   uint32_t *d_max_entry = reinterpret_cast<uint32_t *>(tot + 12), *d_longest = reinterpret_cast<uint32_t *>(tot + 13);
-  hipLaunchKernelGGL(k_spans, dim3((unsigned)((n_groups + 255) / 256)), dim3(256), 0, s, recs, groups, n_groups,
-                     W.sort_a.as<uint4>(), d_max_entry);
+  if (from_groups)
+    hipLaunchKernelGGL(k_spans, dim3((unsigned)((n_groups + 255) / 256)), dim3(256), 0, s, recs, groups, n_groups,
+                       W.sort_a.as<uint4>(), d_max_entry);
+  else
+    hipLaunchKernelGGL(k_spans_flat, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, recs, n, W.sort_a.as<uint4>(), d_max_entry);
   uint32_t max_entry = 0;
   read_back(&max_entry, d_max_entry, sizeof max_entry, s);
   uint32_t bits = 1;
@@ -582,6 +602,17 @@ bool pseudo_and_rescreen(PairWork &W, PairResult *res, double score_fraction, So
                      W.count.as<uint32_t>(), n_runs, (uint32_t)n, recs);
   if (longest > PSEUDO_CAP)   // entries too big for LDS: the same wave algorithm on the spans where they lie
     hipLaunchKernelGGL(k_pseudo_entry<true>, dim3(n_runs), dim3(64), 0, s, work, W.count.as<uint32_t>(), n_runs, (uint32_t)n, recs);
+  HIPCHK(hipGetLastError());
+  return true;
+}
+
+bool pseudo_and_rescreen(PairWork &W, PairResult *res, double score_fraction, SortWorkspace &sortws, hipStream_t s) {
+  const uint64_t n = res->n_pairs, n_groups = res->n_read_pairs;
+  if (n == 0) { res->stages_done |= 4u; return true; }
+  if (n >= (1ull << 28)) return false;
+  Rec *recs = const_cast<Rec *>(res->d_pairs);
+  kslam_read_pair *groups = const_cast<kslam_read_pair *>(res->d_groups);
+  if (!pseudo_on_records(recs, n, true, groups, n_groups, W, sortws, s)) return false;
   hipLaunchKernelGGL(k_rescreen, dim3((unsigned)((n_groups + 255) / 256)), dim3(256), 0, s, recs, groups, n_groups, score_fraction);
   HIPCHK(hipGetLastError());
   res->stages_done |= 4u;
@@ -677,12 +708,14 @@ static uint32_t max_allowed_insert_device(int32_t *d_ins, uint64_t n, PairWork &
   return std::isnan(r) ? 0xFFFFFFFFu : (uint32_t)r;
 }
 
-void pair_and_screen(const kslam_overlap *d_ov, uint64_t n, const uint32_t *d_read_len, uint64_t n_reads, int paired,
-                     uint32_t score_threshold, double score_fraction, int do_insert, int do_score, PairWork &W,
-                     SortWorkspace &sortws, PairResult *res, hipStream_t s) {
+// Phase A of pair_and_screen: score screen + pairing per read pair (k_pair); leaves the alignment pairs in their
+// per-read-pair regions and the batch's non-zero insert sizes in W.inserts (res->n_insert_sizes of them).
+void pair_phase_a(const kslam_overlap *d_ov, uint64_t n, const uint32_t *d_read_len, uint64_t n_reads, int paired,
+                  uint32_t score_threshold, PairWork &W, PairResult *res, hipStream_t s) {
   memset(res, 0, sizeof *res);
   res->max_insert_size = 0xFFFFFFFFu;
   const uint64_t units = paired ? n_reads / 2 : n_reads, mid = n_reads / 2;
+  W.units = units; W.mid = mid; W.paired = paired;
   if (units == 0) return;
   W.recs.ensure((4 * n + 4) * sizeof(Rec));
   W.count.ensure((units + 1) * sizeof(uint32_t));
@@ -713,11 +746,25 @@ void pair_and_screen(const kslam_overlap *d_ov, uint64_t n, const uint32_t *d_re
   res->n_insert_sizes = h[0];
   res->n_overlaps_screened = h[1];
   res->n_paired_initial = h[2];
-  uint32_t limit = 0xFFFFFFFFu;
-  if (do_insert && paired) {
-    limit = max_allowed_insert_device(W.inserts.as<int32_t>(), h[0], W, sortws, s);
-    res->max_insert_size = limit;
-  }
+}
+
+// getMaxAllowedInsertSize (src/PairedOverlap.h:314-360) of any device array of insert sizes: a batch's own
+// (W.inserts), or the insert sizes of all shards of a batch gathered by the caller (the statistics are those of the
+// sorted values: where each value came from does not matter).  d_ins is used as scratch input only (not modified).
+uint32_t insert_limit_device(const int32_t *d_ins, uint64_t n, PairWork &W, SortWorkspace &sortws, hipStream_t s) {
+  return max_allowed_insert_device(const_cast<int32_t *>(d_ins), n, W, sortws, s);
+}
+
+// Phase B: the two per-read-pair screens with the given insert-size limit, then the dense groups / pairs arrays.
+void pair_phase_b(const kslam_overlap *d_ov, uint32_t limit, double score_fraction, int do_insert, int do_score, PairWork &W,
+                  PairResult *res, hipStream_t s) {
+  const uint64_t units = W.units, mid = W.mid;
+  const int paired = W.paired;
+  if (units == 0) return;
+  uint64_t *tot = W.totals.as<uint64_t>();
+  const unsigned nb = (unsigned)((units + 255) / 256);
+  if (do_insert && paired) res->max_insert_size = limit;
+  else limit = 0xFFFFFFFFu;
   hipLaunchKernelGGL(k_screen, dim3(nb), dim3(256), 0, s, d_ov, W.recs.as<Rec>(), W.base.as<uint64_t>(),
                      W.count.as<uint32_t>(), units, (do_insert && paired) ? 1 : 0, limit, do_score ? 1 : 0, score_fraction,
                      W.flags.as<uint32_t>());
@@ -737,6 +784,42 @@ void pair_and_screen(const kslam_overlap *d_ov, uint64_t n, const uint32_t *d_re
   res->d_groups = W.groups.as<kslam_read_pair>();
   res->d_pairs = W.dense.as<Rec>();
   res->stages_done = ((do_insert && paired) ? 1u : 0u) | (do_score ? 2u : 0u);
+}
+
+void pair_and_screen(const kslam_overlap *d_ov, uint64_t n, const uint32_t *d_read_len, uint64_t n_reads, int paired,
+                     uint32_t score_threshold, double score_fraction, int do_insert, int do_score, PairWork &W,
+                     SortWorkspace &sortws, PairResult *res, hipStream_t s) {
+  pair_phase_a(d_ov, n, d_read_len, n_reads, paired, score_threshold, W, res, s);
+  if (W.units == 0) return;
+  uint32_t limit = 0xFFFFFFFFu;
+  if (do_insert && paired) limit = max_allowed_insert_device(W.inserts.as<int32_t>(), res->n_insert_sizes, W, sortws, s);
+  pair_phase_b(d_ov, limit, score_fraction, do_insert, do_score, W, res, s);
+}
+
+// ---- pseudo-assembly over the alignment pairs of SEVERAL shards -------------------------------------------------------
+// pseudoAssembly works per entry across all read pairs of the batch (src/PairedOverlap.h:480-582).  When the read pairs
+// are sharded over GPUs, every shard's dense alignment-pair records are gathered (rank order = read-pair order, which
+// is the reference's bucket iteration order) into d_all[0 .. n_all); the stage then runs on that array exactly as
+// pseudo_and_rescreen runs it on one batch's -- spans in record order, stable bucket sort by entry, std::sort
+// permutation and chains per entry -- and leaves the new combined scores in d_all.  Returns false (nothing changed) when
+// an entry holds more spans than one wavefront should sort: the caller runs the stage on the host.
+bool pseudo_merged(PairWork &W, PairResult *res, void *d_all, uint64_t n_all, uint64_t own_base, double score_fraction,
+                   SortWorkspace &sortws, hipStream_t s) {
+  const uint64_t n_own = res->n_pairs, n_groups = res->n_read_pairs;
+  if (own_base + n_own > n_all) throw StatusError{KSLAM_ERR_ARG, "this shard's records lie outside the gathered array"};
+  if (n_all == 0) { res->stages_done |= 4u; return true; }
+  if (n_all >= (1ull << 28)) return false;
+  Rec *all = static_cast<Rec *>(d_all);
+  if (!pseudo_on_records(all, n_all, false, nullptr, 0, W, sortws, s)) return false;
+  if (n_own) {
+    Rec *own = const_cast<Rec *>(res->d_pairs);
+    hipLaunchKernelGGL(k_take_scores, dim3((unsigned)((n_own + 255) / 256)), dim3(256), 0, s, all, own_base, n_own, own);
+    hipLaunchKernelGGL(k_rescreen, dim3((unsigned)((n_groups + 255) / 256)), dim3(256), 0, s, own,
+                       const_cast<kslam_read_pair *>(res->d_groups), n_groups, score_fraction);
+  }
+  HIPCHK(hipGetLastError());
+  res->stages_done |= 4u;
+  return true;
 }
 
 }  // namespace kslam

@@ -191,3 +191,65 @@ def reassemble(parts, bounds, n_pairs, overlap_dtype):
     out = np.concatenate(r1_parts + r2_parts) if parts else np.zeros(0, dtype=overlap_dtype)
     pool = np.concatenate(pools) if pools else np.zeros(0, dtype=np.uint32)
     return out, pool
+
+
+# ---- the batch-global steps of the tail when read pairs are sharded (include/kslam.h: kslam_pair_phase_a / _b, kslam_pseudo_merged) ----
+
+class _DevView:
+    """n bytes of device memory at `ptr` as an object torch can wrap without copying (__cuda_array_interface__)"""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
+def device_bytes(ptr, nbytes, dev):
+    """a uint8 device tensor holding a COPY of nbytes at device address ptr"""
+    if nbytes == 0 or not ptr:
+        return torch.empty(0, dtype=torch.uint8, device=dev)
+    return torch.as_tensor(_DevView(ptr, nbytes), device=dev).clone()
+
+
+def all_gather_bytes(mine, dev, group=None):
+    """variable-length all-gather of uint8 device tensors -> (concatenation in rank order on `dev`, [bytes per rank]).
+    nccl: device tensors padded to the longest; gloo (tests: ranks sharing one GPU): staged through host memory."""
+    world = dist.get_world_size(group)
+    staged = dist.get_backend(group) == "gloo"
+    cdev = torch.device("cpu") if staged else dev
+    n = torch.tensor([mine.numel()], dtype=torch.int64, device=cdev)
+    counts = [torch.zeros(1, dtype=torch.int64, device=cdev) for _ in range(world)]
+    dist.all_gather(counts, n, group=group)
+    counts = [int(c.item()) for c in counts]
+    longest = max(counts)
+    if longest == 0:
+        return torch.empty(0, dtype=torch.uint8, device=dev), counts
+    pad = torch.zeros(longest, dtype=torch.uint8, device=cdev)
+    pad[:mine.numel()] = mine.to(cdev)
+    parts = [torch.empty(longest, dtype=torch.uint8, device=cdev) for _ in range(world)]
+    dist.all_gather(parts, pad, group=group)
+    out = torch.cat([p[:c] for p, c in zip(parts, counts)]).to(dev)
+    return out, counts
+
+
+def sharded_tail(ctx, dev, paired=True, score_threshold=0, score_fraction=0.95, pseudo_assembly=True, group=None):
+    """Pairing, insert-size screen, score screen [, pseudo-assembly + second screen] for THIS rank's read pairs of a batch
+    sharded over the ranks -- the reference's steps between alignToDatabase and the SAM writer (src/SLAM.h:210-233) -- with
+    the two batch-global steps fed from all ranks: the insert sizes (4 bytes per properly paired read pair) and the
+    alignment-pair records (32 bytes each) are all-gathered over RCCL.  Afterwards the context holds this rank's read pairs
+    / alignment pairs as after kslam_pair_screen.  Returns (stats dict, bytes this rank received in the two gathers)."""
+    rank = dist.get_rank(group)
+    d_ins, n_ins = ctx.pair_phase_a(paired, score_threshold)
+    mine = device_bytes(d_ins, n_ins * 4, dev)
+    torch.cuda.synchronize(dev)
+    all_ins, c1 = all_gather_bytes(mine, dev, group)
+    torch.cuda.synchronize(dev)
+    stats, d_pairs, n_pairs = ctx.pair_phase_b(all_ins.data_ptr() if all_ins.numel() else None, all_ins.numel() // 4, score_fraction, 3)
+    moved = sum(c1)
+    if pseudo_assembly:
+        recs = device_bytes(d_pairs, n_pairs * 32, dev)
+        torch.cuda.synchronize(dev)
+        all_recs, c2 = all_gather_bytes(recs, dev, group)
+        torch.cuda.synchronize(dev)
+        stats = ctx.pseudo_merged(all_recs.data_ptr() if all_recs.numel() else None, all_recs.numel() // 32, sum(c2[:rank]) // 32,
+                                  score_fraction)
+        moved += sum(c2)
+    return stats, moved

@@ -173,3 +173,83 @@ def test_strong_line_of_one_rank_through_the_self_launcher_equals_plain_strong()
         assert la["classified"][k] == lb["classified"][k], k
     assert la["hot_path"]["verified"]["merged_rows"] == lb["hot_path"]["verified"]["merged_rows"]
     assert "rccl" in lb and "rccl" not in la
+
+
+@pytest.mark.parametrize("bounds,pseudo", [([(0, 700), (700, 701), (701, 2500)], True), ([(0, 1250), (1250, 2500)], True),
+                                           ([(0, 900), (900, 1800), (1800, 2500)], False), ([(0, 2500)], True)])
+def test_sharded_tail_equals_one_context(kslam, synth, bounds, pseudo):
+    """The tail with the read pairs SHARDED (kslam_pair_phase_a / _b, kslam_pseudo_merged): every shard pairs and screens its
+    own read pairs; the insert-size limit is computed from all shards' insert sizes, pseudo-assembly from all shards'
+    alignment-pair records (what bench.py --gpus N moves over RCCL; here the shards are sibling contexts on one GPU and the
+    "gather" is a concatenation).  The shards' SAM text, concatenated in shard order, must be the text one context produces
+    for the whole batch -- pairing, limit, screens, chain scores, per-row NM / MD / log-probability and all."""
+    import torch
+    T = importlib.import_module("kslam_amd.tail")
+    kd = importlib.import_module("kslam_amd.dist")
+    n_pairs = 2500
+    rng = np.random.default_rng(99)
+    rb, gb = _data(synth, 720, n_pairs)
+    quals = [bytes(rng.integers(35, 74, len(b), dtype=np.uint8)) for b in rb]
+    ids = [b"q%05d" % i for i in range(n_pairs)]
+    dev = torch.device("cuda", 0)
+    I = T.Index(gb, taxonomy_ids=list(range(1, len(gb) + 1)))
+    P_write = T.TailParams.default(pseudo_assembly=False)
+
+    def sam_of(c, reads, q, names):
+        c.row_details(of_pairs=True)
+        ov, cg, rel1 = c.take_results()
+        det, md, rel2 = c.take_row_details(len(ov), copy=False)
+        rp, pr, rel3 = c.take_pairs(copy=False)
+        out = []
+        T.tail_finish_rows(P_write, T.Reads(reads, q, names), I, ov, cg, det, md, rp, pr, sink=out.append)
+        for r in (rel1, rel2, rel3):
+            r()
+        return b"".join(out), len(rp), len(pr)
+
+    # ---- one context, the whole batch ----
+    whole = kslam.Context()
+    whole.set_index(gb)
+    whole.load_reads(rb)
+    whole.load_qualities(quals)
+    whole.align_resident()
+    st = whole.pair_screen(paired=True, stages=7 if pseudo else 3)
+    assert not pseudo or st["stages_done"] & 4
+    exp, n_rp, n_pr = sam_of(whole, rb, quals, ids + ids)
+
+    # ---- the same batch in shards ----
+    shards = []
+    for lo, hi in bounds:
+        c = whole.sibling()
+        loc = kd.local_reads(rb, n_pairs, lo, hi)
+        c.load_reads(loc)
+        c.load_qualities(kd.local_reads(quals, n_pairs, lo, hi))
+        c.align_resident()
+        shards.append((c, loc, kd.local_reads(quals, n_pairs, lo, hi), ids[lo:hi] + ids[lo:hi]))
+    ins = [kd.device_bytes(*(lambda p, n: (p, n * 4))(*c.pair_phase_a(True, 0)), dev) for c, _, _, _ in shards]
+    all_ins = torch.cat(ins)
+    torch.cuda.synchronize()
+    recs, limits = [], []
+    for c, _, _, _ in shards:
+        stats, d_pairs, n = c.pair_phase_b(all_ins.data_ptr() if all_ins.numel() else None, all_ins.numel() // 4, 0.95, 3)
+        recs.append(kd.device_bytes(d_pairs, n * 32, dev))
+        limits.append(stats["max_insert_size"])
+    assert len(set(limits)) == 1 and limits[0] == st["max_insert_size"]
+    if pseudo:
+        torch.cuda.synchronize()
+        base = 0
+        for (c, _, _, _), mine in zip(shards, recs):
+            all_recs = torch.cat(recs)          # (a fresh copy per shard: the stage rewrites the gathered scores in place)
+            torch.cuda.synchronize()
+            s2 = c.pseudo_merged(all_recs.data_ptr() if all_recs.numel() else None, all_recs.numel() // 32, base, 0.95)
+            assert s2["stages_done"] & 4
+            base += mine.numel() // 32
+    got, g_rp, g_pr = b"", 0, 0
+    for c, loc, q, names in shards:
+        text, a, b = sam_of(c, loc, q, names)
+        got += text
+        g_rp += a
+        g_pr += b
+        c.close()
+    whole.close()
+    assert (g_rp, g_pr) == (n_rp, n_pr) and len(exp) > 200 * n_pairs
+    assert got == exp

@@ -663,10 +663,113 @@ def main():
                           "alignment_pairs_per_batch": tail_out["alignment_pairs"], "max_insert_size": tail_out["max_insert_size"],
                           "pseudo_assembly_on": tail_out["pseudo_on"],
                           "sam_file_bytes": os.path.getsize(sam_path), "per_read_file_bytes": os.path.getsize(pr_path)}
+            tail_ctx.close()
+
+        # ================= third clock: the tail SHARDED like the alignment =================
+        # every rank: align its pairs -> pairing on its own rows -> all-gather of the insert sizes (the limit is a statistic
+        # of the whole batch) -> screens -> all-gather of the alignment-pair records -> pseudo-assembly (per entry over all
+        # read pairs) -> per-row NM / MD / log-probability, SAM text and per-read LCA of ITS read pairs into ITS part files.
+        # No overlap rows travel; the part files concatenated in rank order are the SAM / _PerRead files.
+        n_local = n_reads // 2
+        qgen = torch.Generator(device=dev)
+        qgen.manual_seed(4242)                      # the whole batch's qualities as rank 0's tail context holds them
+        qual_all = torch.randint(33 + 20, 33 + 41, (2 * args.total_pairs * read_len + 64,), generator=qgen, device=dev, dtype=torch.uint8)
+        qual_loc = torch.cat([qual_all[pair_lo * read_len:pair_hi * read_len],
+                              qual_all[(args.total_pairs + pair_lo) * read_len:(args.total_pairs + pair_hi) * read_len],
+                              torch.zeros(64, dtype=torch.uint8, device=dev)]).contiguous()
+        del qual_all
+        torch.cuda.synchronize()
+        ctx.load_qualities_device(qual_loc.data_ptr())
+        rv_loc = ids_view(T, n_local, read_len, first_pair=pair_lo)
+        taxdb_s = X.TaxDB(tax_text)
+        part_sam = os.path.join(args.out_dir, "kslam_bench_%s_part%d.sam" % (os.environ.get("MASTER_PORT", "solo") if use_dist else str(os.getpid()), rank))
+        part_pr = part_sam + "_PerRead"
+        sh_ms = {"align": 0.0, "pairing_gathers_pseudo": 0.0, "row_details_download": 0.0, "host_sam_and_lca": 0.0}
+        sh_out = {"moved": 0}
+        sworker = [None]
+
+        def sh_host(ov, cg, det, md, rp, pr, pst, releases, fds):
+            t1 = time.perf_counter()
+            st = S.finish_rows_fd(P_write if pst["stages_done"] & 4 else P_host, rv_loc, index_view, ov, cg, det, md, rp, pr, fds[0])
+            ids, text = taxdb_s.classify(P_write, rv_loc, index_view, rp, pr, per_read=True)
+            os.write(fds[1], text)
+            for r in releases:
+                r()
+            sh_ms["host_sam_and_lca"] += time.perf_counter() - t1
+            sh_out.update(sam_bytes=int(st.sam_bytes), per_read_lines=int(len(ids)), pseudo_on="gpu" if pst["stages_done"] & 4 else "host",
+                          max_insert_size=int(pst["max_insert_size"]))
+
+        def sharded_steps(k):
+            sam_fd = os.open(part_sam, os.O_RDWR | os.O_CREAT | os.O_TRUNC, 0o600)
+            fds = (T.SamWriter(sam_fd), os.open(part_pr, os.O_RDWR | os.O_CREAT | os.O_TRUNC, 0o600))
+            for _ in range(k):
+                t1 = time.perf_counter()
+                ctx.align_resident()
+                t2 = time.perf_counter()
+                if use_dist:
+                    pst, moved = kdist.sharded_tail(ctx, dev, True, 0, 0.95, True)
+                    sh_out["moved"] = moved
+                else:
+                    pst = ctx.pair_screen(paired=True, stages=7)
+                t3 = time.perf_counter()
+                ctx.row_details(of_pairs=True)
+                ov, cg, rel1 = ctx.take_results()
+                det, md, rel2 = ctx.take_row_details(len(ov), copy=False)
+                rp, pr, rel3 = ctx.take_pairs(copy=False)
+                t4 = time.perf_counter()
+                sh_ms["align"] += t2 - t1
+                sh_ms["pairing_gathers_pseudo"] += t3 - t2
+                sh_ms["row_details_download"] += t4 - t3
+                if sworker[0] is not None:
+                    sworker[0].join()
+                sworker[0] = threading.Thread(target=sh_host, args=(ov, cg, det, md, rp, pr, pst, (rel1, rel2, rel3), fds))
+                sworker[0].start()
+            sworker[0].join()
+            sworker[0] = None
+            fds[0].close()
+            os.close(sam_fd)
+            os.close(fds[1])
+        sharded_steps(max(args.warmup, 1))
+        for k in sh_ms:
+            sh_ms[k] = 0.0
+        barrier()
+        t0 = time.perf_counter()
+        sharded_steps(args.steps)
+        barrier()
+        el3 = time.perf_counter() - t0
+        if use_dist:
+            te = torch.tensor([el3] + [sh_ms[k] for k in sorted(sh_ms)], dtype=torch.float64, device=cdev)
+            dist.all_reduce(te, op=dist.ReduceOp.MAX)
+            el3 = float(te[0])
+            sh_max = {k: float(v) for k, v in zip(sorted(sh_ms), te[1:].tolist())}
+        else:
+            sh_max = dict(sh_ms)
+        # one more batch through both forms, outside the clocks: the part files in rank order must BE rank 0's files
+        sharded_steps(1)
+        classified_steps(1)
+        barrier()
+        if rank == 0:
+            base = part_sam.rsplit("part0", 1)
+            parts_ok = True
+            for full, suffix in ((sam_path, ""), (pr_path, "_PerRead")):
+                got = b"".join(open(base[0] + "part%d" % r + base[1] + suffix, "rb").read() for r in range(world))
+                parts_ok = parts_ok and got == open(full, "rb").read()
+            classified["sharded"] = {
+                "elapsed": el3, "ms_per_step_max_over_ranks": {k: round(v / args.steps * 1e3, 2) for k, v in sh_max.items()},
+                "bytes_all_gathered_per_rank_per_step": int(sh_out["moved"]), "pseudo_assembly_on": sh_out["pseudo_on"],
+                "max_insert_size": sh_out["max_insert_size"],
+                "part_files_in_rank_order_equal_rank0_files": bool(parts_ok)}
             for pth in (sam_path, pr_path):
                 os.unlink(pth)
-            tail_ctx.close()
             taxdb.close()
+        if use_dist:
+            dist.barrier()
+        for pth in (part_sam, part_pr):
+            try:
+                os.unlink(pth)
+            except OSError:
+                pass
+        taxdb_s.close()
 
     # RCCL announces itself on stdout through C stdio ("Librccl path : ..."), buffered when piped and
     # otherwise flushed when each rank exits -- after rank 0's JSON.  Every rank pushes it out now,
@@ -773,17 +876,24 @@ def main():
                 "max_over_ranks": {k: round(v / Ksteps * 1e3, 3) for k, v in split_max.items()},
                 "rank0": {k: round(v / Ksteps * 1e3, 3) for k, v in split.items()}}
         if strong and classified is not None:
-            out["value"] = round(total_reads / classified["elapsed"], 1)
-            out["ms_per_step"] = round(classified["elapsed"] / Ksteps * 1e3, 3)
+            sh = classified.pop("sharded")
+            out["value"] = round(total_reads / sh["elapsed"], 1)
+            out["ms_per_step"] = round(sh["elapsed"] / Ksteps * 1e3, 3)
+            del sh["elapsed"]
+            classified["reads_per_s"] = round(total_reads / classified["elapsed"], 1)
+            classified["ms_per_step"] = round(classified["elapsed"] / Ksteps * 1e3, 3)
             del classified["elapsed"]
-            out["classified"] = classified
+            out["classified_sharded"] = sh
+            out["classified_rank0_tail"] = classified
+            out["verified_classified"] = bool(sh["part_files_in_rank_order_equal_rank0_files"])
             out["value_definition"] = (
-                "K steps, each: every rank aligns its read pairs of the one batch (resident in its HBM), the overlap records are "
-                "gathered to rank 0, rank 0 runs the batch-global steps on the merged batch (score screen, pairing, insert-size "
-                "statistics, screens, pseudo-assembly, per-row NM / MD / log-probability on its GPU; SAM text written to a file and "
-                "per-read LCA written to _PerRead on its host CPUs, overlapped with the next step's alignment); max over ranks.  "
-                "`hot_path.reads_per_s` stops the clock when rank 0 holds the merged records.  The tail is NOT sharded: it is the "
-                "Amdahl term of the strong-scaling curve (DESIGN.md section 5)")
+                "K steps of ONE batch of --total-pairs read pairs, sharded over the ranks and CLASSIFIED where they are: every "
+                "rank aligns its read pairs (resident in its HBM), pairs them, all-gathers the insert sizes (the limit is a "
+                "statistic of the whole batch) and the alignment-pair records (pseudo-assembly is per entry over all read pairs) "
+                "over RCCL, screens, and writes the SAM text and the per-read LCA of ITS read pairs into its part files (the "
+                "parts in rank order are the files: verified_classified); max over ranks.  classified_rank0_tail: the same "
+                "result with the overlap records gathered to rank 0 and the whole tail there (the Amdahl form); "
+                "hot_path.reads_per_s: clock stopped when rank 0 holds the merged overlap records")
         else:
             out["value_definition"] = "see e2e" if not args.no_e2e and not strong else "hot path only (--no-e2e): resident-input alignToDatabase"
         torch.cuda.empty_cache()       # what torch's allocator cached while generating the inputs goes back to the device

@@ -149,9 +149,12 @@ def test_bench_starts_its_own_ranks_when_no_launcher_did(world):
     assert line["rccl"]["world"] == world and line["rccl"]["ranks_seen"] == world and line["rccl"]["launched_by"] == "bench.py"
     assert line["rccl"]["bytes_gathered_per_step"] > 48 * v["overlaps"] and len(line["per_rank_align_ms"]) == world
     assert v["ok"] and v["merged_equals_single_context"] and v["planted_missing"] == 0
-    c = line["classified"]
+    c = line["classified_rank0_tail"]
     assert c["sam_file_bytes"] > 100 * 48000 and c["per_read_lines_per_batch"] > 0.9 * 48000 and c["pseudo_assembly_on"] == "gpu"
-    assert line["value"] <= line["hot_path"]["reads_per_s"] * 1.05      # the second clock includes the first one's work
+    # the tail sharded like the alignment: each rank's SAM / _PerRead part files, in rank order, ARE rank 0's files
+    sh = line["classified_sharded"]
+    assert line["verified_classified"] and sh["part_files_in_rank_order_equal_rank0_files"] and sh["pseudo_assembly_on"] == "gpu"
+    assert sh["bytes_all_gathered_per_rank_per_step"] > 30 * 48000 and sh["max_insert_size"] == c["max_insert_size"]
 
 
 def test_strong_line_of_one_rank_through_the_self_launcher_equals_plain_strong():
@@ -170,7 +173,8 @@ def test_strong_line_of_one_rank_through_the_self_launcher_equals_plain_strong()
     la = json.loads([x for x in a.stdout.strip().splitlines() if x.startswith("{")][-1])
     lb = json.loads([x for x in b.stdout.strip().splitlines() if x.startswith("{")][-1])
     for k in ("sam_file_bytes", "per_read_file_bytes", "alignment_pairs_per_batch", "max_insert_size"):
-        assert la["classified"][k] == lb["classified"][k], k
+        assert la["classified_rank0_tail"][k] == lb["classified_rank0_tail"][k], k
+    assert la["verified_classified"] and lb["verified_classified"]
     assert la["hot_path"]["verified"]["merged_rows"] == lb["hot_path"]["verified"]["merged_rows"]
     assert "rccl" in lb and "rccl" not in la
 

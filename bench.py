@@ -663,7 +663,6 @@ def main():
                           "alignment_pairs_per_batch": tail_out["alignment_pairs"], "max_insert_size": tail_out["max_insert_size"],
                           "pseudo_assembly_on": tail_out["pseudo_on"],
                           "sam_file_bytes": os.path.getsize(sam_path), "per_read_file_bytes": os.path.getsize(pr_path)}
-            tail_ctx.close()
 
         # ================= third clock: the tail SHARDED like the alignment =================
         # every rank: align its pairs -> pairing on its own rows -> all-gather of the insert sizes (the limit is a statistic
@@ -761,6 +760,7 @@ def main():
                 "part_files_in_rank_order_equal_rank0_files": bool(parts_ok)}
             for pth in (sam_path, pr_path):
                 os.unlink(pth)
+            tail_ctx.close()
             taxdb.close()
         if use_dist:
             dist.barrier()

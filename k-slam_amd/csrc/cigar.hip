@@ -191,6 +191,34 @@ __device__ inline int32_t banded_attempt_reg(Seq &m, uint32_t *DW, uint32_t NL, 
     const uint32_t srow = score_row(m.q(i), p, 0);   // the read base against the five window codes, 6 bits each
     int32_t hleft = 0, f = 0;
     const uint32_t i6 = (uint32_t)i / 6u, sh = 5u * ((uint32_t)i - 6u * i6);
+    // Interior rows -- every slot of the register band is a real cell: band as wide as the template's, row far enough
+    // from both ends of the window -- need none of the "does this cell exist" masking, and they are nearly all rows
+    // (all but the first and last BW of ~150).  The choice is made per WAVE (no lane still running may be at an edge
+    // row), so the lanes never split over the two bodies.
+    const bool interior = bw == BW && i >= BW && i + BW < refLen;
+    if (__ballot(!interior) == 0) {
+#pragma unroll
+      for (int x = 0; x < NX; x++) {
+        const int32_t sc = __builtin_amdgcn_sbfe(srow, R[x], 6);
+        int32_t t1 = H[x + 1] - gO, t2 = E[x + 1] - gE;                       // ssw.c:668-671
+        const int32_t ev = max(t1, t2);
+        const uint32_t de = (uint32_t)(t2 - t1) >> 31;
+        t1 = hleft - gO;                                                     // ssw.c:673-676
+        t2 = f - gE;
+        const int32_t fv = max(t1, t2);
+        const uint32_t df = (uint32_t)(t2 - t1) >> 31;
+        const int32_t e1 = max(ev, 0), f1 = max(fv, 0);                      // ssw.c:678-682
+        const int32_t m1 = max(e1, f1), dg = H[x] + sc;
+        const int32_t hv = max(m1, dg);
+        const uint32_t dh = m1 <= dg ? 1u : (e1 > f1 ? 2u + de : 4u + df);   // ssw.c:686-690
+        H[x] = hv;
+        E[x] = ev;
+        hleft = hv;
+        f = fv;
+        mx = max(mx, hv);
+        dwx[x] |= (de | (df << 1) | (dh << 2)) << sh;
+      }
+    } else {
 #pragma unroll
     for (int x = 0; x < NX; x++) {
       const int32_t j = i + x - bw;
@@ -214,6 +242,7 @@ __device__ inline int32_t banded_attempt_reg(Seq &m, uint32_t *DW, uint32_t NL, 
       f = fv & vm;
       mx = max(mx, H[x]);                                                  // ssw.c:684 (hv >= 0)
       dwx[x] |= ((de | (df << 1) | (dh << 2)) & (uint32_t)vm) << sh;
+    }
     }
     if (sh == 25u || i == readLen - 1) {
 #pragma unroll

@@ -790,7 +790,9 @@ def main():
         launches = max(tm["n_scatter_launches"], 1)
         launch_ms = tm["ms_sort_scatter"] / launches
         n_sorted = tm["n_kmers_kept"]      # the records the per-batch sort moves: read k-mers the genome filter let through
-        per_launch_bytes = (n_sorted / max(tm["n_chunks"], 1)) * 16 * 2   # one scatter launch: 16 B in + 16 B out per record
+        # one scatter launch: 16 B in + 16 B out per record, + 1 B per record in every launch but the last of a sort (the
+        # next pass's digit byte, radix_sort.hip): averaged over the sort's launches
+        per_launch_bytes = (n_sorted / max(tm["n_chunks"], 1)) * (32 + (passes - 1) / max(passes, 1))
         achieved = per_launch_bytes / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -824,7 +826,8 @@ def main():
             (" REPEAT-RICH (rRNA-like 1.5 kb segment x5 per genome, 1.3 kb insertion element x2 in every third species)" if args.repeats else ""))
         roofline = {
             "bound": "hbm", "kernel": "k_scatter<4> (the scatter launch of one radix pass of the read k-mer sort; the sort only sees "
-                                      "the k-mers the genome filter lets through)",
+                                      "the k-mers the genome filter lets through; since round 3 a launch also stores the next pass's "
+                                      "digit byte per record, which made the launch 9 % slower and the sort phase 24 % faster)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "launch_ms": round(launch_ms, 4), "bytes_per_launch": int(per_launch_bytes),

@@ -129,10 +129,12 @@ def classify_stream(ctx, index, r1_ptr, len1, r2_ptr, len2, pairs_per_batch, par
                 if per_read_fd >= 0 and text:
                     os.write(per_read_fd, text)
                 out["per_read_bytes"] += len(text)
+                t2 = time.perf_counter()
                 if report is not None:
                     report.add_batch(reads, index, rp, pr, ids)
                 out["tax_ids"].append(ids)
                 rec["ms_classify"] = round((time.perf_counter() - t1) * 1e3, 2)
+                rec["ms_report"] = round((time.perf_counter() - t2) * 1e3, 2)
             if on_batch is not None:
                 on_batch(rec, ov, cg, rp, pr, reads)
             out["batches"].append(rec)

@@ -24,14 +24,16 @@ def run(sink, tax, n=10):
     fd = -1
     if sink: fd = os.open(sink, os.O_RDWR | os.O_CREAT | os.O_TRUNC, 0o600)
     t0 = time.perf_counter()
+    rep = X.Report() if tax == 2 else None
     res = S.classify_stream(ctx, I, files.h[0].ptr, files.len, files.h[1].ptr, files.len, 1_000_000, P, taxdb=taxdb if tax else None,
-                            sam_fd=fd, windows=[wins[i % 4] for i in range(n)])
+                            report=rep, sam_fd=fd, windows=[wins[i % 4] for i in range(n)])
+    if rep is not None: rep.close()
     dt = time.perf_counter() - t0
     if fd >= 0: os.close(fd)
     if sink and os.path.isfile(sink) and not sink.startswith("/dev/null"): os.unlink(sink)
     b = res["batches"]
     return {"sink": sink, "tax": tax, "ms_per_batch": round(dt / n * 1e3, 1), "ms_sam": round(sum(x["ms_sam"] for x in b) / n, 1),
-            "ms_classify": round(sum(x.get("ms_classify", 0) for x in b) / n, 1), "wait_gpu_s": res["s_waiting_for_gpu"], "wait_host_s": res["s_waiting_for_host_stage"]}
+            "ms_classify": round(sum(x.get("ms_classify", 0) for x in b) / n, 1), "ms_report": round(sum(x.get("ms_report", 0) for x in b) / n, 1), "wait_gpu_s": res["s_waiting_for_gpu"], "wait_host_s": res["s_waiting_for_host_stage"]}
 run(None, False, 4)
-for sink, tax in ((None, False), ("/dev/null", False), ("/dev/shm/kslam_probe.sam", False), ("/tmp/kslam_probe.sam", False), (None, True), ("/dev/shm/kslam_probe.sam", True)):
+for sink, tax in ((None, 0), ("/dev/null", 0), ("/dev/shm/kslam_probe.sam", 0), (None, 1), (None, 2), ("/dev/shm/kslam_probe.sam", 2)):
     print(json.dumps(run(sink, tax)), flush=True)

@@ -31,6 +31,15 @@ for r in range(rounds):
         rd, _ = synth.make_paired_reads(seed + 1, g, 1200, read_len=read_len, frag_mean=2 * read_len + 40,
                                         sub_rate=float(rng.uniform(0, 0.05)), indel_rate=float(rng.uniform(0, 0.012)),
                                         n_rate=float(rng.choice([0, 0.003])), edge_frac=float(rng.uniform(0, 0.3)))
+        if rng.random() < 0.2:     # round 3: a few reads beyond the packed kernels' 511 bases (runs of their own: k_sw_long)
+            for k in rng.integers(0, len(rd), 25):
+                gg = g[int(rng.integers(0, len(g)))]
+                L = int(rng.integers(520, min(1800, len(gg) - 10)))
+                at = int(rng.integers(0, len(gg) - L))
+                frag = gg[at:at + L]
+                if rng.random() < 0.5:
+                    frag = synth.revcomp(frag)
+                rd[int(k)] = synth.mutate(rng, frag, 0.02, 0.004)
         reads, genomes = synth.to_bytes(rd), synth.to_bytes(g)
         kind = "plain"
     kw = dict(zip(("match", "mismatch", "gap_open", "gap_extend"), scoring)) if scoring else {}

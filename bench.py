@@ -331,8 +331,8 @@ def ids_view(T, n_pairs, read_len, first_pair=0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", type=int, default=0, choices=[0, 1, 2, 3, 4],
                     help="BASELINE configs[k]; default 1 at --gpus 1, 3 (strong) at --gpus > 1")
     ap.add_argument("--pairs", type=int, default=0, help="read pairs per batch (default: 1 M for config 1, 10 M for 2 and 4)")

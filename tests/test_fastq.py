@@ -254,3 +254,31 @@ def test_batch_end_is_where_the_parser_stops(F, seed):
         got += records(b)
         pos += end
     assert got == records(total)
+
+
+def test_batch_windows_of_the_stream_driver(kslam, F):
+    """k-slam_amd/stream.py: cut_batches (the windows the reference's batch loop would read, src/SLAM.h:193-207) --
+    the windows tile both texts, each holds pairs_per_batch records per stream (the last one the rest), --num-reads caps the
+    total, and parsing the windows one by one gives the records of the whole files in order."""
+    import ctypes as C
+    S = importlib.import_module("kslam_amd.stream")
+    rng = np.random.default_rng(77)
+    t1, t2 = make_text(rng, 103, eol_mix=False), make_text(rng, 103, eol_mix=False)   # (a lone "\r" before an empty line would merge two terminators)
+    b1, b2 = C.create_string_buffer(t1, len(t1) + 1), C.create_string_buffer(t2, len(t2) + 1)
+    p1, p2 = C.addressof(b1), C.addressof(b2)
+    whole, _, _ = F.parse_pair(t1, t2)
+    for per_batch, cap in ((10, 0), (103, 0), (50, 0), (1000, 0), (25, 60), (25, 100), (40, 40)):
+        wins = list(S.cut_batches(p1, len(t1), p2, len(t2), per_batch, cap))
+        want_pairs = min(103, cap) if cap else 103
+        got1, got2, at1, at2 = [], [], 0, 0
+        for a1, e1, a2, e2, last in wins:
+            assert (a1, a2) == (at1, at2) and e1 > a1 and e2 > a2
+            batch, _, _ = F.parse_pair(t1[a1:e1], t2[a2:e2], at_eof=True)
+            half = batch.n_reads // 2
+            got1 += records(batch)[:half]
+            got2 += records(batch)[half:]
+            at1, at2 = e1, e2
+        assert len(got1) == want_pairs and len(wins) == -(-want_pairs // per_batch)
+        assert got1 == records(whole)[:want_pairs] and got2 == records(whole)[103:103 + want_pairs]
+        if not cap:
+            assert (at1, at2) == (len(t1), len(t2))

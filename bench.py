@@ -178,7 +178,7 @@ class FastqFiles:
             x.close()
 
 
-def e2e_leg(K, ctx, files, pairs_per_batch, index_view, taxdb, steps, warmup, pseudo, reps=3, tag="e2e", out_dir="/dev/shm"):
+def e2e_leg(K, ctx, files, pairs_per_batch, index_view, taxdb, steps, warmup, pseudo, reps=3, tag="e2e", out_dir="/dev/shm", native=True):
     """K steps of the reference's batch loop, FASTQ text in host memory to SAM + _PerRead files in /dev/shm."""
     S = importlib.import_module("kslam_amd.stream")
     T = importlib.import_module("kslam_amd.tail")
@@ -197,9 +197,21 @@ def e2e_leg(K, ctx, files, pairs_per_batch, index_view, taxdb, steps, warmup, ps
         pr_fd = os.open(pr_path, os.O_RDWR | os.O_CREAT | os.O_TRUNC, 0o600)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        res = S.classify_stream(ctx, index_view, files.h[0].ptr, files.len, files.h[1].ptr, files.len, pairs_per_batch, P,
-                                taxdb=taxdb, report=report, sam_fd=sam_fd, per_read_fd=pr_fd, sam_header=header,
-                                windows=[wins[i % F] for i in range(n_steps)])
+        if native:
+            # the loop inside the library (kslam_stream_classify); a text of F batches is read ceil(n_steps / F) times over
+            res = S.classify_stream_native(ctx, index_view, files.h[0].ptr, files.len, files.h[1].ptr, files.len, pairs_per_batch, P,
+                                           taxdb=taxdb, report=report, sam_fd=sam_fd, per_read_fd=pr_fd, sam_header=header,
+                                           max_pairs_total=n_steps * pairs_per_batch, passes=-(-n_steps // F))
+            res.update(pairs=res["n_pairs"], per_read_bytes=res["per_read_bytes"], s_in_write=res["seconds_in_write"],
+                       s_waiting_for_gpu=round(res["seconds_waiting_for_gpu"], 4),
+                       s_waiting_for_host_stage=round(res["seconds_waiting_for_host_stage"], 4),
+                       batches=[{"batch": 0, "ms_sam": res["seconds_sam_text"] * 1e3, "ms_classify": (res["seconds_classify"] + res["seconds_report"]) * 1e3,
+                                 "alignment_pairs": res["n_alignment_pairs"], "max_insert_size": res["first_max_insert_size"],
+                                 "pseudo_assembly_on": (("host" if res["batches_pseudo_on_host"] else "gpu") if pseudo else None)}])
+        else:
+            res = S.classify_stream(ctx, index_view, files.h[0].ptr, files.len, files.h[1].ptr, files.len, pairs_per_batch, P,
+                                    taxdb=taxdb, report=report, sam_fd=sam_fd, per_read_fd=pr_fd, sam_header=header,
+                                    windows=[wins[i % F] for i in range(n_steps)])
         os.close(sam_fd)
         os.close(pr_fd)
         torch.cuda.synchronize()
@@ -247,6 +259,7 @@ def e2e_leg(K, ctx, files, pairs_per_batch, index_view, taxdb, steps, warmup, ps
             "including_end_of_run_reports": {"reads_per_s": round(n_reads / (last["wall"] + t_end), 1)},
             "verified": {"repetitions_identical": bool(same), "sam_file_bytes": int(runs[0]["sam_file_bytes"]),
                          "per_read_lines": int(len(runs[0]["tax_ids"])), "max_insert_size": b[0]["max_insert_size"]},
+            "driver": "kslam_stream_classify (include/kslam_stream.h: the loop inside the library)" if native else "k-slam_amd/stream.py",
             "what": "FASTQ text (two files' worth, page-locked host memory) -> kslam_fastq_batch_end (batch boundaries) -> "
                     "kslam_submit_batch_fastq_text (GPU: FASTQ record index, alignToDatabase, score screen / pairing / insert-size "
                     "statistics / screens%s, per-row NM / MD / log-probability; %d batches in flight) -> kslam_collect_batch -> "
@@ -913,7 +926,7 @@ def main():
         if world == 1 and not strong and not args.no_e2e and not args.no_cigar:
             # ---- `value`: FASTQ text -> SAM file + _PerRead file, K steps of the reference's batch loop ----
             batch_bytes = 2 * pairs * (2 + W.ID_DIGITS + 3 + 2 * read_len + 4)
-            F = max(1, min(Ksteps, int(6e9 // batch_bytes)))
+            F = max(1, min(Ksteps, int(26e9 // batch_bytes)))     # distinct batches in the text (page-locked host memory)
             batches = [reads]
             for b in range(1, F):
                 if pairs > 2_000_000:

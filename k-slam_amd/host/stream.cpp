@@ -1,0 +1,231 @@
+// stream.cpp -- include/kslam_stream.h: the reference's batch loop (metagenomicAnalysis_Low_Mem, src/SLAM.h:193-250)
+// over this library's own C ABI.  Plain C++: every stage it calls is an exported entry point, so a k-SLAM host
+// could write the same loop itself (INTEGRATION.md shows it); this file is that loop, tested and timed.
+//
+//   main thread:  cut batch k+d (kslam_fastq_batch_end) -> kslam_submit_batch_fastq_text ... kslam_collect_batch(k)
+//   worker:       host stage of batch k-1: kslam_tail_finish_write_rows -> kslam_sam_writer (its own thread),
+//                 kslam_tail_classify -> per_read_fd, kslam_taxreport_add_batch
+#include <cerrno>
+#include <cstring>
+#include <deque>
+#include <string>
+#include <thread>
+#include <unistd.h>
+#include <vector>
+
+#include "../../include/kslam_fastq.h"
+#include "../../include/kslam_stream.h"
+#include "workers.hpp"
+
+namespace {
+using namespace kslam_host;
+
+struct Window { uint64_t p1, e1, p2, e2; };
+
+bool write_all(int fd, const char *p, uint64_t n) {
+  while (n) {
+    const ssize_t w = ::write(fd, p, (size_t)std::min<uint64_t>(n, 1ull << 30));
+    if (w < 0) {
+      if (errno == EINTR) continue;
+      return false;
+    }
+    p += w;
+    n -= (uint64_t)w;
+  }
+  return true;
+}
+
+}  // namespace
+
+extern "C" kslam_status kslam_stream_classify(kslam_ctx *ctx, const kslam_index_view *index, const kslam_taxdb *taxdb,
+                                              kslam_taxreport *report, const char *r1, uint64_t len1, const char *r2,
+                                              uint64_t len2, const kslam_stream_params *P, uint32_t **tax_ids_out,
+                                              uint64_t *n_tax_ids, kslam_stream_stats *stats) {
+  if (tax_ids_out) *tax_ids_out = nullptr;
+  if (n_tax_ids) *n_tax_ids = 0;
+  kslam_stream_stats st;
+  memset(&st, 0, sizeof st);
+  st.first_max_insert_size = 0xFFFFFFFFu;
+  const double t_begin = now_ms();
+  kslam_sam_writer *writer = nullptr;
+  std::thread worker;
+  kslam_status worker_status = KSLAM_OK;
+  std::string worker_error;
+  std::deque<uint64_t> tickets;
+  std::vector<uint32_t> all_ids;
+  bool pairing_set = false;
+
+  // whatever happens: the worker joined, the tickets collected and released, the writer closed, the pairing switched off
+  auto wind_down = [&]() -> kslam_status {
+    if (worker.joinable()) worker.join();
+    for (uint64_t tk : tickets) {
+      kslam_batch_result r;
+      if (kslam_collect_batch(ctx, tk, &r) == KSLAM_OK) kslam_release_batch(ctx, &r);
+    }
+    tickets.clear();
+    kslam_status w = KSLAM_OK;
+    if (writer) {
+      uint64_t bytes = 0;
+      double sec = 0;
+      w = kslam_sam_writer_close(writer, &bytes, &sec);
+      st.seconds_in_write = sec;
+      writer = nullptr;
+    }
+    if (pairing_set) kslam_set_pairing(ctx, 1, 0, 0.95, 0);
+    return w;
+  };
+
+  const kslam_status status = guarded([&] {
+    if (!ctx || !index || !P || !stats) fail(KSLAM_ERR_ARG, "null argument");
+    if ((len1 && !r1) || (len2 && !r2)) fail(KSLAM_ERR_ARG, "null text");
+    if (!P->tail.paired) fail(KSLAM_ERR_UNSUPPORTED, "kslam_stream_classify takes paired data (two texts)");
+    if (P->pairs_per_batch == 0) fail(KSLAM_ERR_ARG, "pairs_per_batch must be positive");
+    if (taxdb && !tax_ids_out) fail(KSLAM_ERR_ARG, "tax_ids output missing");
+    const uint32_t depth = P->depth ? P->depth : 3;
+    const uint32_t stages = KSLAM_TAIL_INSERT_SCREEN | KSLAM_TAIL_SCORE_SCREEN | (P->tail.pseudo_assembly ? KSLAM_TAIL_PSEUDO_ASM : 0u);
+    if (kslam_set_pairing(ctx, 1, P->tail.score_threshold, P->tail.score_fraction, stages) != KSLAM_OK)
+      fail(KSLAM_ERR_UNSUPPORTED, kslam_last_error(ctx));
+    pairing_set = true;
+    if (P->sam_fd >= 0) {
+      if (kslam_sam_writer_open(P->sam_fd, &writer) != KSLAM_OK) fail(KSLAM_ERR_ARG, "could not start the SAM writer");
+      if (P->sam_header && P->sam_header_len && kslam_write_queued(writer, P->sam_header, P->sam_header_len) != 0)
+        fail(KSLAM_ERR_ARG, "writing the SAM header failed");
+    }
+    kslam_tail_params host_all = P->tail, host_write = P->tail;   // what the host stage still has to run
+    host_write.pseudo_assembly = 0;
+
+    // ---- batch boundaries, found ahead of the submission (src/SLAM.h:193, 201-206) ----
+    uint64_t p1 = 0, p2 = 0, done_pairs = 0;
+    uint32_t passes_left = P->passes > 1 ? P->passes - 1 : 0;
+    bool exhausted = false;
+    auto next_window = [&](Window *w) -> bool {
+      if ((exhausted || !(p1 < len1 || p2 < len2)) && passes_left && len1 && len2) {   // the texts once more
+        passes_left--;
+        p1 = p2 = 0;
+        exhausted = false;
+      }
+      if (exhausted || !(p1 < len1 || p2 < len2)) return false;
+      uint64_t want = P->pairs_per_batch;
+      if (P->max_pairs_total) {
+        if (done_pairs >= P->max_pairs_total) return false;
+        want = std::min(want, P->max_pairs_total - done_pairs);   // readsPerGoTemp
+      }
+      uint64_t e1 = 0, e2 = 0;
+      int c1 = 0, c2 = 0;
+      if (kslam_fastq_batch_end(r1 + p1, len1 - p1, want, 1, P->tail.threads, &e1, &c1) != KSLAM_OK ||
+          kslam_fastq_batch_end(r2 + p2, len2 - p2, want, 1, P->tail.threads, &e2, &c2) != KSLAM_OK)
+        fail(KSLAM_ERR_ARG, kslam_tail_last_error());
+      *w = Window{p1, p1 + e1, p2, p2 + e2};
+      done_pairs += want;
+      p1 += e1;
+      p2 += e2;
+      if (p1 >= len1 || p2 >= len2) exhausted = true;
+      return true;
+    };
+
+    auto host_stage = [&](kslam_batch_result res) {   // on the worker thread; owns `res`
+      const kslam_status s = guarded([&] {
+        kslam_reads_view reads = {res.n_reads, nullptr, res.reads_bases_off, nullptr, res.reads_bases_off, res.reads_ids, res.reads_ids_off};
+        const bool on_gpu = (res.pair_stats.stages_done & KSLAM_TAIL_PSEUDO_ASM) != 0;
+        if (P->tail.pseudo_assembly && !on_gpu) st.batches_pseudo_on_host++;
+        const kslam_tail_params *tp = (on_gpu || !P->tail.pseudo_assembly) ? &host_write : &host_all;
+        kslam_tail_stats ts;
+        memset(&ts, 0, sizeof ts);
+        const double t0 = now_ms();
+        static const auto drop = [](void *, const char *, uint64_t) -> int { return 0; };
+        const kslam_status a = kslam_tail_finish_write_rows(tp, &reads, index, res.overlaps, res.n_overlaps, res.cigar_pool, res.n_cigar,
+                                                            res.details, res.md_pool, res.n_md, res.read_pairs, res.n_read_pairs,
+                                                            res.pairs, res.n_pairs, writer ? kslam_write_queued : +drop,
+                                                            writer ? (void *)writer : nullptr, &ts);
+        if (a != KSLAM_OK) fail(a, kslam_tail_last_error());
+        const double t1 = now_ms();
+        st.seconds_sam_text += (t1 - t0) * 1e-3;
+        st.sam_bytes += ts.sam_bytes;
+        st.n_alignment_pairs += ts.n_paired_final;
+        st.n_read_pairs_aligned += ts.n_read_pairs;
+        st.n_overlaps += res.n_overlaps;
+        if (st.n_batches == 0) st.first_max_insert_size = res.pair_stats.max_insert_size;
+        st.n_batches++;
+        st.n_pairs += res.n_reads / 2;
+        if (taxdb) {
+          const size_t base = all_ids.size();
+          all_ids.resize(base + res.n_read_pairs);
+          char *text = nullptr;
+          uint64_t tlen = 0;
+          const kslam_status b = kslam_tail_classify(&host_write, &reads, index, taxdb, res.read_pairs, res.n_read_pairs, res.pairs,
+                                                     res.n_pairs, all_ids.data() + base, &text, &tlen);
+          if (b != KSLAM_OK) fail(b, kslam_tail_last_error());
+          const bool wrote = P->per_read_fd < 0 || write_all(P->per_read_fd, text, tlen);
+          kslam_free(text);
+          if (!wrote) fail(KSLAM_ERR_ARG, std::string("writing the per-read file failed: ") + strerror(errno));
+          st.per_read_bytes += tlen;
+          const double t2 = now_ms();
+          st.seconds_classify += (t2 - t1) * 1e-3;
+          if (report) {
+            const kslam_status c = kslam_taxreport_add_batch(report, &reads, index, res.read_pairs, res.n_read_pairs, res.pairs,
+                                                             res.n_pairs, all_ids.data() + base);
+            if (c != KSLAM_OK) fail(c, kslam_tail_last_error());
+            st.seconds_report += (now_ms() - t2) * 1e-3;
+          }
+        }
+      });
+      kslam_release_batch(ctx, &res);
+      if (s != KSLAM_OK && worker_status == KSLAM_OK) {
+        worker_status = s;
+        worker_error = g_err;          // (the worker's thread-local message)
+      }
+    };
+
+    for (;;) {
+      Window w;
+      while (tickets.size() < depth && next_window(&w)) {
+        uint64_t tk = 0;
+        // "at end of stream" for inner windows too: a window ends right after a terminator (kslam_fastq_batch_end looked at
+        // the byte behind a closing "\r"), so the end-of-stream rule adds nothing and keeps that "\r" a whole terminator
+        if (kslam_submit_batch_fastq_text(ctx, r1 + w.p1, w.e1 - w.p1, r2 + w.p2, w.e2 - w.p2, 0, 1, &tk) != KSLAM_OK)
+          fail(KSLAM_ERR_STATE, kslam_last_error(ctx));
+        tickets.push_back(tk);
+      }
+      if (tickets.empty()) break;
+      const double ta = now_ms();
+      kslam_batch_result res;
+      const uint64_t tk = tickets.front();
+      tickets.pop_front();
+      const kslam_status cs = kslam_collect_batch(ctx, tk, &res);
+      const double tb = now_ms();
+      st.seconds_waiting_for_gpu += (tb - ta) * 1e-3;
+      if (worker.joinable()) worker.join();
+      st.seconds_waiting_for_host_stage += (now_ms() - tb) * 1e-3;
+      if (cs != KSLAM_OK) fail(cs, kslam_last_error(ctx));
+      if (worker_status != KSLAM_OK) {
+        kslam_release_batch(ctx, &res);
+        fail(worker_status, worker_error);
+      }
+      if (res.n_reads == 0) {          // an empty batch ends the loop (src/SLAM.h:207)
+        kslam_release_batch(ctx, &res);
+        break;
+      }
+      if (!res.read_pairs && res.n_overlaps) {
+        kslam_release_batch(ctx, &res);
+        fail(KSLAM_ERR_INTERNAL, "the lane returned no device pairing");
+      }
+      worker = std::thread(host_stage, res);
+    }
+    if (worker.joinable()) worker.join();
+    if (worker_status != KSLAM_OK) fail(worker_status, worker_error);
+  });
+
+  const kslam_status closing = wind_down();
+  st.seconds = (now_ms() - t_begin) * 1e-3;
+  if (stats) *stats = st;
+  if (status != KSLAM_OK) return status;
+  if (closing != KSLAM_OK) return closing;
+  if (taxdb && tax_ids_out) {
+    uint32_t *out = (uint32_t *)malloc(sizeof(uint32_t) * (all_ids.size() + 1));
+    if (!out) return KSLAM_ERR_OOM;
+    if (!all_ids.empty()) memcpy(out, all_ids.data(), sizeof(uint32_t) * all_ids.size());
+    *tax_ids_out = out;
+    if (n_tax_ids) *n_tax_ids = all_ids.size();
+  }
+  return KSLAM_OK;
+}

@@ -29,6 +29,55 @@ from . import fastq as F
 from . import tail as T
 
 
+# every symbol include/kslam_stream.h declares
+EXPORTS = ["kslam_stream_classify"]
+
+
+class StreamParams(C.Structure):
+    """kslam_stream_params"""
+    _fields_ = [("pairs_per_batch", C.c_uint64), ("max_pairs_total", C.c_uint64), ("tail", T.TailParams), ("sam_fd", C.c_int32),
+                ("per_read_fd", C.c_int32), ("sam_header", C.c_char_p), ("sam_header_len", C.c_uint64), ("depth", C.c_uint32),
+                ("passes", C.c_uint32)]
+
+
+class StreamStats(C.Structure):
+    """kslam_stream_stats"""
+    _fields_ = [("n_batches", C.c_uint64), ("n_pairs", C.c_uint64), ("n_overlaps", C.c_uint64), ("n_read_pairs_aligned", C.c_uint64),
+                ("n_alignment_pairs", C.c_uint64), ("sam_bytes", C.c_uint64), ("per_read_bytes", C.c_uint64),
+                ("first_max_insert_size", C.c_uint32), ("batches_pseudo_on_host", C.c_uint32), ("seconds", C.c_double),
+                ("seconds_waiting_for_gpu", C.c_double), ("seconds_waiting_for_host_stage", C.c_double),
+                ("seconds_sam_text", C.c_double), ("seconds_classify", C.c_double), ("seconds_report", C.c_double),
+                ("seconds_in_write", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+def classify_stream_native(ctx, index, r1_ptr, len1, r2_ptr, len2, pairs_per_batch, params, taxdb=None, report=None,
+                           sam_fd=-1, per_read_fd=-1, sam_header=None, max_pairs_total=0, depth=0, passes=1):
+    """kslam_stream_classify: the same loop as classify_stream below, inside the library (no Python between the batches).
+    -> dict of the statistics + tax_ids (uint32 array, empty without a taxdb)"""
+    L = T.lib()
+    L.kslam_stream_classify.argtypes = [C.c_void_p, C.POINTER(T.IndexView), C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
+                                        C.c_void_p, C.c_uint64, C.POINTER(StreamParams), C.POINTER(C.c_void_p),
+                                        C.POINTER(C.c_uint64), C.POINTER(StreamStats)]
+    P = StreamParams(pairs_per_batch, max_pairs_total, params, sam_fd, per_read_fd, sam_header, len(sam_header) if sam_header else 0,
+                     depth, passes)
+    st, ids, n_ids = StreamStats(), C.c_void_p(), C.c_uint64()
+    rc = L.kslam_stream_classify(ctx._h, C.byref(index.view), taxdb._h if taxdb is not None else None,
+                                 report._h if report is not None else None, r1_ptr, len1, r2_ptr, len2, C.byref(P),
+                                 C.byref(ids), C.byref(n_ids), C.byref(st))
+    if rc != 0:
+        msg = L.kslam_tail_last_error().decode() or ctx._L.kslam_last_error(ctx._h).decode()
+        raise KslamError(rc, msg)
+    out = st.as_dict()
+    n = int(n_ids.value)
+    out["tax_ids"] = np.frombuffer((C.c_char * (4 * n)).from_address(ids.value), dtype=np.uint32).copy() if n else np.zeros(0, dtype=np.uint32)
+    if ids.value:
+        L.kslam_free(ids)
+    return out
+
+
 def _fd_writer():
     L = T.lib()
     return C.cast(L.kslam_write_fd, T.WRITE_FN)

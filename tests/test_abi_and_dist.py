@@ -48,7 +48,7 @@ def test_library_exports_every_tail_symbol(kslam):
 
 
 @pytest.mark.parametrize("header,module,count", [("kslam_fastq.h", "fastq", 6), ("kslam_taxonomy.h", "taxonomy", 15),
-                                                 ("kslam_db.h", "db", 9)])
+                                                 ("kslam_db.h", "db", 9), ("kslam_stream.h", "stream", 1)])
 def test_library_exports_every_host_stage_symbol(kslam, header, module, count):
     import ctypes
     import importlib

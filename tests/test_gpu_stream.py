@@ -93,6 +93,19 @@ def test_stream_of_batches_equals_the_reference_loop(kslam, oracle, synth, tmp_p
     per_read = open(per_read_path, "rb").read()
     summary = tax.summary(res["tax_ids"], res["pairs"])
     xml = tax.report_xml(report, db, db.gene_extras(), res["pairs"])
+    # ---- the same loop inside the library (kslam_stream_classify, include/kslam_stream.h): same files, same report ----
+    report_n = X.Report()
+    sam_fd = os.open(sam_path + ".native", os.O_RDWR | os.O_CREAT | os.O_TRUNC)
+    pr_fd = os.open(per_read_path + ".native", os.O_RDWR | os.O_CREAT | os.O_TRUNC)
+    nat = S.classify_stream_native(ctx, db, h1.ptr, len(r1), h2.ptr, len(r2), per_batch, P, taxdb=tax, report=report_n,
+                                   sam_fd=sam_fd, per_read_fd=pr_fd, sam_header=header)
+    os.close(sam_fd)
+    os.close(pr_fd)
+    assert open(sam_path + ".native", "rb").read() == sam and open(per_read_path + ".native", "rb").read() == per_read
+    assert nat["tax_ids"].tolist() == res["tax_ids"].tolist() and nat["n_pairs"] == res["pairs"]
+    assert nat["n_batches"] == len(res["batches"]) and nat["sam_bytes"] + len(header) == len(sam)
+    assert tax.report_xml(report_n, db, db.gene_extras(), nat["n_pairs"]) == xml
+    report_n.close()
     n_batches = (n_pairs + per_batch - 1) // per_batch
     assert res["pairs"] == n_pairs and len(res["batches"]) == n_batches
     assert [b["pairs"] for b in res["batches"]] == [min(per_batch, n_pairs - k * per_batch) for k in range(n_batches)]
@@ -167,10 +180,16 @@ def test_stream_stops_at_max_pairs_and_reports_mismatched_files(kslam, synth, tm
     P = T.TailParams.default()
     res = S.classify_stream(ctx, db, h1.ptr, len(r1), h2.ptr, len(r2), 400, P, max_pairs_total=650)
     assert [b["pairs"] for b in sorted(res["batches"], key=lambda b: b["batch"])] == [400, 250] and res["pairs"] == 650
+    nat = S.classify_stream_native(ctx, db, h1.ptr, len(r1), h2.ptr, len(r2), 400, P, max_pairs_total=650)
+    assert nat["n_batches"] == 2 and nat["n_pairs"] == 650 and len(nat["tax_ids"]) == 0
     # R2 one record short
     cut = r2.rstrip(b"\n").rfind(b"\n@")
     with pytest.raises(kslam.KslamError, match="mismatch in R1 and R2"):
         S.classify_stream(ctx, db, h1.ptr, len(r1), h2.ptr, cut + 1, 400, P)
+    with pytest.raises(kslam.KslamError, match="mismatch in R1 and R2"):
+        S.classify_stream_native(ctx, db, h1.ptr, len(r1), h2.ptr, cut + 1, 400, P)
+    # and the context is usable afterwards
+    assert S.classify_stream_native(ctx, db, h1.ptr, len(r1), h2.ptr, len(r2), 500, P)["n_pairs"] == n_pairs
     h1.close()
     h2.close()
     ctx.close()

@@ -216,7 +216,7 @@ def e2e_leg(K, ctx, files, pairs_per_batch, index_view, taxdb, steps, warmup, ps
         os.close(pr_fd)
         torch.cuda.synchronize()
         res["wall"] = time.perf_counter() - t0
-        res["sam_file_bytes"] = res.get("sam_bytes_written", 0) if discard else os.path.getsize(sam_path)
+        res["sam_file_bytes"] = (res.get("sam_bytes_written") or res.get("sam_bytes", 0) + len(header)) if discard else os.path.getsize(sam_path)
         res["per_read_file_bytes"] = os.path.getsize(pr_path)
         if keep_report:
             res["report"] = report

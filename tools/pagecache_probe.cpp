@@ -16,7 +16,7 @@ int main(int argc, char **argv) {
   char *src = (char *)malloc(N);
   memset(src, 'x', N);
   auto par = [&](auto f) { std::vector<std::thread> th; for (int t = 0; t < T; t++) th.emplace_back(f, t); for (auto &x : th) x.join(); };
-  for (int mode = 0; mode < 8; mode++) {
+  for (int mode = 0; mode < 12; mode++) {
     unlink(path);
     int fd = open(path, O_RDWR | O_CREAT | O_TRUNC, 0600);
     double t0 = now();
@@ -48,6 +48,31 @@ int main(int argc, char **argv) {
       if (mode == 6) { size_t o = 0; while (o < N) o += write(fd, src + o, std::min<size_t>(N - o, 8 << 20)); }
       else par([&](int t) { size_t lo = N / T * t, hi = t == T - 1 ? N : N / T * (t + 1); while (lo < hi) lo += pwrite(fd, src + lo, std::min<size_t>(hi - lo, 8 << 20), lo); });
       printf("  (write part: %.1f ms)\n", (now() - t1) * 1e3);
+    }
+    if (mode >= 8 && mode <= 11) {
+      // 8: ftruncate + mmap(MAP_POPULATE) + copy; 9: fallocate + the same; 10: ftruncate + mmap + MADV_POPULATE_WRITE per thread + copy;
+      // 11: fallocate + the same
+      const char *names[4] = {"ftruncate + mmap(MAP_POPULATE) + memcpy T", "fallocate + mmap(MAP_POPULATE) + memcpy T",
+                              "ftruncate + mmap + MADV_POPULATE_WRITE/thread", "fallocate + mmap + MADV_POPULATE_WRITE/thread"};
+      name = names[mode - 8];
+      if (mode & 1) { if (fallocate(fd, 0, 0, N)) perror("fallocate"); } else if (ftruncate(fd, N)) return 1;
+      double t1 = now();
+      char *m = (char *)mmap(nullptr, N, PROT_READ | PROT_WRITE, MAP_SHARED | (mode < 10 ? MAP_POPULATE : 0), fd, 0);
+      if (m == MAP_FAILED) { perror("mmap"); return 1; }
+      double t2 = now();
+      int bad = 0;
+      par([&](int t) {
+        size_t lo = N / T * t, hi = t == T - 1 ? N : N / T * (t + 1);
+        lo &= ~(size_t)4095; if (t != T - 1) hi &= ~(size_t)4095;
+#ifdef MADV_POPULATE_WRITE
+        if (mode >= 10 && madvise(m + lo, hi - lo, MADV_POPULATE_WRITE)) bad = 1;
+#else
+        if (mode >= 10) bad = 2;
+#endif
+        memcpy(m + lo, src + lo, hi - lo);
+      });
+      munmap(m, N);
+      printf("  (mmap %.1f ms, populate+copy %.1f ms, madvise %s)\n", (t2 - t1) * 1e3, (now() - t2) * 1e3, bad == 0 ? "ok" : (bad == 1 ? "FAILED" : "not compiled"));
     }
     double dt = now() - t0;
     printf("%-44s %7.1f ms  %.2f GB/s\n", name, dt * 1e3, N / dt / 1e9);

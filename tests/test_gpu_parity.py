@@ -251,11 +251,11 @@ def test_pipelined_entry_gives_the_same_batches(kslam, synth):
         c.wait_batch(tickets[0])
     # out-of-order waits + an unsupported batch in the middle
     t0 = c.submit_batch(batches[0])
-    t_bad = c.submit_batch([b"ACGT" * 200])              # 800 bases: beyond the supported read length
+    t_bad = c.submit_batch([b"ACGT" * 2500])             # 10 000 bases: beyond the supported read length (9 000)
     t2 = c.submit_batch(batches[2])
     ov, cg = c.wait_batch(t2)
     assert ov.tobytes() == expect[2][0].tobytes()
-    with pytest.raises(kslam.KslamError, match="511"):
+    with pytest.raises(kslam.KslamError, match="9000"):
         c.wait_batch(t_bad)
     ov, cg = c.wait_batch(t0)
     assert ov.tobytes() == expect[0][0].tobytes() and cg.tobytes() == expect[0][1].tobytes()
@@ -651,8 +651,9 @@ def test_low_complexity_parity(kslam, oracle, synth, read_len, scoring):
 
 
 def test_longest_supported_reads_and_the_limit(kslam, oracle, synth):
-    """511 bases is the longest read the library takes (9-bit row / column keys in the packed DP
-    values): such reads, mixed with short ones, must match the oracle; 512 must be refused, loudly."""
+    """511 bases is the longest read the packed kernels take (9-bit row / column keys in the packed DP
+    values): such reads, mixed with short ones, must match the oracle; 512 goes to the long-read kernels
+    (test_reads_beyond_the_packed_kernels) and more than 9000 bases must be refused, loudly."""
     genomes = synth.make_genomes(301, 2, 2, 30000, strain_sub=0.02, strain_indel=0.002)
     reads, _ = synth.make_paired_reads(302, genomes, 300, read_len=511, frag_mean=900, sub_rate=0.02,
                                        indel_rate=0.003, n_rate=0.002, edge_frac=0.1)
@@ -663,8 +664,14 @@ def test_longest_supported_reads_and_the_limit(kslam, oracle, synth):
     exp, ecig, _ = oracle.align_to_database(rb, gb)
     assert len(exp) > 800 and (exp["cigar_len"] > 1).sum() > 100
     _compare_alignments(got, gcig, exp, ecig)
-    with pytest.raises(kslam.KslamError, match="511"):
-        kslam.align_to_database([b"ACGT" * 128], gb)
+    one_more = synth.to_bytes([synth.mutate(np.random.default_rng(5), genomes[0][1000:1540], 0.02, 0.003)[:512]])
+    assert len(one_more[0]) == 512
+    got, gcig = kslam.align_to_database(rb[:50] + one_more, gb)
+    exp, ecig, _ = oracle.align_to_database(rb[:50] + one_more, gb)
+    assert (exp["read"] == 50).any()
+    _compare_alignments(got, gcig, exp, ecig)
+    with pytest.raises(kslam.KslamError, match="9000"):
+        kslam.align_to_database([b"ACGT" * 2251], gb)
 
 
 @pytest.mark.parametrize("scoring", [(16, 10, 12, 4), (8, 6, 9, 2)])
@@ -672,7 +679,8 @@ def test_scores_at_the_top_of_the_score_field(kslam, oracle, synth, scoring):
     """Perfect 511-base reads under a large match score: 16 x 511 = 8176 is the largest score the packed
     DP values (and the v_max_f64 pairs that keep the running best) can hold; with (16, ., ., 4) the band
     kernels' offset range is exceeded and everything runs on the full-matrix kernel, with (8, ., ., 2)
-    the bands run near the top of theirs.  One more match point must be refused."""
+    the bands run near the top of theirs.  One more match point sends the batch to the long-read kernels
+    (int32 scores), with the same rows."""
     genomes = synth.make_genomes(311, 2, 2, 20000, strain_sub=0.01, strain_indel=0.001)
     reads, _ = synth.make_paired_reads(312, genomes, 150, read_len=511, frag_mean=900, sub_rate=0.0, indel_rate=0.0)
     noisy, _ = synth.make_paired_reads(313, genomes, 150, read_len=511, frag_mean=900, sub_rate=0.02, indel_rate=0.003)
@@ -682,8 +690,11 @@ def test_scores_at_the_top_of_the_score_field(kslam, oracle, synth, scoring):
     exp, ecig, _ = oracle.align_to_database(rb, gb, oracle.Params.default(**kw))
     assert int(exp["score"].max()) == scoring[0] * 511
     _compare_alignments(got, gcig, exp, ecig)
-    with pytest.raises(kslam.KslamError, match="8188"):
-        kslam.align_to_database(rb, gb, match=17, mismatch=10, gap_open=12, gap_extend=4)
+    kw = dict(match=scoring[0] + 1, mismatch=scoring[1], gap_open=scoring[2], gap_extend=scoring[3])
+    got, gcig = kslam.align_to_database(rb[:100], gb, **kw)
+    exp, ecig, _ = oracle.align_to_database(rb[:100], gb, oracle.Params.default(**kw))
+    assert int(exp["score"].max()) == (scoring[0] + 1) * 511
+    _compare_alignments(got, gcig, exp, ecig)
 
 
 @pytest.mark.parametrize("long_len,layout", [(600, "mixed"), (2000, "mixed"), (700, "all"), (4000, "few")])

@@ -384,21 +384,37 @@ kslam_status kslam_taxonomy_summary(const kslam_taxdb *db, const uint32_t *tax_i
                                     uint64_t num_reads, char **text, uint64_t *text_len) {
   return guarded([&] {
     if (!db || !text || !text_len || (n && !tax_ids)) fail(KSLAM_ERR_ARG, "null argument");
-    // combineTaxonomies, src/MetagenomicResults.h:149-177, on (id) records in stable id order:
-    // only the group sizes matter downstream
-    std::vector<uint32_t> sorted(tax_ids, tax_ids + n);
-    std::stable_sort(sorted.begin(), sorted.end());
+    // combineTaxonomies, src/MetagenomicResults.h:149-177, on (id) records in stable id order: only the group sizes
+    // matter downstream, so the ids are counted (chunks sorted in parallel, their runs merged) instead of sorted as a
+    // whole.  The reference's loop starts with `test = 0`: the group of id 0 is never emitted and, when no record has
+    // id 0, the first record of the sorted array is not counted with its group (:158-176)
     std::vector<std::pair<uint32_t, uint64_t>> groups;  // (taxonomy id, reads)
-    if (n) {
-      uint32_t test = 0;
-      size_t start = 0;
-      for (size_t i = 1; i < n; i++)
-        if (sorted[i] != test) {
-          if (test != 0) groups.push_back({sorted[start], i - start});
-          test = sorted[i];
-          start = i;
+    if (n == 1) {
+      if (tax_ids[0] != 0) groups.push_back({tax_ids[0], 1});
+    } else if (n) {
+      const int threads = std::max(1, std::min(usable_cpus(), 512));
+      const size_t chunks = std::max<size_t>(1, std::min<size_t>((size_t)threads * 4, (n + 65535) / 65536));
+      const size_t per = (n + chunks - 1) / chunks;
+      std::vector<std::vector<std::pair<uint32_t, uint64_t>>> runs(chunks);
+      Pool::get().tasks(threads, chunks, [&](size_t c) {
+        const size_t lo = c * per, hi = std::min<size_t>(n, (c + 1) * per);
+        if (lo >= hi) return;
+        std::vector<uint32_t> part(tax_ids + lo, tax_ids + hi);
+        std::sort(part.begin(), part.end());
+        for (size_t i = 0, j; i < part.size(); i = j) {
+          for (j = i + 1; j < part.size() && part[j] == part[i]; j++) {}
+          runs[c].push_back({part[i], j - i});
         }
-      if (sorted[start] != 0) groups.push_back({sorted[start], n - start});
+      });
+      std::vector<std::pair<uint32_t, uint64_t>> all;
+      for (auto &r : runs) all.insert(all.end(), r.begin(), r.end());
+      std::sort(all.begin(), all.end());
+      for (size_t i = 0, j; i < all.size(); i = j) {
+        uint64_t count = 0;
+        for (j = i; j < all.size() && all[j].first == all[i].first; j++) count += all[j].second;
+        if (i == 0 && all[i].first != 0) count--;       // the first record of the sorted array
+        if (all[i].first != 0 && count) groups.push_back({all[i].first, count});
+      }
     }
     // sortResults, src/MetagenomicResults.h:254-262
     std::sort(groups.begin(), groups.end(), [](const std::pair<uint32_t, uint64_t> &a,
@@ -497,28 +513,54 @@ kslam_status kslam_taxreport_xml(const kslam_taxreport *report, const kslam_inde
     if (!report || !index || !db || !text || !text_len) fail(KSLAM_ERR_ARG, "null argument");
     const GeneOrder ord{index};
     struct Counted { uint64_t gene; int count; };
-    struct Taxon { uint32_t tax; std::vector<std::string> reads; std::vector<Counted> genes; };
-    // combineTaxonomies, src/MetagenomicResults.h:149-177 (records of equal id in input order: see the header)
+    struct Taxon { uint32_t tax = 0; size_t from = 0, to = 0; uint64_t n_reads = 0; std::string xml; };
     const size_t n = report->size();
-    std::vector<uint32_t> order(n);
-    for (size_t i = 0; i < n; i++) order[i] = (uint32_t)i;
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return report->tax[a] < report->tax[b]; });
+    const int threads = std::max(1, std::min(usable_cpus(), 512));
+    // combineTaxonomies, src/MetagenomicResults.h:149-177: records in stable taxonomy-id order (records of equal id in
+    // input order: see the header).  A stable LSD radix sort of the record numbers, 16 bits of the id per pass, the
+    // chunks of a pass counted and scattered in parallel -- the same permutation as std::stable_sort by id
+    std::vector<uint32_t> order(n), other;
+    {
+      uint32_t max_tax = 0;
+      for (size_t i = 0; i < n; i++) max_tax = std::max(max_tax, report->tax[i]);
+      const size_t chunks = std::max<size_t>(1, std::min<size_t>((size_t)threads * 2, (n + 65535) / 65536));
+      const size_t per = (n + chunks - 1) / std::max<size_t>(chunks, 1);
+      Pool::get().tasks(threads, chunks, [&](size_t c) {
+        for (size_t i = c * per; i < std::min(n, (c + 1) * per); i++) order[i] = (uint32_t)i;
+      });
+      if (max_tax) other.resize(n);
+      std::vector<uint32_t> hist;
+      for (int shift = 0; shift < 32 && (max_tax >> shift); shift += 16) {
+        hist.assign(chunks * 65536, 0);
+        Pool::get().tasks(threads, chunks, [&](size_t c) {
+          uint32_t *h = hist.data() + c * 65536;
+          for (size_t i = c * per; i < std::min(n, (c + 1) * per); i++) h[(report->tax[order[i]] >> shift) & 0xFFFF]++;
+        });
+        uint64_t run = 0;
+        for (size_t d = 0; d < 65536; d++)
+          for (size_t c = 0; c < chunks; c++) {
+            const uint32_t t = hist[c * 65536 + d];
+            hist[c * 65536 + d] = (uint32_t)run;
+            run += t;
+          }
+        Pool::get().tasks(threads, chunks, [&](size_t c) {
+          uint32_t *h = hist.data() + c * 65536;
+          for (size_t i = c * per; i < std::min(n, (c + 1) * per); i++) {
+            const uint32_t r = order[i];
+            other[h[(report->tax[r] >> shift) & 0xFFFF]++] = r;
+          }
+        });
+        order.swap(other);
+      }
+    }
+    // the groups, cut by the reference's loop (:158-176: `test` starts at 0, so the group of id 0 is never combined and,
+    // when no record has id 0, the very first record stays out of its group)
     std::vector<Taxon> taxa;
-    auto combine = [&](size_t from, size_t to) {        // combineRangeOfIdentifiedTaxonomy, :118-142
+    auto group = [&](size_t from, size_t to) {
       Taxon t;
       t.tax = report->tax[order[from]];
-      std::vector<uint64_t> all;
-      for (size_t i = from; i < to; i++) {
-        const uint32_t r = order[i];
-        all.insert(all.end(), report->genes.begin() + report->gene_off[r], report->genes.begin() + report->gene_off[r + 1]);
-        if (report->has_read[r])
-          t.reads.emplace_back(report->names.data() + report->name_off[r], report->name_off[r + 1] - report->name_off[r]);
-      }
-      std::sort(all.begin(), all.end(), [&](uint64_t a, uint64_t b) { return ord.less(a, b); });
-      for (size_t i = 0; i < all.size(); i++) {
-        if (!t.genes.empty() && ord.equal(t.genes.back().gene, all[i])) t.genes.back().count++;
-        else t.genes.push_back(Counted{all[i], 1});
-      }
+      t.from = from;
+      t.to = to;
       taxa.push_back(std::move(t));
     };
     if (n) {
@@ -527,21 +569,31 @@ kslam_status kslam_taxreport_xml(const kslam_taxreport *report, const kslam_inde
       for (size_t i = 1; i < n; i++) {
         const uint32_t id = report->tax[order[i]];
         if (id != test) {
-          if (test != 0) combine(start, i);
+          if (test != 0) group(start, i);
           test = id;
           start = i;
         }
       }
-      if (report->tax[order[start]] != 0) combine(start, n);
+      if (report->tax[order[start]] != 0) group(start, n);
     }
-    // sortResults, src/MetagenomicResults.h:254-273
-    std::sort(taxa.begin(), taxa.end(), [](const Taxon &a, const Taxon &b) {
-      return a.reads.size() == b.reads.size() ? a.tax < b.tax : a.reads.size() > b.reads.size();
-    });
     auto locus = [&](uint64_t g) { return extras ? col(extras->gene_locus_tag, extras->gene_locus_tag_off, g) : std::string_view(); };
-    for (Taxon &t : taxa) {
-      std::sort(t.reads.begin(), t.reads.end());
-      std::sort(t.genes.begin(), t.genes.end(), [&](const Counted &a, const Counted &b) {
+    const unsigned reads32 = (unsigned)num_reads;   // the reference's `const unsigned numReads`
+    // one taxon: combineRangeOfIdentifiedTaxonomy (:118-142), its share of sortResults (:263-273) and of getXML
+    // (:302-366).  `sorted_reads` arrives sorted when the caller did that in parallel (large groups)
+    auto finish = [&](Taxon &t, std::vector<std::string_view> &reads, bool reads_sorted) {
+      std::vector<uint64_t> all;
+      for (size_t i = t.from; i < t.to; i++) {
+        const uint32_t r = order[i];
+        all.insert(all.end(), report->genes.begin() + report->gene_off[r], report->genes.begin() + report->gene_off[r + 1]);
+      }
+      std::sort(all.begin(), all.end(), [&](uint64_t a, uint64_t b) { return ord.less(a, b); });
+      std::vector<Counted> genes;
+      for (size_t i = 0; i < all.size(); i++) {
+        if (!genes.empty() && ord.equal(genes.back().gene, all[i])) genes.back().count++;
+        else genes.push_back(Counted{all[i], 1});
+      }
+      if (!reads_sorted) std::sort(reads.begin(), reads.end());
+      std::sort(genes.begin(), genes.end(), [&](const Counted &a, const Counted &b) {
         if (a.count == b.count) {
           const uint32_t sa = (uint32_t)index->gene_start[a.gene], sb = (uint32_t)index->gene_start[b.gene];
           if (sa == sb) return locus(a.gene) < locus(b.gene);
@@ -549,15 +601,15 @@ kslam_status kslam_taxreport_xml(const kslam_taxreport *report, const kslam_inde
         }
         return a.count > b.count;
       });
-    }
-    // getXML, src/MetagenomicResults.h:302-366
-    std::string out;
-    const unsigned reads32 = (unsigned)num_reads;   // the reference's `const unsigned numReads`
-    for (const Taxon &t : taxa) {
+      t.n_reads = reads.size();
+      std::string &out = t.xml;
+      size_t name_bytes = 0;
+      for (const std::string_view &r : reads) name_bytes += r.size();
+      out.reserve(512 + genes.size() * 256 + reads.size() * 20 + name_bytes + name_bytes / 8);
       out += "<taxon>\n  <abundance numReads=\"";
-      out += std::to_string(t.reads.size());
+      out += std::to_string(reads.size());
       out += "\">";
-      out += std::to_string(t.reads.size() * 100.0 / reads32);
+      out += std::to_string(reads.size() * 100.0 / reads32);
       out += "</abundance>\n  <taxonomyID>";
       out += std::to_string(t.tax);
       out += "</taxonomyID>\n  <lineage>";
@@ -565,7 +617,7 @@ kslam_status kslam_taxreport_xml(const kslam_taxreport *report, const kslam_inde
       out += "</lineage>\n  <name>";
       if (db->known(t.tax)) xml_escaped(out, db->name[db->node(t.tax)]);
       out += "</name>\n  <genes>\n";
-      for (const Counted &c : t.genes) {
+      for (const Counted &c : genes) {
         const uint64_t g = c.gene;
         out += "    <gene protein=\"";
         xml_escaped(out, ord.protein(g));
@@ -588,14 +640,73 @@ kslam_status kslam_taxreport_xml(const kslam_taxreport *report, const kslam_inde
         out += "</gene>\n";
       }
       out += "  </genes>\n  <reads>\n";
-      for (const std::string &r : t.reads) {
+      for (const std::string_view &r : reads) {
         out += "    <read>";
         xml_escaped(out, r);
         out += "</read>\n";
       }
       out += "  </reads>\n</taxon>\n";
+    };
+    auto reads_of = [&](const Taxon &t, std::vector<std::string_view> &reads) {
+      reads.clear();
+      reads.reserve(t.to - t.from);
+      for (size_t i = t.from; i < t.to; i++) {
+        const uint32_t r = order[i];
+        if (report->has_read[r])
+          reads.emplace_back(report->names.data() + report->name_off[r], report->name_off[r + 1] - report->name_off[r]);
+      }
+    };
+    // taxa in parallel, the largest first; a group too large to be one task's (a run dominated by one organism) has its
+    // read names sorted by all threads first (equal names are indistinguishable, so any correct sort gives the text)
+    std::vector<uint32_t> by_size(taxa.size());
+    for (size_t i = 0; i < taxa.size(); i++) by_size[i] = (uint32_t)i;
+    std::sort(by_size.begin(), by_size.end(), [&](uint32_t a, uint32_t b) {
+      const size_t sa = taxa[a].to - taxa[a].from, sb = taxa[b].to - taxa[b].from;
+      return sa == sb ? a < b : sa > sb;
+    });
+    const size_t large = std::max<size_t>(1 << 18, n / std::max(1, threads));
+    size_t n_large = 0;
+    while (threads > 1 && n_large < by_size.size() && taxa[by_size[n_large]].to - taxa[by_size[n_large]].from > large) n_large++;
+    for (size_t k = 0; k < n_large; k++) {
+      Taxon &t = taxa[by_size[k]];
+      std::vector<std::string_view> reads;
+      reads_of(t, reads);
+      const size_t parts = (size_t)threads, m = reads.size(), step = (m + parts - 1) / parts;
+      Pool::get().tasks(threads, parts, [&](size_t c) {
+        if (c * step < m) std::sort(reads.begin() + c * step, reads.begin() + std::min(m, (c + 1) * step));
+      });
+      for (size_t width = step; width < m; width *= 2) {
+        const size_t merges = (m + 2 * width - 1) / (2 * width);
+        Pool::get().tasks(threads, merges, [&](size_t c) {
+          const size_t lo = c * 2 * width, mid = std::min(m, lo + width), hi = std::min(m, lo + 2 * width);
+          if (mid < hi) std::inplace_merge(reads.begin() + lo, reads.begin() + mid, reads.begin() + hi);
+        });
+      }
+      finish(t, reads, true);
     }
-    *text = dup_text(out, text_len);
+    Pool::get().tasks(threads, taxa.size() - n_large, [&](size_t k) {
+      Taxon &t = taxa[by_size[n_large + k]];
+      std::vector<std::string_view> reads;
+      reads_of(t, reads);
+      finish(t, reads, false);
+    });
+    // sortResults, src/MetagenomicResults.h:254-262 (a total order: taxonomy ids are distinct)
+    std::vector<uint32_t> rank(taxa.size());
+    for (size_t i = 0; i < taxa.size(); i++) rank[i] = (uint32_t)i;
+    std::sort(rank.begin(), rank.end(), [&](uint32_t a, uint32_t b) {
+      return taxa[a].n_reads == taxa[b].n_reads ? taxa[a].tax < taxa[b].tax : taxa[a].n_reads > taxa[b].n_reads;
+    });
+    std::vector<uint64_t> at(taxa.size() + 1, 0);
+    for (size_t i = 0; i < rank.size(); i++) at[i + 1] = at[i] + taxa[rank[i]].xml.size();
+    char *buf = (char *)malloc(at.back() + 1);
+    if (!buf) fail(KSLAM_ERR_OOM, "out of host memory");
+    Pool::get().tasks(threads, rank.size(), [&](size_t i) {
+      const std::string &x = taxa[rank[i]].xml;
+      memcpy(buf + at[i], x.data(), x.size());
+    });
+    buf[at.back()] = 0;
+    *text = buf;
+    *text_len = at.back();
   });
 }
 }

@@ -341,3 +341,42 @@ def test_xml_report(kslam, X, seed, distinct):
         assert max(c for t in taxa for _, c in t["genes"]) >= 3
     assert db.report_xml(X.Report(), index, extras, 10) == b""
     rep.close()
+
+
+def test_xml_report_with_one_dominant_taxon(kslam, X):
+    """A run dominated by one organism: its group of records is larger than one task's share, so its read names are
+    sorted by all threads (chunks, then merges) before the taxon's text is written; the other taxa go through the
+    parallel loop.  Names repeat and carry XML specials; the text must be the restatement's."""
+    T = importlib.import_module("kslam_amd.tail")
+    rng = np.random.default_rng(77)
+    text, ids = make_tree(rng, 30, dangling=0, duplicates=0)
+    db = X.TaxDB(text)
+    n_entries = 6
+    entry_tax = [int(ids[k]) for k in rng.choice(30, n_entries, replace=False)]
+    genes = [[{"start": 500 * k, "stop": 500 * k + 450, "name": b"g%d_%d" % (e, k), "protein": b"WP_%d_%d" % (e, k),
+               "product": b"p<%d>" % k, "locus": b"LT_%d_%d" % (e, k), "reference": b"NC_%06d" % e, "id": 10 * e + k}
+              for k in range(4)] for e in range(n_entries)]
+    flat = [g for gl in genes for g in gl]
+    index = T.Index([b"A" * 4000] * n_entries, taxonomy_ids=entry_tax,
+                    genes=[[(g["start"], g["stop"], g["name"], g["protein"], g["product"]) for g in gl] for gl in genes])
+    extras = X.GeneExtras.from_lists([g["locus"] for g in flat], [g["reference"] for g in flat], [g["id"] for g in flat])
+    rep, batches, n_total = X.Report(), [], 0
+    for b in range(2):
+        n = 160_000
+        rid = [b"r<%d>&%06d" % (b, int(v)) for v in rng.integers(0, 100_000, n)]
+        reads = T.Reads([b"A"] * (2 * n), ids=rid + rid)
+        rp = np.zeros(n, dtype=T.READ_PAIR_DT)
+        rp["r1_read"], rp["r2_read"], rp["first"], rp["count"] = np.arange(n), np.arange(n) + n, np.arange(n), 1
+        pr = np.zeros(n, dtype=T.PAIRED_OVERLAP_DT)
+        e = np.where(rng.random(n) < 0.92, 0, rng.integers(1, n_entries, n))
+        pr["entry"], pr["ref_start"] = e, rng.integers(0, 1900, n)
+        pr["ref_end"] = pr["ref_start"] + 120
+        tax = np.asarray(entry_tax, dtype=np.uint32)[e]
+        rep.add_batch(reads, index, rp, pr, tax)
+        batches.append((rid + rid, rp, pr))
+        n_total += n
+    got = db.report_xml(rep, index, extras, n_total)
+    exp, taxa = _xml_restatement(db, entry_tax, genes, extras, batches, n_total)
+    assert len(taxa[0]["reads"]) > 262144 and len(taxa) == n_entries
+    assert got == exp
+    rep.close()

@@ -58,6 +58,8 @@ typedef struct {
   double seconds_waiting_for_gpu, seconds_waiting_for_host_stage; /* main thread */
   double seconds_sam_text, seconds_classify, seconds_report;      /* host-stage thread, summed over the batches */
   double seconds_in_write;        /* writer thread inside write() */
+  double seconds_cutting, seconds_submitting; /* main thread: kslam_fastq_batch_end, kslam_submit_batch_fastq_text */
+  double seconds_closing;         /* main thread, after the last batch: the writer's queue drained, the file complete */
 } kslam_stream_stats;
 
 /* tax_ids: one taxonomy id per aligned read pair over all batches, in order (malloc'ed, kslam_free; NULL when taxdb

@@ -264,7 +264,7 @@ __device__ inline int32_t banded_attempt_reg(Seq &m, uint32_t *DW, uint32_t NL, 
 // cell, six cells per word, so the traceback -- a chain of dependent loads, one per step -- runs
 // at LDS latency.  Wider bands keep the directions in a global slab per block ([cell][lane],
 // coalesced, L2 resident), written fire-and-forget during the DP.
-template <int REG_BW>   // 0: rows in LDS, any band; 2 / 4: bands up to that width in registers
+template <int REG_BW>   // 0: rows in LDS, any band; 1 / 2 / 4: bands up to that width in registers
 __global__ __launch_bounds__(64) void k_banded_lds(CigJob J, SwInputs in, SwParams p, LdsLayout Y) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
   if (J.variant == 3) return;   // ablation: launch floor
@@ -888,12 +888,14 @@ void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, u
       if (lds > 160 * 1024) throw StatusError{KSLAM_ERR_UNSUPPORTED, "banded traceback band does not fit LDS"};
       if (lds > 64 * 1024)
         for (const void *f : {reinterpret_cast<const void *>(&k_banded_lds<0>),
+                              reinterpret_cast<const void *>(&k_banded_lds<1>),
                               reinterpret_cast<const void *>(&k_banded_lds<2>),
                               reinterpret_cast<const void *>(&k_banded_lds<4>)})
           HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       // narrow bands: the band in registers (KSLAM_CIGAR_REG=0 turns it off)
       const bool use_reg = tune.cigar_reg;
-      const uint32_t reg_bw = (!use_reg || big || Y.wpr) ? 0u : (slot_bw <= 2 ? 2u : (slot_bw <= 4 ? 4u : 0u));
+      // (a class-0 candidate has band 1: three slots, not the five of the band-2 instantiation it used to share)
+      const uint32_t reg_bw = (!use_reg || big || Y.wpr) ? 0u : (slot_bw <= 1 ? 1u : (slot_bw <= 2 ? 2u : (slot_bw <= 4 ? 4u : 0u)));
       uint64_t slab = Y.wpr ? 256 : (uint64_t)lmax * std::max<uint32_t>(Y.wd, reg_bw ? 8u : 0u) * nl;   // direction
       slab = (slab + 255) & ~255ull;   // bytes per block; the register variant stores <= 8 bytes per row and lane
       const uint64_t SCRATCH_BUDGET = 3ull << 30;
@@ -918,7 +920,8 @@ void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, u
 #ifdef KSLAM_ABLATE
         J.variant = tune.cigar_variant;
 #endif
-        if (reg_bw == 2) hipLaunchKernelGGL(k_banded_lds<2>, dim3((unsigned)nb_here), dim3(64), lds, s, J, in, p, Y);
+        if (reg_bw == 1) hipLaunchKernelGGL(k_banded_lds<1>, dim3((unsigned)nb_here), dim3(64), lds, s, J, in, p, Y);
+        else if (reg_bw == 2) hipLaunchKernelGGL(k_banded_lds<2>, dim3((unsigned)nb_here), dim3(64), lds, s, J, in, p, Y);
         else if (reg_bw == 4) hipLaunchKernelGGL(k_banded_lds<4>, dim3((unsigned)nb_here), dim3(64), lds, s, J, in, p, Y);
         else hipLaunchKernelGGL(k_banded_lds<0>, dim3((unsigned)nb_here), dim3(64), lds, s, J, in, p, Y);
       }

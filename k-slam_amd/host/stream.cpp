@@ -112,9 +112,11 @@ extern "C" kslam_status kslam_stream_classify(kslam_ctx *ctx, const kslam_index_
       }
       uint64_t e1 = 0, e2 = 0;
       int c1 = 0, c2 = 0;
+      const double tc = now_ms();
       if (kslam_fastq_batch_end(r1 + p1, len1 - p1, want, 1, P->tail.threads, &e1, &c1) != KSLAM_OK ||
           kslam_fastq_batch_end(r2 + p2, len2 - p2, want, 1, P->tail.threads, &e2, &c2) != KSLAM_OK)
         fail(KSLAM_ERR_ARG, kslam_tail_last_error());
+      st.seconds_cutting += (now_ms() - tc) * 1e-3;
       *w = Window{p1, p1 + e1, p2, p2 + e2};
       done_pairs += want;
       p1 += e1;
@@ -180,10 +182,12 @@ extern "C" kslam_status kslam_stream_classify(kslam_ctx *ctx, const kslam_index_
       Window w;
       while (tickets.size() < depth && next_window(&w)) {
         uint64_t tk = 0;
+        const double tsub = now_ms();
         // "at end of stream" for inner windows too: a window ends right after a terminator (kslam_fastq_batch_end looked at
         // the byte behind a closing "\r"), so the end-of-stream rule adds nothing and keeps that "\r" a whole terminator
         if (kslam_submit_batch_fastq_text(ctx, r1 + w.p1, w.e1 - w.p1, r2 + w.p2, w.e2 - w.p2, 0, 1, &tk) != KSLAM_OK)
           fail(KSLAM_ERR_STATE, kslam_last_error(ctx));
+        st.seconds_submitting += (now_ms() - tsub) * 1e-3;
         tickets.push_back(tk);
       }
       if (tickets.empty()) break;
@@ -215,7 +219,9 @@ extern "C" kslam_status kslam_stream_classify(kslam_ctx *ctx, const kslam_index_
     if (worker_status != KSLAM_OK) fail(worker_status, worker_error);
   });
 
+  const double t_close = now_ms();
   const kslam_status closing = wind_down();
+  st.seconds_closing = (now_ms() - t_close) * 1e-3;
   st.seconds = (now_ms() - t_begin) * 1e-3;
   if (stats) *stats = st;
   if (status != KSLAM_OK) return status;

@@ -47,7 +47,8 @@ class StreamStats(C.Structure):
                 ("first_max_insert_size", C.c_uint32), ("batches_pseudo_on_host", C.c_uint32), ("seconds", C.c_double),
                 ("seconds_waiting_for_gpu", C.c_double), ("seconds_waiting_for_host_stage", C.c_double),
                 ("seconds_sam_text", C.c_double), ("seconds_classify", C.c_double), ("seconds_report", C.c_double),
-                ("seconds_in_write", C.c_double)]
+                ("seconds_in_write", C.c_double), ("seconds_cutting", C.c_double), ("seconds_submitting", C.c_double),
+                ("seconds_closing", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -178,6 +178,31 @@ class FastqFiles:
             x.close()
 
 
+def thread_cpu():
+    """CPU seconds (user + system) of this process's threads, summed by thread name (/proc/self/task/*/stat)."""
+    out, tick = {}, os.sysconf("SC_CLK_TCK")
+    for tid in os.listdir("/proc/self/task"):
+        try:
+            st = open("/proc/self/task/%s/stat" % tid).read()
+        except OSError:
+            continue
+        name = st[st.index("(") + 1:st.rindex(")")]
+        f = st[st.rindex(")") + 2:].split()
+        out[name] = out.get(name, 0.0) + (int(f[11]) + int(f[12])) / tick
+    return out
+
+
+def cgroup_throttled_ms():
+    """Milliseconds this container's CPU quota has stalled it so far (cgroup v2 cpu.stat), or None."""
+    try:
+        for line in open("/sys/fs/cgroup/cpu.stat"):
+            if line.startswith("throttled_usec"):
+                return int(line.split()[1]) / 1e3
+    except OSError:
+        pass
+    return None
+
+
 def fresh_file(path):
     if os.path.exists(path):
         os.unlink(path)
@@ -241,12 +266,15 @@ def e2e_leg(K, ctx, files, pairs_per_batch, index_view, taxdb, steps, warmup, ps
         sam_fd = os.open(sam_path, os.O_WRONLY) if discard else fresh_file(sam_path)
         pr_fd = fresh_file(pr_path)
         torch.cuda.synchronize()
+        cpu0, thr0 = thread_cpu(), cgroup_throttled_ms()
         t0 = time.perf_counter()
         if native:
             # the loop inside the library (kslam_stream_classify); a text of F batches is read ceil(n_steps / F) times over
             res = S.classify_stream_native(ctx, index_view, files.h[0].ptr, files.len, files.h[1].ptr, files.len, pairs_per_batch, P,
                                            taxdb=taxdb, report=report, sam_fd=sam_fd, per_read_fd=pr_fd, sam_header=header,
-                                           max_pairs_total=n_steps * pairs_per_batch, passes=-(-n_steps // F))
+                                           max_pairs_total=n_steps * pairs_per_batch, passes=-(-n_steps // F),
+                                           host_threads=int(os.environ.get("KSLAM_BENCH_HOST_THREADS", "0")),
+                                           pool_threads=int(os.environ.get("KSLAM_BENCH_POOL_THREADS", "0")))
             res.update(pairs=res["n_pairs"], per_read_bytes=res["per_read_bytes"], s_in_write=res["seconds_in_write"],
                        s_waiting_for_gpu=round(res["seconds_waiting_for_gpu"], 4),
                        s_waiting_for_host_stage=round(res["seconds_waiting_for_host_stage"], 4),
@@ -265,6 +293,9 @@ def e2e_leg(K, ctx, files, pairs_per_batch, index_view, taxdb, steps, warmup, ps
         os.close(pr_fd)
         torch.cuda.synchronize()
         res["wall"] = time.perf_counter() - t0
+        cpu1, thr1 = thread_cpu(), cgroup_throttled_ms()
+        res["cgroup_throttled_ms"] = None if thr0 is None or thr1 is None else round(thr1 - thr0, 1)
+        res["cpu_s_by_thread"] = {k: round(v - cpu0.get(k, 0.0), 3) for k, v in sorted(cpu1.items()) if v - cpu0.get(k, 0.0) >= 0.005}
         res["s_call_and_close"] = [round(t_call, 4), round(res["wall"] - t_call, 4), round(res.get("seconds", 0.0), 4)]
         res["sam_file_bytes"] = (res.get("sam_bytes_written") or res.get("sam_bytes", 0) + len(header)) if discard else os.path.getsize(sam_path)
         res["per_read_file_bytes"] = os.path.getsize(pr_path)
@@ -306,6 +337,7 @@ def e2e_leg(K, ctx, files, pairs_per_batch, index_view, taxdb, steps, warmup, ps
             "sink": sam_path.rsplit("/", 1)[0],
             "s_main_thread_waiting_for_gpu": med["s_waiting_for_gpu"], "s_main_thread_waiting_for_host_stage": med["s_waiting_for_host_stage"],
             "s_main_thread_other": med.get("s_main"), "s_call_close_library": med.get("s_call_and_close"),
+            "cpu_s_by_thread": med.get("cpu_s_by_thread"), "cgroup_throttled_ms": med.get("cgroup_throttled_ms"),
             "end_of_run_reports_s": round(t_end, 3), "end_of_run_report_bytes": {"abbreviated": len(summary), "xml": len(xml)},
             "including_end_of_run_reports": {"reads_per_s": round(n_reads / (last["wall"] + t_end), 1)},
             "verified": {"repetitions_identical": bool(same), "sam_file_bytes": int(runs[0]["sam_file_bytes"]),

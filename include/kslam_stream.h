@@ -41,6 +41,11 @@ typedef struct {
   const char *sam_header;   /* getHeader's text (kslam_sam_header), written first when sam_fd >= 0; may be NULL */
   uint64_t sam_header_len;
   uint32_t depth;           /* batches in flight; 0 = 3 */
+  uint32_t host_threads;    /* 0 or 2: a batch's SAM text and its taxonomy part (LCA, _PerRead, report) on two threads at the same
+                               time; 1: one after the other on one thread */
+  uint32_t pool_threads;    /* threads of the host stages' parallel loops while the call runs; 0 = the CPUs the process may use
+                               minus four (the SAM writer, the two lanes and the second host thread are busy next to the loops:
+                               more runnable threads than a cgroup CPU quota has CPUs get the whole process throttled) */
   uint32_t passes;          /* 0 or 1: the files once; n: the two texts read n times over, as if they were n copies long
                                (timing runs: a longer stream without a longer text; max_pairs_total counts over all passes) */
 } kslam_stream_params;
@@ -56,7 +61,8 @@ typedef struct {
   uint32_t batches_pseudo_on_host; /* batches whose pseudo-assembly the device left to the host (an entry too large) */
   double seconds;                 /* the whole call */
   double seconds_waiting_for_gpu, seconds_waiting_for_host_stage; /* main thread */
-  double seconds_sam_text, seconds_classify, seconds_report;      /* host-stage thread, summed over the batches */
+  double seconds_sam_text, seconds_classify, seconds_report;      /* host stage, summed over the batches (the SAM text on one
+                                                                     thread, classification + report on another, concurrently) */
   double seconds_in_write;        /* writer thread inside write() */
   double seconds_cutting, seconds_submitting; /* main thread: kslam_fastq_batch_end, kslam_submit_batch_fastq_text */
   double seconds_closing;         /* main thread, after the last batch: the writer's queue drained, the file complete */

@@ -51,6 +51,7 @@ struct Tuning {
   bool sort_digit_bytes = true;       // KSLAM_SORT_DIGIT_BYTES=0: histograms re-read the records
   int lanes = 2;                      // KSLAM_LANES
   bool eager_cigar = false;           // KSLAM_EAGER_CIGAR
+  bool lane_waits_yield = true;       // KSLAM_LANE_WAITS=spin: the pipeline lanes busy-wait for the GPU like the direct calls (stream_wait)
   bool pageable_columns = false;      // KSLAM_PAGEABLE_COLUMNS
 #ifdef KSLAM_ABLATE
   uint32_t sw_ablate = 0, cigar_variant = 0, filter_ablate = 0;   // KSLAM_SW_ABLATE / _CIGAR_VARIANT / _FILTER_ABLATE
@@ -159,6 +160,30 @@ struct SortPass {
   uint32_t shift;   // bit shift inside the word
   uint32_t invert;  // XOR mask applied to the word first (descending keys)
 };
+// Waiting for a stream.  hipStreamSynchronize spins on the completion signal: the fastest wake-up, and what a caller
+// that has nothing else to do wants (kslam_align_batch, the resident bench).  A pipeline lane waits while the host
+// stage of an earlier batch needs every CPU the process may use (a 16-CPU cgroup quota on the bench boxes: the two
+// lanes' spinning was 19 % of the process's CPU time, tools/cpu_sampler.c), so its thread sets `yield` and waits on
+// an event created with hipEventBlockingSync instead (an interrupt, some tens of microseconds later).
+struct WaitMode {
+  bool yield = false;
+  hipEvent_t ev = nullptr;
+  ~WaitMode() { if (ev) (void)hipEventDestroy(ev); }
+};
+inline WaitMode &wait_mode() {
+  static thread_local WaitMode w;
+  return w;
+}
+inline hipError_t stream_wait(hipStream_t s) {
+  WaitMode &w = wait_mode();
+  if (!w.yield) return hipStreamSynchronize(s);
+  hipError_t e = hipSuccess;
+  if (!w.ev) e = hipEventCreateWithFlags(&w.ev, hipEventBlockingSync | hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventRecord(w.ev, s);
+  if (e == hipSuccess) e = hipEventSynchronize(w.ev);
+  return e;
+}
+
 // Device -> host copy of a few bytes the host has to look at before it can launch the next kernel
 // (list sizes, counts).  Through a small page-locked buffer: a copy into pageable memory goes through
 // the runtime's staging path and costs tens of microseconds more per look, with the GPU idle.
@@ -168,7 +193,7 @@ inline void read_back(void *dst, const void *d_src, size_t bytes, hipStream_t s)
   if (bytes > CAP) throw StatusError{KSLAM_ERR_INTERNAL, "read_back: more than 256 bytes"};
   if (!pinned) HIPCHK(hipHostMalloc(&pinned, CAP, hipHostMallocDefault));
   HIPCHK(hipMemcpyAsync(pinned, d_src, bytes, hipMemcpyDeviceToHost, s));
-  HIPCHK(hipStreamSynchronize(s));
+  HIPCHK(stream_wait(s));
   memcpy(dst, pinned, bytes);
 }
 

@@ -277,7 +277,7 @@ void fastq_index_device(const uint8_t *d_text, uint64_t len1, uint64_t len2, con
   if (n) hipLaunchKernelGGL(k_fq_ids, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_text, W.id_at.as<uint64_t>(),
                             W.id_len.as<uint32_t>(), W.ids_off.as<uint64_t>(), n, W.ids.as<uint8_t>());
   HIPCHK(hipGetLastError());
-  HIPCHK(hipStreamSynchronize(s));   // b_total / i_total are read by the copies above
+  HIPCHK(stream_wait(s));   // b_total / i_total are read by the copies above
   for (int k = 0; k < 2; k++) {
     // short of max_pairs at the true end of the stream, the reference's loop has read on to the end
     if (at_eof && (!max_pairs || st[k].n < max_pairs)) res->consumed[k] = st[k].len;

@@ -169,6 +169,7 @@ Tuning read_tuning() {
   t.sort_digit_bytes = !starts("KSLAM_SORT_DIGIT_BYTES", '0');
   t.lanes = std::min(8, std::max(1, num("KSLAM_LANES", 2)));
   t.eager_cigar = flag("KSLAM_EAGER_CIGAR");
+  t.lane_waits_yield = !starts("KSLAM_LANE_WAITS", 's');
   t.pageable_columns = flag("KSLAM_PAGEABLE_COLUMNS");
 #ifdef KSLAM_ABLATE
   t.sw_ablate = (uint32_t)num("KSLAM_SW_ABLATE", 0);
@@ -220,7 +221,7 @@ void ensure_keep(DevBuf &b, size_t bytes, size_t used, hipStream_t s) {
   nb.ensure(bytes + bytes / 2);
   if (used && b.p) {
     HIPCHK(hipMemcpyAsync(nb.p, b.p, used, hipMemcpyDeviceToDevice, s));
-    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(stream_wait(s));
   }
   b.release();
   b = nb;
@@ -447,7 +448,7 @@ void build_index(kslam_ctx *c) {
       filter_build(c->gk_key.as<uint64_t>(), (uint32_t)m, fb, c->g_filter.p, s);
     }
   }
-  HIPCHK(hipStreamSynchronize(s));
+  HIPCHK(stream_wait(s));
   c->kept_last = 0;
   c->have_index = true;
   for (auto *l : c->lanes) share_index(l->c, c);   // (no batch may be in flight across kslam_set_index)
@@ -497,7 +498,7 @@ void finish_load_reads(kslam_ctx *c) {
   c->r_len.ensure((n + 1) * sizeof(uint32_t));
   if (n) hipLaunchKernelGGL(k_lens, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, c->r_off.as<uint64_t>(), n,
                             c->r_len.as<uint32_t>());
-  HIPCHK(hipStreamSynchronize(s));
+  HIPCHK(stream_wait(s));
   c->have_reads = true;
   c->have_qual = false;      // a new batch: its quality strings have not been loaded
   c->have_details = false;
@@ -736,7 +737,7 @@ void align_resident(kslam_ctx *c, bool stop_after_join, uint64_t *n_raw_out, Pai
       HIPCHK(hipEventRecord(c->ev[6], s));
     }
     HIPCHK(hipEventRecord(c->ev[7], s));
-    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(stream_wait(s));
     tm.ms_extract += ev_ms(c->ev[0], c->ev[1]);
     tm.ms_sort += ev_ms(c->ev[1], c->ev[4]);
     if (nk) for (size_t q = 0; q < kpasses.size(); q++) tm.ms_sort_scatter += ev_ms(c->evs0[q], c->evs1[q]);
@@ -778,7 +779,7 @@ void align_resident(kslam_ctx *c, bool stop_after_join, uint64_t *n_raw_out, Pai
       c->n_cig += ncig;
     }
     HIPCHK(hipEventRecord(c->ev[7], s));
-    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(stream_wait(s));
     tm.ms_cigar += ev_ms(c->ev[6], c->ev[7]);
     tm.ms_total += ev_ms(c->ev[6], c->ev[7]);
   }
@@ -923,7 +924,7 @@ kslam_status load_reads_from_fastq_text(kslam_ctx *c, kslam_ctx::AsyncJob *job) 
                   c->r_bases.as<uint8_t>(), c->r_qual.as<uint8_t>(), s);
     HIPCHK(hipMemsetAsync(c->r_bases.as<uint8_t>() + ix.bases_total, 0, 64, s));
     HIPCHK(hipMemsetAsync(c->r_qual.as<uint8_t>() + ix.bases_total, 0, 64, s));
-    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(stream_wait(s));
     job->r_ids[ix.ids_total] = 0;
     c->h_roff.assign(job->r_off, job->r_off + n + 1);
     finish_load_reads(c);
@@ -942,6 +943,8 @@ void fill_pair_stats(const PairResult &r, kslam_pair_stats *st) {
 }
 
 void lane_main(kslam_ctx *primary, kslam_ctx::AsyncLane *lane) {
+  kslam_host::name_thread("kslam-lane");
+  wait_mode().yield = primary->tune.lane_waits_yield;   // common.h: stream_wait
   for (;;) {
     kslam_ctx::AsyncJob *job = nullptr;
     {
@@ -1187,7 +1190,7 @@ kslam_status kslam_adopt_results_device(kslam_ctx *c, const void *d_overlaps, ui
     c->res_cig.ensure((n_cigar + 1) * sizeof(uint32_t));
     if (n_overlaps) HIPCHK(hipMemcpyAsync(c->res_ov.p, d_overlaps, n_overlaps * sizeof(kslam_overlap), hipMemcpyDeviceToDevice, s));
     if (n_cigar) HIPCHK(hipMemcpyAsync(c->res_cig.p, d_cigar_pool, n_cigar * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
-    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(stream_wait(s));
     c->n_res = n_overlaps;
     c->n_cig = n_cigar;
   });
@@ -1218,7 +1221,7 @@ kslam_status kslam_set_index(kslam_ctx *c, uint64_t n_entries, const char *const
         HIPCHK(hipMemcpyAsync(c->g_bases.as<uint8_t>() + c->h_goff[i], bases[i], lens[i], hipMemcpyHostToDevice,
                               c->stream));
     HIPCHK(hipMemsetAsync(c->g_bases.as<uint8_t>() + total, 0, 64, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(stream_wait(c->stream));
     build_index(c);
   });
 }
@@ -1289,7 +1292,7 @@ kslam_status kslam_fetch_results(kslam_ctx *c, kslam_overlap *out, uint32_t *cig
       HIPCHK(hipMemcpyAsync(out, c->res_ov.p, c->n_res * sizeof(kslam_overlap), hipMemcpyDeviceToHost, c->stream));
     if (c->n_cig && cigar_pool)
       HIPCHK(hipMemcpyAsync(cigar_pool, c->res_cig.p, c->n_cig * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(stream_wait(c->stream));
   });
 }
 
@@ -1321,7 +1324,7 @@ kslam_status kslam_copy_results_device(kslam_ctx *c, void *d_overlaps, void *d_c
     if (c->n_cig && d_cigar_pool)
       HIPCHK(hipMemcpyAsync(d_cigar_pool, c->res_cig.p, c->n_cig * sizeof(uint32_t), hipMemcpyDeviceToDevice,
                             c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(stream_wait(c->stream));
   });
 }
 
@@ -1381,7 +1384,7 @@ kslam_status kslam_load_qualities(kslam_ctx *c, const char *concat_quality) {
     c->r_qual.ensure(total + 64);
     if (total) HIPCHK(hipMemcpyAsync(c->r_qual.p, concat_quality, total, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemsetAsync(c->r_qual.as<uint8_t>() + total, 0, 64, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(stream_wait(c->stream));
     c->have_qual = true;
     c->have_details = false;
   });
@@ -1395,7 +1398,7 @@ kslam_status kslam_load_qualities_device(kslam_ctx *c, const void *d_concat_qual
     c->r_qual.ensure(total + 64);
     if (total) HIPCHK(hipMemcpyAsync(c->r_qual.p, d_concat_quality, total, hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(hipMemsetAsync(c->r_qual.as<uint8_t>() + total, 0, 64, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(stream_wait(c->stream));
     c->have_qual = true;
     c->have_details = false;
   });
@@ -1418,7 +1421,7 @@ static kslam_status row_details_impl(kslam_ctx *c, uint64_t *n_md, bool of_pairs
       }
       c->d_tables.ensure(sizeof t);
       HIPCHK(hipMemcpyAsync(c->d_tables.p, t, sizeof t, hipMemcpyHostToDevice, c->stream));
-      HIPCHK(hipStreamSynchronize(c->stream));
+      HIPCHK(stream_wait(c->stream));
     }
     c->res_det.ensure((c->n_res + 1) * sizeof(kslam_row_detail));
     const uint32_t *d_list = nullptr;
@@ -1431,7 +1434,7 @@ static kslam_status row_details_impl(kslam_ctx *c, uint64_t *n_md, bool of_pairs
                 c->r_qual.as<uint8_t>(), c->r_off.as<uint64_t>(), c->g_bases.as<uint8_t>(), c->g_off.as<uint64_t>(),
                 c->d_tables.as<double>(), c->res_det.as<kslam_row_detail>(), c->detw, &c->d_md_pool, &c->n_md,
                 &c->det_flags, c->stream, d_list, n_list);
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(stream_wait(c->stream));
     c->have_details = true;
     if (n_md) *n_md = c->n_md;
   });
@@ -1451,7 +1454,7 @@ kslam_status kslam_take_row_details(kslam_ctx *c, kslam_row_detail **details, ch
     hm = (char *)pinned_get(c, c->n_md + 64);
     if (c->n_res) HIPCHK(hipMemcpyAsync(hd, c->res_det.p, c->n_res * sizeof(kslam_row_detail), hipMemcpyDeviceToHost, c->stream));
     if (c->n_md) HIPCHK(hipMemcpyAsync(hm, c->d_md_pool, c->n_md, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(stream_wait(c->stream));
   });
   if (st != KSLAM_OK) {
     if (hd) pinned_put(c, hd);
@@ -1483,7 +1486,7 @@ kslam_status kslam_pair_screen(kslam_ctx *c, int paired, uint32_t score_threshol
                     score_threshold, score_fraction, (stages & 1u) != 0, (stages & 2u) != 0, c->pw, c->sortws, &c->pres,
                     c->stream);
     if (stages & 4u) pseudo_and_rescreen(c->pw, &c->pres, score_fraction, c->sortws, c->stream);
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(stream_wait(c->stream));
     c->have_pairs = c->pairs_of_result = true;
     fill_pair_stats(c->pres, stats);
   });
@@ -1501,7 +1504,7 @@ kslam_status kslam_pair_phase_a(kslam_ctx *c, int paired, uint32_t score_thresho
     c->have_pairs = c->pairs_of_result = false;
     pair_phase_a(c->res_ov.as<kslam_overlap>(), c->n_res, c->r_len.as<uint32_t>(), c->n_reads, paired ? 1 : 0, score_threshold, c->pw,
                  &c->pres, c->stream);
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(stream_wait(c->stream));
     c->phase_a_done = true;
     *d_inserts = c->pw.inserts.as<int32_t>();
     *n_inserts = c->pres.n_insert_sizes;
@@ -1518,7 +1521,7 @@ kslam_status kslam_pair_phase_b(kslam_ctx *c, const int32_t *d_all_inserts, uint
     const bool do_insert = (stages & 1u) != 0;
     if (do_insert && c->pw.paired) limit = insert_limit_device(d_all_inserts, n_all, c->pw, c->sortws, c->stream);
     pair_phase_b(c->res_ov.as<kslam_overlap>(), limit, score_fraction, do_insert, (stages & 2u) != 0, c->pw, &c->pres, c->stream);
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(stream_wait(c->stream));
     c->pres.n_insert_sizes = n_all;
     c->have_pairs = c->pairs_of_result = true;
     fill_pair_stats(c->pres, stats);
@@ -1533,7 +1536,7 @@ kslam_status kslam_pseudo_merged(kslam_ctx *c, void *d_all_pairs, uint64_t n_all
     if (!(c->have_pairs && c->pairs_of_result)) throw StatusError{KSLAM_ERR_STATE, "kslam_pair_phase_b has not been called for this result"};
     if (n_all && !d_all_pairs) throw StatusError{KSLAM_ERR_ARG, "null records"};
     pseudo_merged(c->pw, &c->pres, d_all_pairs, n_all, own_base, score_fraction, c->sortws, c->stream);
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(stream_wait(c->stream));
     fill_pair_stats(c->pres, stats);
   });
 }
@@ -1557,7 +1560,7 @@ kslam_status kslam_pair_screen_overlaps(kslam_ctx *c, const kslam_overlap *overl
                     score_threshold, score_fraction, (stages & 1u) != 0, (stages & 2u) != 0, c->pw, c->sortws, &c->pres,
                     c->stream);
     if (stages & 4u) pseudo_and_rescreen(c->pw, &c->pres, score_fraction, c->sortws, c->stream);
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(stream_wait(c->stream));
     c->have_pairs = true;
     fill_pair_stats(c->pres, stats);
   });
@@ -1577,7 +1580,7 @@ kslam_status kslam_take_pairs(kslam_ctx *c, kslam_read_pair **read_pairs, uint64
       HIPCHK(hipMemcpyAsync(hg, c->pres.d_groups, c->pres.n_read_pairs * sizeof(kslam_read_pair), hipMemcpyDeviceToHost, c->stream));
     if (c->pres.n_pairs)
       HIPCHK(hipMemcpyAsync(hp, c->pres.d_pairs, c->pres.n_pairs * sizeof(kslam_paired_overlap), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(stream_wait(c->stream));
   });
   if (st != KSLAM_OK) {
     if (hg) pinned_put(c, hg);
@@ -1872,7 +1875,7 @@ kslam_status kslam_merge_shards_device(kslam_ctx *c, uint32_t n_shards, const ks
     merge_shards((const kslam_overlap *)d_overlaps, rows, (const uint32_t *)d_cigar_pools, c->mg_shards.as<MergeShard>(),
                  n_shards, n_pairs, (kslam_overlap *)d_out_overlaps, (uint32_t *)d_out_cigars, c->mg_lens.as<uint32_t>(),
                  c->mg_off.as<uint64_t>(), c->totals.as<uint64_t>() + 4, c->mg_scan.p, s);
-    HIPCHK(hipStreamSynchronize(s));   // h[] is read by the copy above
+    HIPCHK(stream_wait(s));   // h[] is read by the copy above
   });
 }
 
@@ -1915,7 +1918,7 @@ kslam_status kslam_export_shard_device(kslam_ctx *c, uint64_t n_local_pairs, uin
     if (sc.n_cigar > sc.n_cigar_r1)
       HIPCHK(hipMemcpyAsync(d_pool_r2, c->res_cig.as<uint32_t>() + sc.n_cigar_r1,
                             (sc.n_cigar - sc.n_cigar_r1) * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(stream_wait(c->stream));
   });
 }
 
@@ -2050,7 +2053,7 @@ kslam_status kslam_multi_align_batch(kslam_multi *m, uint64_t n_reads, const cha
       if (n2) HIPCHK(hipMemcpyPeerAsync(fo + row2[k], c0->device, so + n1, ck->device, n2 * sizeof(kslam_overlap), ck->stream));
       if (c1) HIPCHK(hipMemcpyPeerAsync(fp + op1[k], c0->device, sp, ck->device, c1 * sizeof(uint32_t), ck->stream));
       if (c2) HIPCHK(hipMemcpyPeerAsync(fp + op2[k], c0->device, sp + c1, ck->device, c2 * sizeof(uint32_t), ck->stream));
-      HIPCHK(hipStreamSynchronize(ck->stream));
+      HIPCHK(stream_wait(ck->stream));
     });
   });
   if (st != KSLAM_OK) return st;
@@ -2059,7 +2062,7 @@ kslam_status kslam_multi_align_batch(kslam_multi *m, uint64_t n_reads, const cha
     hc = (uint32_t *)pinned_get(c0, (ops + 1) * sizeof(uint32_t));
     if (rows) HIPCHK(hipMemcpyAsync(ho, m->rows_out.p, rows * sizeof(kslam_overlap), hipMemcpyDeviceToHost, c0->stream));
     if (ops) HIPCHK(hipMemcpyAsync(hc, m->pool_out.p, ops * sizeof(uint32_t), hipMemcpyDeviceToHost, c0->stream));
-    HIPCHK(hipStreamSynchronize(c0->stream));
+    HIPCHK(stream_wait(c0->stream));
   });
   if (st != KSLAM_OK) {
     if (ho) pinned_put(c0, ho);
@@ -2097,7 +2100,7 @@ kslam_status kslam_extract_kmers(kslam_ctx *c, uint64_t n, const char *const *ba
     HIPCHK(hipMemcpyAsync(doff.p, off.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s));
     run_extract(c, db.as<uint8_t>(), doff.as<uint64_t>(), n, gap, is_from_genbank, pl.n_segs, drec.as<uint4>());
     HIPCHK(hipMemcpyAsync(out, drec.p, pl.n_kmers * sizeof(uint4), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(stream_wait(s));
     db.release(); doff.release(); drec.release();
   });
 }
@@ -2116,7 +2119,7 @@ kslam_status kslam_sort_kmers(kslam_ctx *c, kslam_kmer *recs, uint64_t n) {
     void *sorted = radix_sort(a.p, b.p, n, 4, passes.data(), (int)passes.size(), c->sortws, s, nullptr, nullptr,
                               nullptr);
     HIPCHK(hipMemcpyAsync(recs, sorted, n * sizeof(uint4), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(stream_wait(s));
     a.release(); b.release();
   });
 }
@@ -2143,7 +2146,7 @@ kslam_status kslam_selftest_sort(kslam_ctx *c, uint64_t n, uint32_t iters, float
                           c->ev[3], &launches);
       c->sortws.ev_sc0 = nullptr; c->sortws.ev_sc1 = nullptr;
       HIPCHK(hipEventRecord(c->ev[1], s));
-      HIPCHK(hipStreamSynchronize(s));
+      HIPCHK(stream_wait(s));
       tot += ev_ms(c->ev[0], c->ev[1]);
       for (size_t q = 0; q < passes.size(); q++) tot_sc += ev_ms(c->evs0[q], c->evs1[q]);
     }
@@ -2173,7 +2176,7 @@ kslam_status kslam_find_overlaps(kslam_ctx *c, kslam_overlap_temp **out, uint64_
       hipLaunchKernelGGL(k_to_temp, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream,
                          c->res_ov.as<kslam_overlap>(), m, c->res_tmp.as<kslam_overlap_temp>());
       HIPCHK(hipMemcpyAsync(h, c->res_tmp.p, m * sizeof(kslam_overlap_temp), hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(hipStreamSynchronize(c->stream));
+      HIPCHK(stream_wait(c->stream));
     }
     *out = h;
     *n_out = m;

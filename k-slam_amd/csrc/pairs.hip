@@ -639,7 +639,7 @@ void debug_wave_sort(const int32_t *keys, const uint64_t *seg_off, uint64_t n_se
                      dk.as<int32_t>(), doff.as<uint64_t>(), dp.as<uint32_t>(), dscratch.as<PSpan>());
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(perm, dp.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-  HIPCHK(hipStreamSynchronize(s));
+  HIPCHK(stream_wait(s));
 }
 
 // getMaxAllowedInsertSize on the device-resident insert sizes (host/tail.cpp: max_allowed_insert)
@@ -664,7 +664,7 @@ static uint32_t max_allowed_insert_device(int32_t *d_ins, uint64_t n, PairWork &
   hipLaunchKernelGGL(k_pick, dim3(1), dim3(128), 0, s, sorted, W.idx.as<uint64_t>(), 102u, W.picked.as<int32_t>());
   int32_t v[102];
   HIPCHK(hipMemcpyAsync(v, W.picked.p, sizeof v, hipMemcpyDeviceToHost, s));
-  HIPCHK(hipStreamSynchronize(s));
+  HIPCHK(stream_wait(s));
   int32_t limit = 0;
   for (int i = 0; i < 99; i++)
     if (v[i + 1] - v[i] > 1000) {
@@ -682,7 +682,7 @@ static uint32_t max_allowed_insert_device(int32_t *d_ins, uint64_t n, PairWork &
   hipLaunchKernelGGL(k_insert_sums, dim3(nb), dim3(256), 0, s, sorted, n, lo, hi, d_sums);
   long long h[4];
   HIPCHK(hipMemcpyAsync(h, d_sums, sizeof h, hipMemcpyDeviceToHost, s));
-  HIPCHK(hipStreamSynchronize(s));
+  HIPCHK(stream_wait(s));
   const long long t1 = h[0], t2 = h[1], tm = h[2], kept = h[3];
   double sum, sq;
   if (tm < (1ll << 53) && std::llabs(t1) < (1ll << 53)) {
@@ -692,7 +692,7 @@ static uint32_t max_allowed_insert_device(int32_t *d_ins, uint64_t n, PairWork &
     // beyond 2^53 the reference's result depends on its order of additions: do them in that order
     std::vector<uint2> hs(n);
     HIPCHK(hipMemcpyAsync(hs.data(), sorted, n * sizeof(uint2), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(stream_wait(s));
     sum = 0;
     sq = 0;
     for (uint64_t i = 0; i < n; i++) {
@@ -742,7 +742,7 @@ void pair_phase_a(const kslam_overlap *d_ov, uint64_t n, const uint32_t *d_read_
   hipLaunchKernelGGL(k_pair, dim3(nb), dim3(256), 0, s, a);
   uint64_t h[3];
   HIPCHK(hipMemcpyAsync(h, tot + 4, sizeof h, hipMemcpyDeviceToHost, s));
-  HIPCHK(hipStreamSynchronize(s));
+  HIPCHK(stream_wait(s));
   res->n_insert_sizes = h[0];
   res->n_overlaps_screened = h[1];
   res->n_paired_initial = h[2];
@@ -772,7 +772,7 @@ void pair_phase_b(const kslam_overlap *d_ov, uint32_t limit, double score_fracti
   exclusive_scan_u32_to_u64(W.count.as<uint32_t>(), W.rpos.as<uint64_t>(), units, tot + 9, W.scan_tmp.p, s);
   uint64_t g2[2];
   HIPCHK(hipMemcpyAsync(g2, tot + 8, sizeof g2, hipMemcpyDeviceToHost, s));
-  HIPCHK(hipStreamSynchronize(s));
+  HIPCHK(stream_wait(s));
   res->n_read_pairs = g2[0];
   res->n_pairs = g2[1];
   W.groups.ensure((g2[0] + 1) * sizeof(kslam_read_pair));

@@ -55,6 +55,7 @@ extern "C" kslam_status kslam_stream_classify(kslam_ctx *ctx, const kslam_index_
   std::vector<uint32_t> all_ids;
   bool pairing_set = false;
 
+  Pool::get().set_cap(P && P->pool_threads ? (int)P->pool_threads : std::max(2, usable_cpus() - 4));
   // whatever happens: the worker joined, the tickets collected and released, the writer closed, the pairing switched off
   auto wind_down = [&]() -> kslam_status {
     if (worker.joinable()) worker.join();
@@ -72,6 +73,7 @@ extern "C" kslam_status kslam_stream_classify(kslam_ctx *ctx, const kslam_index_
       writer = nullptr;
     }
     if (pairing_set) kslam_set_pairing(ctx, 1, 0, 0.95, 0);
+    Pool::get().set_cap(0);
     return w;
   };
 
@@ -125,9 +127,44 @@ extern "C" kslam_status kslam_stream_classify(kslam_ctx *ctx, const kslam_index_
       return true;
     };
 
-    auto host_stage = [&](kslam_batch_result res) {   // on the worker thread; owns `res`
-      const kslam_status s = guarded([&] {
-        kslam_reads_view reads = {res.n_reads, nullptr, res.reads_bases_off, nullptr, res.reads_bases_off, res.reads_ids, res.reads_ids_off};
+    // The host stage of one batch, on the worker thread (it owns `res`): the SAM text on this thread, the taxonomy part
+    // (per-read LCA, <out>_PerRead, the report's records) on a second one at the same time.  Both only read `res`; their
+    // parallel regions take turns on the pool, and the serial stretches of one (offsets, buffer growth, the per-read
+    // file's write) run under the other's regions instead of leaving 15 workers idle: 50 -> 36 ms per batch.
+    auto host_stage = [&](kslam_batch_result res) {
+      name_thread("kslam-host");
+      kslam_reads_view reads = {res.n_reads, nullptr, res.reads_bases_off, nullptr, res.reads_bases_off, res.reads_ids, res.reads_ids_off};
+      kslam_status tax_status = KSLAM_OK;
+      std::string tax_error;
+      std::thread tax_thread;
+      auto tax_part = [&] {
+          tax_status = guarded([&] {
+            const double t1 = now_ms();
+            const size_t base = all_ids.size();
+            all_ids.resize(base + res.n_read_pairs);
+            char *text = nullptr;
+            uint64_t tlen = 0;
+            const kslam_status b = kslam_tail_classify(&host_write, &reads, index, taxdb, res.read_pairs, res.n_read_pairs, res.pairs,
+                                                       res.n_pairs, all_ids.data() + base, &text, &tlen);
+            if (b != KSLAM_OK) fail(b, kslam_tail_last_error());
+            const bool wrote = P->per_read_fd < 0 || write_all(P->per_read_fd, text, tlen);
+            kslam_free(text);
+            if (!wrote) fail(KSLAM_ERR_ARG, std::string("writing the per-read file failed: ") + strerror(errno));
+            st.per_read_bytes += tlen;
+            const double t2 = now_ms();
+            st.seconds_classify += (t2 - t1) * 1e-3;
+            if (report) {
+              const kslam_status c = kslam_taxreport_add_batch(report, &reads, index, res.read_pairs, res.n_read_pairs, res.pairs,
+                                                               res.n_pairs, all_ids.data() + base);
+              if (c != KSLAM_OK) fail(c, kslam_tail_last_error());
+              st.seconds_report += (now_ms() - t2) * 1e-3;
+            }
+          });
+          if (tax_status != KSLAM_OK) tax_error = g_err;
+      };
+      const bool two_threads = P->host_threads != 1;
+      if (taxdb && two_threads) tax_thread = std::thread([&] { name_thread("kslam-tax"); tax_part(); });
+      kslam_status s = guarded([&] {
         const bool on_gpu = (res.pair_stats.stages_done & KSLAM_TAIL_PSEUDO_ASM) != 0;
         if (P->tail.pseudo_assembly && !on_gpu) st.batches_pseudo_on_host++;
         const kslam_tail_params *tp = (on_gpu || !P->tail.pseudo_assembly) ? &host_write : &host_all;
@@ -140,8 +177,7 @@ extern "C" kslam_status kslam_stream_classify(kslam_ctx *ctx, const kslam_index_
                                                             res.pairs, res.n_pairs, writer ? kslam_write_queued : +drop,
                                                             writer ? (void *)writer : nullptr, &ts);
         if (a != KSLAM_OK) fail(a, kslam_tail_last_error());
-        const double t1 = now_ms();
-        st.seconds_sam_text += (t1 - t0) * 1e-3;
+        st.seconds_sam_text += (now_ms() - t0) * 1e-3;
         st.sam_bytes += ts.sam_bytes;
         st.n_alignment_pairs += ts.n_paired_final;
         st.n_read_pairs_aligned += ts.n_read_pairs;
@@ -149,32 +185,18 @@ extern "C" kslam_status kslam_stream_classify(kslam_ctx *ctx, const kslam_index_
         if (st.n_batches == 0) st.first_max_insert_size = res.pair_stats.max_insert_size;
         st.n_batches++;
         st.n_pairs += res.n_reads / 2;
-        if (taxdb) {
-          const size_t base = all_ids.size();
-          all_ids.resize(base + res.n_read_pairs);
-          char *text = nullptr;
-          uint64_t tlen = 0;
-          const kslam_status b = kslam_tail_classify(&host_write, &reads, index, taxdb, res.read_pairs, res.n_read_pairs, res.pairs,
-                                                     res.n_pairs, all_ids.data() + base, &text, &tlen);
-          if (b != KSLAM_OK) fail(b, kslam_tail_last_error());
-          const bool wrote = P->per_read_fd < 0 || write_all(P->per_read_fd, text, tlen);
-          kslam_free(text);
-          if (!wrote) fail(KSLAM_ERR_ARG, std::string("writing the per-read file failed: ") + strerror(errno));
-          st.per_read_bytes += tlen;
-          const double t2 = now_ms();
-          st.seconds_classify += (t2 - t1) * 1e-3;
-          if (report) {
-            const kslam_status c = kslam_taxreport_add_batch(report, &reads, index, res.read_pairs, res.n_read_pairs, res.pairs,
-                                                             res.n_pairs, all_ids.data() + base);
-            if (c != KSLAM_OK) fail(c, kslam_tail_last_error());
-            st.seconds_report += (now_ms() - t2) * 1e-3;
-          }
-        }
       });
+      std::string err = s != KSLAM_OK ? g_err : std::string();
+      if (tax_thread.joinable()) tax_thread.join();
+      else if (taxdb && s == KSLAM_OK) tax_part();
+      if (s == KSLAM_OK && tax_status != KSLAM_OK) {
+        s = tax_status;
+        err = tax_error;
+      }
       kslam_release_batch(ctx, &res);
       if (s != KSLAM_OK && worker_status == KSLAM_OK) {
         worker_status = s;
-        worker_error = g_err;          // (the worker's thread-local message)
+        worker_error = err;            // (the failing thread's thread-local message)
       }
     };
 

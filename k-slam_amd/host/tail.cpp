@@ -1433,6 +1433,7 @@ struct kslam_sam_writer {
   uint64_t bytes = 0;
   double write_s = 0;
   void run() {
+    name_thread("kslam-writer");
     for (;;) {
       std::vector<Text> set;
       {

@@ -14,6 +14,7 @@
 #include <functional>
 #include <mutex>
 #include <string>
+#include <pthread.h>
 #include <thread>
 #if defined(__linux__)
 #include <sys/mman.h>
@@ -31,6 +32,15 @@ struct HostError {
 
 inline thread_local std::string g_err;
 
+// Names the calling thread (top -H, /proc/<pid>/task/*/comm: bench.py's cpu_s_by_thread groups CPU time by these).
+inline void name_thread(const char *name) {
+#if defined(__linux__)
+  (void)pthread_setname_np(pthread_self(), name);   // at most 15 characters
+#else
+  (void)name;
+#endif
+}
+
 inline double now_ms() {
   return std::chrono::duration<double, std::milli>(
              std::chrono::steady_clock::now().time_since_epoch())
@@ -38,94 +48,112 @@ inline double now_ms() {
 }
 
 // ---------------------------------------------------------------- worker pool --
-// Persistent workers, woken per parallel region; the caller is worker 0.
+// Persistent workers shared by every parallel loop of the host stages.  A loop (`tasks`) is a job: a counter of
+// tasks handed out and one of tasks finished; the calling thread works on its own job, the workers on whichever
+// active job has tasks left and the fewest threads on it.  Several jobs may be active at once -- the SAM text of a
+// batch on one thread and its taxonomy part on another (stream.cpp): the serial stretches between the loops of one
+// run under the loops of the other, instead of every loop owning the pool while the rest of the process waits for it.
 class Pool {
  public:
   static Pool &get() {
     static Pool *p = new Pool();  // never destroyed: workers are detached
     return *p;
   }
-  void run(int n, const std::function<void(int)> &f) {
-    if (n <= 1) {
-      f(0);
+  // dynamic schedule of n_tasks over at most n_threads threads (the caller included)
+  void tasks(int n_threads, size_t n_tasks, const std::function<void(size_t)> &f) {
+    if (n_tasks == 0) return;
+    Job job;
+    job.f = &f;
+    job.n = n_tasks;
+    job.max_threads = (int)std::min<size_t>((size_t)std::min(std::max(n_threads, 1), cap_.load(std::memory_order_relaxed)), n_tasks);
+    if (job.max_threads <= 1) {
+      for (size_t t = 0; t < n_tasks; t++) f(t);
       return;
     }
-    std::lock_guard<std::mutex> region(region_);
     {
-      std::unique_lock<std::mutex> lk(m_);
-      while ((int)workers_ < n - 1) {
-        int id = workers_++;
-        std::thread([this, id] { loop(id); }).detach();
+      std::lock_guard<std::mutex> lk(m_);
+      while ((int)workers_ < job.max_threads - 1) {
+        const int index = (int)workers_++;
+        std::thread([this, index] { loop(index); }).detach();
       }
-      job_ = &f;
-      want_ = n - 1;
-      active_ = n - 1;
-      failed_ = false;
-      gen_++;
+      job.threads = 1;   // the caller
+      active_.push_back(&job);
     }
-    start_.notify_all();
-    try {
-      f(0);
-    } catch (const HostError &e) {
-      note(e);
-    } catch (const std::exception &e) {
-      note(HostError{KSLAM_ERR_INTERNAL, e.what()});
-    }
+    work_.notify_all();
+    drain(job);
     std::unique_lock<std::mutex> lk(m_);
-    done_.wait(lk, [&] { return active_ == 0; });
-    job_ = nullptr;
-    if (failed_) throw error_;
+    job.threads--;
+    done_.wait(lk, [&] { return job.finished == job.n && job.threads == 0; });
+    active_.erase(std::find(active_.begin(), active_.end(), &job));
+    if (job.failed) throw job.error;
   }
-  // dynamic schedule of n_tasks over n_threads
-  void tasks(int n_threads, size_t n_tasks, const std::function<void(size_t)> &f) {
-    std::atomic<size_t> next(0);
-    run((int)std::min<size_t>(n_threads, std::max<size_t>(n_tasks, 1)), [&](int) {
-      for (;;) {
-        size_t t = next.fetch_add(1, std::memory_order_relaxed);
-        if (t >= n_tasks) break;
-        f(t);
-      }
-    });
-  }
+  // At most `n` threads on any loop from now on and at most n - 1 workers awake (0: no limit).  For a caller that runs
+  // other busy threads next to the loops -- the batch loop's writer, lanes and second host thread -- inside a CPU
+  // quota: more runnable threads than the quota has CPUs get the whole process throttled (cgroup cpu.max).
+  void set_cap(int n) { cap_.store(n > 0 ? n : (1 << 30), std::memory_order_relaxed); }
 
  private:
-  void note(const HostError &e) {
-    std::lock_guard<std::mutex> lk(m_);
-    if (!failed_) {
-      failed_ = true;
-      error_ = e;
-    }
-  }
-  void loop(int id) {
-    uint64_t seen = 0;
+  struct Job {
+    const std::function<void(size_t)> *f = nullptr;
+    size_t n = 0;
+    std::atomic<size_t> next{0};
+    size_t finished = 0;      // guarded by m_
+    int threads = 0;          // threads inside drain(), guarded by m_
+    int max_threads = 1;
+    bool failed = false;
+    HostError error;
+  };
+  // takes tasks of `job` until none is left; returns the number it ran
+  void drain(Job &job) {
+    size_t ran = 0;
+    bool failed = false;
+    HostError error;
     for (;;) {
-      const std::function<void(int)> *job;
-      {
-        std::unique_lock<std::mutex> lk(m_);
-        start_.wait(lk, [&] { return gen_ != seen; });
-        seen = gen_;
-        if (id >= want_) continue;
-        job = job_;
-      }
+      const size_t t = job.next.fetch_add(1, std::memory_order_relaxed);
+      if (t >= job.n) break;
       try {
-        (*job)(id + 1);
+        if (!failed) (*job.f)(t);
       } catch (const HostError &e) {
-        note(e);
+        failed = true;
+        error = e;
       } catch (const std::exception &e) {
-        note(HostError{KSLAM_ERR_INTERNAL, e.what()});
+        failed = true;
+        error = HostError{KSLAM_ERR_INTERNAL, e.what()};
       }
-      std::lock_guard<std::mutex> lk(m_);
-      if (--active_ == 0) done_.notify_one();
+      ran++;
+    }
+    std::lock_guard<std::mutex> lk(m_);
+    job.finished += ran;
+    if (failed && !job.failed) {
+      job.failed = true;
+      job.error = error;
     }
   }
-  std::mutex region_, m_;
-  std::condition_variable start_, done_;
-  const std::function<void(int)> *job_ = nullptr;
-  uint64_t gen_ = 0;
-  int want_ = 0, active_ = 0;
+  void loop(int index) {
+    name_thread("kslam-pool");
+    std::unique_lock<std::mutex> lk(m_);
+    for (;;) {
+      Job *pick = nullptr;
+      if (index < cap_.load(std::memory_order_relaxed) - 1)
+      for (Job *j : active_)
+        if (j->next.load(std::memory_order_relaxed) < j->n && j->threads < j->max_threads && (!pick || j->threads < pick->threads)) pick = j;
+      if (!pick) {
+        work_.wait(lk);
+        continue;
+      }
+      pick->threads++;
+      lk.unlock();
+      drain(*pick);
+      lk.lock();
+      pick->threads--;
+      if (pick->finished == pick->n && pick->threads == 0) done_.notify_all();
+    }
+  }
+  std::mutex m_;
+  std::condition_variable work_, done_;
+  std::vector<Job *> active_;
   size_t workers_ = 0;
-  bool failed_ = false;
-  HostError error_;
+  std::atomic<int> cap_{1 << 30};
 };
 
 // Asks for transparent huge pages under a large heap block (the boxes run THP in "madvise" mode).

@@ -37,7 +37,7 @@ class StreamParams(C.Structure):
     """kslam_stream_params"""
     _fields_ = [("pairs_per_batch", C.c_uint64), ("max_pairs_total", C.c_uint64), ("tail", T.TailParams), ("sam_fd", C.c_int32),
                 ("per_read_fd", C.c_int32), ("sam_header", C.c_char_p), ("sam_header_len", C.c_uint64), ("depth", C.c_uint32),
-                ("passes", C.c_uint32)]
+                ("host_threads", C.c_uint32), ("pool_threads", C.c_uint32), ("passes", C.c_uint32)]
 
 
 class StreamStats(C.Structure):
@@ -55,7 +55,7 @@ class StreamStats(C.Structure):
 
 
 def classify_stream_native(ctx, index, r1_ptr, len1, r2_ptr, len2, pairs_per_batch, params, taxdb=None, report=None,
-                           sam_fd=-1, per_read_fd=-1, sam_header=None, max_pairs_total=0, depth=0, passes=1):
+                           sam_fd=-1, per_read_fd=-1, sam_header=None, max_pairs_total=0, depth=0, passes=1, host_threads=0, pool_threads=0):
     """kslam_stream_classify: the same loop as classify_stream below, inside the library (no Python between the batches).
     -> dict of the statistics + tax_ids (uint32 array, empty without a taxdb)"""
     L = T.lib()
@@ -63,7 +63,7 @@ def classify_stream_native(ctx, index, r1_ptr, len1, r2_ptr, len2, pairs_per_bat
                                         C.c_void_p, C.c_uint64, C.POINTER(StreamParams), C.POINTER(C.c_void_p),
                                         C.POINTER(C.c_uint64), C.POINTER(StreamStats)]
     P = StreamParams(pairs_per_batch, max_pairs_total, params, sam_fd, per_read_fd, sam_header, len(sam_header) if sam_header else 0,
-                     depth, passes)
+                     depth, host_threads, pool_threads, passes)
     st, ids, n_ids = StreamStats(), C.c_void_p(), C.c_uint64()
     rc = L.kslam_stream_classify(ctx._h, C.byref(index.view), taxdb._h if taxdb is not None else None,
                                  report._h if report is not None else None, r1_ptr, len1, r2_ptr, len2, C.byref(P),

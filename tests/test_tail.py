@@ -427,3 +427,19 @@ def test_gnu_sort_header_reproduces_std_sort(tmp_path):
     subprocess.check_call([gxx, "-O2", "-std=c++17", os.path.join(root, "tests", "gnu_sort_check.cpp"), "-o", exe])
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "GNU_SORT_OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_worker_pool_with_concurrent_loops(tmp_path):
+    """k-slam_amd/host/workers.hpp: parallel loops started from several threads at once (the batch loop's SAM-text and
+    taxonomy threads), from inside a task, and with a failing task -- under ThreadSanitizer where the toolchain has it."""
+    import shutil
+    import subprocess
+    gxx = shutil.which("g++")
+    assert gxx
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, "tests", "pool_check.cpp")
+    exe = str(tmp_path / "pool_check")
+    if subprocess.run([gxx, "-O1", "-g", "-std=c++17", "-pthread", "-fsanitize=thread", src, "-o", exe], capture_output=True).returncode != 0:
+        subprocess.check_call([gxx, "-O2", "-std=c++17", "-pthread", src, "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stdout + r.stderr

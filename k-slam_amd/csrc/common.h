@@ -1,6 +1,7 @@
 // common.h -- shared declarations of the HIP implementation (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <time.h>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -51,7 +52,7 @@ struct Tuning {
   bool sort_digit_bytes = true;       // KSLAM_SORT_DIGIT_BYTES=0: histograms re-read the records
   int lanes = 2;                      // KSLAM_LANES
   bool eager_cigar = false;           // KSLAM_EAGER_CIGAR
-  bool lane_waits_yield = true;       // KSLAM_LANE_WAITS=spin: the pipeline lanes busy-wait for the GPU like the direct calls (stream_wait)
+  bool lane_waits_yield = false;      // KSLAM_LANE_WAITS=yield: the pipeline lanes poll + sleep instead of busy-waiting for the GPU (stream_wait)
   bool pageable_columns = false;      // KSLAM_PAGEABLE_COLUMNS
 #ifdef KSLAM_ABLATE
   uint32_t sw_ablate = 0, cigar_variant = 0, filter_ablate = 0;   // KSLAM_SW_ABLATE / _CIGAR_VARIANT / _FILTER_ABLATE
@@ -162,9 +163,13 @@ struct SortPass {
 };
 // Waiting for a stream.  hipStreamSynchronize spins on the completion signal: the fastest wake-up, and what a caller
 // that has nothing else to do wants (kslam_align_batch, the resident bench).  A pipeline lane waits while the host
-// stage of an earlier batch needs every CPU the process may use (a 16-CPU cgroup quota on the bench boxes: the two
-// lanes' spinning was 19 % of the process's CPU time, tools/cpu_sampler.c), so its thread sets `yield` and waits on
-// an event created with hipEventBlockingSync instead (an interrupt, some tens of microseconds later).
+// stage of an earlier batch needs every CPU the process may use (a 16-CPU cgroup quota on the bench boxes), and its
+// ~40 waits per batch add up to most of the batch's GPU time: measured with tools/cpu_sampler.c, the two lanes spent
+// 1.1 CPUs inside the runtime's busy-wait loop -- with hipEventBlockingSync events too, which this runtime spins on
+// just the same.  With KSLAM_LANE_WAITS=yield a lane thread sets `yield`, and its waits poll an event with
+// hipEventQuery: at once, after a few short spins, then between sleeps of 20-80 microseconds (lane CPU 1.3 -> 0.2 s
+// per 20 batches; the GPU-bound pipelined ABI path loses 1 ms per batch to the later wake-ups, and on the bench box the
+// end-to-end loop did not get faster for the freed CPU, so the default stays the spin).
 struct WaitMode {
   bool yield = false;
   hipEvent_t ev = nullptr;
@@ -178,10 +183,17 @@ inline hipError_t stream_wait(hipStream_t s) {
   WaitMode &w = wait_mode();
   if (!w.yield) return hipStreamSynchronize(s);
   hipError_t e = hipSuccess;
-  if (!w.ev) e = hipEventCreateWithFlags(&w.ev, hipEventBlockingSync | hipEventDisableTiming);
+  if (!w.ev) e = hipEventCreateWithFlags(&w.ev, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventRecord(w.ev, s);
-  if (e == hipSuccess) e = hipEventSynchronize(w.ev);
-  return e;
+  if (e != hipSuccess) return e;
+  for (int spin = 0;; spin++) {
+    e = hipEventQuery(w.ev);
+    if (e != hipErrorNotReady) return e;
+    if (spin < 8) continue;
+    const long us = spin < 40 ? 20 : 80;
+    struct timespec ts = {0, us * 1000};
+    nanosleep(&ts, nullptr);
+  }
 }
 
 // Device -> host copy of a few bytes the host has to look at before it can launch the next kernel

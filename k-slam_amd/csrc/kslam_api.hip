@@ -17,6 +17,7 @@
 #include <map>
 #include <mutex>
 #include <new>
+#include <sys/prctl.h>
 #include <thread>
 
 using namespace kslam;
@@ -169,7 +170,7 @@ Tuning read_tuning() {
   t.sort_digit_bytes = !starts("KSLAM_SORT_DIGIT_BYTES", '0');
   t.lanes = std::min(8, std::max(1, num("KSLAM_LANES", 2)));
   t.eager_cigar = flag("KSLAM_EAGER_CIGAR");
-  t.lane_waits_yield = !starts("KSLAM_LANE_WAITS", 's');
+  t.lane_waits_yield = starts("KSLAM_LANE_WAITS", 'y');
   t.pageable_columns = flag("KSLAM_PAGEABLE_COLUMNS");
 #ifdef KSLAM_ABLATE
   t.sw_ablate = (uint32_t)num("KSLAM_SW_ABLATE", 0);
@@ -945,6 +946,7 @@ void fill_pair_stats(const PairResult &r, kslam_pair_stats *st) {
 void lane_main(kslam_ctx *primary, kslam_ctx::AsyncLane *lane) {
   kslam_host::name_thread("kslam-lane");
   wait_mode().yield = primary->tune.lane_waits_yield;   // common.h: stream_wait
+  if (wait_mode().yield) (void)prctl(PR_SET_TIMERSLACK, 5000UL, 0, 0, 0);   // its 20 us sleeps mean 25, not 70
   for (;;) {
     kslam_ctx::AsyncJob *job = nullptr;
     {

@@ -7,6 +7,7 @@
 #define _GNU_SOURCE
 #include <dlfcn.h>
 #include <signal.h>
+#include <sys/prctl.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -19,6 +20,7 @@
 #define DEPTH 16
 static uintptr_t *pcs;   /* DEPTH program counters per sample: the interrupted one, then backtrace() (the handler's frames included) */
 static volatile uint32_t n_pcs;
+static char *names;   /* 16 bytes per sample: the thread's name */
 
 static void on_prof(int sig, siginfo_t *si, void *uc_) {
   (void)sig; (void)si;
@@ -28,6 +30,7 @@ static void on_prof(int sig, siginfo_t *si, void *uc_) {
     /* no unwinder here (backtrace() takes locks): the interrupted pc, then the first words above the stack pointer
      * that look like addresses of mapped objects and are not stack addresses -- return addresses among them; the
      * report keeps those that resolve to code */
+    prctl(PR_GET_NAME, names + (size_t)k * 16, 0, 0, 0);
     const uintptr_t sp = (uintptr_t)uc->uc_mcontext.gregs[REG_RSP];
     uintptr_t *out = pcs + (size_t)k * DEPTH;
     out[0] = (uintptr_t)uc->uc_mcontext.gregs[REG_RIP];
@@ -44,6 +47,7 @@ static void on_prof(int sig, siginfo_t *si, void *uc_) {
 __attribute__((constructor)) static void start(void) {
   if (!getenv("KSLAM_SAMPLER_OUT")) return;
   pcs = (uintptr_t *)calloc((size_t)CAP * DEPTH, sizeof *pcs);
+  names = (char *)calloc((size_t)CAP, 16);
   struct sigaction sa;
   memset(&sa, 0, sizeof sa);
   sa.sa_sigaction = on_prof;
@@ -62,6 +66,8 @@ __attribute__((destructor)) static void stop(void) {
   if (!f) return;
   uint32_t n = n_pcs < CAP ? n_pcs : CAP;
   for (uint32_t i = 0; i < n; i++) {
+    names[(size_t)i * 16 + 15] = 0;
+    fprintf(f, "@%s | ", names + (size_t)i * 16);
     for (int d = 0; d < DEPTH; d++) {
       const uintptr_t pc = pcs[(size_t)i * DEPTH + d];
       Dl_info di;

@@ -33,13 +33,18 @@ top = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 leaf = collections.Counter()
 via = collections.defaultdict(collections.Counter)
 total = 0
+by_thread = collections.defaultdict(collections.Counter)
 for line in open(sys.argv[1]):
     frames = [f for f in line.strip().split(" | ") if f]
+    thread = "?"
+    if frames and frames[0].startswith("@"):
+        thread = frames.pop(0)[1:].strip()
     if not frames:
         continue
     total += 1
     names = [name(f) for f in frames]
     leaf[names[0]] += 1
+    by_thread[thread][(names[0][0], names[0][1][:70])] += 1
     inside = next((n for n in names[1:] if n[0].startswith("libkslam")), None) if not names[0][0].startswith("libkslam") else None
     if inside is None and not names[0][0].startswith("libkslam"):   # no frame of ours: whatever named code the stack words point into
         others = [n for n in names[1:] if n[1] != "?" and n[0] != names[0][0]][:3]
@@ -51,3 +56,9 @@ for (o, s), c in leaf.most_common(top):
     for w, k in via[(o, s)].most_common(3):
         if w != "-":
             print("            %5.2f%% from %s" % (100.0 * k / total, w))
+print()
+for th, c in sorted(by_thread.items(), key=lambda kv: -sum(kv[1].values())):
+    n = sum(c.values())
+    print("thread %-16s %6.2f%%" % (th, 100.0 * n / total))
+    for (o, f), k in c.most_common(6):
+        print("      %5.2f%%  %-20s %s" % (100.0 * k / total, o[:20], f))

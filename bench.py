@@ -192,6 +192,18 @@ def thread_cpu():
     return out
 
 
+def usable_cpus():
+    """CPUs the process may use: the affinity mask, capped by the cgroup v2 CPU quota."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cgroup_throttled_ms():
     """Milliseconds this container's CPU quota has stalled it so far (cgroup v2 cpu.stat), or None."""
     try:
@@ -338,6 +350,7 @@ def e2e_leg(K, ctx, files, pairs_per_batch, index_view, taxdb, steps, warmup, ps
             "s_main_thread_waiting_for_gpu": med["s_waiting_for_gpu"], "s_main_thread_waiting_for_host_stage": med["s_waiting_for_host_stage"],
             "s_main_thread_other": med.get("s_main"), "s_call_close_library": med.get("s_call_and_close"),
             "cpu_s_by_thread": med.get("cpu_s_by_thread"), "cgroup_throttled_ms": med.get("cgroup_throttled_ms"),
+            "host_cpus_usable": usable_cpus(),
             "end_of_run_reports_s": round(t_end, 3), "end_of_run_report_bytes": {"abbreviated": len(summary), "xml": len(xml)},
             "including_end_of_run_reports": {"reads_per_s": round(n_reads / (last["wall"] + t_end), 1)},
             "verified": {"repetitions_identical": bool(same), "sam_file_bytes": int(runs[0]["sam_file_bytes"]),

@@ -439,7 +439,10 @@ def test_worker_pool_with_concurrent_loops(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     src = os.path.join(root, "tests", "pool_check.cpp")
     exe = str(tmp_path / "pool_check")
-    if subprocess.run([gxx, "-O1", "-g", "-std=c++17", "-pthread", "-fsanitize=thread", src, "-o", exe], capture_output=True).returncode != 0:
+    tsan = subprocess.run([gxx, "-O1", "-g", "-std=c++17", "-pthread", "-fsanitize=thread", src, "-o", exe], capture_output=True).returncode == 0
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600) if tsan else None
+    if r is None or (r.returncode != 0 and "data race" not in r.stderr and "FAILED" not in r.stdout):
+        # no sanitizer in this toolchain, or its runtime cannot start here (address-space layout of some containers)
         subprocess.check_call([gxx, "-O2", "-std=c++17", "-pthread", src, "-o", exe])
-    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.strip() == "ok", r.stdout + r.stderr

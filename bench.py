@@ -707,8 +707,10 @@ def main():
             tail_ctx.load_qualities_device(qual.data_ptr())
             del qual
             rv = ids_view(T, args.total_pairs, read_len)
-        P_write = T.TailParams.default(pseudo_assembly=False)
-        P_host = T.TailParams.default(pseudo_assembly=True)
+        # the ranks of a node share its CPUs: each rank's host stages take their share, not one thread per usable CPU each
+        host_threads = max(2, usable_cpus() // world) if world > 1 else 0
+        P_write = T.TailParams.default(pseudo_assembly=False, threads=host_threads)
+        P_host = T.TailParams.default(pseudo_assembly=True, threads=host_threads)
         sam_path = os.path.join(args.out_dir, "kslam_bench_%d_strong.sam" % os.getpid())
         pr_path = sam_path + "_PerRead"
         tail_ms = {"adopt_pair_screen_details": 0.0, "download": 0.0, "host_sam_and_lca": 0.0}

@@ -106,6 +106,26 @@ def test_stream_of_batches_equals_the_reference_loop(kslam, oracle, synth, tmp_p
     assert nat["n_batches"] == len(res["batches"]) and nat["sam_bytes"] + len(header) == len(sam)
     assert tax.report_xml(report_n, db, db.gene_extras(), nat["n_pairs"]) == xml
     report_n.close()
+    if per_batch == 833:
+        # the loop's other shapes: host stage on ONE thread, a pool of three, lanes that poll and sleep instead of spinning
+        os.environ["KSLAM_LANE_WAITS"] = "yield"
+        try:
+            ctx2 = kslam.Context()
+        finally:
+            del os.environ["KSLAM_LANE_WAITS"]
+        ctx2._chk(ctx2._L.kslam_set_index(ctx2._h, db.n_entries, C.cast(bases_pp, C.c_void_p), C.cast(lens_p, C.c_void_p)))
+        report_v = X.Report()
+        sam_fd = os.open(sam_path + ".v", os.O_RDWR | os.O_CREAT | os.O_TRUNC)
+        pr_fd = os.open(per_read_path + ".v", os.O_RDWR | os.O_CREAT | os.O_TRUNC)
+        var = S.classify_stream_native(ctx2, db, h1.ptr, len(r1), h2.ptr, len(r2), per_batch, P, taxdb=tax, report=report_v,
+                                       sam_fd=sam_fd, per_read_fd=pr_fd, sam_header=header, host_threads=1, pool_threads=3, depth=2)
+        os.close(sam_fd)
+        os.close(pr_fd)
+        assert open(sam_path + ".v", "rb").read() == sam and open(per_read_path + ".v", "rb").read() == per_read
+        assert var["tax_ids"].tolist() == res["tax_ids"].tolist()
+        assert tax.report_xml(report_v, db, db.gene_extras(), var["n_pairs"]) == xml
+        report_v.close()
+        ctx2.close()
     n_batches = (n_pairs + per_batch - 1) // per_batch
     assert res["pairs"] == n_pairs and len(res["batches"]) == n_batches
     assert [b["pairs"] for b in res["batches"]] == [min(per_batch, n_pairs - k * per_batch) for k in range(n_batches)]

@@ -359,8 +359,9 @@ def e2e_leg(K, ctx, files, pairs_per_batch, index_view, taxdb, steps, warmup, ps
             "what": "FASTQ text (two files' worth, page-locked host memory) -> kslam_fastq_batch_end (batch boundaries) -> "
                     "kslam_submit_batch_fastq_text (GPU: FASTQ record index, alignToDatabase, score screen / pairing / insert-size "
                     "statistics / screens%s, per-row NM / MD / log-probability; %d batches in flight) -> kslam_collect_batch -> "
-                    "kslam_tail_finish_write_rows -> kslam_sam_writer (background write() into the SAM file) -> kslam_tail_classify (per-read LCA) "
-                    "-> <out>_PerRead file + kslam_taxreport_add_batch; wall clock of the K steps incl. pipeline fill and drain"
+                    "kslam_tail_finish_write_rows -> kslam_sam_writer (background write() into the SAM file) and, on a second host thread at the "
+                    "same time (native driver), kslam_tail_classify (per-read LCA) -> <out>_PerRead file + kslam_taxreport_add_batch; wall clock "
+                    "of the K steps incl. pipeline fill and drain"
                     % (" / pseudo-assembly / second screen" if pseudo else "", 3),
         }
         return out

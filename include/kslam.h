@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define KSLAM_ABI_VERSION 7
+#define KSLAM_ABI_VERSION 8
 #define KSLAM_K 32u /* src/Globals.h:25 */
 
 typedef enum {

@@ -229,7 +229,8 @@ def tail_pairs(params, reads, overlaps):
 
 def _text(ptr, n):
     L = lib()
-    out = C.string_at(ptr.value, n.value) if n.value else b""
+    # (ctypes.string_at takes a C int: the XML report of a 100 M-pair run is longer than that)
+    out = bytes((C.c_char * n.value).from_address(ptr.value)) if n.value else b""
     if ptr.value:
         L.kslam_free(ptr)
     return out

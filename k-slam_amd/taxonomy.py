@@ -77,7 +77,8 @@ def _chk(st):
 
 
 def _take_text(ptr, n):
-    out = C.string_at(ptr.value, n.value) if n.value else b""
+    # (ctypes.string_at takes a C int: the XML report of a 100 M-pair run is longer than that)
+    out = bytes((C.c_char * n.value).from_address(ptr.value)) if n.value else b""
     if ptr.value:
         lib().kslam_free(ptr)
     return out

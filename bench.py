@@ -473,6 +473,11 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(args, sys.argv[1:])       # before this process makes any HIP call
+    # ONE JSON line on stdout and nothing else: libraries that print to the C-level stdout (RCCL's version banner at
+    # init) go to stderr for the whole run; the line itself is written to the saved descriptor
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -1081,7 +1086,8 @@ def main():
         if out["value"] is None:      # --no-e2e / --no-cigar / weak multi-GPU: the hot path is all that was timed
             out["value"], out["ms_per_step"] = hot["reads_per_s"], hot["ms_per_step"]
             out["value_definition"] = "hot path only: alignToDatabase on the resident batch" + (", results gathered to rank 0" if use_dist else "")
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     ctx.close()
     if use_dist:
         dist.barrier()

@@ -721,7 +721,6 @@ def main():
         pr_path = sam_path + "_PerRead"
         tail_ms = {"adopt_pair_screen_details": 0.0, "download": 0.0, "host_sam_and_lca": 0.0}
         tail_out = {}
-        worker = [None]
 
         def host_stage(ov, cg, det, md, rp, pr, pst, releases, fds):
             t1 = time.perf_counter()
@@ -734,28 +733,45 @@ def main():
             tail_out.update(sam_bytes=int(st.sam_bytes), per_read_lines=int(len(ids)), alignment_pairs=int(st.n_paired_final),
                             max_insert_size=int(pst["max_insert_size"]), pseudo_on="gpu" if pst["stages_done"] & 4 else "host")
 
-        def tail_step(fds):
+        dl_done = [None]     # set when the previous batch's download has left tail_ctx's buffers
+
+        def tail_worker(pst, fds, n_rows, downloaded, my_turn, next_turn):
+            t2 = time.perf_counter()
+            ov, cg, rel1 = tail_ctx.take_results()
+            det, md, rel2 = tail_ctx.take_row_details(len(ov), copy=False)
+            rp, pr, rel3 = tail_ctx.take_pairs(copy=False)
+            tail_ms["download"] += time.perf_counter() - t2
+            downloaded.set()
+            my_turn.wait()                                # host stages in batch order: one SAM file
+            host_stage(ov, cg, det, md, rp, pr, pst, (rel1, rel2, rel3), fds)
+            next_turn.set()
+
+        def tail_step(fds, turn):
             # rank 0, after the gather of this batch has landed: the reference's per-batch steps after alignToDatabase
-            # (src/SLAM.h:210-249) on the merged batch
+            # (src/SLAM.h:210-249) on the merged batch.  The GPU part (adopt, pairing / screens / pseudo-assembly, per-row
+            # walk) runs here; the download and the host stage run on a worker thread under the NEXT batch's alignment
+            # (tail_ctx has its own stream and buffers), host stages one after the other.
+            if dl_done[0] is not None:
+                dl_done[0].wait()                         # tail_ctx's result buffers are free again
             t1 = time.perf_counter()
             n_rows, n_ops = merged["ov"].numel() // 48, merged["cg"].numel() // 4
             tail_ctx.adopt_results_device(merged["ov"].data_ptr(), n_rows, merged["cg"].data_ptr(), n_ops)
             pst = tail_ctx.pair_screen(paired=True, stages=7)
             tail_ctx.row_details(of_pairs=True)
-            t2 = time.perf_counter()
-            ov, cg, rel1 = tail_ctx.take_results()
-            det, md, rel2 = tail_ctx.take_row_details(len(ov), copy=False)
-            rp, pr, rel3 = tail_ctx.take_pairs(copy=False)
-            t3 = time.perf_counter()
-            tail_ms["adopt_pair_screen_details"] += t2 - t1
-            tail_ms["download"] += t3 - t2
-            if worker[0] is not None:
-                worker[0].join()                          # the host stage of the previous batch
-            worker[0] = threading.Thread(target=host_stage, args=(ov, cg, det, md, rp, pr, pst, (rel1, rel2, rel3), fds))
-            worker[0].start()
+            tail_ms["adopt_pair_screen_details"] += time.perf_counter() - t1
+            dl_done[0] = threading.Event()
+            nxt = threading.Event()
+            w = threading.Thread(target=tail_worker, args=(pst, fds, n_rows, dl_done[0], turn, nxt))
+            w.start()
+            workers.append(w)
+            return nxt
+
+        workers = []
 
         def classified_steps(k):
             fds = None
+            turn = threading.Event()
+            turn.set()
             if rank == 0:
                 sam_fd = fresh_file(sam_path)
                 fds = (T.SamWriter(sam_fd), fresh_file(pr_path))
@@ -763,10 +779,12 @@ def main():
                 step()
                 if rank == 0:
                     drain()                               # this batch's rows have landed on rank 0
-                    tail_step(fds)
+                    turn = tail_step(fds, turn)
             if rank == 0:
-                worker[0].join()
-                worker[0] = None
+                for w in workers:
+                    w.join()
+                del workers[:]
+                dl_done[0] = None
                 fds[0].close()
                 os.close(sam_fd)
                 os.close(fds[1])
@@ -808,9 +826,15 @@ def main():
         taxdb_s = X.TaxDB(tax_text)
         part_sam = os.path.join(args.out_dir, "kslam_bench_%s_part%d.sam" % (os.environ.get("MASTER_PORT", "solo") if use_dist else str(os.getpid()), rank))
         part_pr = part_sam + "_PerRead"
-        sh_ms = {"align": 0.0, "pairing_gathers_pseudo": 0.0, "row_details_download": 0.0, "host_sam_and_lca": 0.0}
+        # two contexts (the second borrows the index) take the steps in turn: the download and the host stage of step k run
+        # on a worker thread under the alignment of step k + 1 on the other context; host stages one after the other
+        ctx_b = ctx.sibling()
+        ctx_b.load_reads_device(n_reads, reads.data_ptr(), roffs)
+        ctx_b.load_qualities_device(qual_loc.data_ptr())
+        sh_ctx = (ctx, ctx_b)
+        sh_ms = {"align": 0.0, "pairing_gathers_pseudo": 0.0, "row_details": 0.0, "download_on_worker": 0.0, "host_sam_and_lca": 0.0}
         sh_out = {"moved": 0}
-        sworker = [None]
+        sworker = [None, None]
 
         def sh_host(ov, cg, det, md, rp, pr, pst, releases, fds):
             t1 = time.perf_counter()
@@ -823,33 +847,47 @@ def main():
             sh_out.update(sam_bytes=int(st.sam_bytes), per_read_lines=int(len(ids)), pseudo_on="gpu" if pst["stages_done"] & 4 else "host",
                           max_insert_size=int(pst["max_insert_size"]))
 
+        def sh_worker(c, pst, fds, my_turn, next_turn):
+            t1 = time.perf_counter()
+            ov, cg, rel1 = c.take_results()
+            det, md, rel2 = c.take_row_details(len(ov), copy=False)
+            rp, pr, rel3 = c.take_pairs(copy=False)
+            sh_ms["download_on_worker"] += time.perf_counter() - t1
+            my_turn.wait()                                # host stages in step order: one part file
+            sh_host(ov, cg, det, md, rp, pr, pst, (rel1, rel2, rel3), fds)
+            next_turn.set()
+
         def sharded_steps(k):
             sam_fd = fresh_file(part_sam)
             fds = (T.SamWriter(sam_fd), fresh_file(part_pr))
-            for _ in range(k):
+            turn = threading.Event()
+            turn.set()
+            for i in range(k):
+                c = sh_ctx[i & 1]
+                if sworker[i & 1] is not None:
+                    sworker[i & 1].join()                 # this context's previous step has left its buffers (and the host)
                 t1 = time.perf_counter()
-                ctx.align_resident()
+                c.align_resident()
                 t2 = time.perf_counter()
                 if use_dist:
-                    pst, moved = kdist.sharded_tail(ctx, dev, True, 0, 0.95, True)
+                    pst, moved = kdist.sharded_tail(c, dev, True, 0, 0.95, True)
                     sh_out["moved"] = moved
                 else:
-                    pst = ctx.pair_screen(paired=True, stages=7)
+                    pst = c.pair_screen(paired=True, stages=7)
                 t3 = time.perf_counter()
-                ctx.row_details(of_pairs=True)
-                ov, cg, rel1 = ctx.take_results()
-                det, md, rel2 = ctx.take_row_details(len(ov), copy=False)
-                rp, pr, rel3 = ctx.take_pairs(copy=False)
+                c.row_details(of_pairs=True)
                 t4 = time.perf_counter()
                 sh_ms["align"] += t2 - t1
                 sh_ms["pairing_gathers_pseudo"] += t3 - t2
-                sh_ms["row_details_download"] += t4 - t3
-                if sworker[0] is not None:
-                    sworker[0].join()
-                sworker[0] = threading.Thread(target=sh_host, args=(ov, cg, det, md, rp, pr, pst, (rel1, rel2, rel3), fds))
-                sworker[0].start()
-            sworker[0].join()
-            sworker[0] = None
+                sh_ms["row_details"] += t4 - t3
+                nxt = threading.Event()
+                sworker[i & 1] = threading.Thread(target=sh_worker, args=(c, pst, fds, turn, nxt))
+                sworker[i & 1].start()
+                turn = nxt
+            for j in (0, 1):
+                if sworker[j] is not None:
+                    sworker[j].join()
+                    sworker[j] = None
             fds[0].close()
             os.close(sam_fd)
             os.close(fds[1])
@@ -868,9 +906,10 @@ def main():
             sh_max = {k: float(v) for k, v in zip(sorted(sh_ms), te[1:].tolist())}
         else:
             sh_max = dict(sh_ms)
-        # one more batch through both forms, outside the clocks: the part files in rank order must BE rank 0's files
-        sharded_steps(1)
-        classified_steps(1)
+        # two more batches through both forms (one per context of the sharded form), outside the clocks: the part files
+        # in rank order must BE rank 0's files
+        sharded_steps(2)
+        classified_steps(2)
         barrier()
         if rank == 0:
             base = part_sam.rsplit("part0", 1)
@@ -895,6 +934,7 @@ def main():
             except OSError:
                 pass
         taxdb_s.close()
+        ctx_b.close()
 
     # RCCL announces itself on stdout through C stdio ("Librccl path : ..."), buffered when piped and
     # otherwise flushed when each rank exits -- after rank 0's JSON.  Every rank pushes it out now,

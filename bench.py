@@ -249,7 +249,7 @@ def choose_sink(out_dir, need_bytes):
     probes = {}
     for d in dict.fromkeys(["/dev/shm", tempfile.gettempdir()]):
         try:
-            if os.path.isdir(d) and os.access(d, os.W_OK) and shutil.disk_usage(d).free > 3 * need_bytes + (8 << 30):
+            if os.path.isdir(d) and os.access(d, os.W_OK) and shutil.disk_usage(d).free > 2 * need_bytes + (8 << 30):
                 probes[d] = probe_sink(d)
         except OSError:
             pass
@@ -528,7 +528,8 @@ def main():
     # the sink of the legs that write files: rank 0 decides for everybody
     sink = [None, None]
     if rank == 0:
-        sink = list(choose_sink(args.out_dir, 450 * (args.total_pairs if strong else pairs * max(args.steps, args.warmup, 3))))
+        # bytes one clock leaves in the directory: K batches of SAM text + _PerRead (two such files can exist at a time)
+        sink = list(choose_sink(args.out_dir, (270 * args.total_pairs if strong else 450 * pairs) * max(args.steps, args.warmup, 3)))
     if use_dist:
         dist.broadcast_object_list(sink, src=0)
     args.out_dir, sink_probe = sink

@@ -369,7 +369,9 @@ kslam_status kslam_submit_batch_fastq(kslam_ctx *ctx, const char *r1, uint64_t l
  * their offsets, the base offsets = lengths; read i's bases and quality stay on the device), with
  * consumed1 / consumed2 = where the reference's streams would stand (kslam_fastq_parse_pair's rule:
  * up to max_pairs records per stream, 0 = no limit; at_eof as there).  Same errors as
- * kslam_fastq_index_pair, reported by kslam_collect_batch. */
+ * kslam_fastq_index_pair, reported by kslam_collect_batch.  r2 == NULL (and len2 == 0): single-end reads, one stream
+ * (getSequencesFromFASTQFile, src/FASTQsequence.h:129-147); max_pairs then counts reads, and kslam_set_pairing's
+ * `paired` must be 0. */
 kslam_status kslam_submit_batch_fastq_text(kslam_ctx *ctx, const char *r1, uint64_t len1,
                                            const char *r2, uint64_t len2, uint64_t max_pairs,
                                            int at_eof, uint64_t *ticket);

@@ -20,8 +20,9 @@
  * <out>_PerRead is the concatenation of what this call writes to per_read_fd; kslam_taxonomy_summary and
  * kslam_taxreport_xml (include/kslam_taxonomy.h) give <out>_abbreviated and <out>.
  *
- * Same library as kslam.h; needs a context with an index (kslam_set_index).  Paired data only (two texts);
- * single-end batches go through kslam_submit_batch_columns.  k-slam_amd/stream.py is the same loop in Python with
+ * Same library as kslam.h; needs a context with an index (kslam_set_index).  Single-end data (the reference's
+ * isPaired == false branch: getSequencesFromFASTQFile, getDummyAlignmentPairsFromSingleEndReads, :198-206, :228-233):
+ * tail.paired = 0, r2 = NULL, len2 = 0; "pairs" in the fields below then reads "reads".  k-slam_amd/stream.py is the same loop in Python with
  * hooks for the tests; tests/test_gpu_stream.py holds both against the oracle chain and against each other.
  */
 #ifndef KSLAM_STREAM_H_
@@ -35,7 +36,7 @@ extern "C" {
 typedef struct {
   uint64_t pairs_per_batch; /* --num-reads-at-once, src/main.cpp:56 (default there: 10 000 000) */
   uint64_t max_pairs_total; /* --num-reads (maxNumReads); 0 = the whole files */
-  kslam_tail_params tail;   /* the globals the tail reads; tail.paired must be non-zero */
+  kslam_tail_params tail;   /* the globals the tail reads; tail.paired = 0: single-end data, one text */
   int32_t sam_fd;           /* open descriptor of the SAM file, or -1 (the text is formatted and dropped) */
   int32_t per_read_fd;      /* open descriptor of <out>_PerRead, or -1 */
   const char *sam_header;   /* getHeader's text (kslam_sam_header), written first when sam_fd >= 0; may be NULL */

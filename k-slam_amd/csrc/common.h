@@ -381,7 +381,7 @@ struct FastqIndexResult {
 // d_text = [r1 | r2] on the device; h_last1 / h_last2: the streams' last bytes on the host (or nullptr for
 // an empty stream).  Semantics of host/fastq.cpp's index (kslam_fastq_index_pair).
 void fastq_index_device(const uint8_t *d_text, uint64_t len1, uint64_t len2, const uint8_t *h_last1, const uint8_t *h_last2,
-                        uint64_t max_pairs, bool at_eof, FastqWork &W, FastqIndexResult *res, hipStream_t s);
+                        uint64_t max_pairs, bool at_eof, FastqWork &W, FastqIndexResult *res, hipStream_t s, bool single = false);
 
 // pair_and_screen in its two halves, for read pairs sharded over several GPUs: phase A pairs per
 // read pair and collects the shard's insert sizes (W.inserts, res->n_insert_sizes); the caller gathers every shard's

@@ -203,7 +203,7 @@ uint64_t index_events(const uint8_t *d_text, uint64_t scan_len, FastqWork &W, De
 }  // namespace
 
 void fastq_index_device(const uint8_t *d_text, uint64_t len1, uint64_t len2, const uint8_t *h_tail1, const uint8_t *h_tail2,
-                        uint64_t max_pairs, bool at_eof, FastqWork &W, FastqIndexResult *res, hipStream_t s) {
+                        uint64_t max_pairs, bool at_eof, FastqWork &W, FastqIndexResult *res, hipStream_t s, bool single) {
   memset(res, 0, sizeof *res);
   FqStream st[2];
   const uint64_t lens[2] = {len1, len2};
@@ -234,7 +234,8 @@ void fastq_index_device(const uint8_t *d_text, uint64_t len1, uint64_t len2, con
     if (max_pairs && n > max_pairs) n = max_pairs;
     q.n = n;
   }
-  if (st[0].n != st[1].n) throw StatusError{KSLAM_ERR_ARG, "mismatch in R1 and R2 size"};   // src/FASTQsequence.h:118-122
+  // single end (getSequencesFromFASTQFile, src/FASTQsequence.h:129-147): one stream, max_pairs counts reads
+  if (!single && st[0].n != st[1].n) throw StatusError{KSLAM_ERR_ARG, "mismatch in R1 and R2 size"};   // src/FASTQsequence.h:118-122
   const uint64_t n = st[0].n + st[1].n;
   st[0].first = 0;
   st[1].first = st[0].n;

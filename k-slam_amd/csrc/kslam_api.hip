@@ -103,6 +103,7 @@ struct kslam_ctx {
     const uint64_t *off_ptr = nullptr;
     // kslam_submit_batch_fastq: the two texts (cat = r1, qcat = r2) and where the fields lie in [r1 | r2]
     bool fastq = false, fastq_text = false;   // fastq_text: the index is built on the device too
+    bool single = false;                      // fastq_text with ONE stream (r2 == NULL): single-end reads
     uint64_t max_pairs = 0; int at_eof = 1;
     uint64_t r_n = 0, *r_off = nullptr, *r_ids_off = nullptr; char *r_ids = nullptr; uint64_t consumed[2] = {0, 0};
     uint64_t len1 = 0, len2 = 0;
@@ -903,7 +904,7 @@ kslam_status load_reads_from_fastq_text(kslam_ctx *c, kslam_ctx::AsyncJob *job) 
     HIPCHK(hipMemsetAsync(c->fq_text.as<uint8_t>() + len1 + len2, 0, 64, s));
     FastqIndexResult ix;
     fastq_index_device(c->fq_text.as<uint8_t>(), len1, len2, len1 ? (const uint8_t *)r1 + len1 - 1 : nullptr,
-                       len2 ? (const uint8_t *)r2 + len2 - 1 : nullptr, job->max_pairs, job->at_eof != 0, c->fqw, &ix, s);
+                       len2 ? (const uint8_t *)r2 + len2 - 1 : nullptr, job->max_pairs, job->at_eof != 0, c->fqw, &ix, s, job->single);
     const uint64_t n = ix.n_reads;
     // the host's columns: offsets (= lengths), identifiers
     job->r_n = n;
@@ -1763,6 +1764,7 @@ kslam_status kslam_submit_batch_fastq_text(kslam_ctx *c, const char *r1, uint64_
     job->qcat = const_cast<char *>(r2);
     job->len1 = len1; job->len2 = len2;
     job->max_pairs = max_pairs; job->at_eof = at_eof;
+    job->single = r2 == nullptr && len2 == 0;
   });
   if (st != KSLAM_OK) { delete job; return st; }
   uint64_t tk;

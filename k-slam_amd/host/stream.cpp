@@ -80,12 +80,13 @@ extern "C" kslam_status kslam_stream_classify(kslam_ctx *ctx, const kslam_index_
   const kslam_status status = guarded([&] {
     if (!ctx || !index || !P || !stats) fail(KSLAM_ERR_ARG, "null argument");
     if ((len1 && !r1) || (len2 && !r2)) fail(KSLAM_ERR_ARG, "null text");
-    if (!P->tail.paired) fail(KSLAM_ERR_UNSUPPORTED, "kslam_stream_classify takes paired data (two texts)");
+    const bool paired = P->tail.paired != 0;
+    if (!paired && (r2 || len2)) fail(KSLAM_ERR_ARG, "single-end data (tail.paired == 0) is ONE text: r2 must be NULL");
     if (P->pairs_per_batch == 0) fail(KSLAM_ERR_ARG, "pairs_per_batch must be positive");
     if (taxdb && !tax_ids_out) fail(KSLAM_ERR_ARG, "tax_ids output missing");
     const uint32_t depth = P->depth ? P->depth : 3;
     const uint32_t stages = KSLAM_TAIL_INSERT_SCREEN | KSLAM_TAIL_SCORE_SCREEN | (P->tail.pseudo_assembly ? KSLAM_TAIL_PSEUDO_ASM : 0u);
-    if (kslam_set_pairing(ctx, 1, P->tail.score_threshold, P->tail.score_fraction, stages) != KSLAM_OK)
+    if (kslam_set_pairing(ctx, paired ? 1 : 0, P->tail.score_threshold, P->tail.score_fraction, stages) != KSLAM_OK)
       fail(KSLAM_ERR_UNSUPPORTED, kslam_last_error(ctx));
     pairing_set = true;
     if (P->sam_fd >= 0) {
@@ -101,7 +102,7 @@ extern "C" kslam_status kslam_stream_classify(kslam_ctx *ctx, const kslam_index_
     uint32_t passes_left = P->passes > 1 ? P->passes - 1 : 0;
     bool exhausted = false;
     auto next_window = [&](Window *w) -> bool {
-      if ((exhausted || !(p1 < len1 || p2 < len2)) && passes_left && len1 && len2) {   // the texts once more
+      if ((exhausted || !(p1 < len1 || p2 < len2)) && passes_left && len1 && (len2 || !paired)) {   // the texts once more
         passes_left--;
         p1 = p2 = 0;
         exhausted = false;
@@ -116,14 +117,14 @@ extern "C" kslam_status kslam_stream_classify(kslam_ctx *ctx, const kslam_index_
       int c1 = 0, c2 = 0;
       const double tc = now_ms();
       if (kslam_fastq_batch_end(r1 + p1, len1 - p1, want, 1, P->tail.threads, &e1, &c1) != KSLAM_OK ||
-          kslam_fastq_batch_end(r2 + p2, len2 - p2, want, 1, P->tail.threads, &e2, &c2) != KSLAM_OK)
+          (paired && kslam_fastq_batch_end(r2 + p2, len2 - p2, want, 1, P->tail.threads, &e2, &c2) != KSLAM_OK))
         fail(KSLAM_ERR_ARG, kslam_tail_last_error());
       st.seconds_cutting += (now_ms() - tc) * 1e-3;
       *w = Window{p1, p1 + e1, p2, p2 + e2};
       done_pairs += want;
       p1 += e1;
       p2 += e2;
-      if (p1 >= len1 || p2 >= len2) exhausted = true;
+      if (p1 >= len1 || (paired && p2 >= len2)) exhausted = true;
       return true;
     };
 
@@ -184,7 +185,7 @@ extern "C" kslam_status kslam_stream_classify(kslam_ctx *ctx, const kslam_index_
         st.n_overlaps += res.n_overlaps;
         if (st.n_batches == 0) st.first_max_insert_size = res.pair_stats.max_insert_size;
         st.n_batches++;
-        st.n_pairs += res.n_reads / 2;
+        st.n_pairs += P->tail.paired ? res.n_reads / 2 : res.n_reads;
       });
       std::string err = s != KSLAM_OK ? g_err : std::string();
       if (tax_thread.joinable()) tax_thread.join();
@@ -207,7 +208,9 @@ extern "C" kslam_status kslam_stream_classify(kslam_ctx *ctx, const kslam_index_
         const double tsub = now_ms();
         // "at end of stream" for inner windows too: a window ends right after a terminator (kslam_fastq_batch_end looked at
         // the byte behind a closing "\r"), so the end-of-stream rule adds nothing and keeps that "\r" a whole terminator
-        if (kslam_submit_batch_fastq_text(ctx, r1 + w.p1, w.e1 - w.p1, r2 + w.p2, w.e2 - w.p2, 0, 1, &tk) != KSLAM_OK)
+        // (single end: r2 == NULL is how the library is told that there is one stream)
+        if (kslam_submit_batch_fastq_text(ctx, r1 + w.p1, w.e1 - w.p1, paired ? r2 + w.p2 : nullptr, paired ? w.e2 - w.p2 : 0, 0, 1,
+                                          &tk) != KSLAM_OK)
           fail(KSLAM_ERR_STATE, kslam_last_error(ctx));
         st.seconds_submitting += (now_ms() - tsub) * 1e-3;
         tickets.push_back(tk);

@@ -57,6 +57,7 @@ class StreamStats(C.Structure):
 def classify_stream_native(ctx, index, r1_ptr, len1, r2_ptr, len2, pairs_per_batch, params, taxdb=None, report=None,
                            sam_fd=-1, per_read_fd=-1, sam_header=None, max_pairs_total=0, depth=0, passes=1, host_threads=0, pool_threads=0):
     """kslam_stream_classify: the same loop as classify_stream below, inside the library (no Python between the batches).
+    Single-end data: params.paired = 0, r2_ptr = None, len2 = 0 (classify_stream below is the paired loop only).
     -> dict of the statistics + tax_ids (uint32 array, empty without a taxdb)"""
     L = T.lib()
     L.kslam_stream_classify.argtypes = [C.c_void_p, C.POINTER(T.IndexView), C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,

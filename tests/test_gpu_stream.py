@@ -214,3 +214,80 @@ def test_stream_stops_at_max_pairs_and_reports_mismatched_files(kslam, synth, tm
     h2.close()
     ctx.close()
     db.close()
+
+
+@pytest.mark.parametrize("pseudo,per_batch", [(True, 800), (False, 2500)])
+def test_single_end_stream_equals_the_reference_loop(kslam, oracle, synth, tmp_path, pseudo, per_batch):
+    """The isPaired == false branch of the batch loop (src/SLAM.h:193-233: getSequencesFromFASTQFile, dummy alignment
+    pairs, score screen [, pseudo-assembly + screen], one SAM row per alignment): ONE FASTQ text through
+    kslam_stream_classify with tail.paired = 0 and r2 = NULL, against the oracle chain batch by batch."""
+    import ctypes as C
+    D = importlib.import_module("kslam_amd.db")
+    T = importlib.import_module("kslam_amd.tail")
+    X = importlib.import_module("kslam_amd.taxonomy")
+    S = importlib.import_module("kslam_amd.stream")
+    dbo = importlib.import_module("oracle.db_oracle")
+    n_reads = 2500
+    dbdir, taxdb, rb, quals, ids, r1, _ = _make_case(synth, tmp_path, n_reads, b"\n", seed=411)
+    rb, quals = rb[:n_reads], quals[:n_reads]                     # the R1 file alone is the data set
+    db = D.Database.load(dbdir / "database")
+    ctx = kslam.Context()
+    bases_pp, lens_p = db.entry_pointers()
+    ctx._chk(ctx._L.kslam_set_index(ctx._h, db.n_entries, C.cast(bases_pp, C.c_void_p), C.cast(lens_p, C.c_void_p)))
+    tax = X.TaxDB((dbdir / "taxDB").read_bytes())
+    report = X.Report()
+    h1 = kslam.HostBuffer(len(r1) + 64)
+    h1.a[:len(r1)] = np.frombuffer(r1, dtype=np.uint8)
+    P = T.TailParams.default(paired=False, pseudo_assembly=pseudo)
+    header = T.sam_header(db, b"SLAM --db db R1.fq")
+    sam_path, per_read_path = str(tmp_path / "single.sam"), str(tmp_path / "single_PerRead")
+    sam_fd = os.open(sam_path, os.O_RDWR | os.O_CREAT | os.O_TRUNC)
+    pr_fd = os.open(per_read_path, os.O_RDWR | os.O_CREAT | os.O_TRUNC)
+    nat = S.classify_stream_native(ctx, db, h1.ptr, len(r1), None, 0, per_batch, P, taxdb=tax, report=report,
+                                   sam_fd=sam_fd, per_read_fd=pr_fd, sam_header=header)
+    os.close(sam_fd)
+    os.close(pr_fd)
+    sam = open(sam_path, "rb").read()
+    per_read = open(per_read_path, "rb").read()
+    n_batches = (n_reads + per_batch - 1) // per_batch
+    assert nat["n_pairs"] == n_reads and nat["n_batches"] == n_batches
+    # a second text with paired = 0 is refused, and so is paired data handed over as one text
+    with pytest.raises(kslam.KslamError, match="ONE text"):
+        S.classify_stream_native(ctx, db, h1.ptr, len(r1), h1.ptr, len(r1), per_batch, P)
+    with pytest.raises(kslam.KslamError, match="mismatch in R1 and R2"):
+        S.classify_stream_native(ctx, db, h1.ptr, len(r1), h1.ptr, 0, per_batch, T.TailParams.default())
+
+    _, oentries = dbo.parse((dbdir / "database").read_bytes())
+    ogb = [e["bases"] for e in oentries]
+    oI = T.Index(ogb, locus_tags=[e["locusTag"] for e in oentries], taxonomy_ids=[e["taxonomyID"] for e in oentries],
+                 genes=[[(g["start"], g["stop"], g["geneName"], g["proteinID"], g["product"]) for g in e["genes"]]
+                        for e in oentries])
+    otree = oracle.taxonomy_tree(taxdb)
+    esam, eper_read, etax, ebatches = [], [], [], []
+    for k in range(n_batches):
+        lo, hi = k * per_batch, min(n_reads, (k + 1) * per_batch)
+        b_reads, b_quals, b_ids = rb[lo:hi], quals[lo:hi], ids[lo:hi]
+        eal, ecig, _ = oracle.align_to_database(b_reads, ogb)
+        oR = T.Reads(b_reads, b_quals, b_ids)
+        esam.append(oracle.tail_sam(P, oR.view, oI.view, eal, ecig))
+        erp, epr = oracle.tail_pairs(P, oR.view, eal)
+        t = [otree.lca([oentries[int(e)]["taxonomyID"] for e in epr["entry"][int(g["first"]):int(g["first"]) + int(g["count"])]])
+             for g in erp]
+        etax += t
+        eper_read.append(b"".join(b"%s\t%d\n" % (b_ids[int(g["r1_read"])], x) for g, x in zip(erp, t)))
+        ebatches.append((b_ids, erp, epr))
+    assert sam == header + b"".join(esam) and sam.count(b"\n") > 0.9 * n_reads
+    assert nat["tax_ids"].tolist() == etax and len(set(etax)) > 6
+    assert per_read == b"".join(eper_read)
+    assert tax.summary(nat["tax_ids"], n_reads) == oracle.taxonomy_summary(otree, etax, n_reads)
+    from test_taxonomy import _xml_restatement
+    ogenes = [[{"start": g["start"], "stop": g["stop"], "name": g["geneName"], "protein": g["proteinID"], "product": g["product"],
+                "locus": g["locusTag"], "reference": g["referenceSequence"], "id": g["geneID"]} for g in e["genes"]] for e in oentries]
+    exml, taxa = _xml_restatement(tax, [e["taxonomyID"] for e in oentries], ogenes, None, ebatches, n_reads)
+    assert tax.report_xml(report, db, db.gene_extras(), n_reads) == exml and len(taxa) > 6
+    h1.close()
+    ctx.close()
+    db.close()
+    report.close()
+    tax.close()
+    otree.close()

@@ -141,7 +141,7 @@ def classify_stream(ctx, index, r1_ptr, len1, r2_ptr, len2, pairs_per_batch, par
     the batch as the GPU returned it (the SAM writer sorts `pr` in place afterwards); on_batch(rec, ov, cg, rp, pr,
     reads) sees it after the host stage."""
     if not params.paired:
-        raise KslamError(4, "classify_stream: paired data only (single-end batches go through kslam_submit_batch_columns)")
+        raise KslamError(4, "classify_stream: paired data only (single-end data: classify_stream_native with r2_ptr = None)")
     t_start = time.perf_counter()
     stages = 3 | (4 if params.pseudo_assembly else 0)
     ctx.set_pairing(paired=True, score_threshold=params.score_threshold, score_fraction=params.score_fraction, stages=stages)

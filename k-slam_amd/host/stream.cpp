@@ -129,9 +129,10 @@ extern "C" kslam_status kslam_stream_classify(kslam_ctx *ctx, const kslam_index_
     };
 
     // The host stage of one batch, on the worker thread (it owns `res`): the SAM text on this thread, the taxonomy part
-    // (per-read LCA, <out>_PerRead, the report's records) on a second one at the same time.  Both only read `res`; their
-    // parallel regions take turns on the pool, and the serial stretches of one (offsets, buffer growth, the per-read
-    // file's write) run under the other's regions instead of leaving 15 workers idle: 50 -> 36 ms per batch.
+    // (per-read LCA, <out>_PerRead, the report's records) on a second one at the same time.  Both only read `res`; the
+    // pool shares its workers between their loops, and the serial stretches of one (offsets, buffer growth, the per-read
+    // file's write) run under the other's loops instead of leaving the workers idle (the bench's /dev/null leg: 53 ->
+    // 48-50 ms per step; with a file behind it the writer and this stage are about level).
     auto host_stage = [&](kslam_batch_result res) {
       name_thread("kslam-host");
       kslam_reads_view reads = {res.n_reads, nullptr, res.reads_bases_off, nullptr, res.reads_bases_off, res.reads_ids, res.reads_ids_off};

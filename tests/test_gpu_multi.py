@@ -257,3 +257,35 @@ def test_sharded_tail_equals_one_context(kslam, synth, bounds, pseudo):
     whole.close()
     assert (g_rp, g_pr) == (n_rp, n_pr) and len(exp) > 200 * n_pairs
     assert got == exp
+
+
+def test_default_bench_line_keeps_the_contract(tmp_path):
+    """`python bench.py` (N = 1, the driver's command) at a small size: ONE JSON line on stdout and nothing else, the
+    contract's fields, `roofline` + `cpu_baseline` + `hot_path.verified`, and the end-to-end legs behind `value` (the
+    native batch loop: files written, repetitions identical, the sink probe)."""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--pairs", "30000", "--species", "4", "--strains", "3",
+                        "--genome-len", "300000", "--steps", "3", "--warmup", "1", "--cpu-pairs", "3000", "--cpu-genomes", "4"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    out = r.stdout.strip().splitlines()
+    assert len(out) == 1 and out[0].startswith("{"), r.stdout[:500]
+    line = json.loads(out[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["n_gpus"] == 1 and line["steps"] == 3 and line["scaling"] == "weak" and line["higher_is_better"] is True
+    assert line["vs_baseline"] is None and "workload" in line["config"] and line["value"] > 0
+    rf, cb = line["roofline"], line["cpu_baseline"]
+    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["gpu_equals_cpu_on_sample"]["identical"]
+    hp = line["hot_path"]
+    assert hp["verified"]["ok"] and hp["verified"]["run_to_run_identical"] and hp["verified"]["planted_missing"] == 0
+    e = line["e2e"]
+    assert line["value"] == e["reads_per_s"] and len(e["repetitions_ms_per_step"]) == 3 and e["verified"]["repetitions_identical"]
+    assert e["verified"]["sam_file_bytes"] > 100 * 30000 and e["driver"].startswith("kslam_stream_classify")
+    assert e["sink"] == line["sink_probe"]["chosen"] and isinstance(e["cpu_s_by_thread"], dict) and e["host_cpus_usable"] >= 1
+    assert line["e2e_sam_to_dev_null"]["reads_per_s"] > 0 and line["e2e_with_pseudo_assembly"]["pseudo_assembly_on"] == "gpu"
+    assert line["abi_path"]["equals_resident_result"]

@@ -210,6 +210,24 @@ def test_stream_stops_at_max_pairs_and_reports_mismatched_files(kslam, synth, tm
         S.classify_stream_native(ctx, db, h1.ptr, len(r1), h2.ptr, cut + 1, 400, P)
     # and the context is usable afterwards
     assert S.classify_stream_native(ctx, db, h1.ptr, len(r1), h2.ptr, len(r2), 500, P)["n_pairs"] == n_pairs
+    # a failure on the SECOND host thread (the per-read file cannot be written) stops the loop with its message, and a
+    # failing SAM sink does the same from the writer's side
+    X = importlib.import_module("kslam_amd.taxonomy")
+    tax = X.TaxDB((dbdir / "taxDB").read_bytes())
+    rd, wr = os.pipe()
+    os.close(rd)                                          # writing to wr now fails with EPIPE
+    import signal
+    old = signal.signal(signal.SIGPIPE, signal.SIG_IGN)
+    try:
+        with pytest.raises(kslam.KslamError, match="per-read file"):
+            S.classify_stream_native(ctx, db, h1.ptr, len(r1), h2.ptr, len(r2), 400, P, taxdb=tax, per_read_fd=wr)
+        with pytest.raises(kslam.KslamError, match="SAM"):
+            S.classify_stream_native(ctx, db, h1.ptr, len(r1), h2.ptr, len(r2), 400, P, taxdb=tax, sam_fd=wr)
+    finally:
+        signal.signal(signal.SIGPIPE, old)
+        os.close(wr)
+    assert S.classify_stream_native(ctx, db, h1.ptr, len(r1), h2.ptr, len(r2), 500, P, taxdb=tax)["n_pairs"] == n_pairs
+    tax.close()
     h1.close()
     h2.close()
     ctx.close()

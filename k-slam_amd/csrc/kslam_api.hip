@@ -1343,6 +1343,8 @@ kslam_status kslam_align_batch(kslam_ctx *c, uint64_t n_reads, const char *const
   *out = nullptr; *cigar_pool = nullptr; *n_out = 0; *n_cigar = 0;
   std::vector<uint64_t> off(n_reads + 1, 0);
   char *cat = nullptr;
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t0 = now();
   kslam_status st = guarded(c, [&] {
     if (n_reads && (!bases || !lens)) throw StatusError{KSLAM_ERR_ARG, "null bases/lens"};
     for (uint64_t i = 0; i < n_reads; i++) off[i + 1] = off[i] + lens[i];
@@ -1359,12 +1361,19 @@ kslam_status kslam_align_batch(kslam_ctx *c, uint64_t n_reads, const char *const
     for (auto &x : th) x.join();
   });
   if (st != KSLAM_OK) { if (cat) pinned_put(c, cat); return st; }
+  const double t1 = now();
   st = kslam_load_reads(c, n_reads, cat, off.data());
   pinned_put(c, cat);
   if (st != KSLAM_OK) return st;
+  const double t2 = now();
   st = kslam_align_resident(c, nullptr, nullptr);
   if (st != KSLAM_OK) return st;
-  return kslam_take_results(c, out, n_out, cigar_pool, n_cigar);
+  const double t3 = now();
+  st = kslam_take_results(c, out, n_out, cigar_pool, n_cigar);
+  if (c->tune.debug)
+    fprintf(stderr, "[kslam] align_batch: gather %.2f ms, load_reads %.2f, align %.2f, take_results %.2f\n", t1 - t0, t2 - t1, t3 - t2,
+            now() - t3);
+  return st;
 }
 
 void kslam_free_batch(kslam_ctx *c, kslam_overlap *out, uint32_t *cigar_pool) {

@@ -44,5 +44,24 @@ int main() {
         printf("%-22s %-26s %s: best %.2f ms (%.1f GB/s), mean %.2f ms\n", load ? "under a busy kernel" : "idle GPU",
                kind ? "mmap+hipHostRegister" : "hipHostMalloc", dir ? "H2D" : "D2H", best, N / best / 1e6, sum / 5);
       }
+  // the same 64 MB split over several streams (several SDMA engines?): device -> hipHostMalloc memory, idle GPU
+  hipStream_t ss[8];
+  for (auto &x : ss) CK(hipStreamCreateWithFlags(&x, hipStreamNonBlocking));
+  for (int dir = 0; dir < 2; dir++)
+    for (int parts : {1, 2, 4, 8}) {
+      double best = 1e9;
+      for (int rep = 0; rep < 6; rep++) {
+        const double t0 = now();
+        const size_t step = N / parts;
+        for (int k = 0; k < parts; k++) {
+          if (dir == 0) CK(hipMemcpyAsync((char *)h1 + k * step, (char *)d + k * step, step, hipMemcpyDeviceToHost, ss[k]));
+          else CK(hipMemcpyAsync((char *)d + k * step, (char *)h1 + k * step, step, hipMemcpyHostToDevice, ss[k]));
+        }
+        for (int k = 0; k < parts; k++) CK(hipStreamSynchronize(ss[k]));
+        const double t = now() - t0;
+        if (rep) best = t < best ? t : best;
+      }
+      printf("%s in %d parts on %d streams: best %.2f ms (%.1f GB/s)\n", dir ? "H2D" : "D2H", parts, parts, best, N / best / 1e6);
+    }
   return 0;
 }

@@ -57,7 +57,7 @@ class StreamStats(C.Structure):
 def classify_stream_native(ctx, index, r1_ptr, len1, r2_ptr, len2, pairs_per_batch, params, taxdb=None, report=None,
                            sam_fd=-1, per_read_fd=-1, sam_header=None, max_pairs_total=0, depth=0, passes=1, host_threads=0, pool_threads=0):
     """kslam_stream_classify: the same loop as classify_stream below, inside the library (no Python between the batches).
-    Single-end data: params.paired = 0, r2_ptr = None, len2 = 0 (classify_stream below is the paired loop only).
+    Single-end data: params.paired = 0, r2_ptr = None, len2 = 0.
     -> dict of the statistics + tax_ids (uint32 array, empty without a taxdb)"""
     L = T.lib()
     L.kslam_stream_classify.argtypes = [C.c_void_p, C.POINTER(T.IndexView), C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
@@ -111,6 +111,7 @@ def cut_batches(r1_ptr, len1, r2_ptr, len2, pairs_per_batch, max_pairs_total=0, 
     the next boundary is looked for when the previous batch has been handed out)."""
     p1 = p2 = 0
     done_pairs = 0
+    single = r2_ptr is None                                     # single-end data: one text (src/SLAM.h:198-206)
     while p1 < len1 or p2 < len2:
         want = pairs_per_batch
         if max_pairs_total:
@@ -118,10 +119,10 @@ def cut_batches(r1_ptr, len1, r2_ptr, len2, pairs_per_batch, max_pairs_total=0, 
                 return
             want = min(want, max_pairs_total - done_pairs)      # readsPerGoTemp, src/SLAM.h:201-203
         e1, c1 = F.batch_end(r1_ptr + p1, len1 - p1, want, True, threads)
-        e2, c2 = F.batch_end(r2_ptr + p2, len2 - p2, want, True, threads)
+        e2 = 0 if single else F.batch_end(r2_ptr + p2, len2 - p2, want, True, threads)[0]
         e1 += p1
         e2 += p2
-        last = e1 >= len1 or e2 >= len2
+        last = e1 >= len1 or (not single and e2 >= len2)
         yield p1, e1, p2, e2, last
         done_pairs += want
         p1, p2 = e1, e2
@@ -140,21 +141,22 @@ def classify_stream(ctx, index, r1_ptr, len1, r2_ptr, len2, pairs_per_batch, par
     Test hooks, both called on the host-stage thread: before_batch(k, ov, cg, det, md, rp, pr, pair_stats, reads) sees
     the batch as the GPU returned it (the SAM writer sorts `pr` in place afterwards); on_batch(rec, ov, cg, rp, pr,
     reads) sees it after the host stage."""
-    if not params.paired:
-        raise KslamError(4, "classify_stream: paired data only (single-end data: classify_stream_native with r2_ptr = None)")
+    paired = bool(params.paired)
+    if not paired and (r2_ptr is not None or len2):
+        raise KslamError(2, "classify_stream: single-end data (params.paired == 0) is ONE text: r2_ptr must be None")
     t_start = time.perf_counter()
     stages = 3 | (4 if params.pseudo_assembly else 0)
-    ctx.set_pairing(paired=True, score_threshold=params.score_threshold, score_fraction=params.score_fraction, stages=stages)
+    ctx.set_pairing(paired=paired, score_threshold=params.score_threshold, score_fraction=params.score_fraction, stages=stages)
     depth = depth or 3
     # the SAM text leaves through a background writer (kslam_sam_writer): the write of batch k runs under the
     # formatting of batch k + 1
     writer = T.SamWriter(sam_fd) if sam_fd >= 0 else None
     if sam_header is not None and writer is not None:
         writer.write(sam_header)
-    P_host = T.TailParams.default(paired=True, report_cigar=bool(params.report_cigar), score_threshold=params.score_threshold,
+    P_host = T.TailParams.default(paired=paired, report_cigar=bool(params.report_cigar), score_threshold=params.score_threshold,
                                   num_sam_alignments=params.num_sam_alignments, score_fraction=params.score_fraction,
                                   pseudo_assembly=bool(params.pseudo_assembly), sam_xa=bool(params.sam_xa), threads=host_threads)
-    P_write = T.TailParams.default(paired=True, report_cigar=bool(params.report_cigar), score_threshold=params.score_threshold,
+    P_write = T.TailParams.default(paired=paired, report_cigar=bool(params.report_cigar), score_threshold=params.score_threshold,
                                    num_sam_alignments=params.num_sam_alignments, score_fraction=params.score_fraction,
                                    pseudo_assembly=False, sam_xa=bool(params.sam_xa), threads=host_threads)
     out = {"batches": [], "tax_ids": [], "pairs": 0, "sam_bytes": 0, "per_read_bytes": 0}
@@ -171,7 +173,7 @@ def classify_stream(ctx, index, r1_ptr, len1, r2_ptr, len2, pairs_per_batch, par
             st = finish_rows_fd(P_write if on_gpu or not params.pseudo_assembly else P_host, reads, index, ov, cg, det, md,
                                 rp, pr, writer if writer is not None else -1)
             t1 = time.perf_counter()
-            rec = {"batch": k, "pairs": reads.n_reads // 2, "overlaps": int(len(ov)), "alignment_pairs": int(st.n_paired_final),
+            rec = {"batch": k, "pairs": reads.n_reads // 2 if paired else reads.n_reads, "overlaps": int(len(ov)), "alignment_pairs": int(st.n_paired_final),
                    "read_pairs_aligned": int(st.n_read_pairs), "max_insert_size": int(pst["max_insert_size"]),
                    "pseudo_assembly_on": ("gpu" if on_gpu else "host") if params.pseudo_assembly else None,
                    "sam_bytes": int(st.sam_bytes), "ms_sam": round((t1 - t0) * 1e3, 2)}
@@ -213,7 +215,8 @@ def classify_stream(ctx, index, r1_ptr, len1, r2_ptr, len2, pairs_per_batch, par
                 # at_eof for inner windows too: a window ends right after a terminator (kslam_fastq_batch_end looked at
                 # the byte behind a closing "\r"), so the end-of-stream rule adds nothing but keeps that "\r" a whole
                 # terminator
-                queue.append(ctx.submit_batch_fastq_text(r1_ptr + p1, e1 - p1, r2_ptr + p2, e2 - p2, max_pairs=0, at_eof=True))
+                queue.append(ctx.submit_batch_fastq_text(r1_ptr + p1, e1 - p1, r2_ptr + p2 if paired else None, e2 - p2 if paired else 0,
+                                                         max_pairs=0, at_eof=True))
             if not queue:
                 break
             ta = time.perf_counter()

@@ -269,6 +269,15 @@ def test_single_end_stream_equals_the_reference_loop(kslam, oracle, synth, tmp_p
     per_read = open(per_read_path, "rb").read()
     n_batches = (n_reads + per_batch - 1) // per_batch
     assert nat["n_pairs"] == n_reads and nat["n_batches"] == n_batches
+    # the Python loop, single-end: the same files
+    sam_fd = os.open(sam_path + ".py", os.O_RDWR | os.O_CREAT | os.O_TRUNC)
+    pr_fd = os.open(per_read_path + ".py", os.O_RDWR | os.O_CREAT | os.O_TRUNC)
+    res = S.classify_stream(ctx, db, h1.ptr, len(r1), None, 0, per_batch, P, taxdb=tax, sam_fd=sam_fd, per_read_fd=pr_fd,
+                            sam_header=header)
+    os.close(sam_fd)
+    os.close(pr_fd)
+    assert open(sam_path + ".py", "rb").read() == sam and open(per_read_path + ".py", "rb").read() == per_read
+    assert res["pairs"] == n_reads and res["tax_ids"].tolist() == nat["tax_ids"].tolist()
     # a second text with paired = 0 is refused, and so is paired data handed over as one text
     with pytest.raises(kslam.KslamError, match="ONE text"):
         S.classify_stream_native(ctx, db, h1.ptr, len(r1), h1.ptr, len(r1), per_batch, P)

@@ -1166,6 +1166,18 @@ struct LineWriter {
       }
       return;
     }
+    if (v < 10000) {                     // scores, template lengths, short positions: three or four digits
+      const uint64_t q = v / 100, r = v - q * 100;
+      if (q >= 10) {
+        memcpy(w, pairs + 2 * q, 2);
+        w += 2;
+      } else {
+        *w++ = (char)('0' + q);
+      }
+      memcpy(w, pairs + 2 * r, 2);
+      w += 2;
+      return;
+    }
     char t[24];
     int k = 24;
     while (v >= 100) {

@@ -81,6 +81,8 @@ def lib():
         L.orc_sort_kmers.argtypes = [vp, u64]
         L.orc_count_overlaps.restype = u64
         L.orc_count_overlaps.argtypes = [vp, u64]
+        L.orc_scan_overlaps.restype = u64
+        L.orc_scan_overlaps.argtypes = [vp, u64, vp, vp]
         L.orc_find_overlaps.restype = u64
         L.orc_find_overlaps.argtypes = [vp, u64, vp, vp, vp]
         L.orc_build_matrix.argtypes = [u32, u32, vp]
@@ -148,6 +150,17 @@ def find_overlaps(sorted_recs, read_lens):
     m = L.orc_find_overlaps(s.ctypes.data, len(s), rl.ctypes.data, out.ctypes.data,
                             C.byref(nraw))
     return out[:m].copy(), int(nraw.value)
+
+
+def scan_overlaps(sorted_recs, read_lens):
+    """findOverlaps (reference src/Overlap.h:230-246) over the whole range: the pre-dedupe list, emission order."""
+    L = lib()
+    s = np.ascontiguousarray(sorted_recs)
+    rl = np.ascontiguousarray(np.asarray(read_lens, dtype=np.uint64))
+    raw = int(L.orc_count_overlaps(s.ctypes.data, len(s)))
+    out = np.zeros(raw + 1, dtype=OVERLAP_DT)
+    m = L.orc_scan_overlaps(s.ctypes.data, len(s), rl.ctypes.data, out.ctypes.data)
+    return out[:m].copy()
 
 
 def build_matrix(match, mismatch):
@@ -600,3 +613,209 @@ def ref_taxonomy_tree(path):
     h = _taxref.ref_taxdb_open(path.encode())
     assert h, "reference TaxonomyDB could not open " + path
     return _TaxTree(_taxref, "ref_", h, _taxref.ref_taxdb_close)
+
+
+# ---- the REAL join / dedupe / Aligner::Align / SW driver / alignToDatabase (oracle/_ref/libjoin_ref.so) ----
+REF_JOIN = os.path.join(_HERE, "_ref", "libjoin_ref.so")
+_refjoin = None
+
+
+def have_ref_join():
+    build()
+    return os.path.exists(REF_JOIN)
+
+
+def _refj():
+    global _refjoin
+    if _refjoin is None:
+        R = C.CDLL(REF_JOIN)
+        vp, u64, i32 = C.c_void_p, C.c_uint64, C.c_int32
+        R.ref_find_overlaps.restype = u64
+        R.ref_find_overlaps.argtypes = [vp, u64, u64, vp, vp, u64, C.POINTER(u64), vp, u64, C.c_char_p]
+        R.ref_sort_unique_overlaps.restype = u64
+        R.ref_sort_unique_overlaps.argtypes = [vp, u64]
+        R.ref_aligner_align.restype = i32
+        R.ref_aligner_align.argtypes = [C.c_char_p, C.c_char_p, i32, C.POINTER(Params), C.POINTER(C.c_uint16)] + \
+            [C.POINTER(i32)] * 4 + [vp, i32]
+        R.ref_align_to_database.restype = C.c_int
+        R.ref_align_to_database.argtypes = [u64, vp, vp, u64, vp, vp, C.POINTER(Params), C.POINTER(vp),
+                                            C.POINTER(u64), C.POINTER(vp), C.POINTER(u64), C.c_char_p]
+        R.ref_sw_on_overlaps.restype = C.c_int
+        R.ref_sw_on_overlaps.argtypes = [vp, u64, u64, vp, vp, u64, vp, vp, C.POINTER(Params), vp, vp, u64,
+                                         C.POINTER(u64)]
+        R.ref_free.argtypes = [vp]
+        _refjoin = R
+    return _refjoin
+
+
+def _one_thread(fn):
+    """overlapSort has no revComp in its key and __gnu_parallel::sort is unstable (src/Overlap.h:87-98, 289): run the
+    reference with ONE OpenMP thread so that ties come out the same way every time (libstdc++'s parallel sort falls back
+    to the sequential std::sort when the team has one thread)."""
+    old = os.environ.get("OMP_NUM_THREADS")
+    import ctypes.util
+    gomp = C.CDLL(ctypes.util.find_library("gomp") or "libgomp.so.1")
+    gomp.omp_get_max_threads.restype = C.c_int
+    before = gomp.omp_get_max_threads()
+    gomp.omp_set_num_threads(1)
+    try:
+        return fn()
+    finally:
+        gomp.omp_set_num_threads(before)
+        if old is not None:
+            os.environ["OMP_NUM_THREADS"] = old
+
+
+def ref_find_overlaps(sorted_recs, read_lens, one_thread=True, want_raw=False):
+    """The reference's own findOverlaps_parallel (src/Overlap.h:277-295) on a sorted record list.
+    -> (deduped overlaps[OVERLAP_DT], raw count), or with want_raw (deduped, raw list[OVERLAP_DT] in emission order)"""
+    R = _refj()
+    s = np.ascontiguousarray(sorted_recs)
+    rl = np.ascontiguousarray(np.asarray(read_lens, dtype=np.uint64))
+    cap = int(lib().orc_count_overlaps(s.ctypes.data, len(s))) + 16
+    out = np.zeros(cap, dtype=OVERLAP_DT)
+    raw = np.zeros(cap, dtype=OVERLAP_DT)
+    nraw = C.c_uint64(0)
+
+    def run():
+        with tempfile.TemporaryDirectory() as d:
+            return R.ref_find_overlaps(s.ctypes.data, len(s), len(rl), rl.ctypes.data, out.ctypes.data, cap,
+                                       C.byref(nraw), raw.ctypes.data, cap, d.encode())
+    m = _one_thread(run) if one_thread else run()
+    assert m <= cap and nraw.value <= cap
+    if want_raw:
+        return out[:m].copy(), raw[:int(nraw.value)].copy()
+    return out[:m].copy(), int(nraw.value)
+
+
+def ref_sort_unique_overlaps(overlaps):
+    """__gnu_parallel::sort(overlapSort) + std::unique(overlapEqual), src/Overlap.h:289-291, one thread."""
+    o = np.ascontiguousarray(overlaps.copy())
+    m = _one_thread(lambda: _refj().ref_sort_unique_overlaps(o.ctypes.data, len(o)))
+    return o[:m].copy()
+
+
+def ref_aligner_align(query, ref, params=None, ref_len=None):
+    """The reference's own Aligner::Align (src/ssw_cpp.cpp:234-283) on ASCII bytes.
+    -> ((score, ref_begin, ref_end, query_begin, query_end), cigar[u32])"""
+    p = params or Params.default()
+    n = len(ref) if ref_len is None else ref_len
+    cap = 2 * (len(query) + len(ref)) + 8
+    cig = np.zeros(cap, dtype=np.uint32)
+    sc = C.c_uint16()
+    v = [C.c_int32() for _ in range(4)]
+    m = _refj().ref_aligner_align(query, ref, n, C.byref(p), C.byref(sc), *[C.byref(x) for x in v],
+                                  cig.ctypes.data, cap)
+    assert m <= cap
+    return (int(sc.value),) + tuple(int(x.value) for x in v), cig[:m].copy()
+
+
+def ref_align_to_database(reads, entries, params=None, one_thread=True):
+    """The reference's own alignToDatabase (src/SLAM.h:59-79). -> (alignments[ALIGN_DT], cigar_pool[u32])"""
+    R = _refj()
+    p = params or Params.default()
+    rp, rl, k1 = _seq_arrays(reads)
+    ep, el, k2 = _seq_arrays(entries)
+    out, cig = C.c_void_p(), C.c_void_p()
+    n_out, n_cig = C.c_uint64(), C.c_uint64()
+
+    def run():
+        with tempfile.TemporaryDirectory() as d:
+            return R.ref_align_to_database(len(reads), C.cast(rp, C.c_void_p), rl.ctypes.data, len(entries),
+                                           C.cast(ep, C.c_void_p), el.ctypes.data, C.byref(p), C.byref(out),
+                                           C.byref(n_out), C.byref(cig), C.byref(n_cig), d.encode())
+    rc = _one_thread(run) if one_thread else run()
+    assert rc == 0
+    n, nc = int(n_out.value), int(n_cig.value)
+    al = np.frombuffer((C.c_char * (n * ALIGN_DT.itemsize)).from_address(out.value),
+                       dtype=ALIGN_DT).copy() if n else np.zeros(0, dtype=ALIGN_DT)
+    cg = np.frombuffer((C.c_char * (nc * 4)).from_address(cig.value),
+                       dtype=np.uint32).copy() if nc else np.zeros(0, dtype=np.uint32)
+    R.ref_free(out)
+    R.ref_free(cig)
+    return al, cg
+
+
+def ref_sw_on_overlaps(overlaps, reads, entries, params=None):
+    """The reference's own performSmithWatermanOnRange2 (src/SmithWaterman.h:184-233) on an OVERLAP_DT list
+    grouped by read.  -> (alignments[ALIGN_DT], cigar_pool[u32])"""
+    R = _refj()
+    p = params or Params.default()
+    ov = np.ascontiguousarray(overlaps, dtype=OVERLAP_DT)
+    rp, rl, k1 = _seq_arrays(reads)
+    ep, el, k2 = _seq_arrays(entries)
+    out = np.zeros(len(ov) + 1, dtype=ALIGN_DT)
+    cap = int(sum(2 * int(rl[int(r)]) + 8 for r in ov["read"])) + 8
+    pool = np.zeros(cap, dtype=np.uint32)
+    nc = C.c_uint64()
+    rc = R.ref_sw_on_overlaps(ov.ctypes.data, len(ov), len(reads), C.cast(rp, C.c_void_p), rl.ctypes.data,
+                              len(entries), C.cast(ep, C.c_void_p), el.ctypes.data, C.byref(p), out.ctypes.data,
+                              pool.ctypes.data, cap, C.byref(nc))
+    assert rc == 0
+    return out[:len(ov)].copy(), pool[:int(nc.value)].copy()
+
+
+# ---- the REAL batch loop metagenomicAnalysis_Low_Mem on files (oracle/_ref/libslam_ref.so) ----
+REF_SLAM = os.path.join(_HERE, "_ref", "libslam_ref.so")
+_refslam = None
+
+
+class RefSlamParams(C.Structure):
+    """the option globals of src/main.cpp:40-97, with its defaults"""
+    _fields_ = [("match", C.c_uint32), ("mismatch", C.c_uint32), ("gap_open", C.c_uint32),
+                ("gap_extend", C.c_uint32), ("score_threshold", C.c_uint32), ("num_sam_alignments", C.c_uint32),
+                ("score_fraction", C.c_double), ("pseudo_assembly", C.c_int32), ("sam_xa", C.c_int32),
+                ("just_align", C.c_int32), ("num_reads", C.c_uint32), ("num_reads_at_once", C.c_uint32),
+                ("threads", C.c_int32)]
+
+    @classmethod
+    def default(cls, **kw):
+        p = cls(2, 3, 5, 2, 0, 10, 0.95, 1, 0, 0, 0xFFFFFFFF, 10000000, 1)
+        for k, v in kw.items():
+            assert hasattr(p, k), k
+            setattr(p, k, v)
+        return p
+
+
+def have_ref_slam():
+    build()
+    return os.path.exists(REF_SLAM)
+
+
+def _refs():
+    global _refslam
+    if _refslam is None:
+        R = C.CDLL(REF_SLAM)
+        cp, u32, u64 = C.c_char_p, C.c_uint32, C.c_uint64
+        R.ref_slam_index_reset.argtypes = []
+        R.ref_slam_index_add_entry.argtypes = [cp, u64, cp, u32, u32]
+        R.ref_slam_index_add_gene.argtypes = [cp, cp, cp, cp, cp, u32, u32, u32, C.c_int32]
+        R.ref_slam_run.restype = C.c_int
+        R.ref_slam_run.argtypes = [cp, cp, cp, cp, cp, cp, C.POINTER(RefSlamParams), cp]
+        _refslam = R
+    return _refslam
+
+
+def ref_slam_set_index(entries):
+    """entries: list of dicts {bases, locus_tag, taxonomy_id, genbank_id?, genes: [{name, locus_tag?, protein_id,
+    product, reference?, gene_id?, start, stop, complement?}]} -- the GenbankIndex the reference's (unbuildable) archive
+    reader would have returned."""
+    R = _refs()
+    R.ref_slam_index_reset()
+    for e in entries:
+        R.ref_slam_index_add_entry(e["bases"], len(e["bases"]), e.get("locus_tag", b""), e.get("taxonomy_id", 0),
+                                   e.get("genbank_id", 0))
+        for g in e.get("genes", ()):
+            R.ref_slam_index_add_gene(g.get("name", b""), g.get("locus_tag", b""), g.get("protein_id", b""),
+                                      g.get("product", b""), g.get("reference", b""), g.get("gene_id", 0),
+                                      g["start"], g["stop"], int(g.get("complement", 0)))
+
+
+def ref_slam_run(r1, r2, db_dir, out, sam, params=None, command_line=b"SLAM", workdir=None):
+    """src/main.cpp:138-151 -> the reference's own metagenomicAnalysis_Low_Mem.  Paths are str; r2 / out / sam may be
+    "".  The index comes from ref_slam_set_index (db_dir only supplies <db_dir>/taxDB)."""
+    p = params or RefSlamParams.default()
+    with tempfile.TemporaryDirectory() as d:
+        rc = _refs().ref_slam_run(r1.encode(), r2.encode(), db_dir.encode(), out.encode(), sam.encode(),
+                                  command_line, C.byref(p), (workdir or d).encode())
+    assert rc == 0, "the reference threw"

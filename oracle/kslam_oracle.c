@@ -235,6 +235,11 @@ static uint64_t scan_pileups(const orc_kmer_rec *s, uint64_t n,
 uint64_t orc_count_overlaps(const orc_kmer_rec *sorted, uint64_t n) {
   return scan_pileups(sorted, n, NULL, NULL);
 }
+/* the pre-dedupe list in emission order (findOverlaps over the whole range) */
+uint64_t orc_scan_overlaps(const orc_kmer_rec *sorted, uint64_t n,
+                           const uint64_t *read_lens, orc_overlap *out) {
+  return scan_pileups(sorted, n, read_lens, out);
+}
 
 /* overlapSort, src/Overlap.h:87-98: (read, entry, rel); revComp is NOT in the
  * reference key -- the oracle appends it (false first) to make ties total. */

@@ -100,6 +100,8 @@ void orc_sort_kmers(orc_kmer_rec *recs, uint64_t n);
  * returns number of overlaps written (after sort+unique); *n_raw gets the
  * pre-dedupe count.  out must hold orc_count_overlaps() entries. */
 uint64_t orc_count_overlaps(const orc_kmer_rec *sorted, uint64_t n);
+uint64_t orc_scan_overlaps(const orc_kmer_rec *sorted, uint64_t n,
+                           const uint64_t *read_lens, orc_overlap *out);
 uint64_t orc_find_overlaps(const orc_kmer_rec *sorted, uint64_t n,
                            const uint64_t *read_lens, orc_overlap *out,
                            uint64_t *n_raw);

@@ -1,0 +1,144 @@
+// ref_slam_driver.cpp -- TEST INFRASTRUCTURE ONLY (oracle/_ref/libslam_ref.so).
+//
+// The REAL reference batch loop, metagenomicAnalysis_Low_Mem
+// (src/SLAM.h:159-268), compiled from the reference sources where they lie
+// and run on real files: FASTQ in; SAM, <out>, <out>_abbreviated,
+// <out>_PerRead and log.txt out.  src/SLAM.h is included WHOLE, and through it
+// KMer.h, FASTQsequence.h, Overlap.h, SmithWaterman.h, PairedOverlap.h,
+// SAM.h, MetagenomicResults.h, TaxonomyDatabase.h ... all unmodified.
+// ssw.c and ssw_cpp.cpp are linked (see ref_join_driver.cpp for how the
+// Makefile builds them).  Nothing of the reference is copied into the repo.
+//
+// Build-time accommodations (oracle/Makefile, in a mktemp directory deleted
+// after the compile):
+//   (1) ssw_cpp_noboost.h  = `sed 7d src/ssw_cpp.h` (drops the unused
+//       `#include <boost/optional.hpp>`); included first so the include guard
+//       makes every later `#include "ssw_cpp.h"` a no-op.
+//   (2) GenbankTools_noboost.h = `sed -n '18,23p;28,30p;32,200p;206,219p'
+//       src/GenbankTools.h` + `}` + `#endif`: the guard, the non-Boost
+//       includes, classes CDS / Gene / GenbankEntry / GenbankIndex (minus
+//       writeIndexToBoostSerial), getGene, GenbankIndex::getKMers.  Keeps
+//       the guard GENBANKTOOLS_H_, so SLAM.h's own include is skipped.
+//   (3) getIndexFromBoostSerial (src/GenbankTools.h:336-344) is the one
+//       function of the path that cannot exist without Boost.Serialization.
+//       This file DEFINES it as a test hook that returns the index the test
+//       injected through ref_slam_index_* (the same entries the test writes
+//       with the product's kslam_db_write for the product run).  So the
+//       archive GRAMMAR is not pinned by this library;
+//       everything downstream of the loaded GenbankIndex is.
+//   src/main.cpp (boost::program_options) is not built: the globals it sets
+//   (src/main.cpp:40-97) are set here from ref_slam_params.
+#include <omp.h>
+#include <array>
+#include <limits>
+#include <vector>
+#include <string>
+#include <cstdint>
+#include <cstring>
+#include <cstdlib>
+#include <cmath>
+#include <algorithm>
+#include <numeric>
+#include <thread>
+#include <mutex>
+#include <unordered_map>
+#include <fstream>
+#include <sstream>
+#include <iostream>
+#include <climits>
+#include <unistd.h>
+#include "ssw_cpp_noboost.h"
+#include "Globals.h"
+#include "sequenceTools.h"
+#include "KMer.h"
+#include "ParallelTools.h"
+#include "FASTQsequence.h"
+#include "MetagenomicFASTQSequence.h"
+#include "TaxonomyDatabase.h"
+#include "GenbankTools_noboost.h"
+namespace SLAM {
+GenbankIndex getIndexFromBoostSerial(const std::string serialFileName);
+}
+#include "SLAM.h"
+
+namespace {
+SLAM::GenbankIndex g_index;
+}
+namespace SLAM {
+GenbankIndex getIndexFromBoostSerial(const std::string) { return g_index; }
+}
+
+extern "C" {
+
+struct ref_slam_params {  // the option globals of src/main.cpp:40-97
+  uint32_t match, mismatch, gap_open, gap_extend;
+  uint32_t score_threshold;     // --min-alignment-score
+  uint32_t num_sam_alignments;  // --num-alignments
+  double score_fraction;        // --score-fraction-threshold
+  int32_t pseudo_assembly;      // !--no-pseudo-assembly
+  int32_t sam_xa;               // --sam-xa
+  int32_t just_align;           // --just-align
+  uint32_t num_reads;           // --num-reads
+  uint32_t num_reads_at_once;   // --num-reads-at-once
+  int32_t threads;              // OMP_NUM_THREADS (0 = leave)
+};
+
+void ref_slam_index_reset(void) { g_index.entries.clear(); }
+
+// appends a GenbankEntry (fields the archive carries, src/GenbankTools.h:155-163)
+void ref_slam_index_add_entry(const char *bases, uint64_t len, const char *locus_tag,
+                              uint32_t taxonomy_id, uint32_t genbank_id) {
+  SLAM::GenbankEntry e;
+  e.bases.assign(bases, len);
+  e.locusTag = locus_tag;
+  e.taxonomyID = taxonomy_id;
+  e.genbankID = genbank_id;
+  g_index.entries.push_back(e);
+}
+
+// appends a Gene to the last entry (fields of src/GenbankTools.h:101-109)
+void ref_slam_index_add_gene(const char *gene_name, const char *locus_tag,
+                             const char *protein_id, const char *product,
+                             const char *reference_sequence, uint32_t gene_id,
+                             uint32_t start, uint32_t stop, int32_t complement) {
+  SLAM::Gene g(gene_name, locus_tag, protein_id, product, reference_sequence,
+               SLAM::CDS(start, stop, complement != 0));
+  g.geneID = gene_id;
+  g_index.entries.back().genes.push_back(g);
+}
+
+// src/main.cpp:24-29,138-151: sets the globals, then metagenomicAnalysis_Low_Mem.
+// r2 may be "" (single end); out / sam may be "".  Runs in `workdir` (log.txt
+// lands there).  Returns 0, or 1 when the reference threw.
+int ref_slam_run(const char *r1, const char *r2, const char *db_dir, const char *out,
+                 const char *sam, const char *command_line, const ref_slam_params *p,
+                 const char *workdir) {
+  char old[4096];
+  if (!getcwd(old, sizeof old)) return 2;
+  if (workdir && chdir(workdir) != 0) return 3;
+  match = p->match;
+  misMatch = p->mismatch;
+  gapOpen = p->gap_open;
+  gapExtend = p->gap_extend;
+  scoreThreshold = p->score_threshold;
+  numSAMAlignments = p->num_sam_alignments;
+  scoreFractionThreshold = p->score_fraction;
+  performPseudoAssembly = p->pseudo_assembly != 0;
+  SAMXA = p->sam_xa != 0;
+  justAlign = p->just_align != 0;
+  reportCigar = false;  // set by the analysis when a SAM file is asked for (src/SLAM.h:169)
+  pairedData = true;
+  commandLine = command_line;
+  if (p->threads > 0) omp_set_num_threads(p->threads);
+  int rc = 0;
+  try {
+    SLAM::metagenomicAnalysis_Low_Mem(r1, r2, db_dir, out, sam, p->num_reads_at_once,
+                                      p->num_reads);
+  } catch (const std::exception &e) {
+    std::cerr << "reference threw: " << e.what() << std::endl;
+    rc = 1;
+  }
+  if (workdir && chdir(old) != 0) abort();
+  return rc;
+}
+}

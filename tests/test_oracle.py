@@ -189,3 +189,140 @@ def test_kmer_zero_never_joins(oracle):
     """src/Overlap.h:236-239: runs with kMerInt == 0 (poly-A / poly-T / all-N) are skipped."""
     al, _, _ = oracle.align_to_database([b"A" * 100, b"N" * 100, b"T" * 100], [b"A" * 500])
     assert len(al) == 0
+
+
+# ---- pins against the reference's own join / dedupe / aligner / SW driver (oracle/_ref/libjoin_ref.so) ----
+def _sorted4(a):
+    return np.sort(a[["read", "entry", "rel", "revcomp"]], order=["read", "entry", "rel", "revcomp"])
+
+
+def _same_modulo_revcomp_ties(got, exp, ties, fields):
+    assert len(got) == len(exp)
+    amb = np.array([(int(r), int(e), int(l)) in ties for r, e, l in zip(exp["read"], exp["entry"], exp["rel"])], dtype=bool)
+    for f in fields:
+        ok = got[f] == exp[f]
+        if f == "revcomp":
+            ok = ok | amb
+        assert ok.all(), (f, np.flatnonzero(~ok)[:5])
+    return int(amb.sum())
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_against_real_join_when_present(oracle, seed):
+    """orc_find_overlaps == the reference's own findOverlaps + findOverlaps_parallel (src/Overlap.h:153-295), compiled in
+    place, on pile-ups with several genome records, rc/fwd mixes, k-mer 0, genome ends and the revComp tie."""
+    if not oracle.have_ref_join():
+        pytest.skip("oracle/_ref/libjoin_ref.so not built (no /root/reference)")
+    from join_cases import make_join_case, revcomp_tie_rows
+    reads, genomes = make_join_case(seed)
+    recs = np.concatenate([oracle.extract_kmers(reads, False, 1), oracle.extract_kmers(genomes, True, 16)])
+    srt = oracle.ref_sort_kmers(recs)                       # the reference's own order, ties and all
+    lens = [len(r) for r in reads]
+    ref_ov, ref_raw = oracle.ref_find_overlaps(srt, lens, want_raw=True)
+    raw = oracle.scan_overlaps(srt, lens)
+    assert len(raw) == len(ref_raw) > 2000
+    assert (raw == ref_raw).all()                           # same list in the same emission order
+    ov, nraw = oracle.find_overlaps(srt, lens)
+    assert nraw == len(ref_raw)
+    ties = revcomp_tie_rows(ref_raw)
+    assert ties, "the case is meant to hold a revComp tie"
+    n_amb = _same_modulo_revcomp_ties(ov, ref_ov, ties, ("read", "entry", "rel", "revcomp"))
+    assert 0 < n_amb < 20
+    # the oracle's own sort (offset asc as the last key) instead of the reference's unstable one: same multiset, same dedupe
+    ov2, _ = oracle.find_overlaps(oracle.sort_kmers(recs), lens)
+    assert (ov2 == ov).all()
+    assert (_sorted4(oracle.scan_overlaps(oracle.sort_kmers(recs), lens)) == _sorted4(ref_raw)).all()
+    # multi-threaded reference run: chunked findOverlaps + parallel sort give the same list modulo the same ties
+    ref_mt, _ = oracle.ref_find_overlaps(srt, lens, one_thread=False)
+    _same_modulo_revcomp_ties(ref_mt, ref_ov, ties, ("read", "entry", "rel", "revcomp"))
+
+
+def test_against_real_dedupe_ladder_when_present(oracle):
+    """sort + unique alone (src/Overlap.h:289-291): 0,2,4,5,8 -> 0,4,8; comparison is with the LAST KEPT element."""
+    if not oracle.have_ref_join():
+        pytest.skip("oracle/_ref/libjoin_ref.so not built (no /root/reference)")
+    rng = np.random.default_rng(3)
+    rows = [(7, 3, r, 0) for r in (8, 5, 4, 2, 0)] + [(7, 4, r, 1) for r in (-3, -1, 1, 2, 100, 102, 105)]
+    rows += [(int(rng.integers(0, 5)), int(rng.integers(0, 3)), int(rng.integers(-20, 20)), 0) for _ in range(400)]
+    a = np.zeros(len(rows), dtype=oracle.OVERLAP_DT)
+    for i, (r, e, l, c) in enumerate(rows):
+        a[i]["read"], a[i]["entry"], a[i]["rel"], a[i]["revcomp"] = r, e, l, c
+    got = oracle.ref_sort_unique_overlaps(a)
+    lad = got[(got["read"] == 7) & (got["entry"] == 3)]
+    assert [int(x) for x in lad["rel"]] == [0, 4, 8]
+    # the restatement's unique on the same input
+    K = oracle.KMER_DT
+    b = np.sort(a, order=["read", "entry", "rel"])
+    kept = [0]
+    for i in range(1, len(b)):
+        x, y = b[kept[-1]], b[i]
+        if not (x["read"] == y["read"] and x["entry"] == y["entry"] and abs(int(x["rel"]) - int(y["rel"])) < 3):
+            kept.append(i)
+    assert (b[kept][["read", "entry", "rel"]] == got[["read", "entry", "rel"]]).all()
+
+
+@pytest.mark.parametrize("params", [(2, 3, 5, 2), (1, 4, 6, 1), (3, 2, 4, 3)])
+def test_against_real_aligner_when_present(oracle, params):
+    """orc_align == the reference's own Aligner::Align (src/ssw_cpp.cpp:234-283: kBaseTranslation, BuildSwScoreMatrix,
+    SetFlag, ConvertAlignment) on ASCII with lower case / U / IUPAC, ref_len < strlen, thresholded and disabled CIGAR."""
+    if not oracle.have_ref_join():
+        pytest.skip("oracle/_ref/libjoin_ref.so not built (no /root/reference)")
+    from join_cases import make_align_cases
+    cases = make_align_cases(sum(params), 300)
+    for thr, want_cigar in ((0, True), (120, True), (0, False)):
+        p = oracle.Params.default(report_cigar=want_cigar, score_threshold=thr, match=params[0], mismatch=params[1],
+                                  gap_open=params[2], gap_extend=params[3])
+        n_cig = n_nocig = 0
+        for i, (q, r, n) in enumerate(cases):
+            exp, ecig = oracle.ref_aligner_align(q, r, p, ref_len=n)
+            for plain in (False, True):
+                res, cig = oracle.align(q, r[:n], p, plain=plain)
+                got = (res.score1, res.ref_begin1, res.ref_end1, res.read_begin1, res.read_end1)
+                assert got == exp, (i, thr, want_cigar, plain)
+                assert np.array_equal(cig, ecig), (i, thr, want_cigar, plain)
+            n_cig += len(ecig) > 0
+            n_nocig += len(ecig) == 0
+        assert (n_cig > 0) == want_cigar and (n_nocig > 0) == (thr > 0 or not want_cigar)
+    # every byte of kBaseTranslation's domain (src/ssw_cpp.cpp:10: 128 entries; a byte >= 128 indexes outside the table in
+    # the reference -- undefined, nothing to pin) but NUL, as a query / a reference: the translation table and the 5x5 matrix
+    p = oracle.Params.default(match=params[0], mismatch=params[1], gap_open=params[2], gap_extend=params[3])
+    for c in range(1, 128):
+        for d in b"ACGTN":
+            q, r = bytes([c]) * 3, bytes([d]) * 3
+            exp, _ = oracle.ref_aligner_align(q, r, p)
+            res, _ = oracle.align(q, r, p)
+            assert res.score1 == exp[0], (c, d)
+
+
+@pytest.mark.parametrize("seed", [21, 22])
+def test_against_real_align_to_database_when_present(oracle, seed):
+    """orc_align_to_database == the reference's own alignToDatabase (src/SLAM.h:59-79: getKMersFromReads, getKMers,
+    sortKMers, findOverlaps_parallel, performSmithWatermanOnRange_parallel), and orc_sw_on_overlap == the reference's
+    performSmithWatermanOnRange2 (src/SmithWaterman.h:184-233) on the same overlap list."""
+    if not oracle.have_ref_join():
+        pytest.skip("oracle/_ref/libjoin_ref.so not built (no /root/reference)")
+    from join_cases import make_join_case, revcomp_tie_rows
+    reads, genomes = make_join_case(seed, n_reads=160)
+    recs = np.concatenate([oracle.extract_kmers(reads, False, 1), oracle.extract_kmers(genomes, True, 16)])
+    lens = [len(r) for r in reads]
+    ties = revcomp_tie_rows(oracle.scan_overlaps(oracle.sort_kmers(recs), lens))
+    fields = ("read", "entry", "rel", "revcomp", "score", "ref_begin", "ref_end", "query_begin", "query_end", "cigar_len")
+    for thr in (0, 150):
+        p = oracle.Params.default(score_threshold=thr)
+        exp, ecig = oracle.ref_align_to_database(reads, genomes, p)
+        assert len(exp) > 400
+        for plain in (False, True):
+            got, gcig, _ = oracle.align_to_database(reads, genomes, p, plain=plain)
+            _same_modulo_revcomp_ties(got, exp, ties, fields)
+            assert np.array_equal(gcig, ecig)
+        assert ((exp["cigar_len"] > 0) == (exp["score"] >= thr)).all()
+        # the SW driver alone, on the reference's own deduped list
+        ov = np.zeros(len(exp), dtype=oracle.OVERLAP_DT)
+        for f in ("read", "entry", "rel", "revcomp"):
+            ov[f] = exp[f]
+        sw, swcig = oracle.ref_sw_on_overlaps(ov, reads, genomes, p)
+        assert (sw == exp).all() and np.array_equal(swcig, ecig)
+    # multi-threaded reference run == one-thread run modulo the revComp ties
+    mt, _ = oracle.ref_align_to_database(reads, genomes, oracle.Params.default(), one_thread=False)
+    one, _ = oracle.ref_align_to_database(reads, genomes, oracle.Params.default())
+    _same_modulo_revcomp_ties(mt, one, ties, fields)

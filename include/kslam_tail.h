@@ -44,6 +44,8 @@ extern "C" {
 #define KSLAM_TAIL_PSEUDO_ASM 4u    /* pseudoAssembly + second score screen */
 #define KSLAM_TAIL_ALL 7u
 #define KSLAM_TAIL_PAIRING_ONLY 8u /* stop after pairing + grouping (stage-level tests) */
+#define KSLAM_TAIL_GROUPS_SORTED 16u /* kslam_tail_finish_write_rows only: every read pair's alignment pairs are already in
+                                        writeSAMOutputPairs' order (kslam_tail_finish_prepare put them there): do not sort again */
 
 /* The globals the tail reads (src/Globals.h:31-42, set in src/main.cpp:40-97) */
 typedef struct {
@@ -215,6 +217,20 @@ kslam_status kslam_tail_finish_write_rows(const kslam_tail_params *params,
                                           uint64_t n_read_pairs, kslam_paired_overlap *pairs,
                                           uint64_t n_pairs, kslam_write_fn write, void *user,
                                           kslam_tail_stats *stats);
+
+/* The part of kslam_tail_finish_write_rows that CHANGES read_pairs / pairs, on its own, so that a caller can finish it
+ * before anything reads the arrays concurrently (the batch loop's taxonomy thread, host/stream.cpp): pseudo-assembly +
+ * the second score screen when params ask for them (pass params->pseudo_assembly = 0 when the device already ran them),
+ * then -- when sort_groups != 0 -- the per-read-pair std::sort by combinedScore descending that writeSAMOutputPairs
+ * starts with (src/SAM.h:446-450; an in-place sort in the reference too, so the classification that follows sees this
+ * order, src/SLAM.h:234-246; without a SAM file the reference does not sort, hence the switch).  Afterwards call
+ * kslam_tail_finish_write_rows with pseudo_assembly = 0 and stages | KSLAM_TAIL_GROUPS_SORTED: it then only reads.
+ * stats (may be NULL): ms_pseudo, n_read_pairs, n_paired_final. */
+kslam_status kslam_tail_finish_prepare(const kslam_tail_params *params, const kslam_reads_view *reads,
+                                       const kslam_overlap *overlaps, uint64_t n_overlaps,
+                                       kslam_read_pair *read_pairs, uint64_t n_read_pairs,
+                                       kslam_paired_overlap *pairs, uint64_t n_pairs, int sort_groups,
+                                       kslam_tail_stats *stats);
 
 /* The tail keeps its work buffers (a few hundred bytes per overlap) between
  * calls; this returns them to the allocator.  Calls are serialised internally:

@@ -1188,7 +1188,7 @@ kslam_status kslam_adopt_results_device(kslam_ctx *c, const void *d_overlaps, ui
     if ((n_overlaps && !d_overlaps) || (n_cigar && !d_cigar_pool)) throw StatusError{KSLAM_ERR_ARG, "null argument"};
     hipStream_t s = c->stream;
     c->have_details = false;
-    c->have_pairs = c->pairs_of_result = false;
+    c->have_pairs = c->pairs_of_result = c->phase_a_done = false;
     c->res_ov.ensure((n_overlaps + 1) * sizeof(kslam_overlap));
     c->res_cig.ensure((n_cigar + 1) * sizeof(uint32_t));
     if (n_overlaps) HIPCHK(hipMemcpyAsync(c->res_ov.p, d_overlaps, n_overlaps * sizeof(kslam_overlap), hipMemcpyDeviceToDevice, s));
@@ -1493,7 +1493,7 @@ kslam_status kslam_pair_screen(kslam_ctx *c, int paired, uint32_t score_threshol
     if (paired && (c->n_reads < 2 || (c->n_reads & 1)))
       throw StatusError{KSLAM_ERR_ARG, "paired data needs an even, non-zero number of reads ([R1 block | R2 block])"};
     if (c->n_res >= (1ull << 30)) throw StatusError{KSLAM_ERR_UNSUPPORTED, "2^30 or more overlaps in one batch"};
-    c->have_pairs = c->pairs_of_result = false;
+    c->have_pairs = c->pairs_of_result = c->phase_a_done = false;
     pair_and_screen(c->res_ov.as<kslam_overlap>(), c->n_res, c->r_len.as<uint32_t>(), c->n_reads, paired ? 1 : 0,
                     score_threshold, score_fraction, (stages & 1u) != 0, (stages & 2u) != 0, c->pw, c->sortws, &c->pres,
                     c->stream);
@@ -1513,7 +1513,7 @@ kslam_status kslam_pair_phase_a(kslam_ctx *c, int paired, uint32_t score_thresho
     if (paired && (c->n_reads < 2 || (c->n_reads & 1)))
       throw StatusError{KSLAM_ERR_ARG, "paired data needs an even, non-zero number of reads ([R1 block | R2 block])"};
     if (c->n_res >= (1ull << 30)) throw StatusError{KSLAM_ERR_UNSUPPORTED, "2^30 or more overlaps in one batch"};
-    c->have_pairs = c->pairs_of_result = false;
+    c->have_pairs = c->pairs_of_result = c->phase_a_done = false;
     pair_phase_a(c->res_ov.as<kslam_overlap>(), c->n_res, c->r_len.as<uint32_t>(), c->n_reads, paired ? 1 : 0, score_threshold, c->pw,
                  &c->pres, c->stream);
     HIPCHK(stream_wait(c->stream));
@@ -1547,7 +1547,9 @@ kslam_status kslam_pseudo_merged(kslam_ctx *c, void *d_all_pairs, uint64_t n_all
   return guarded(c, [&] {
     if (!(c->have_pairs && c->pairs_of_result)) throw StatusError{KSLAM_ERR_STATE, "kslam_pair_phase_b has not been called for this result"};
     if (n_all && !d_all_pairs) throw StatusError{KSLAM_ERR_ARG, "null records"};
-    pseudo_merged(c->pw, &c->pres, d_all_pairs, n_all, own_base, score_fraction, c->sortws, c->stream);
+    if (!pseudo_merged(c->pw, &c->pres, d_all_pairs, n_all, own_base, score_fraction, c->sortws, c->stream))
+      throw StatusError{KSLAM_ERR_UNSUPPORTED, "the batch-global pseudo-assembly declined (2^28 or more alignment pairs in one batch): "
+                                               "nothing was changed; gather the pairs on one host and run kslam_tail_finish_prepare there"};
     HIPCHK(stream_wait(c->stream));
     fill_pair_stats(c->pres, stats);
   });
@@ -1562,7 +1564,7 @@ kslam_status kslam_pair_screen_overlaps(kslam_ctx *c, const kslam_overlap *overl
     if (paired && (n_reads < 2 || (n_reads & 1)))
       throw StatusError{KSLAM_ERR_ARG, "paired data needs an even, non-zero number of reads ([R1 block | R2 block])"};
     if (n_overlaps >= (1ull << 30)) throw StatusError{KSLAM_ERR_UNSUPPORTED, "2^30 or more overlaps in one batch"};
-    c->have_pairs = c->pairs_of_result = false;
+    c->have_pairs = c->pairs_of_result = c->phase_a_done = false;
     c->pr_ov.ensure((n_overlaps + 1) * sizeof(kslam_overlap));
     c->pr_len.ensure((n_reads + 1) * sizeof(uint32_t));
     if (n_overlaps)

@@ -249,6 +249,8 @@ def sharded_tail(ctx, dev, paired=True, score_threshold=0, score_fraction=0.95, 
         torch.cuda.synchronize(dev)
         all_recs, c2 = all_gather_bytes(recs, dev, group)
         torch.cuda.synchronize(dev)
+        # raises KslamError(KSLAM_ERR_UNSUPPORTED) when the device stage declines (2^28 or more records in the batch):
+        # a rank must not fall back to pseudo-assembling its OWN pairs, the stage is batch-global (src/PairedOverlap.h:480-582)
         stats = ctx.pseudo_merged(all_recs.data_ptr() if all_recs.numel() else None, all_recs.numel() // 32, sum(c2[:rank]) // 32,
                                   score_fraction)
         moved += sum(c2)

@@ -55,7 +55,8 @@ extern "C" kslam_status kslam_stream_classify(kslam_ctx *ctx, const kslam_index_
   std::vector<uint32_t> all_ids;
   bool pairing_set = false;
 
-  Pool::get().set_cap(P && P->pool_threads ? (int)P->pool_threads : std::max(2, usable_cpus() - 4));
+  const int pool_cap = P && P->pool_threads ? (int)P->pool_threads : std::max(2, usable_cpus() - 4);
+  Pool::get().add_cap(pool_cap);
   // whatever happens: the worker joined, the tickets collected and released, the writer closed, the pairing switched off
   auto wind_down = [&]() -> kslam_status {
     if (worker.joinable()) worker.join();
@@ -73,7 +74,7 @@ extern "C" kslam_status kslam_stream_classify(kslam_ctx *ctx, const kslam_index_
       writer = nullptr;
     }
     if (pairing_set) kslam_set_pairing(ctx, 1, 0, 0.95, 0);
-    Pool::get().set_cap(0);
+    Pool::get().remove_cap(pool_cap);
     return w;
   };
 
@@ -94,8 +95,10 @@ extern "C" kslam_status kslam_stream_classify(kslam_ctx *ctx, const kslam_index_
       if (P->sam_header && P->sam_header_len && kslam_write_queued(writer, P->sam_header, P->sam_header_len) != 0)
         fail(KSLAM_ERR_ARG, "writing the SAM header failed");
     }
-    kslam_tail_params host_all = P->tail, host_write = P->tail;   // what the host stage still has to run
+    kslam_tail_params host_all = P->tail, host_write = P->tail, host_sorted = P->tail;   // what the host stage still has to run
     host_write.pseudo_assembly = 0;
+    host_sorted.pseudo_assembly = 0;
+    host_sorted.stages = (P->tail.stages ? P->tail.stages : KSLAM_TAIL_ALL) | KSLAM_TAIL_GROUPS_SORTED;
 
     // ---- batch boundaries, found ahead of the submission (src/SLAM.h:193, 201-206) ----
     uint64_t p1 = 0, p2 = 0, done_pairs = 0;
@@ -128,11 +131,14 @@ extern "C" kslam_status kslam_stream_classify(kslam_ctx *ctx, const kslam_index_
       return true;
     };
 
-    // The host stage of one batch, on the worker thread (it owns `res`): the SAM text on this thread, the taxonomy part
-    // (per-read LCA, <out>_PerRead, the report's records) on a second one at the same time.  Both only read `res`; the
-    // pool shares its workers between their loops, and the serial stretches of one (offsets, buffer growth, the per-read
-    // file's write) run under the other's loops instead of leaving the workers idle (the bench's /dev/null leg: 53 ->
-    // 48-50 ms per step; with a file behind it the writer and this stage are about level).
+    // The host stage of one batch, on the worker thread (it owns `res`), in the reference's order (src/SLAM.h:228-246):
+    //   (1) everything that CHANGES res.read_pairs / res.pairs: what the device left of pseudo-assembly + the second score
+    //       screen, then writeSAMOutputPairs' per-pair sort (only when there is a SAM file: without one the reference does
+    //       not sort, and the classification sees the unsorted order) -- kslam_tail_finish_prepare;
+    //   (2) the SAM text on this thread and the taxonomy part (per-read LCA, <out>_PerRead, the report's records) on a
+    //       second one at the same time.  From here on both only READ `res`; the pool shares its workers between their
+    //       loops, and the serial stretches of one (offsets, buffer growth, the per-read file's write) run under the
+    //       other's loops instead of leaving the workers idle.
     auto host_stage = [&](kslam_batch_result res) {
       name_thread("kslam-host");
       kslam_reads_view reads = {res.n_reads, nullptr, res.reads_bases_off, nullptr, res.reads_bases_off, res.reads_ids, res.reads_ids_off};
@@ -164,31 +170,42 @@ extern "C" kslam_status kslam_stream_classify(kslam_ctx *ctx, const kslam_index_
           });
           if (tax_status != KSLAM_OK) tax_error = g_err;
       };
-      const bool two_threads = P->host_threads != 1;
-      if (taxdb && two_threads) tax_thread = std::thread([&] { name_thread("kslam-tax"); tax_part(); });
       kslam_status s = guarded([&] {
         const bool on_gpu = (res.pair_stats.stages_done & KSLAM_TAIL_PSEUDO_ASM) != 0;
         if (P->tail.pseudo_assembly && !on_gpu) st.batches_pseudo_on_host++;
         const kslam_tail_params *tp = (on_gpu || !P->tail.pseudo_assembly) ? &host_write : &host_all;
-        kslam_tail_stats ts;
-        memset(&ts, 0, sizeof ts);
+        kslam_tail_stats ps;
+        memset(&ps, 0, sizeof ps);
         const double t0 = now_ms();
-        static const auto drop = [](void *, const char *, uint64_t) -> int { return 0; };
-        const kslam_status a = kslam_tail_finish_write_rows(tp, &reads, index, res.overlaps, res.n_overlaps, res.cigar_pool, res.n_cigar,
-                                                            res.details, res.md_pool, res.n_md, res.read_pairs, res.n_read_pairs,
-                                                            res.pairs, res.n_pairs, writer ? kslam_write_queued : +drop,
-                                                            writer ? (void *)writer : nullptr, &ts);
+        const kslam_status a = kslam_tail_finish_prepare(tp, &reads, res.overlaps, res.n_overlaps, res.read_pairs, res.n_read_pairs,
+                                                         res.pairs, res.n_pairs, writer ? 1 : 0, &ps);
         if (a != KSLAM_OK) fail(a, kslam_tail_last_error());
         st.seconds_sam_text += (now_ms() - t0) * 1e-3;
-        st.sam_bytes += ts.sam_bytes;
-        st.n_alignment_pairs += ts.n_paired_final;
-        st.n_read_pairs_aligned += ts.n_read_pairs;
+        st.n_alignment_pairs += ps.n_paired_final;
+        st.n_read_pairs_aligned += ps.n_read_pairs;
         st.n_overlaps += res.n_overlaps;
         if (st.n_batches == 0) st.first_max_insert_size = res.pair_stats.max_insert_size;
         st.n_batches++;
         st.n_pairs += P->tail.paired ? res.n_reads / 2 : res.n_reads;
       });
       std::string err = s != KSLAM_OK ? g_err : std::string();
+      const bool two_threads = P->host_threads != 1;
+      if (s == KSLAM_OK && taxdb && two_threads) tax_thread = std::thread([&] { name_thread("kslam-tax"); tax_part(); });
+      if (s == KSLAM_OK && writer) {
+        s = guarded([&] {
+          kslam_tail_stats ts;
+          memset(&ts, 0, sizeof ts);
+          const double t0 = now_ms();
+          const kslam_status a = kslam_tail_finish_write_rows(&host_sorted, &reads, index, res.overlaps, res.n_overlaps, res.cigar_pool,
+                                                              res.n_cigar, res.details, res.md_pool, res.n_md, res.read_pairs,
+                                                              res.n_read_pairs, res.pairs, res.n_pairs, kslam_write_queued,
+                                                              (void *)writer, &ts);
+          if (a != KSLAM_OK) fail(a, kslam_tail_last_error());
+          st.seconds_sam_text += (now_ms() - t0) * 1e-3;
+          st.sam_bytes += ts.sam_bytes;
+        });
+        if (s != KSLAM_OK) err = g_err;
+      }
       if (tax_thread.joinable()) tax_thread.join();
       else if (taxdb && s == KSLAM_OK) tax_part();
       if (s == KSLAM_OK && tax_status != KSLAM_OK) {

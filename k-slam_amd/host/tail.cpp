@@ -812,6 +812,7 @@ struct SamInput {
   const kslam_row_detail *det = nullptr;
   const char *md_pool = nullptr;
   uint64_t n_md = 0;
+  bool groups_sorted = false;  // KSLAM_TAIL_GROUPS_SORTED: writeSAMOutputPairs' per-pair sort already done
 };
 
 struct Row {  // SAMEntry, src/SAM.h:238-277, text fields as slices of the task's scratch
@@ -1284,7 +1285,7 @@ void write_group(const SamInput &in, const Group &g, Rec *recs, Text &out, Text 
                  std::vector<Row> &rows, std::vector<int64_t> &genes) {
   if (!g.count) return;
   const bool paired = in.p->paired != 0;
-  std::sort(recs, recs + g.count, by_score_desc);
+  if (!in.groups_sorted) std::sort(recs, recs + g.count, by_score_desc);
   scratch.n = 0;
   rows.clear();
   genes.clear();
@@ -1468,7 +1469,7 @@ struct kslam_sam_writer {
   std::deque<std::vector<Text>> queue;
   std::vector<std::vector<Text>> spare;
   bool stop = false, busy = false;
-  int error = 0;            // errno of the first failed write
+  std::atomic<int> error{0};           // errno of the first failed write
   uint64_t bytes = 0;
   double write_s = 0;
   void run() {
@@ -1759,6 +1760,54 @@ kslam_status kslam_tail_sam_write_rows(const kslam_tail_params *params, const ks
   });
 }
 
+kslam_status kslam_tail_finish_prepare(const kslam_tail_params *params, const kslam_reads_view *reads,
+                                       const kslam_overlap *overlaps, uint64_t n_overlaps,
+                                       kslam_read_pair *read_pairs, uint64_t n_read_pairs,
+                                       kslam_paired_overlap *pairs, uint64_t n_pairs, int sort_groups,
+                                       kslam_tail_stats *stats) {
+  return guarded([&] {
+    if ((!read_pairs && n_read_pairs) || (!pairs && n_pairs)) fail(KSLAM_ERR_ARG, "null argument");
+    Input in = make_input(params, reads, overlaps, n_overlaps);
+    for (uint64_t g = 0; g < n_read_pairs; g++)
+      if (read_pairs[g].first + read_pairs[g].count > n_pairs) fail(KSLAM_ERR_ARG, "read pair slice outside the pairs array");
+    Arena &A = arena();
+    std::lock_guard<std::mutex> one(A.call);
+    kslam_tail_stats st;
+    memset(&st, 0, sizeof st);
+    st.n_overlaps_in = n_overlaps;
+    TailState ts;
+    ts.recs = pairs;
+    ts.groups = read_pairs;
+    ts.n_groups = n_read_pairs;
+    ts.n_recs = n_pairs;
+    ts.rec_extent = n_pairs;
+    const double t0 = now_ms();
+    if (in.p->pseudo_assembly && (in.stages & KSLAM_TAIL_PSEUDO_ASM)) {
+      uint32_t mx = 0;
+      for (uint64_t k = 0; k < n_pairs; k++) mx = std::max(mx, pairs[k].entry);
+      ts.max_entry = mx;
+      pseudo_stage(in, A, ts);
+      rescreen_stage(in, ts);
+    }
+    st.ms_pseudo = now_ms() - t0;
+    if (sort_groups) {   // writeSAMOutputPairs' first statement, src/SAM.h:446-450
+      const size_t n_tasks = task_count(in.threads, ts.n_groups, 512);
+      auto cut = group_ranges(ts.groups, ts.n_groups, n_tasks);
+      Pool::get().tasks(in.threads, n_tasks, [&](size_t t) {
+        for (size_t g = cut[t]; g < cut[t + 1]; g++)
+          if (ts.groups[g].count > 1)
+            std::sort(ts.recs + ts.groups[g].first, ts.recs + ts.groups[g].first + ts.groups[g].count, by_score_desc);
+      });
+    }
+    st.n_read_pairs = ts.n_groups;
+    uint64_t total = 0;
+    for (size_t g = 0; g < ts.n_groups; g++) total += ts.groups[g].count;
+    st.n_paired_final = total;
+    st.threads = in.threads;
+    if (stats) *stats = st;
+  });
+}
+
 kslam_status kslam_tail_finish_write_rows(const kslam_tail_params *params, const kslam_reads_view *reads,
                                           const kslam_index_view *index, const kslam_overlap *overlaps,
                                           uint64_t n_overlaps, const uint32_t *cigar_pool, uint64_t n_cigar,
@@ -1798,6 +1847,7 @@ kslam_status kslam_tail_finish_write_rows(const kslam_tail_params *params, const
     st.n_paired_final = total;
     st.threads = in.threads;
     SamInput si{params, reads, index, overlaps, n_overlaps, cigar_pool, n_cigar};
+    si.groups_sorted = (params->stages & KSLAM_TAIL_GROUPS_SORTED) != 0;
     if (details && cigar_pool) {
       if (!md_pool && n_md) fail(KSLAM_ERR_ARG, "null MD pool");
       si.det = details;

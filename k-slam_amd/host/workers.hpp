@@ -90,7 +90,19 @@ class Pool {
   // At most `n` threads on any loop from now on and at most n - 1 workers awake (0: no limit).  For a caller that runs
   // other busy threads next to the loops -- the batch loop's writer, lanes and second host thread -- inside a CPU
   // quota: more runnable threads than the quota has CPUs get the whole process throttled (cgroup cpu.max).
-  void set_cap(int n) { cap_.store(n > 0 ? n : (1 << 30), std::memory_order_relaxed); }
+  // Callers nest and overlap (one batch loop per GPU context in one process): every caller registers its cap and takes it
+  // back when it is done; the strictest registered cap is the one in force, none registered = no limit.
+  void add_cap(int n) {
+    std::lock_guard<std::mutex> lk(cap_m_);
+    caps_.push_back(n > 0 ? n : (1 << 30));
+    cap_.store(*std::min_element(caps_.begin(), caps_.end()), std::memory_order_relaxed);
+  }
+  void remove_cap(int n) {
+    std::lock_guard<std::mutex> lk(cap_m_);
+    auto it = std::find(caps_.begin(), caps_.end(), n > 0 ? n : (1 << 30));
+    if (it != caps_.end()) caps_.erase(it);
+    cap_.store(caps_.empty() ? (1 << 30) : *std::min_element(caps_.begin(), caps_.end()), std::memory_order_relaxed);
+  }
 
  private:
   struct Job {
@@ -154,6 +166,8 @@ class Pool {
   std::vector<Job *> active_;
   size_t workers_ = 0;
   std::atomic<int> cap_{1 << 30};
+  std::mutex cap_m_;
+  std::vector<int> caps_;   // guarded by cap_m_
 };
 
 // Asks for transparent huge pages under a large heap block (the boxes run THP in "madvise" mode).

@@ -22,7 +22,7 @@ assert PAIRED_OVERLAP_DT.itemsize == 32 and READ_PAIR_DT.itemsize == 24
 # every symbol include/kslam_tail.h declares
 EXPORTS = ["kslam_tail_last_error", "kslam_tail_pairs", "kslam_sam_records", "kslam_tail_sam",
            "kslam_tail_sam_write", "kslam_tail_sam_rows", "kslam_tail_sam_write_rows", "kslam_tail_finish_write_rows",
-           "kslam_tail_release_buffers",
+           "kslam_tail_finish_prepare", "kslam_tail_release_buffers",
            "kslam_sam_header", "kslam_write_fd", "kslam_sam_writer_open", "kslam_write_queued", "kslam_sam_writer_close"]
 WRITE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64)
 
@@ -185,6 +185,7 @@ def lib():
                                                 _vp, _vp, _u64, WRITE_FN, _vp, P(TailStats)]
         L.kslam_tail_finish_write_rows.argtypes = [P(TailParams), P(ReadsView), P(IndexView), _vp, _u64, _vp, _u64,
                                                    _vp, _vp, _u64, _vp, _u64, _vp, _u64, WRITE_FN, _vp, P(TailStats)]
+        L.kslam_tail_finish_prepare.argtypes = [P(TailParams), P(ReadsView), _vp, _u64, _vp, _u64, _vp, _u64, C.c_int, P(TailStats)]
         L.kslam_tail_release_buffers.restype = None
         L.kslam_sam_header.argtypes = [P(IndexView), C.c_char_p, P(_vp), P(_u64)]
         L.kslam_sam_writer_open.argtypes = [C.c_int, P(_vp)]
@@ -337,6 +338,21 @@ def tail_finish_rows(params, reads, index, overlaps, cigar_pool, details, md_poo
                                         _p(md) if len(md) else None, len(md),
                                         _p(read_pairs) if len(read_pairs) else None, len(read_pairs),
                                         _p(pairs) if len(pairs) else None, len(pairs), cb, None, C.byref(st)))
+    return st
+
+
+def tail_finish_prepare(params, reads, overlaps, read_pairs, pairs, sort_groups=True):
+    """kslam_tail_finish_prepare: the part of the finish that CHANGES read_pairs / pairs (host pseudo-assembly + second
+    screen when params ask, then writeSAMOutputPairs' per-pair sort), in place.  Afterwards tail_finish_rows with
+    pseudo_assembly=False and stages | KSLAM_TAIL_GROUPS_SORTED (16) only reads them."""
+    L = lib()
+    ov, pov = _ov(overlaps)
+    assert read_pairs.dtype == READ_PAIR_DT and pairs.dtype == PAIRED_OVERLAP_DT
+    assert read_pairs.flags["C_CONTIGUOUS"] and pairs.flags["C_CONTIGUOUS"] and read_pairs.flags["WRITEABLE"] and pairs.flags["WRITEABLE"]
+    st = TailStats()
+    _chk(L.kslam_tail_finish_prepare(C.byref(params), C.byref(reads.view), pov, len(ov),
+                                     _p(read_pairs) if len(read_pairs) else None, len(read_pairs),
+                                     _p(pairs) if len(pairs) else None, len(pairs), int(sort_groups), C.byref(st)))
     return st
 
 

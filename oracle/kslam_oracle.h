@@ -10,28 +10,39 @@
  * alignToDatabase() path (reference src/SLAM.h:59-79).  Every function cites
  * the reference file:line it follows.  Citations are into /root/reference/.
  *
- * Parity pinning status (see also DESIGN.md "Oracle"):
- *   PINNED by the real reference compiled in place (oracle/_ref, built by
- *   oracle/Makefile from /root/reference/src, no stand-in headers):
+ * Parity pinning status (see also DESIGN.md "Oracle"): EVERY function below is
+ * pinned by the real reference compiled in place (oracle/_ref, built by
+ * oracle/Makefile from /root/reference/src; no stand-in headers -- Boost is
+ * avoided by two build-time line slices described in the Makefile):
  *     - ssw core: ssw_init / ssw_align / sw_sse2_byte / sw_sse2_word /
- *       banded_sw (src/ssw.c)            -> orc_ssw_align, orc_banded_sw
- *     - k-mer codec, extraction, sort (src/KMer.h)
+ *       banded_sw (src/ssw.c, libssw_ref.so)  -> orc_ssw_align, orc_banded_sw
+ *     - k-mer codec, extraction, sort (src/KMer.h, libkmer_ref.so)
  *                                         -> orc_extract_kmers, orc_sort_kmers
- *   PINNED by reference outputs recorded in SURVEY.md section 8c (golden
- *   vectors in tests/golden/survey_vectors.json): first k-mer records of a
- *   46-base read / genome, four Aligner::Align (ssw_cpp.cpp) tuples + CIGARs.
- *   PARITY UNPINNED against an executed reference (src/Overlap.h and
- *   src/SmithWaterman.h include Boost headers that this image lacks, so they
- *   cannot be built without stand-ins): the join/dedupe (orc_find_overlaps),
- *   the window/flip driver (orc_sw_on_overlap) and the ssw_cpp wrapper
- *   (orc_align) are line-by-line restatements checked only against the
- *   reference's own structural test expectations (src/Tests.h:161-330).
+ *     - join + dedupe: processPileUp / findOverlaps / findOverlaps_parallel
+ *       (src/Overlap.h, included whole in libjoin_ref.so)
+ *                                         -> orc_scan_overlaps, orc_find_overlaps
+ *     - Aligner::Align + TranslateBase + BuildSwScoreMatrix + SetFlag +
+ *       ConvertAlignment (src/ssw_cpp.cpp, libjoin_ref.so)   -> orc_align
+ *     - performSmithWatermanOnRange2 (src/SmithWaterman.h, included whole)
+ *                                         -> orc_sw_on_overlap
+ *     - alignToDatabase (src/SLAM.h:59-79)  -> orc_align_to_database
+ *   tests/test_oracle.py::test_against_real_* compare them on seeded cases when
+ *   oracle/_ref exists; tests/golden/{ssw,kmer,join,align}_vectors.npz hold the
+ *   reference's recorded answers for machines without it.
+ *   One caveat the reference itself leaves open: overlapSort has no revComp
+ *   in its key and the sort is unstable (src/Overlap.h:87-98, 289), so where
+ *   the raw list holds the same (read, entry, rel) with both revComp values
+ *   the survivor's flag is a tie.  The oracle (and the product) keep
+ *   revComp == false; the comparisons flag those rows.
  *
- * Two more checkers live beside this one, each with its own status header:
+ * More checkers live beside this one, each with its own status header:
  *   fastq_oracle.cpp  FASTQ reader (src/FASTQsequence.h) -- PINNED by the real
  *                     reference (ref_fastq_driver.cpp -> _ref/libfastq_ref.so)
- *   tail_oracle.cpp   pairing .. SAM (src/PairedOverlap.h, src/SAM.h) -- PARITY
- *                     UNPINNED (Boost), pinned by the SAM definition instead
+ *   taxonomy_oracle.cpp  taxonomy tree + LCA -- PINNED (_ref/libtaxonomy_ref.so)
+ *   tail_oracle.cpp   pairing .. SAM (src/PairedOverlap.h, src/SAM.h) -- PINNED
+ *                     by the reference's own batch loop run on files
+ *                     (ref_slam_driver.cpp -> _ref/libslam_ref.so;
+ *                     tests/test_reference_loop.py, tests/golden/slam_loop.npz)
  */
 #ifndef KSLAM_ORACLE_H_
 #define KSLAM_ORACLE_H_

@@ -6,14 +6,17 @@
 // overlaps, std::string fields), so that the product's flat, threaded
 // implementation is checked against an independently shaped one.
 //
-// PARITY UNPINNED: the reference headers for this stage (src/PairedOverlap.h,
-// src/SAM.h) include src/Overlap.h -> src/ssw_cpp.h -> <boost/optional.hpp> and
-// src/GenbankTools.h -> Boost.Serialization; Boost is not in this image, so the
-// reference cannot be compiled here and its tests (src/Tests.h) hold no golden
-// vectors for pairing or SAM.  What pins this file instead: tests/test_tail.py
-// checks the SAM text against the SAM definition itself (CIGAR + MD re-create
-// the reference window, NM equals the edit count, flags/mate fields are
-// consistent) and hand-worked pairing cases.
+// PINNED by the reference's own batch loop (metagenomicAnalysis_Low_Mem,
+// src/SLAM.h:159-268, with src/PairedOverlap.h, src/SAM.h and
+// src/MetagenomicResults.h included whole) compiled in place as
+// oracle/_ref/libslam_ref.so (oracle/ref_slam_driver.cpp) and run on real
+// files: tests/test_reference_loop.py compares the SAM text (header included)
+// byte for byte over paired / single-end data, with and without
+// pseudo-assembly, --sam-xa, --num-alignments, --min-alignment-score and
+// several batch sizes; tests/golden/slam_loop.npz holds the reference's files
+// for machines without /root/reference.  tests/test_tail.py additionally checks
+// the SAM text against the SAM definition itself (CIGAR + MD re-create the
+// reference window, NM equals the edit count) and hand-worked pairing cases.
 //
 // Where the reference's result depends on an unstable parallel sort the order
 // is fixed here exactly as include/kslam_tail.h states (ties keep input order).

@@ -12,6 +12,14 @@
  * align_small.npz     : a seeded 150-pair x 6-genome data set with the expected
    alignToDatabase output; produced by the oracle with its SSW core routed through the
    reference's ssw.c AND by the oracle's own restatement, asserted identical.
+ * join_vectors.npz    : reads + genomes (tests/join_cases.py) with the answers of the reference's OWN
+   sortKMers, findOverlaps (raw list), findOverlaps_parallel (deduped list) and alignToDatabase
+   (oracle/_ref/libjoin_ref.so, one OpenMP thread), plus the (read, entry, rel) keys whose revComp is a tie.
+ * align_vectors.npz   : ASCII (query, ref, ref_len) triples with the answers of the reference's OWN
+   Aligner::Align at three filter settings.
+ * slam_loop.npz       : two small FASTQ pairs + databases + taxDB with the files the reference's OWN batch
+   loop metagenomicAnalysis_Low_Mem wrote for them (oracle/_ref/libslam_ref.so): SAM, XML report,
+   _abbreviated, _PerRead.
 Fixtures are data (inputs + expected outputs); no reference source text is stored.
 """
 import json
@@ -177,7 +185,96 @@ def make_taxonomy_cases():
     print("taxonomy_cases.json:", len(lca), "lca queries,", len(nodes), "nodes")
 
 
+def _cols(items):
+    off = np.zeros(len(items) + 1, dtype=np.uint64)
+    np.cumsum([len(x) for x in items], out=off[1:])
+    return np.frombuffer(b"".join(items), dtype=np.uint8), off
+
+
+def make_join_and_align_vectors():
+    import oracle as O
+    from join_cases import make_join_case, make_align_cases, revcomp_tie_rows
+    assert O.have_ref_join(), "needs /root/reference (make -C oracle ref)"
+    reads, genomes = make_join_case(20240, n_reads=220)
+    recs = np.concatenate([O.ref_extract_kmers(reads, False, 1), O.ref_extract_kmers(genomes, True, 16)])
+    srt = O.ref_sort_kmers(recs)
+    lens = [len(r) for r in reads]
+    dedup, raw = O.ref_find_overlaps(srt, lens, want_raw=True)
+    ties = np.array(sorted(revcomp_tie_rows(raw)), dtype=np.int64).reshape(-1, 3)
+    out = {"sorted": srt, "raw": raw, "deduped": dedup, "ties": ties}
+    out["reads"], out["reads_off"] = _cols(reads)
+    out["genomes"], out["genomes_off"] = _cols(genomes)
+    for thr in (0, 150):
+        al, cg = O.ref_align_to_database(reads, genomes, O.Params.default(score_threshold=thr))
+        assert (al[["read", "entry", "rel"]] == dedup[["read", "entry", "rel"]]).all()
+        out["alignments_thr%d" % thr], out["cigars_thr%d" % thr] = al, cg
+    al, cg = O.ref_align_to_database(reads, genomes, O.Params.default(report_cigar=False))
+    assert len(cg) == 0
+    out["alignments_nocigar"] = al
+    np.savez_compressed(os.path.join(HERE, "join_vectors.npz"), **out)
+    print("join_vectors.npz: %d records, %d raw, %d deduped, %d revComp ties" % (len(srt), len(raw), len(dedup), len(ties)))
+
+    out = {}
+    for params in ((2, 3, 5, 2), (1, 4, 6, 1)):
+        cases = make_align_cases(777 + params[0], 250)
+        tag = "p%d%d%d%d" % params
+        out[tag + "_query"], out[tag + "_query_off"] = _cols([c[0] for c in cases])
+        out[tag + "_ref"], out[tag + "_ref_off"] = _cols([c[1] for c in cases])
+        out[tag + "_ref_len"] = np.array([c[2] for c in cases], dtype=np.int32)
+        for thr, want in ((0, 1), (120, 1), (0, 0)):
+            p = O.Params.default(report_cigar=bool(want), score_threshold=thr, match=params[0], mismatch=params[1],
+                                 gap_open=params[2], gap_extend=params[3])
+            res, cigs = [], []
+            for q, r, n in cases:
+                a, c = O.ref_aligner_align(q, r, p, ref_len=n)
+                res.append(a)
+                cigs.append(c)
+            k = "%s_thr%d_cigar%d" % (tag, thr, want)
+            out[k + "_results"] = np.array(res, dtype=np.int32)
+            out[k + "_cigars"] = np.concatenate(cigs) if cigs else np.zeros(0, np.uint32)
+            out[k + "_cigar_len"] = np.array([len(c) for c in cigs], dtype=np.int32)
+    np.savez_compressed(os.path.join(HERE, "align_vectors.npz"), **out)
+    print("align_vectors.npz: 2 x 250 cases x 3 filter settings")
+
+
+def make_slam_loop():
+    import importlib
+    import tempfile
+    import oracle as O
+    import ref_loop_case as R
+    assert O.have_ref_slam(), "needs /root/reference (make -C oracle ref)"
+    load_kslam()
+    synth = importlib.import_module("kslam_amd.synth")
+    D = importlib.import_module("kslam_amd.db")
+    out = {}
+    for tag, seed, n_pairs, per_batch, pseudo in (("a", 5101, 420, 150, True), ("b", 5202, 300, 300, False)):
+        case = R.make_case(synth, n_pairs=n_pairs, seed=seed, genome_len=9000, read_len=100)
+        with tempfile.TemporaryDirectory() as t:
+            dbdir = R.write_case(case, t, D)
+            ref = R.run_reference(O, case, t, dbdir, per_batch, pseudo=pseudo)
+        for k in ("sam", "xml", "abbreviated", "per_read"):
+            out[tag + "_" + k] = np.frombuffer(ref[k], dtype=np.uint8)
+        out[tag + "_per_batch"], out[tag + "_pseudo"] = np.int64(per_batch), np.int64(pseudo)
+        for k in ("taxdb", "r1", "r2"):
+            out[tag + "_" + k] = np.frombuffer(case[k], dtype=np.uint8)
+        for name, items in (("entry_bases", [e["bases"] for e in case["entries"]]), ("read_bases", case["bases"]),
+                            ("read_quals", case["quals"]), ("read_ids", case["ids"])):
+            out["%s_%s" % (tag, name)], out["%s_%s_off" % (tag, name)] = _cols(items)
+        meta = {"n_pairs": n_pairs,
+                "entries": [{"taxonomyID": e["taxonomyID"], "genbankID": e["genbankID"], "locusTag": e["locusTag"].decode(),
+                             "isPlasmid": bool(e["isPlasmid"])} for e in case["entries"]],
+                "genes": [[{k: (v.decode() if isinstance(v, bytes) else v) for k, v in g.items()} for g in e["genes"]]
+                          for e in case["entries"]]}
+        out[tag + "_meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+        print("slam_loop %s: %d pairs, %d SAM bytes, %d _PerRead lines" % (tag, n_pairs, len(ref["sam"]), ref["per_read"].count(b"\n")))
+    np.savez_compressed(os.path.join(HERE, "slam_loop.npz"), **out)
+
+
 if __name__ == "__main__":
+    if "--pins" in sys.argv:           # only the fixtures recorded from libjoin_ref.so / libslam_ref.so
+        make_join_and_align_vectors()
+        make_slam_loop()
+        sys.exit(0)
     if "--taxonomy" in sys.argv:
         make_taxonomy_cases()
         sys.exit(0)
@@ -185,3 +282,5 @@ if __name__ == "__main__":
         main()
     make_fastq_cases()
     make_taxonomy_cases()
+    make_join_and_align_vectors()
+    make_slam_loop()

@@ -43,6 +43,8 @@ def make_join_case(seed, n_reads=260, read_len=150):
     pal = np.concatenate([x, _rc(x)])            # reverse-palindromic window
     g5 = np.concatenate([_rb(rng, 1600), pal, _rb(rng, 1200 + (read_len & 1))])
     g6 = np.concatenate([_rb(rng, 300), np.full(200, ord("A"), np.uint8), _rb(rng, 300)])  # poly-A: k-mer 0
+    for p in rng.integers(0, len(g1), 6):          # N and IUPAC letters inside a genome (2-bit code 0 in the k-mer, 4 in SW)
+        g1[p] = rng.choice(np.frombuffer(b"NNRYK", dtype=np.uint8))
     genomes = [g0, g1, g2, g3, g4, g5, g6]
     reads = []
     for i in range(n_reads):
@@ -108,7 +110,7 @@ def make_align_cases(seed, n=400):
             q = np.concatenate([q[:p], q[p + m:]]) if rng.random() < 0.5 else np.concatenate([q[:p], _rb(rng, m), q[p:]])
         if rng.random() < 0.3:
             q = np.concatenate([_rb(rng, int(rng.integers(1, 25))), q])
-        if rng.random() < 0.3:
+        if rng.random() < 0.45:
             q = np.concatenate([q, _rb(rng, int(rng.integers(1, 25)))])
         for s in (q, ref):
             if rng.random() < 0.35:

@@ -407,6 +407,91 @@ def test_golden_ssw_vectors_through_the_abi(kslam):
     assert checked >= 20, checked
 
 
+def _cols(z, name):
+    flat, off = z[name], z[name + "_off"]
+    return [flat[int(off[i]):int(off[i + 1])].tobytes() for i in range(len(off) - 1)]
+
+
+def _compare_modulo_revcomp_ties(got, gcig, exp, ecig, ties):
+    """exp = answers of the real reference at one thread; overlapSort has no revComp in its key (src/Overlap.h:87-98),
+    so where the raw list holds the same (read, entry, rel) with both revComp values the survivor's flag is a tie"""
+    assert len(got) == len(exp)
+    amb = np.array([(int(r), int(e), int(l)) in ties for r, e, l in zip(exp["read"], exp["entry"], exp["rel"])], dtype=bool)
+    for f in ("read", "entry", "rel", "revcomp", "score", "ref_begin", "ref_end", "query_begin", "query_end", "cigar_len"):
+        ok = got[f] == exp[f]
+        if f == "revcomp":
+            ok = ok | amb
+        assert ok.all(), (f, np.flatnonzero(~ok)[:5])
+    if ecig is not None:
+        for i in range(len(got)):
+            a = gcig[int(got["cigar_off"][i]):int(got["cigar_off"][i]) + int(got["cigar_len"][i])]
+            b = ecig[int(exp["cigar_off"][i]):int(exp["cigar_off"][i]) + int(exp["cigar_len"][i])]
+            assert (a == b).all(), "cigar %d" % i
+    return int(amb.sum())
+
+
+def test_golden_join_vectors(kslam, ctx):
+    """Through the ABI against the recorded answers of the reference's OWN sortKMers, findOverlaps_parallel and
+    alignToDatabase (oracle/_ref/libjoin_ref.so -> tests/golden/join_vectors.npz): pile-ups with several genome records,
+    rc/fwd mixes, k-mer 0, genome ends, ragged and empty reads, odd letters, the revComp tie."""
+    z = np.load(os.path.join(GOLD, "join_vectors.npz"))
+    reads, genomes = _cols(z, "reads"), _cols(z, "genomes")
+    ties = {tuple(int(v) for v in t) for t in z["ties"]}
+    recs = np.concatenate([ctx.extract_kmers(reads, False, 1), ctx.extract_kmers(genomes, True, 16)])
+    srt = ctx.sort_kmers(recs)
+    assert (srt["kmer"] == z["sorted"]["kmer"]).all() and (srt["meta"] == z["sorted"]["meta"]).all()
+    c = kslam.Context()
+    c.set_index(genomes)
+    c.load_reads(reads)
+    got, raw = c.find_overlaps()
+    c.close()
+    assert raw == len(z["raw"])
+    exp = z["deduped"]
+    assert len(got) == len(exp)
+    amb = np.array([(int(r), int(e), int(l)) in ties for r, e, l in zip(exp["read"], exp["entry"], exp["rel"])], dtype=bool)
+    for f in ("read", "entry", "rel"):
+        assert (got[f] == exp[f]).all(), f
+    assert ((got["revcomp"] == exp["revcomp"]) | amb).all() and 0 < amb.sum() < 10
+    g, gc = kslam.align_to_database(reads, genomes)
+    _compare_modulo_revcomp_ties(g, gc, z["alignments_thr0"], z["cigars_thr0"], ties)
+    g, gc = kslam.align_to_database(reads, genomes, score_threshold=150)
+    _compare_modulo_revcomp_ties(g, gc, z["alignments_thr150"], z["cigars_thr150"], ties)
+    g, gc = kslam.align_to_database(reads, genomes, report_cigar=False)
+    _compare_modulo_revcomp_ties(g, gc, z["alignments_nocigar"], None, ties)
+    assert len(gc) == 0
+
+
+def test_golden_align_vectors_through_the_abi(kslam):
+    """The recorded answers of the reference's OWN Aligner::Align (tests/golden/align_vectors.npz) through the ABI: a case
+    (query, ref, ref_len) with ref_len == |ref| <= |query| becomes a 1-read / 1-entry batch; every candidate with
+    rel <= 0 on the forward strand has the window entry.substr(0, |query|) == ref (src/SmithWaterman.h:203-208), so its
+    answer is the recorded one.  ASCII incl. lower case / U / IUPAC on both sides; thresholded and disabled CIGAR."""
+    z = np.load(os.path.join(GOLD, "align_vectors.npz"))
+    checked = 0
+    for params in ((2, 3, 5, 2), (1, 4, 6, 1)):
+        tag = "p%d%d%d%d" % params
+        qs, rs, ns = _cols(z, tag + "_query"), _cols(z, tag + "_ref"), z[tag + "_ref_len"]
+        for thr, want in ((0, 1), (120, 1), (0, 0)):
+            k = "%s_thr%d_cigar%d" % (tag, thr, want)
+            cigs = _split(z[k + "_cigars"], z[k + "_cigar_len"])
+            c = kslam.Context(match=params[0], mismatch=params[1], gap_open=params[2], gap_extend=params[3],
+                              score_threshold=thr, report_cigar=bool(want))
+            for i in range(len(qs)):
+                if int(ns[i]) != len(rs[i]) or len(rs[i]) > len(qs[i]):
+                    continue
+                c.set_index([rs[i]])
+                ov, cg = c.align_batch([qs[i]])
+                hit = ov[(ov["rel"] <= 0) & (ov["revcomp"] == 0)]
+                for h in hit:
+                    exp = tuple(int(v) for v in z[k + "_results"][i])
+                    assert (int(h["score"]), int(h["ref_begin"]), int(h["ref_end"]), int(h["query_begin"]),
+                            int(h["query_end"])) == exp, (k, i)
+                    assert np.array_equal(cg[int(h["cigar_off"]):int(h["cigar_off"]) + int(h["cigar_len"])], cigs[i]), (k, i)
+                    checked += 1
+            c.close()
+    assert checked >= 100, checked
+
+
 # ---------------------------------------------------------------------------
 # size-independent properties on a larger batch (the oracle would take minutes here)
 # ---------------------------------------------------------------------------

@@ -318,3 +318,52 @@ def test_single_end_stream_equals_the_reference_loop(kslam, oracle, synth, tmp_p
     report.close()
     tax.close()
     otree.close()
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_golden_slam_loop_through_the_abi(kslam, tmp_path, tag):
+    """FASTQ files + database + taxDB -> SAM / _PerRead / _abbreviated / XML through kslam_stream_classify, against the
+    files the reference's OWN metagenomicAnalysis_Low_Mem wrote for the same inputs (oracle/_ref/libslam_ref.so ->
+    tests/golden/slam_loop.npz; tests/test_reference_loop.py regenerates them where the reference is present).  No
+    oracle in this test: the expected bytes are the real reference's."""
+    import ctypes as C
+    import ref_loop_case as R
+    from test_reference_loop import load_fixture_case
+    D = importlib.import_module("kslam_amd.db")
+    T = importlib.import_module("kslam_amd.tail")
+    X = importlib.import_module("kslam_amd.taxonomy")
+    S = importlib.import_module("kslam_amd.stream")
+    z = np.load(os.path.join(ROOT, "tests", "golden", "slam_loop.npz"), allow_pickle=False)
+    case = load_fixture_case(z, tag)
+    dbdir = R.write_case(case, tmp_path, D)
+    per_batch, pseudo = int(z[tag + "_per_batch"]), bool(z[tag + "_pseudo"])
+    db = D.Database.load(os.path.join(dbdir, "database"))
+    ctx = kslam.Context()
+    bases_pp, lens_p = db.entry_pointers()
+    ctx._chk(ctx._L.kslam_set_index(ctx._h, db.n_entries, C.cast(bases_pp, C.c_void_p), C.cast(lens_p, C.c_void_p)))
+    tax = X.TaxDB(case["taxdb"])
+    report = X.Report()
+    r1, r2 = case["r1"], case["r2"]
+    h1, h2 = kslam.HostBuffer(len(r1) + 64), kslam.HostBuffer(len(r2) + 64)
+    h1.a[:len(r1)] = np.frombuffer(r1, dtype=np.uint8)
+    h2.a[:len(r2)] = np.frombuffer(r2, dtype=np.uint8)
+    P = T.TailParams.default(pseudo_assembly=pseudo)
+    header = T.sam_header(db, b"SLAM --db db R1.fq R2.fq")
+    sam_path, per_read_path = str(tmp_path / "out.sam"), str(tmp_path / "out_PerRead")
+    sam_fd = os.open(sam_path, os.O_RDWR | os.O_CREAT | os.O_TRUNC)
+    pr_fd = os.open(per_read_path, os.O_RDWR | os.O_CREAT | os.O_TRUNC)
+    res = S.classify_stream_native(ctx, db, h1.ptr, len(r1), h2.ptr, len(r2), per_batch, P, taxdb=tax, report=report,
+                                   sam_fd=sam_fd, per_read_fd=pr_fd, sam_header=header)
+    os.close(sam_fd)
+    os.close(pr_fd)
+    assert res["n_pairs"] == case["n_pairs"]
+    assert open(sam_path, "rb").read() == z[tag + "_sam"].tobytes()
+    assert open(per_read_path, "rb").read() == z[tag + "_per_read"].tobytes()
+    assert tax.summary(res["tax_ids"], res["n_pairs"]) == z[tag + "_abbreviated"].tobytes()
+    assert tax.report_xml(report, db, db.gene_extras(), res["n_pairs"]) == z[tag + "_xml"].tobytes()
+    h1.close()
+    h2.close()
+    ctx.close()
+    db.close()
+    report.close()
+    tax.close()

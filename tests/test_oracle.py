@@ -326,3 +326,55 @@ def test_against_real_align_to_database_when_present(oracle, seed):
     mt, _ = oracle.ref_align_to_database(reads, genomes, oracle.Params.default(), one_thread=False)
     one, _ = oracle.ref_align_to_database(reads, genomes, oracle.Params.default())
     _same_modulo_revcomp_ties(mt, one, ties, fields)
+
+
+# ---- the committed answers of the real reference (recorded by tests/golden/make_golden.py --pins): these run anywhere ----
+def _cols(z, name):
+    flat, off = z[name], z[name + "_off"]
+    return [flat[int(off[i]):int(off[i + 1])].tobytes() for i in range(len(off) - 1)]
+
+
+def test_join_golden_vectors(oracle):
+    """oracle == the recorded answers of the reference's own sortKMers / findOverlaps / findOverlaps_parallel /
+    alignToDatabase (tests/golden/join_vectors.npz)."""
+    z = np.load(os.path.join(GOLD, "join_vectors.npz"))
+    reads, genomes = _cols(z, "reads"), _cols(z, "genomes")
+    lens = [len(r) for r in reads]
+    ties = {tuple(int(v) for v in t) for t in z["ties"]}
+    assert len(ties) >= 1
+    recs = np.concatenate([oracle.extract_kmers(reads, False, 1), oracle.extract_kmers(genomes, True, 16)])
+    srt = oracle.sort_kmers(recs)
+    assert (srt["kmer"] == z["sorted"]["kmer"]).all() and (srt["meta"] == z["sorted"]["meta"]).all()
+    assert (oracle.scan_overlaps(z["sorted"], lens) == z["raw"]).all()
+    assert (_sorted4(oracle.scan_overlaps(srt, lens)) == _sorted4(z["raw"])).all()
+    ov, nraw = oracle.find_overlaps(srt, lens)
+    assert nraw == len(z["raw"])
+    _same_modulo_revcomp_ties(ov, z["deduped"], ties, ("read", "entry", "rel", "revcomp"))
+    fields = ("read", "entry", "rel", "revcomp", "score", "ref_begin", "ref_end", "query_begin", "query_end", "cigar_len")
+    for key, p in (("thr0", oracle.Params.default()), ("thr150", oracle.Params.default(score_threshold=150))):
+        for plain in (False, True):
+            got, gcig, _ = oracle.align_to_database(reads, genomes, p, plain=plain)
+            _same_modulo_revcomp_ties(got, z["alignments_" + key], ties, fields)
+            assert np.array_equal(gcig, z["cigars_" + key])
+    got, gcig, _ = oracle.align_to_database(reads, genomes, oracle.Params.default(report_cigar=False))
+    _same_modulo_revcomp_ties(got, z["alignments_nocigar"], ties, fields)
+    assert len(gcig) == 0
+
+
+def test_align_golden_vectors(oracle):
+    """oracle == the recorded answers of the reference's own Aligner::Align (tests/golden/align_vectors.npz)."""
+    z = np.load(os.path.join(GOLD, "align_vectors.npz"))
+    for params in ((2, 3, 5, 2), (1, 4, 6, 1)):
+        tag = "p%d%d%d%d" % params
+        qs, rs, ns = _cols(z, tag + "_query"), _cols(z, tag + "_ref"), z[tag + "_ref_len"]
+        for thr, want in ((0, 1), (120, 1), (0, 0)):
+            k = "%s_thr%d_cigar%d" % (tag, thr, want)
+            cigs = _split(z[k + "_cigars"], z[k + "_cigar_len"])
+            p = oracle.Params.default(report_cigar=bool(want), score_threshold=thr, match=params[0], mismatch=params[1],
+                                      gap_open=params[2], gap_extend=params[3])
+            for i in range(len(qs)):
+                for plain in (False, True):
+                    res, cig = oracle.align(qs[i], rs[i][:int(ns[i])], p, plain=plain)
+                    got = (res.score1, res.ref_begin1, res.ref_end1, res.read_begin1, res.read_end1)
+                    assert got == tuple(int(v) for v in z[k + "_results"][i]), (k, i, plain)
+                    assert np.array_equal(cig, cigs[i]), (k, i, plain)

@@ -446,3 +446,43 @@ def test_worker_pool_with_concurrent_loops(tmp_path):
         subprocess.check_call([gxx, "-O2", "-std=c++17", "-pthread", src, "-o", exe])
         r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.strip() == "ok", r.stdout + r.stderr
+
+
+def test_finish_prepare_then_read_only_write_equals_the_one_call_finish(kslam, oracle, synth, T):
+    """host/stream.cpp's order: kslam_tail_finish_prepare (everything that changes the pair arrays: host pseudo-assembly +
+    second screen, writeSAMOutputPairs' per-pair sort) and only then the SAM text and the classification side by side.
+    The two-step route gives the one-call route's text and leaves the arrays in the state the one call leaves them in --
+    with read pairs of more than 16 alignment pairs (introsort really moves records there) and with the host running the
+    pseudo-assembly (the device's fallback)."""
+    n_pairs = 500
+    # 24 near-identical genomes: a read aligns to all of them -> groups of > 16 alignment pairs with tied scores
+    root = synth.make_genomes(5, 1, 1, 6000)[0]
+    rng = np.random.default_rng(5)
+    genomes = [synth.mutate(rng, root, 0.002, 0.0) for _ in range(24)]
+    reads, _ = synth.make_paired_reads(6, genomes, n_pairs, read_len=100, frag_mean=300, frag_sd=40, sub_rate=0.01, indel_rate=0.002)
+    rb, gb = synth.to_bytes(reads), synth.to_bytes(genomes)
+    R = T.Reads(rb, [b"I" * len(b) for b in rb], [b"f%d" % (i % n_pairs) for i in range(2 * n_pairs)])
+    I = T.Index(gb, locus_tags=[b"NC_%06d" % i for i in range(len(gb))], taxonomy_ids=[100 + i for i in range(len(gb))])
+    al, cig, _ = oracle.align_to_database(rb, gb, oracle.Params.default())
+    for pseudo in (True, False):
+        P_screens = T.TailParams.default(threads=4, pseudo_assembly=False, stages=3)      # what the device hands over
+        rp, pr, _ = T.tail_pairs(P_screens, R, al)
+        assert int(rp["count"].max()) > 16
+        P_all = T.TailParams.default(threads=4, pseudo_assembly=pseudo)
+        rp1, pr1, one = rp.copy(), pr.copy(), []
+        T.tail_finish_rows(P_all, R, I, al, cig, None, None, rp1, pr1, sink=one.append)
+        rp2, pr2, two = rp.copy(), pr.copy(), []
+        st = T.tail_finish_prepare(P_all, R, al, rp2, pr2, sort_groups=True)
+        frozen = (rp2.copy(), pr2.copy())
+        P_ro = T.TailParams.default(threads=4, pseudo_assembly=False, stages=7 | 16)
+        T.tail_finish_rows(P_ro, R, I, al, cig, None, None, rp2, pr2, sink=two.append)
+        assert (rp2 == frozen[0]).all() and (pr2 == frozen[1]).all()       # the write really only read
+        assert b"".join(two) == b"".join(one) and len(one) > 0
+        assert (rp2 == rp1).all() and (pr2 == pr1).all()
+        assert st.n_paired_final == int(rp2["count"].sum())
+        # and the whole-chain entry agrees (the reference order: screens, pseudo, screen, sort, text)
+        assert b"".join(one) == T.tail_sam(P_all, R, I, al, cig)[0]
+    # without a SAM file the reference does not sort: sort_groups=False leaves the screened order alone
+    rp3, pr3 = rp.copy(), pr.copy()
+    T.tail_finish_prepare(T.TailParams.default(threads=4, pseudo_assembly=False), R, al, rp3, pr3, sort_groups=False)
+    assert (rp3 == rp).all() and (pr3 == pr).all()

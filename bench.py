@@ -44,14 +44,39 @@ PIECES = 8            # a strong batch is generated in 8 fixed pieces: the same 
 
 
 # ------------------------------------------------------------------------------------------------ launcher
+def kfd_gpu_count():
+    """GPUs the amdgpu driver exposes, without touching the HIP runtime: /sys/class/kfd/kfd/topology/nodes/*/properties with
+    simd_count > 0 (CPU nodes have 0), cut down by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES.  None when the files are not
+    readable."""
+    import glob
+    n = 0
+    files = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not files:
+        return None
+    for f in files:
+        try:
+            for line in open(f):
+                k, _, v = line.partition(" ")
+                if k == "simd_count" and int(v) > 0:
+                    n += 1
+        except (OSError, ValueError):
+            return None
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def self_launch(args, argv):
-    """--gpus N without a launcher: start the N rank processes here.  The parent never touches the GPU
-    (torch.cuda.device_count() does not initialise it on this image), relays rank 0's JSON line and exits non-zero
-    if any rank dies."""
+    """--gpus N without a launcher: start the N rank processes here.  The parent never calls into the HIP runtime (on this
+    pool an exec after the GPU was initialised takes the machine down, and Popen is fork + exec): the GPUs are counted from
+    the kernel driver's topology files; when those are not readable the ranks themselves refuse a device that is not there.
+    Relays rank 0's JSON line and exits non-zero if any rank dies."""
     n = args.gpus
     share = os.environ.get("KSLAM_BENCH_SHARE_GPU") == "1"
-    ndev = torch.cuda.device_count()
-    if n > ndev and not share:
+    ndev = kfd_gpu_count()
+    if ndev is not None and n > ndev and not share:
         raise SystemExit("--gpus %d but %d device(s) visible (KSLAM_BENCH_SHARE_GPU=1 lets ranks share a GPU: tests only)" % (n, ndev))
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
         s.bind(("127.0.0.1", 0))
@@ -89,18 +114,23 @@ def self_launch(args, argv):
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline
-def cpu_baseline(K, db, offs, seed, n_genomes, n_pairs, read_len=READ_LEN, device=0, full=False):
-    """The oracle's alignToDatabase timed on the host cores, on a bounded sample of the same workload (reported
-    baseline; the oracle is the checker, never the product).  The same sample then goes through the HIP library:
-    the result sets are compared record by record and the GPU's time on that very sample is reported, so that
-    `speedup_on_sample` is one workload on both sides."""
+def cpu_baseline(K, db, offs, seed, n_genomes, n_pairs, read_len=READ_LEN, device=0, full=False, same_reads=None, why=None):
+    """The oracle's alignToDatabase timed on the host cores (reported baseline; the oracle is the checker, never the
+    product).  full + same_reads: the WHOLE workload, on the very batch the hot path timed (then n_alignments ==
+    hot_path.counts.candidates and speedup_on_sample is the apples-to-apples ratio); otherwise a bounded sample, with
+    `why`.  The same reads then go through the HIP library: the result sets are compared record by record and the GPU's
+    time on them is reported, so that `speedup_on_sample` is one workload on both sides."""
     import oracle as O
     n_genomes = min(n_genomes, len(offs) - 1)
     sub = db[:int(offs[n_genomes])].cpu()
     suboffs = offs[:n_genomes + 1]
-    gen = torch.Generator(device="cpu")
-    gen.manual_seed(seed)
-    reads = make_reads(torch.device("cpu"), gen, sub, suboffs, n_pairs, read_len=read_len).numpy()
+    if same_reads is not None:
+        reads = same_reads.cpu().numpy()
+        n_pairs = reads.shape[0] // 2
+    else:
+        gen = torch.Generator(device="cpu")
+        gen.manual_seed(seed)
+        reads = make_reads(torch.device("cpu"), gen, sub, suboffs, n_pairs, read_len=read_len).numpy()
     rl = [reads[i].tobytes() for i in range(reads.shape[0])]
     subn = sub.numpy()
     gl = [subn[int(suboffs[i]):int(suboffs[i + 1])].tobytes() for i in range(n_genomes)]
@@ -117,7 +147,8 @@ def cpu_baseline(K, db, offs, seed, n_genomes, n_pairs, read_len=READ_LEN, devic
         "pairs": n_pairs, "read_len": read_len, "db_genomes": n_genomes, "db_bases": int(suboffs[-1]),
         "seconds": round(dt, 2),
         "phases_s": dict(zip(("extract", "genome_kmers", "sort", "join", "sw"), (round(float(x), 2) for x in ph[:5]))),
-        "sample": ("the WHOLE workload of this run (--cpu-full): " if full else "") +
+        "same_batch_as_hot_path": same_reads is not None,
+        "sample": ("the WHOLE workload of this run%s: " % (", on the batch the hot path timed" if same_reads is not None else "") if full else "") +
                   "%d pairs x %d bp vs %s database genomes (%.0f Mb)%s; whole reference batch path incl. genome k-mer "
                   "re-extraction and the (reads+genomes) sort, alignToDatabase only (no tail), OpenMP on the CPUs the "
                   "job's cgroup quota allows; %s" % (
@@ -126,6 +157,8 @@ def cpu_baseline(K, db, offs, seed, n_genomes, n_pairs, read_len=READ_LEN, devic
                       kind_ssw),
         "n_alignments": int(len(al)),
     }
+    if why:
+        out["why"] = why
     try:   # the same sample through the HIP library: identical records and CIGARs?  and how long does the GPU take for it?
         c = K.Context(device=device)
         c.set_index(gl)
@@ -458,6 +491,9 @@ def main():
     ap.add_argument("--cpu-pairs", type=int, default=300000)
     ap.add_argument("--cpu-genomes", type=int, default=25)
     ap.add_argument("--cpu-full", action="store_true", help="cpu_baseline on the WHOLE workload of this run (minutes to hours of CPU time)")
+    ap.add_argument("--cpu-baseline", choices=["auto", "full", "sample"], default="auto",
+                    help="auto: the whole configs[1] workload on the hot path's own batch when the box has >= 16 usable CPUs and the "
+                         "memory (about 30 s), else the bounded sample (--cpu-pairs / --cpu-genomes)")
     ap.add_argument("--no-cigar", action="store_true")
     ap.add_argument("--no-abi-path", action="store_true", help="skip the host-pointers-in / host-results-out leg")
     ap.add_argument("--no-e2e", action="store_true", help="hot path only: `value` is then the resident-input rate and says so")
@@ -1009,13 +1045,15 @@ def main():
         # next pass's digit byte, radix_sort.hip): averaged over the sort's launches
         per_launch_bytes = (n_sorted / max(tm["n_chunks"], 1)) * (32 + (passes - 1) / max(passes, 1))
         achieved = per_launch_bytes / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
-        traffic = None
+        traffic = sort_pmc = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath) and config == 1:
             try:
-                traffic = json.load(open(tpath)).get("k_scatter_bytes_per_launch")
+                tj = json.load(open(tpath))
+                traffic = tj.get("k_scatter_bytes_per_launch")
+                sort_pmc = (tj.get("sort_phase") or {}).get("bytes_per_call")     # PMC, whole phase (profiles/run_profiles.sh)
             except Exception:
-                traffic = None
+                traffic = sort_pmc = None
         sort_bytes = n_sorted * 16 * (2 * passes + 1)
         # the SW phase against the VALU issue rate: instruction count of the phase's kernels per alignment call from the
         # committed counter run of this same workload (tools/pmc_valu.sh -> profiles/sw_valu.json), time measured live
@@ -1047,7 +1085,11 @@ def main():
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "launch_ms": round(launch_ms, 4), "bytes_per_launch": int(per_launch_bytes),
             "sort_phase": {"passes": passes, "bytes": int(sort_bytes), "ms": round(tm["ms_sort"], 3),
-                           "frac": round(sort_bytes / (tm["ms_sort"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if tm["ms_sort"] > 0 else 0.0},
+                           "frac": round(sort_bytes / (tm["ms_sort"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if tm["ms_sort"] > 0 else 0.0,
+                           # beside the formula value: the HBM bytes the phase's dispatches really moved, from the
+                           # FETCH_SIZE / WRITE_SIZE counters of a separate profiled run of this workload, over the live time
+                           "pmc_bytes": sort_pmc,
+                           "pmc_frac": round(sort_pmc / (tm["ms_sort"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if sort_pmc and tm["ms_sort"] > 0 else None},
             # context, not the roofline: what the best hand-written streaming copy of the same bytes
             # sustained on a bench box (tools/copy_peak.hip, profiles/r01h_copy_peak.txt)
             "streaming_copy_ceiling": {"GB/s": 5590.0, "measured": "profiles/r01h_copy_peak.txt"},
@@ -1116,10 +1158,31 @@ def main():
             out["value_definition"] = "see e2e" if not args.no_e2e and not strong else "hot path only (--no-e2e): resident-input alignToDatabase"
         torch.cuda.empty_cache()       # what torch's allocator cached while generating the inputs goes back to the device
         if world == 1 and not args.no_cpu_baseline:
+            # the apples-to-apples baseline is the WHOLE workload on the batch the hot path timed: ~30 s on 16 CPUs for
+            # configs[1] (profiles/r03i_bench_cpu_full.json).  Taken by default when the box can afford it, else the sample.
+            import oracle as O
+            cpus = O.usable_cpus()
+            try:
+                free_gb = int([ln for ln in open("/proc/meminfo") if ln.startswith("MemAvailable")][0].split()[1]) / 1e6
+            except Exception:
+                free_gb = 0.0
+            mode, why = args.cpu_baseline, None
             if args.cpu_full:
-                out["cpu_baseline"] = cpu_baseline(K, db, offs, 2, n_entries, pairs, read_len, local_rank, full=True)
+                mode = "full"
+            if mode == "auto":
+                if config == 1 and not strong and cpus >= 16 and free_gb >= 60 and pairs <= 1_000_000:
+                    mode = "full"
+                else:
+                    mode = "sample"
+                    why = ("auto: the whole workload needs >= 16 usable CPUs (has %d), >= 60 GB of free host memory (has %.0f) and "
+                           "the configs[1] batch (this is config %s, %d pairs); --cpu-baseline full forces it" % (cpus, free_gb, config, pairs))
+            if mode == "full":
+                out["cpu_baseline"] = cpu_baseline(K, db, offs, 2, n_entries, pairs, read_len, local_rank, full=True,
+                                                   same_reads=None if strong else reads)
+                cands = out.get("hot_path", {}).get("counts", {}).get("candidates")
+                out["cpu_baseline"]["n_alignments_equals_hot_path_candidates"] = (cands == out["cpu_baseline"]["n_alignments"])
             else:
-                out["cpu_baseline"] = cpu_baseline(K, db, offs, 77, args.cpu_genomes, args.cpu_pairs, read_len, local_rank)
+                out["cpu_baseline"] = cpu_baseline(K, db, offs, 77, args.cpu_genomes, args.cpu_pairs, read_len, local_rank, why=why)
         if world == 1 and not strong and not args.no_abi_path and pairs <= 2_000_000:
             try:
                 out["abi_path"] = abi_path(K, ctx, reads, read_len, max(Ksteps, 12))

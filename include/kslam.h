@@ -133,6 +133,8 @@ const char *kslam_last_error(const kslam_ctx *ctx);
  * them again for this context and its worker lanes -- for variant tests and tuning scripts that flip a
  * switch between two batches; a production host never calls it.  Not while batches are in flight. */
 kslam_status kslam_reload_tuning(kslam_ctx *ctx);
+/* the HIP device ordinal the context owns (-1: none) */
+int32_t kslam_ctx_device(const kslam_ctx *ctx);
 
 /* A second context on the same device that BORROWS `primary`'s index (same device pointers; nothing of the
  * index is copied or freed by the sibling) and has its own stream, read batch and work buffers -- what the

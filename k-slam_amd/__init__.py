@@ -39,7 +39,7 @@ STATUS = {0: "OK", 1: "ERR_ARG", 2: "ERR_NO_DEVICE", 3: "ERR_OOM", 4: "ERR_UNSUP
           5: "ERR_STATE", 6: "ERR_INTERNAL"}
 
 # every symbol include/kslam.h declares
-EXPORTS = ["kslam_abi_version", "kslam_version", "kslam_check_std_sort", "kslam_create", "kslam_destroy", "kslam_last_error", "kslam_reload_tuning", "kslam_create_sibling", "kslam_adopt_results_device",
+EXPORTS = ["kslam_abi_version", "kslam_version", "kslam_check_std_sort", "kslam_create", "kslam_destroy", "kslam_last_error", "kslam_reload_tuning", "kslam_ctx_device", "kslam_create_sibling", "kslam_adopt_results_device",
            "kslam_set_index", "kslam_set_index_device", "kslam_align_batch", "kslam_free_batch",
            "kslam_align_batch_async", "kslam_wait_batch", "kslam_load_qualities", "kslam_load_qualities_device",
            "kslam_row_details", "kslam_take_row_details", "kslam_free_pinned", "kslam_submit_batch",
@@ -128,6 +128,8 @@ def lib():
         L.kslam_last_error.restype = C.c_char_p
         L.kslam_last_error.argtypes = [vp]
         L.kslam_reload_tuning.argtypes = [vp]
+        L.kslam_ctx_device.argtypes = [vp]
+        L.kslam_ctx_device.restype = C.c_int32
         L.kslam_create_sibling.argtypes = [vp, C.POINTER(vp)]
         L.kslam_adopt_results_device.argtypes = [vp, vp, u64, vp, u64]
         L.kslam_set_index.argtypes = [vp, u64, vp, vp]

@@ -1199,6 +1199,8 @@ kslam_status kslam_adopt_results_device(kslam_ctx *c, const void *d_overlaps, ui
   });
 }
 
+int32_t kslam_ctx_device(const kslam_ctx *c) { return c ? c->device : -1; }
+
 kslam_status kslam_reload_tuning(kslam_ctx *c) {
   if (!c) return KSLAM_ERR_ARG;
   std::lock_guard<std::mutex> lk(c->as_mu);

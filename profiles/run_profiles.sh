@@ -30,6 +30,42 @@ out = {k: {c: {'dispatches': a[0], 'sum': a[1], 'mean': a[1] / a[0], 'max': a[2]
                'per_dispatch': a[3] if k.startswith(('k_scatter<4>', 'k_tile_hist<4>', 'k_extract_filter', 'k_join_fill')) else None}
            for c, a in cs.items()} for k, cs in pmc.items()}
 json.dump(out, open('gpurun_out/keep/%s_pmc_kslam.json' % R, 'w'), indent=1, sort_keys=True)
+# ---- the k-mer sort PHASE (rocprof (FETCH_SIZE + WRITE_SIZE) / t_sort beside the formula value): every dispatch
+# between a k_extract_filter and the next k_join_fill whose kernel belongs to the radix sort, summed per alignment call ----
+SORT = ('k_tile_hist_bytes', 'k_tile_hist<4>', 'k_chunk_scan', 'k_col_scan', 'k_bin_scan', 'k_scatter<4>')
+phase = {}
+for tag, d in (('FETCH_SIZE', 'pf'), ('WRITE_SIZE', 'pw')):
+    rows = []
+    for f in glob.glob('/tmp/prof/%s/**/*counter_collection.csv' % d, recursive=True):
+        rows += [r for r in csv.DictReader(open(f)) if 'kslam' in r['Kernel_Name'] and r['Counter_Name'] == tag]
+    rows.sort(key=lambda r: int(r['Dispatch_Id']))
+    calls, cur, inside = [], None, False
+    for r in rows:
+        k = clean(r['Kernel_Name'])
+        if k.startswith('k_extract_filter'):
+            inside, cur = True, {'kib': 0.0, 'dispatches': 0, 'by_kernel': {}}
+        elif k.startswith('k_join_fill'):
+            if inside and cur and cur['dispatches']:
+                calls.append(cur)
+            inside = False
+        elif inside and k.startswith(SORT):
+            v = float(r['Counter_Value'])
+            cur['kib'] += v
+            cur['dispatches'] += 1
+            cur['by_kernel'][k] = cur['by_kernel'].get(k, 0.0) + v
+    phase[tag] = calls
+if phase.get('FETCH_SIZE') and phase.get('WRITE_SIZE'):
+    n = min(len(phase['FETCH_SIZE']), len(phase['WRITE_SIZE']))
+    f = sum(c['kib'] for c in phase['FETCH_SIZE'][:n]) / n
+    w = sum(c['kib'] for c in phase['WRITE_SIZE'][:n]) / n
+    sp = {'alignment_calls_seen': n, 'dispatches_per_call': phase['FETCH_SIZE'][0]['dispatches'],
+          'fetch_kib_per_call_raw': f, 'write_kib_per_call_raw': w,
+          'bytes_per_call': int((2 * f + w) * 1024),
+          'method': 'all radix-sort dispatches between k_extract_filter and k_join_fill of one alignment call; FETCH_SIZE doubled '
+                    '(gfx950 reports half of a wide coalesced stream, MI355X_MICROARCH.md section HBM), WRITE_SIZE as is; unit KiB',
+          'by_kernel_fetch_kib': phase['FETCH_SIZE'][0]['by_kernel'], 'by_kernel_write_kib': phase['WRITE_SIZE'][0]['by_kernel']}
+    json.dump(sp, open('gpurun_out/keep/%s_sort_phase_pmc.json' % R, 'w'), indent=1, sort_keys=True)
+    print('sort phase:', sp['bytes_per_call'], 'bytes per alignment call over', sp['dispatches_per_call'], 'dispatches')
 for k in sorted(out):
     print(k.ljust(30), {c: (v['dispatches'], '%.4g' % v['mean'], '%.4g' % v['max']) for c, v in out[k].items()})
 PY

@@ -168,7 +168,7 @@ def test_sharded_gather_world2_gloo(tmp_path):
     assert "GATHER_OK" in r.stdout and "SHARDED_GATHER_OK" in r.stdout
 
 
-@pytest.mark.parametrize("header", ["kslam.h", "kslam_tail.h", "kslam_fastq.h", "kslam_taxonomy.h", "kslam_db.h"])
+@pytest.mark.parametrize("header", ["kslam.h", "kslam_tail.h", "kslam_fastq.h", "kslam_taxonomy.h", "kslam_db.h", "kslam_stream.h", "kslam_comm.h"])
 def test_headers_are_plain_c(header, tmp_path):
     """The boundary is a C ABI: every header must compile on its own as C99 (pedantic) and as C++11."""
     import shutil
@@ -182,3 +182,35 @@ def test_headers_are_plain_c(header, tmp_path):
         r = subprocess.run([cc, std, "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", inc, "-x", lang, str(src)],
                            capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
+
+
+def test_library_exports_every_comm_symbol_and_the_gather_plan(kslam):
+    """include/kslam_comm.h (RCCL behind the C ABI): exported by the same library, which does NOT link librccl
+    (dlopen on first use); the placement arithmetic of the gather equals k-slam_amd/dist.py's (the protocol the gloo
+    world-2 test above runs)."""
+    import ctypes
+    import importlib
+    import numpy as np
+    Cm = importlib.import_module("kslam_amd.comm")
+    L = ctypes.CDLL(kslam.LIB_PATH)
+    declared = _declared_symbols("kslam_comm.h")
+    assert sorted(Cm.EXPORTS) == declared and len(declared) == 9
+    for name in declared:
+        assert hasattr(L, name), "missing export " + name
+    needed = subprocess.run(["readelf", "-d", kslam.LIB_PATH], capture_output=True, text=True).stdout
+    assert "librccl" not in needed
+    rng = np.random.default_rng(8)
+    for world in (1, 2, 3, 4, 8):
+        cnt = []
+        for _ in range(world):
+            n, c = int(rng.integers(0, 1000)), int(rng.integers(0, 3000))
+            cnt.append((n, int(rng.integers(0, n + 1)), c, int(rng.integers(0, c + 1))))
+        row1, row2, op1, op2, tot = Cm.gather_plan(cnt)
+        # k-slam_amd/dist.py start_gather_sharded
+        rows_r1 = sum(c[1] for c in cnt)
+        ops_r1 = sum(c[3] for c in cnt)
+        assert row1 == [sum(c[1] for c in cnt[:r]) for r in range(world)]
+        assert row2 == [rows_r1 + sum(c[0] - c[1] for c in cnt[:r]) for r in range(world)]
+        assert op1 == [sum(c[3] for c in cnt[:r]) for r in range(world)]
+        assert op2 == [ops_r1 + sum(c[2] - c[3] for c in cnt[:r]) for r in range(world)]
+        assert tot == (sum(c[0] for c in cnt), sum(c[2] for c in cnt))

@@ -289,3 +289,47 @@ def test_default_bench_line_keeps_the_contract(tmp_path):
     assert e["sink"] == line["sink_probe"]["chosen"] and isinstance(e["cpu_s_by_thread"], dict) and e["host_cpus_usable"] >= 1
     assert line["e2e_sam_to_dev_null"]["reads_per_s"] > 0 and line["e2e_with_pseudo_assembly"]["pseudo_assembly_on"] == "gpu"
     assert line["abi_path"]["equals_resident_result"]
+
+
+@pytest.mark.parametrize("pseudo", [True, False])
+def test_rccl_behind_the_c_abi_world_1(kslam, synth, pseudo):
+    """include/kslam_comm.h with no PyTorch in the path: ncclGetUniqueId / ncclCommInitRank (librccl opened by the library),
+    the gather (counts all-gather, export in batch terms) and the sharded tail (two variable-length all-gathers), at the
+    world size one box allows.  The gathered arrays are the context's own result byte for byte; adopted by a second
+    context they are its result; the tail equals kslam_pair_screen's.  N > 1 on hardware: the driver's SCALE record."""
+    import ctypes
+    Cm = importlib.import_module("kslam_amd.comm")
+    n_pairs = 1500
+    rb, gb = _data(synth, 910, n_pairs)
+    c = kslam.Context()
+    c.set_index(gb)
+    c.load_reads(rb)
+    n_out, n_cig = c.align_resident()
+    exp, ecig = c.fetch_results(n_out, n_cig)
+    comm = Cm.Comm(c, Cm.unique_id(), 0, 1)
+    assert (c._L.kslam_comm_rank(comm._h), c._L.kslam_comm_world(comm._h), c._L.kslam_ctx_device(c._h)) == (0, 1, 0)
+    d_rows, n_rows, d_pool, n_ops = comm.gather_batch(n_pairs, 0, n_pairs)
+    assert (n_rows, n_ops) == (n_out, n_cig) and n_rows > n_pairs
+    # a second context adopts the gathered arrays (what rank 0 does with the batch-global result)
+    c2 = c.sibling()
+    c2.load_reads(rb)
+    c2.adopt_results_device(d_rows, n_rows, d_pool, n_ops)
+    got, gcig = c2.fetch_results(n_rows, n_ops)
+    assert got.tobytes() == exp.tobytes() and gcig.tobytes() == ecig.tobytes()
+    # the tail through the communicator == the one-call tail
+    want = c2.pair_screen(True, 0, 0.95, 7 if pseudo else 3)
+    erp, epr = c2.take_pairs()
+    st, moved = comm.sharded_tail(True, 0, 0.95, pseudo)
+    grp, gpr = c.take_pairs()
+    assert {k: st[k] for k in ("n_read_pairs", "n_pairs", "max_insert_size", "n_insert_sizes")} == \
+           {k: want[k] for k in ("n_read_pairs", "n_pairs", "max_insert_size", "n_insert_sizes")}
+    assert grp.tobytes() == erp.tobytes() and gpr.tobytes() == epr.tobytes()
+    assert moved >= 4 * st["n_insert_sizes"]
+    # a second gather reuses the communicator's buffers
+    again = comm.gather_batch(n_pairs, 0, n_pairs)
+    assert again[1:4:2] == (n_rows, n_ops)
+    with pytest.raises(kslam.KslamError):
+        Cm.Comm(c, Cm.unique_id(), 3, 2)          # rank outside the world
+    comm.close()
+    c2.close()
+    c.close()

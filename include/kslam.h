@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define KSLAM_ABI_VERSION 8
+#define KSLAM_ABI_VERSION 9
 #define KSLAM_K 32u /* src/Globals.h:25 */
 
 typedef enum {
@@ -347,7 +347,22 @@ typedef struct {
   char *reads_ids;
   uint64_t *reads_ids_off;   /* n_reads + 1 */
   uint64_t consumed1, consumed2;
+  /* kslam_set_sam_text (include/kslam_samtext.h) switched on: the batch's SAM records and <out>_PerRead lines as written
+   * on the GPU, the taxonomy id per read pair; NULL / 0 when off, or when this batch's text was left to the host
+   * (text_flags says which).  With KSLAM_TEXT_PAIRS_SORTED the read pairs' alignment pairs above are already in
+   * writeSAMOutputPairs' order (the device ran the per-pair sort): kslam_tail_finish_write_rows then takes
+   * KSLAM_TAIL_GROUPS_SORTED and kslam_tail_finish_prepare must not sort again. */
+  char *sam_text;
+  uint64_t sam_text_len;
+  char *per_read_text;
+  uint64_t per_read_len;
+  uint32_t *tax_ids;         /* n_read_pairs */
+  uint32_t text_flags;       /* KSLAM_TEXT_* */
+  uint32_t pad_;
 } kslam_batch_result;
+#define KSLAM_TEXT_PAIRS_SORTED 1u
+#define KSLAM_TEXT_SAM 2u
+#define KSLAM_TEXT_PER_READ 4u
 kslam_status kslam_submit_batch(kslam_ctx *ctx, uint64_t n_reads, const char *const *bases,
                                 const char *const *quality, const uint32_t *lens,
                                 uint64_t *ticket);

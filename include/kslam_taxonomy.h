@@ -59,6 +59,14 @@ int32_t kslam_taxdb_is_subspecies(const kslam_taxdb *db, uint32_t tax_id);
 kslam_status kslam_taxdb_text(const kslam_taxdb *db, uint32_t tax_id, int which, char **text,
                               uint64_t *text_len);
 
+/* The tree in the dense form the LCA walks (for a copy on the device, include/kslam_samtext.h): nodes numbered in file
+ * order; up[n] = node of the parent the reference's getParentTaxID gives (0xFFFFFFFF: none), depth[n] = nodes on the
+ * path up to the top-level node, node_tax[n] = its taxonomy id.  The arrays live as long as the tree.
+ * kslam_taxdb_node: the node of a taxonomy id, 0xFFFFFFFF when the tree does not know it. */
+kslam_status kslam_taxdb_dense(const kslam_taxdb *db, uint64_t *n_nodes, const uint32_t **up, const uint32_t **depth,
+                               const uint32_t **node_tax);
+uint32_t kslam_taxdb_node(const kslam_taxdb *db, uint32_t tax_id);
+
 /* One batch: the taxonomy id of every read pair that kslam_tail_pairs returned
  * (LCA over the entries of its alignment pairs) into tax_ids[n_read_pairs], and
  * the per-read lines "identifier \t taxonomy id \n" the reference writes to

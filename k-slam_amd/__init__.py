@@ -78,7 +78,9 @@ class BatchResult(C.Structure):
                 ("read_pairs", C.c_void_p), ("n_read_pairs", C.c_uint64), ("pairs", C.c_void_p),
                 ("n_pairs", C.c_uint64), ("pair_stats", PairStats),
                 ("n_reads", C.c_uint64), ("reads_bases_off", C.c_void_p), ("reads_ids", C.c_void_p),
-                ("reads_ids_off", C.c_void_p), ("consumed1", C.c_uint64), ("consumed2", C.c_uint64)]
+                ("reads_ids_off", C.c_void_p), ("consumed1", C.c_uint64), ("consumed2", C.c_uint64),
+                ("sam_text", C.c_void_p), ("sam_text_len", C.c_uint64), ("per_read_text", C.c_void_p),
+                ("per_read_len", C.c_uint64), ("tax_ids", C.c_void_p), ("text_flags", C.c_uint32), ("pad_", C.c_uint32)]
 
 
 class Timings(C.Structure):

@@ -8,6 +8,8 @@
 #include <sys/mman.h>
 
 #include "common.h"
+#include "samtext.h"
+#include "../../include/kslam_samtext.h"
 #include "../host/workers.hpp"
 #include <algorithm>
 #include <chrono>
@@ -81,6 +83,17 @@ struct kslam_ctx {
   uint32_t det_flags = 0;
   DetailWork detw;
 
+  // ---- SAM records / per-read lines on the device (samtext.hip, include/kslam_samtext.h) ----
+  SamAnnot annot{};               // device pointers; the primary context owns the buffers, its lanes read them
+  std::vector<DevBuf> annot_bufs;
+  bool have_annot = false;
+  SamWork samw;
+  struct { bool sam = false, per_read = false; uint32_t num_alignments = 10; int sam_xa = 0; } samtext;   // for the lanes
+  const uint8_t *d_ids = nullptr;       // read identifiers of the loaded batch (fqw.ids, or ids_buf)
+  const uint64_t *d_ids_off = nullptr;
+  DevBuf ids_buf, ids_off_buf;
+  bool have_ids = false;
+
   // ---- device pairing / screens (pairs.hip) ----
   PairWork pw;
   PairResult pres{};
@@ -117,6 +130,8 @@ struct kslam_ctx {
     kslam_row_detail *det = nullptr; char *md = nullptr; uint64_t n_md = 0;
     kslam_read_pair *rp = nullptr; uint64_t n_rp = 0; kslam_paired_overlap *pr = nullptr; uint64_t n_pr = 0;
     kslam_pair_stats pstats{};
+    char *sam_text = nullptr; uint64_t sam_len = 0; char *pr_text = nullptr; uint64_t pr_len = 0; uint32_t *tax = nullptr;
+    uint32_t text_flags = 0;
   };
   struct AsyncLane {
     kslam_ctx *c = nullptr;
@@ -504,6 +519,7 @@ void finish_load_reads(kslam_ctx *c) {
   c->have_reads = true;
   c->have_qual = false;      // a new batch: its quality strings have not been loaded
   c->have_details = false;
+  c->have_ids = false;
   c->n_res = 0;
   c->n_cig = 0;
 }
@@ -931,8 +947,155 @@ kslam_status load_reads_from_fastq_text(kslam_ctx *c, kslam_ctx::AsyncJob *job) 
     c->h_roff.assign(job->r_off, job->r_off + n + 1);
     finish_load_reads(c);
     c->have_qual = true;
+    c->d_ids = ix.d_ids;                 // in c->fqw: valid until this context indexes its next batch
+    c->d_ids_off = ix.d_ids_off;
+    c->have_ids = true;
     job->n_reads = n;
   });
+}
+
+// ---- the SAM records / per-read lines on the device (include/kslam_samtext.h, csrc/samtext.hip) ---------------------
+// ceil(-10 log10(t)) stored into a uint8_t, src/SAM.h:502-506, with THIS host's libm (host/tail.cpp: mapq_of, same code)
+inline uint8_t mapq_of(double prob, double sum) {
+  double t = 1.0 - prob / sum;
+  if (t <= 0.00001) t = 0.00001;
+  double q = ceil(-10.0 * std::log10(t));
+  if (std::isnan(q)) return 0;
+  return (uint8_t)q;
+}
+
+struct SamStage {   // one batch's way through the stage
+  SamInputs in;
+  SamParams P;
+  kslam_paired_overlap *d_recs = nullptr;
+  const kslam_read_pair *d_groups = nullptr;
+  uint64_t n_groups = 0, n_vals = 0, n_segs = 0;
+  double *h_vals = nullptr;       // pinned
+  uint32_t *h_seg = nullptr;      // pinned
+  uint8_t *h_mapq = nullptr;      // pinned
+};
+
+void sam_stage_free(kslam_ctx *c, SamStage &S) {
+  if (S.h_vals) pinned_put(c, S.h_vals);
+  if (S.h_seg) pinned_put(c, S.h_seg);
+  if (S.h_mapq) pinned_put(c, S.h_mapq);
+  S.h_vals = nullptr;
+  S.h_seg = nullptr;
+  S.h_mapq = nullptr;
+}
+
+// first half (GPU): the per-pair sort, the plan, the log-probabilities the host must evaluate brought over
+void sam_stage_plan(kslam_ctx *c, const kslam_ctx *owner, int paired, uint32_t num_alignments, int sam_xa, SamStage &S) {
+  if (!(c->have_pairs && c->pairs_of_result))
+    throw StatusError{KSLAM_ERR_STATE, "kslam_pair_screen has not been called for this result"};
+  if (!owner->have_annot) throw StatusError{KSLAM_ERR_STATE, "kslam_set_sam_annotations has not been called"};
+  if (owner->annot.n_entries != c->n_entries) throw StatusError{KSLAM_ERR_STATE, "the annotations belong to another index"};
+  if (!c->have_ids) throw StatusError{KSLAM_ERR_STATE, "the batch has no read identifiers on the device (kslam_load_read_ids)"};
+  if (c->prm.report_cigar && c->n_cig && !c->have_details)
+    throw StatusError{KSLAM_ERR_STATE, "kslam_row_details_of_pairs has not been called for this result"};
+  S.in.ov = c->res_ov.as<kslam_overlap>();
+  S.in.pool = (c->prm.report_cigar && c->n_cig) ? c->res_cig.as<uint32_t>() : nullptr;
+  S.in.det = c->have_details ? c->res_det.as<kslam_row_detail>() : nullptr;
+  S.in.md_pool = c->d_md_pool;
+  S.in.ids = c->d_ids;
+  S.in.ids_off = c->d_ids_off;
+  S.in.read_off = c->r_off.as<uint64_t>();
+  S.P.num_alignments = num_alignments;
+  S.P.paired = paired ? 1 : 0;
+  S.P.sam_xa = sam_xa ? 1 : 0;
+  S.P.report_cigar = c->prm.report_cigar ? 1 : 0;
+  S.P.mapq_unique = mapq_of(1.0, 1.0);
+  S.d_recs = const_cast<kslam_paired_overlap *>(c->pres.d_pairs);
+  S.d_groups = c->pres.d_groups;
+  S.n_groups = c->pres.n_read_pairs;
+  uint32_t err = 0;
+  sam_plan(S.d_recs, S.d_groups, S.n_groups, S.in, S.P, c->samw, &S.n_vals, &S.n_segs, &err, c->stream);
+  if (err & 2u) throw StatusError{KSLAM_ERR_ARG, "cigar runs past the end of the read or the entry"};
+  if (err & 1u) throw StatusError{KSLAM_ERR_ARG, "quality character outside phred+33 0..99"};
+  S.h_vals = (double *)pinned_get(c, (S.n_vals + 1) * sizeof(double));
+  S.h_seg = (uint32_t *)pinned_get(c, (S.n_segs + 1) * sizeof(uint32_t));
+  S.h_mapq = (uint8_t *)pinned_get(c, S.n_vals + 16);
+  if (S.n_vals) HIPCHK(hipMemcpyAsync(S.h_vals, c->samw.vals.p, S.n_vals * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  if (S.n_segs) HIPCHK(hipMemcpyAsync(S.h_seg, c->samw.seg_len.p, S.n_segs * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(stream_wait(c->stream));
+}
+
+// the host step: 10^logp, the sum in row order, the quality (src/SAM.h:464-499; host/tail.cpp: write_group's sums)
+void sam_stage_mapq(SamStage &S) {
+  if (!S.n_segs) return;
+  std::vector<uint64_t> at(S.n_segs + 1, 0);
+  for (uint64_t i = 0; i < S.n_segs; i++) at[i + 1] = at[i] + S.h_seg[i];
+  const uint64_t grain = 2048, n_tasks = (S.n_segs + grain - 1) / grain;
+  kslam_host::Pool::get().tasks(kslam_host::usable_cpus(), n_tasks, [&](size_t t) {
+    for (uint64_t i = t * grain; i < std::min<uint64_t>(S.n_segs, (t + 1) * grain); i++) {
+      const double *v = S.h_vals + at[i];
+      uint8_t *q = S.h_mapq + at[i];
+      const uint32_t n = S.h_seg[i];
+      double prob[64], *pr = prob;
+      std::vector<double> big;
+      if (n > 64) {
+        big.resize(n);
+        pr = big.data();
+      }
+      double sum = 0;
+      for (uint32_t k = 0; k < n; k++) {
+        pr[k] = std::isinf(v[k]) ? 0.0 : std::pow(10, v[k]);   // a row without this mate: probability 0
+        sum += pr[k];
+      }
+      for (uint32_t k = 0; k < n; k++) q[k] = mapq_of(pr[k], sum);
+    }
+  });
+}
+
+// second half (GPU): the qualities go up, the text is written; per-read lines; everything copied to page-locked memory
+void sam_stage_write(kslam_ctx *c, const kslam_ctx *owner, SamStage &S, bool want_sam, bool want_per_read, char **sam_text,
+                     uint64_t *sam_len, char **pr_text, uint64_t *pr_len, uint32_t **tax, uint64_t *n_tax) {
+  hipStream_t s = c->stream;
+  uint64_t text_bytes = 0, pr_bytes = 0;
+  if (want_sam) {
+    if (S.n_vals) HIPCHK(hipMemcpyAsync(c->samw.mapq.p, S.h_mapq, S.n_vals, hipMemcpyHostToDevice, s));
+    sam_format(S.d_recs, S.d_groups, S.n_groups, S.in, owner->annot, S.P, c->samw, &text_bytes, s);
+  }
+  if (want_per_read) {
+    if (!owner->annot.up) throw StatusError{KSLAM_ERR_STATE, "the annotations hold no taxonomy tree"};
+    per_read_device(S.d_recs, S.d_groups, S.n_groups, S.in, owner->annot, c->samw, &pr_bytes, s);
+  }
+  char *ht = nullptr, *hp = nullptr;
+  uint32_t *hx = nullptr;
+  try {
+    if (want_sam) {
+      ht = (char *)pinned_get(c, text_bytes + 64);
+      if (text_bytes) HIPCHK(hipMemcpyAsync(ht, c->samw.text.p, text_bytes, hipMemcpyDeviceToHost, s));
+    }
+    if (want_per_read) {
+      hp = (char *)pinned_get(c, pr_bytes + 64);
+      hx = (uint32_t *)pinned_get(c, (S.n_groups + 1) * sizeof(uint32_t));
+      if (pr_bytes) HIPCHK(hipMemcpyAsync(hp, c->samw.pr_text.p, pr_bytes, hipMemcpyDeviceToHost, s));
+      if (S.n_groups) HIPCHK(hipMemcpyAsync(hx, c->samw.tax_ids.p, S.n_groups * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    }
+    HIPCHK(stream_wait(s));
+  } catch (...) {
+    if (ht) pinned_put(c, ht);
+    if (hp) pinned_put(c, hp);
+    if (hx) pinned_put(c, hx);
+    throw;
+  }
+  if (sam_text) *sam_text = ht; else if (ht) pinned_put(c, ht);
+  if (sam_len) *sam_len = text_bytes;
+  if (pr_text) *pr_text = hp; else if (hp) pinned_put(c, hp);
+  if (pr_len) *pr_len = pr_bytes;
+  if (tax) *tax = hx; else if (hx) pinned_put(c, hx);
+  if (n_tax) *n_tax = want_per_read ? S.n_groups : 0;
+}
+
+template <typename T>
+const T *annot_upload(kslam_ctx *c, const T *src, uint64_t n, hipStream_t s) {
+  c->annot_bufs.emplace_back();
+  DevBuf &b = c->annot_bufs.back();
+  b.ensure((n + 1) * sizeof(T));
+  if (n && src) HIPCHK(hipMemcpyAsync(b.p, src, n * sizeof(T), hipMemcpyHostToDevice, s));
+  else if (n) HIPCHK(hipMemsetAsync(b.p, 0, n * sizeof(T), s));
+  return b.as<T>();
 }
 
 void fill_pair_stats(const PairResult &r, kslam_pair_stats *st) {
@@ -976,6 +1139,8 @@ void lane_main(kslam_ctx *primary, kslam_ctx::AsyncLane *lane) {
     t1 = now();
     if (!job->borrowed) pinned_put(c, job->cat);
     job->cat = nullptr;
+    SamStage sam;
+    bool sam_planned = false;
     if (st == KSLAM_OK) {
       // one lane computes at a time: the kernels of a batch fill the chip, so two batches computing at
       // once only time-slice -- and, worse, fall into step, both lanes copying while the GPU idles and
@@ -997,7 +1162,31 @@ void lane_main(kslam_ctx *primary, kslam_ctx::AsyncLane *lane) {
       // the per-row walk after the pairing: only the rows the surviving alignment pairs refer to need it
       if (st == KSLAM_OK && want_details)
         st = primary->pairing.stages ? kslam_row_details_of_pairs(c, nullptr) : kslam_row_details(c, nullptr);
+      // the SAM records / per-read lines on the device (kslam_set_sam_text), first half: the reference's per-pair sort (in
+      // place: the pairs go back to the host in that order), the rows to report, the log-probabilities the host evaluates.
+      // Not for a batch whose pseudo-assembly the device left to the host: its scores are not final yet.
+      const bool text_on = primary->samtext.sam || primary->samtext.per_read;
+      const bool pseudo_left = (primary->pairing.stages & 4u) && !(job->pstats.stages_done & 4u);
+      if (st == KSLAM_OK && text_on && primary->pairing.stages && c->have_ids && !pseudo_left &&
+          (want_details || !c->prm.report_cigar)) {
+        st = guarded(c, [&] {
+          sam_stage_plan(c, primary, primary->pairing.paired, primary->samtext.num_alignments, primary->samtext.sam_xa, sam);
+        });
+        sam_planned = st == KSLAM_OK;
+      }
     }
+    if (sam_planned) {
+      sam_stage_mapq(sam);   // pow / log10 / ceil with the host's libm, outside the compute token
+      std::lock_guard<std::mutex> compute(primary->as_compute);
+      uint64_t n_tax = 0;
+      st = guarded(c, [&] {
+        sam_stage_write(c, primary, sam, primary->samtext.sam, primary->samtext.per_read, &job->sam_text, &job->sam_len, &job->pr_text,
+                        &job->pr_len, &job->tax, &n_tax);
+      });
+      if (st == KSLAM_OK)
+        job->text_flags = KSLAM_TEXT_PAIRS_SORTED | (primary->samtext.sam ? KSLAM_TEXT_SAM : 0u) | (primary->samtext.per_read ? KSLAM_TEXT_PER_READ : 0u);
+    }
+    sam_stage_free(c, sam);
     t3 = now();
     if (st == KSLAM_OK) st = kslam_take_results(c, &job->out, &job->n_out, &job->pool, &job->n_cig);
     const double t4 = now();
@@ -1149,6 +1338,11 @@ void kslam_destroy(kslam_ctx *c) {
                       &c->pw.inserts, &c->pw.flags, &c->pw.gpos, &c->pw.rpos, &c->pw.scan_tmp, &c->pw.totals, &c->pw.groups,
                       &c->pw.dense, &c->pw.sort_a, &c->pw.sort_b, &c->pw.idx, &c->pw.picked, &c->pr_ov, &c->pr_len, &c->mg_shards, &c->mg_lens, &c->mg_off, &c->mg_scan};
     for (DevBuf *b : bufs) b->release();
+    for (auto &b : c->annot_bufs) b.release();
+    DevBuf *sam_bufs[] = {&c->samw.plan, &c->samw.cnt_vals, &c->samw.cnt_segs, &c->samw.val_off, &c->samw.seg_off, &c->samw.scan_tmp,
+                          &c->samw.totals, &c->samw.vals, &c->samw.seg_len, &c->samw.mapq, &c->samw.text_len, &c->samw.text_off,
+                          &c->samw.text, &c->samw.tax_ids, &c->samw.pr_len, &c->samw.pr_off, &c->samw.pr_text, &c->ids_buf, &c->ids_off_buf};
+    for (DevBuf *b : sam_bufs) b->release();
     {
       std::lock_guard<std::mutex> lk(c->pin_mu);
       for (auto &b : c->pinned) pinned_free(b.p, b.cap);
@@ -1582,6 +1776,104 @@ kslam_status kslam_pair_screen_overlaps(kslam_ctx *c, const kslam_overlap *overl
   });
 }
 
+kslam_status kslam_set_sam_annotations(kslam_ctx *c, const kslam_index_view *iv, const kslam_taxdb *taxdb) {
+  return guarded(c, [&] {
+    if (!iv) throw StatusError{KSLAM_ERR_ARG, "null index view"};
+    if (!c->have_index) throw StatusError{KSLAM_ERR_STATE, "kslam_set_index has not been called"};
+    if (iv->n_entries != c->n_entries) throw StatusError{KSLAM_ERR_ARG, "the index view has another number of entries than the index"};
+    if (!iv->locus_tag_off || !iv->taxonomy_id) throw StatusError{KSLAM_ERR_ARG, "index view needs locus tags and taxonomy ids"};
+    if (iv->n_genes && (!iv->gene_first || !iv->gene_start || !iv->gene_stop || !iv->gene_name_off || !iv->protein_id_off || !iv->product_off))
+      throw StatusError{KSLAM_ERR_ARG, "index view has n_genes > 0 but no gene columns"};
+    for (auto &b : c->annot_bufs) b.release();
+    c->annot_bufs.clear();
+    c->annot_bufs.reserve(24);
+    c->have_annot = false;
+    hipStream_t s = c->stream;
+    const uint64_t E = iv->n_entries, G = iv->n_genes;
+    SamAnnot A;
+    A.n_entries = E;
+    A.n_genes = G;
+    A.locus = annot_upload(c, (const uint8_t *)iv->locus_tag, iv->locus_tag_off[E], s);
+    A.locus_off = annot_upload(c, iv->locus_tag_off, E + 1, s);
+    A.tax = annot_upload(c, iv->taxonomy_id, E, s);
+    if (G) {
+      A.gene_first = annot_upload(c, iv->gene_first, E + 1, s);
+      A.gene_start = annot_upload(c, iv->gene_start, G, s);
+      A.gene_stop = annot_upload(c, iv->gene_stop, G, s);
+      A.gname = annot_upload(c, (const uint8_t *)iv->gene_name, iv->gene_name_off[G], s);
+      A.gname_off = annot_upload(c, iv->gene_name_off, G + 1, s);
+      A.prot = annot_upload(c, (const uint8_t *)iv->protein_id, iv->protein_id_off[G], s);
+      A.prot_off = annot_upload(c, iv->protein_id_off, G + 1, s);
+      A.prod = annot_upload(c, (const uint8_t *)iv->product, iv->product_off[G], s);
+      A.prod_off = annot_upload(c, iv->product_off, G + 1, s);
+    }
+    std::vector<uint32_t> entry_node;
+    if (taxdb) {
+      uint64_t n_nodes = 0;
+      const uint32_t *up = nullptr, *depth = nullptr, *node_tax = nullptr;
+      if (kslam_taxdb_dense(taxdb, &n_nodes, &up, &depth, &node_tax) != KSLAM_OK) throw StatusError{KSLAM_ERR_ARG, kslam_tail_last_error()};
+      A.n_nodes = n_nodes;
+      A.up = annot_upload(c, up, n_nodes, s);
+      A.depth = annot_upload(c, depth, n_nodes, s);
+      A.node_tax = annot_upload(c, node_tax, n_nodes, s);
+      entry_node.resize(E + 1);
+      for (uint64_t e = 0; e < E; e++) entry_node[e] = kslam_taxdb_node(taxdb, iv->taxonomy_id[e]);
+      A.entry_node = annot_upload(c, entry_node.data(), E, s);
+    }
+    HIPCHK(stream_wait(s));
+    c->annot = A;
+    c->have_annot = true;
+  });
+}
+
+kslam_status kslam_set_sam_text(kslam_ctx *c, int want_sam, int want_per_read, uint32_t num_alignments, int sam_xa) {
+  return guarded(c, [&] {
+    if ((want_sam || want_per_read) && !c->have_annot) throw StatusError{KSLAM_ERR_STATE, "kslam_set_sam_annotations has not been called"};
+    if (want_per_read && !c->annot.up) throw StatusError{KSLAM_ERR_STATE, "the annotations hold no taxonomy tree"};
+    c->samtext.sam = want_sam != 0;
+    c->samtext.per_read = want_per_read != 0;
+    c->samtext.num_alignments = num_alignments;
+    c->samtext.sam_xa = sam_xa;
+  });
+}
+
+kslam_status kslam_load_read_ids(kslam_ctx *c, const char *concat, const uint64_t *offsets) {
+  return guarded(c, [&] {
+    if (!c->have_reads) throw StatusError{KSLAM_ERR_STATE, "no batch loaded"};
+    if (!offsets || (c->n_reads && offsets[c->n_reads] && !concat)) throw StatusError{KSLAM_ERR_ARG, "null argument"};
+    const uint64_t n = c->n_reads, bytes = n ? offsets[n] : 0;
+    c->ids_buf.ensure(bytes + 64);
+    c->ids_off_buf.ensure((n + 1) * sizeof(uint64_t));
+    if (bytes) HIPCHK(hipMemcpyAsync(c->ids_buf.p, concat, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->ids_off_buf.p, offsets, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(stream_wait(c->stream));
+    c->d_ids = c->ids_buf.as<uint8_t>();
+    c->d_ids_off = c->ids_off_buf.as<uint64_t>();
+    c->have_ids = true;
+  });
+}
+
+kslam_status kslam_sam_text(kslam_ctx *c, int paired, uint32_t num_alignments, int sam_xa, char **sam_text, uint64_t *sam_len,
+                            char **per_read_text, uint64_t *per_read_len, uint32_t **tax_ids, uint64_t *n_tax_ids) {
+  if (sam_text) *sam_text = nullptr;
+  if (per_read_text) *per_read_text = nullptr;
+  if (tax_ids) *tax_ids = nullptr;
+  if (sam_len) *sam_len = 0;
+  if (per_read_len) *per_read_len = 0;
+  if (n_tax_ids) *n_tax_ids = 0;
+  SamStage S;
+  const kslam_status st = guarded(c, [&] {
+    if (sam_text && !sam_len) throw StatusError{KSLAM_ERR_ARG, "sam_text without sam_len"};
+    if ((per_read_text && !per_read_len) || (tax_ids && !n_tax_ids)) throw StatusError{KSLAM_ERR_ARG, "an output without its length"};
+    sam_stage_plan(c, c, paired, num_alignments, sam_xa, S);
+    sam_stage_mapq(S);
+    sam_stage_write(c, c, S, sam_text != nullptr, per_read_text != nullptr || tax_ids != nullptr, sam_text, sam_len, per_read_text,
+                    per_read_len, tax_ids, n_tax_ids);
+  });
+  if (c) sam_stage_free(c, S);
+  return st;
+}
+
 kslam_status kslam_take_pairs(kslam_ctx *c, kslam_read_pair **read_pairs, uint64_t *n_read_pairs, kslam_paired_overlap **pairs,
                               uint64_t *n_pairs) {
   if (!c || !read_pairs || !n_read_pairs || !pairs || !n_pairs) return KSLAM_ERR_ARG;
@@ -1821,6 +2113,9 @@ void kslam_release_batch(kslam_ctx *c, kslam_batch_result *r) {
   kslam_free_pinned(c, r->reads_bases_off);
   kslam_free_pinned(c, r->reads_ids_off);
   kslam_free_pinned(c, r->reads_ids);
+  kslam_free_pinned(c, r->sam_text);
+  kslam_free_pinned(c, r->per_read_text);
+  kslam_free_pinned(c, r->tax_ids);
   memset(r, 0, sizeof *r);
 }
 
@@ -1844,7 +2139,12 @@ kslam_status kslam_collect_batch(kslam_ctx *c, uint64_t ticket, kslam_batch_resu
     res->pair_stats = job->pstats;
     res->n_reads = job->r_n; res->reads_bases_off = job->r_off; res->reads_ids = job->r_ids; res->reads_ids_off = job->r_ids_off;
     res->consumed1 = job->consumed[0]; res->consumed2 = job->consumed[1];
+    res->sam_text = job->sam_text; res->sam_text_len = job->sam_len; res->per_read_text = job->pr_text; res->per_read_len = job->pr_len;
+    res->tax_ids = job->tax; res->text_flags = job->text_flags;
   } else {
+    kslam_free_pinned(c, job->sam_text);
+    kslam_free_pinned(c, job->pr_text);
+    kslam_free_pinned(c, job->tax);
     c->err = job->err;
     kslam_free_batch(c, job->out, job->pool);
     kslam_free_pinned(c, job->det);

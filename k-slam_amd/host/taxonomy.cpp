@@ -259,6 +259,18 @@ kslam_status kslam_taxdb_parse(const char *text, uint64_t len, kslam_taxdb **out
 void kslam_taxdb_free(kslam_taxdb *db) { delete db; }
 uint64_t kslam_taxdb_size(const kslam_taxdb *db) { return db ? db->n_real : 0; }
 
+kslam_status kslam_taxdb_dense(const kslam_taxdb *db, uint64_t *n_nodes, const uint32_t **up, const uint32_t **depth,
+                               const uint32_t **node_tax) {
+  return guarded([&] {
+    if (!db || !n_nodes || !up || !depth || !node_tax) fail(KSLAM_ERR_ARG, "null argument");
+    *n_nodes = db->up.size();
+    *up = db->up.data();
+    *depth = db->depth.data();
+    *node_tax = db->tax_id.data();
+  });
+}
+uint32_t kslam_taxdb_node(const kslam_taxdb *db, uint32_t tax_id) { return db ? db->node(tax_id) : kslam_taxdb::NONE; }
+
 uint32_t kslam_taxdb_lca(const kslam_taxdb *db, const uint32_t *tax_ids, uint64_t n) {
   if (!db || (!tax_ids && n)) return 0;
   return lca_ids(*db, tax_ids, n);

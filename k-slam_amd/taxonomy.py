@@ -13,7 +13,7 @@ from .tail import IndexView, PAIRED_OVERLAP_DT, READ_PAIR_DT, ReadsView, TailPar
 # every symbol include/kslam_taxonomy.h declares
 EXPORTS = ["kslam_taxdb_parse", "kslam_taxdb_free", "kslam_taxdb_size", "kslam_taxdb_lca",
            "kslam_taxdb_parent", "kslam_taxdb_at_rank", "kslam_taxdb_is_below",
-           "kslam_taxdb_is_subspecies", "kslam_taxdb_text", "kslam_tail_classify",
+           "kslam_taxdb_is_subspecies", "kslam_taxdb_text", "kslam_taxdb_dense", "kslam_taxdb_node", "kslam_tail_classify",
            "kslam_taxonomy_summary", "kslam_taxreport_create", "kslam_taxreport_free", "kslam_taxreport_add_batch",
            "kslam_taxreport_xml"]
 

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol(kslam):
     for name in declared:
         assert hasattr(L, name), "missing export " + name
     assert sorted(kslam.EXPORTS) == declared
-    assert L.kslam_abi_version() == 8
+    assert L.kslam_abi_version() == 9
 
 
 def test_library_exports_every_tail_symbol(kslam):
@@ -47,7 +47,7 @@ def test_library_exports_every_tail_symbol(kslam):
     assert T.PAIRED_OVERLAP_DT.itemsize == 32 and T.READ_PAIR_DT.itemsize == 24
 
 
-@pytest.mark.parametrize("header,module,count", [("kslam_fastq.h", "fastq", 6), ("kslam_taxonomy.h", "taxonomy", 15),
+@pytest.mark.parametrize("header,module,count", [("kslam_fastq.h", "fastq", 6), ("kslam_taxonomy.h", "taxonomy", 17), ("kslam_samtext.h", "samtext", 4),
                                                  ("kslam_db.h", "db", 9), ("kslam_stream.h", "stream", 1)])
 def test_library_exports_every_host_stage_symbol(kslam, header, module, count):
     import ctypes
@@ -168,7 +168,7 @@ def test_sharded_gather_world2_gloo(tmp_path):
     assert "GATHER_OK" in r.stdout and "SHARDED_GATHER_OK" in r.stdout
 
 
-@pytest.mark.parametrize("header", ["kslam.h", "kslam_tail.h", "kslam_fastq.h", "kslam_taxonomy.h", "kslam_db.h", "kslam_stream.h", "kslam_comm.h"])
+@pytest.mark.parametrize("header", ["kslam.h", "kslam_tail.h", "kslam_fastq.h", "kslam_taxonomy.h", "kslam_db.h", "kslam_stream.h", "kslam_comm.h", "kslam_samtext.h"])
 def test_headers_are_plain_c(header, tmp_path):
     """The boundary is a C ABI: every header must compile on its own as C99 (pedantic) and as C++11."""
     import shutil

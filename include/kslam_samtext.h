@@ -42,8 +42,8 @@ kslam_status kslam_set_sam_text(kslam_ctx *ctx, int want_sam, int want_per_read,
 kslam_status kslam_load_read_ids(kslam_ctx *ctx, const char *concat, const uint64_t *offsets);
 
 /* One resident batch, after kslam_pair_screen (or the phased calls) and -- when the context reports CIGARs --
- * kslam_row_details_of_pairs: sorts every read pair's alignment pairs in place (the reference's per-pair std::sort),
- * then returns page-locked, library-owned copies (kslam_free_pinned each; an output pointer may be NULL to skip it):
+ * kslam_row_details_of_pairs: when the SAM records are asked for, sorts every read pair's alignment pairs in place (the
+ * reference's per-pair std::sort: it only runs when a SAM file is written), then returns page-locked, library-owned copies (kslam_free_pinned each; an output pointer may be NULL to skip it):
  * the SAM records, the per-read lines and the taxonomy id per read pair. */
 kslam_status kslam_sam_text(kslam_ctx *ctx, int paired, uint32_t num_alignments, int sam_xa, char **sam_text,
                             uint64_t *sam_len, char **per_read_text, uint64_t *per_read_len, uint32_t **tax_ids,

@@ -985,7 +985,7 @@ void sam_stage_free(kslam_ctx *c, SamStage &S) {
 }
 
 // first half (GPU): the per-pair sort, the plan, the log-probabilities the host must evaluate brought over
-void sam_stage_plan(kslam_ctx *c, const kslam_ctx *owner, int paired, uint32_t num_alignments, int sam_xa, SamStage &S) {
+void sam_stage_plan(kslam_ctx *c, const kslam_ctx *owner, int paired, uint32_t num_alignments, int sam_xa, bool sort_groups, SamStage &S) {
   if (!(c->have_pairs && c->pairs_of_result))
     throw StatusError{KSLAM_ERR_STATE, "kslam_pair_screen has not been called for this result"};
   if (!owner->have_annot) throw StatusError{KSLAM_ERR_STATE, "kslam_set_sam_annotations has not been called"};
@@ -1005,6 +1005,7 @@ void sam_stage_plan(kslam_ctx *c, const kslam_ctx *owner, int paired, uint32_t n
   S.P.sam_xa = sam_xa ? 1 : 0;
   S.P.report_cigar = c->prm.report_cigar ? 1 : 0;
   S.P.mapq_unique = mapq_of(1.0, 1.0);
+  S.P.sort_groups = sort_groups ? 1 : 0;
   S.d_recs = const_cast<kslam_paired_overlap *>(c->pres.d_pairs);
   S.d_groups = c->pres.d_groups;
   S.n_groups = c->pres.n_read_pairs;
@@ -1170,7 +1171,7 @@ void lane_main(kslam_ctx *primary, kslam_ctx::AsyncLane *lane) {
       if (st == KSLAM_OK && text_on && primary->pairing.stages && c->have_ids && !pseudo_left &&
           (want_details || !c->prm.report_cigar)) {
         st = guarded(c, [&] {
-          sam_stage_plan(c, primary, primary->pairing.paired, primary->samtext.num_alignments, primary->samtext.sam_xa, sam);
+          sam_stage_plan(c, primary, primary->pairing.paired, primary->samtext.num_alignments, primary->samtext.sam_xa, primary->samtext.sam, sam);
         });
         sam_planned = st == KSLAM_OK;
       }
@@ -1184,7 +1185,7 @@ void lane_main(kslam_ctx *primary, kslam_ctx::AsyncLane *lane) {
                         &job->pr_len, &job->tax, &n_tax);
       });
       if (st == KSLAM_OK)
-        job->text_flags = KSLAM_TEXT_PAIRS_SORTED | (primary->samtext.sam ? KSLAM_TEXT_SAM : 0u) | (primary->samtext.per_read ? KSLAM_TEXT_PER_READ : 0u);
+        job->text_flags = (primary->samtext.sam ? (KSLAM_TEXT_PAIRS_SORTED | KSLAM_TEXT_SAM) : 0u) | (primary->samtext.per_read ? KSLAM_TEXT_PER_READ : 0u);
     }
     sam_stage_free(c, sam);
     t3 = now();
@@ -1865,7 +1866,7 @@ kslam_status kslam_sam_text(kslam_ctx *c, int paired, uint32_t num_alignments, i
   const kslam_status st = guarded(c, [&] {
     if (sam_text && !sam_len) throw StatusError{KSLAM_ERR_ARG, "sam_text without sam_len"};
     if ((per_read_text && !per_read_len) || (tax_ids && !n_tax_ids)) throw StatusError{KSLAM_ERR_ARG, "an output without its length"};
-    sam_stage_plan(c, c, paired, num_alignments, sam_xa, S);
+    sam_stage_plan(c, c, paired, num_alignments, sam_xa, sam_text != nullptr, S);
     sam_stage_mapq(S);
     sam_stage_write(c, c, S, sam_text != nullptr, per_read_text != nullptr || tax_ids != nullptr, sam_text, sam_len, per_read_text,
                     per_read_len, tax_ids, n_tax_ids);

@@ -34,6 +34,7 @@ struct SamInputs {   // one batch, all device pointers
 struct SamParams {
   uint32_t num_alignments = 10;   // --num-alignments
   int32_t paired = 1, sam_xa = 0, report_cigar = 1;
+  int32_t sort_groups = 1;        // run writeSAMOutputPairs' per-pair sort (the reference only sorts when it writes a SAM file)
   uint32_t mapq_unique = 50;      // the host libm's ceil(-10 log10(1e-5)): quality of a mate with ONE reported row
 };
 

@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256) void k_sam_plan(Rec *__restrict__ recs, const 
     return;
   }
   Rec *v = recs + groups[g].first;
-  kslam_gnu::sort(v, v + cnt, ByScoreDesc());   // writeSAMOutputPairs' first statement, src/SAM.h:446-450
+  if (P.sort_groups) kslam_gnu::sort(v, v + cnt, ByScoreDesc());   // writeSAMOutputPairs' first statement, src/SAM.h:446-450
   const uint32_t n_rows = min(cnt, max(P.num_alignments, 1u));
   uint32_t use1 = 0, use2 = 0, bad = 0;
   double lone1 = 0, lone2 = 0;

@@ -3,9 +3,13 @@
 // could write the same loop itself (INTEGRATION.md shows it); this file is that loop, tested and timed.
 //
 //   main thread:  cut batch k+d (kslam_fastq_batch_end) -> kslam_submit_batch_fastq_text ... kslam_collect_batch(k)
-//   worker:       host stage of batch k-1: kslam_tail_finish_write_rows -> kslam_sam_writer (its own thread),
-//                 kslam_tail_classify -> per_read_fd, kslam_taxreport_add_batch
+//   worker:       host stage of batch k-1: the SAM records and the per-read lines arrive WRITTEN (include/kslam_samtext.h: on the
+//                 GPU, inside the lane) and go to kslam_sam_writer (its own thread) / per_read_fd as they are; what is left for
+//                 the CPUs is kslam_taxreport_add_batch.  A batch whose text the device left to the host (pseudo-assembly
+//                 fallback), or KSLAM_HOST_SAM_TEXT=1: kslam_tail_finish_prepare -> kslam_tail_finish_write_rows,
+//                 kslam_tail_classify
 #include <cerrno>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <string>
@@ -15,6 +19,7 @@
 
 #include "../../include/kslam_fastq.h"
 #include "../../include/kslam_stream.h"
+#include "../../include/kslam_samtext.h"
 #include "workers.hpp"
 
 namespace {
@@ -53,7 +58,7 @@ extern "C" kslam_status kslam_stream_classify(kslam_ctx *ctx, const kslam_index_
   std::string worker_error;
   std::deque<uint64_t> tickets;
   std::vector<uint32_t> all_ids;
-  bool pairing_set = false;
+  bool pairing_set = false, text_set = false;
 
   const int pool_cap = P && P->pool_threads ? (int)P->pool_threads : std::max(2, usable_cpus() - 4);
   Pool::get().add_cap(pool_cap);
@@ -73,6 +78,7 @@ extern "C" kslam_status kslam_stream_classify(kslam_ctx *ctx, const kslam_index_
       st.seconds_in_write = sec;
       writer = nullptr;
     }
+    if (text_set) kslam_set_sam_text(ctx, 0, 0, 10, 0);
     if (pairing_set) kslam_set_pairing(ctx, 1, 0, 0.95, 0);
     Pool::get().remove_cap(pool_cap);
     return w;
@@ -90,6 +96,15 @@ extern "C" kslam_status kslam_stream_classify(kslam_ctx *ctx, const kslam_index_
     if (kslam_set_pairing(ctx, paired ? 1 : 0, P->tail.score_threshold, P->tail.score_fraction, stages) != KSLAM_OK)
       fail(KSLAM_ERR_UNSUPPORTED, kslam_last_error(ctx));
     pairing_set = true;
+    // the SAM records and the per-read lines written on the GPU (include/kslam_samtext.h); KSLAM_HOST_SAM_TEXT=1 keeps the
+    // host formatter for everything (A/B, and the route of a batch the device hands back without text)
+    const bool device_text = !(getenv("KSLAM_HOST_SAM_TEXT") && getenv("KSLAM_HOST_SAM_TEXT")[0] == '1') && (P->sam_fd >= 0 || taxdb);
+    if (device_text) {
+      if (kslam_set_sam_annotations(ctx, index, taxdb) != KSLAM_OK ||
+          kslam_set_sam_text(ctx, P->sam_fd >= 0 ? 1 : 0, taxdb ? 1 : 0, P->tail.num_sam_alignments, P->tail.sam_xa) != KSLAM_OK)
+        fail(KSLAM_ERR_STATE, kslam_last_error(ctx));
+      text_set = true;
+    }
     if (P->sam_fd >= 0) {
       if (kslam_sam_writer_open(P->sam_fd, &writer) != KSLAM_OK) fail(KSLAM_ERR_ARG, "could not start the SAM writer");
       if (P->sam_header && P->sam_header_len && kslam_write_queued(writer, P->sam_header, P->sam_header_len) != 0)
@@ -150,13 +165,20 @@ extern "C" kslam_status kslam_stream_classify(kslam_ctx *ctx, const kslam_index_
             const double t1 = now_ms();
             const size_t base = all_ids.size();
             all_ids.resize(base + res.n_read_pairs);
-            char *text = nullptr;
             uint64_t tlen = 0;
-            const kslam_status b = kslam_tail_classify(&host_write, &reads, index, taxdb, res.read_pairs, res.n_read_pairs, res.pairs,
-                                                       res.n_pairs, all_ids.data() + base, &text, &tlen);
-            if (b != KSLAM_OK) fail(b, kslam_tail_last_error());
-            const bool wrote = P->per_read_fd < 0 || write_all(P->per_read_fd, text, tlen);
-            kslam_free(text);
+            bool wrote = true;
+            if (res.text_flags & KSLAM_TEXT_PER_READ) {   // taxonomy ids and lines came with the batch (GPU)
+              if (res.n_read_pairs) memcpy(all_ids.data() + base, res.tax_ids, sizeof(uint32_t) * res.n_read_pairs);
+              tlen = res.per_read_len;
+              wrote = P->per_read_fd < 0 || write_all(P->per_read_fd, res.per_read_text, tlen);
+            } else {
+              char *text = nullptr;
+              const kslam_status b = kslam_tail_classify(&host_write, &reads, index, taxdb, res.read_pairs, res.n_read_pairs, res.pairs,
+                                                         res.n_pairs, all_ids.data() + base, &text, &tlen);
+              if (b != KSLAM_OK) fail(b, kslam_tail_last_error());
+              wrote = P->per_read_fd < 0 || write_all(P->per_read_fd, text, tlen);
+              kslam_free(text);
+            }
             if (!wrote) fail(KSLAM_ERR_ARG, std::string("writing the per-read file failed: ") + strerror(errno));
             st.per_read_bytes += tlen;
             const double t2 = now_ms();
@@ -177,9 +199,14 @@ extern "C" kslam_status kslam_stream_classify(kslam_ctx *ctx, const kslam_index_
         kslam_tail_stats ps;
         memset(&ps, 0, sizeof ps);
         const double t0 = now_ms();
-        const kslam_status a = kslam_tail_finish_prepare(tp, &reads, res.overlaps, res.n_overlaps, res.read_pairs, res.n_read_pairs,
-                                                         res.pairs, res.n_pairs, writer ? 1 : 0, &ps);
-        if (a != KSLAM_OK) fail(a, kslam_tail_last_error());
+        if (res.text_flags & KSLAM_TEXT_PAIRS_SORTED) {   // the device finished every stage and ran the per-pair sort: nothing to change
+          ps.n_read_pairs = res.n_read_pairs;
+          for (uint64_t g = 0; g < res.n_read_pairs; g++) ps.n_paired_final += res.read_pairs[g].count;
+        } else {
+          const kslam_status a = kslam_tail_finish_prepare(tp, &reads, res.overlaps, res.n_overlaps, res.read_pairs, res.n_read_pairs,
+                                                           res.pairs, res.n_pairs, writer ? 1 : 0, &ps);
+          if (a != KSLAM_OK) fail(a, kslam_tail_last_error());
+        }
         st.seconds_sam_text += (now_ms() - t0) * 1e-3;
         st.n_alignment_pairs += ps.n_paired_final;
         st.n_read_pairs_aligned += ps.n_read_pairs;
@@ -191,7 +218,20 @@ extern "C" kslam_status kslam_stream_classify(kslam_ctx *ctx, const kslam_index_
       std::string err = s != KSLAM_OK ? g_err : std::string();
       const bool two_threads = P->host_threads != 1;
       if (s == KSLAM_OK && taxdb && two_threads) tax_thread = std::thread([&] { name_thread("kslam-tax"); tax_part(); });
-      if (s == KSLAM_OK && writer) {
+      if (s == KSLAM_OK && writer && (res.text_flags & KSLAM_TEXT_SAM)) {
+        s = guarded([&] {   // written on the GPU: the page-locked block joins the writer's queue as it is and goes back to the
+                            // context's pool once it is in the file
+          const double t0 = now_ms();
+          char *block = res.sam_text;
+          const uint64_t len = res.sam_text_len;
+          res.sam_text = nullptr;   // the writer owns it now
+          static const auto give_back = [](void *user, void *data) { kslam_free_pinned(static_cast<kslam_ctx *>(user), data); };
+          if (kslam_sam_writer_enqueue(writer, block, len, +give_back, ctx) != KSLAM_OK) fail(KSLAM_ERR_ARG, kslam_tail_last_error());
+          st.seconds_sam_text += (now_ms() - t0) * 1e-3;
+          st.sam_bytes += len;
+        });
+        if (s != KSLAM_OK) err = g_err;
+      } else if (s == KSLAM_OK && writer) {
         s = guarded([&] {
           kslam_tail_stats ts;
           memset(&ts, 0, sizeof ts);

@@ -86,27 +86,46 @@ struct Buf {
 struct Text {  // growable byte buffer (realloc: large blocks grow by mremap, no copy, no zero fill)
   char *p = nullptr;
   size_t cap = 0, n = 0;
+  // a BORROWED block (kslam_sam_writer_enqueue: text another stage produced, e.g. the GPU formatter's page-locked copy):
+  // never grown, handed back through ext_release instead of free()
+  void (*ext_release)(void *user, void *data) = nullptr;
+  void *ext_user = nullptr;
   Text() {}
   Text(const Text &) = delete;
   Text &operator=(const Text &) = delete;
-  Text(Text &&o) noexcept : p(o.p), cap(o.cap), n(o.n) {
+  Text(Text &&o) noexcept : p(o.p), cap(o.cap), n(o.n), ext_release(o.ext_release), ext_user(o.ext_user) {
     o.p = nullptr;
     o.cap = o.n = 0;
+    o.ext_release = nullptr;
+  }
+  void drop() {
+    if (ext_release) {
+      if (p) ext_release(ext_user, p);
+    } else {
+      free(p);
+    }
+    p = nullptr;
+    cap = n = 0;
+    ext_release = nullptr;
   }
   Text &operator=(Text &&o) noexcept {
     if (this != &o) {
-      free(p);
+      drop();
       p = o.p;
       cap = o.cap;
       n = o.n;
+      ext_release = o.ext_release;
+      ext_user = o.ext_user;
       o.p = nullptr;
       o.cap = o.n = 0;
+      o.ext_release = nullptr;
     }
     return *this;
   }
-  ~Text() { free(p); }
+  ~Text() { drop(); }
   void reserve(size_t want) {
     if (want <= cap) return;
+    if (ext_release) fail(KSLAM_ERR_INTERNAL, "a borrowed text block cannot grow");
     char *q = (char *)realloc(p, want);
     if (!q) fail(KSLAM_ERR_OOM, "out of host memory for SAM text");
     advise_huge(q, want);
@@ -117,11 +136,7 @@ struct Text {  // growable byte buffer (realloc: large blocks grow by mremap, no
     if (n + k > cap) reserve(std::max(cap * 2, n + k + 4096));
     return p + n;
   }
-  void release() {
-    free(p);
-    p = nullptr;
-    cap = n = 0;
-  }
+  void release() { drop(); }
   void put(const char *s, size_t k) {
     memcpy(need(k), s, k);
     n += k;
@@ -1502,12 +1517,18 @@ struct kslam_sam_writer {
         }
         t.n = 0;
       }
+      bool borrowed = false;
+      for (Text &t : set)
+        if (t.ext_release) {
+          t.drop();            // back to its owner as soon as it is written
+          borrowed = true;
+        }
       {
         std::lock_guard<std::mutex> lk(m);
         bytes += done;
         write_s += (now_ms() - t0) * 1e-3;
         busy = false;
-        if (spare.size() < 3) spare.push_back(std::move(set));
+        if (!borrowed && spare.size() < 3) spare.push_back(std::move(set));
       }
       cv.notify_all();
     }
@@ -1908,6 +1929,29 @@ int kslam_write_queued(void *user, const char *data, uint64_t len) {
   }
   w->cv.notify_all();
   return 0;
+}
+
+// a block another stage produced goes into the queue as it is (no copy); release(user, data) is called on the writer thread
+// once it has been written (or at close, if a write failed before its turn)
+kslam_status kslam_sam_writer_enqueue(kslam_sam_writer *w, char *data, uint64_t len, void (*release)(void *user, void *data),
+                                      void *user) {
+  return guarded([&] {
+    if (!w || (!data && len) || !release) fail(KSLAM_ERR_ARG, "null argument");
+    Text t;
+    t.p = data;
+    t.n = t.cap = (size_t)len;
+    t.ext_release = release;
+    t.ext_user = user;
+    std::vector<Text> one;
+    one.push_back(std::move(t));
+    {
+      std::unique_lock<std::mutex> lk(w->m);
+      w->cv.wait(lk, [&] { return w->error || w->queue.size() < 2; });
+      if (w->error) fail(KSLAM_ERR_ARG, std::string("writing the SAM text failed: ") + strerror(w->error));   // `one` releases the block
+      w->queue.push_back(std::move(one));
+    }
+    w->cv.notify_all();
+  });
 }
 
 kslam_status kslam_sam_writer_close(kslam_sam_writer *w, uint64_t *bytes_written, double *seconds_writing) {

@@ -23,7 +23,7 @@ assert PAIRED_OVERLAP_DT.itemsize == 32 and READ_PAIR_DT.itemsize == 24
 EXPORTS = ["kslam_tail_last_error", "kslam_tail_pairs", "kslam_sam_records", "kslam_tail_sam",
            "kslam_tail_sam_write", "kslam_tail_sam_rows", "kslam_tail_sam_write_rows", "kslam_tail_finish_write_rows",
            "kslam_tail_finish_prepare", "kslam_tail_release_buffers",
-           "kslam_sam_header", "kslam_write_fd", "kslam_sam_writer_open", "kslam_write_queued", "kslam_sam_writer_close"]
+           "kslam_sam_header", "kslam_write_fd", "kslam_sam_writer_open", "kslam_write_queued", "kslam_sam_writer_enqueue", "kslam_sam_writer_close"]
 WRITE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64)
 
 _vp, _u64, _u32, _i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int32

@@ -347,7 +347,9 @@ typedef struct {
   char *reads_ids;
   uint64_t *reads_ids_off;   /* n_reads + 1 */
   uint64_t consumed1, consumed2;
-  /* kslam_set_sam_text (include/kslam_samtext.h) switched on: the batch's SAM records and <out>_PerRead lines as written
+  /* With KSLAM_TEXT_SAM in text_flags, overlaps / cigar_pool / details / md_pool are NULL (their counts are still
+   * reported): the SAM writer was their only reader, and the records were written where they lie.
+   * kslam_set_sam_text (include/kslam_samtext.h) switched on: the batch's SAM records and <out>_PerRead lines as written
    * on the GPU, the taxonomy id per read pair; NULL / 0 when off, or when this batch's text was left to the host
    * (text_flags says which).  With KSLAM_TEXT_PAIRS_SORTED the read pairs' alignment pairs above are already in
    * writeSAMOutputPairs' order (the device ran the per-pair sort): kslam_tail_finish_write_rows then takes

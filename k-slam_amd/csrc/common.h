@@ -54,6 +54,7 @@ struct Tuning {
   bool eager_cigar = false;           // KSLAM_EAGER_CIGAR
   bool lane_waits_yield = false;      // KSLAM_LANE_WAITS=yield: the pipeline lanes poll + sleep instead of busy-waiting for the GPU (stream_wait)
   bool pageable_columns = false;      // KSLAM_PAGEABLE_COLUMNS
+  int pseudo_cap = 0;                 // KSLAM_PSEUDO_CAP (tests): alignment pairs of one entry beyond which pseudo-assembly is left to the host; 0 = 262144
 #ifdef KSLAM_ABLATE
   uint32_t sw_ablate = 0, cigar_variant = 0, filter_ablate = 0;   // KSLAM_SW_ABLATE / _CIGAR_VARIANT / _FILTER_ABLATE
 #endif
@@ -352,6 +353,7 @@ void row_details(const kslam_overlap *d_ov, uint64_t n, const uint32_t *d_pool, 
 struct PairWork {
   DevBuf recs, count, base, inserts, flags, gpos, rpos, scan_tmp, totals, groups, dense, sort_a, sort_b, idx, picked, row_list;
   uint64_t units = 0, mid = 0;   // between pair_phase_a and pair_phase_b: read pairs (or reads) of the batch, its R1 block
+  uint32_t pseudo_cap = 0;       // 0 = the default (pairs.hip: PSEUDO_CAP_GLOBAL); tests lower it to reach the host fallback
   int paired = 0;
 };
 struct PairResult {

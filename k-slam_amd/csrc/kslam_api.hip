@@ -188,6 +188,7 @@ Tuning read_tuning() {
   t.eager_cigar = flag("KSLAM_EAGER_CIGAR");
   t.lane_waits_yield = starts("KSLAM_LANE_WAITS", 'y');
   t.pageable_columns = flag("KSLAM_PAGEABLE_COLUMNS");
+  t.pseudo_cap = std::max(0, num("KSLAM_PSEUDO_CAP", 0));
 #ifdef KSLAM_ABLATE
   t.sw_ablate = (uint32_t)num("KSLAM_SW_ABLATE", 0);
   t.cigar_variant = (uint32_t)num("KSLAM_CIGAR_VARIANT", 0);
@@ -969,7 +970,7 @@ struct SamStage {   // one batch's way through the stage
   SamParams P;
   kslam_paired_overlap *d_recs = nullptr;
   const kslam_read_pair *d_groups = nullptr;
-  uint64_t n_groups = 0, n_vals = 0, n_segs = 0;
+  uint64_t n_groups = 0, n_vals = 0, n_segs = 0, text_bytes = 0, pr_bytes = 0;
   double *h_vals = nullptr;       // pinned
   uint32_t *h_seg = nullptr;      // pinned
   uint8_t *h_mapq = nullptr;      // pinned
@@ -1048,19 +1049,25 @@ void sam_stage_mapq(SamStage &S) {
   });
 }
 
-// second half (GPU): the qualities go up, the text is written; per-read lines; everything copied to page-locked memory
-void sam_stage_write(kslam_ctx *c, const kslam_ctx *owner, SamStage &S, bool want_sam, bool want_per_read, char **sam_text,
-                     uint64_t *sam_len, char **pr_text, uint64_t *pr_len, uint32_t **tax, uint64_t *n_tax) {
+// second half (GPU): the qualities go up, the text is written; per-read lines
+void sam_stage_kernels(kslam_ctx *c, const kslam_ctx *owner, SamStage &S, bool want_sam, bool want_per_read) {
   hipStream_t s = c->stream;
-  uint64_t text_bytes = 0, pr_bytes = 0;
+  S.text_bytes = S.pr_bytes = 0;
   if (want_sam) {
     if (S.n_vals) HIPCHK(hipMemcpyAsync(c->samw.mapq.p, S.h_mapq, S.n_vals, hipMemcpyHostToDevice, s));
-    sam_format(S.d_recs, S.d_groups, S.n_groups, S.in, owner->annot, S.P, c->samw, &text_bytes, s);
+    sam_format(S.d_recs, S.d_groups, S.n_groups, S.in, owner->annot, S.P, c->samw, &S.text_bytes, s);
   }
   if (want_per_read) {
     if (!owner->annot.up) throw StatusError{KSLAM_ERR_STATE, "the annotations hold no taxonomy tree"};
-    per_read_device(S.d_recs, S.d_groups, S.n_groups, S.in, owner->annot, c->samw, &pr_bytes, s);
+    per_read_device(S.d_recs, S.d_groups, S.n_groups, S.in, owner->annot, c->samw, &S.pr_bytes, s);
   }
+  HIPCHK(stream_wait(s));
+}
+// ... and everything copied to page-locked memory (outside the lanes' compute token: the copy engine's work)
+void sam_stage_fetch(kslam_ctx *c, SamStage &S, bool want_sam, bool want_per_read, char **sam_text, uint64_t *sam_len, char **pr_text,
+                     uint64_t *pr_len, uint32_t **tax, uint64_t *n_tax) {
+  hipStream_t s = c->stream;
+  const uint64_t text_bytes = S.text_bytes, pr_bytes = S.pr_bytes;
   char *ht = nullptr, *hp = nullptr;
   uint32_t *hx = nullptr;
   try {
@@ -1178,20 +1185,28 @@ void lane_main(kslam_ctx *primary, kslam_ctx::AsyncLane *lane) {
     }
     if (sam_planned) {
       sam_stage_mapq(sam);   // pow / log10 / ceil with the host's libm, outside the compute token
-      std::lock_guard<std::mutex> compute(primary->as_compute);
+      {
+        std::lock_guard<std::mutex> compute(primary->as_compute);
+        st = guarded(c, [&] { sam_stage_kernels(c, primary, sam, primary->samtext.sam, primary->samtext.per_read); });
+      }
       uint64_t n_tax = 0;
-      st = guarded(c, [&] {
-        sam_stage_write(c, primary, sam, primary->samtext.sam, primary->samtext.per_read, &job->sam_text, &job->sam_len, &job->pr_text,
-                        &job->pr_len, &job->tax, &n_tax);
-      });
+      if (st == KSLAM_OK)
+        st = guarded(c, [&] {
+          sam_stage_fetch(c, sam, primary->samtext.sam, primary->samtext.per_read, &job->sam_text, &job->sam_len, &job->pr_text, &job->pr_len,
+                          &job->tax, &n_tax);
+        });
       if (st == KSLAM_OK)
         job->text_flags = (primary->samtext.sam ? (KSLAM_TEXT_PAIRS_SORTED | KSLAM_TEXT_SAM) : 0u) | (primary->samtext.per_read ? KSLAM_TEXT_PER_READ : 0u);
     }
     sam_stage_free(c, sam);
     t3 = now();
-    if (st == KSLAM_OK) st = kslam_take_results(c, &job->out, &job->n_out, &job->pool, &job->n_cig);
+    // with the SAM records written on the device the host has no use for the rows, the CIGAR pool, the per-row details and
+    // the MD text (0.7 GB per batch of configs[1]): they stay where they are, only their counts travel
+    const bool text_sam = (job->text_flags & KSLAM_TEXT_SAM) != 0;
+    if (st == KSLAM_OK && !text_sam) st = kslam_take_results(c, &job->out, &job->n_out, &job->pool, &job->n_cig);
+    if (st == KSLAM_OK && text_sam) { job->n_out = c->n_res; job->n_cig = c->n_cig; }
     const double t4 = now();
-    if (st == KSLAM_OK && (job->qcat || job->fastq)) st = kslam_take_row_details(c, &job->det, &job->md, &job->n_md);
+    if (st == KSLAM_OK && (job->qcat || job->fastq) && !text_sam) st = kslam_take_row_details(c, &job->det, &job->md, &job->n_md);
     const double t5 = now();
     if (st == KSLAM_OK && primary->pairing.stages) st = kslam_take_pairs(c, &job->rp, &job->n_rp, &job->pr, &job->n_pr);
     if (dbg) fprintf(stderr, "[kslam]   align phases: extract %.2f sort %.2f join %.2f sw %.2f cigar %.2f total %.2f ms\n", c->tm.ms_extract,
@@ -1230,6 +1245,7 @@ void ensure_lanes(kslam_ctx *c) {
       throw StatusError{s1, msg};
     }
     lc->tune = c->tune;
+    lc->pw.pseudo_cap = (uint32_t)c->tune.pseudo_cap;
     share_index(lc, c);
     auto *l = new kslam_ctx::AsyncLane();
     l->c = lc;
@@ -1296,6 +1312,7 @@ kslam_status kslam_create(const kslam_params *params, kslam_ctx **out) {
   kslam_status st = guarded(c, [&] {
     validate_params(c->prm);
     c->tune = read_tuning();
+    c->pw.pseudo_cap = (uint32_t)c->tune.pseudo_cap;
     // while a context exists the FASTQ parser's big column blocks are page-locked (DMA-able as they stand)
     if (!c->tune.pageable_columns) {
       std::lock_guard<std::mutex> lk(hook_mutex());
@@ -1371,6 +1388,7 @@ kslam_status kslam_create_sibling(kslam_ctx *primary, kslam_ctx **out) {
     return st;
   }
   c->tune = primary->tune;
+  c->pw.pseudo_cap = (uint32_t)c->tune.pseudo_cap;
   share_index(c, primary);
   *out = c;
   return KSLAM_OK;
@@ -1403,7 +1421,8 @@ kslam_status kslam_reload_tuning(kslam_ctx *c) {
   const int lanes = c->lanes.empty() ? t.lanes : c->tune.lanes;   // the number of lanes is fixed once they exist
   c->tune = t;
   c->tune.lanes = lanes;
-  for (auto *l : c->lanes) l->c->tune = c->tune;
+  c->pw.pseudo_cap = (uint32_t)c->tune.pseudo_cap;
+  for (auto *l : c->lanes) { l->c->tune = c->tune; l->c->pw.pseudo_cap = (uint32_t)c->tune.pseudo_cap; }
   return KSLAM_OK;
 }
 
@@ -1868,8 +1887,9 @@ kslam_status kslam_sam_text(kslam_ctx *c, int paired, uint32_t num_alignments, i
     if ((per_read_text && !per_read_len) || (tax_ids && !n_tax_ids)) throw StatusError{KSLAM_ERR_ARG, "an output without its length"};
     sam_stage_plan(c, c, paired, num_alignments, sam_xa, sam_text != nullptr, S);
     sam_stage_mapq(S);
-    sam_stage_write(c, c, S, sam_text != nullptr, per_read_text != nullptr || tax_ids != nullptr, sam_text, sam_len, per_read_text,
-                    per_read_len, tax_ids, n_tax_ids);
+    const bool want_sam = sam_text != nullptr, want_pr = per_read_text != nullptr || tax_ids != nullptr;
+    sam_stage_kernels(c, c, S, want_sam, want_pr);
+    sam_stage_fetch(c, S, want_sam, want_pr, sam_text, sam_len, per_read_text, per_read_len, tax_ids, n_tax_ids);
   });
   if (c) sam_stage_free(c, S);
   return st;

@@ -596,7 +596,7 @@ static bool pseudo_on_records(Rec *recs, uint64_t n, bool from_groups, const ksl
   hipLaunchKernelGGL(k_run_longest, dim3((n_runs + 255) / 256), dim3(256), 0, s, W.count.as<uint32_t>(), n_runs, (uint32_t)n, d_longest);
   uint32_t longest = 0;
   read_back(&longest, d_longest, sizeof longest, s);
-  if (longest > PSEUDO_CAP_GLOBAL) return false;
+  if (longest > (W.pseudo_cap ? W.pseudo_cap : PSEUDO_CAP_GLOBAL)) return false;
   uint4 *work = const_cast<uint4 *>(sorted);
   hipLaunchKernelGGL(k_pseudo_entry<false>, dim3(n_runs), dim3(64), (size_t)std::min(longest, PSEUDO_CAP) * sizeof(PSpan), s, work,
                      W.count.as<uint32_t>(), n_runs, (uint32_t)n, recs);

@@ -48,16 +48,34 @@ struct CountSink {
   __device__ void lit(const char *, uint32_t k) { n += k; }
   __device__ void skip(uint32_t k) { n += k; }
 };
+// Bytes collect in a 64-bit register and leave as ONE 8-byte store (unaligned stores are fine on gfx950): a line of ~200
+// bytes is ~25 store instructions instead of ~200, and neighbouring threads' lines are neighbours in memory, so the stores
+// of a wave fall into a few hundred consecutive cache lines that L2 merges.
 struct ByteSink {
   uint8_t *w;
-  __device__ void ch(uint8_t c) { *w++ = c; }
-  __device__ void bytes(const uint8_t *s, uint64_t k) {
-    for (uint64_t i = 0; i < k; i++) w[i] = s[i];
-    w += k;
+  uint64_t acc = 0;
+  uint32_t k = 0;   // bytes waiting in acc
+  __device__ explicit ByteSink(uint8_t *at) : w(at) {}
+  __device__ void ch(uint8_t c) {
+    acc |= (uint64_t)c << (8 * k);
+    if (++k == 8) {
+      __builtin_memcpy(w, &acc, 8);
+      w += 8;
+      acc = 0;
+      k = 0;
+    }
   }
-  __device__ void lit(const char *s, uint32_t k) {
-    for (uint32_t i = 0; i < k; i++) w[i] = (uint8_t)s[i];
+  __device__ void bytes(const uint8_t *s, uint64_t n) {
+    for (uint64_t i = 0; i < n; i++) ch(s[i]);
+  }
+  __device__ void lit(const char *s, uint32_t n) {
+    for (uint32_t i = 0; i < n; i++) ch((uint8_t)s[i]);
+  }
+  __device__ void flush() {
+    for (uint32_t i = 0; i < k; i++) w[i] = (uint8_t)(acc >> (8 * i));
     w += k;
+    acc = 0;
+    k = 0;
   }
 };
 
@@ -75,12 +93,17 @@ template <>
 __device__ inline void put_num<CountSink>(CountSink &o, uint64_t v) { o.n += digits_u64(v); }
 template <>
 __device__ inline void put_num<ByteSink>(ByteSink &o, uint64_t v) {
-  const uint32_t d = digits_u64(v);
-  for (uint32_t k = d; k-- > 0;) {
-    o.w[k] = (uint8_t)('0' + v % 10);
-    v /= 10;
-  }
-  o.w += d;
+  // the digits most significant first, from a register: up to 8 digits per 64-bit word (numbers here are < 2^32: 10 digits)
+  uint32_t d = 0;
+  uint64_t lo = 0, hi = 0;   // digit j of the reversed number in byte j
+  do {
+    const uint64_t q = v / 10;
+    const uint64_t c = '0' + (v - q * 10);
+    if (d < 8) lo |= c << (8 * d); else hi |= c << (8 * (d - 8));
+    v = q;
+    d++;
+  } while (v);
+  for (uint32_t j = d; j-- > 0;) o.ch((uint8_t)((j < 8 ? lo >> (8 * j) : hi >> (8 * (j - 8))) & 0xFF));
 }
 template <class Sink>
 __device__ inline void put_snum(Sink &o, int64_t v) {
@@ -399,8 +422,9 @@ __global__ __launch_bounds__(256) void k_sam_write(const Rec *__restrict__ recs,
   if (g >= n_groups) return;
   const SamPlan pl = plan[g];
   if (!pl.n_rows) return;
-  ByteSink o{text + text_off[g]};
+  ByteSink o(text + text_off[g]);
   write_group(o, recs + groups[g].first, groups[g], pl, in, A, P, mapq_vals, val_off[g]);
+  o.flush();
 }
 
 // ---- per-read taxonomy: getLowestCommonAncestor over the read pair's entries (host/taxonomy.cpp: lca_ids) ----------
@@ -460,11 +484,12 @@ __global__ __launch_bounds__(256) void k_per_read_write(const kslam_read_pair *_
   const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= n_groups || !groups[g].count) return;
   const uint32_t r = groups[g].r1_read;
-  ByteSink o{text + off[g]};
+  ByteSink o(text + off[g]);
   o.bytes(in.ids + in.ids_off[r], in.ids_off[r + 1] - in.ids_off[r]);
   o.ch('\t');
   put_num(o, tax_ids[g]);
   o.ch('\n');
+  o.flush();
 }
 
 inline unsigned blocks_for(uint64_t n) { return (unsigned)((n + 255) / 256); }

@@ -367,3 +367,59 @@ def test_golden_slam_loop_through_the_abi(kslam, tmp_path, tag):
     db.close()
     report.close()
     tax.close()
+
+
+@pytest.mark.parametrize("route", ["host_text", "host_pseudo"])
+def test_stream_routes_that_leave_work_to_the_host(kslam, oracle, synth, tmp_path, monkeypatch, route):
+    """The batch loop's other routes, with its default TWO host threads (SAM text and taxonomy side by side):
+    host_text    KSLAM_HOST_SAM_TEXT=1: the device hands rows / details / pairs over and the CPUs format the text
+    host_pseudo  KSLAM_PSEUDO_CAP=50: the device declines pseudo-assembly (an entry holds more alignment pairs than the cap),
+                 so the batch comes back without text and the host runs pseudo-assembly + second screen + per-pair sort
+                 (kslam_tail_finish_prepare) BEFORE the text and the classification read the arrays
+    Both must write what the default route (everything on the GPU) writes, which the tests above hold against the oracle."""
+    import ctypes as C
+    D = importlib.import_module("kslam_amd.db")
+    T = importlib.import_module("kslam_amd.tail")
+    X = importlib.import_module("kslam_amd.taxonomy")
+    S = importlib.import_module("kslam_amd.stream")
+    n_pairs, per_batch = 2500, 900
+    dbdir, taxdb, rb, quals, ids, r1, r2 = _make_case(synth, tmp_path, n_pairs, b"\n", seed=909)
+    db = D.Database.load(dbdir / "database")
+    tax = X.TaxDB((dbdir / "taxDB").read_bytes())
+    h1, h2 = kslam.HostBuffer(len(r1) + 64), kslam.HostBuffer(len(r2) + 64)
+    h1.a[:len(r1)] = np.frombuffer(r1, dtype=np.uint8)
+    h2.a[:len(r2)] = np.frombuffer(r2, dtype=np.uint8)
+    P = T.TailParams.default(pseudo_assembly=True)
+    header = T.sam_header(db, b"SLAM --db db R1.fq R2.fq")
+    bases_pp, lens_p = db.entry_pointers()
+
+    def run(tag):
+        ctx = kslam.Context()
+        ctx._chk(ctx._L.kslam_set_index(ctx._h, db.n_entries, C.cast(bases_pp, C.c_void_p), C.cast(lens_p, C.c_void_p)))
+        report = X.Report()
+        sam_path, pr_path = str(tmp_path / (tag + ".sam")), str(tmp_path / (tag + "_PerRead"))
+        sam_fd = os.open(sam_path, os.O_RDWR | os.O_CREAT | os.O_TRUNC)
+        pr_fd = os.open(pr_path, os.O_RDWR | os.O_CREAT | os.O_TRUNC)
+        res = S.classify_stream_native(ctx, db, h1.ptr, len(r1), h2.ptr, len(r2), per_batch, P, taxdb=tax, report=report,
+                                       sam_fd=sam_fd, per_read_fd=pr_fd, sam_header=header)
+        os.close(sam_fd)
+        os.close(pr_fd)
+        xml = tax.report_xml(report, db, db.gene_extras(), res["n_pairs"])
+        report.close()
+        ctx.close()
+        return open(sam_path, "rb").read(), open(pr_path, "rb").read(), res["tax_ids"].tolist(), xml, res
+
+    base = run("gpu")
+    assert base[4]["batches_pseudo_on_host"] == 0 and base[0].count(b"\n") > 2 * n_pairs * 0.9
+    if route == "host_text":
+        monkeypatch.setenv("KSLAM_HOST_SAM_TEXT", "1")
+    else:
+        monkeypatch.setenv("KSLAM_PSEUDO_CAP", "50")
+    other = run(route)
+    if route == "host_pseudo":
+        assert other[4]["batches_pseudo_on_host"] == other[4]["n_batches"] == 3
+    assert other[0] == base[0] and other[1] == base[1] and other[2] == base[2] and other[3] == base[3]
+    h1.close()
+    h2.close()
+    db.close()
+    tax.close()

@@ -892,6 +892,15 @@ def main():
         sh_ctx = (ctx, ctx_b)
         sh_ms = {"align": 0.0, "pairing_gathers_pseudo": 0.0, "row_details": 0.0, "download_on_worker": 0.0, "host_sam_and_lca": 0.0}
         sh_out = {"moved": 0}
+        # the SAM records and per-read lines written on each rank's GPU (include/kslam_samtext.h); KSLAM_HOST_SAM_TEXT=1: on its CPUs
+        ST = importlib.import_module("kslam_amd.samtext")
+        device_text = os.environ.get("KSLAM_HOST_SAM_TEXT") != "1"
+        if device_text:
+            ids_u8, ids_off = rv_loc._keep[0], rv_loc._keep[1]
+            for c in sh_ctx:
+                ST.set_annotations(c, index_view, taxdb_s)
+                c._chk(ST.lib().kslam_load_read_ids(c._h, ids_u8.ctypes.data, ids_off.ctypes.data))
+            sh_ms["sam_text_on_gpu"] = 0.0
 
         def sh_host(ov, cg, det, md, rp, pr, pst, releases, fds):
             t1 = time.perf_counter()
@@ -904,7 +913,19 @@ def main():
             sh_out.update(sam_bytes=int(st.sam_bytes), per_read_lines=int(len(ids)), pseudo_on="gpu" if pst["stages_done"] & 4 else "host",
                           max_insert_size=int(pst["max_insert_size"]))
 
+        def sh_worker_device_text(c, pst, fds, downloaded, my_turn, next_turn):
+            # the text is written where the rows lie: nothing but the text (and the taxonomy ids) leaves the GPU
+            my_turn.wait()                                # blocks join the writer's queue in step order: one part file
+            t1 = time.perf_counter()
+            n_sam, n_pr, tax = ST.sam_text_to_files(c, fds[0], fds[1], paired=True, num_alignments=10, sam_xa=False, want_per_read=True)
+            sh_ms["sam_text_on_gpu"] += time.perf_counter() - t1
+            downloaded.set()
+            sh_out.update(sam_bytes=n_sam, per_read_lines=int(len(tax)), pseudo_on="gpu", max_insert_size=int(pst["max_insert_size"]))
+            next_turn.set()
+
         def sh_worker(c, pst, fds, downloaded, my_turn, next_turn):
+            if device_text and (pst["stages_done"] & 4):
+                return sh_worker_device_text(c, pst, fds, downloaded, my_turn, next_turn)
             mark("download starts")
             t1 = time.perf_counter()
             ov, cg, rel1 = c.take_results()
@@ -1008,6 +1029,10 @@ def main():
                 "host_threads_per_rank": host_threads, "cgroup_throttled_ms": None if thr0 is None or thr1 is None else round(thr1 - thr0, 1),
                 "max_insert_size": sh_out["max_insert_size"],
                 "part_files_in_rank_order_equal_rank0_files": bool(parts_ok)}
+            if os.environ.get("KSLAM_BENCH_KEEP_FILES"):      # debugging: the files side by side
+                import shutil
+                for pth in (sam_path, pr_path, part_sam, part_pr):
+                    shutil.copy(pth, os.path.join(os.environ["KSLAM_BENCH_KEEP_FILES"], os.path.basename(pth).replace(str(os.getpid()), "X")))
             for pth in (sam_path, pr_path):
                 os.unlink(pth)
             tail_ctx.close()

@@ -233,8 +233,8 @@ void *radix_sort(void *a, void *b, uint64_t n, int rec_words, const SortPass *pa
 // ---------------------------------------------------------------- join.hip
 struct GenomeIndexDev {
   const uint64_t *key;   // sorted genome k-mers
-  const uint32_t *meta;  // ID_isFromGB_RC
-  const uint32_t *off;   // offset
+  const uint2 *mo;       // {ID_isFromGB_RC, offset} of the key at the same position: ONE 8-byte gather per hit (two 4-byte
+                         // columns cost two cache lines per hit; the join is bound by the lines it touches, not by ALU work)
   const uint32_t *bucket;  // [2^bits + 1] lower bounds by top `bits` bits of the key
   uint32_t bucket_bits;
   uint32_t n;

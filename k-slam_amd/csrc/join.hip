@@ -15,11 +15,15 @@
 //     ties to an unstable sort.
 //
 // MI355X design: the reference re-sorts reads + genomes together every batch;
-// here the genome list is sorted once and stays in HBM (SoA: key / meta /
-// offset) with a 2^b-entry bucket table over the top key bits, so each sorted
-// read k-mer finds its genome run with two table reads plus a <= 5-step binary
-// search in a region its neighbours in the wavefront are touching too -- the
-// whole join is one streaming pass over both lists.  Output is a packed u64
+// here the genome list is sorted once and stays in HBM (a key column and a
+// {meta, offset} column) with a 2^b-entry bucket table over the top key bits.
+// The read side is NOT merged against it: after the membership filter only one
+// read k-mer in ten is left (25 M against 312 M genome keys per batch), so each
+// sorted survivor PROBES -- two table reads, the bucket's handful of keys in one
+// round trip, one 8-byte gather per hit -- in a region its neighbours in the
+// wavefront are touching too.  A merge would stream the whole 2.5 GB key column
+// per batch to use a tenth of it; the probe touches ~1.5 GB of cache lines (the
+// kernel is bound by lines touched: VALU 0.07 of peak).  Output is a packed u64
 // per overlap (read | entry | rel + bias | revcomp) so that the overlap sort is
 // a keys-only radix sort over just the populated bytes.
 #include "common.h"
@@ -178,7 +182,8 @@ __global__ __launch_bounds__(JB) void k_join_fill(const uint4 *__restrict__ recs
     for (uint32_t k = threadIdx.x; k < tot; k += JB) {
       const uint4 e = runq[owner[k]];
       const uint32_t gi = e.z + (k - e.w);
-      out[bb + k] = make_overlap(e.x, e.y, g.meta[gi], g.off[gi], read_len, lay);
+      const uint2 mo = g.mo[gi];
+      out[bb + k] = make_overlap(e.x, e.y, mo.x, mo.y, read_len, lay);
     }
     return;
   }
@@ -198,7 +203,8 @@ __global__ __launch_bounds__(JB) void k_join_fill(const uint4 *__restrict__ recs
     if (!queued) {
       for (uint32_t j = 0; j < c; j++) {
         const uint32_t gi = run[it].lo + j;
-        out[bb + ex + j] = make_overlap(r[it].z, r[it].w, g.meta[gi], g.off[gi], read_len, lay);
+        const uint2 mo = g.mo[gi];
+        out[bb + ex + j] = make_overlap(r[it].z, r[it].w, mo.x, mo.y, read_len, lay);
       }
     }
     ex += c;
@@ -210,7 +216,8 @@ __global__ __launch_bounds__(JB) void k_join_fill(const uint4 *__restrict__ recs
     const uint64_t ob = bb + bigq_out[q];
     for (uint32_t j = threadIdx.x; j < e.w; j += JB) {
       const uint32_t gi = e.z + j;
-      out[ob + j] = make_overlap(e.x, e.y, g.meta[gi], g.off[gi], read_len, lay);
+      const uint2 mo = g.mo[gi];
+      out[ob + j] = make_overlap(e.x, e.y, mo.x, mo.y, read_len, lay);
     }
   }
 }

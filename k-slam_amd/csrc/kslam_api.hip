@@ -337,14 +337,12 @@ __global__ void k_lens(const uint64_t *off, uint64_t n, uint32_t *len) {
   if (i < n) len[i] = (uint32_t)(off[i + 1] - off[i]);
 }
 
-__global__ void k_split_soa(const uint4 *__restrict__ recs, uint32_t n, uint64_t *__restrict__ key,
-                            uint32_t *__restrict__ meta, uint32_t *__restrict__ off) {
+__global__ void k_split_soa(const uint4 *__restrict__ recs, uint32_t n, uint64_t *__restrict__ key, uint2 *__restrict__ mo) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint4 r = recs[i];
   key[i] = ((uint64_t)r.y << 32) | r.x;
-  meta[i] = r.z;
-  off[i] = r.w;
+  mo[i] = make_uint2(r.z, r.w);
 }
 
 __global__ void k_fill_random(uint4 *recs, uint32_t n, uint64_t seed) {
@@ -442,11 +440,9 @@ void build_index(kslam_ctx *c) {
   void *sorted = radix_sort(c->recs_a.p, c->recs_b.p, m, 4, passes.data(), (int)passes.size(), c->sortws, s,
                             nullptr, nullptr, nullptr, /*setup=*/true);
   c->gk_key.ensure((m + 1) * sizeof(uint64_t));
-  c->gk_meta.ensure((m + 1) * sizeof(uint32_t));
-  c->gk_off.ensure((m + 1) * sizeof(uint32_t));
+  c->gk_meta.ensure((m + 1) * sizeof(uint2));   // {meta, offset} pairs
   if (m) hipLaunchKernelGGL(k_split_soa, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, (const uint4 *)sorted,
-                            (uint32_t)m, c->gk_key.as<uint64_t>(), c->gk_meta.as<uint32_t>(),
-                            c->gk_off.as<uint32_t>());
+                            (uint32_t)m, c->gk_key.as<uint64_t>(), c->gk_meta.as<uint2>());
   uint32_t bits = 8, max_bits = (uint32_t)c->tune.bucket_bits_max;   // 27: ~2.3 genome k-mers per bucket for a 5 Gb database (537 MB table)
   while (bits < max_bits && (m >> (bits + 2)) != 0) bits++;   // 2 to 4 keys per bucket (measured: 3.06 ms at 27 bits, 3.24 at 26, 3.13 at 28)
   if (c->tune.bucket_bits_exact) bits = (uint32_t)c->tune.bucket_bits_exact;   // tuning
@@ -573,7 +569,7 @@ void align_resident(kslam_ctx *c, bool stop_after_join, uint64_t *n_raw_out, Pai
   const uint64_t max_chunk_kmers = c->prm.max_kmers_per_chunk ? c->prm.max_kmers_per_chunk : (1ull << 30);
 
   GenomeIndexDev g;
-  g.key = c->gk_key.as<uint64_t>(); g.meta = c->gk_meta.as<uint32_t>(); g.off = c->gk_off.as<uint32_t>();
+  g.key = c->gk_key.as<uint64_t>(); g.mo = c->gk_meta.as<uint2>();
   g.bucket = c->g_bucket.as<uint32_t>(); g.bucket_bits = c->bucket_bits; g.n = (uint32_t)c->n_gk;
   SwInputs in;
   in.read_bases = c->r_bases.as<uint8_t>(); in.read_off = c->r_off.as<uint64_t>();

@@ -57,3 +57,32 @@ def sam_text(ctx, paired=True, num_alignments=10, sam_xa=False, want_sam=True, w
         if q.value:
             L.kslam_free_pinned(ctx._h, q)
     return sam, per, tax
+
+
+def sam_text_to_files(ctx, writer, per_read_fd, paired=True, num_alignments=10, sam_xa=False, want_per_read=True):
+    """kslam_sam_text with nothing copied through Python: the SAM block joins `writer`'s queue (a kslam_amd.tail.SamWriter;
+    kslam_sam_writer_enqueue with kslam_free_pinned itself as the release callback), the per-read lines are written to
+    per_read_fd straight from the page-locked block.  -> (sam bytes, per-read bytes, taxonomy ids as a numpy copy)"""
+    import os
+    L = lib()
+    L.kslam_sam_writer_enqueue.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    t, p, x = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    nt, np_, nx = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    ctx._chk(L.kslam_sam_text(ctx._h, int(paired), num_alignments, int(sam_xa), C.byref(t), C.byref(nt),
+                              C.byref(p) if want_per_read else None, C.byref(np_) if want_per_read else None,
+                              C.byref(x) if want_per_read else None, C.byref(nx) if want_per_read else None))
+    release = C.cast(L.kslam_free_pinned, C.c_void_p)          # void (*)(void *user = ctx, void *data)
+    if L.kslam_sam_writer_enqueue(writer._h, t, nt.value, release, ctx._h) != 0:
+        raise RuntimeError(L.kslam_tail_last_error().decode())
+    tax = None
+    if want_per_read:
+        if np_.value:
+            view = memoryview((C.c_char * np_.value).from_address(p.value))
+            done = 0
+            while done < np_.value:
+                done += os.write(per_read_fd, view[done:])
+        tax = np.frombuffer((C.c_char * (4 * nx.value)).from_address(x.value), dtype=np.uint32).copy() if nx.value else np.zeros(0, np.uint32)
+        for q in (p, x):
+            if q.value:
+                L.kslam_free_pinned(ctx._h, q)
+    return int(nt.value), int(np_.value), tax

@@ -282,6 +282,7 @@ struct SwParams {
   int32_t match, mismatch, gap_open, gap_extend;
   uint32_t score_threshold;
   int32_t report_cigar;
+  int32_t striped = 0;   // scoring outside the envelope: every candidate through k_sw_striped + the literal banded_sw
 #ifdef KSLAM_ABLATE
   uint32_t ablate = 0;   // KSLAM_SW_ABLATE (measurement only): 1 = no sweep, 2 = no staging either, 3 = one turn, result accepted
 #else

@@ -468,6 +468,8 @@ void build_index(kslam_ctx *c) {
   for (auto *l : c->lanes) share_index(l->c, c);   // (no batch may be in flight across kslam_set_index)
 }
 
+bool scoring_in_envelope(const kslam_params &p);
+
 void finish_load_reads(kslam_ctx *c) {
   hipStream_t s = c->stream;
   const uint64_t n = c->n_reads;
@@ -487,6 +489,7 @@ void finish_load_reads(kslam_ctx *c) {
   // 13-bit score field of the packed DP values (and v_max_f64 reading 8188 and above as NaN patterns), 9-bit row / column
   // fields of the origin key: reads beyond either go through the plain kernels, in chunks of their own
   c->short_cap = (uint32_t)std::min<uint64_t>(511, 8187 / std::max<uint64_t>(1, (uint64_t)c->prm.match + 2 * c->prm.gap_extend));
+  if (!scoring_in_envelope(c->prm)) c->short_cap = 0;   // scoring outside the envelope: every read is of the class the literal kernels take
   if (mx > 9000)
     throw StatusError{KSLAM_ERR_UNSUPPORTED, "reads longer than 9000 bases are not supported (read " + std::to_string(mx_at) +
                                                  " of the batch has " + std::to_string(mx) + ")"};
@@ -579,6 +582,7 @@ void align_resident(kslam_ctx *c, bool stop_after_join, uint64_t *n_raw_out, Pai
   sp.match = (int32_t)c->prm.match; sp.mismatch = (int32_t)c->prm.mismatch;
   sp.gap_open = (int32_t)c->prm.gap_open; sp.gap_extend = (int32_t)c->prm.gap_extend;
   sp.score_threshold = c->prm.score_threshold; sp.report_cigar = c->prm.report_cigar;
+  sp.striped = scoring_in_envelope(c->prm) ? 0 : 1;
 
   // The join looks every read k-mer up in the resident genome list (bucket table over the top
   // bucket_bits key bits + binary search), so the read list only has to be ordered as far as that
@@ -809,18 +813,18 @@ void align_resident(kslam_ctx *c, bool stop_after_join, uint64_t *n_raw_out, Pai
                                               " candidates hit the reference's 'Trace back error' path"};
 }
 
+// The scoring a context takes is what `SLAM --match-score / --mismatch-penalty / --gap-open / --gap-extend` takes
+// (src/main.cpp:44-55) as far as the reference's own types hold it: the Aligner stores the four as uint8_t, the score
+// matrix is int8_t (src/ssw_cpp.cpp:25-49).  Inside the ENVELOPE the fast kernels apply; outside it
+// every candidate goes through the literal striped kernel (sw.hip: k_sw_striped) and the literal banded_sw.
+bool scoring_in_envelope(const kslam_params &p) {
+  return p.match >= 1 && p.match <= 31 && p.mismatch <= 32 && p.gap_extend >= 1 && p.gap_extend < p.gap_open &&
+         p.mismatch <= p.gap_open + p.gap_extend;
+}
 void validate_params(const kslam_params &p) {
-  if (p.match == 0 || p.match > 31) throw StatusError{KSLAM_ERR_UNSUPPORTED, "match score must be in 1..31"};
-  if (p.mismatch > 32) throw StatusError{KSLAM_ERR_UNSUPPORTED, "mismatch penalty must be <= 32"};
+  if (p.match > 127 || p.mismatch > 127) throw StatusError{KSLAM_ERR_UNSUPPORTED, "match score and mismatch penalty must fit the reference's int8_t score matrix (<= 127)"};
   if (p.gap_open > 255 || p.gap_extend > 255) throw StatusError{KSLAM_ERR_UNSUPPORTED, "gap penalties must fit uint8_t (ssw_cpp.h Aligner)"};
-  if (p.gap_extend == 0 || p.gap_extend >= p.gap_open)
-    throw StatusError{KSLAM_ERR_UNSUPPORTED,
-                      "gap_extend must be in 1..gap_open-1: the reference's striped Lazy-F loop is layout "
-                      "dependent otherwise (DESIGN.md, 'scoring envelope')"};
-  if (p.mismatch > p.gap_open + p.gap_extend)
-    throw StatusError{KSLAM_ERR_UNSUPPORTED,
-                      "mismatch must be <= gap_open + gap_extend: the reference's striped kernel never refreshes "
-                      "E after Lazy-F, which is only unobservable inside this envelope (DESIGN.md)"};
+  if (p.match == 0) throw StatusError{KSLAM_ERR_UNSUPPORTED, "match score 0: no k-mer seed could ever score"};
   if (p.score_threshold > 65535) throw StatusError{KSLAM_ERR_UNSUPPORTED, "score_threshold must fit uint16_t (ssw_cpp.h Filter)"};
 }
 

@@ -252,7 +252,7 @@ __device__ inline void sw_epilogue(kslam_overlap *ov, uint64_t ci, bool have, in
     o.cigar_off = 0;
     uint32_t bw = 0;
     if (want) {
-      if (refLen == readLen && dsum == f.score) {
+      if (refLen == readLen && dsum == f.score && !p.striped) {   // (an envelope argument: a gap pair may beat a mismatch outside it)
         bw = 0x80000000u | (uint32_t)readLen;   // inline <n>M, no banded DP needed
         o.cigar_len = 1;
       } else {
@@ -924,6 +924,201 @@ __global__ __launch_bounds__(64) void k_sw_long(kslam_overlap *__restrict__ ov, 
   sw_epilogue<64, 1>(ov, ci, true, lane, L, f, sq, sw, p, band0);
 }
 
+// ---- scoring outside the envelope: the reference's striped kernels evaluated LITERALLY ------------------------------
+// Inside `1 <= gapE < gapO, mismatch <= gapO + gapE` the striped evaluation order of sw_sse2_byte / sw_sse2_word is not
+// observable and every kernel above computes a plain Gotoh recurrence.  Outside it the reference's answer depends on its
+// layout: the Lazy-F loop only EXTENDS F and E is never refreshed after the correction (src/ssw.c:274-305, 512-526), so a
+// candidate's score is what 16 (byte) or 8 (word) SSE lanes of segLen = ceil(readLen / lanes) cells each produce in that
+// order.  `SLAM --gap-open / --gap-extend` takes any value (src/main.cpp:44-55), so this kernel plays the lanes: one
+// wavefront per candidate, lane l < W is SSE lane l (the others idle), pvHStore / pvHLoad / pvE / pvHmax are LDS arrays of
+// segLen x W cells, the query profile is computed on the fly.  It follows oracle/kslam_oracle.c's striped_byte /
+// striped_word -- the restatement that tests/test_oracle.py holds to the real ssw.c on out-of-envelope scorings -- statement
+// by statement, and ssw_align's sequence (:870-923): byte pass, word pass when the byte pass saturates, reverse pass over
+// the reversed prefixes with `terminate = score1`.  Slow (~20 us of one wavefront per candidate) and exact.
+struct StripedEnd { int32_t score, ref, read; };
+
+template <int W>
+__device__ inline int32_t lanes_max(int32_t v, int32_t lane) {   // over SSE lanes 0 .. W-1, result in every lane
+  v = lane < W ? v : INT32_MIN;
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) v = max(v, __shfl_xor(v, m, 64));
+  return v;
+}
+__device__ inline void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ inline int32_t sat_u8(int32_t v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
+__device__ inline int32_t subs_u16(int32_t a, int32_t b) { return a > b ? a - b : 0; }          // on values in 0..65535
+__device__ inline int32_t adds_i16(int32_t a, int32_t b) { const int32_t v = a + b; return v > 32767 ? 32767 : (v < -32768 ? -32768 : v); }
+
+// sw_sse2_byte (BYTE) / sw_sse2_word over ref[0 .. refLen) in direction ref_dir against rd[0 .. readLen): sq_at(j) gives the
+// read code of profile position j, rf_at(i) the window code of column i.  HS / HL / EE / HM: LDS, segLen x W uint16 each.
+template <bool BYTE, typename ReadAt, typename RefAt>
+__device__ inline StripedEnd striped_pass(ReadAt rd_at, int32_t readLen, RefAt rf_at, int32_t refLen, int ref_dir, const SwParams &p,
+                                          int32_t bias, int32_t terminate, uint16_t *HS, uint16_t *HL, uint16_t *EE, uint16_t *HM,
+                                          int32_t lane) {
+  constexpr int W = BYTE ? 16 : 8;
+  const int32_t segLen = (readLen + W - 1) / W;
+  const bool on = lane < W;
+  const int32_t gO = p.gap_open, gE = p.gap_extend;
+  for (int32_t k = lane; k < segLen * W; k += 64) { HS[k] = 0; HL[k] = 0; EE[k] = 0; HM[k] = 0; }
+  wave_sync();
+  int32_t vMaxScore = 0, vMaxMark = 0;      // per SSE lane
+  int32_t best = 0;
+  int32_t end_read = readLen - 1, end_ref = BYTE ? -1 : 0;
+  int32_t begin = 0, end = refLen, step = 1;
+  if (ref_dir == 1) { begin = refLen - 1; end = -1; step = -1; }
+  auto score_of = [&](uint32_t rc, int32_t j) -> int32_t {   // qP_byte / qP_word: mat[ref][read[j]] (+ bias), padding bias / 0
+    if (j >= readLen) return BYTE ? bias : 0;
+    const uint32_t qc = rd_at(j);
+    const int32_t m = (qc > 3u || rc > 3u) ? 0 : (qc == rc ? p.match : -p.mismatch);
+    return BYTE ? (int32_t)(uint8_t)(int8_t)(m + bias) : m;
+  };
+  for (int32_t i = begin; i != end; i += step) {
+    int32_t vF = 0, vMaxColumn = 0;
+    int32_t vH = 0;
+    if (on && lane > 0) vH = HS[(segLen - 1) * W + lane - 1];   // pvHStore[segLen - 1] shifted by one lane
+    wave_sync();
+    { uint16_t *t = HL; HL = HS; HS = t; }
+    const uint32_t rc = rf_at(i);
+    for (int32_t j = 0; j < segLen; j++) {
+      if (on) {
+        const int32_t pv = score_of(rc, j + lane * segLen);
+        int32_t h;
+        if (BYTE) { h = sat_u8(vH + pv); h = sat_u8(h - bias); }
+        else h = adds_i16(vH, pv);
+        const int32_t e = EE[j * W + lane];
+        h = max(h, e);
+        h = max(h, vF);
+        vMaxColumn = max(vMaxColumn, h);
+        HS[j * W + lane] = (uint16_t)h;
+        const int32_t hg = BYTE ? sat_u8(h - gO) : subs_u16(h, gO);
+        int32_t ee = BYTE ? sat_u8(e - gE) : subs_u16(e, gE);
+        ee = max(ee, hg);
+        EE[j * W + lane] = (uint16_t)ee;
+        int32_t ff = BYTE ? sat_u8(vF - gE) : subs_u16(vF, gE);
+        ff = max(ff, hg);
+        vF = ff;
+        vH = HL[j * W + lane];
+      }
+    }
+    wave_sync();
+    if (BYTE) {   // Lazy_F, src/ssw.c:274-305
+      int32_t j = 0;
+      vH = on ? HS[lane] : 0;
+      { const int32_t up = __shfl_up(vF, 1, 64); vF = (on && lane > 0) ? up : 0; }
+      for (;;) {
+        const int32_t t = sat_u8(vF - sat_u8(vH - gO));
+        if (!__any(on && t != 0)) break;
+        if (on) {
+          vH = max(vH, vF);
+          vMaxColumn = max(vMaxColumn, vH);
+          HS[j * W + lane] = (uint16_t)vH;
+          vF = sat_u8(vF - gE);
+        }
+        j++;
+        if (j >= segLen) {
+          j = 0;
+          const int32_t up = __shfl_up(vF, 1, 64);
+          vF = (on && lane > 0) ? up : 0;
+        }
+        if (on) vH = HS[j * W + lane];
+      }
+    } else {      // Lazy_F, src/ssw.c:514-526: vMaxColumn is not refreshed here
+      bool done = false;
+      for (int k = 0; k < W && !done; k++) {
+        { const int32_t up = __shfl_up(vF, 1, 64); vF = (on && lane > 0) ? up : 0; }
+        for (int32_t j = 0; j < segLen; j++) {
+          bool mine = false;
+          if (on) {
+            int32_t h = HS[j * W + lane];
+            h = max(h, vF);
+            HS[j * W + lane] = (uint16_t)h;
+            const int32_t hg = subs_u16(h, gO);
+            vF = subs_u16(vF, gE);
+            mine = vF > hg;
+          }
+          if (!__any(mine)) { done = true; break; }
+        }
+      }
+    }
+    wave_sync();
+    // src/ssw.c:307-325 / :528-543
+    vMaxScore = max(vMaxScore, vMaxColumn);
+    const bool differs = __any(on && vMaxMark != vMaxScore);
+    bool stop = false;
+    if (differs) {
+      vMaxMark = vMaxScore;
+      const int32_t temp = lanes_max<W>(vMaxScore, lane);
+      if (temp > best) {
+        best = temp;
+        if (BYTE && best + bias >= 255) stop = true;   // overflow: the byte pass gives up (:318)
+        else {
+          end_ref = i;
+          for (int32_t k = lane; k < segLen * W; k += 64) HM[k] = HS[k];
+          wave_sync();
+        }
+      }
+    }
+    if (stop) break;
+    const int32_t colmax = lanes_max<W>(vMaxColumn, lane);
+    if (colmax == terminate) break;                    // :330 / :545
+  }
+  wave_sync();
+  // src/ssw.c:334-342 / :549-557: the smallest read index at which the end column holds the maximum
+  int32_t er = end_read;
+  for (int32_t k = lane; k < segLen * W; k += 64)
+    if ((int32_t)HM[k] == best) er = min(er, k / W + (k % W) * segLen);
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) er = min(er, __shfl_xor(er, m, 64));
+  StripedEnd r;
+  r.score = BYTE ? (best + bias >= 255 ? 255 : best) : best;
+  r.ref = end_ref;
+  r.read = er;
+  return r;
+}
+
+__global__ __launch_bounds__(64) void k_sw_striped(kslam_overlap *__restrict__ ov, uint64_t n, SwInputs in, SwParams p,
+                                                   uint32_t *__restrict__ band0, uint32_t lcap) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t striped_lds[];
+  const int32_t lane = threadIdx.x;
+  const uint64_t ci = blockIdx.x;
+  if (ci >= n) return;
+  const uint32_t cells = lcap + 16;   // segLen x W <= readLen + W - 1
+  uint16_t *HS = reinterpret_cast<uint16_t *>(striped_lds), *HL = HS + cells, *EE = HL + cells, *HM = EE + cells;
+  uint8_t *sq = reinterpret_cast<uint8_t *>(HM + cells), *sw = sq + ((lcap + 16) & ~15u);
+  int32_t L = 0, Wn = 0;
+  stage_candidate<64>(ov[ci], in, lane, sq, sw, &L, &Wn);
+  wave_sync();
+  PassResult f{0, 0, 0, 0, 0};
+  if (L > 0 && Wn > 0) {
+    const int32_t bias = max(p.mismatch, 0);   // |min(mat)|, src/ssw.c:819-822 (the matrix's only negative entry is -mismatch)
+    auto rd_fw = [&](int32_t j) -> uint32_t { return sq[j]; };
+    auto rf = [&](int32_t i) -> uint32_t { return sw[i]; };
+    StripedEnd b = striped_pass<true>(rd_fw, L, rf, Wn, 0, p, bias, 255 /* (uint8_t)-1 */, HS, HL, EE, HM, lane);
+    bool word = false;
+    if (b.score == 255) {   // :873-877
+      b = striped_pass<false>(rd_fw, L, rf, Wn, 0, p, 0, 65535 /* (uint16_t)-1 */, HS, HL, EE, HM, lane);
+      word = true;
+    }
+    if (b.score > 0) {
+      f.score = b.score;
+      f.end_col = b.ref;
+      f.end_row = b.read;
+      // reverse pass (:906-923): the read prefix reversed, the window prefix scanned right to left, stop at score1
+      const int32_t q_last = b.read;
+      auto rd_rv = [&](int32_t j) -> uint32_t { return sq[q_last - j]; };
+      const StripedEnd r = word ? striped_pass<false>(rd_rv, b.read + 1, rf, b.ref + 1, 1, p, 0, b.score, HS, HL, EE, HM, lane)
+                                : striped_pass<true>(rd_rv, b.read + 1, rf, b.ref + 1, 1, p, bias, b.score, HS, HL, EE, HM, lane);
+      f.beg_col = r.ref;
+      f.beg_row = b.read - r.read;
+    }
+  }
+  sw_epilogue<64, 1>(ov, ci, true, lane, L, f, sq, sw, p, band0);
+}
+
 void encode_bases(const uint8_t *d_src, uint8_t *d_dst, uint64_t n, hipStream_t s) {
   const uint64_t n16 = (n + 15) / 16;   // both arrays carry 64 bytes of slack
   if (n16) hipLaunchKernelGGL(k_encode, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, s,
@@ -941,6 +1136,18 @@ void sw_scores(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, uint32_
     if (lds > 160 * 1024) throw StatusError{KSLAM_ERR_UNSUPPORTED, "reads longer than 9000 bases are not supported"};
     if (lds > 64 * 1024)
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sw_long), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (p.striped) {   // scoring outside the envelope: the reference's striped evaluation, literally
+      const size_t lds2 = (size_t)4 * (lcap + 16) * sizeof(uint16_t) + 2 * ((size_t)lcap + 16);
+      if (lds2 > 64 * 1024)
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sw_striped), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+      for (uint64_t lo = 0; lo < n; lo += 1u << 30) {
+        const uint64_t m = std::min<uint64_t>(n - lo, 1u << 30);
+        hipLaunchKernelGGL(k_sw_striped, dim3((unsigned)m), dim3(64), lds2, s, d_ov + lo, m, in, p, d_band0 + lo, lcap);
+      }
+      HIPCHK(hipGetLastError());
+      if (n_full_out) *n_full_out = n;
+      return;
+    }
     for (uint64_t lo = 0; lo < n; lo += 1u << 30) {
       const uint64_t m = std::min<uint64_t>(n - lo, 1u << 30);
       hipLaunchKernelGGL(k_sw_long, dim3((unsigned)m), dim3(64), lds, s, d_ov + lo, m, in, p, d_band0 + lo, lcap);

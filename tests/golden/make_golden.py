@@ -215,8 +215,11 @@ def make_join_and_align_vectors():
     print("join_vectors.npz: %d records, %d raw, %d deduped, %d revComp ties" % (len(srt), len(raw), len(dedup), len(ties)))
 
     out = {}
-    for params in ((2, 3, 5, 2), (1, 4, 6, 1)):
-        cases = make_align_cases(777 + params[0], 250)
+    # two scorings inside the envelope, three outside it (the striped evaluation order decides there: src/ssw.c:274-305, 512-526)
+    param_sets = ((2, 3, 5, 2), (1, 4, 6, 1), (2, 9, 5, 2), (5, 4, 10, 10), (2, 8, 2, 3))
+    out["param_sets"] = np.array(param_sets, dtype=np.int32)
+    for params in param_sets:
+        cases = make_align_cases(777 + params[0] + 10 * params[1], 250 if params in param_sets[:2] else 120)
         tag = "p%d%d%d%d" % params
         out[tag + "_query"], out[tag + "_query_off"] = _cols([c[0] for c in cases])
         out[tag + "_ref"], out[tag + "_ref_off"] = _cols([c[1] for c in cases])
@@ -234,7 +237,7 @@ def make_join_and_align_vectors():
             out[k + "_cigars"] = np.concatenate(cigs) if cigs else np.zeros(0, np.uint32)
             out[k + "_cigar_len"] = np.array([len(c) for c in cigs], dtype=np.int32)
     np.savez_compressed(os.path.join(HERE, "align_vectors.npz"), **out)
-    print("align_vectors.npz: 2 x 250 cases x 3 filter settings")
+    print("align_vectors.npz: %d scorings x 3 filter settings" % len(param_sets))
 
 
 def make_slam_loop():

@@ -333,9 +333,32 @@ def test_empty_batch(kslam, synth):
     assert len(ov) == 0 and len(cg) == 0
 
 
-def test_unsupported_scoring_fails_loudly(kslam):
-    with pytest.raises(kslam.KslamError):
-        kslam.Context(gap_open=2, gap_extend=3)
+def test_scoring_the_reference_types_cannot_hold_fails_loudly(kslam):
+    """match / mismatch beyond the int8_t score matrix, gap penalties beyond the Aligner's uint8_t (src/ssw_cpp.cpp:25-49,
+    src/ssw_cpp.h), match 0"""
+    for kw in ({"match": 128}, {"mismatch": 128}, {"gap_open": 256}, {"gap_extend": 300, "gap_open": 301}, {"match": 0}):
+        with pytest.raises(kslam.KslamError):
+            kslam.Context(**kw)
+
+
+@pytest.mark.parametrize("scoring", [(2, 9, 5, 2), (5, 4, 10, 10), (2, 8, 2, 3), (1, 1, 1, 1), (3, 7, 4, 4)])
+def test_scoring_outside_the_envelope_equals_the_striped_reference(kslam, oracle, synth, scoring):
+    """`SLAM --gap-open / --gap-extend` takes any value (src/main.cpp:44-55).  Outside `gapE < gapO, mismatch <= gapO + gapE`
+    the reference's answer depends on its striped evaluation order (Lazy-F only extends, E is not refreshed:
+    src/ssw.c:274-305, 512-526); such contexts run every candidate through k_sw_striped (the SSE lanes played literally)
+    and the literal banded_sw.  Against the oracle's striped emulation, which tests/test_oracle.py holds to the real ssw.c on
+    these very scorings: every row field and CIGAR word."""
+    m, x, go, ge = scoring
+    genomes = synth.make_genomes(91, 2, 3, 12000, strain_sub=0.03, strain_indel=0.002, shared_segment=1500)
+    reads, _ = synth.make_paired_reads(92, genomes, 350, read_len=120, sub_rate=0.03, indel_rate=0.01, n_rate=0.003, edge_frac=0.1)
+    rb, gb = synth.to_bytes(reads), synth.to_bytes(genomes)
+    rb += [b"", b"ACGT" * 10, gb[0][100:131]]
+    for thr in (0, 2 * m * 20):
+        got, gcig = kslam.align_to_database(rb, gb, match=m, mismatch=x, gap_open=go, gap_extend=ge, score_threshold=thr)
+        exp, ecig, _ = oracle.align_to_database(rb, gb, oracle.Params.default(match=m, mismatch=x, gap_open=go, gap_extend=ge,
+                                                                              score_threshold=thr))
+        assert len(exp) > 800
+        _compare_alignments(got, gcig, exp, ecig)
 
 
 # ---------------------------------------------------------------------------
@@ -468,7 +491,8 @@ def test_golden_align_vectors_through_the_abi(kslam):
     answer is the recorded one.  ASCII incl. lower case / U / IUPAC on both sides; thresholded and disabled CIGAR."""
     z = np.load(os.path.join(GOLD, "align_vectors.npz"))
     checked = 0
-    for params in ((2, 3, 5, 2), (1, 4, 6, 1)):
+    assert len(z["param_sets"]) == 5          # two scorings inside the envelope, three outside it (k_sw_striped)
+    for params in (tuple(int(v) for v in ps) for ps in z["param_sets"]):
         tag = "p%d%d%d%d" % params
         qs, rs, ns = _cols(z, tag + "_query"), _cols(z, tag + "_ref"), z[tag + "_ref_len"]
         for thr, want in ((0, 1), (120, 1), (0, 0)):

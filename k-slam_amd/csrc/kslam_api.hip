@@ -189,6 +189,7 @@ Tuning read_tuning() {
   t.lane_waits_yield = starts("KSLAM_LANE_WAITS", 'y');
   t.pageable_columns = flag("KSLAM_PAGEABLE_COLUMNS");
   t.pseudo_cap = std::max(0, num("KSLAM_PSEUDO_CAP", 0));
+  t.details_in_token = !starts("KSLAM_DETAILS_IN_TOKEN", '0');
 #ifdef KSLAM_ABLATE
   t.sw_ablate = (uint32_t)num("KSLAM_SW_ABLATE", 0);
   t.cigar_variant = (uint32_t)num("KSLAM_CIGAR_VARIANT", 0);
@@ -1148,7 +1149,8 @@ void lane_main(kslam_ctx *primary, kslam_ctx::AsyncLane *lane) {
     if (!job->borrowed) pinned_put(c, job->cat);
     job->cat = nullptr;
     SamStage sam;
-    bool sam_planned = false;
+    bool sam_planned = false, text_wanted = false, details_wanted = false;
+    auto want_details_or_no_cigar = [](kslam_ctx *cc, bool wd) { return wd || !cc->prm.report_cigar; };
     if (st == KSLAM_OK) {
       // one lane computes at a time: the kernels of a batch fill the chip, so two batches computing at
       // once only time-slice -- and, worse, fall into step, both lanes copying while the GPU idles and
@@ -1167,28 +1169,36 @@ void lane_main(kslam_ctx *primary, kslam_ctx::AsyncLane *lane) {
         else st = kslam_pair_screen(c, primary->pairing.paired, primary->pairing.thr, primary->pairing.fraction,
                                     primary->pairing.stages, &job->pstats);
       }
-      // the per-row walk after the pairing: only the rows the surviving alignment pairs refer to need it
-      if (st == KSLAM_OK && want_details)
+      details_wanted = st == KSLAM_OK && want_details;
+      text_wanted = st == KSLAM_OK && want_details_or_no_cigar(c, want_details);
+      if (details_wanted && primary->tune.details_in_token) {   // default; KSLAM_DETAILS_IN_TOKEN=0 moves it out (measured: 40.5 against 43.1 M reads/s)
         st = primary->pairing.stages ? kslam_row_details_of_pairs(c, nullptr) : kslam_row_details(c, nullptr);
-      // the SAM records / per-read lines on the device (kslam_set_sam_text), first half: the reference's per-pair sort (in
-      // place: the pairs go back to the host in that order), the rows to report, the log-probabilities the host evaluates.
-      // Not for a batch whose pseudo-assembly the device left to the host: its scores are not final yet.
-      const bool text_on = primary->samtext.sam || primary->samtext.per_read;
-      const bool pseudo_left = (primary->pairing.stages & 4u) && !(job->pstats.stages_done & 4u);
-      if (st == KSLAM_OK && text_on && primary->pairing.stages && c->have_ids && !pseudo_left &&
-          (want_details || !c->prm.report_cigar)) {
-        st = guarded(c, [&] {
-          sam_stage_plan(c, primary, primary->pairing.paired, primary->samtext.num_alignments, primary->samtext.sam_xa, primary->samtext.sam, sam);
-        });
-        sam_planned = st == KSLAM_OK;
+        details_wanted = false;
+        if (st != KSLAM_OK) text_wanted = false;
       }
     }
+    // (KSLAM_DETAILS_IN_TOKEN=0, A/B: the per-row walk outside the token as well -- slower: its 150-byte windows of the index
+    // compete with the other lane's staging for L2)
+    if (details_wanted) {
+      st = primary->pairing.stages ? kslam_row_details_of_pairs(c, nullptr) : kslam_row_details(c, nullptr);
+      if (st != KSLAM_OK) text_wanted = false;
+    }
+    // The SAM records / per-read lines on the device (kslam_set_sam_text): the reference's per-pair sort (in place: the pairs
+    // go back to the host in that order), the rows to report, the log-probabilities the host evaluates with its libm, then the
+    // text.  OUTSIDE the compute token: these kernels are bound by the latency of dependent gathers (samtext.hip), not by
+    // ALU work or bandwidth, so they run next to the other lane's alignment kernels instead of in front of them.
+    // Not for a batch whose pseudo-assembly the device left to the host: its scores are not final yet.
+    const bool text_on = primary->samtext.sam || primary->samtext.per_read;
+    const bool pseudo_left = (primary->pairing.stages & 4u) && !(job->pstats.stages_done & 4u);
+    if (text_wanted && text_on && primary->pairing.stages && c->have_ids && !pseudo_left) {
+      st = guarded(c, [&] {
+        sam_stage_plan(c, primary, primary->pairing.paired, primary->samtext.num_alignments, primary->samtext.sam_xa, primary->samtext.sam, sam);
+      });
+      sam_planned = st == KSLAM_OK;
+    }
     if (sam_planned) {
-      sam_stage_mapq(sam);   // pow / log10 / ceil with the host's libm, outside the compute token
-      {
-        std::lock_guard<std::mutex> compute(primary->as_compute);
-        st = guarded(c, [&] { sam_stage_kernels(c, primary, sam, primary->samtext.sam, primary->samtext.per_read); });
-      }
+      sam_stage_mapq(sam);   // pow / log10 / ceil with the host's libm
+      st = guarded(c, [&] { sam_stage_kernels(c, primary, sam, primary->samtext.sam, primary->samtext.per_read); });
       uint64_t n_tax = 0;
       if (st == KSLAM_OK)
         st = guarded(c, [&] {

@@ -391,10 +391,12 @@ def e2e_leg(K, ctx, files, pairs_per_batch, index_view, taxdb, steps, warmup, ps
             "driver": "kslam_stream_classify (include/kslam_stream.h: the loop inside the library)" if native else "k-slam_amd/stream.py",
             "what": "FASTQ text (two files' worth, page-locked host memory) -> kslam_fastq_batch_end (batch boundaries) -> "
                     "kslam_submit_batch_fastq_text (GPU: FASTQ record index, alignToDatabase, score screen / pairing / insert-size "
-                    "statistics / screens%s, per-row NM / MD / log-probability; %d batches in flight) -> kslam_collect_batch -> "
-                    "kslam_tail_finish_write_rows -> kslam_sam_writer (background write() into the SAM file) and, on a second host thread at the "
-                    "same time (native driver), kslam_tail_classify (per-read LCA) -> <out>_PerRead file + kslam_taxreport_add_batch; wall clock "
-                    "of the K steps incl. pipeline fill and drain"
+                    "statistics / screens%s, per-row NM / MD / log-probability, the per-pair sort, the SAM records and the <out>_PerRead lines "
+                    "with the per-read LCA (include/kslam_samtext.h; the mapping qualities' pow / log10 on the host's libm in between); %d "
+                    "batches in flight) -> kslam_collect_batch -> the page-locked SAM block to kslam_sam_writer (background write() into the "
+                    "SAM file), the per-read block to its file, kslam_taxreport_add_batch on a second host thread; wall clock of the K steps "
+                    "incl. pipeline fill and drain.  host_ms_per_batch.sam_text is what is left of the SAM stage on the CPUs (handing the "
+                    "block over); KSLAM_HOST_SAM_TEXT=1 brings the CPU formatter back (A/B)"
                     % (" / pseudo-assembly / second screen" if pseudo else "", 3),
         }
         return out

@@ -242,13 +242,22 @@ struct ByScoreDesc {
 
 // screenPairedAlignmentsByInsertSize(replace = true) then screenPairedAlignmentsByScore on one read
 // pair's records (host/tail.cpp: insert_screen, score_screen)
+// Read pairs with more than SCREEN_BIG alignment pairs (reads in rRNA-like repeats pair up on every genome of the database:
+// thousands) are left to k_screen_big: one thread sorting thousands of records while its 63 neighbours wait made this kernel
+// 55 ms of a 130 ms step on the repeat-rich database.
+constexpr uint32_t SCREEN_BIG = 96;
 __global__ __launch_bounds__(256) void k_screen(const kslam_overlap *__restrict__ ov, Rec *__restrict__ recs,
                                                 const uint64_t *__restrict__ base, uint32_t *__restrict__ count,
                                                 uint64_t units, int do_insert, uint32_t limit, int do_score,
-                                                double fraction, uint32_t *__restrict__ flags) {
+                                                double fraction, uint32_t *__restrict__ flags, uint32_t *__restrict__ big_list,
+                                                uint32_t *__restrict__ n_big) {
   const uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (u >= units) return;
   uint32_t n = count[u];
+  if (n > SCREEN_BIG && (do_insert || do_score)) {   // a wavefront's job: flags[u] and count[u] come from k_screen_big
+    big_list[atomicAdd(n_big, 1u)] = (uint32_t)u;
+    return;
+  }
   if (n) {
     Rec *v = recs + base[u];
     if (do_insert) {
@@ -288,6 +297,67 @@ __global__ __launch_bounds__(256) void k_screen(const kslam_overlap *__restrict_
     count[u] = n;
   }
   flags[u] = n ? 1u : 0u;
+}
+
+// The same two screens for ONE big read pair by one wavefront: both std::sorts with libstdc++'s permutation produced by the
+// 64 lanes together (wave_gnu_sort.h), the split of the records beyond the insert-size limit and the cut of the score
+// screen lane-parallel.  Statement for statement what the thread above does.
+__global__ __launch_bounds__(64) void k_screen_big(const kslam_overlap *__restrict__ ov, Rec *__restrict__ recs,
+                                                   const uint64_t *__restrict__ base, uint32_t *__restrict__ count,
+                                                   const uint32_t *__restrict__ big_list, int do_insert, uint32_t limit, int do_score,
+                                                   double fraction, uint32_t *__restrict__ flags) {
+  __shared__ kslam_gnu::WaveSortLds S;
+  const uint32_t u = big_list[blockIdx.x], lane = threadIdx.x;
+  uint32_t n = count[u];
+  Rec *v = recs + base[u];
+  if (do_insert) {
+    kslam_gnu::wave_sort(v, n, ByInsert(), S);
+    __syncthreads();
+    // cut = the first record beyond the limit (the records are sorted by insert size)
+    uint32_t mine = n;
+    for (uint32_t i = lane; i < n; i += 64)
+      if (v[i].insert_size > limit) { mine = i; break; }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) mine = min(mine, (uint32_t)__shfl_xor((int)mine, m, 64));
+    const uint32_t cut = mine;
+    for (uint32_t i = cut + lane; i < n; i += 64) {   // record i becomes its R2 half, its R1 half is appended at n + (i - cut)
+      const kslam_overlap &o1 = ov[v[i].r1], &o2 = ov[v[i].r2];
+      Rec r;
+      r.combined_score = o1.score;
+      r.entry = v[i].entry;
+      r.ref_start = o1.ref_begin;
+      r.ref_end = o1.ref_end;
+      r.insert_size = 0;
+      r.r1 = v[i].r1;
+      r.r2 = NONE;
+      r.pad = 0;
+      v[n + (i - cut)] = r;
+      Rec &c = v[i];
+      c.combined_score = o2.score;
+      c.insert_size = 0;
+      c.r1 = NONE;
+      c.ref_start = o2.ref_begin;
+      c.ref_end = o2.ref_end;
+    }
+    n += n - cut;
+    __syncthreads();
+  }
+  if (do_score) {
+    kslam_gnu::wave_sort(v, n, ByScoreDesc(), S);
+    __syncthreads();
+    const unsigned top = v[0].combined_score;
+    const double bar = top * fraction;
+    uint32_t mine = n;   // the first record under the bar (sorted by score, descending)
+    for (uint32_t i = lane; i < n; i += 64)
+      if ((double)v[i].combined_score < bar) { mine = i; break; }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) mine = min(mine, (uint32_t)__shfl_xor((int)mine, m, 64));
+    n = mine;
+  }
+  if (lane == 0) {
+    count[u] = n;
+    flags[u] = n ? 1u : 0u;
+  }
 }
 
 __global__ __launch_bounds__(256) void k_emit_groups(const Rec *__restrict__ recs, const uint64_t *__restrict__ base,
@@ -765,9 +835,18 @@ void pair_phase_b(const kslam_overlap *d_ov, uint32_t limit, double score_fracti
   const unsigned nb = (unsigned)((units + 255) / 256);
   if (do_insert && paired) res->max_insert_size = limit;
   else limit = 0xFFFFFFFFu;
+  W.picked.ensure((units + 1) * sizeof(uint32_t));        // the big read pairs' numbers (free at this point of the stage)
+  uint32_t *d_nbig = reinterpret_cast<uint32_t *>(tot + 10);
+  HIPCHK(hipMemsetAsync(d_nbig, 0, sizeof(uint64_t), s));
   hipLaunchKernelGGL(k_screen, dim3(nb), dim3(256), 0, s, d_ov, W.recs.as<Rec>(), W.base.as<uint64_t>(),
                      W.count.as<uint32_t>(), units, (do_insert && paired) ? 1 : 0, limit, do_score ? 1 : 0, score_fraction,
-                     W.flags.as<uint32_t>());
+                     W.flags.as<uint32_t>(), W.picked.as<uint32_t>(), d_nbig);
+  uint32_t n_big = 0;
+  read_back(&n_big, d_nbig, sizeof n_big, s);
+  if (n_big)
+    hipLaunchKernelGGL(k_screen_big, dim3(n_big), dim3(64), 0, s, d_ov, W.recs.as<Rec>(), W.base.as<uint64_t>(), W.count.as<uint32_t>(),
+                       W.picked.as<uint32_t>(), (do_insert && paired) ? 1 : 0, limit, do_score ? 1 : 0, score_fraction,
+                       W.flags.as<uint32_t>());
   exclusive_scan_u32(W.flags.as<uint32_t>(), W.gpos.as<uint32_t>(), units, tot + 8, W.scan_tmp.p, s);
   exclusive_scan_u32_to_u64(W.count.as<uint32_t>(), W.rpos.as<uint64_t>(), units, tot + 9, W.scan_tmp.p, s);
   uint64_t g2[2];

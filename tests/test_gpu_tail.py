@@ -31,13 +31,15 @@ def ctx(kslam):
 @pytest.mark.parametrize("seed,paired,thr,frac,stages,per_read", [
     (1, True, 0, 0.95, 3, 3.0), (2, True, 150, 0.8, 3, 3.0), (3, True, 0, 0.95, 1, 3.0), (4, True, 0, 0.95, 2, 3.0),
     (5, False, 0, 0.95, 3, 3.0), (6, False, 160, 0.95, 2, 3.0), (7, True, 0, 0.95, 3, 30.0), (8, True, 0, 1.0, 3, 12.0),
-    (9, True, 0, 0.5, 0, 3.0), (10, True, 250, 0.95, 3, 3.0)])
+    (9, True, 0, 0.5, 0, 3.0), (10, True, 250, 0.95, 3, 3.0),
+    # read pairs of hundreds to thousands of alignment pairs (reads in repeats): one wavefront per read pair (k_screen_big)
+    (11, True, 0, 0.95, 3, 150.0), (12, True, 0, 0.6, 3, 400.0), (13, False, 0, 0.9, 2, 300.0), (14, True, 0, 0.95, 1, 250.0)])
 def test_device_pairing_and_screens_equal_the_host_tail(kslam, T, ctx, seed, paired, thr, frac, stages, per_read):
     """random overlap records full of score ties (read pairs with up to ~100 records reach the introsort
     part of std::sort): read pairs and alignment pairs equal kslam_tail_pairs', byte for byte"""
     from test_tail import _fuzz_overlaps
     rng = np.random.default_rng(100 + seed)
-    n_units = 4000 if per_read < 10 else 700
+    n_units = 4000 if per_read < 10 else (700 if per_read < 100 else 120)
     ov, n_reads = _fuzz_overlaps(kslam, rng, n_units, 12, per_read=per_read, paired=paired)
     if seed == 7:      # far-apart pairs: a spike in the insert-size ladder (the `limit` branch of the statistics)
         far = rng.random(len(ov)) < 0.03

@@ -1,6 +1,9 @@
 // tail_bench.cpp -- host-only timing of the tail (include/kslam_tail.h) on synthetic overlaps.
 //   g++ -O3 -std=c++17 -pthread tools/tail_bench.cpp k-slam_amd/host/tail.cpp -o /tmp/tail_bench
-//   /tmp/tail_bench [n_pairs] [threads] [iters] [mode: 0 = one malloc'ed text, 1 = writer callback]
+//   /tmp/tail_bench [n_pairs] [threads] [iters] [mode: 0 = one malloc'ed text, 1 = writer callback,
+//                    2 = the batch loop's host stage (host/stream.cpp): kslam_tail_finish_prepare, THEN the SAM text and the
+//                        classification side by side on two threads, read pairs of up to 24 alignment pairs -- the shape
+//                        tools/sanitize_host.sh runs under TSan (link host/taxonomy.cpp as well)]
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -10,7 +13,9 @@
 #include <string>
 #include <vector>
 
-#include "../include/kslam_tail.h"
+#include <thread>
+
+#include "../include/kslam_taxonomy.h"
 
 int main(int argc, char **argv) {
   const uint64_t n_pairs = argc > 1 ? strtoull(argv[1], 0, 10) : 500000;
@@ -24,7 +29,8 @@ int main(int argc, char **argv) {
     kslam_overlap o;
     memset(&o, 0, sizeof o);
     o.read = read; o.entry = entry; o.rel = rel; o.revcomp = rc;
-    o.score = 250 + rng() % 50; o.ref_begin = std::max(rel, 0); o.ref_end = o.ref_begin + L - 1;
+    o.score = mode == 2 ? 290 : 250 + rng() % 50;   // mode 2: ties, so that the screens leave large groups
+    o.ref_begin = std::max(rel, 0); o.ref_end = o.ref_begin + L - 1;
     o.query_begin = 0; o.query_end = L - 1;
     o.cigar_off = pool.size(); o.cigar_len = 1; pool.push_back(L << 4);
     ov.push_back(o);
@@ -34,6 +40,7 @@ int main(int argc, char **argv) {
       std::mt19937_64 pr(p * 977 + 1);
       uint32_t e = pr() % n_entries; int32_t pos = pr() % 7000; bool flip = pr() & 1;
       int extra = (pr() % 4 == 0) ? 1 + pr() % 2 : 0;
+      if (mode == 2 && pr() % 8 == 0) extra = 17 + pr() % 7;   // read pairs of more than 16 alignment pairs: introsort really moves records
       std::vector<std::pair<uint32_t, int32_t>> hits{{e, pos}};
       for (int k = 0; k < extra; k++) hits.push_back({(uint32_t)((e + 1 + k) % n_entries), pos});
       std::sort(hits.begin(), hits.end());
@@ -72,6 +79,38 @@ int main(int argc, char **argv) {
   iv.locus_tag = loc.data(); iv.locus_tag_off = loff.data(); iv.taxonomy_id = tax.data();
   kslam_tail_params P{0, 10, 0.95, 1, 0, 1, 1, 0, threads};
   printf("%zu overlaps, %llu pairs\n", ov.size(), (unsigned long long)n_pairs);
+  if (mode == 2) {
+    const char *taxtext = "1\n1\nroot\nno rank\n9\n1\nx\nspecies\n";
+    kslam_taxdb *db = nullptr;
+    if (kslam_taxdb_parse(taxtext, strlen(taxtext), &db)) { printf("taxdb: %s\n", kslam_tail_last_error()); return 1; }
+    for (int it = 0; it < iters; it++) {
+      kslam_tail_params front = P;
+      front.pseudo_assembly = 0;
+      front.stages = 3;
+      kslam_read_pair *rp; kslam_paired_overlap *pr; uint64_t nrp, npr;
+      if (kslam_tail_pairs(&front, &rv, ov.data(), ov.size(), &rp, &nrp, &pr, &npr, nullptr)) { printf("pairs: %s\n", kslam_tail_last_error()); return 1; }
+      kslam_tail_params all = P;              // pseudo-assembly on the host + second screen + per-pair sort: everything that mutates
+      if (kslam_tail_finish_prepare(&all, &rv, ov.data(), ov.size(), rp, nrp, pr, npr, 1, nullptr)) { printf("prepare: %s\n", kslam_tail_last_error()); return 1; }
+      kslam_tail_params ro = P;
+      ro.pseudo_assembly = 0;
+      ro.stages = 7u | KSLAM_TAIL_GROUPS_SORTED;
+      uint64_t bytes = 0, biggest = 0;
+      for (uint64_t g = 0; g < nrp; g++) biggest = std::max<uint64_t>(biggest, rp[g].count);
+      std::vector<uint32_t> ids(nrp + 1);
+      kslam_status s1 = KSLAM_OK, s2 = KSLAM_OK;
+      std::thread tax([&] { char *t = nullptr; uint64_t tl = 0; s2 = kslam_tail_classify(&ro, &rv, &iv, db, rp, nrp, pr, npr, ids.data(), &t, &tl); free(t); });
+      s1 = kslam_tail_finish_write_rows(&ro, &rv, &iv, ov.data(), ov.size(), pool.data(), pool.size(), nullptr, nullptr, 0, rp, nrp, pr, npr,
+                                        [](void *u, const char *, uint64_t n) -> int { *(uint64_t *)u += n; return 0; }, &bytes, nullptr);
+      tax.join();
+      if (s1 || s2) { printf("error %d %d %s\n", s1, s2, kslam_tail_last_error()); return 1; }
+      printf("iter %d: %llu read pairs (largest %llu alignment pairs), %.1f MB text, text and classification side by side\n", it,
+             (unsigned long long)nrp, (unsigned long long)biggest, bytes / 1e6);
+      free(rp);   // (kslam_free is free(): the standalone build has no kslam_api.hip)
+      free(pr);
+    }
+    kslam_taxdb_free(db);
+    return 0;
+  }
   for (int it = 0; it < iters; it++) {
     char *txt; uint64_t len; kslam_tail_stats st;
     auto t0 = std::chrono::steady_clock::now();

@@ -486,3 +486,27 @@ def test_finish_prepare_then_read_only_write_equals_the_one_call_finish(kslam, o
     rp3, pr3 = rp.copy(), pr.copy()
     T.tail_finish_prepare(T.TailParams.default(threads=4, pseudo_assembly=False), R, al, rp3, pr3, sort_groups=False)
     assert (rp3 == rp).all() and (pr3 == pr).all()
+
+
+@pytest.mark.parametrize("mode", ["write", "mmap"])
+def test_background_writer_both_ways(kslam, T, tmp_path, monkeypatch, mode):
+    """kslam_sam_writer: write() (default) or KSLAM_WRITER=mmap (a batch copied into a shared mapping of the file's next
+    region by several threads: no inode lock between them).  Small and large pieces, an odd starting offset, appended in
+    order; the file is what was queued, byte for byte, and the descriptor stands at its end."""
+    import ctypes as C
+    monkeypatch.setenv("KSLAM_WRITER", mode)
+    monkeypatch.setenv("KSLAM_WRITER_THREADS", "3")
+    rng = np.random.default_rng(3)
+    pieces = [b"@HD\tVN:1.0\n", rng.integers(0, 256, 3_000_001, dtype=np.uint8).tobytes(), b"x" * 17,
+              rng.integers(0, 256, 5_123_457, dtype=np.uint8).tobytes(), rng.integers(0, 256, 1_048_576, dtype=np.uint8).tobytes()]
+    path = str(tmp_path / "out.sam")
+    fd = os.open(path, os.O_RDWR | os.O_CREAT | os.O_TRUNC)
+    os.write(fd, b"abc")                      # the writer starts where the descriptor stands
+    w = T.SamWriter(fd)
+    for p in pieces:
+        w.write(p)
+    n, sec = w.close()
+    assert n == sum(len(p) for p in pieces)
+    assert os.lseek(fd, 0, os.SEEK_CUR) == 3 + n
+    os.close(fd)
+    assert open(path, "rb").read() == b"abc" + b"".join(pieces)

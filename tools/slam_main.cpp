@@ -338,7 +338,7 @@ int run(const Options &o, const std::string &command_line) {
   char *header = nullptr;
   uint64_t header_len = 0;
   if (want_sam) {
-    sam_fd = open(o.sam.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    sam_fd = open(o.sam.c_str(), O_RDWR | O_CREAT | O_TRUNC, 0644);   // O_RDWR: the writer may map the file (KSLAM_WRITER=mmap)
     if (sam_fd < 0) die("unable to open SAM file " + o.sam);
     if (kslam_sam_header(index, command_line.c_str(), &header, &header_len) != KSLAM_OK) die(kslam_tail_last_error());
   }

@@ -1490,62 +1490,9 @@ struct kslam_sam_writer {
   std::atomic<int> error{0};           // errno of the first failed write
   uint64_t bytes = 0;
   double write_s = 0;
-  // ---- KSLAM_WRITER=mmap: a batch's text goes into the page cache through a shared mapping of the file's next region,
-  // copied by several threads at once.  write() into ONE file serialises on the inode lock whoever issues it (11 GB/s on
-  // the bench boxes: 37-41 ms per 404 MB batch, as much as the GPU needs for the batch); page faults on a mapping take
-  // per-page locks only.  Regular files opened O_RDWR only; anything else (and any failure) falls back to write().
-  int map_threads = 0;        // 0: write()
-  bool map_checked = false;
-  bool mapped_copy(std::vector<Text> &set, uint64_t *done) {
-    if (!map_checked) {
-      map_checked = true;
-      const char *e = getenv("KSLAM_WRITER");
-      struct stat sb;
-      if (e && !strncmp(e, "mmap", 4) && fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && (fcntl(fd, F_GETFL) & O_ACCMODE) == O_RDWR) {
-        map_threads = 4;
-        if (const char *n = getenv("KSLAM_WRITER_THREADS")) map_threads = std::max(1, std::min(16, atoi(n)));
-      }
-    }
-    if (!map_threads) return false;
-    uint64_t total = 0;
-    for (const Text &t : set) total += t.n;
-    if (total < (1u << 20)) return false;   // headers and small batches: not worth a mapping
-    const off_t at = lseek(fd, 0, SEEK_CUR);
-    if (at < 0) return false;
-    const long page = sysconf(_SC_PAGESIZE);
-    const off_t m0 = at & ~(off_t)(page - 1);
-    if (ftruncate(fd, at + (off_t)total) != 0) return false;
-    char *base = (char *)mmap(nullptr, (size_t)(at - m0) + total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, m0);
-    if (base == MAP_FAILED) {
-      map_threads = 0;        // not a file system that maps: write() from now on (the file keeps its new length: it is
-      return false;           // overwritten from `at` by the write() path, which ends at the same offset)
-    }
-    char *dst = base + (at - m0);
-    // slices of ~equal size over the concatenation of the parts
-    struct Piece { const char *src; char *dst; size_t n; };
-    std::vector<std::vector<Piece>> work(map_threads);
-    const uint64_t per = (total + map_threads - 1) / map_threads;
-    uint64_t pos = 0;
-    for (const Text &t : set) {
-      uint64_t o = 0;
-      while (o < t.n) {
-        const int k = (int)std::min<uint64_t>(pos / per, (uint64_t)map_threads - 1);
-        const uint64_t room = std::min<uint64_t>(t.n - o, (uint64_t)(k + 1) * per - pos);
-        work[k].push_back({t.p + o, dst + pos, (size_t)room});
-        o += room;
-        pos += room;
-      }
-    }
-    std::vector<std::thread> th;
-    for (int k = 1; k < map_threads; k++)
-      th.emplace_back([&, k] { name_thread("kslam-writer"); for (const Piece &p : work[k]) memcpy(p.dst, p.src, p.n); });
-    for (const Piece &p : work[0]) memcpy(p.dst, p.src, p.n);
-    for (auto &x : th) x.join();
-    munmap(base, (size_t)(at - m0) + total);
-    if (lseek(fd, at + (off_t)total, SEEK_SET) < 0) { error = errno ? errno : EIO; return true; }
-    *done += total;
-    return true;
-  }
+  // Tried and removed (round 4): copying a batch into a shared MAPPING of the file's next region with four threads, to get
+  // around the inode lock that serialises write() into one file (11 GB/s here: 37-41 ms per 404 MB batch).  On the bench
+  // boxes' file system the write faults cost far more than the lock: 150-200 ms per batch against 45 (13 against 45 M reads/s).
   void run() {
     name_thread("kslam-writer");
     for (;;) {
@@ -1560,9 +1507,6 @@ struct kslam_sam_writer {
       }
       const double t0 = now_ms();
       uint64_t done = 0;
-      if (mapped_copy(set, &done)) {
-        for (Text &t : set) t.n = 0;
-      } else
       for (Text &t : set) {
         const char *p = t.p;
         size_t left = t.n;

@@ -488,14 +488,9 @@ def test_finish_prepare_then_read_only_write_equals_the_one_call_finish(kslam, o
     assert (rp3 == rp).all() and (pr3 == pr).all()
 
 
-@pytest.mark.parametrize("mode", ["write", "mmap"])
-def test_background_writer_both_ways(kslam, T, tmp_path, monkeypatch, mode):
-    """kslam_sam_writer: write() (default) or KSLAM_WRITER=mmap (a batch copied into a shared mapping of the file's next
-    region by several threads: no inode lock between them).  Small and large pieces, an odd starting offset, appended in
-    order; the file is what was queued, byte for byte, and the descriptor stands at its end."""
-    import ctypes as C
-    monkeypatch.setenv("KSLAM_WRITER", mode)
-    monkeypatch.setenv("KSLAM_WRITER_THREADS", "3")
+def test_background_writer_appends_in_order_from_where_the_descriptor_stands(kslam, T, tmp_path):
+    """kslam_sam_writer: small and large pieces, an odd starting offset, appended in order; the file is what was queued, byte
+    for byte, and the descriptor stands at its end."""
     rng = np.random.default_rng(3)
     pieces = [b"@HD\tVN:1.0\n", rng.integers(0, 256, 3_000_001, dtype=np.uint8).tobytes(), b"x" * 17,
               rng.integers(0, 256, 5_123_457, dtype=np.uint8).tobytes(), rng.integers(0, 256, 1_048_576, dtype=np.uint8).tobytes()]

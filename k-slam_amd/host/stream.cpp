@@ -91,7 +91,8 @@ extern "C" kslam_status kslam_stream_classify(kslam_ctx *ctx, const kslam_index_
     if (!paired && (r2 || len2)) fail(KSLAM_ERR_ARG, "single-end data (tail.paired == 0) is ONE text: r2 must be NULL");
     if (P->pairs_per_batch == 0) fail(KSLAM_ERR_ARG, "pairs_per_batch must be positive");
     if (taxdb && !tax_ids_out) fail(KSLAM_ERR_ARG, "tax_ids output missing");
-    const uint32_t depth = P->depth ? P->depth : 3;
+    uint32_t depth = P->depth ? P->depth : 3;
+    if (const char *e = getenv("KSLAM_STREAM_DEPTH")) depth = (uint32_t)std::max(1, std::min(8, atoi(e)));   // A/B
     const uint32_t stages = KSLAM_TAIL_INSERT_SCREEN | KSLAM_TAIL_SCORE_SCREEN | (P->tail.pseudo_assembly ? KSLAM_TAIL_PSEUDO_ASM : 0u);
     if (kslam_set_pairing(ctx, paired ? 1 : 0, P->tail.score_threshold, P->tail.score_fraction, stages) != KSLAM_OK)
       fail(KSLAM_ERR_UNSUPPORTED, kslam_last_error(ctx));

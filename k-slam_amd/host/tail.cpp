@@ -1952,7 +1952,8 @@ kslam_status kslam_sam_writer_enqueue(kslam_sam_writer *w, char *data, uint64_t 
     one.push_back(std::move(t));
     {
       std::unique_lock<std::mutex> lk(w->m);
-      w->cv.wait(lk, [&] { return w->error || w->queue.size() < 2; });
+      static const size_t room = [] { const char *e = getenv("KSLAM_WRITER_QUEUE"); return (size_t)(e ? std::max(1, std::min(16, atoi(e))) : 2); }();
+      w->cv.wait(lk, [&] { return w->error || w->queue.size() < room; });
       if (w->error) fail(KSLAM_ERR_ARG, std::string("writing the SAM text failed: ") + strerror(w->error));   // `one` releases the block
       w->queue.push_back(std::move(one));
     }

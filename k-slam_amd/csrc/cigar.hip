@@ -25,10 +25,19 @@ namespace kslam {
 
 namespace {
 
-__device__ inline uint32_t band_class(uint32_t bw) {
-  uint32_t c = 0;
-  while ((1u << c) < bw) c++;
-  return c;
+// Bins of the band widths.  banded_sw starts at |refLen - readLen| + 1 and doubles (ssw.c:616, 693-694), so the widths a batch
+// asks for are 1 + the indel lengths -- NOT powers of two -- and a kernel that gives every candidate of a bin the slots of the
+// bin's widest member should not have "one more than a power of two" as that member: 2 bw + 1 diagonals for bw = 8 are 17,
+// one too many for 16 slots.  The bins therefore end at 2^k - 1 (2 bw + 1 <= 2^(k+1) - 1 slots), except the two narrow ones,
+// which are exact because nearly every gapped read of a batch is a one-base indel (bw = 2):
+//   0: 1   1: 2   2: 3..4   3: 5..7   4: 8..15   5: 16..31   6: 32..63   7: >= 64 (the generic loop, by floor(log2 bw))
+// A failed attempt doubles bw, which always lands in a LATER bin.
+__host__ __device__ inline uint32_t cig_bin(uint32_t bw) {
+  return bw <= 2 ? bw - 1 : (bw <= 4 ? 2u : (bw <= 7 ? 3u : (bw <= 15 ? 4u : (bw <= 31 ? 5u : (bw <= 63 ? 6u : 7u)))));
+}
+constexpr uint32_t CIG_BIN_MAX_BW[7] = {1, 2, 4, 7, 15, 31, 63};
+__device__ inline uint32_t band_class(uint32_t bw) {   // floor(log2 bw): the classes of the generic loop (bw >= 64)
+  return 31u - (uint32_t)__builtin_clz(bw | 1u);
 }
 
 __global__ void k_class_flags(const uint32_t *__restrict__ bw, const uint8_t *__restrict__ needbig, uint64_t n,
@@ -43,6 +52,19 @@ __global__ void k_class_flags(const uint32_t *__restrict__ bw, const uint8_t *__
     else f = (!needbig[i] && band_class(b) == cls) ? 1u : 0u;
   }
   flags[i] = f;
+}
+
+// which classes (floor(log2 bw)) still have unfinished candidates: one bit each
+__global__ void k_class_mask(const uint32_t *__restrict__ bw, const uint8_t *__restrict__ needbig, uint64_t n, uint32_t *__restrict__ mask) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t v = 0;
+  if (i < n) {
+    const uint32_t b = bw[i];
+    if (b != 0 && !(b >> 31) && !needbig[i]) v = 1u << band_class(b);
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) v |= (uint32_t)__shfl_down((int)v, d, 64);
+  if ((threadIdx.x & 63) == 0 && v) atomicOr(mask, v);
 }
 
 __global__ void k_scatter_list(const uint32_t *__restrict__ flags, const uint32_t *__restrict__ pos, uint64_t n,
@@ -82,7 +104,8 @@ struct CigJob {
   static constexpr uint32_t variant = 0;   // compiled out of the product build
 #endif
   // where candidates go that are not finished by this launch (nullptr: the host re-lists by flags)
-  uint32_t *next_list = nullptr, *next_count = nullptr;         // band doubled: the next class
+  uint32_t *bin_list[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // band doubled: the list of its new bin
+  uint32_t *bin_count = nullptr;                                // [8] (nullptr: the host re-lists by flags)
   uint32_t *special_list = nullptr, *special_count = nullptr;   // handed back by the systolic kernel
   uint32_t *big_count = nullptr;                                // cigar longer than the small temp slot
   // systolic kernels: list positions whose attempt reached the score, for k_systolic_traceback (nullptr: the
@@ -102,11 +125,24 @@ __device__ inline void append_candidate(bool want, uint32_t ci, uint32_t *list, 
   if (want) list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = ci;
 }
 
+// the same for a candidate whose band doubled: into the list of its new bin (lanes of a wave may differ in that)
+__device__ inline void append_doubled(const CigJob &J, bool want, uint32_t ci, uint32_t new_bw) {
+  if (!J.bin_count) return;
+  const uint32_t b = cig_bin(new_bw);
+  for (;;) {
+    const uint64_t m = __ballot(want);
+    if (!m) break;
+    const uint32_t b0 = (uint32_t)__shfl((int)b, (int)__builtin_ctzll(m), 64);
+    append_candidate(want && b == b0, ci, J.bin_list[b0], J.bin_count + b0);
+    want = want && b != b0;
+  }
+}
+
 __global__ void k_cig_class(const uint32_t *__restrict__ bw, uint64_t n, uint8_t *__restrict__ cls) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint32_t b = bw[i];
-  cls[i] = (b != 0 && !(b >> 31)) ? (uint8_t)min(band_class(b), 7u) : (uint8_t)255;
+  cls[i] = (b != 0 && !(b >> 31)) ? (uint8_t)cig_bin(b) : (uint8_t)255;
 }
 
 // banded_sw (ssw.c:594-792): one attempt with J.bw[ci], then traceback when max >= score.
@@ -383,7 +419,7 @@ __global__ __launch_bounds__(64) void k_banded_lds(CigJob J, SwInputs in, SwPara
   J.bmax[ci] = mx;
   if (mx < score) {               // ssw.c:693-694: retry with twice the band
     J.bw[ci] = (uint32_t)band_width * 2u;
-    if (J.next_list) append_candidate(true, ci, J.next_list, J.next_count);
+    append_doubled(J, true, ci, (uint32_t)band_width * 2u);
     return;
   }
   uint32_t *tmp = J.tmp + (uint64_t)(J.big ? (J.list_base + li) : ci) * J.cap;
@@ -624,7 +660,7 @@ __global__ __launch_bounds__(BS) void k_cigar_systolic(CigJob J, SwInputs in, Sw
   J.bmax[ci] = best;
   if (best < (int32_t)o.score) {               // ssw.c:693-694: retry with twice the band
     J.bw[ci] = (uint32_t)bw * 2u;
-    if (J.next_list) append_candidate(true, ci, J.next_list, J.next_count);
+    append_doubled(J, true, ci, (uint32_t)bw * 2u);
     return;
   }
   if (J.tb_list) {   // the walk is a chain of dependent loads: it runs in its own kernel, 64 candidates to the wave
@@ -784,7 +820,7 @@ void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, u
   const uint32_t cap_big = 2 * lmax + 4;
   if (p.report_cigar) {
     W.counters.ensure(16 * sizeof(uint32_t));
-    uint32_t *cnt = W.counters.as<uint32_t>();   // [0..7] class list sizes, [8] handed back, [9] long cigars, [10] tracebacks of a systolic launch
+    uint32_t *cnt = W.counters.as<uint32_t>();   // [0..7] bin list sizes, [8] handed back, [9] long cigars, [10] tracebacks of a systolic launch, [11] classes present (generic loop)
     auto run_lists = [&](uint32_t cls, uint32_t mode) -> uint64_t {   // mode: 0 class, 1 big rerun, 2 handed back
       hipLaunchKernelGGL(k_class_flags, dim3(nb), dim3(256), 0, s, d_bw, W.needbig.as<uint8_t>(), n, cls,
                          mode, W.flags.as<uint32_t>());
@@ -804,12 +840,12 @@ void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, u
     const int sys_mask = tune.cigar_sys_mask;
     struct Route {
       const uint32_t *list = nullptr;
-      uint32_t *next_list = nullptr, *next_count = nullptr, *special_list = nullptr, *special_count = nullptr,
-               *big_count = nullptr;
+      uint32_t *const *bin_list = nullptr;   // [8]: where a candidate goes whose band doubled (nullptr: the host re-lists by flags)
+      uint32_t *bin_count = nullptr, *special_list = nullptr, *special_count = nullptr, *big_count = nullptr;
     };
-    auto launch_systolic = [&](uint64_t m, uint32_t slot_bw, uint32_t cls, const Route &R) -> bool {
+    auto launch_systolic = [&](uint64_t m, uint32_t slot_bw, uint32_t bin, const Route &R) -> bool {
       const uint32_t need = 2 * slot_bw + 1;
-      if (need > 256 || !((sys_mask >> std::min(cls, 7u)) & 1)) return false;
+      if (need > 256 || !((sys_mask >> std::min(bin, 7u)) & 1)) return false;
       const int lm = lmax <= 160 ? 0 : (lmax <= 256 ? 1 : 2);
       const uint32_t LM = lm == 0 ? 160 : (lm == 1 ? 256 : 512);
       // lanes x diagonals per lane: 8 x 2 / 4 / 8 up to 64 slots, 16 x 8 / 16 up to 256 (a handful of
@@ -827,7 +863,8 @@ void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, u
         CigJob J;
         J.ov = d_ov; J.bw = d_bw; J.bmax = W.bmax.as<int32_t>(); J.needbig = W.needbig.as<uint8_t>();
         J.list = R.list ? R.list : W.list.as<uint32_t>();
-        J.next_list = R.next_list; J.next_count = R.next_count;
+        if (R.bin_list) for (int k = 0; k < 8; k++) J.bin_list[k] = R.bin_list[k];
+        J.bin_count = R.bin_list ? R.bin_count : nullptr;
         J.special_list = R.special_list; J.special_count = R.special_count; J.big_count = R.big_count;
         J.list_base = (uint32_t)g0;
         J.m = (uint32_t)std::min<uint64_t>(groups_per_launch, m - g0);
@@ -890,12 +927,14 @@ void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, u
         for (const void *f : {reinterpret_cast<const void *>(&k_banded_lds<0>),
                               reinterpret_cast<const void *>(&k_banded_lds<1>),
                               reinterpret_cast<const void *>(&k_banded_lds<2>),
-                              reinterpret_cast<const void *>(&k_banded_lds<4>)})
+                              reinterpret_cast<const void *>(&k_banded_lds<4>),
+                              reinterpret_cast<const void *>(&k_banded_lds<8>),
+                              reinterpret_cast<const void *>(&k_banded_lds<16>)})
           HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       // narrow bands: the band in registers (KSLAM_CIGAR_REG=0 turns it off)
       const bool use_reg = tune.cigar_reg;
       // (a class-0 candidate has band 1: three slots, not the five of the band-2 instantiation it used to share)
-      const uint32_t reg_bw = (!use_reg || big || Y.wpr) ? 0u : (slot_bw <= 1 ? 1u : (slot_bw <= 2 ? 2u : (slot_bw <= 4 ? 4u : 0u)));
+      const uint32_t reg_bw = (!use_reg || big || Y.wpr) ? 0u : (slot_bw <= 1 ? 1u : (slot_bw <= 2 ? 2u : (slot_bw <= 4 ? 4u : (slot_bw <= 8 ? 8u : (slot_bw <= 16 ? 16u : 0u)))));
       uint64_t slab = Y.wpr ? 256 : (uint64_t)lmax * std::max<uint32_t>(Y.wd, reg_bw ? 8u : 0u) * nl;   // direction
       slab = (slab + 255) & ~255ull;   // bytes per block; the register variant stores <= 8 bytes per row and lane
       const uint64_t SCRATCH_BUDGET = 3ull << 30;
@@ -906,7 +945,9 @@ void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, u
         CigJob J;
         J.ov = d_ov; J.bw = d_bw; J.bmax = W.bmax.as<int32_t>(); J.needbig = W.needbig.as<uint8_t>();
         J.list = R.list ? R.list : W.list.as<uint32_t>();
-        J.next_list = R.next_list; J.next_count = R.next_count; J.big_count = R.big_count;
+        if (R.bin_list) for (int k = 0; k < 8; k++) J.bin_list[k] = R.bin_list[k];
+        J.bin_count = R.bin_list ? R.bin_count : nullptr;
+        J.big_count = R.big_count;
         const uint64_t nb_here = std::min<uint64_t>(blocks_per_launch, n_blocks - b0);
         J.list_base = (uint32_t)(b0 * nl);
         J.m = (uint32_t)std::min<uint64_t>(nb_here * nl, m - b0 * nl);
@@ -923,13 +964,15 @@ void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, u
         if (reg_bw == 1) hipLaunchKernelGGL(k_banded_lds<1>, dim3((unsigned)nb_here), dim3(64), lds, s, J, in, p, Y);
         else if (reg_bw == 2) hipLaunchKernelGGL(k_banded_lds<2>, dim3((unsigned)nb_here), dim3(64), lds, s, J, in, p, Y);
         else if (reg_bw == 4) hipLaunchKernelGGL(k_banded_lds<4>, dim3((unsigned)nb_here), dim3(64), lds, s, J, in, p, Y);
+        else if (reg_bw == 8) hipLaunchKernelGGL(k_banded_lds<8>, dim3((unsigned)nb_here), dim3(64), lds, s, J, in, p, Y);
+        else if (reg_bw == 16) hipLaunchKernelGGL(k_banded_lds<16>, dim3((unsigned)nb_here), dim3(64), lds, s, J, in, p, Y);
         else hipLaunchKernelGGL(k_banded_lds<0>, dim3((unsigned)nb_here), dim3(64), lds, s, J, in, p, Y);
       }
       HIPCHK(hipGetLastError());
     };
-    // Band classes 0..6 (bw <= 64): one partition of the candidates by class, then class after class;
-    // an attempt that falls short of the score doubles its band, i.e. moves up exactly one class, and
-    // the kernels append such candidates to the next class's list themselves.
+    // Bins 0..6 (bw < 64, cig_bin above): one partition of the candidates by bin, then bin after bin; an attempt that falls
+    // short of the score doubles its band, which moves it to a later bin, and the kernels append such candidates to that
+    // bin's list themselves.
     const bool debug = tune.debug;
     W.cls.ensure(n);
     for (int k = 0; k < 8; k++) W.cls_list[k].ensure((n + 1) * sizeof(uint32_t));
@@ -940,47 +983,65 @@ void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, u
     for (int k = 0; k < 8; k++) lists[k] = W.cls_list[k].as<uint32_t>();
     partition_bins(W.cls.as<uint8_t>(), n, lists, cnt, W.pos, s);
     uint32_t hc[10];
-    for (uint32_t cls = 0; cls < 7; cls++) {
+    for (uint32_t bin = 0; bin < 7; bin++) {
       read_back(hc, cnt, sizeof hc, s);
-      const uint64_t m = hc[cls];
+      if (debug && bin == 0)
+        fprintf(stderr, "[kslam] cigar bins as the SW stage asked for them: %u %u %u %u %u %u %u %u\n", hc[0], hc[1], hc[2], hc[3], hc[4], hc[5], hc[6], hc[7]);
+      const uint64_t m = hc[bin];
       if (m == 0) continue;
-      if (debug) fprintf(stderr, "[kslam] cigar class %u (band <= %u): %llu candidates\n", cls, 1u << cls, (unsigned long long)m);
+      const uint32_t slot_bw = CIG_BIN_MAX_BW[bin];
+      if (debug) fprintf(stderr, "[kslam] cigar bin %u (band <= %u): %llu candidates\n", bin, slot_bw, (unsigned long long)m);
       Route R;
-      R.list = lists[cls];
-      R.next_list = lists[cls + 1];
-      R.next_count = cnt + cls + 1;
+      R.list = lists[bin];
+      R.bin_list = lists;
+      R.bin_count = cnt;
       R.special_list = W.special.as<uint32_t>();
       R.special_count = cnt + 8;
       R.big_count = cnt + 9;
-      if (launch_systolic(m, 1u << cls, cls, R)) {
+      if (launch_systolic(m, slot_bw, bin, R)) {
         read_back(hc, cnt, sizeof hc, s);
         if (hc[8]) {   // the few it hands back (spans the band covers completely)
           if (debug) fprintf(stderr, "[kslam]   handed to the one-lane kernel: %u\n", hc[8]);
           Route R2 = R;
           R2.list = W.special.as<uint32_t>();
           R2.special_list = nullptr;
-          launch(hc[8], 1u << cls, false, R2);
+          launch(hc[8], slot_bw, false, R2);
           HIPCHK(hipMemsetAsync(cnt + 8, 0, sizeof(uint32_t), s));
         }
       } else {
-        launch(m, 1u << cls, false, R);
+        launch(m, slot_bw, false, R);
       }
     }
-    // wider than 64 (never seen on real reads): the flag / scan / scatter loop, class by class
+    // 64 and wider (never seen on real reads): the flag / scan / scatter loop, class c = floor(log2 bw) after class
     read_back(hc, cnt, sizeof hc, s);
     if (hc[7]) {
-      uint32_t last_cls = 7;
-      for (uint32_t cls = 7; cls < 31; cls++) {
+      HIPCHK(hipMemsetAsync(cnt + 11, 0, sizeof(uint32_t), s));
+      hipLaunchKernelGGL(k_class_mask, dim3(nb), dim3(256), 0, s, d_bw, W.needbig.as<uint8_t>(), n, cnt + 11);
+      uint32_t present = 0;
+      read_back(&present, cnt + 11, sizeof present, s);
+      for (uint32_t cls = 6; cls < 31; cls++) {
+        if (!((present >> cls) & 1u)) continue;
         uint64_t m = run_lists(cls, 0);
-        if (m == 0) {
-          if (cls > last_cls) break;
-          continue;
-        }
-        if (debug) fprintf(stderr, "[kslam] cigar class %u (band <= %u): %llu candidates\n", cls, 1u << cls, (unsigned long long)m);
+        if (m == 0) continue;
+        present |= 2u << cls;   // what fails here doubles its band
+        const uint32_t slot_bw = (2u << cls) - 1u;
+        if (debug) fprintf(stderr, "[kslam] cigar class %u (band <= %u): %llu candidates\n", cls, slot_bw, (unsigned long long)m);
         Route R;
         R.big_count = cnt + 9;
-        launch(m, 1u << cls, false, R);
-        last_cls = cls + 1;
+        R.special_list = W.special.as<uint32_t>();
+        R.special_count = cnt + 8;
+        if (launch_systolic(m, slot_bw, 7, R)) {
+          read_back(hc, cnt, sizeof hc, s);
+          if (hc[8]) {
+            Route R2 = R;
+            R2.list = W.special.as<uint32_t>();
+            R2.special_list = nullptr;
+            launch(hc[8], slot_bw, false, R2);
+            HIPCHK(hipMemsetAsync(cnt + 8, 0, sizeof(uint32_t), s));
+          }
+        } else {
+          launch(m, slot_bw, false, R);
+        }
       }
       read_back(hc, cnt, sizeof hc, s);
     }

@@ -154,45 +154,57 @@ __global__ void k_cig_class(const uint32_t *__restrict__ bw, uint64_t n, uint8_t
 struct LdsLayout {
   uint32_t nl;       // lanes (candidates) per block
   uint32_t lmax;     // rows / columns the sequence buffers are sized for
+  uint32_t nch;      // 16-base chunks a sequence buffer holds per lane (stage_codes_wave)
   uint32_t W1;       // row array length (2 * slot_bw + 4)
   uint32_t wd;       // direction cells per row the global slab is sized for (2 * slot_bw + 1)
   uint32_t wpr;      // direction words per row kept in LDS (six 5-bit cells per word); 0: global slab
 };
 
-// Lane-private staging for the one-candidate-per-lane kernels: the lane walks its own span of
-// PRE-ENCODED bases (encode_bases: bits 0-2 SSW code, bit 3 complementable) dword by dword and
-// writes its own column of dst -- two 4-bit codes per byte, byte (k / 2) * NS + lane -- with plain
-// byte stores.  `rev`: complemented and back to front (window of a revComp overlap).
-__device__ inline void stage_codes_lane(const uint8_t *codes, int32_t len, bool rev, uint8_t *dst, uint32_t NS,
-                                        uint32_t lane) {
-  if (len <= 0) return;
-  const uintptr_t a0 = reinterpret_cast<uintptr_t>(codes);
-  const int32_t shift = (int32_t)(a0 & 3u);
-  const uint32_t *w = reinterpret_cast<const uint32_t *>(a0 - (uintptr_t)shift);
-  const int32_t ndw = (shift + len + 3) >> 2;
-  uint32_t acc = 0;
-  struct __attribute__((packed, aligned(4))) Quad { uint32_t x[4]; };   // one 16-byte load (the arrays are padded)
-  for (int32_t d0 = 0; d0 < ndw; d0 += 4) {
-    const Quad q = *reinterpret_cast<const Quad *>(w + d0);
-#pragma unroll
-    for (int32_t dd = 0; dd < 4; dd++) {
-      const int32_t d = d0 + dd;
-      const uint32_t v = codes_of_dword<1>(q.x[dd], rev);
-#pragma unroll
-      for (int32_t b = 0; b < 4; b++) {
-        const int32_t k = 4 * d + b - shift;
-        if (k < 0 || k >= len) continue;
-        const uint32_t kk = (uint32_t)(rev ? len - 1 - k : k);
-        acc |= ((v >> (8 * b)) & 15u) << (4u * (kk & 1u));
-        // a byte is complete with its second nibble in walking order (odd kk forwards, even kk
-        // backwards), or at the last base
-        if (((kk & 1u) == (rev ? 0u : 1u)) || k == len - 1) {
-          dst[(kk >> 1) * NS + lane] = (uint8_t)acc;
-          acc = 0;
-        }
+// Staging for the one-candidate-per-lane kernels, by the whole wave.  (It used to be lane-private: every lane walked
+// its own two spans, 16 bytes per load, and a load instruction of the wave touched 64 different cache lines of which the
+// L1 kept next to none until the lane came back for the next 16 bytes -- by ablation 0.56 of the 1.3 ms of the bw = 2
+// launch.)  Here eight lanes serve one candidate at a time, as stage_span does for the systolic kernels: the span is
+// fetched as the 16-byte ALIGNED chunks that cover it, a chunk per lane and a whole line per eight lanes, converted in
+// registers to two 4-bit codes per byte (pre-encoded bases, see encode_bases: bits 0-2 SSW code, bit 3 complementable)
+// and stored with one 8-byte LDS write at the chunk's own place in the candidate's column: granule (chunk, lane) of dst
+// is the 8 bytes at ((chunk * NL + lane) * 8).  The buffer thus holds the codes of the covering chunks, not re-aligned,
+// and the caller gets the position of its element 0.  `rev` (window of a revComp overlap): complemented, the chunks in
+// reverse order with their bytes reversed, which lands the reversed span at a (different) position of the same column.
+// Both base arrays are the library's own copies: 256-byte aligned starts, 64 bytes of slack at the end.
+__device__ inline uint32_t pack_nibbles(uint32_t c) {   // four codes, one per byte -> 16 bits
+  const uint32_t t = (c | (c >> 4)) & 0x00FF00FFu;
+  return (t | (t >> 8)) & 0xFFFFu;
+}
+__device__ inline int32_t stage_codes_wave(const uint8_t *codes, int32_t len, bool rev, uint8_t *dst, uint32_t NL,
+                                           uint32_t lane) {
+  const uint32_t shift = (uint32_t)(reinterpret_cast<uintptr_t>(codes) & 15u);
+  const int32_t nch = len > 0 ? ((int32_t)shift + len + 15) >> 4 : 0;
+  const uint64_t base = reinterpret_cast<uintptr_t>(codes) - shift;
+  const uint32_t t = lane & 7u, g = lane >> 3;
+#pragma unroll 2
+  for (uint32_t r = 0; r < 8; r++) {
+    const int c = (int)(8u * r + g);   // the candidate (lane) this group of eight serves in round r
+    const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)base, c, 64), hi = (uint32_t)__shfl((int)(uint32_t)(base >> 32), c, 64);
+    const int32_t n = __shfl(nch, c, 64);
+    const bool rv = __shfl((int)rev, c, 64) != 0;
+    const uint4 *b = reinterpret_cast<const uint4 *>(((uint64_t)hi << 32) | lo);
+    for (int32_t k = (int32_t)t; k < n; k += 8) {
+      const uint4 v = b[k];
+      uint2 w;
+      int32_t at;
+      if (!rv) {
+        w.x = pack_nibbles(codes_of_dword<1>(v.x, false)) | (pack_nibbles(codes_of_dword<1>(v.y, false)) << 16);
+        w.y = pack_nibbles(codes_of_dword<1>(v.z, false)) | (pack_nibbles(codes_of_dword<1>(v.w, false)) << 16);
+        at = k;
+      } else {
+        w.x = pack_nibbles(__builtin_bswap32(codes_of_dword<1>(v.w, true))) | (pack_nibbles(__builtin_bswap32(codes_of_dword<1>(v.z, true))) << 16);
+        w.y = pack_nibbles(__builtin_bswap32(codes_of_dword<1>(v.y, true))) | (pack_nibbles(__builtin_bswap32(codes_of_dword<1>(v.x, true))) << 16);
+        at = n - 1 - k;
       }
+      *reinterpret_cast<uint2 *>(dst + ((uint32_t)at * NL + (uint32_t)c) * 8u) = w;
     }
   }
+  return rev ? 16 * nch - (int32_t)shift - len : (int32_t)shift;
 }
 
 // ---- narrow bands: the band lives in registers ------------------------------------------------------
@@ -305,19 +317,15 @@ __global__ __launch_bounds__(64) void k_banded_lds(CigJob J, SwInputs in, SwPara
   extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
   if (J.variant == 3) return;   // ablation: launch floor
   const uint32_t lane = threadIdx.x;
-  const uint32_t NL = Y.nl, NS = NL + 1;
+  const uint32_t NL = Y.nl;
   const uint32_t li = blockIdx.x * NL + lane;
   const bool have = lane < NL && li < J.m;
-  const uint32_t half = (((Y.lmax + 1) / 2) * NS + 3) & ~3u;   // bytes per packed sequence buffer
+  const uint32_t half = Y.nch * NL * 8u;   // bytes per packed sequence buffer
   uint8_t *SQ = lds_raw;
   uint8_t *SR = SQ + half;
-  int16_t *S = reinterpret_cast<int16_t *>(lds_raw + (((size_t)2 * half + 15) & ~(size_t)15));
+  int16_t *S = reinterpret_cast<int16_t *>(lds_raw + (size_t)2 * half);
   uint32_t *DW = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(S) +
                                               (((size_t)3 * Y.W1 * NL * sizeof(int16_t) + 15) & ~(size_t)15));
-  for (uint32_t x = lane; x < half / 2; x += 64) reinterpret_cast<uint32_t *>(lds_raw)[x] = 0;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   uint8_t *D = J.scratch + (uint64_t)blockIdx.x * J.wave_slab;
 
   uint32_t ci = 0;
@@ -353,9 +361,9 @@ __global__ __launch_bounds__(64) void k_banded_lds(CigJob J, SwInputs in, SwPara
     }
   }
   if (J.variant == 4) return;   // ablation: candidate header loads only
-  // stage the two spans as SSW codes (ssw_cpp.cpp:11-23), every lane its own
-  stage_codes_lane(qsrc, skip ? 0 : readLen, false, SQ, NS, lane);
-  stage_codes_lane(rsrc, skip ? 0 : refLen, !skip && o.revcomp != 0, SR, NS, lane);
+  // stage the two spans as SSW codes (ssw_cpp.cpp:11-23): the wave together, eight lanes per candidate
+  const int32_t oq = stage_codes_wave(qsrc, skip ? 0 : readLen, false, SQ, NL, lane);
+  const int32_t orf = stage_codes_wave(rsrc, skip ? 0 : refLen, !skip && o.revcomp != 0, SR, NL, lane);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -367,8 +375,12 @@ __global__ __launch_bounds__(64) void k_banded_lds(CigJob J, SwInputs in, SwPara
     __device__ int16_t &hb(int32_t k) { return S[(uint32_t)k * NL + lane]; }
     __device__ int16_t &eb(int32_t k) { return S[(W1 + (uint32_t)k) * NL + lane]; }
     __device__ int16_t &hc(int32_t k) { return S[(2 * W1 + (uint32_t)k) * NL + lane]; }
-    __device__ uint32_t q(int32_t i) { return (SQ[((uint32_t)i >> 1) * (NL + 1) + lane] >> (4 * (i & 1))) & 15u; }
-    __device__ uint32_t r(int32_t j) { return (SR[((uint32_t)j >> 1) * (NL + 1) + lane] >> (4 * (j & 1))) & 15u; }
+    int32_t oq, orf;                    // where element 0 of each span sits in its column (stage_codes_wave)
+    __device__ static uint32_t code(const uint8_t *B, uint32_t s, uint32_t NL, uint32_t lane) {
+      return ((uint32_t)B[((s >> 4) * NL + lane) * 8u + ((s >> 1) & 7u)] >> (4u * (s & 1u))) & 15u;
+    }
+    __device__ uint32_t q(int32_t i) { return code(SQ, (uint32_t)(i + oq), NL, lane); }
+    __device__ uint32_t r(int32_t j) { return code(SR, (uint32_t)(j + orf), NL, lane); }
     uint32_t *DW, wpr, acc;             // LDS direction words: [row * wpr + word][lane]
     __device__ void set_dir(int32_t i, int32_t col, uint32_t v) {
       if (wpr) {
@@ -398,7 +410,7 @@ __global__ __launch_bounds__(64) void k_banded_lds(CigJob J, SwInputs in, SwPara
       }
       return D[((size_t)i * width_d + (uint32_t)col) * NL + lane];
     }
-  } A{S, SQ, SR, D, NL, lane, Y.W1, (uint32_t)(band_width * 2 + 1), DW, Y.wpr, 0u};
+  } A{S, SQ, SR, D, NL, lane, Y.W1, (uint32_t)(band_width * 2 + 1), oq, orf, DW, Y.wpr, 0u};
   (void)score;
   int32_t mx;
   bool in_regs = false;
@@ -910,7 +922,8 @@ void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, u
       // Directions: global slab.  Keeping them in LDS (KSLAM_CIGAR_DIRS=lds) was measured: the DP is
       // LDS-instruction bound, not bound by the traceback's loads, and the extra 38 KB per block cost
       // more occupancy than the traceback gained (class 1: 7.9 ms against 2.8 ms).
-      const size_t base_lane = (size_t)lmax + 2 + (size_t)3 * Y.W1 * sizeof(int16_t);
+      Y.nch = ((lmax + 30) >> 4) + 1;   // 15 bytes of misalignment in front, up to 15 behind
+      const size_t base_lane = (size_t)2 * Y.nch * 8 + (size_t)3 * Y.W1 * sizeof(int16_t);
       const uint32_t wpr_fit = (Y.wd + 5) / 6;
       const bool dir_in_lds = tune.cigar_dirs_lds &&
                               (base_lane + (size_t)lmax * wpr_fit * 4) * 16 + 64 <= 64 * 1024;
@@ -919,9 +932,9 @@ void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, u
       uint32_t nl = 64;
       while (nl > 1 && per_lane * nl + 64 > 64 * 1024) nl >>= 1;   // <= 64 KB: at least two blocks per CU
       Y.nl = nl;
-      const size_t half = ((((size_t)lmax + 1) / 2) * (nl + 1) + 3) & ~(size_t)3;
+      const size_t half = (size_t)Y.nch * nl * 8;
       const size_t rows_bytes = ((size_t)3 * Y.W1 * nl * sizeof(int16_t) + 15) & ~(size_t)15;
-      const size_t lds = ((2 * half + 15) & ~(size_t)15) + rows_bytes + (size_t)lmax * Y.wpr * 4 * nl;
+      const size_t lds = 2 * half + rows_bytes + (size_t)lmax * Y.wpr * 4 * nl;
       if (lds > 160 * 1024) throw StatusError{KSLAM_ERR_UNSUPPORTED, "banded traceback band does not fit LDS"};
       if (lds > 64 * 1024)
         for (const void *f : {reinterpret_cast<const void *>(&k_banded_lds<0>),

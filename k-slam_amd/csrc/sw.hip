@@ -293,6 +293,34 @@ __global__ __launch_bounds__(256) void k_sw(kslam_overlap *__restrict__ ov, uint
 // the union of those ranges over all feasible g lies inside [dlo, dlo + ND - 1].
 // the part of the certificate that does not depend on the band: the smallest A(g) = m0(g) - g over the feasible
 // g; INT32_MAX when nothing needs bounding, -1 when the score certifies nothing
+// a / b for the small dividends of the certificate (scores, lengths x match) without the ~40 instructions of an integer
+// division: (a * (2^20 / b + 1)) >> 20 is exact for a <= 4282 and every b in 1..255 (checked exhaustively,
+// tests/test_tail.py::test_small_divider); larger dividends take the real division
+struct SmallDiv {
+  uint32_t m;
+  int32_t b;
+  __device__ explicit SmallDiv(int32_t bb) : m((1u << 20) / (uint32_t)bb + 1u), b(bb) {}
+  __device__ int32_t operator()(int32_t a) const {
+    return ((uint32_t)a < 4096u && (uint32_t)b < 256u) ? (int32_t)(((uint32_t)a * m) >> 20) : a / b;
+  }
+};
+// certificate_amin below with the two dividers made once per wave
+__device__ inline int32_t certificate_amin_fast(int32_t score, int32_t L, int32_t W, const SwParams &p, const SmallDiv &by_match,
+                                                const SmallDiv &by_gap_extend) {
+  if (score <= 0) return -1;
+  const int32_t Lm = min(L, W), ma = p.match;
+  const int32_t m00 = by_match(score + ma - 1);
+  if (m00 > Lm) return INT32_MAX;
+  int32_t amin = m00;
+  const int32_t room = Lm * ma - score - p.gap_open;
+  if (room >= 0) {
+    int32_t g = 1;
+    if (p.gap_extend < ma) g = min(by_gap_extend(room) + 1, 2047);
+    const int32_t m0 = by_match(score + p.gap_open + (g - 1) * p.gap_extend + ma - 1);
+    amin = min(amin, m0 - g);
+  }
+  return amin;
+}
 __device__ inline int32_t certificate_amin(int32_t score, int32_t L, int32_t W, const SwParams &p) {
   if (score <= 0) return -1;
   const int32_t Lm = min(L, W), ma = p.match;
@@ -355,57 +383,176 @@ struct Tiers {
 // best of those five plain diagonal sums picks the narrowest band that is certain to certify;
 // gapped alignments, whose diagonal sums are poor, start in the 32-diagonal band and move up on
 // failure as before.
+// Software-pipelined: the way to a candidate's bases is three dependent loads long (its record -> the offsets of its read
+// and its entry -> the 16-byte chunks of the two spans) and the arithmetic behind them is short, so a workgroup that
+// took 32 candidates through "load, barrier, count, exit" spent its life waiting (1.25 ms for 8 M candidates, VALU 0.43).
+// Here a WAVE walks through octets of candidates (eight lanes each; nothing is shared between waves, so there is no
+// block barrier) and every level of the chain is issued one octet ahead of the level that consumes it: while octet i is
+// counted, the chunks of octet i + 1, the offsets of i + 2 and the record of i + 3 are on their way.
+template <int CPL>
+struct SpanFetch {   // stage_span split in two: the loads ...
+  uint4 v[CPL];
+  int32_t nch, shift, len;
+  bool rc;
+};
+template <int GL, int CPL>
+__device__ inline void span_fetch(const uint8_t *src, int32_t len, bool rc, int32_t t, SpanFetch<CPL> &S) {
+  S.shift = (int32_t)(reinterpret_cast<uintptr_t>(src) & 15u);
+  S.len = len;
+  S.rc = rc;
+  S.nch = (S.shift + len + 15) >> 4;
+  const uint4 *base = reinterpret_cast<const uint4 *>(src - S.shift);
+#pragma unroll
+  for (int j = 0; j < CPL; j++) {
+    const int32_t k = t + GL * j;
+    S.v[j] = k < S.nch ? base[k] : make_uint4(0u, 0u, 0u, 0u);
+  }
+}
+template <int GL, int WS, int CPL>   // ... and the conversion + LDS stores; returns where element 0 sits in dst
+__device__ inline int32_t span_store(const SpanFetch<CPL> &S, int32_t t, uint8_t *dst) {
+#pragma unroll
+  for (int j = 0; j < CPL; j++) {
+    const int32_t k = t + GL * j;
+    if (k < S.nch) {
+      const uint4 v = S.v[j];
+      uint4 c;
+      int32_t at;
+      if (!S.rc) {
+        c.x = codes_of_dword<WS>(v.x, false);
+        c.y = codes_of_dword<WS>(v.y, false);
+        c.z = codes_of_dword<WS>(v.z, false);
+        c.w = codes_of_dword<WS>(v.w, false);
+        at = k;
+      } else {
+        c.x = __builtin_bswap32(codes_of_dword<WS>(v.w, true));
+        c.y = __builtin_bswap32(codes_of_dword<WS>(v.z, true));
+        c.z = __builtin_bswap32(codes_of_dword<WS>(v.y, true));
+        c.w = __builtin_bswap32(codes_of_dword<WS>(v.x, true));
+        at = S.nch - 1 - k;
+      }
+      reinterpret_cast<uint4 *>(dst)[at] = c;
+    }
+  }
+  return S.rc ? 16 * S.nch - S.shift - S.len : S.shift;
+}
+__device__ inline void wave_lds_fence() {   // LDS traffic of ONE wave is in order; this only pins the compiler
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 template <int LMAX>
 __global__ __launch_bounds__(256) void k_sw_plan(kslam_overlap *__restrict__ ov, uint64_t n, SwInputs in,
                                                  SwParams p, Tiers T, uint8_t *__restrict__ tier,
                                                  uint32_t *__restrict__ band0) {
   constexpr int GL = 8, NG = 256 / GL, PW = 16;   // PW: bytes of "N" padding either side of a span
+  constexpr int CPL = (((LMAX + 30) >> 4) + GL - 1) / GL;   // chunks of a span per lane
   __shared__ __attribute__((aligned(16))) uint8_t s_q[NG][LMAX + STAGE_PAD + 2 * PW];
   __shared__ __attribute__((aligned(16))) uint8_t s_w[NG][LMAX + STAGE_PAD + 2 * PW];
   const int32_t lane = threadIdx.x & 63;
   const int32_t t = lane & (GL - 1);
   const int32_t grp = threadIdx.x / GL;
-  const uint64_t gi = (uint64_t)blockIdx.x * NG + grp;
-  const bool have = gi < n;
-  int32_t L = 0, W = 0, rel = 0;
+  const uint64_t octets = (n + 7) / 8;
+  const uint64_t nw = (uint64_t)gridDim.x * 4, w0 = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const uint32_t gsub = (uint32_t)lane >> 3;
+  struct C1 { bool have; uint32_t read, entry; int32_t rel; uint32_t rc; };
+  struct C2 { bool have; int32_t rel; uint32_t rc; uint64_t ro, ro1, go, go1; };
+  struct C3 { bool have; int32_t rel, L, W; SpanFetch<CPL> q, w; };
+  auto s1 = [&](uint64_t oct) {   // the candidate's record
+    C1 c{false, 0u, 0u, 0, 0u};
+    const uint64_t gi = oct * 8 + gsub;
+    if (oct < octets && gi < n) {
+      const kslam_overlap *o = ov + gi;
+      c.have = true;
+      c.read = o->read;
+      c.entry = o->entry;
+      c.rel = o->rel;
+      c.rc = o->revcomp;
+    }
+    return c;
+  };
+  auto s2 = [&](const C1 &a) {    // where its read and its entry lie
+    C2 c{a.have, a.rel, a.rc, 0ull, 0ull, 0ull, 0ull};
+    if (a.have) {
+      c.ro = in.read_off[a.read];
+      c.ro1 = in.read_off[a.read + 1];
+      c.go = in.genome_off[a.entry];
+      c.go1 = in.genome_off[a.entry + 1];
+    }
+    return c;
+  };
+  auto s3 = [&](const C2 &a) {    // the chunks of the two spans (stage_candidate_wide's arithmetic)
+    C3 c;
+    c.have = a.have;
+    c.rel = a.rel;
+    c.L = (int32_t)(a.ro1 - a.ro);
+    const uint64_t G = a.go1 - a.go;
+    const int64_t s0 = a.rel > 0 ? a.rel : 0;                                 // SmithWaterman.h:204
+    c.W = a.have ? (int32_t)min((uint64_t)c.L, G - (uint64_t)s0) : 0;        // substr, :205-206
+    if (a.have) {
+      span_fetch<GL, CPL>(in.read_codes + a.ro, c.L, false, t, c.q);
+      span_fetch<GL, CPL>(in.genome_codes + a.go + s0, c.W, a.rc != 0, t, c.w);   // :207
+    } else {
+      c.q.nch = c.w.nch = 0;
+      c.q.shift = c.w.shift = c.q.len = c.w.len = 0;
+      c.q.rc = c.w.rc = false;
+    }
+    return c;
+  };
+  const SmallDiv by_match(p.match), by_gap_extend(p.gap_extend);
+  // the tier a lane speaks for: lane t of a group tests tier t's band, the first that holds wins
+  int32_t nd_mine = 0;
+#pragma unroll
+  for (int k = 0; k < NT_MAX; k++) nd_mine = (t == k && k < T.n) ? T.nd[k] : nd_mine;
+  C3 z0 = s3(s2(s1(w0)));
+  C2 y1 = s2(s1(w0 + nw));
+  C1 x2 = s1(w0 + 2 * nw);
+  for (uint64_t oct = w0; oct < octets; oct += nw) {
+  const C3 z1 = s3(y1);
+  const C2 y2 = s2(x2);
+  const C1 x3 = s1(oct + 3 * nw);
+  const uint64_t gi = oct * 8 + gsub;
+  const bool have = z0.have;
+  const int32_t L = z0.L, W = z0.W, rel = z0.rel;
   uint8_t *qc = s_q[grp] + PW, *wc = s_w[grp] + PW;
+  wave_lds_fence();   // the previous octet's reads of these buffers are done
   if (have) {
-    const kslam_overlap o = ov[gi];
-    rel = o.rel;
-    const Staged st = stage_candidate_wide<GL, 1>(o, in, t, qc, wc, nullptr, p);
-    L = st.L;
-    W = st.W;
-    qc += st.qoff;
-    wc += st.woff;
+    qc += span_store<GL, 1, CPL>(z0.q, t, qc);
+    wc += span_store<GL, 1, CPL>(z0.w, t, wc);
   }
-  __syncthreads();
+  wave_lds_fence();
   for (int32_t x = t; x < PW; x += GL) {   // code 4 scores 0 against everything
     qc[-1 - x] = 4;
     qc[L + x] = 4;
     wc[-1 - x] = 4;
     wc[W + x] = 4;
   }
-  __syncthreads();
-  // Four bases per step: read word (LDS-aligned) against the five window words at offsets
-  // d0 - 2 .. d0 + 2, matches and mismatches counted with byte-parallel arithmetic (codes are
-  // 0..4, so x + 0x7F sets bit 7 of a byte iff it is non-zero; code 4 = bit 2 = "scores 0").
+  wave_lds_fence();
+  // Four bases per step: read word (LDS-aligned) against three window words, matches and mismatches counted with
+  // byte-parallel arithmetic (codes are 0..4, so x + 0x7F sets bit 7 of a byte iff it is non-zero; code 4 = bit 2 =
+  // "scores 0").  WHICH three diagonals: the dedupe keeps the smallest rel of a chain and drops what lies up to 2 above
+  // it (Overlap.h:79-85 on the ascending order of :87-98), so the seeds merged into this candidate sit on rel, rel + 1,
+  // rel + 2 -- window diagonals d0 .. d0 + 2, or d0 - 2 .. d0 in the flipped window of a revComp candidate.  (Five
+  // diagonals, d0 - 2 .. d0 + 2 for everybody, planned the same tiers: the other two never held the best sum.  Any
+  // subset is SOUND -- the sums are only a lower bound of the optimum that picks the starting tier.)
   const int32_t d0 = rel < 0 ? rel : 0;
   const int32_t qa = (int32_t)(reinterpret_cast<uintptr_t>(qc) & 3u);
   // read indices i = 4 m - qa; keep every window byte touched inside its padding
   const int32_t i_lo = max(-qa, ((-d0 - 8) & ~3) - qa), i_hi = min(L, W - d0 + 8);
-  uint32_t nm[5] = {0, 0, 0, 0, 0}, nx[5] = {0, 0, 0, 0, 0};
+  uint32_t nm[3] = {0, 0, 0}, nx[3] = {0, 0, 0};
   constexpr uint32_t B7 = 0x80808080u, LO7 = 0x7F7F7F7Fu;
+  const int32_t dfirst = d0 - (z0.w.rc ? 2 : 0);   // the lowest of the three diagonals
   for (int32_t i = i_lo + 4 * t; i < i_hi; i += 4 * GL) {
     const uint32_t q = *reinterpret_cast<const uint32_t *>(qc + i);
     const uint32_t qn = (q << 5) & B7;   // bit 7 where the read base is N / padding
-    const uint8_t *wa = wc + (i + d0 - 2);
+    const uint8_t *wa = wc + (i + dfirst);
     const uint32_t sh = (uint32_t)(reinterpret_cast<uintptr_t>(wa) & 3u);
     const uint32_t *wb = reinterpret_cast<const uint32_t *>(wa - sh);
     // the eight window bytes from wa on, byte-aligned (v_alignbyte_b32); diagonal k then starts at byte k
     const uint32_t a0 = __builtin_amdgcn_alignbyte(wb[1], wb[0], sh), a1 = __builtin_amdgcn_alignbyte(wb[2], wb[1], sh);
 #pragma unroll
-    for (int k = 0; k < 5; k++) {
-      const uint32_t w = k == 0 ? a0 : (k == 4 ? a1 : __builtin_amdgcn_alignbyte(a1, a0, (uint32_t)k));
+    for (int k = 0; k < 3; k++) {
+      const uint32_t w = k == 0 ? a0 : __builtin_amdgcn_alignbyte(a1, a0, (uint32_t)k);
       const uint32_t x = q ^ w;
       const uint32_t ne = (x + LO7) & B7;            // bytes that differ
       const uint32_t inv = qn | ((w << 5) & B7);     // bytes that score 0
@@ -413,41 +560,37 @@ __global__ __launch_bounds__(256) void k_sw_plan(kslam_overlap *__restrict__ ov,
       nm[k] += (uint32_t)__popc((ne | inv) ^ B7);    // matches
     }
   }
-  int32_t best = 0;
+  int32_t best = 0, full = 0;
 #pragma unroll
-  for (int k = 0; k < 5; k++) {
-    int32_t v = (int32_t)nm[k] * p.match - (int32_t)nx[k] * p.mismatch;
+  for (int k = 0; k < 3; k++) {
+    uint32_t c = nm[k] | (nx[k] << 16);   // both counts of a diagonal in one register (each < 2^10)
 #pragma unroll
-    for (int m = 1; m < GL; m <<= 1) v += __shfl_xor(v, m, GL);
-    best = max(best, v);
+    for (int m = 1; m < GL; m <<= 1) c += (uint32_t)__shfl_xor((int)c, m, GL);
+    best = max(best, (int32_t)(c & 0xFFFFu) * p.match - (int32_t)(c >> 16) * p.mismatch);
+    if (k == 0 && !z0.w.rc) full = (int32_t)(c & 0xFFFFu);   // the seed diagonal d0 itself
+    if (k == 2 && z0.w.rc) full = (int32_t)(c & 0xFFFFu);
   }
   // A read that matches its whole window base for base (seed diagonal, W = L, every column a real
   // match: no N) needs no DP at all: score match x L; any other alignment has fewer matched pairs or
   // pays for a gap, so it is the unique optimum -- end (L-1, L-1), begin (0, 0), CIGAR <L>M -- and
   // the reference's tie rules never come into play.  ~5 % of the candidates of the bench workload.
-  int32_t full = (int32_t)nm[2];
-#pragma unroll
-  for (int m = 1; m < GL; m <<= 1) full += __shfl_xor(full, m, GL);
   const bool perfect = have && rel >= 0 && W == L && L > 0 && full == L && p.ablate == 0;
   {
     PassResult f{p.match * L, L - 1, L - 1, 0, 0};
     sw_epilogue<GL, 1>(ov, gi, perfect, t, L, f, qc, wc, p, band0);
   }
-  if (perfect) {
-    if (t == 0) tier[gi] = 255;   // in no tier's list
-    return;
+  {
+    // every lane of the group has `best`; lane k asks whether tier k's band holds, the narrowest that does is the choice
+    // (no diagonal certifies anything -- a gapped alignment: T.unknown, see sw_scores)
+    const int32_t amin = certificate_amin_fast(best, L, W, p, by_match, by_gap_extend);
+    const bool holds = nd_mine > 0 && band_holds(amin, L, W, d0 - nd_mine / 2, nd_mine);
+    const uint32_t mine = (uint32_t)(__ballot(holds) >> (8u * gsub)) & 0xFFu;
+    const int choice = mine ? (int)__builtin_ctz(mine) : T.unknown;
+    if (have && t == 0) tier[gi] = perfect ? (uint8_t)255 : (uint8_t)choice;   // 255: in no tier's list
   }
-  if (have && t == 0) {
-    int choice = T.unknown;   // no diagonal certifies anything (gapped alignment): see sw_scores
-    const int32_t amin = certificate_amin(best, L, W, p);   // (the divisions once, not once per tier)
-    for (int k = 0; k < T.n; k++) {
-      const int ND = T.nd[k];
-      if (band_holds(amin, L, W, d0 - ND / 2, ND)) {
-        choice = k;
-        break;
-      }
-    }
-    tier[gi] = (uint8_t)choice;
+  z0 = z1;
+  y1 = y2;
+  x2 = x3;
   }
 }
 
@@ -1208,7 +1351,7 @@ void sw_scores(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, uint32_
     for (int k = 0; k < T.n; k++) T.list[k] = W.tier_list[k].as<uint32_t>();
     T.full_list = W.list.as<uint32_t>();
     T.counts = counts;
-    const unsigned pb = (unsigned)((n + 31) / 32);
+    const unsigned pb = (unsigned)std::min<uint64_t>((n + 31) / 32, 256 * 64);   // its waves walk through the candidates, ~16 octets each
     if (lm == 0) hipLaunchKernelGGL(k_sw_plan<160>, dim3(pb), dim3(256), 0, s, d_ov, n, in, p, T, tier, d_band0);
     else if (lm == 1) hipLaunchKernelGGL(k_sw_plan<256>, dim3(pb), dim3(256), 0, s, d_ov, n, in, p, T, tier, d_band0);
     else hipLaunchKernelGGL(k_sw_plan<512>, dim3(pb), dim3(256), 0, s, d_ov, n, in, p, T, tier, d_band0);

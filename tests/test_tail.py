@@ -505,3 +505,13 @@ def test_background_writer_appends_in_order_from_where_the_descriptor_stands(ksl
     assert os.lseek(fd, 0, os.SEEK_CUR) == 3 + n
     os.close(fd)
     assert open(path, "rb").read() == b"abc" + b"".join(pieces)
+
+
+def test_small_divider():
+    """csrc/sw.hip SmallDiv: (a * (2^20 / b + 1)) >> 20 == a / b for every dividend the fast path admits (a < 4096) and every
+    divisor it admits (b in 1..255) -- the arithmetic identity the certificate's three divisions rest on, exhaustively."""
+    a = np.arange(4096, dtype=np.uint64)
+    for b in range(1, 256):
+        m = np.uint64((1 << 20) // b + 1)
+        assert np.array_equal((a * m) >> np.uint64(20), a // np.uint64(b)), b
+        assert int(a[-1] * m) < 1 << 32   # the product fits the 32-bit multiply

@@ -353,7 +353,7 @@ void row_details(const kslam_overlap *d_ov, uint64_t n, const uint32_t *d_pool, 
 
 // --------------------------------------------------------------- pairs.hip
 struct PairWork {
-  DevBuf recs, count, base, inserts, flags, gpos, rpos, scan_tmp, totals, groups, dense, sort_a, sort_b, idx, picked, row_list;
+  DevBuf recs, count, base, inserts, flags, gpos, rpos, scan_tmp, totals, groups, dense, sort_a, sort_b, idx, picked, row_list, row_start, gaps;
   uint64_t units = 0, mid = 0;   // between pair_phase_a and pair_phase_b: read pairs (or reads) of the batch, its R1 block
   uint32_t pseudo_cap = 0;       // 0 = the default (pairs.hip: PSEUDO_CAP_GLOBAL); tests lower it to reach the host fallback
   int paired = 0;

@@ -57,10 +57,34 @@ __device__ inline Rec single_rec(const kslam_overlap &o, uint32_t idx, bool is_r
   return r;
 }
 
+// first row of every read (the rows are sorted by read): row_start[r] for r in 0 .. n_reads, row_start[n_reads] = n.  One
+// thread per row fills the entries between its predecessor's read and its own -- k_pair then finds a read pair's two runs
+// with four loads instead of four binary searches of 23 dependent probes each (0.7 of its 1.2 ms).
+__global__ void k_row_starts(const kslam_overlap *__restrict__ ov, uint64_t n, uint64_t n_reads, uint32_t *__restrict__ row_start,
+                             uint4 *__restrict__ gaps, uint32_t *__restrict__ n_gaps) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > n) return;
+  const int64_t prev = i > 0 ? (int64_t)ov[i - 1].read : -1;
+  const int64_t cur = min(i < n ? (int64_t)ov[i].read : (int64_t)n_reads, (int64_t)n_reads);
+  if (cur - prev > 64) {   // a long stretch of reads without rows (an empty result: all of them): k_fill_gaps, in parallel
+    gaps[atomicAdd(n_gaps, 1u)] = make_uint4((uint32_t)(prev + 1), (uint32_t)cur, (uint32_t)i, 0u);
+    return;
+  }
+  for (int64_t r = prev + 1; r <= cur; r++) row_start[r] = (uint32_t)i;
+}
+__global__ __launch_bounds__(256) void k_fill_gaps(const uint4 *__restrict__ gaps, const uint32_t *__restrict__ n_gaps,
+                                                    uint32_t *__restrict__ row_start) {
+  const uint32_t ng = *n_gaps;
+  for (uint32_t g = blockIdx.x; g < ng; g += gridDim.x) {
+    const uint4 e = gaps[g];
+    for (uint64_t r = (uint64_t)e.x + threadIdx.x; r <= e.y; r += 256) row_start[r] = e.z;
+  }
+}
+
 struct PairArgs {
   const kslam_overlap *ov;
   uint64_t n;              // overlap records
-  const uint64_t *split;   // device: first row of the R2 block (paired)
+  const uint32_t *row_start;   // [n_reads + 1] (k_row_starts)
   const uint32_t *read_len;
   uint64_t units, mid;     // read pairs (or reads); reads per block
   uint32_t thr;            // score threshold
@@ -80,9 +104,9 @@ __global__ __launch_bounds__(256) void k_pair(PairArgs a) {
   if (u < a.units) {
     const kslam_overlap *ov = a.ov;
     if (a.paired) {
-      const uint64_t split = *a.split;
-      uint64_t i = first_read_at_least(ov, 0, split, u), i1 = first_read_at_least(ov, i, split, u + 1);
-      uint64_t j = first_read_at_least(ov, split, a.n, a.mid + u), j1 = first_read_at_least(ov, j, a.n, a.mid + u + 1);
+      const uint64_t split = a.row_start[a.mid];
+      uint64_t i = a.row_start[u], i1 = a.row_start[u + 1];
+      uint64_t j = a.row_start[a.mid + u], j1 = a.row_start[a.mid + u + 1];
       const uint64_t base = 4 * (i + (j - split));
       a.base[u] = base;
       out = a.recs + base;
@@ -142,7 +166,7 @@ __global__ __launch_bounds__(256) void k_pair(PairArgs a) {
       if (open) close_run();
     } else {
       // getPerReadOverlaps (single end) + dummy pairs: every overlap of the read as an R1-only record
-      uint64_t i = first_read_at_least(ov, 0, a.n, u), i1 = first_read_at_least(ov, i, a.n, u + 1);
+      uint64_t i = a.row_start[u], i1 = a.row_start[u + 1];
       const uint64_t base = 4 * i;
       a.base[u] = base;
       out = a.recs + base;
@@ -798,10 +822,16 @@ void pair_phase_a(const kslam_overlap *d_ov, uint64_t n, const uint32_t *d_read_
   W.totals.ensure(16 * sizeof(uint64_t));
   uint64_t *tot = W.totals.as<uint64_t>();
   HIPCHK(hipMemsetAsync(tot, 0, 16 * sizeof(uint64_t), s));
-  // tot[0..1]: split (rows of the R1 block) by the shard kernel; [4] inserts, [5] kept, [6] pairs after pairing
-  shard_counts(d_ov, n, (uint32_t)mid, 0, tot, s);
+  // tot[4] inserts, [5] kept, [6] pairs after pairing
+  if (n >= (1ull << 32)) throw StatusError{KSLAM_ERR_UNSUPPORTED, ">= 2^32 overlap records in one batch"};
+  W.row_start.ensure((n_reads + 2) * sizeof(uint32_t));
+  W.gaps.ensure((n_reads / 64 + 2) * sizeof(uint4));   // stretches of more than 64 reads without rows: at most that many
+  uint32_t *d_ngaps = reinterpret_cast<uint32_t *>(tot + 11);
+  hipLaunchKernelGGL(k_row_starts, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, s, d_ov, n, n_reads, W.row_start.as<uint32_t>(),
+                     W.gaps.as<uint4>(), d_ngaps);
+  hipLaunchKernelGGL(k_fill_gaps, dim3(64), dim3(256), 0, s, W.gaps.as<uint4>(), d_ngaps, W.row_start.as<uint32_t>());
   PairArgs a;
-  a.ov = d_ov; a.n = n; a.split = tot; a.read_len = d_read_len; a.units = units; a.mid = mid;
+  a.ov = d_ov; a.n = n; a.row_start = W.row_start.as<uint32_t>(); a.read_len = d_read_len; a.units = units; a.mid = mid;
   a.thr = score_threshold; a.paired = paired;
   a.recs = W.recs.as<Rec>(); a.count = W.count.as<uint32_t>(); a.base = W.base.as<uint64_t>();
   a.inserts = W.inserts.as<int32_t>();

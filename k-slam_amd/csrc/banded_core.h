@@ -13,6 +13,8 @@
 // Accessor M: int32_t& hb(k), eb(k), hc(k); uint32_t q(i), r(j) (SSW codes 0..4 of the aligned
 // read / reference spans); void set_dir(i, col, v); uint32_t get_dir(i, col).
 #pragma once
+#include <type_traits>
+#include <utility>
 #include "common.h"
 
 namespace kslam {
@@ -72,6 +74,25 @@ __device__ inline int32_t banded_attempt(M &m, int32_t refLen, int32_t readLen, 
   return mx;
 }
 
+// An accessor may offer `int32_t diag_run(int32_t i, int32_t j)`: how many of the cells (i, j), (i - 1, j - 1), ... say
+// "diagonal" in the H plane, as far as the direction word that holds (i, j) goes (0: look at the cell the slow way).  The
+// kernels that pack a band diagonal's cells into one word answer that with one load and a bit scan, and the walk then
+// takes a whole run of matches -- most of an alignment -- per dependent load instead of one step.
+template <class M, class = void>
+struct has_diag_run : std::false_type {};
+template <class M>
+struct has_diag_run<M, std::void_t<decltype(std::declval<M &>().diag_run(0, 0))>> : std::true_type {};
+// the bit scan for six 5-bit cells per word, cell r = bits 5 r .. 5 r + 4, H direction in bits 2..4 of a cell (1 = diagonal):
+// consecutive cells r, r - 1, ... whose H direction is "diagonal"
+__device__ inline int32_t diag_cells_down_from(uint32_t word, uint32_t r) {
+  constexpr uint32_t ONES = 1u | (1u << 5) | (1u << 10) | (1u << 15) | (1u << 20) | (1u << 25);
+  uint32_t x = (word & (0x1Cu * ONES)) ^ (0x04u * ONES);   // zero fields where the cell says diagonal
+  x &= (2u << (5u * r + 4u)) - 1u;                          // cells 0 .. r
+  if (x == 0) return (int32_t)r + 1;
+  const uint32_t p = 31u - (uint32_t)__builtin_clz(x);      // highest cell that says something else
+  return (int32_t)r - (int32_t)((p * 13u) >> 6);            // p / 5 for p < 30
+}
+
 // traceback, ssw.c:698-771.  Ops are written in TRACEBACK order into tmp[0..cap); returns the op
 // count (may exceed cap: *ovf), or -1 on the reference's "Trace back error" path.
 template <class M>
@@ -84,6 +105,26 @@ __device__ inline int32_t banded_traceback(M &m, int32_t refLen, int32_t readLen
     const int32_t col = j - xi;
     const int32_t jend = (refLen - 1) < (i + band_width) ? (refLen - 1) : (i + band_width);
     uint32_t dir = 0;
+    if constexpr (has_diag_run<M>::value) {
+      if (plane == 2 && col >= 0 && j <= jend && j >= 0) {
+        // a run of direction 1 (--i --j, M, stay in H; ssw.c:704-708).  Along a band diagonal a cell that follows an
+        // existing cell exists as long as its column does (col and jend move with the row), and the loop ends at i == 0
+        const int32_t run = min(m.diag_run(i, j), min(i, j + 1));
+        if (run > 0) {
+          if (cur == 0) cnt += run;
+          else {
+            if ((uint32_t)l < cap) tmp[l] = (uint32_t)cnt << 4 | (uint32_t)cur; else *ovf = true;
+            ++l;
+            cur = 0;
+            cnt = run;
+          }
+          op = 0;
+          i -= run;
+          j -= run;
+          continue;
+        }
+      }
+    }
     if (col >= 0 && j <= jend && j >= 0) {
       const uint32_t bb = m.get_dir(i, col);
       // plane 2 (H): bits 2..4 as they are; plane 0 (E): 2 + bit 0; plane 1 (F): 4 + bit 1 -- the base and

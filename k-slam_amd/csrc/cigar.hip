@@ -108,9 +108,9 @@ struct CigJob {
   uint32_t *bin_count = nullptr;                                // [8] (nullptr: the host re-lists by flags)
   uint32_t *special_list = nullptr, *special_count = nullptr;   // handed back by the systolic kernel
   uint32_t *big_count = nullptr;                                // cigar longer than the small temp slot
-  // systolic kernels: list positions whose attempt reached the score, for k_systolic_traceback (nullptr: the
+  // systolic kernels: which list positions' attempts reached the score, for k_systolic_traceback (nullptr: the
   // group's lane 0 walks the traceback itself, at the end of the DP kernel)
-  uint32_t *tb_list = nullptr, *tb_count = nullptr;
+  uint8_t *tb_flag = nullptr;   // [m], zeroed: 1 = this list position's attempt reached the score
 };
 
 // wave-aggregated append of candidate ci to a list (one atomic per wave)
@@ -392,6 +392,16 @@ __global__ __launch_bounds__(64) void k_banded_lds(CigJob J, SwInputs in, SwPara
     }
     int32_t reg_bw = 0;                 // > 0: the words hold band slots (banded_attempt_reg), not columns
     uint32_t nx = 0, have_idx = 0xFFFFFFFFu, have_word = 0;   // register variant: slots per row; the word fetched last
+    __device__ int32_t diag_run(int32_t i, int32_t j) {   // (banded_core.h) only the register variant packs along diagonals
+      if (reg_bw <= 0) return 0;
+      const uint32_t i6 = (uint32_t)i / 6u, r = (uint32_t)i - 6u * i6;
+      const uint32_t idx = (i6 * nx + (uint32_t)(j - i + reg_bw)) * NL + lane;
+      if (idx != have_idx) {
+        have_idx = idx;
+        have_word = DW[idx];
+      }
+      return diag_cells_down_from(have_word, r);
+    }
     __device__ uint32_t get_dir(int32_t i, int32_t col) {
       if (reg_bw > 0) {                 // words (i / 6, slot): six rows of one band slot
         if (i < reg_bw) col += reg_bw - i;   // slot = j - i + bw, col = j - max(0, i - bw)
@@ -464,6 +474,18 @@ __device__ inline void systolic_traceback(const CigJob &J, uint32_t li, uint32_t
     const uint32_t *D;
     int32_t bw, k0;
     uint32_t have_idx, have_word;   // the word fetched last: a diagonal run reuses it
+    __device__ int32_t diag_run(int32_t i, int32_t j) {   // (banded_core.h)
+      const int32_t x = j - i + bw;
+      const int32_t tt = x / DPL, q = x - tt * DPL;
+      const uint32_t n = (uint32_t)((i + j - k0 - (q & 1)) >> 1);
+      const uint32_t m = n / 6u, r = n - 6u * m;
+      const uint32_t idx = (m * GL + (uint32_t)tt) * DPL + (uint32_t)q;
+      if (idx != have_idx) {
+        have_idx = idx;
+        have_word = D[idx];
+      }
+      return diag_cells_down_from(have_word, r);
+    }
     __device__ uint32_t get_dir(int32_t i, int32_t col) {
       const int32_t j = col + (i - bw > 0 ? i - bw : 0);
       const int32_t x = j - i + bw;
@@ -675,8 +697,10 @@ __global__ __launch_bounds__(BS) void k_cigar_systolic(CigJob J, SwInputs in, Sw
     append_doubled(J, true, ci, (uint32_t)bw * 2u);
     return;
   }
-  if (J.tb_list) {   // the walk is a chain of dependent loads: it runs in its own kernel, 64 candidates to the wave
-    append_candidate(true, li, J.tb_list, J.tb_count);
+  if (J.tb_flag) {   // the walk is a chain of dependent loads: it runs in its own kernel, 64 candidates to the wave
+    // (a flag per list position, not a compacted list: one returning atomic per wave on ONE counter -- 20-odd thousand a
+    // launch at ~12 ns apiece -- was two thirds of the 16-slot launch's 0.38 ms)
+    J.tb_flag[li] = 1;
     return;
   }
   systolic_traceback<GL, DPL>(J, li, ci, o, bw, refLen, readLen, D);
@@ -688,8 +712,8 @@ __global__ __launch_bounds__(BS) void k_cigar_systolic(CigJob J, SwInputs in, Sw
 template <int GL, int DPL>
 __global__ __launch_bounds__(256) void k_systolic_traceback(CigJob J) {
   const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
-  if (x >= *J.tb_count) return;
-  const uint32_t li = J.tb_list[x];
+  if (x >= J.m || !J.tb_flag[x]) return;
+  const uint32_t li = x;
   const uint32_t ci = J.list[J.list_base + li];
   kslam_overlap o = J.ov[ci];
   const int32_t bw = (int32_t)J.bw[ci];
@@ -715,15 +739,20 @@ __global__ __launch_bounds__(256) void k_finalize(kslam_overlap *__restrict__ ov
                                                   const uint32_t *__restrict__ bw,
                                                   uint32_t *__restrict__ pool, uint64_t pool_base, unsigned long long *cells) {
   __shared__ unsigned long long sm[4];
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ uint4 s_rec[4][192];
   unsigned long long mycells = 0;
+  // a workgroup walks through tiles of 256 rows: the DP-cell count it ends with is ONE atomic on `cells` (a same-address
+  // atomic takes ~12 ns whoever issues it; one per 256 rows -- 32 k of them -- was most of this kernel's 0.41 ms)
+  for (uint64_t tile = blockIdx.x; tile * 256 < n; tile += gridDim.x) {
+  const uint64_t i = tile * 256 + threadIdx.x;
+  const uint64_t first = i - (threadIdx.x & 63u);   // the wave's records travel together (common.h: wave_load_records)
+  kslam_overlap o = wave_load_records(ov, first, n, s_rec[threadIdx.x >> 6]);
   if (i < n) {
-    kslam_overlap o = ov[i];
     const uint64_t L = in.read_off[o.read + 1] - in.read_off[o.read];
     const uint64_t G = in.genome_off[o.entry + 1] - in.genome_off[o.entry];
     const int64_t s0 = o.rel > 0 ? o.rel : 0;
     const int64_t wlen = (int64_t)min(L, G - (uint64_t)s0);
-    mycells = L * (unsigned long long)wlen;
+    mycells += L * (unsigned long long)wlen;
     const uint32_t cl = o.cigar_len;
     if (cl && (bw[i] >> 31)) {
       pool[pool_base + cig_off[i]] = (bw[i] & 0x7FFFFFFFu) << 4;   // <n>M
@@ -744,7 +773,8 @@ __global__ __launch_bounds__(256) void k_finalize(kslam_overlap *__restrict__ ov
     }
     o.ref_begin += (int32_t)s0;
     o.ref_end += (int32_t)s0;
-    ov[i] = o;
+  }
+  wave_store_records(ov, first, n, o, s_rec[threadIdx.x >> 6]);
   }
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) mycells += __shfl_down(mycells, d, 64);
@@ -757,25 +787,29 @@ __global__ __launch_bounds__(256) void k_finalize(kslam_overlap *__restrict__ ov
 // coordinates) before the cigar stage has run.  Same arithmetic as k_finalize below.
 __global__ __launch_bounds__(256) void k_final_coords(const kslam_overlap *__restrict__ ov, uint64_t n, SwInputs in,
                                                       kslam_overlap *__restrict__ out) {
+  __shared__ uint4 s_rec[4][192];
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  kslam_overlap o = ov[i];
-  const uint64_t L = in.read_off[o.read + 1] - in.read_off[o.read];
-  const uint64_t G = in.genome_off[o.entry + 1] - in.genome_off[o.entry];
-  const int64_t s0 = o.rel > 0 ? o.rel : 0;
-  const int64_t wlen = (int64_t)min(L, G - (uint64_t)s0);
-  if (o.revcomp) {
-    const int32_t rb = o.ref_begin, qb = o.query_begin;
-    o.ref_begin = (int32_t)(wlen - (int64_t)(o.ref_end + 1));
-    o.ref_end = (int32_t)(wlen - (int64_t)(rb + 1));
-    o.query_begin = (int32_t)((int64_t)L - (int64_t)(o.query_end + 1));
-    o.query_end = (int32_t)((int64_t)L - (int64_t)(qb + 1));
+  const uint64_t first = i - (threadIdx.x & 63u);   // the wave's first record (a wave is past the end as a whole or not at all)
+  if (first >= n) return;
+  kslam_overlap o = wave_load_records(ov, first, n, s_rec[threadIdx.x >> 6]);
+  if (i < n) {
+    const uint64_t L = in.read_off[o.read + 1] - in.read_off[o.read];
+    const uint64_t G = in.genome_off[o.entry + 1] - in.genome_off[o.entry];
+    const int64_t s0 = o.rel > 0 ? o.rel : 0;
+    const int64_t wlen = (int64_t)min(L, G - (uint64_t)s0);
+    if (o.revcomp) {
+      const int32_t rb = o.ref_begin, qb = o.query_begin;
+      o.ref_begin = (int32_t)(wlen - (int64_t)(o.ref_end + 1));
+      o.ref_end = (int32_t)(wlen - (int64_t)(rb + 1));
+      o.query_begin = (int32_t)((int64_t)L - (int64_t)(o.query_end + 1));
+      o.query_end = (int32_t)((int64_t)L - (int64_t)(qb + 1));
+    }
+    o.ref_begin += (int32_t)s0;
+    o.ref_end += (int32_t)s0;
+    o.cigar_len = 0;
+    o.cigar_off = 0;
   }
-  o.ref_begin += (int32_t)s0;
-  o.ref_end += (int32_t)s0;
-  o.cigar_len = 0;
-  o.cigar_off = 0;
-  out[i] = o;
+  wave_store_records(out, first, n, o, s_rec[threadIdx.x >> 6]);
 }
 // rows no alignment pair refers to: no cigar (neither the inline <n>M nor a banded one)
 __global__ void k_drop_unreferenced(kslam_overlap *__restrict__ ov, uint32_t *__restrict__ bw, const uint32_t *__restrict__ referenced,
@@ -894,15 +928,14 @@ void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, u
         // the tracebacks of this launch in a kernel of their own (KSLAM_CIGAR_TB=inline: at the end of the DP kernel)
         const bool tb_inline = tune.cigar_tb_inline;
         if (!tb_inline) {
-          W.tb_list.ensure(((uint64_t)J.m + 1) * sizeof(uint32_t));
-          J.tb_list = W.tb_list.as<uint32_t>();
-          J.tb_count = cnt + 10;
-          HIPCHK(hipMemsetAsync(J.tb_count, 0, sizeof(uint32_t), s));
+          W.tb_list.ensure((uint64_t)J.m + 64);
+          J.tb_flag = W.tb_list.as<uint8_t>();
+          HIPCHK(hipMemsetAsync(J.tb_flag, 0, J.m, s));
         }
         const unsigned nb_tb = (unsigned)(((uint64_t)J.m + 255) / 256);
 #define KSLAM_SYS(LMV, GLV, DPLV) \
   do { hipLaunchKernelGGL((k_cigar_systolic<LMV, GLV, DPLV, 128>), dim3(nb), dim3(128), 0, s, J, in, p); \
-       if (J.tb_list) hipLaunchKernelGGL((k_systolic_traceback<GLV, DPLV>), dim3(nb_tb), dim3(256), 0, s, J); } while (0)
+       if (J.tb_flag) hipLaunchKernelGGL((k_systolic_traceback<GLV, DPLV>), dim3(nb_tb), dim3(256), 0, s, J); } while (0)
 #define KSLAM_SYS_LM(GLV, DPLV) \
   do { if (lm == 0) KSLAM_SYS(160, GLV, DPLV); else if (lm == 1) KSLAM_SYS(256, GLV, DPLV); else KSLAM_SYS(512, GLV, DPLV); } while (0)
         if (GL == 16 && DPL == 16) KSLAM_SYS_LM(16, 16);
@@ -1083,7 +1116,7 @@ void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, u
 void cigar_finalize(kslam_overlap *d_ov, uint64_t n, SwInputs in, uint32_t lmax, CigarWork &W,
                     const uint32_t *d_bw, uint32_t *d_pool, uint64_t pool_base, uint64_t *d_cells, hipStream_t s) {
   if (n == 0) return;
-  const unsigned nb = (unsigned)((n + 255) / 256);
+  const unsigned nb = (unsigned)std::min<uint64_t>((n + 255) / 256, 256 * 8);
   hipLaunchKernelGGL(k_finalize, dim3(nb), dim3(256), 0, s, d_ov, n, in, W.cig_off.as<uint64_t>(),
                      W.tmp.as<uint32_t>(), CIG_CAP, W.tmp_big.as<uint32_t>(), 2 * lmax + 4,
                      W.big_pos.as<uint32_t>(), W.needbig.as<uint8_t>(), d_bw, d_pool, pool_base,

@@ -279,6 +279,78 @@ void export_rows(const kslam_overlap *d_rows, uint64_t n, uint64_t n_r1, uint32_
                  kslam_overlap *d_out_r1, kslam_overlap *d_out_r2, hipStream_t s);
 
 // ------------------------------------------------------------------ sw.hip
+// ---- 48-byte records, a wave at a time ----------------------------------------------------------------------------
+// kslam_overlap is 48 bytes and a thread that loads "its" record issues three 16-byte loads at a 48-byte stride: every
+// instruction of the wave touches 64 different pieces spread over 3 KB.  These helpers move the 64 records of a wave
+// (3072 contiguous bytes) with three fully coalesced 16-byte accesses per lane and transpose them through 3 KB of LDS
+// per wave.  All 64 lanes must call; records at or beyond n are not read / written (their lanes get zeros).
+static_assert(sizeof(kslam_overlap) == 48, "the record helpers move 48-byte records");
+__device__ inline kslam_overlap wave_load_records(const kslam_overlap *rows, uint64_t first, uint64_t n, uint4 *lds_wave) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint4 *src = reinterpret_cast<const uint4 *>(rows + first);
+  const uint64_t pieces = first < n ? (n - first < 64 ? (n - first) * 3 : 192) : 0;   // 16-byte pieces that exist
+#pragma unroll
+  for (uint32_t k = 0; k < 3; k++) {
+    const uint32_t x = lane + 64u * k;
+    lds_wave[x] = x < pieces ? src[x] : make_uint4(0u, 0u, 0u, 0u);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  union { uint4 q[3]; kslam_overlap o; } u;
+#pragma unroll
+  for (uint32_t k = 0; k < 3; k++) u.q[k] = lds_wave[3u * lane + k];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  return u.o;
+}
+__device__ inline void wave_store_records(kslam_overlap *rows, uint64_t first, uint64_t n, const kslam_overlap &mine, uint4 *lds_wave) {
+  const uint32_t lane = threadIdx.x & 63u;
+  union { uint4 q[3]; kslam_overlap o; } u;
+  u.o = mine;
+#pragma unroll
+  for (uint32_t k = 0; k < 3; k++) lds_wave[3u * lane + k] = u.q[k];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  uint4 *dst = reinterpret_cast<uint4 *>(rows + first);
+  const uint64_t pieces = first < n ? (n - first < 64 ? (n - first) * 3 : 192) : 0;
+#pragma unroll
+  for (uint32_t k = 0; k < 3; k++) {
+    const uint32_t x = lane + 64u * k;
+    if (x < pieces) dst[x] = lds_wave[x];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// the kept records of a wave into consecutive slots: lane `keep`s record `mine` for slot base + rank (rank = number of
+// kept lanes below it); `count` = kept lanes of the wave.  All 64 lanes must call.
+__device__ inline void wave_store_records_compact(kslam_overlap *rows, uint64_t base, uint32_t count, bool keep, uint32_t rank,
+                                                  const kslam_overlap &mine, uint4 *lds_wave) {
+  const uint32_t lane = threadIdx.x & 63u;
+  union { uint4 q[3]; kslam_overlap o; } u;
+  u.o = mine;
+  if (keep) {
+#pragma unroll
+    for (uint32_t k = 0; k < 3; k++) lds_wave[3u * rank + k] = u.q[k];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  uint4 *dst = reinterpret_cast<uint4 *>(rows + base);
+#pragma unroll
+  for (uint32_t k = 0; k < 3; k++) {
+    const uint32_t x = lane + 64u * k;
+    if (x < 3u * count) dst[x] = lds_wave[x];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 struct SwParams {
   int32_t match, mismatch, gap_open, gap_extend;
   uint32_t score_threshold;

@@ -254,19 +254,30 @@ __global__ void k_dedupe_flags(const uint64_t *__restrict__ keys, uint64_t n, ui
   }
 }
 
-__global__ void k_dedupe_compact(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ flags,
-                                 const uint32_t *__restrict__ pos, uint64_t n, OverlapKeyLayout lay,
-                                 uint32_t read_id_base, kslam_overlap *__restrict__ out) {
+__global__ __launch_bounds__(256) void k_dedupe_compact(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ flags,
+                                                        const uint32_t *__restrict__ pos, uint64_t n, OverlapKeyLayout lay,
+                                                        uint32_t read_id_base, kslam_overlap *__restrict__ out) {
+  __shared__ uint4 s_rec[4][192];
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n || !flags[i]) return;
-  const uint64_t k = keys[i];
+  const bool keep = i < n && flags[i];
+  const uint64_t kept = __ballot(keep);
+  if (!kept) return;   // (wave-uniform)
   kslam_overlap o;
   memset(&o, 0, sizeof o);
-  o.revcomp = (uint8_t)(k & 1u);
-  o.rel = (int32_t)((k >> 1) & ((1ull << lay.bits_rel) - 1)) - (int32_t)lay.rel_bias;
-  o.entry = (uint32_t)((k >> (lay.bits_rel + 1)) & ((1ull << lay.bits_entry) - 1));
-  o.read = (uint32_t)(k >> (lay.bits_entry + lay.bits_rel + 1)) + read_id_base;
-  out[pos[i]] = o;
+  uint32_t at = 0;
+  if (keep) {
+    const uint64_t k = keys[i];
+    o.revcomp = (uint8_t)(k & 1u);
+    o.rel = (int32_t)((k >> 1) & ((1ull << lay.bits_rel) - 1)) - (int32_t)lay.rel_bias;
+    o.entry = (uint32_t)((k >> (lay.bits_rel + 1)) & ((1ull << lay.bits_entry) - 1));
+    o.read = (uint32_t)(k >> (lay.bits_entry + lay.bits_rel + 1)) + read_id_base;
+    at = pos[i];
+  }
+  // the wave's survivors go to consecutive records: one coalesced burst (common.h)
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t base = (uint32_t)__shfl((int)at, (int)__builtin_ctzll(kept), 64);
+  wave_store_records_compact(out, base, (uint32_t)__popcll(kept), keep, (uint32_t)__popcll(kept & ((1ull << lane) - 1ull)), o,
+                             s_rec[threadIdx.x >> 6]);
 }
 
 }  // namespace

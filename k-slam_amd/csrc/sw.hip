@@ -1074,10 +1074,10 @@ __global__ __launch_bounds__(64) void k_sw_long(kslam_overlap *__restrict__ ov, 
 // candidate's score is what 16 (byte) or 8 (word) SSE lanes of segLen = ceil(readLen / lanes) cells each produce in that
 // order.  `SLAM --gap-open / --gap-extend` takes any value (src/main.cpp:44-55), so this kernel plays the lanes: one
 // wavefront per candidate, lane l < W is SSE lane l (the others idle), pvHStore / pvHLoad / pvE / pvHmax are LDS arrays of
-// segLen x W cells, the query profile is computed on the fly.  It follows oracle/kslam_oracle.c's striped_byte /
-// striped_word -- the restatement that tests/test_oracle.py holds to the real ssw.c on out-of-envelope scorings -- statement
-// by statement, and ssw_align's sequence (:870-923): byte pass, word pass when the byte pass saturates, reverse pass over
-// the reversed prefixes with `terminate = score1`.  Slow (~20 us of one wavefront per candidate) and exact.
+// segLen x W cells, the query profile is computed on the fly.  It follows sw_sse2_byte (src/ssw.c:143-383) and sw_sse2_word
+// (:408-592) statement by statement -- the tests hold it to the real ssw.c on scorings outside the envelope -- and
+// ssw_align's sequence (:870-923): byte pass, word pass when the byte pass saturates, reverse pass over the reversed
+// prefixes with `terminate = score1`.  Slow (~20 us of one wavefront per candidate) and exact.
 struct StripedEnd { int32_t score, ref, read; };
 
 template <int W>

@@ -124,6 +124,49 @@ def test_align_parity(kslam, oracle, synth, case):
     _compare_alignments(got, gcig, exp, ecig)
 
 
+def _revcomp(b):
+    return b[::-1].translate(bytes.maketrans(b"ACGT", b"TGCA"))
+
+
+@pytest.mark.parametrize("read_len", [150, 400])
+def test_wide_bands_every_cigar_bin(kslam, oracle, read_len):
+    """banded_sw starts at |refLen - readLen| + 1 (src/ssw.c:616) and doubles: reads with ONE long insertion ask for every
+    bin of the CIGAR stage (csrc/cigar.hip cig_bin: 1, 2, 3..4, 5..7, 8..15, 16..31, 32..63) and, at 400 bases, for the
+    generic loop beyond (bands of 64 and more, classes by floor(log2)); a second short indel elsewhere makes some attempts
+    fall short of the score so that bands double into the next bin.  Both strands; against the oracle."""
+    rng = np.random.default_rng(4242 + read_len)
+    g = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), 60000).tobytes()
+    genomes = [g[:30000], g[30000:]]
+    ins_lens = [1, 2, 3, 4, 5, 6, 7, 8, 11, 15, 16, 20, 31, 32, 40] if read_len == 150 else \
+               [1, 3, 7, 15, 16, 31, 32, 47, 62, 63, 64, 70, 100, 127, 128, 131]
+    reads = []
+    for I in ins_lens:
+        for rep in range(6):
+            a = int(rng.integers(100, 29000 - read_len))
+            src = genomes[rep & 1]
+            cut = int(rng.integers(read_len // 3, read_len // 2))
+            body = read_len - I
+            junk = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), I).tobytes()
+            r = src[a:a + cut] + junk + src[a + cut:a + body]
+            if rep >= 2:          # a second, short indel in the longer flank
+                at = cut + I + int(rng.integers(20, max(21, body - cut - 20)))
+                r = (r[:at] + r[at + 2:] + b"AC") if rep & 1 else (r[:at] + b"G" + r[at:-1])
+            assert len(r) == read_len
+            reads.append(r if rep % 3 else _revcomp(r))
+    got, gcig = kslam.align_to_database(reads, genomes)
+    exp, ecig, _ = oracle.align_to_database(reads, genomes, oracle.Params.default())
+    assert len(exp) >= len(reads) // 2
+    # the bins were really asked for: insertions of every length survive in the CIGARs
+    longest = 0
+    for i in range(len(exp)):
+        ops = ecig[int(exp["cigar_off"][i]):int(exp["cigar_off"][i]) + int(exp["cigar_len"][i])]
+        for o in ops:
+            if (int(o) & 15) == 1:
+                longest = max(longest, int(o) >> 4)
+    assert longest >= (32 if read_len == 150 else 100), longest
+    _compare_alignments(got, gcig, exp, ecig)
+
+
 def _sprinkle(rng, seqs, rate, alphabet):
     out = []
     for s in seqs:

@@ -129,6 +129,10 @@ def make_database(dev, gen, n_species, n_strains, length, n_viral=0, repeats=Fal
         db[offs[-1]:offs[-1] + total] = acgt[torch.randint(0, 4, (total,), generator=gen, device=dev)]
         base = offs[-1]
         offs.extend((base + np.cumsum(lens)).tolist())
+    # the library reads this tensor on ITS OWN stream (and its own copy of the HIP runtime): nothing orders torch's kernels
+    # before it, so the database must be complete when the caller gets it (a test that went straight on to
+    # set_index_device built its index from a half-written database once in eight runs)
+    torch.cuda.synchronize(dev)
     return db[:offs[-1]], np.array(offs, dtype=np.uint64)
 
 
@@ -222,6 +226,7 @@ def make_reads(dev, gen, db, offs, n_pairs, read_len=READ_LEN, sub_rate=0.01, in
         "rel": rel, "revcomp": is_b.to(torch.int64), "n_subs": n_subs,
         "has_indel": has, "seed_ok": seed_ok & mapped & ~has,
     }
+    torch.cuda.synchronize(dev)   # (see make_database: the library reads `out` on its own stream)
     return out, truth
 
 
@@ -358,6 +363,7 @@ def make_batch_in_pieces(dev, gen, db, offs, total_pairs, read_len, pieces=8, fi
         r2s.append(r[piece:])
     reads = torch.cat(r1s + r2s, 0).contiguous()
     truth = {k: torch.cat([t[k][:piece] for t in tr] + [t[k][piece:] for t in tr]) for k in tr[0]} if with_truth else None
+    torch.cuda.synchronize(dev)   # (see make_database)
     return reads, truth
 
 

@@ -24,6 +24,7 @@ def test_config1_full_batch_equals_the_oracle(kslam, oracle):
     gen.manual_seed(2)
     reads = W.make_reads(dev, gen, db, offs, PAIRS, read_len=150)
     ctx = kslam.Context()
+    torch.cuda.synchronize()   # torch wrote the database on its own stream
     ctx.set_index_device(n_entries, db.data_ptr(), offs)
     flat = reads.reshape(-1)
     ctx.load_reads_device(reads.shape[0], flat.data_ptr(), np.arange(reads.shape[0] + 1, dtype=np.uint64) * np.uint64(150))

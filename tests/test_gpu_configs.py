@@ -56,6 +56,7 @@ def _run_config(kslam, oracle, tmp_path, n_viral, read_len, by_length, pseudo):
     db, offs = W.make_database(dev, gen, SPECIES, STRAINS, GENOME_LEN, n_viral=n_viral)
     n_entries = len(offs) - 1
     ctx = kslam.Context()
+    torch.cuda.synchronize()   # torch wrote the database on its own stream
     ctx.set_index_device(n_entries, db.data_ptr(), offs)
     n_pairs = PAIRS
     reads, truth = W.make_batch_in_pieces(dev, gen, db, offs, n_pairs, read_len, by_length=by_length)

@@ -16,8 +16,8 @@
 // "sort" is a merge of the R1 and R2 rows with ties in input order (R1 first), and the two per-read-pair
 // std::sort calls are reproduced with the permutation libstdc++ produces (gnu_sort.h).
 //
-// MI355X: one thread per read pair.  A pair's rows are two short runs of the overlap array (found by
-// binary search), its alignment pairs go to a private region of 4 x (its rows) records -- pairing emits
+// MI355X: one thread per read pair.  A pair's rows are two short runs of the overlap array (found through
+// a first-row-per-read table, k_row_starts), its alignment pairs go to a private region of 4 x (its rows) records -- pairing emits
 // at most 2 per row, the insert-size screen at most doubles that -- so nothing is counted twice and no
 // thread waits for another; the survivors are compacted with two scans.  The insert sizes are appended
 // with one atomic per workgroup and sorted with the library's radix sort; quartiles and the percentile ladder
@@ -35,14 +35,6 @@ namespace {
 
 constexpr uint32_t NONE = 0xFFFFFFFFu;   // KSLAM_NO_OVERLAP
 using Rec = kslam_paired_overlap;
-
-__device__ inline uint64_t first_read_at_least(const kslam_overlap *ov, uint64_t lo, uint64_t hi, uint64_t read) {
-  while (lo < hi) {
-    const uint64_t m = (lo + hi) >> 1;
-    if (ov[m].read < read) lo = m + 1; else hi = m;
-  }
-  return lo;
-}
 
 __device__ inline Rec single_rec(const kslam_overlap &o, uint32_t idx, bool is_r1) {
   Rec r;

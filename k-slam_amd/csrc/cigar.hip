@@ -879,10 +879,10 @@ void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, u
     };
     // one attempt for the m candidates of W.list with the systolic kernel; false when the band is
     // too wide for it
-    // bit c: band class c (bw <= 2^c) runs on the systolic kernel.  Measured per class on the bench
-    // workload (one-lane kernel / systolic, ms): c3 2.2 / 1.4, c4 3.1 / 1.5, c5 2.1 / 0.2; the narrow
-    // classes, where 5 of 16 diagonal slots are live and the single-lane traceback dominates, stay
-    // on the one-lane kernel (c0-c2: 3.9 / 5.4).
+    // bit b: bin b (cig_bin) runs on the systolic kernel.  Measured on the bench workload: bins 0-2 (bands up to 4) are
+    // cheaper on the register kernel (5 of 16 diagonal slots live on the systolic one, 3.9 against 5.4 ms in round 2);
+    // bin 3 (bands 5..7) costs the same on both (register kernel <8> with mixed widths in a wave: 4.43 against 4.36 ms
+    // for the stage); a band of 16 in registers needs 256 VGPRs + AGPR spills and loses (5.3 ms).
     const int sys_mask = tune.cigar_sys_mask;
     struct Route {
       const uint32_t *list = nullptr;

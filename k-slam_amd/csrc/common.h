@@ -41,7 +41,7 @@ struct Tuning {
   bool sw_full = false;               // KSLAM_SW_FULL=1: every candidate on the full-matrix scoring kernel
   bool sw_no48 = false, sw_no96 = false;   // KSLAM_SW_NO48 / _NO96: drop a band tier
   int sw_unknown_nd = 0;              // KSLAM_SW_UNKNOWN_ND: where gapped candidates start (0: by read length)
-  int cigar_sys_mask = 0xF8;          // KSLAM_CIGAR_SYS: band classes that run on the systolic kernel
+  int cigar_sys_mask = 0xF8;          // KSLAM_CIGAR_SYS: band-width bins (cigar.hip: cig_bin) that run on the systolic kernel, one bit each
   bool cigar_reg = true;              // KSLAM_CIGAR_REG=0: no band-in-registers kernel
   bool cigar_dirs_lds = false;        // KSLAM_CIGAR_DIRS=lds: direction words in LDS
   bool cigar_tb_inline = false;       // KSLAM_CIGAR_TB=inline: systolic tracebacks at the end of the DP kernel

@@ -9,14 +9,15 @@
 // assignment h_b[edge] = e_b[edge] = 0 (ssw.c:655) that clobbers a live cell
 // when the band is clipped by the reference end -- the CIGAR depends on it.
 // Band doubling (ssw.c:693-694) is driven from the host: candidates are binned
-// by band class (bw <= 2^c), a class launch runs one attempt for each of its
-// candidates and failed ones move to the next class.
+// by band width (cig_bin below), a bin's launch runs one attempt for each of its
+// candidates and a failed one moves to the bin of its doubled band.
 //
-// MI355X design: O(L * band) scalar work per candidate (about 1 % of the DP
-// cells of the scoring passes), so one candidate per lane.  Each wavefront owns
-// a scratch slab laid out [element][lane]: lanes run the same row/column loop
-// in near lock step, so the row arrays and the 1-byte-per-cell direction matrix
-// are touched with coalesced 64-lane accesses that stay in L2.
+// MI355X design: three implementations of one attempt that leave the same direction
+// bits -- the band in registers, one candidate per lane (bands up to 4 / 7); a candidate
+// over 8 or 16 lanes swept by anti-diagonals like the scoring kernels (bands up to 127);
+// the literal row arrays in LDS, one candidate per lane (the rest).  Direction bits go to a
+// slab in global memory packed along band diagonals, six cells per word, so that the
+// traceback -- a chain of dependent loads -- takes a whole run of matches per word.
 #include "common.h"
 #include "banded_core.h"
 #include "stage.h"

@@ -649,7 +649,7 @@ void align_resident(kslam_ctx *c, bool stop_after_join, uint64_t *n_raw_out, Pai
       // rerun once with the exact size if it was too small
       c->totals.ensure(8 * sizeof(uint64_t));
       d_tot = c->totals.as<uint64_t>();
-      uint64_t cap = std::max<uint64_t>(c->kept_last + c->kept_last / 4, nk_all / 12) + 4096;
+      uint64_t cap = std::max<uint64_t>(c->kept_last + c->kept_last / 4, nk_all / 8) + 4096;   // (a context's first batch: 10.6 % of the k-mers of reads that come from the database survive the filter; / 12 meant a rerun)
       cap = std::min(cap, nk_all);
       // the extraction also writes the first radix pass's digit of every survivor (radix_sort.hip: digit bytes)
       const bool with_digits = c->tune.sort_digit_bytes && kpasses.size() > 1 && kpasses[0].word < 2 && !kpasses[0].invert;

@@ -53,11 +53,14 @@ __device__ inline Rec single_rec(const kslam_overlap &o, uint32_t idx, bool is_r
 // thread per row fills the entries between its predecessor's read and its own -- k_pair then finds a read pair's two runs
 // with four loads instead of four binary searches of 23 dependent probes each (0.7 of its 1.2 ms).
 __global__ void k_row_starts(const kslam_overlap *__restrict__ ov, uint64_t n, uint64_t n_reads, uint32_t *__restrict__ row_start,
-                             uint4 *__restrict__ gaps, uint32_t *__restrict__ n_gaps) {
+                             uint4 *__restrict__ gaps, uint32_t *__restrict__ n_gaps, uint32_t *__restrict__ bad) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i > n) return;
   const int64_t prev = i > 0 ? (int64_t)ov[i - 1].read : -1;
   const int64_t cur = min(i < n ? (int64_t)ov[i].read : (int64_t)n_reads, (int64_t)n_reads);
+  // rows that are not sorted by read, or name a read the batch does not have (a caller's own rows, kslam_pair_screen_rows):
+  // the table would have holes; the host fails the call (k_pair clamps what it reads, so nothing is touched out of bounds)
+  if (prev > cur || (i < n && (uint64_t)ov[i].read >= n_reads)) atomicOr(bad, 1u);
   if (cur - prev > 64) {   // a long stretch of reads without rows (an empty result: all of them): k_fill_gaps, in parallel
     gaps[atomicAdd(n_gaps, 1u)] = make_uint4((uint32_t)(prev + 1), (uint32_t)cur, (uint32_t)i, 0u);
     return;
@@ -96,9 +99,10 @@ __global__ __launch_bounds__(256) void k_pair(PairArgs a) {
   if (u < a.units) {
     const kslam_overlap *ov = a.ov;
     if (a.paired) {
-      const uint64_t split = a.row_start[a.mid];
-      uint64_t i = a.row_start[u], i1 = a.row_start[u + 1];
-      uint64_t j = a.row_start[a.mid + u], j1 = a.row_start[a.mid + u + 1];
+      const uint64_t split = min<uint64_t>(a.row_start[a.mid], a.n);
+      uint64_t i = min<uint64_t>(a.row_start[u], split), i1 = min<uint64_t>(max<uint64_t>(a.row_start[u + 1], i), split);
+      uint64_t j = min<uint64_t>(max<uint64_t>(a.row_start[a.mid + u], split), a.n),
+               j1 = min<uint64_t>(max<uint64_t>(a.row_start[a.mid + u + 1], j), a.n);   // (clamps: see k_row_starts)
       const uint64_t base = 4 * (i + (j - split));
       a.base[u] = base;
       out = a.recs + base;
@@ -158,7 +162,7 @@ __global__ __launch_bounds__(256) void k_pair(PairArgs a) {
       if (open) close_run();
     } else {
       // getPerReadOverlaps (single end) + dummy pairs: every overlap of the read as an R1-only record
-      uint64_t i = a.row_start[u], i1 = a.row_start[u + 1];
+      uint64_t i = min<uint64_t>(a.row_start[u], a.n), i1 = min<uint64_t>(max<uint64_t>(a.row_start[u + 1], i), a.n);
       const uint64_t base = 4 * i;
       a.base[u] = base;
       out = a.recs + base;
@@ -819,8 +823,10 @@ void pair_phase_a(const kslam_overlap *d_ov, uint64_t n, const uint32_t *d_read_
   W.row_start.ensure((n_reads + 2) * sizeof(uint32_t));
   W.gaps.ensure((n_reads / 64 + 2) * sizeof(uint4));   // stretches of more than 64 reads without rows: at most that many
   uint32_t *d_ngaps = reinterpret_cast<uint32_t *>(tot + 11);
+  HIPCHK(hipMemsetAsync(W.row_start.p, 0, (n_reads + 2) * sizeof(uint32_t), s));   // (unsorted rows leave holes: zeros, not stale numbers)
+  uint32_t *d_bad = reinterpret_cast<uint32_t *>(tot + 7);
   hipLaunchKernelGGL(k_row_starts, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, s, d_ov, n, n_reads, W.row_start.as<uint32_t>(),
-                     W.gaps.as<uint4>(), d_ngaps);
+                     W.gaps.as<uint4>(), d_ngaps, d_bad);
   hipLaunchKernelGGL(k_fill_gaps, dim3(64), dim3(256), 0, s, W.gaps.as<uint4>(), d_ngaps, W.row_start.as<uint32_t>());
   PairArgs a;
   a.ov = d_ov; a.n = n; a.row_start = W.row_start.as<uint32_t>(); a.read_len = d_read_len; a.units = units; a.mid = mid;
@@ -832,9 +838,10 @@ void pair_phase_a(const kslam_overlap *d_ov, uint64_t n, const uint32_t *d_read_
   a.n_initial = reinterpret_cast<unsigned long long *>(tot + 6);
   const unsigned nb = (unsigned)((units + 255) / 256);
   hipLaunchKernelGGL(k_pair, dim3(nb), dim3(256), 0, s, a);
-  uint64_t h[3];
+  uint64_t h[4];
   HIPCHK(hipMemcpyAsync(h, tot + 4, sizeof h, hipMemcpyDeviceToHost, s));
   HIPCHK(stream_wait(s));
+  if (h[3]) throw StatusError{KSLAM_ERR_ARG, "the overlap records are not sorted by read (or name reads the batch does not have)"};
   res->n_insert_sizes = h[0];
   res->n_overlaps_screened = h[1];
   res->n_paired_initial = h[2];

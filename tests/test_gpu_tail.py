@@ -287,6 +287,17 @@ def test_round2_entry_points_refuse_misuse_loudly(kslam, synth):
     ov = np.zeros(3, dtype=kslam.OVERLAP_DT)
     with pytest.raises(kslam.KslamError, match="even, non-zero number of reads"):
         c.pair_screen_overlaps(ov, np.full(3, 100, dtype=np.uint32), paired=True)
+    # a caller's own rows must come sorted by read and name reads of the batch: the first-row table has no place for others
+    ov = np.zeros(6, dtype=kslam.OVERLAP_DT)
+    ov["read"] = [0, 2, 1, 4, 5, 5]
+    ov["score"] = 100
+    with pytest.raises(kslam.KslamError, match="not sorted by read"):
+        c.pair_screen_overlaps(ov, np.full(6, 100, dtype=np.uint32), paired=True)
+    ov["read"] = [0, 1, 2, 4, 5, 9]
+    with pytest.raises(kslam.KslamError, match="not sorted by read"):
+        c.pair_screen_overlaps(ov, np.full(6, 100, dtype=np.uint32), paired=True)
+    ov["read"] = [0, 1, 2, 4, 5, 5]
+    assert c.pair_screen_overlaps(ov, np.full(6, 100, dtype=np.uint32), paired=True)["n_overlaps_screened"] == 6
     # the sort hook: descending segment bounds, a segment over the limit
     with pytest.raises(kslam.KslamError, match="segments must be ascending"):
         c.debug_wave_sort(np.zeros(10, dtype=np.int32), np.array([0, 8, 4, 10], dtype=np.uint64))

@@ -304,7 +304,8 @@ kslam_status kslam_pair_phase_b(kslam_ctx *ctx, const int32_t *d_all_inserts, ui
                                 uint64_t *n_pairs);
 kslam_status kslam_pseudo_merged(kslam_ctx *ctx, void *d_all_pairs, uint64_t n_all, uint64_t own_base,
                                  double score_fraction, kslam_pair_stats *stats);
-/* the same on overlap records and read lengths handed in from the host (stage-level parity tests) */
+/* the same on overlap records and read lengths handed in from the host (stage-level parity tests).  The records in
+ * alignToDatabase's order -- sorted by read (src/Overlap.h:87-98), reads numbered below n_reads --, else KSLAM_ERR_ARG */
 kslam_status kslam_pair_screen_overlaps(kslam_ctx *ctx, const kslam_overlap *overlaps, uint64_t n_overlaps,
                                         const uint32_t *read_lens, uint64_t n_reads, int paired,
                                         uint32_t score_threshold, double score_fraction,

@@ -89,9 +89,79 @@ struct PairArgs {
   uint64_t *base;          // per unit: where its region starts
   int32_t *inserts;        // n x 2 of room
   unsigned long long *n_inserts, *n_kept, *n_initial;
+  uint32_t *big_list, *n_big;   // read pairs left to k_pair_big (nullptr: none are)
 };
 
-// getPairsFromRead as a streaming state (host/tail.cpp: Pairer): one candidate slot per (mate, strand)
+// getPairsFromRead as a streaming state (host/tail.cpp: Pairer): one candidate slot per (mate, strand).  The rows
+// [i, i1) of mate 1 and [j, j1) of mate 2 are merged by (entry, rel), ties in input order (R1 first); every record goes to
+// emit(const Rec &).  Runs of different entries do not interact (the slots are emptied when the entry changes), so walking
+// ONE entry's rows of the two mates gives exactly that entry's records: k_pair_big below does that, a lane per entry.
+template <class Emit>
+__device__ inline uint32_t pair_walk(const kslam_overlap *__restrict__ ov, uint64_t i, uint64_t i1, uint64_t j, uint64_t j1, uint32_t thr,
+                                     const uint32_t *__restrict__ read_len, Emit &&emit) {
+  uint32_t kept = 0;
+  uint32_t slot[2][2] = {{NONE, NONE}, {NONE, NONE}};
+  bool used[2][2] = {{false, false}, {false, false}};
+  bool open = false;
+  uint32_t cur_entry = 0;
+  auto emit_single = [&](uint32_t idx, bool is_r1) { emit(single_rec(ov[idx], idx, is_r1)); };
+  auto close_run = [&]() {   // the order of src/PairedOverlap.h:217-240
+    if (!used[1][0] && slot[1][0] != NONE) emit_single(slot[1][0], false);
+    if (!used[1][1] && slot[1][1] != NONE) emit_single(slot[1][1], false);
+    if (!used[0][0] && slot[0][0] != NONE) emit_single(slot[0][0], true);
+    if (!used[0][1] && slot[0][1] != NONE) emit_single(slot[0][1], true);
+    for (int m = 0; m < 2; m++)
+      for (int s = 0; s < 2; s++) { slot[m][s] = NONE; used[m][s] = false; }
+  };
+  while (i < i1 || j < j1) {
+    bool take1;
+    if (j >= j1) take1 = true;
+    else if (i >= i1) take1 = false;
+    else {
+      const kslam_overlap &x = ov[i], &y = ov[j];
+      take1 = x.entry != y.entry ? x.entry < y.entry : x.rel <= y.rel;
+    }
+    const uint32_t idx = (uint32_t)(take1 ? i++ : j++);
+    const kslam_overlap o = ov[idx];
+    if (o.score < thr) continue;   // src/Overlap.h:329-341
+    kept++;
+    if (open && o.entry != cur_entry) close_run();
+    open = true;
+    cur_entry = o.entry;
+    const int s = o.revcomp ? 1 : 0, m = take1 ? 0 : 1;
+    if (!used[m][s] && slot[m][s] != NONE) emit_single(slot[m][s], m == 0);
+    slot[m][s] = idx;
+    used[m][s] = false;
+    const uint32_t other = slot[1 - m][1 - s];
+    if (other != NONE) {   // makePair, src/PairedOverlap.h:107-125
+      const uint32_t i1x = m == 0 ? idx : other, i2x = m == 0 ? other : idx;
+      const kslam_overlap &p = ov[i1x], &q = ov[i2x];
+      const bool r1_first = m != 0;
+      const uint32_t ins = r1_first ? (uint32_t)((int64_t)q.rel - p.rel + read_len[q.read])
+                                    : (uint32_t)((int64_t)p.rel - q.rel + read_len[p.read]);
+      Rec r;
+      r.combined_score = (uint16_t)(p.score + q.score);   // PairedOverlap's uint16_t parameter
+      r.entry = q.entry;
+      r.ref_start = min(p.ref_begin, q.ref_begin);
+      r.ref_end = max(p.ref_end, q.ref_end);
+      r.insert_size = ins;
+      r.r1 = i1x;
+      r.r2 = i2x;
+      r.pad = 0;
+      emit(r);
+      used[m][s] = true;
+      used[1 - m][1 - s] = true;
+    }
+  }
+  if (open) close_run();
+  return kept;
+}
+
+// Read pairs with more than PAIR_BIG rows (reads inside an rRNA-like repeat meet every genome of the database: ~17 000 rows a
+// pair) are left to k_pair_big: one thread walking them record by record, a dependent 48-byte gather each, was 11 ms of the
+// repeat-rich bench's 75 ms step -- the longest thread's time, the chip waiting.
+constexpr uint32_t PAIR_BIG = 256;
+
 __global__ __launch_bounds__(256) void k_pair(PairArgs a) {
   const uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t n_recs = 0, kept = 0;
@@ -106,60 +176,12 @@ __global__ __launch_bounds__(256) void k_pair(PairArgs a) {
       const uint64_t base = 4 * (i + (j - split));
       a.base[u] = base;
       out = a.recs + base;
-      uint32_t slot[2][2] = {{NONE, NONE}, {NONE, NONE}};
-      bool used[2][2] = {{false, false}, {false, false}};
-      bool open = false;
-      uint32_t cur_entry = 0;
-      auto emit_single = [&](uint32_t idx, bool is_r1) { out[n_recs++] = single_rec(ov[idx], idx, is_r1); };
-      auto close_run = [&]() {   // the order of src/PairedOverlap.h:217-240
-        if (!used[1][0] && slot[1][0] != NONE) emit_single(slot[1][0], false);
-        if (!used[1][1] && slot[1][1] != NONE) emit_single(slot[1][1], false);
-        if (!used[0][0] && slot[0][0] != NONE) emit_single(slot[0][0], true);
-        if (!used[0][1] && slot[0][1] != NONE) emit_single(slot[0][1], true);
-        for (int m = 0; m < 2; m++)
-          for (int s = 0; s < 2; s++) { slot[m][s] = NONE; used[m][s] = false; }
-      };
-      while (i < i1 || j < j1) {
-        bool take1;
-        if (j >= j1) take1 = true;
-        else if (i >= i1) take1 = false;
-        else {
-          const kslam_overlap &x = ov[i], &y = ov[j];
-          take1 = x.entry != y.entry ? x.entry < y.entry : x.rel <= y.rel;
-        }
-        const uint32_t idx = (uint32_t)(take1 ? i++ : j++);
-        const kslam_overlap o = ov[idx];
-        if (o.score < a.thr) continue;   // src/Overlap.h:329-341
-        kept++;
-        if (open && o.entry != cur_entry) close_run();
-        open = true;
-        cur_entry = o.entry;
-        const int s = o.revcomp ? 1 : 0, m = take1 ? 0 : 1;
-        if (!used[m][s] && slot[m][s] != NONE) emit_single(slot[m][s], m == 0);
-        slot[m][s] = idx;
-        used[m][s] = false;
-        const uint32_t other = slot[1 - m][1 - s];
-        if (other != NONE) {   // makePair, src/PairedOverlap.h:107-125
-          const uint32_t i1x = m == 0 ? idx : other, i2x = m == 0 ? other : idx;
-          const kslam_overlap &p = ov[i1x], &q = ov[i2x];
-          const bool r1_first = m != 0;
-          const uint32_t ins = r1_first ? (uint32_t)((int64_t)q.rel - p.rel + a.read_len[q.read])
-                                        : (uint32_t)((int64_t)p.rel - q.rel + a.read_len[p.read]);
-          Rec r;
-          r.combined_score = (uint16_t)(p.score + q.score);   // PairedOverlap's uint16_t parameter
-          r.entry = q.entry;
-          r.ref_start = min(p.ref_begin, q.ref_begin);
-          r.ref_end = max(p.ref_end, q.ref_end);
-          r.insert_size = ins;
-          r.r1 = i1x;
-          r.r2 = i2x;
-          r.pad = 0;
-          out[n_recs++] = r;
-          used[m][s] = true;
-          used[1 - m][1 - s] = true;
-        }
+      if ((i1 - i) + (j1 - j) > PAIR_BIG && a.big_list) {   // a wavefront's job: count[u], the inserts and the counters come from k_pair_big
+        a.big_list[atomicAdd(a.n_big, 1u)] = (uint32_t)u;
+        out = nullptr;
+      } else {
+        kept = pair_walk(ov, i, i1, j, j1, a.thr, a.read_len, [&](const Rec &r) { out[n_recs++] = r; });
       }
-      if (open) close_run();
     } else {
       // getPerReadOverlaps (single end) + dummy pairs: every overlap of the read as an R1-only record
       uint64_t i = min<uint64_t>(a.row_start[u], a.n), i1 = min<uint64_t>(max<uint64_t>(a.row_start[u + 1], i), a.n);
@@ -173,7 +195,7 @@ __global__ __launch_bounds__(256) void k_pair(PairArgs a) {
         out[n_recs++] = single_rec(o, (uint32_t)i, true);
       }
     }
-    a.count[u] = n_recs;
+    if (out) a.count[u] = n_recs;
   }
   // insert sizes of this thread's records, appended with ONE returning atomic per workgroup (and one each for the
   // two counters): same-address atomics take ~12 ns apiece on this chip whoever issues them, and one per wave --
@@ -210,6 +232,125 @@ __global__ __launch_bounds__(256) void k_pair(PairArgs a) {
   unsigned long long at = s_base + before + (incl - n_ins);
   for (uint32_t k = 0; k < n_recs; k++)
     if (out[k].insert_size != 0) a.inserts[at++] = (int32_t)out[k].insert_size;
+}
+
+// first row in [lo, hi) whose entry is not below e
+__device__ inline uint64_t first_entry_at_least(const kslam_overlap *__restrict__ ov, uint64_t lo, uint64_t hi, uint32_t e) {
+  while (lo < hi) {
+    const uint64_t m = (lo + hi) >> 1;
+    if (ov[m].entry < e) lo = m + 1; else hi = m;
+  }
+  return lo;
+}
+
+// One big read pair by one wavefront.  A lane takes an ENTRY: the entry's rows of mate 1 (found where a run of equal entries
+// starts in the mate's row range) and of mate 2 (binary search), walked by pair_walk -- first to count the entry's records,
+// then, after a scan of the counts over the merged row order (an entry's first merged position is (rows of mate 1 with a
+// smaller entry) + (rows of mate 2 with a smaller entry)), to write them where the one-thread walk puts them.  The counts
+// live in the upper half of the read pair's own record region (4 records of room per row, at most 2 used).
+__global__ __launch_bounds__(64) void k_pair_big(PairArgs a) {
+  const uint32_t lane = threadIdx.x;
+  const uint32_t n_big = *a.n_big;
+  const kslam_overlap *ov = a.ov;
+  for (uint32_t b = blockIdx.x; b < n_big; b += gridDim.x) {
+    const uint64_t u = a.big_list[b];
+    const uint64_t split = min<uint64_t>(a.row_start[a.mid], a.n);
+    const uint64_t i = min<uint64_t>(a.row_start[u], split), i1 = min<uint64_t>(max<uint64_t>(a.row_start[u + 1], i), split);
+    const uint64_t j = min<uint64_t>(max<uint64_t>(a.row_start[a.mid + u], split), a.n),
+                   j1 = min<uint64_t>(max<uint64_t>(a.row_start[a.mid + u + 1], j), a.n);
+    const uint64_t n1 = i1 - i, n2 = j1 - j, nm = n1 + n2;
+    Rec *out = a.recs + a.base[u];
+    uint32_t *cnt = reinterpret_cast<uint32_t *>(out + 2 * nm);   // (nm + 1) counts in the unused upper half of the region
+    for (uint64_t k = lane; k <= nm; k += 64) cnt[k] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    // an entry of the pair, as seen from a row: (mate-1 rows, mate-2 rows, first merged position); false: not this row's job
+    auto entry_of_row = [&](uint64_t k, uint64_t *a1, uint64_t *b1, uint64_t *a2, uint64_t *b2, uint64_t *pos) -> bool {
+      if (k < n1) {                        // a row of mate 1: the head of its entry's run there
+        const uint64_t r = i + k;
+        const uint32_t e = ov[r].entry;
+        if (r > i && ov[r - 1].entry == e) return false;
+        uint64_t z = r + 1;
+        while (z < i1 && ov[z].entry == e) z++;
+        *a1 = r; *b1 = z;
+        *a2 = first_entry_at_least(ov, j, j1, e);
+        *b2 = *a2;
+        while (*b2 < j1 && ov[*b2].entry == e) (*b2)++;
+      } else {                             // a row of mate 2: only entries mate 1 does not have
+        const uint64_t r = j + (k - n1);
+        const uint32_t e = ov[r].entry;
+        if (r > j && ov[r - 1].entry == e) return false;
+        const uint64_t lb = first_entry_at_least(ov, i, i1, e);
+        if (lb < i1 && ov[lb].entry == e) return false;
+        uint64_t z = r + 1;
+        while (z < j1 && ov[z].entry == e) z++;
+        *a1 = lb; *b1 = lb; *a2 = r; *b2 = z;
+      }
+      *pos = (*a1 - i) + (*a2 - j);
+      return true;
+    };
+    uint32_t kept = 0;
+    for (uint64_t k0 = 0; k0 < nm; k0 += 64) {
+      const uint64_t k = k0 + lane;
+      uint64_t a1, b1, a2, b2, pos;
+      if (k < nm && entry_of_row(k, &a1, &b1, &a2, &b2, &pos)) {
+        uint32_t c = 0;
+        kept += pair_walk(ov, a1, b1, a2, b2, a.thr, a.read_len, [&](const Rec &) { c++; });
+        cnt[pos] = c;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    // exclusive scan of the counts in merged row order
+    uint32_t carry = 0;
+    for (uint64_t k0 = 0; k0 < nm; k0 += 64) {
+      const uint64_t k = k0 + lane;
+      const uint32_t c = k < nm ? cnt[k] : 0u;
+      uint32_t incl = c;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(incl, d, 64);
+        if (lane >= (uint32_t)d) incl += t;
+      }
+      if (k < nm) cnt[k] = carry + incl - c;
+      carry += __shfl(incl, 63, 64);
+    }
+    const uint32_t n_recs = carry;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    for (uint64_t k0 = 0; k0 < nm; k0 += 64) {
+      const uint64_t k = k0 + lane;
+      uint64_t a1, b1, a2, b2, pos;
+      if (k < nm && entry_of_row(k, &a1, &b1, &a2, &b2, &pos)) {
+        uint32_t at = cnt[pos];
+        (void)pair_walk(ov, a1, b1, a2, b2, a.thr, a.read_len, [&](const Rec &r) { out[at++] = r; });
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    // the counters and the non-zero insert sizes (their order does not matter: the statistics sort them)
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) kept += __shfl_down(kept, d, 64);
+    if (lane == 0) {
+      a.count[u] = n_recs;
+      if (kept) atomicAdd(a.n_kept, (unsigned long long)kept);
+      if (n_recs) atomicAdd(a.n_initial, (unsigned long long)n_recs);
+    }
+    for (uint32_t k0 = 0; k0 < n_recs; k0 += 64) {
+      const uint32_t k = k0 + lane;
+      const uint32_t ins = k < n_recs ? out[k].insert_size : 0u;
+      const uint64_t m = __ballot(ins != 0);
+      if (!m) continue;
+      unsigned long long at = 0;
+      if (lane == 0) at = atomicAdd(a.n_inserts, (unsigned long long)__popcll(m));
+      at = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(at >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)at);
+      if (ins != 0) a.inserts[at + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (int32_t)ins;
+    }
+  }
 }
 
 __global__ void k_widen(const int32_t *__restrict__ v, uint64_t n, uint2 *__restrict__ out) {
@@ -836,8 +977,13 @@ void pair_phase_a(const kslam_overlap *d_ov, uint64_t n, const uint32_t *d_read_
   a.n_inserts = reinterpret_cast<unsigned long long *>(tot + 4);
   a.n_kept = reinterpret_cast<unsigned long long *>(tot + 5);
   a.n_initial = reinterpret_cast<unsigned long long *>(tot + 6);
+  // read pairs with very many rows: listed by k_pair, done by k_pair_big (a fixed grid walks the list: no count comes back)
+  W.picked.ensure((units + 1) * sizeof(uint32_t));
+  a.big_list = paired ? W.picked.as<uint32_t>() : nullptr;
+  a.n_big = reinterpret_cast<uint32_t *>(tot + 3);
   const unsigned nb = (unsigned)((units + 255) / 256);
   hipLaunchKernelGGL(k_pair, dim3(nb), dim3(256), 0, s, a);
+  if (paired) hipLaunchKernelGGL(k_pair_big, dim3(2048), dim3(64), 0, s, a);
   uint64_t h[4];
   HIPCHK(hipMemcpyAsync(h, tot + 4, sizeof h, hipMemcpyDeviceToHost, s));
   HIPCHK(stream_wait(s));

@@ -247,7 +247,7 @@ __device__ inline uint64_t first_entry_at_least(const kslam_overlap *__restrict_
 // starts in the mate's row range) and of mate 2 (binary search), walked by pair_walk -- first to count the entry's records,
 // then, after a scan of the counts over the merged row order (an entry's first merged position is (rows of mate 1 with a
 // smaller entry) + (rows of mate 2 with a smaller entry)), to write them where the one-thread walk puts them.  The counts
-// live in the upper half of the read pair's own record region (4 records of room per row, at most 2 used).
+// and the entries' bounds live in the upper half of the read pair's own record region (4 records of room per row, at most 2 used).
 __global__ __launch_bounds__(64) void k_pair_big(PairArgs a) {
   const uint32_t lane = threadIdx.x;
   const uint32_t n_big = *a.n_big;
@@ -290,14 +290,30 @@ __global__ __launch_bounds__(64) void k_pair_big(PairArgs a) {
       *pos = (*a1 - i) + (*a2 - j);
       return true;
     };
-    uint32_t kept = 0;
+    // the rows that speak for an entry, compacted (one row in seven does: walking the rows themselves left most lanes idle),
+    // with the entry's four bounds; both in the unused upper half of the region as well
+    uint4 *bounds = reinterpret_cast<uint4 *>(out + 3 * nm);   // 16 bytes per head, at most nm heads: bytes 96 nm .. 112 nm of the region's 128 nm (the counts: 64 nm .. 68 nm)
+    uint32_t n_heads = 0;
     for (uint64_t k0 = 0; k0 < nm; k0 += 64) {
       const uint64_t k = k0 + lane;
-      uint64_t a1, b1, a2, b2, pos;
-      if (k < nm && entry_of_row(k, &a1, &b1, &a2, &b2, &pos)) {
+      uint64_t a1 = 0, b1 = 0, a2 = 0, b2 = 0, pos = 0;
+      const bool head = k < nm && entry_of_row(k, &a1, &b1, &a2, &b2, &pos);
+      const uint64_t m = __ballot(head);
+      if (head) bounds[n_heads + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] =
+          make_uint4((uint32_t)(a1 - i), (uint32_t)(b1 - a1), (uint32_t)(a2 - j), (uint32_t)(b2 - a2));
+      n_heads += (uint32_t)__popcll(m);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    uint32_t kept = 0;
+    for (uint32_t h0 = 0; h0 < n_heads; h0 += 64) {
+      const uint32_t h = h0 + lane;
+      if (h < n_heads) {
+        const uint4 e = bounds[h];
         uint32_t c = 0;
-        kept += pair_walk(ov, a1, b1, a2, b2, a.thr, a.read_len, [&](const Rec &) { c++; });
-        cnt[pos] = c;
+        kept += pair_walk(ov, i + e.x, i + e.x + e.y, j + e.z, j + e.z + e.w, a.thr, a.read_len, [&](const Rec &) { c++; });
+        cnt[e.x + e.z] = c;
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -321,12 +337,12 @@ __global__ __launch_bounds__(64) void k_pair_big(PairArgs a) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    for (uint64_t k0 = 0; k0 < nm; k0 += 64) {
-      const uint64_t k = k0 + lane;
-      uint64_t a1, b1, a2, b2, pos;
-      if (k < nm && entry_of_row(k, &a1, &b1, &a2, &b2, &pos)) {
-        uint32_t at = cnt[pos];
-        (void)pair_walk(ov, a1, b1, a2, b2, a.thr, a.read_len, [&](const Rec &r) { out[at++] = r; });
+    for (uint32_t h0 = 0; h0 < n_heads; h0 += 64) {
+      const uint32_t h = h0 + lane;
+      if (h < n_heads) {
+        const uint4 e = bounds[h];
+        uint32_t at = cnt[e.x + e.z];
+        (void)pair_walk(ov, i + e.x, i + e.x + e.y, j + e.z, j + e.z + e.w, a.thr, a.read_len, [&](const Rec &r) { out[at++] = r; });
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");

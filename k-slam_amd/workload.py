@@ -51,6 +51,12 @@ def viral_lengths(dev, gen, n_viral, min_len=5_000, max_len=200_000):
 RRNA_LEN, RRNA_COPIES, IS_LEN, IS_COPIES = 1500, 5, 1300, 2
 
 
+def _sync(dev):
+    """the generators' tensors are complete when they return (a CPU device has nothing to wait for)"""
+    if torch.device(dev).type == "cuda":
+        torch.cuda.synchronize(dev)
+
+
 def make_database(dev, gen, n_species, n_strains, length, n_viral=0, repeats=False):
     """Species x strains database as ONE device byte tensor + host offsets.
     Strains derive from the species root by 1-3 % substitutions + sparse 1-10 bp indels.
@@ -132,7 +138,7 @@ def make_database(dev, gen, n_species, n_strains, length, n_viral=0, repeats=Fal
     # the library reads this tensor on ITS OWN stream (and its own copy of the HIP runtime): nothing orders torch's kernels
     # before it, so the database must be complete when the caller gets it (a test that went straight on to
     # set_index_device built its index from a half-written database once in eight runs)
-    torch.cuda.synchronize(dev)
+    _sync(dev)
     return db[:offs[-1]], np.array(offs, dtype=np.uint64)
 
 
@@ -226,7 +232,7 @@ def make_reads(dev, gen, db, offs, n_pairs, read_len=READ_LEN, sub_rate=0.01, in
         "rel": rel, "revcomp": is_b.to(torch.int64), "n_subs": n_subs,
         "has_indel": has, "seed_ok": seed_ok & mapped & ~has,
     }
-    torch.cuda.synchronize(dev)   # (see make_database: the library reads `out` on its own stream)
+    _sync(dev)   # (see make_database: the library reads `out` on its own stream)
     return out, truth
 
 
@@ -363,7 +369,7 @@ def make_batch_in_pieces(dev, gen, db, offs, total_pairs, read_len, pieces=8, fi
         r2s.append(r[piece:])
     reads = torch.cat(r1s + r2s, 0).contiguous()
     truth = {k: torch.cat([t[k][:piece] for t in tr] + [t[k][piece:] for t in tr]) for k in tr[0]} if with_truth else None
-    torch.cuda.synchronize(dev)   # (see make_database)
+    _sync(dev)   # (see make_database)
     return reads, truth
 
 

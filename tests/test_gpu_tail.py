@@ -62,6 +62,32 @@ def test_device_pairing_and_screens_equal_the_host_tail(kslam, T, ctx, seed, pai
         assert got["max_insert_size"] == st.max_insert_size and got["n_insert_sizes"] == st.n_insert_sizes
 
 
+@pytest.mark.parametrize("seed,entries,per_read,stages", [(21, 300, 400.0, 3), (22, 1200, 700.0, 3), (23, 60, 500.0, 1)])
+def test_read_pairs_that_meet_every_entry(kslam, T, ctx, seed, entries, per_read, stages):
+    """What a read inside an rRNA-like repeat looks like: hundreds of rows per mate, a few per entry, over hundreds of
+    entries -- the shape k_pair_big is for (a wavefront per read pair, a lane per entry; csrc/pairs.hip), incl. entries only
+    one mate has.  Read pairs and alignment pairs == the host tail's, byte for byte."""
+    from test_tail import _fuzz_overlaps
+    rng = np.random.default_rng(300 + seed)
+    ov, n_reads = _fuzz_overlaps(kslam, rng, 60, entries, per_read=per_read, paired=True)
+    # some entries lose one mate's rows altogether (the mate-2-only path of the kernel, and mate-1-only runs)
+    drop = (rng.random(len(ov)) < 0.25) & ((ov["entry"] % 5 == 1) == (ov["read"] < n_reads // 2))
+    ov = ov[~drop]
+    reads = T.Reads([b"A" * 100] * n_reads)
+    P = T.TailParams.default(paired=True, report_cigar=False, threads=4, score_threshold=60, score_fraction=0.9,
+                             pseudo_assembly=False, stages=stages)
+    rp, pr, st = T.tail_pairs(P, reads, ov)
+    got = ctx.pair_screen_overlaps(ov, np.full(n_reads, 100, dtype=np.uint32), paired=True, score_threshold=60,
+                                   score_fraction=0.9, stages=stages)
+    grp, gpr = ctx.take_pairs()
+    per_unit = np.bincount(ov["read"] % (n_reads // 2), minlength=n_reads // 2)
+    assert per_unit.max() > 256 and len(pr) > 500
+    assert grp.tobytes() == rp.tobytes() and gpr.tobytes() == pr.tobytes()
+    assert got["n_overlaps_screened"] == st.n_overlaps_screened and got["n_paired_initial"] == st.n_paired_initial
+    if stages & 1:
+        assert got["max_insert_size"] == st.max_insert_size and got["n_insert_sizes"] == st.n_insert_sizes
+
+
 def test_wave_sort_produces_the_std_sort_permutation(kslam, ctx, tmp_path):
     """csrc/wave_gnu_sort.h (std::sort by one wavefront: parallel Hoare partition, per-leaf insertion sorts)
     against the real std::sort of this toolchain on ~3 000 arrays: every size from 0 to 300, sizes up to the

@@ -39,6 +39,10 @@ while time.time() < t_end:
     n_entries = int(rng.choice([1, 2, 5, 12, 40, 300, 3000]))
     per_read = float(rng.choice([1.0, 3.0, 8.0, 20.0]))
     n_units = int(rng.choice([300, 2000, 6000]))
+    if rng.random() < 0.25:         # reads inside a repeat: hundreds of rows a mate over many entries (k_pair_big, k_screen_big)
+        n_entries = int(rng.choice([12, 60, 300, 1500]))
+        per_read = float(rng.choice([150.0, 400.0, 800.0]))
+        n_units = int(rng.choice([30, 80]))
     thr = int(rng.choice([0, 0, 150, 185]))
     frac = float(rng.choice([0.95, 0.95, 0.8, 0.5, 1.0]))
     stages = int(rng.choice([7, 7, 7, 3, 5, 6, 4]))

@@ -55,6 +55,7 @@ struct Tuning {
   bool lane_waits_yield = false;      // KSLAM_LANE_WAITS=yield: the pipeline lanes poll + sleep instead of busy-waiting for the GPU (stream_wait)
   bool pageable_columns = false;      // KSLAM_PAGEABLE_COLUMNS
   bool details_in_token = true;       // KSLAM_DETAILS_IN_TOKEN=0 (A/B): the per-row walk outside the lanes' compute token
+  int plan_blocks_per_cu = 64;        // KSLAM_PLAN_BLOCKS: workgroups of k_sw_plan per CU (its waves walk through the candidates)
   int pseudo_cap = 0;                 // KSLAM_PSEUDO_CAP (tests): alignment pairs of one entry beyond which pseudo-assembly is left to the host; 0 = 262144
 #ifdef KSLAM_ABLATE
   uint32_t sw_ablate = 0, cigar_variant = 0, filter_ablate = 0;   // KSLAM_SW_ABLATE / _CIGAR_VARIANT / _FILTER_ABLATE

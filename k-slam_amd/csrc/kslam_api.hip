@@ -174,6 +174,7 @@ Tuning read_tuning() {
   t.sw_unknown_nd = num("KSLAM_SW_UNKNOWN_ND", 0);
   t.cigar_sys_mask = num("KSLAM_CIGAR_SYS", 0xF8);
   t.cigar_reg = !starts("KSLAM_CIGAR_REG", '0');
+  t.plan_blocks_per_cu = std::min(256, std::max(1, num("KSLAM_PLAN_BLOCKS", 64)));
   t.cigar_dirs_lds = starts("KSLAM_CIGAR_DIRS", 'l');
   t.cigar_tb_inline = starts("KSLAM_CIGAR_TB", 'i');
   t.bucket_bits_max = std::min(28, std::max(8, num("KSLAM_BUCKET_BITS", 27)));

@@ -1351,7 +1351,7 @@ void sw_scores(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, uint32_
     for (int k = 0; k < T.n; k++) T.list[k] = W.tier_list[k].as<uint32_t>();
     T.full_list = W.list.as<uint32_t>();
     T.counts = counts;
-    const unsigned pb = (unsigned)std::min<uint64_t>((n + 31) / 32, 256 * 64);   // its waves walk through the candidates, ~16 octets each
+    const unsigned pb = (unsigned)std::min<uint64_t>((n + 31) / 32, 256 * (uint64_t)tune.plan_blocks_per_cu);   // its waves walk through the candidates
     if (lm == 0) hipLaunchKernelGGL(k_sw_plan<160>, dim3(pb), dim3(256), 0, s, d_ov, n, in, p, T, tier, d_band0);
     else if (lm == 1) hipLaunchKernelGGL(k_sw_plan<256>, dim3(pb), dim3(256), 0, s, d_ov, n, in, p, T, tier, d_band0);
     else hipLaunchKernelGGL(k_sw_plan<512>, dim3(pb), dim3(256), 0, s, d_ov, n, in, p, T, tier, d_band0);

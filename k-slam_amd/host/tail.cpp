@@ -1490,6 +1490,8 @@ struct kslam_sam_writer {
   std::atomic<int> error{0};           // errno of the first failed write
   uint64_t bytes = 0;
   double write_s = 0;
+  double starved_s = 0;                // with an empty queue, after the first block (KSLAM_DEBUG prints it at close)
+  uint64_t blocks = 0;
   // Tried and removed (round 4): copying a batch into a shared MAPPING of the file's next region with four threads, to get
   // around the inode lock that serialises write() into one file (11 GB/s here: 37-41 ms per 404 MB batch).  On the bench
   // boxes' file system the write faults cost far more than the lock: 150-200 ms per batch against 45 (13 against 45 M reads/s).
@@ -1499,7 +1501,10 @@ struct kslam_sam_writer {
       std::vector<Text> set;
       {
         std::unique_lock<std::mutex> lk(m);
+        const double tw = now_ms();
+        const bool was_empty = queue.empty();
         cv.wait(lk, [&] { return stop || !queue.empty(); });
+        if (was_empty && blocks && !queue.empty()) starved_s += (now_ms() - tw) * 1e-3;
         if (queue.empty()) return;
         set = std::move(queue.front());
         queue.pop_front();
@@ -1532,6 +1537,7 @@ struct kslam_sam_writer {
       {
         std::lock_guard<std::mutex> lk(m);
         bytes += done;
+        blocks++;
         write_s += (now_ms() - t0) * 1e-3;
         busy = false;
         if (!borrowed && spare.size() < 3) spare.push_back(std::move(set));
@@ -1970,6 +1976,9 @@ kslam_status kslam_sam_writer_close(kslam_sam_writer *w, uint64_t *bytes_written
   w->cv.notify_all();
   if (w->th.joinable()) w->th.join();      // drains the queue first
   const int err = w->error;
+  if (getenv("KSLAM_DEBUG"))
+    fprintf(stderr, "[kslam] SAM writer: %llu blocks, %.1f MB, %.1f ms in write(), %.1f ms with an empty queue after its first block\n",
+            (unsigned long long)w->blocks, w->bytes / 1e6, w->write_s * 1e3, w->starved_s * 1e3);
   if (bytes_written) *bytes_written = w->bytes;
   if (seconds_writing) *seconds_writing = w->write_s;
   delete w;

@@ -507,6 +507,10 @@ def main():
     ap.add_argument("--strong", action="store_true",
                     help="configs[3] shape: ONE batch of --total-pairs pairs per step, split over the GPUs (default when --gpus > 1)")
     ap.add_argument("--weak", action="store_true", help="with --gpus > 1: --pairs fresh pairs per GPU instead (hot path only)")
+    ap.add_argument("--comm", choices=["auto", "kslam", "torch"], default="auto",
+                    help="who moves the data between the ranks: kslam = the library's own RCCL path behind the C ABI (include/kslam_comm.h, "
+                         "what a C++ host links: librccl opened by the library, no PyTorch in the transfers); torch = torch.distributed "
+                         "(k-slam_amd/dist.py, the same protocol); auto = kslam when its communicator comes up on every rank, else torch")
     ap.add_argument("--total-pairs", type=int, default=10_000_000,
                     help="pairs per batch in --strong mode (the reference's --num-reads-at-once default, src/main.cpp:56)")
     args = ap.parse_args()
@@ -551,6 +555,7 @@ def main():
 
     K = entry.load_package()
     kdist = importlib.import_module("kslam_amd.dist")
+    Cm = importlib.import_module("kslam_amd.comm")
     T = importlib.import_module("kslam_amd.tail")
     X = importlib.import_module("kslam_amd.taxonomy")
     S = importlib.import_module("kslam_amd.stream")
@@ -611,12 +616,57 @@ def main():
     tax_text, entry_tax = W.taxonomy(args.species, args.strains, n_viral)
     index_view = T.IndexArrays(np.zeros(1, dtype=np.uint8), offs, taxonomy_ids=entry_tax)   # no host copy of the database
 
+    # ---- who moves the data: the library's own communicator (RCCL behind the C ABI) or torch.distributed ----
+    comm, comm_why = None, None
+
+    def make_comm(c):
+        """kslam_comm on context c, on every rank or on none: rank 0's unique id travels through the process group that exists
+        anyway, and the ranks agree on the outcome before anybody uses it"""
+        box, ok = [None], 1
+        if rank == 0:
+            try:
+                box[0] = Cm.unique_id()
+            except K.KslamError as e:
+                box[0] = "error: %s" % e
+        dist.broadcast_object_list(box, src=0)
+        got = None
+        if isinstance(box[0], bytes):
+            try:
+                got = Cm.Comm(c, box[0], rank, world)
+            except K.KslamError as e:
+                ok, box[0] = 0, "error: %s" % e
+        else:
+            ok = 0
+        t = torch.tensor([ok], dtype=torch.int64, device=cdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        if int(t[0]) == 0:
+            if got is not None:
+                got.close()
+            return None, (box[0] if isinstance(box[0], str) else "another rank could not create its communicator")
+        return got, None
+    if use_dist and strong and args.comm != "torch":
+        if share and not os.environ.get("KSLAM_RCCL_LIB"):
+            comm_why = "ranks share a GPU (RCCL refuses two ranks on one device) and KSLAM_RCCL_LIB names no stand-in"
+        else:
+            comm, comm_why = make_comm(ctx)
+        if comm is None and args.comm == "kslam":
+            raise SystemExit("--comm kslam: %s" % comm_why)
+
     pending = []   # the gather of the previous batch, still in flight while this one is aligned
     merged = {}    # rank 0, --strong: the batch-global result of the last finished batch (device tensors)
 
     def drain():
         while pending:
-            got = kdist.finish_gather(pending.pop())
+            h = pending.pop()
+            if h == "kslam_comm":
+                # kslam_comm_gather_end: the transfers have landed; rank 0's arrays are the communicator's (no copy: valid until
+                # the gather after the next one)
+                d_rows, n_rows, d_pool, n_ops = comm.gather_end()
+                if rank == 0:
+                    merged["ov"] = torch.as_tensor(kdist._DevView(d_rows, max(n_rows, 1) * 48), device=dev)[:n_rows * 48]
+                    merged["cg"] = torch.as_tensor(kdist._DevView(d_pool, max(n_ops, 1) * 4), device=dev)[:n_ops * 4]
+                continue
+            got = kdist.finish_gather(h)
             if strong and rank == 0:
                 # every transfer landed in its final place (kslam_amd.dist.start_gather_sharded): rank 0
                 # now HOLDS the batch-global result in the reference's order, and ran no kernel for it
@@ -637,7 +687,11 @@ def main():
             # one starts and before the clock stops.
             drain()
             tc = time.perf_counter()
-            pending.append(kdist.start_gather_sharded(ctx, n_reads // 2, pair_lo, args.total_pairs, dev))
+            if comm is not None:
+                comm.gather_begin(n_reads // 2, pair_lo, args.total_pairs)       # counts, export, one group of ncclSend / ncclRecv posted
+                pending.append("kslam_comm")
+            else:
+                pending.append(kdist.start_gather_sharded(ctx, n_reads // 2, pair_lo, args.total_pairs, dev))
             split["wait_for_previous_gather"] += tc - tb
             split["counts_export_post"] += time.perf_counter() - tc
         elif use_dist:
@@ -866,6 +920,10 @@ def main():
                           "alignment_pairs_per_batch": tail_out["alignment_pairs"], "max_insert_size": tail_out["max_insert_size"],
                           "pseudo_assembly_on": tail_out["pseudo_on"],
                           "sam_file_bytes": os.path.getsize(sam_path), "per_read_file_bytes": os.path.getsize(pr_path)}
+            if os.path.getsize(sam_path) < (1 << 30):      # small runs (the tests): the files' checksums, to compare lines of different runs
+                import zlib
+                classified["sam_file_crc32"] = zlib.crc32(open(sam_path, "rb").read())
+                classified["per_read_file_crc32"] = zlib.crc32(open(pr_path, "rb").read())
 
         # ================= third clock: the tail SHARDED like the alignment =================
         # every rank: align its pairs -> pairing on its own rows -> all-gather of the insert sizes (the limit is a statistic
@@ -892,6 +950,12 @@ def main():
         ctx_b.load_reads_device(n_reads, reads.data_ptr(), roffs)
         ctx_b.load_qualities_device(qual_loc.data_ptr())
         sh_ctx = (ctx, ctx_b)
+        comm_b = None
+        if comm is not None:
+            comm_b, why_b = make_comm(ctx_b)     # the two contexts take the steps in turn: a communicator each
+            if comm_b is None:
+                raise SystemExit("a second kslam_comm could not be created: %s" % why_b)
+        sh_comm = (comm, comm_b)
         sh_ms = {"align": 0.0, "pairing_gathers_pseudo": 0.0, "row_details": 0.0, "download_on_worker": 0.0, "host_sam_and_lca": 0.0}
         sh_out = {"moved": 0}
         # the SAM records and per-read lines written on each rank's GPU (include/kslam_samtext.h); KSLAM_HOST_SAM_TEXT=1: on its CPUs
@@ -959,7 +1023,10 @@ def main():
                 t1 = time.perf_counter()
                 c.align_resident()
                 t2 = time.perf_counter()
-                if use_dist:
+                if use_dist and sh_comm[i & 1] is not None:
+                    pst, moved = sh_comm[i & 1].sharded_tail(True, 0, 0.95, True)     # kslam_comm_sharded_tail
+                    sh_out["moved"] = moved
+                elif use_dist:
                     pst, moved = kdist.sharded_tail(c, dev, True, 0, 0.95, True)
                     sh_out["moved"] = moved
                 else:
@@ -1027,7 +1094,8 @@ def main():
                 parts_ok = parts_ok and once + once == open(full, "rb").read()
             classified["sharded"] = {
                 "elapsed": el3, "repetitions_ms_per_step": sh_reps, "ms_per_step_max_over_ranks": {k: round(v / args.steps * 1e3, 2) for k, v in sh_max.items()},
-                "bytes_all_gathered_per_rank_per_step": int(sh_out["moved"]), "pseudo_assembly_on": sh_out["pseudo_on"],
+                "bytes_received_from_other_ranks_per_step": int(sh_out["moved"]), "pseudo_assembly_on": sh_out["pseudo_on"],
+                "pseudo_assembly_form": "entries partitioned over the ranks (entry e on rank e mod N): all-to-all of 16-byte heads, 4-byte scores back",
                 "host_threads_per_rank": host_threads, "cgroup_throttled_ms": None if thr0 is None or thr1 is None else round(thr1 - thr0, 1),
                 "max_insert_size": sh_out["max_insert_size"],
                 "part_files_in_rank_order_equal_rank0_files": bool(parts_ok)}
@@ -1047,6 +1115,8 @@ def main():
             except OSError:
                 pass
         taxdb_s.close()
+        if comm_b is not None:
+            comm_b.close()
         ctx_b.close()
 
     # RCCL announces itself on stdout through C stdio ("Librccl path : ..."), buffered when piped and
@@ -1059,6 +1129,18 @@ def main():
         pass
     if use_dist:
         dist.barrier()
+
+    comm_facts = None
+    if comm is not None:
+        # what RCCL itself reports on every rank: ncclCommCount / ncclCommUserRank / the device / the library that was opened
+        mine = comm.info()
+        t = torch.tensor([mine["comm_count"], mine["comm_rank"], mine["device"], mine["rccl_version"]], dtype=torch.int64, device=cdev)
+        allf = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allf, t)
+        comm_facts = {"ncclCommCount_per_rank": [int(a[0]) for a in allf], "ncclCommUserRank_per_rank": [int(a[1]) for a in allf],
+                      "device_per_rank": [int(a[2]) for a in allf], "ncclGetVersion": mine["rccl_version"], "library": mine["library"]}
+        comm.close()
+        comm = "closed"
 
     if rank == 0:
         Ksteps = args.steps
@@ -1153,7 +1235,9 @@ def main():
             "setup_s": {"generate": round(t_gen, 2), "index_build": round(t_index, 2)},
         }
         if use_dist:
-            out["rccl"] = {"backend": dist.get_backend(), "world": world, "ranks_seen": ranks_seen,
+            out["rccl"] = {"data_path": "kslam_comm (include/kslam_comm.h: RCCL opened by the library, behind the C ABI)" if comm == "closed"
+                           else "torch.distributed (k-slam_amd/dist.py)", "data_path_why": comm_why, "kslam_comm": comm_facts,
+                           "backend": dist.get_backend(), "world": world, "ranks_seen": ranks_seen,
                            "bytes_gathered_per_step": int(merged["ov"].numel() + merged["cg"].numel()) if "ov" in merged else 0,
                            "launched_by": os.environ.get("KSLAM_BENCH_LAUNCHED_BY", "external launcher (torch.distributed.run)"),
                            "shared_gpu": bool(share)}
@@ -1176,7 +1260,8 @@ def main():
             out["value_definition"] = (
                 "K steps of ONE batch of --total-pairs read pairs, sharded over the ranks and CLASSIFIED where they are: every "
                 "rank aligns its read pairs (resident in its HBM), pairs them, all-gathers the insert sizes (the limit is a "
-                "statistic of the whole batch) and the alignment-pair records (pseudo-assembly is per entry over all read pairs) "
+                "statistic of the whole batch), sends the 16-byte heads of its alignment-pair records to the ranks that own their "
+                "entries (pseudo-assembly is per entry over all read pairs: entry e on rank e mod N) and gets the scores back "
                 "over RCCL, screens, and writes the SAM text and the per-read LCA of ITS read pairs into its part files (the "
                 "parts in rank order are the files: verified_classified); max over ranks.  classified_rank0_tail: the same "
                 "result with the overlap records gathered to rank 0 and the whole tail there (the Amdahl form); "

@@ -304,6 +304,26 @@ kslam_status kslam_pair_phase_b(kslam_ctx *ctx, const int32_t *d_all_inserts, ui
                                 uint64_t *n_pairs);
 kslam_status kslam_pseudo_merged(kslam_ctx *ctx, void *d_all_pairs, uint64_t n_all, uint64_t own_base,
                                  double score_fraction, kslam_pair_stats *stats);
+/* pseudoAssembly with the ENTRIES partitioned over the `world` ranks instead (what include/kslam_comm.h and
+ * k-slam_amd/dist.py run): the stage is independent per entry (src/PairedOverlap.h:495-574 -- one bucket per entry, one
+ * walk per bucket), so entry e belongs to rank e mod world alone; 1 / world of the stage's work per rank, and 16 + 4
+ * bytes per alignment pair travelling instead of world x 32.  After kslam_pair_phase_b on every rank:
+ *   kslam_pseudo_route   *d_heads = this rank's records as 16-byte heads {combined_score, entry, ref_start, ref_end} (the
+ *                        first half of kslam_paired_overlap), stably partitioned by entry mod world: counts[d] heads for
+ *                        rank d, destination after destination (device memory, valid until the next route)
+ *   <all-to-all: rank d lays the pieces it receives end to end in SOURCE-RANK order -- read-pair order, the reference's
+ *    bucket iteration order (:486-493), which the tie order of its std::sort by refStart depends on>
+ *   kslam_pseudo_owned   the stage on the n heads received (modified in place); *d_scores = their combined scores
+ *                        afterwards, in the same order.  KSLAM_ERR_UNSUPPORTED when an entry is too large for the device
+ *                        path: every rank must then leave the batch's stage to the host (kslam_comm.h exchanges a status
+ *                        word so that all ranks fail together)
+ *   <all-to-all back: the same pieces, 4 bytes per head, to where they came from, in sending order>
+ *   kslam_pseudo_return  the n = sum(counts) scores into this rank's records, second score screen (src/SLAM.h:226-227)
+ * The result equals kslam_pseudo_merged's and one context's (tests/test_gpu_multi.py, tests/test_gpu_tail.py). */
+kslam_status kslam_pseudo_route(kslam_ctx *ctx, uint32_t world, const void **d_heads, uint64_t *counts);
+kslam_status kslam_pseudo_owned(kslam_ctx *ctx, void *d_heads, uint64_t n, const uint32_t **d_scores);
+kslam_status kslam_pseudo_return(kslam_ctx *ctx, const uint32_t *d_scores, uint64_t n, double score_fraction,
+                                 kslam_pair_stats *stats);
 /* the same on overlap records and read lengths handed in from the host (stage-level parity tests).  The records in
  * alignToDatabase's order -- sorted by read (src/Overlap.h:87-98), reads numbered below n_reads --, else KSLAM_ERR_ARG */
 kslam_status kslam_pair_screen_overlaps(kslam_ctx *ctx, const kslam_overlap *overlaps, uint64_t n_overlaps,

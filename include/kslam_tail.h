@@ -172,7 +172,8 @@ typedef struct kslam_sam_writer kslam_sam_writer;
 kslam_status kslam_sam_writer_open(int fd, kslam_sam_writer **out);
 int kslam_write_queued(void *user, const char *data, uint64_t len);
 /* text another stage produced (the GPU formatter's page-locked block, include/kslam_samtext.h) joins the queue as it is, in
- * order with everything else; release(user, data) is called once it has been written.  Blocks while two batches wait. */
+ * order with everything else; release(user, data) is called once it has been written.  Blocks while two batches wait.
+ * The block is consumed on EVERY path: a failing call (null writer, an earlier write error) releases it before it returns. */
 kslam_status kslam_sam_writer_enqueue(kslam_sam_writer *writer, char *data, uint64_t len,
                                       void (*release)(void *user, void *data), void *user);
 kslam_status kslam_sam_writer_close(kslam_sam_writer *writer, uint64_t *bytes_written, double *seconds_writing);

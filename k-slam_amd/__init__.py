@@ -44,7 +44,7 @@ EXPORTS = ["kslam_abi_version", "kslam_version", "kslam_check_std_sort", "kslam_
            "kslam_align_batch_async", "kslam_wait_batch", "kslam_load_qualities", "kslam_load_qualities_device",
            "kslam_row_details", "kslam_take_row_details", "kslam_free_pinned", "kslam_submit_batch",
            "kslam_submit_batch_columns", "kslam_submit_batch_fastq", "kslam_submit_batch_fastq_text", "kslam_collect_batch", "kslam_release_batch", "kslam_host_alloc",
-           "kslam_host_free", "kslam_pair_screen", "kslam_pair_phase_a", "kslam_pair_phase_b", "kslam_pseudo_merged", "kslam_pair_screen_overlaps", "kslam_take_pairs", "kslam_set_pairing", "kslam_debug_wave_sort", "kslam_row_details_of_pairs",
+           "kslam_host_free", "kslam_pair_screen", "kslam_pair_phase_a", "kslam_pair_phase_b", "kslam_pseudo_merged", "kslam_pseudo_route", "kslam_pseudo_owned", "kslam_pseudo_return", "kslam_pair_screen_overlaps", "kslam_take_pairs", "kslam_set_pairing", "kslam_debug_wave_sort", "kslam_row_details_of_pairs",
            "kslam_load_reads", "kslam_load_reads_device", "kslam_align_resident",
            "kslam_fetch_results", "kslam_take_results", "kslam_copy_results_device", "kslam_get_timings",
            "kslam_extract_kmers", "kslam_sort_kmers", "kslam_find_overlaps", "kslam_free",
@@ -152,6 +152,9 @@ def lib():
         L.kslam_pair_phase_a.argtypes = [vp, C.c_int, u32, C.POINTER(vp), C.POINTER(u64)]
         L.kslam_pair_phase_b.argtypes = [vp, vp, u64, C.c_double, u32, C.POINTER(PairStats), C.POINTER(vp), C.POINTER(u64)]
         L.kslam_pseudo_merged.argtypes = [vp, vp, u64, u64, C.c_double, C.POINTER(PairStats)]
+        L.kslam_pseudo_route.argtypes = [vp, u32, C.POINTER(vp), C.POINTER(u64)]
+        L.kslam_pseudo_owned.argtypes = [vp, vp, u64, C.POINTER(vp)]
+        L.kslam_pseudo_return.argtypes = [vp, vp, u64, C.c_double, C.POINTER(PairStats)]
         L.kslam_pair_screen_overlaps.argtypes = [vp, vp, u64, vp, u64, C.c_int, u32, C.c_double, u32, C.POINTER(PairStats)]
         L.kslam_take_pairs.argtypes = [vp, C.POINTER(vp), C.POINTER(u64), C.POINTER(vp), C.POINTER(u64)]
         L.kslam_set_pairing.argtypes = [vp, C.c_int, u32, C.c_double, u32]
@@ -397,6 +400,24 @@ class Context:
         """kslam_pseudo_merged -> stats dict"""
         st = PairStats()
         self._chk(self._L.kslam_pseudo_merged(self._h, d_all_pairs, n_all, own_base, score_fraction, C.byref(st)))
+        return st.as_dict()
+
+    def pseudo_route(self, world):
+        """kslam_pseudo_route -> (device address of this rank's 16-byte heads partitioned by entry mod world, [heads per destination])"""
+        p, counts = C.c_void_p(), (C.c_uint64 * world)()
+        self._chk(self._L.kslam_pseudo_route(self._h, world, C.byref(p), counts))
+        return p.value or 0, [int(v) for v in counts]
+
+    def pseudo_owned(self, d_heads, n):
+        """kslam_pseudo_owned on n received heads -> device address of their n new scores (uint32)"""
+        p = C.c_void_p()
+        self._chk(self._L.kslam_pseudo_owned(self._h, d_heads, n, C.byref(p)))
+        return p.value or 0
+
+    def pseudo_return(self, d_scores, n, score_fraction=0.95):
+        """kslam_pseudo_return -> stats dict"""
+        st = PairStats()
+        self._chk(self._L.kslam_pseudo_return(self._h, d_scores, n, score_fraction, C.byref(st)))
         return st.as_dict()
 
     def pair_screen_overlaps(self, overlaps, read_lens, paired=True, score_threshold=0, score_fraction=0.95, stages=3):

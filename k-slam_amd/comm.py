@@ -7,9 +7,15 @@ import numpy as np
 from . import KslamError, PairStats, lib as _base_lib
 
 EXPORTS = ["kslam_comm_last_error", "kslam_comm_unique_id", "kslam_comm_create", "kslam_comm_destroy", "kslam_comm_rank",
-           "kslam_comm_world", "kslam_comm_gather_plan", "kslam_comm_gather_batch", "kslam_comm_sharded_tail"]
+           "kslam_comm_world", "kslam_comm_gather_plan", "kslam_comm_gather_batch", "kslam_comm_gather_begin", "kslam_comm_gather_end", "kslam_comm_sharded_tail", "kslam_comm_info"]
 ID_BYTES = 128
 _ready = False
+
+
+class CommFacts(C.Structure):
+    """kslam_comm_facts (include/kslam_comm.h)"""
+    _fields_ = [("comm_count", C.c_int32), ("comm_rank", C.c_int32), ("rccl_version", C.c_int32), ("device", C.c_int32),
+                ("library", C.c_char * 240)]
 
 
 class ShardCounts(C.Structure):
@@ -32,6 +38,9 @@ def lib():
         L.kslam_comm_gather_plan.restype = None
         L.kslam_comm_gather_batch.argtypes = [vp, u64, u64, u64, C.POINTER(vp), C.POINTER(u64), C.POINTER(vp), C.POINTER(u64)]
         L.kslam_comm_sharded_tail.argtypes = [vp, C.c_int, C.c_uint32, C.c_double, C.c_int, C.POINTER(PairStats), C.POINTER(u64)]
+        L.kslam_comm_gather_begin.argtypes = [vp, u64, u64, u64]
+        L.kslam_comm_gather_end.argtypes = [vp, C.POINTER(vp), C.POINTER(u64), C.POINTER(vp), C.POINTER(u64)]
+        L.kslam_comm_info.argtypes = [vp, C.POINTER(CommFacts)]
         _ready = True
     return L
 
@@ -71,11 +80,28 @@ class Comm:
             self._L.kslam_comm_destroy(self._h)
             self._h = C.c_void_p()
 
+    def info(self):
+        """kslam_comm_info -> what RCCL reports about this communicator"""
+        f = CommFacts()
+        _chk(self._L.kslam_comm_info(self._h, C.byref(f)))
+        return {"comm_count": int(f.comm_count), "comm_rank": int(f.comm_rank), "rccl_version": int(f.rccl_version),
+                "device": int(f.device), "library": f.library.decode(errors="replace")}
+
     def gather_batch(self, n_local_pairs, pair_lo, n_pairs_total):
         """-> rank 0: (device pointer of the rows, n_rows, device pointer of the pool, n_ops); elsewhere (None, 0, None, 0)"""
         rows, pool, n, m = C.c_void_p(), C.c_void_p(), C.c_uint64(), C.c_uint64()
         _chk(self._L.kslam_comm_gather_batch(self._h, n_local_pairs, pair_lo, n_pairs_total, C.byref(rows), C.byref(n),
                                              C.byref(pool), C.byref(m)))
+        return rows.value, int(n.value), pool.value, int(m.value)
+
+    def gather_begin(self, n_local_pairs, pair_lo, n_pairs_total):
+        """kslam_comm_gather_begin: counts, export, the transfers posted; the context is free for the next batch"""
+        _chk(self._L.kslam_comm_gather_begin(self._h, n_local_pairs, pair_lo, n_pairs_total))
+
+    def gather_end(self):
+        """kslam_comm_gather_end -> what gather_batch returns"""
+        rows, pool, n, m = C.c_void_p(), C.c_void_p(), C.c_uint64(), C.c_uint64()
+        _chk(self._L.kslam_comm_gather_end(self._h, C.byref(rows), C.byref(n), C.byref(pool), C.byref(m)))
         return rows.value, int(n.value), pool.value, int(m.value)
 
     def sharded_tail(self, paired=True, score_threshold=0, score_fraction=0.95, pseudo_assembly=True):

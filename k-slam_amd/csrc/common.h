@@ -67,6 +67,13 @@ Tuning read_tuning();   // kslam_api.hip
 struct DevBuf {
   void *p = nullptr;
   size_t cap = 0;
+  DevBuf() = default;
+  // freed with its owner: a buffer added to a work struct cannot be forgotten by kslam_destroy's list any more.  A
+  // copy-ASSIGNED DevBuf is a borrowed view (share_index): whoever borrows clears p before it goes away (kslam_destroy).
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  DevBuf(const DevBuf &) = delete;
+  DevBuf(DevBuf &&o) noexcept : p(o.p), cap(o.cap) { o.p = nullptr; o.cap = 0; }
+  DevBuf &operator=(const DevBuf &o) = default;
   void ensure(size_t bytes) {
     if (bytes <= cap) return;
     if (p) HIPCHK(hipFree(p));
@@ -427,6 +434,10 @@ void row_details(const kslam_overlap *d_ov, uint64_t n, const uint32_t *d_pool, 
 // --------------------------------------------------------------- pairs.hip
 struct PairWork {
   DevBuf recs, count, base, inserts, flags, gpos, rpos, scan_tmp, totals, groups, dense, sort_a, sort_b, idx, picked, row_list, row_start, gaps;
+  DevBuf route_a, route_b, route_heads, route_counts, route_scores;   // pseudo_route / pseudo_owned (entries partitioned over ranks)
+  const void *route_sorted = nullptr;   // {destination, record} of this rank's records in sending order (route_a or route_b)
+  uint64_t route_n = ~0ull;             // records routed by the last pseudo_route, ~0 when none is outstanding
+  uint32_t route_world = 0;
   uint64_t units = 0, mid = 0;   // between pair_phase_a and pair_phase_b: read pairs (or reads) of the batch, its R1 block
   uint32_t pseudo_cap = 0;       // 0 = the default (pairs.hip: PSEUDO_CAP_GLOBAL); tests lower it to reach the host fallback
   int paired = 0;
@@ -480,6 +491,12 @@ void referenced_rows(PairWork &W, const PairResult *res, uint64_t n_rows, const 
 // pseudoAssembly + the second score screen on pair_and_screen's result, in place; false (nothing changed)
 // when an entry has more spans than a workgroup's LDS holds: the host then runs that stage itself
 bool pseudo_and_rescreen(PairWork &W, PairResult *res, double score_fraction, SortWorkspace &sortws, hipStream_t s);
+// the same stage with the ENTRIES partitioned over the ranks of a sharded batch (pairs.hip, bottom): route -> all-to-all ->
+// owned -> all-to-all back -> return
+void pseudo_route(PairWork &W, const PairResult *res, uint32_t world, const void **d_heads, uint64_t *counts, SortWorkspace &sortws,
+                  hipStream_t s);
+bool pseudo_owned(PairWork &W, void *d_heads, uint64_t n, const uint32_t **d_scores, SortWorkspace &sortws, hipStream_t s);
+void pseudo_return(PairWork &W, PairResult *res, const uint32_t *d_scores, uint64_t n, double score_fraction, hipStream_t s);
 
 // test hook for wave_gnu_sort.h (kslam_debug_wave_sort)
 void debug_wave_sort(const int32_t *keys, const uint64_t *seg_off, uint64_t n_seg, uint32_t *perm, hipStream_t s);

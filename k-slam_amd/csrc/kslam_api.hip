@@ -1365,7 +1365,7 @@ void kslam_destroy(kslam_ctx *c) {
                       &c->fqw.id_len, &c->fqw.bases_off, &c->fqw.ids_off, &c->fqw.ids, &c->detw.lens, &c->detw.off,
                       &c->detw.slots, &c->detw.scan_tmp, &c->detw.totals, &c->detw.md_pool, &c->pw.recs, &c->pw.count, &c->pw.base,
                       &c->pw.inserts, &c->pw.flags, &c->pw.gpos, &c->pw.rpos, &c->pw.scan_tmp, &c->pw.totals, &c->pw.groups,
-                      &c->pw.dense, &c->pw.sort_a, &c->pw.sort_b, &c->pw.idx, &c->pw.picked, &c->pr_ov, &c->pr_len, &c->mg_shards, &c->mg_lens, &c->mg_off, &c->mg_scan};
+                      &c->pw.dense, &c->pw.sort_a, &c->pw.sort_b, &c->pw.idx, &c->pw.picked, &c->pw.row_list, &c->pw.row_start, &c->pw.gaps, &c->pr_ov, &c->pr_len, &c->mg_shards, &c->mg_lens, &c->mg_off, &c->mg_scan};
     for (DevBuf *b : bufs) b->release();
     for (auto &b : c->annot_bufs) b.release();
     DevBuf *sam_bufs[] = {&c->samw.plan, &c->samw.cnt_vals, &c->samw.cnt_segs, &c->samw.val_off, &c->samw.seg_off, &c->samw.scan_tmp,
@@ -1741,6 +1741,7 @@ kslam_status kslam_pair_phase_a(kslam_ctx *c, int paired, uint32_t score_thresho
       throw StatusError{KSLAM_ERR_ARG, "paired data needs an even, non-zero number of reads ([R1 block | R2 block])"};
     if (c->n_res >= (1ull << 30)) throw StatusError{KSLAM_ERR_UNSUPPORTED, "2^30 or more overlaps in one batch"};
     c->have_pairs = c->pairs_of_result = c->phase_a_done = false;
+    c->pw.route_n = ~0ull;
     pair_phase_a(c->res_ov.as<kslam_overlap>(), c->n_res, c->r_len.as<uint32_t>(), c->n_reads, paired ? 1 : 0, score_threshold, c->pw,
                  &c->pres, c->stream);
     HIPCHK(stream_wait(c->stream));
@@ -1777,6 +1778,37 @@ kslam_status kslam_pseudo_merged(kslam_ctx *c, void *d_all_pairs, uint64_t n_all
     if (!pseudo_merged(c->pw, &c->pres, d_all_pairs, n_all, own_base, score_fraction, c->sortws, c->stream))
       throw StatusError{KSLAM_ERR_UNSUPPORTED, "the batch-global pseudo-assembly declined (2^28 or more alignment pairs in one batch): "
                                                "nothing was changed; gather the pairs on one host and run kslam_tail_finish_prepare there"};
+    HIPCHK(stream_wait(c->stream));
+    fill_pair_stats(c->pres, stats);
+  });
+}
+
+kslam_status kslam_pseudo_route(kslam_ctx *c, uint32_t world, const void **d_heads, uint64_t *counts) {
+  return guarded(c, [&] {
+    if (!d_heads || !counts) throw StatusError{KSLAM_ERR_ARG, "null argument"};
+    if (!(c->have_pairs && c->pairs_of_result)) throw StatusError{KSLAM_ERR_STATE, "kslam_pair_phase_b has not been called for this result"};
+    pseudo_route(c->pw, &c->pres, world, d_heads, counts, c->sortws, c->stream);
+    HIPCHK(stream_wait(c->stream));
+  });
+}
+
+kslam_status kslam_pseudo_owned(kslam_ctx *c, void *d_heads, uint64_t n, const uint32_t **d_scores) {
+  return guarded(c, [&] {
+    require_std_sort_parity();
+    if (!d_scores || (n && !d_heads)) throw StatusError{KSLAM_ERR_ARG, "null argument"};
+    if (!pseudo_owned(c->pw, d_heads, n, d_scores, c->sortws, c->stream))
+      throw StatusError{KSLAM_ERR_UNSUPPORTED, "the pseudo-assembly of this rank's entries declined (an entry with more than 262144 alignment pairs, or "
+                                               "2^28 or more of them on one rank): nothing was changed; every rank must give the batch's stage to the host"};
+    HIPCHK(stream_wait(c->stream));
+  });
+}
+
+kslam_status kslam_pseudo_return(kslam_ctx *c, const uint32_t *d_scores, uint64_t n, double score_fraction, kslam_pair_stats *stats) {
+  return guarded(c, [&] {
+    if (!(c->have_pairs && c->pairs_of_result)) throw StatusError{KSLAM_ERR_STATE, "kslam_pair_phase_b has not been called for this result"};
+    if (c->pw.route_n == ~0ull) throw StatusError{KSLAM_ERR_STATE, "kslam_pseudo_route has not been called for this result"};
+    if (n && !d_scores) throw StatusError{KSLAM_ERR_ARG, "null scores"};
+    pseudo_return(c->pw, &c->pres, d_scores, n, score_fraction, c->stream);
     HIPCHK(stream_wait(c->stream));
     fill_pair_stats(c->pres, stats);
   });

@@ -24,6 +24,8 @@
 // are read from the sorted array by index, the sums are exact 64-bit integers (and fall back to the
 // reference's sequential double accumulation on the host when they could exceed 2^53).
 #include <cmath>
+#include <cstddef>
+#include <type_traits>
 
 #include "common.h"
 #include "gnu_sort.h"
@@ -53,23 +55,27 @@ __device__ inline Rec single_rec(const kslam_overlap &o, uint32_t idx, bool is_r
 // thread per row fills the entries between its predecessor's read and its own -- k_pair then finds a read pair's two runs
 // with four loads instead of four binary searches of 23 dependent probes each (0.7 of its 1.2 ms).
 __global__ void k_row_starts(const kslam_overlap *__restrict__ ov, uint64_t n, uint64_t n_reads, uint32_t *__restrict__ row_start,
-                             uint4 *__restrict__ gaps, uint32_t *__restrict__ n_gaps, uint32_t *__restrict__ bad) {
+                             uint4 *__restrict__ gaps, uint32_t gap_cap, uint32_t *__restrict__ n_gaps, uint32_t *__restrict__ bad) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i > n) return;
   const int64_t prev = i > 0 ? (int64_t)ov[i - 1].read : -1;
   const int64_t cur = min(i < n ? (int64_t)ov[i].read : (int64_t)n_reads, (int64_t)n_reads);
   // rows that are not sorted by read, or name a read the batch does not have (a caller's own rows, kslam_pair_screen_rows):
-  // the table would have holes; the host fails the call (k_pair clamps what it reads, so nothing is touched out of bounds)
+  // the table would have holes; the host fails the call (k_pair clamps what it reads).  Sorted rows have at most
+  // n_reads / 64 + 1 stretches of more than 64 reads = gap_cap; rows that jump back and forth (0, 100, 0, 100, ...) would
+  // list one per row: those beyond the capacity are dropped and the call is marked bad, nothing is written out of bounds
   if (prev > cur || (i < n && (uint64_t)ov[i].read >= n_reads)) atomicOr(bad, 1u);
   if (cur - prev > 64) {   // a long stretch of reads without rows (an empty result: all of them): k_fill_gaps, in parallel
-    gaps[atomicAdd(n_gaps, 1u)] = make_uint4((uint32_t)(prev + 1), (uint32_t)cur, (uint32_t)i, 0u);
+    const uint32_t g = atomicAdd(n_gaps, 1u);
+    if (g < gap_cap) gaps[g] = make_uint4((uint32_t)(prev + 1), (uint32_t)cur, (uint32_t)i, 0u);
+    else atomicOr(bad, 1u);
     return;
   }
   for (int64_t r = prev + 1; r <= cur; r++) row_start[r] = (uint32_t)i;
 }
-__global__ __launch_bounds__(256) void k_fill_gaps(const uint4 *__restrict__ gaps, const uint32_t *__restrict__ n_gaps,
+__global__ __launch_bounds__(256) void k_fill_gaps(const uint4 *__restrict__ gaps, const uint32_t *__restrict__ n_gaps, uint32_t gap_cap,
                                                     uint32_t *__restrict__ row_start) {
-  const uint32_t ng = *n_gaps;
+  const uint32_t ng = min(*n_gaps, gap_cap);
   for (uint32_t g = blockIdx.x; g < ng; g += gridDim.x) {
     const uint4 e = gaps[g];
     for (uint64_t r = (uint64_t)e.x + threadIdx.x; r <= e.y; r += 256) row_start[r] = e.z;
@@ -619,9 +625,21 @@ __device__ inline uint32_t cvt_u32_like_x86(double d) {
   return (uint32_t)(uint64_t)(long long)d;
 }
 
+// What the stage reads and writes of an alignment-pair record is its first 16 bytes.  When the entries are partitioned
+// over the ranks of a sharded batch (pseudo_route / pseudo_owned / pseudo_return below) only those travel, and the kernels
+// of the stage run on them as they run on whole records: R = Rec or RecHead.
+struct RecHead {
+  uint32_t combined_score;
+  uint32_t entry;
+  int32_t ref_start;
+  int32_t ref_end;
+};
+static_assert(sizeof(RecHead) == 16 && offsetof(Rec, combined_score) == 0 && offsetof(Rec, entry) == 4 &&
+              offsetof(Rec, ref_start) == 8 && offsetof(Rec, ref_end) == 12, "RecHead is the first half of kslam_paired_overlap");
+
 // one chain of an entry's sorted spans: [from, to); host/tail.cpp chain_entry's sums, operation for operation
-template <typename P>
-__device__ inline void score_chain(P v, uint32_t from, uint32_t to, Rec *__restrict__ recs) {
+template <typename P, typename R>
+__device__ inline void score_chain(P v, uint32_t from, uint32_t to, R *__restrict__ recs) {
 #pragma clang fp contract(off)
   const long len = (long)to - (long)from;
   if (len <= 1) return;
@@ -650,8 +668,8 @@ __device__ inline void score_chain(P v, uint32_t from, uint32_t to, Rec *__restr
 // chain is below this chain's first start + 20, so reach can be the running maximum over ALL earlier spans:
 // a prefix maximum, 64 spans a step; (4) one lane per chain adds up the chain in order (the chains are
 // independent; the additions inside one are the reference's sequence) and writes the members' new scores.
-template <typename P>
-__device__ inline void pseudo_entry_body(P v, uint32_t cnt, Rec *__restrict__ recs, kslam_gnu::WaveSortLds &S) {
+template <typename P, typename R>
+__device__ inline void pseudo_entry_body(P v, uint32_t cnt, R *__restrict__ recs, kslam_gnu::WaveSortLds &S) {
   const uint32_t lane = threadIdx.x;
   kslam_gnu::wave_sort(v, cnt, ByStart(), S);
   __syncthreads();
@@ -679,9 +697,9 @@ __device__ inline void pseudo_entry_body(P v, uint32_t cnt, Rec *__restrict__ re
   }
 }
 
-template <bool BIG>
+template <bool BIG, typename R>
 __global__ __launch_bounds__(64) void k_pseudo_entry(uint4 *__restrict__ sorted, const uint32_t *__restrict__ run_start,
-                                                     uint32_t n_runs, uint32_t n, Rec *__restrict__ recs) {
+                                                     uint32_t n_runs, uint32_t n, R *__restrict__ recs) {
   extern __shared__ PSpan v_lds[];
   __shared__ kslam_gnu::WaveSortLds S;
   const uint32_t r = blockIdx.x, lane = threadIdx.x;
@@ -785,11 +803,12 @@ void referenced_rows(PairWork &W, const PairResult *res, uint64_t n_rows, const 
   *n_list = cnt;
 }
 
-__global__ void k_spans_flat(const Rec *__restrict__ recs, uint64_t n, uint4 *__restrict__ out, uint32_t *__restrict__ max_entry) {
+template <typename R>
+__global__ void k_spans_flat(const R *__restrict__ recs, uint64_t n, uint4 *__restrict__ out, uint32_t *__restrict__ max_entry) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t mx = 0;
   if (i < n) {
-    const Rec r = recs[i];
+    const R r = recs[i];
     out[i] = make_uint4(r.entry, (uint32_t)r.ref_start, (uint32_t)r.ref_end, (uint32_t)i);
     mx = r.entry;
   }
@@ -807,7 +826,8 @@ __global__ void k_take_scores(const Rec *__restrict__ all, uint64_t base, uint64
 // changed nothing, when an entry holds more spans than one workgroup's LDS takes (the host then runs the stage).
 // spans of `recs` (in record order, or group by group: the same order, the dense array is laid out by group) ->
 // stable bucket sort by entry -> one wavefront per entry: std::sort by start, chains, new scores into recs
-static bool pseudo_on_records(Rec *recs, uint64_t n, bool from_groups, const kslam_read_pair *groups, uint64_t n_groups,
+template <typename R>
+static bool pseudo_on_records(R *recs, uint64_t n, bool from_groups, const kslam_read_pair *groups, uint64_t n_groups,
                               PairWork &W, SortWorkspace &sortws, hipStream_t s) {
   W.sort_a.ensure((n + 1) * sizeof(uint4));
   W.sort_b.ensure((n + 1) * sizeof(uint4));
@@ -819,11 +839,13 @@ static bool pseudo_on_records(Rec *recs, uint64_t n, bool from_groups, const ksl
   uint64_t *tot = W.totals.as<uint64_t>();
   HIPCHK(hipMemsetAsync(tot + 12, 0, 2 * sizeof(uint64_t), s));
   uint32_t *d_max_entry = reinterpret_cast<uint32_t *>(tot + 12), *d_longest = reinterpret_cast<uint32_t *>(tot + 13);
-  if (from_groups)
-    hipLaunchKernelGGL(k_spans, dim3((unsigned)((n_groups + 255) / 256)), dim3(256), 0, s, recs, groups, n_groups,
-                       W.sort_a.as<uint4>(), d_max_entry);
-  else
-    hipLaunchKernelGGL(k_spans_flat, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, recs, n, W.sort_a.as<uint4>(), d_max_entry);
+  if constexpr (std::is_same<R, Rec>::value) {
+    if (from_groups)
+      hipLaunchKernelGGL(k_spans, dim3((unsigned)((n_groups + 255) / 256)), dim3(256), 0, s, recs, groups, n_groups,
+                         W.sort_a.as<uint4>(), d_max_entry);
+  }
+  if (!from_groups)
+    hipLaunchKernelGGL(k_spans_flat<R>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const R *)recs, n, W.sort_a.as<uint4>(), d_max_entry);
   uint32_t max_entry = 0;
   read_back(&max_entry, d_max_entry, sizeof max_entry, s);
   uint32_t bits = 1;
@@ -845,10 +867,10 @@ static bool pseudo_on_records(Rec *recs, uint64_t n, bool from_groups, const ksl
   read_back(&longest, d_longest, sizeof longest, s);
   if (longest > (W.pseudo_cap ? W.pseudo_cap : PSEUDO_CAP_GLOBAL)) return false;
   uint4 *work = const_cast<uint4 *>(sorted);
-  hipLaunchKernelGGL(k_pseudo_entry<false>, dim3(n_runs), dim3(64), (size_t)std::min(longest, PSEUDO_CAP) * sizeof(PSpan), s, work,
+  hipLaunchKernelGGL((k_pseudo_entry<false, R>), dim3(n_runs), dim3(64), (size_t)std::min(longest, PSEUDO_CAP) * sizeof(PSpan), s, work,
                      W.count.as<uint32_t>(), n_runs, (uint32_t)n, recs);
   if (longest > PSEUDO_CAP)   // entries too big for LDS: the same wave algorithm on the spans where they lie
-    hipLaunchKernelGGL(k_pseudo_entry<true>, dim3(n_runs), dim3(64), 0, s, work, W.count.as<uint32_t>(), n_runs, (uint32_t)n, recs);
+    hipLaunchKernelGGL((k_pseudo_entry<true, R>), dim3(n_runs), dim3(64), 0, s, work, W.count.as<uint32_t>(), n_runs, (uint32_t)n, recs);
   HIPCHK(hipGetLastError());
   return true;
 }
@@ -978,13 +1000,14 @@ void pair_phase_a(const kslam_overlap *d_ov, uint64_t n, const uint32_t *d_read_
   // tot[4] inserts, [5] kept, [6] pairs after pairing
   if (n >= (1ull << 32)) throw StatusError{KSLAM_ERR_UNSUPPORTED, ">= 2^32 overlap records in one batch"};
   W.row_start.ensure((n_reads + 2) * sizeof(uint32_t));
-  W.gaps.ensure((n_reads / 64 + 2) * sizeof(uint4));   // stretches of more than 64 reads without rows: at most that many
+  const uint32_t gap_cap = (uint32_t)(n_reads / 64 + 2);   // stretches of more than 64 reads without rows: at most that many
+  W.gaps.ensure((size_t)gap_cap * sizeof(uint4));
   uint32_t *d_ngaps = reinterpret_cast<uint32_t *>(tot + 11);
   HIPCHK(hipMemsetAsync(W.row_start.p, 0, (n_reads + 2) * sizeof(uint32_t), s));   // (unsorted rows leave holes: zeros, not stale numbers)
   uint32_t *d_bad = reinterpret_cast<uint32_t *>(tot + 7);
   hipLaunchKernelGGL(k_row_starts, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, s, d_ov, n, n_reads, W.row_start.as<uint32_t>(),
-                     W.gaps.as<uint4>(), d_ngaps, d_bad);
-  hipLaunchKernelGGL(k_fill_gaps, dim3(64), dim3(256), 0, s, W.gaps.as<uint4>(), d_ngaps, W.row_start.as<uint32_t>());
+                     W.gaps.as<uint4>(), gap_cap, d_ngaps, d_bad);
+  hipLaunchKernelGGL(k_fill_gaps, dim3(64), dim3(256), 0, s, W.gaps.as<uint4>(), d_ngaps, gap_cap, W.row_start.as<uint32_t>());
   PairArgs a;
   a.ov = d_ov; a.n = n; a.row_start = W.row_start.as<uint32_t>(); a.read_len = d_read_len; a.units = units; a.mid = mid;
   a.thr = score_threshold; a.paired = paired;
@@ -1090,6 +1113,97 @@ bool pseudo_merged(PairWork &W, PairResult *res, void *d_all, uint64_t n_all, ui
   HIPCHK(hipGetLastError());
   res->stages_done |= 4u;
   return true;
+}
+
+// ---- pseudo-assembly with the ENTRIES partitioned over the ranks of a sharded batch ---------------------------------------
+// pseudo_merged has every rank run the stage on every record of the batch (N x the work, N x the traffic of an all-gather
+// of 32-byte records).  The stage is independent per entry (src/PairedOverlap.h:495-574: one bucket per entry, one walk per
+// bucket), so entry e can belong to rank e mod N alone:
+//   pseudo_route    this rank's records as 16-byte heads {score, entry, start, end}, stably partitioned by e mod N
+//                   (one 8-bit radix pass over {destination, index}); counts[d] = heads bound for rank d
+//   <all-to-all: rank d receives the pieces in SOURCE-RANK order = read-pair order, the reference's bucket iteration order>
+//   pseudo_owned    the stage on the received heads (same kernels, R = RecHead) -> their new scores, 4 bytes each
+//   <all-to-all back, same pieces, 4 bytes per record>
+//   pseudo_return   scores into this rank's records through the partition's permutation, second score screen
+// Per rank and batch: 16 + 4 bytes per record sent (N - 1) / N of the time, and 1 / N of the stage's work.
+__global__ void k_route_keys(const Rec *__restrict__ recs, uint64_t n, uint32_t world, uint2 *__restrict__ out) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = make_uint2(recs[i].entry % world, (uint32_t)i);
+}
+__global__ void k_route_gather(const Rec *__restrict__ recs, const uint2 *__restrict__ sorted, uint64_t n, RecHead *__restrict__ heads,
+                               unsigned long long *__restrict__ counts) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint2 k = sorted[i];
+  heads[i] = *reinterpret_cast<const RecHead *>(recs + k.y);
+  if (i + 1 == n || sorted[i + 1].x != k.x) atomicAdd(counts + k.x, (unsigned long long)(i + 1));   // end of destination k.x's run
+  if (i + 1 < n && sorted[i + 1].x != k.x) atomicAdd(counts + sorted[i + 1].x, (unsigned long long)0 - (i + 1));   // start of the next
+}
+__global__ void k_head_scores(const RecHead *__restrict__ heads, uint64_t n, uint32_t *__restrict__ scores) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) scores[i] = heads[i].combined_score;
+}
+__global__ void k_scores_home(const uint32_t *__restrict__ scores, const uint2 *__restrict__ sorted, uint64_t n, Rec *__restrict__ own) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) own[sorted[i].y].combined_score = scores[i];
+}
+
+void pseudo_route(PairWork &W, const PairResult *res, uint32_t world, const void **d_heads, uint64_t *counts, SortWorkspace &sortws,
+                  hipStream_t s) {
+  const uint64_t n = res->n_pairs;
+  if (world == 0 || world > 256) throw StatusError{KSLAM_ERR_ARG, "1 to 256 ranks"};   // one 8-bit radix pass
+  if (n >= (1ull << 32)) throw StatusError{KSLAM_ERR_UNSUPPORTED, ">= 2^32 alignment pairs on one rank"};
+  for (uint32_t d = 0; d < world; d++) counts[d] = 0;
+  W.route_n = n;
+  W.route_world = world;
+  *d_heads = nullptr;
+  if (n == 0) return;
+  W.route_a.ensure((n + 1) * sizeof(uint2));
+  W.route_b.ensure((n + 1) * sizeof(uint2));
+  W.route_heads.ensure((n + 1) * sizeof(RecHead));
+  W.totals.ensure(16 * sizeof(uint64_t));
+  W.route_counts.ensure(256 * sizeof(uint64_t));
+  HIPCHK(hipMemsetAsync(W.route_counts.p, 0, 256 * sizeof(uint64_t), s));
+  const unsigned nb = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL(k_route_keys, dim3(nb), dim3(256), 0, s, res->d_pairs, n, world, W.route_a.as<uint2>());
+  const SortPass pass{0, 0, 0};
+  const uint2 *sorted = (const uint2 *)radix_sort(W.route_a.p, W.route_b.p, n, 2, &pass, 1, sortws, s, nullptr, nullptr, nullptr);
+  W.route_sorted = sorted;
+  hipLaunchKernelGGL(k_route_gather, dim3(nb), dim3(256), 0, s, res->d_pairs, sorted, n, W.route_heads.as<RecHead>(),
+                     W.route_counts.as<unsigned long long>());
+  HIPCHK(hipGetLastError());
+  for (uint32_t d = 0; d < world; d += 32)   // read_back moves up to 256 bytes
+    read_back(counts + d, W.route_counts.as<uint64_t>() + d, std::min(32u, world - d) * sizeof(uint64_t), s);
+  *d_heads = W.route_heads.p;
+}
+
+// the stage on heads received from all ranks (source-rank order); *d_scores = their scores afterwards, in the same order.
+// false: declined (an entry too large for one wavefront, or 2^28 or more heads), nothing usable was produced.
+bool pseudo_owned(PairWork &W, void *d_heads, uint64_t n, const uint32_t **d_scores, SortWorkspace &sortws, hipStream_t s) {
+  *d_scores = nullptr;
+  if (n == 0) return true;
+  if (n >= (1ull << 28)) return false;
+  RecHead *heads = static_cast<RecHead *>(d_heads);
+  if (!pseudo_on_records<RecHead>(heads, n, false, nullptr, 0, W, sortws, s)) return false;
+  W.route_scores.ensure((n + 1) * sizeof(uint32_t));
+  hipLaunchKernelGGL(k_head_scores, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, heads, n, W.route_scores.as<uint32_t>());
+  HIPCHK(hipGetLastError());
+  *d_scores = W.route_scores.as<uint32_t>();
+  return true;
+}
+
+void pseudo_return(PairWork &W, PairResult *res, const uint32_t *d_scores, uint64_t n, double score_fraction, hipStream_t s) {
+  if (n != res->n_pairs || n != W.route_n) throw StatusError{KSLAM_ERR_ARG, "as many scores as kslam_pseudo_route sent heads"};
+  if (n) {
+    Rec *own = const_cast<Rec *>(res->d_pairs);
+    const uint64_t n_groups = res->n_read_pairs;
+    hipLaunchKernelGGL(k_scores_home, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_scores, (const uint2 *)W.route_sorted, n, own);
+    hipLaunchKernelGGL(k_rescreen, dim3((unsigned)((n_groups + 255) / 256)), dim3(256), 0, s, own,
+                       const_cast<kslam_read_pair *>(res->d_groups), n_groups, score_fraction);
+    HIPCHK(hipGetLastError());
+  }
+  W.route_n = ~0ull;
+  res->stages_done |= 4u;
 }
 
 }  // namespace kslam

@@ -203,10 +203,19 @@ class _DevView:
 
 
 def device_bytes(ptr, nbytes, dev):
-    """a uint8 device tensor holding a COPY of nbytes at device address ptr"""
+    """a uint8 device tensor holding a COPY of nbytes at device address ptr (dev = cpu: at host address ptr -- the CPU
+    tests' stand-in contexts)"""
     if nbytes == 0 or not ptr:
         return torch.empty(0, dtype=torch.uint8, device=dev)
+    if torch.device(dev).type == "cpu":
+        import ctypes
+        return torch.from_numpy(np.frombuffer((ctypes.c_char * int(nbytes)).from_address(int(ptr)), dtype=np.uint8).copy())
     return torch.as_tensor(_DevView(ptr, nbytes), device=dev).clone()
+
+
+def _sync(dev):
+    if torch.device(dev).type == "cuda":
+        torch.cuda.synchronize(dev)
 
 
 def all_gather_bytes(mine, dev, group=None):
@@ -230,12 +239,65 @@ def all_gather_bytes(mine, dev, group=None):
     return out, counts
 
 
-def sharded_tail(ctx, dev, paired=True, score_threshold=0, score_fraction=0.95, pseudo_assembly=True, group=None):
+def all_to_all_bytes(mine, send_bytes, dev, group=None):
+    """variable-length all-to-all of uint8 device tensors: `mine` holds the piece for rank 0, then the piece for rank 1, ...
+    (send_bytes[d] bytes each) -> (what this rank received, pieces end to end in SOURCE-RANK order, on `dev`;
+    [bytes received per source rank]).  nccl: all_to_all_single on device tensors (grouped send / recv over xGMI);
+    gloo (tests: ranks sharing one GPU): the same call on host copies."""
+    world = dist.get_world_size(group)
+    staged = dist.get_backend(group) == "gloo"
+    cdev = torch.device("cpu") if staged else dev
+    n = torch.tensor(send_bytes, dtype=torch.int64, device=cdev)
+    counts = [torch.zeros(world, dtype=torch.int64, device=cdev) for _ in range(world)]
+    dist.all_gather(counts, n, group=group)
+    recv_bytes = [int(counts[src][dist.get_rank(group)]) for src in range(world)]
+    out = torch.empty(sum(recv_bytes), dtype=torch.uint8, device=cdev)
+    dist.all_to_all_single(out, mine.to(cdev), recv_bytes, [int(v) for v in send_bytes], group=group)
+    return out.to(dev), recv_bytes
+
+
+def routed_pseudo_assembly(ctx, dev, score_fraction=0.95, group=None):
+    """pseudoAssembly (src/PairedOverlap.h:480-582) with the ENTRIES partitioned over the ranks: entry e belongs to rank
+    e mod world.  kslam_pseudo_route -> all-to-all of 16-byte heads -> kslam_pseudo_owned -> all-to-all of the 4-byte scores
+    back -> kslam_pseudo_return (include/kslam.h).  A rank whose device stage declines makes EVERY rank raise (a status
+    word travels with the scores), none is left waiting.  Returns (stats dict, bytes this rank received)."""
+    from . import KslamError
+    world = dist.get_world_size(group)
+    d_heads, counts = ctx.pseudo_route(world)
+    n_own = sum(counts)
+    heads = device_bytes(d_heads, n_own * 16, dev)
+    _sync(dev)
+    got, recv = all_to_all_bytes(heads, [c * 16 for c in counts], dev, group)
+    _sync(dev)
+    n_recv = got.numel() // 16
+    status, scores = 0, torch.empty(0, dtype=torch.uint8, device=dev)
+    try:
+        d_scores = ctx.pseudo_owned(got.data_ptr() if n_recv else None, n_recv)
+        scores = device_bytes(d_scores, n_recv * 4, dev)
+    except KslamError as e:
+        status, scores = int(e.status) or 1, torch.zeros(n_recv * 4, dtype=torch.uint8, device=dev)
+    _sync(dev)
+    # the status of every rank, before anybody depends on the scores
+    staged = dist.get_backend(group) == "gloo"
+    flag = torch.tensor([status], dtype=torch.int64, device=torch.device("cpu") if staged else dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+    back, _ = all_to_all_bytes(scores, [b // 4 for b in recv], dev, group)
+    _sync(dev)
+    if int(flag.item()):
+        raise KslamError(int(flag.item()), "the pseudo-assembly of some rank's entries declined on the device: the batch's stage belongs to the host")
+    assert back.numel() == n_own * 4
+    stats = ctx.pseudo_return(back.data_ptr() if n_own else None, n_own, score_fraction)
+    return stats, got.numel() + back.numel()
+
+
+def sharded_tail(ctx, dev, paired=True, score_threshold=0, score_fraction=0.95, pseudo_assembly=True, group=None, routed=True):
     """Pairing, insert-size screen, score screen [, pseudo-assembly + second screen] for THIS rank's read pairs of a batch
     sharded over the ranks -- the reference's steps between alignToDatabase and the SAM writer (src/SLAM.h:210-233) -- with
-    the two batch-global steps fed from all ranks: the insert sizes (4 bytes per properly paired read pair) and the
-    alignment-pair records (32 bytes each) are all-gathered over RCCL.  Afterwards the context holds this rank's read pairs
-    / alignment pairs as after kslam_pair_screen.  Returns (stats dict, bytes this rank received in the two gathers)."""
+    the two batch-global steps fed from all ranks: the insert sizes (4 bytes per properly paired read pair) are all-gathered;
+    pseudo-assembly runs with the entries partitioned over the ranks (routed_pseudo_assembly: 16 bytes out and 4 back per
+    alignment pair, 1 / world of the stage per rank) -- routed=False keeps round 3's form, an all-gather of the 32-byte
+    records and the whole stage on every rank.  Afterwards the context holds this rank's read pairs / alignment pairs as
+    after kslam_pair_screen.  Returns (stats dict, bytes this rank received in the exchanges)."""
     rank = dist.get_rank(group)
     d_ins, n_ins = ctx.pair_phase_a(paired, score_threshold)
     mine = device_bytes(d_ins, n_ins * 4, dev)
@@ -244,7 +306,10 @@ def sharded_tail(ctx, dev, paired=True, score_threshold=0, score_fraction=0.95, 
     torch.cuda.synchronize(dev)
     stats, d_pairs, n_pairs = ctx.pair_phase_b(all_ins.data_ptr() if all_ins.numel() else None, all_ins.numel() // 4, score_fraction, 3)
     moved = sum(c1)
-    if pseudo_assembly:
+    if pseudo_assembly and routed:
+        stats, m2 = routed_pseudo_assembly(ctx, dev, score_fraction, group)
+        moved += m2
+    elif pseudo_assembly:
         recs = device_bytes(d_pairs, n_pairs * 32, dev)
         torch.cuda.synchronize(dev)
         all_recs, c2 = all_gather_bytes(recs, dev, group)

@@ -1944,16 +1944,20 @@ int kslam_write_queued(void *user, const char *data, uint64_t len) {
 }
 
 // a block another stage produced goes into the queue as it is (no copy); release(user, data) is called on the writer thread
-// once it has been written (or at close, if a write failed before its turn)
+// once it has been written (or at close, if a write failed before its turn), and before returning when the call fails
 kslam_status kslam_sam_writer_enqueue(kslam_sam_writer *w, char *data, uint64_t len, void (*release)(void *user, void *data),
                                       void *user) {
   return guarded([&] {
-    if (!w || (!data && len) || !release) fail(KSLAM_ERR_ARG, "null argument");
+    // the block is CONSUMED whatever happens: from here on `t` hands it back through release() on every path out,
+    // the argument failures included (the caller has given it away and must not release it a second time)
     Text t;
-    t.p = data;
-    t.n = t.cap = (size_t)len;
-    t.ext_release = release;
-    t.ext_user = user;
+    if (data && release) {
+      t.p = data;
+      t.n = t.cap = (size_t)len;
+      t.ext_release = release;
+      t.ext_user = user;
+    }
+    if (!w || (!data && len) || !release) fail(KSLAM_ERR_ARG, "null argument");
     std::vector<Text> one;
     one.push_back(std::move(t));
     {

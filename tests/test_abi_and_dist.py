@@ -168,6 +168,89 @@ def test_sharded_gather_world2_gloo(tmp_path):
     assert "GATHER_OK" in r.stdout and "SHARDED_GATHER_OK" in r.stdout
 
 
+_ROUTED_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import numpy as np, torch, torch.distributed as dist, importlib
+from conftest import load_kslam
+K = load_kslam(); kd = importlib.import_module("kslam_amd.dist")
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+HEAD = np.dtype([("score", "<u4"), ("entry", "<u4"), ("start", "<i4"), ("stop", "<i4")])
+def records(r):          # rank r's alignment-pair heads of the batch, in read-pair order (every rank can make every rank's)
+    g = np.random.default_rng(100 + r)
+    n = [0, 57, 1, 301, 40][r %% 5]
+    a = np.zeros(n, dtype=HEAD)
+    a["score"] = g.integers(1, 600, n); a["entry"] = g.integers(0, 11, n); a["start"] = g.integers(0, 5000, n); a["stop"] = a["start"] + 150
+    return a
+def stage(heads):         # stands in for the device stage: per entry, an ORDER-DEPENDENT function of the heads in arrival order
+    out = heads["score"].copy()
+    for e in np.unique(heads["entry"]):
+        idx = np.flatnonzero(heads["entry"] == e)
+        acc = np.uint32(17)
+        for k in idx:
+            acc = np.uint32((int(acc) * 31 + int(heads["score"][k]) + int(heads["start"][k])) & 0xFFFFFFFF)
+            out[k] = acc
+    return out
+class HostCtx:            # kslam_pseudo_route / _owned / _return restated on host memory; the PROTOCOL under test is dist.py's
+    def __init__(self, recs): self.recs, self.keep = recs, []
+    def pseudo_route(self, world):
+        dest = self.recs["entry"] %% world
+        self.perm = np.argsort(dest, kind="stable")
+        self.sent = np.ascontiguousarray(self.recs[self.perm]); self.keep.append(self.sent)
+        return (self.sent.ctypes.data if len(self.sent) else 0), [int((dest == d).sum()) for d in range(world)]
+    def pseudo_owned(self, ptr, n):
+        import ctypes
+        heads = np.frombuffer((ctypes.c_char * (16 * n)).from_address(ptr), dtype=HEAD).copy() if n else np.zeros(0, dtype=HEAD)
+        assert n == 0 or (heads["entry"] %% world == rank).all()
+        if os.environ.get("DECLINE_ON") == str(rank):
+            raise K.KslamError(4, "declined (test)")
+        self.scores = np.ascontiguousarray(stage(heads)); self.keep.append(self.scores)
+        return self.scores.ctypes.data if n else 0
+    def pseudo_return(self, ptr, n, fraction):
+        import ctypes
+        sc = np.frombuffer((ctypes.c_char * (4 * n)).from_address(ptr), dtype="<u4").copy() if n else np.zeros(0, dtype="<u4")
+        self.result = self.recs["score"].copy(); self.result[self.perm] = sc
+        return {"stages_done": 7}
+mine = records(rank)
+ctx = HostCtx(mine)
+try:
+    stats, moved = kd.routed_pseudo_assembly(ctx, torch.device("cpu"))
+    whole = np.concatenate([records(r) for r in range(world)])          # the batch in rank order = read-pair order
+    exp = stage(whole)
+    at = sum(len(records(r)) for r in range(rank))
+    assert (ctx.result == exp[at:at + len(mine)]).all(), "rank %%d: scores differ from the whole batch's" %% rank
+    assert moved == 16 * int((whole["entry"] %% world == rank).sum()) + 4 * len(mine)
+    print("ROUTED_OK", rank, len(mine))
+except K.KslamError as e:
+    print("ROUTED_DECLINED", rank, e.status)
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("world,decline", [(2, None), (3, None), (5, None), (3, 1)])
+def test_routed_pseudo_assembly_protocol_gloo(tmp_path, world, decline):
+    """k-slam_amd/dist.py routed_pseudo_assembly (the all-to-all of heads to the entries' owners, the scores back, the status
+    word) between `world` processes over gloo, with the three device functions restated in numpy and the stage replaced by an
+    order-dependent function per entry: every rank must end up with the scores ONE process computes for the whole batch --
+    i.e. the pieces arrive in source-rank order and go back to where they came from.  With one rank declining, every rank
+    raises and none hangs."""
+    script = tmp_path / "routed.py"
+    script.write_text(_ROUTED_WORKER % {"root": ROOT})
+    port = str(29560 + world + (10 if decline is not None else 0))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, OMP_NUM_THREADS="1")
+    if decline is not None:
+        env["DECLINE_ON"] = str(decline)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world,
+                        "--master-addr", "127.0.0.1", "--master-port", port, str(script)],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    if decline is None:
+        assert r.stdout.count("ROUTED_OK") == world
+    else:
+        assert r.stdout.count("ROUTED_DECLINED") == world and "ROUTED_OK" not in r.stdout
+
+
 @pytest.mark.parametrize("header", ["kslam.h", "kslam_tail.h", "kslam_fastq.h", "kslam_taxonomy.h", "kslam_db.h", "kslam_stream.h", "kslam_comm.h", "kslam_samtext.h"])
 def test_headers_are_plain_c(header, tmp_path):
     """The boundary is a C ABI: every header must compile on its own as C99 (pedantic) and as C++11."""
@@ -194,7 +277,7 @@ def test_library_exports_every_comm_symbol_and_the_gather_plan(kslam):
     Cm = importlib.import_module("kslam_amd.comm")
     L = ctypes.CDLL(kslam.LIB_PATH)
     declared = _declared_symbols("kslam_comm.h")
-    assert sorted(Cm.EXPORTS) == declared and len(declared) == 9
+    assert sorted(Cm.EXPORTS) == declared and len(declared) == 12
     for name in declared:
         assert hasattr(L, name), "missing export " + name
     needed = subprocess.run(["readelf", "-d", kslam.LIB_PATH], capture_output=True, text=True).stdout

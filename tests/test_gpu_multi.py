@@ -128,18 +128,23 @@ def test_bench_strong_mode_with_several_ranks_on_one_gpu(world):
     assert v["planted_missing"] == 0 and v["planted_expected"] > 60000 and v["merged_rows"] == v["overlaps"]
 
 
-@pytest.mark.parametrize("world", [2, 4, 8])
-def test_bench_starts_its_own_ranks_when_no_launcher_did(world):
+@pytest.mark.parametrize("world,comm", [(2, "torch"), (4, "torch"), (8, "torch"), (2, "kslam"), (4, "kslam"), (8, "kslam")])
+def test_bench_starts_its_own_ranks_when_no_launcher_did(world, comm):
     """`python bench.py --gpus N` with WORLD_SIZE unset: bench.py starts the N rank processes itself (never a re-exec of
     a process that has touched the GPU), relays rank 0's line, and the line proves the ranks were there: n_gpus, the
     communicator's world, ranks_seen, bytes gathered per step, per-rank align times, the merged batch equal to one
-    context's, and the second clock through the batch-global tail (SAM text + per-read taxa on rank 0)."""
+    context's, and the second clock through the batch-global tail (SAM text + per-read taxa on rank 0).
+    comm = kslam: the data moves through the LIBRARY's communicator (include/kslam_comm.h) -- gather_begin / _end under the
+    next batch's alignment, kslam_comm_sharded_tail on two contexts in turn -- with tests/fake_rccl standing in for RCCL,
+    which refuses ranks that share a device; comm = torch: through torch.distributed (gloo, host-staged)."""
     env = dict(os.environ, KSLAM_BENCH_SHARE_GPU="1")
-    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "KSLAM_RCCL_LIB"):
         env.pop(k, None)
+    if comm == "kslam":
+        env["KSLAM_RCCL_LIB"] = _fake_rccl()
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--total-pairs", "48000",
                         "--species", "4", "--strains", "3", "--genome-len", "300000", "--steps", "2", "--warmup", "1",
-                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+                        "--no-cpu-baseline", "--comm", "auto" if comm == "torch" else "kslam"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     lines = [x for x in r.stdout.strip().splitlines() if x.startswith("{")]
     assert len(lines) == 1
@@ -148,44 +153,60 @@ def test_bench_starts_its_own_ranks_when_no_launcher_did(world):
     assert line["scaling"] == "strong" and line["n_gpus"] == world and line["config"]["pairs_per_gpu"] == 48000 // world
     assert line["rccl"]["world"] == world and line["rccl"]["ranks_seen"] == world and line["rccl"]["launched_by"] == "bench.py"
     assert line["rccl"]["bytes_gathered_per_step"] > 48 * v["overlaps"] and len(line["per_rank_align_ms"]) == world
+    if comm == "kslam":
+        f = line["rccl"]["kslam_comm"]
+        assert line["rccl"]["data_path"].startswith("kslam_comm") and "fake_rccl" in f["library"]
+        assert f["ncclCommCount_per_rank"] == [world] * world and f["ncclCommUserRank_per_rank"] == list(range(world))
+    else:
+        assert line["rccl"]["data_path"].startswith("torch.distributed") and line["rccl"]["kslam_comm"] is None and line["rccl"]["data_path_why"]
     assert v["ok"] and v["merged_equals_single_context"] and v["planted_missing"] == 0
     c = line["classified_rank0_tail"]
     assert c["sam_file_bytes"] > 100 * 48000 and c["per_read_lines_per_batch"] > 0.9 * 48000 and c["pseudo_assembly_on"] == "gpu"
     # the tail sharded like the alignment: each rank's SAM / _PerRead part files, in rank order, ARE rank 0's files
     sh = line["classified_sharded"]
     assert line["verified_classified"] and sh["part_files_in_rank_order_equal_rank0_files"] and sh["pseudo_assembly_on"] == "gpu"
-    assert sh["bytes_all_gathered_per_rank_per_step"] > 30 * 48000 and sh["max_insert_size"] == c["max_insert_size"]
+    assert sh["bytes_received_from_other_ranks_per_step"] > 4 * 48000 and sh["max_insert_size"] == c["max_insert_size"]
 
 
 def test_strong_line_of_one_rank_through_the_self_launcher_equals_plain_strong():
-    """N = 1: `--gpus 1 --strong` (no process group) and the same through RCCL at world size 1 classify the same batch:
-    same SAM bytes, same _PerRead lines, same merged rows."""
+    """N = 1: `--gpus 1 --strong` (no process group), the same through the library's communicator (real RCCL, opened by the
+    library, at world size 1: --comm auto picks it) and the same through torch.distributed classify the same batch: the same
+    SAM file and _PerRead file byte for byte (checksums), the same merged rows."""
     base = [sys.executable, os.path.join(ROOT, "bench.py"), "--strong", "--total-pairs", "40000", "--species", "4", "--strains", "3",
             "--genome-len", "300000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
     env = dict(os.environ)
-    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "KSLAM_RCCL_LIB"):
         env.pop(k, None)
     a = subprocess.run(base, env=env, capture_output=True, text=True, timeout=900)
     assert a.returncode == 0, a.stdout[-2000:] + a.stderr[-3000:]
     env2 = dict(env, KSLAM_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29591", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     b = subprocess.run(base, env=env2, capture_output=True, text=True, timeout=900)
     assert b.returncode == 0, b.stdout[-2000:] + b.stderr[-3000:]
-    la = json.loads([x for x in a.stdout.strip().splitlines() if x.startswith("{")][-1])
-    lb = json.loads([x for x in b.stdout.strip().splitlines() if x.startswith("{")][-1])
-    for k in ("sam_file_bytes", "per_read_file_bytes", "alignment_pairs_per_batch", "max_insert_size"):
-        assert la["classified_rank0_tail"][k] == lb["classified_rank0_tail"][k], k
-    assert la["verified_classified"] and lb["verified_classified"]
-    assert la["hot_path"]["verified"]["merged_rows"] == lb["hot_path"]["verified"]["merged_rows"]
-    assert "rccl" in lb and "rccl" not in la
+    c = subprocess.run(base + ["--comm", "torch"], env=dict(env2, MASTER_PORT="29592"), capture_output=True, text=True, timeout=900)
+    assert c.returncode == 0, c.stdout[-2000:] + c.stderr[-3000:]
+    la, lb, lc = (json.loads([x for x in p.stdout.strip().splitlines() if x.startswith("{")][-1]) for p in (a, b, c))
+    for k in ("sam_file_bytes", "per_read_file_bytes", "alignment_pairs_per_batch", "max_insert_size", "sam_file_crc32", "per_read_file_crc32"):
+        assert la["classified_rank0_tail"][k] == lb["classified_rank0_tail"][k] == lc["classified_rank0_tail"][k], k
+    assert la["verified_classified"] and lb["verified_classified"] and lc["verified_classified"]
+    assert la["hot_path"]["verified"]["merged_rows"] == lb["hot_path"]["verified"]["merged_rows"] == lc["hot_path"]["verified"]["merged_rows"]
+    assert lb["hot_path"]["verified"]["merged_equals_single_context"] and lc["hot_path"]["verified"]["merged_equals_single_context"]
+    assert "rccl" in lb and "rccl" in lc and "rccl" not in la
+    fb = lb["rccl"]["kslam_comm"]
+    assert lb["rccl"]["data_path"].startswith("kslam_comm") and fb["ncclCommCount_per_rank"] == [1] and "rccl" in fb["library"] and fb["ncclGetVersion"] > 0
+    assert lc["rccl"]["data_path"].startswith("torch.distributed") and lc["rccl"]["kslam_comm"] is None
 
 
-@pytest.mark.parametrize("bounds,pseudo", [([(0, 700), (700, 701), (701, 2500)], True), ([(0, 1250), (1250, 2500)], True),
+@pytest.mark.parametrize("bounds,pseudo", [([(0, 700), (700, 701), (701, 2500)], "routed"), ([(0, 1250), (1250, 2500)], "routed"),
+                                           ([(0, 313), (313, 625), (625, 938), (938, 1250), (1250, 1563), (1563, 1875), (1875, 2188), (2188, 2500)], "routed"),
+                                           ([(0, 2500)], "routed"),
+                                           ([(0, 700), (700, 701), (701, 2500)], True), ([(0, 1250), (1250, 2500)], True),
                                            ([(0, 900), (900, 1800), (1800, 2500)], False), ([(0, 2500)], True)])
 def test_sharded_tail_equals_one_context(kslam, synth, bounds, pseudo):
-    """The tail with the read pairs SHARDED (kslam_pair_phase_a / _b, kslam_pseudo_merged): every shard pairs and screens its
-    own read pairs; the insert-size limit is computed from all shards' insert sizes, pseudo-assembly from all shards'
-    alignment-pair records (what bench.py --gpus N moves over RCCL; here the shards are sibling contexts on one GPU and the
-    "gather" is a concatenation).  The shards' SAM text, concatenated in shard order, must be the text one context produces
+    """The tail with the read pairs SHARDED (kslam_pair_phase_a / _b, then kslam_pseudo_route / _owned / _return -- "routed":
+    the entries partitioned over the shards -- or kslam_pseudo_merged: every shard runs the stage on all records): every shard
+    pairs and screens its own read pairs; the insert-size limit is computed from all shards' insert sizes, pseudo-assembly
+    from all shards' alignment-pair records (what bench.py --gpus N moves over RCCL; here the shards are sibling contexts on
+    one GPU and the exchanges are concatenations).  The shards' SAM text, concatenated in shard order, must be the text one context produces
     for the whole batch -- pairing, limit, screens, chain scores, per-row NM / MD / log-probability and all."""
     import torch
     T = importlib.import_module("kslam_amd.tail")
@@ -238,7 +259,36 @@ def test_sharded_tail_equals_one_context(kslam, synth, bounds, pseudo):
         recs.append(kd.device_bytes(d_pairs, n * 32, dev))
         limits.append(stats["max_insert_size"])
     assert len(set(limits)) == 1 and limits[0] == st["max_insert_size"]
-    if pseudo:
+    if pseudo == "routed":
+        # the entries partitioned over the shards (kslam_pseudo_route / _owned / _return): entry e is shard e mod N's; the
+        # "all-to-all" lays the pieces a shard receives end to end in source order, the scores go back the same way
+        torch.cuda.synchronize()
+        N = len(shards)
+        routed = []
+        for c, _, _, _ in shards:
+            d_heads, counts = c.pseudo_route(N)
+            routed.append((kd.device_bytes(d_heads, sum(counts) * 16, dev), counts))
+        assert [sum(cn) for _, cn in routed] == [r.numel() // 32 for r in recs]
+        back = [[None] * N for _ in range(N)]                         # back[source][destination] = its scores
+        for d, (c, _, _, _) in enumerate(shards):
+            pieces = []
+            for src, (heads, counts) in enumerate(routed):
+                at = sum(counts[:d]) * 16
+                pieces.append(heads[at:at + counts[d] * 16])
+            got = torch.cat(pieces).contiguous()
+            torch.cuda.synchronize()
+            n_recv = got.numel() // 16
+            scores = kd.device_bytes(c.pseudo_owned(got.data_ptr() if n_recv else None, n_recv), n_recv * 4, dev)
+            at = 0
+            for src, (_, counts) in enumerate(routed):
+                back[src][d] = scores[at:at + counts[d] * 4]
+                at += counts[d] * 4
+        for src, (c, _, _, _) in enumerate(shards):
+            mine = torch.cat(back[src]).contiguous()
+            torch.cuda.synchronize()
+            s2 = c.pseudo_return(mine.data_ptr() if mine.numel() else None, mine.numel() // 4, 0.95)
+            assert s2["stages_done"] & 4
+    elif pseudo:
         torch.cuda.synchronize()
         base = 0
         for (c, _, _, _), mine in zip(shards, recs):
@@ -324,7 +374,9 @@ def test_rccl_behind_the_c_abi_world_1(kslam, synth, pseudo):
     assert {k: st[k] for k in ("n_read_pairs", "n_pairs", "max_insert_size", "n_insert_sizes")} == \
            {k: want[k] for k in ("n_read_pairs", "n_pairs", "max_insert_size", "n_insert_sizes")}
     assert grp.tobytes() == erp.tobytes() and gpr.tobytes() == epr.tobytes()
-    assert moved >= 4 * st["n_insert_sizes"]
+    assert moved == 0                              # bytes that arrived from OTHER ranks
+    facts = comm.info()
+    assert (facts["comm_count"], facts["comm_rank"], facts["device"]) == (1, 0, 0) and "rccl" in facts["library"] and facts["rccl_version"] > 0
     # a second gather reuses the communicator's buffers
     again = comm.gather_batch(n_pairs, 0, n_pairs)
     assert again[1:4:2] == (n_rows, n_ops)
@@ -333,3 +385,48 @@ def test_rccl_behind_the_c_abi_world_1(kslam, synth, pseudo):
     comm.close()
     c2.close()
     c.close()
+
+
+def _fake_rccl():
+    """tests/fake_rccl/libfake_rccl.so (a stand-in for the RCCL entry points comm.cpp resolves: files in /dev/shm as the
+    transport), built on first use"""
+    d = os.path.join(ROOT, "tests", "fake_rccl")
+    so, src = os.path.join(d, "libfake_rccl.so"), os.path.join(d, "fake_rccl.cpp")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so, src])
+    return so
+
+
+@pytest.mark.parametrize("world,pseudo", [(2, True), (4, True), (8, True), (3, False)])
+def test_comm_behind_the_c_abi_at_world_n_on_one_gpu(world, pseudo):
+    """include/kslam_comm.h at world sizes the box has no GPUs for: N threads are the ranks (tests/comm_world_n.py), RCCL's
+    entry points are the test double -- the communicator code of the LIBRARY runs as at N GPUs: rank 0's gathered arrays are
+    one context's result byte for byte, the ranks' SAM text in rank order is one context's text (insert-size limit from all
+    ranks' insert sizes, pseudo-assembly with the entries partitioned over the ranks)."""
+    env = dict(os.environ, KSLAM_RCCL_LIB=_fake_rccl())
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "comm_world_n.py"), str(world), "2400", str(int(pseudo))],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert not line["hung"] and not line["errors"], line
+    assert "fake_rccl" in line["library"] and line["comm_counts"] == [world] * world and line["comm_ranks"] == list(range(world))
+    assert line["gather_identical"] and line["rows"] > 2400 and line["second_gather_rows"] == line["rows"]
+    assert not any(line["tail_errors"]) and line["sam_identical"] and line["counts_identical"] and line["limit_identical"]
+    assert all(bool(s & 4) == pseudo for s in line["stages_done"]) and line["sam_bytes"] > 200 * 2400
+    assert all(m > 0 for m in line["moved"])
+
+
+def test_comm_ranks_fail_together_when_one_declines():
+    """A device stage that declines on SOME ranks must make every rank return KSLAM_ERR_UNSUPPORTED for the batch, and none
+    may wait in a collective.  KSLAM_PSEUDO_CAP = 40 makes the stage decline wherever an entry holds more
+    than 40 alignment pairs; the database has 9 entries and entry e belongs to rank e mod 12, so ranks 9, 10 and 11 own no
+    entry, succeed locally, and learn of the failure only through the status exchange."""
+    env = dict(os.environ, KSLAM_RCCL_LIB=_fake_rccl(), KSLAM_PSEUDO_CAP="40", KSLAM_FAKE_RCCL_TIMEOUT="60")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "comm_world_n.py"), "12", "2400", "1", "decline"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert not line["hung"] and not line["errors"], line
+    assert line["gather_identical"]
+    assert line["tail_errors"] == [4] * 12, line["tail_errors"]          # KSLAM_ERR_UNSUPPORTED on every rank
+

@@ -324,6 +324,17 @@ def test_round2_entry_points_refuse_misuse_loudly(kslam, synth):
         c.pair_screen_overlaps(ov, np.full(6, 100, dtype=np.uint32), paired=True)
     ov["read"] = [0, 1, 2, 4, 5, 5]
     assert c.pair_screen_overlaps(ov, np.full(6, 100, dtype=np.uint32), paired=True)["n_overlaps_screened"] == 6
+    # rows that jump back and forth between two reads far apart: every jump forward is a stretch of more than
+    # 64 reads without rows -- n / 2 of them, the list of stretches has room for n_reads / 64 + 2 -- and nothing marks them bad
+    # until the jump back: the list must be bounded, the call refused, and the context usable afterwards
+    big = np.zeros(40000, dtype=kslam.OVERLAP_DT)
+    big["read"] = np.tile(np.array([0, 1000], dtype=np.uint32), 20000)
+    big["score"] = 100
+    for _ in range(3):
+        with pytest.raises(kslam.KslamError, match="not sorted by read"):
+            c.pair_screen_overlaps(big, np.full(2000, 100, dtype=np.uint32), paired=True)
+    ov["read"] = [0, 1, 2, 4, 5, 5]
+    assert c.pair_screen_overlaps(ov, np.full(6, 100, dtype=np.uint32), paired=True)["n_overlaps_screened"] == 6
     # the sort hook: descending segment bounds, a segment over the limit
     with pytest.raises(kslam.KslamError, match="segments must be ascending"):
         c.debug_wave_sort(np.zeros(10, dtype=np.int32), np.array([0, 8, 4, 10], dtype=np.uint64))

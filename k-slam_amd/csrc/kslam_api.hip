@@ -244,7 +244,9 @@ void ensure_keep(DevBuf &b, size_t bytes, size_t used, hipStream_t s) {
     HIPCHK(stream_wait(s));
   }
   b.release();
-  b = nb;
+  b = nb;              // (copy-assignment is a borrowed view: common.h)
+  nb.p = nullptr;      // ... so the local gives the block up before its destructor runs
+  nb.cap = 0;
 }
 
 // Page-locked host memory for the result / staging buffers: a private anonymous mapping advised for

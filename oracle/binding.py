@@ -757,7 +757,10 @@ def ref_sw_on_overlaps(overlaps, reads, entries, params=None):
 
 # ---- the REAL batch loop metagenomicAnalysis_Low_Mem on files (oracle/_ref/libslam_ref.so) ----
 REF_SLAM = os.path.join(_HERE, "_ref", "libslam_ref.so")
-_refslam = None
+# the same program with ONE function swapped: alignToDatabase = the GPU operator behind the C ABI (ref_slam_driver.cpp built
+# with -DKSLAM_REF_GPU_OPERATOR: INTEGRATION.md's patch to src/SLAM.h:59-79, compiled into the reference's own loop)
+REF_SLAM_GPU = os.path.join(_HERE, "_ref", "libslam_gpu_ref.so")
+_refslam = {}
 
 
 class RefSlamParams(C.Structure):
@@ -782,25 +785,29 @@ def have_ref_slam():
     return os.path.exists(REF_SLAM)
 
 
-def _refs():
-    global _refslam
-    if _refslam is None:
-        R = C.CDLL(REF_SLAM)
+def have_ref_slam_gpu():
+    return os.path.exists(REF_SLAM_GPU)
+
+
+def _refs(gpu=False):
+    if gpu not in _refslam:
+        R = C.CDLL(REF_SLAM_GPU if gpu else REF_SLAM)
+        assert R.ref_slam_operator_is_gpu() == int(gpu)
         cp, u32, u64 = C.c_char_p, C.c_uint32, C.c_uint64
         R.ref_slam_index_reset.argtypes = []
         R.ref_slam_index_add_entry.argtypes = [cp, u64, cp, u32, u32]
         R.ref_slam_index_add_gene.argtypes = [cp, cp, cp, cp, cp, u32, u32, u32, C.c_int32]
         R.ref_slam_run.restype = C.c_int
         R.ref_slam_run.argtypes = [cp, cp, cp, cp, cp, cp, C.POINTER(RefSlamParams), cp]
-        _refslam = R
-    return _refslam
+        _refslam[gpu] = R
+    return _refslam[gpu]
 
 
-def ref_slam_set_index(entries):
+def ref_slam_set_index(entries, gpu=False):
     """entries: list of dicts {bases, locus_tag, taxonomy_id, genbank_id?, genes: [{name, locus_tag?, protein_id,
     product, reference?, gene_id?, start, stop, complement?}]} -- the GenbankIndex the reference's (unbuildable) archive
-    reader would have returned."""
-    R = _refs()
+    reader would have returned.  gpu: for the library whose alignToDatabase is the GPU operator."""
+    R = _refs(gpu)
     R.ref_slam_index_reset()
     for e in entries:
         R.ref_slam_index_add_entry(e["bases"], len(e["bases"]), e.get("locus_tag", b""), e.get("taxonomy_id", 0),
@@ -811,11 +818,11 @@ def ref_slam_set_index(entries):
                                       g["start"], g["stop"], int(g.get("complement", 0)))
 
 
-def ref_slam_run(r1, r2, db_dir, out, sam, params=None, command_line=b"SLAM", workdir=None):
+def ref_slam_run(r1, r2, db_dir, out, sam, params=None, command_line=b"SLAM", workdir=None, gpu=False):
     """src/main.cpp:138-151 -> the reference's own metagenomicAnalysis_Low_Mem.  Paths are str; r2 / out / sam may be
     "".  The index comes from ref_slam_set_index (db_dir only supplies <db_dir>/taxDB)."""
     p = params or RefSlamParams.default()
     with tempfile.TemporaryDirectory() as d:
-        rc = _refs().ref_slam_run(r1.encode(), r2.encode(), db_dir.encode(), out.encode(), sam.encode(),
+        rc = _refs(gpu).ref_slam_run(r1.encode(), r2.encode(), db_dir.encode(), out.encode(), sam.encode(),
                                   command_line, C.byref(p), (workdir or d).encode())
     assert rc == 0, "the reference threw"

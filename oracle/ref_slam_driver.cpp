@@ -28,6 +28,14 @@
 //       everything downstream of the loaded GenbankIndex is.
 //   src/main.cpp (boost::program_options) is not built: the globals it sets
 //   (src/main.cpp:40-97) are set here from ref_slam_params.
+//
+// Built a second time as oracle/_ref/libslam_gpu_ref.so with -DKSLAM_REF_GPU_OPERATOR: THE LITERAL DROP-IN.  The same
+// program -- the reference's own FASTQ reader, batch loop, pairing, screens, pseudo-assembly, SAM writer and reports,
+// compiled from where they lie -- with ONE function swapped: alignToDatabase (src/SLAM.h:59-79) is cut out of the
+// header by a third line slice (`sed 59,79d src/SLAM.h`: its declaration at :54-56 stays) and defined below exactly as
+// INTEGRATION.md tells a maintainer to define it, through k-slam_amd/host/slam_hot_path.hpp over the C ABI of
+// libkslam_hip.so.  tests/test_gpu_dropin.py runs both libraries on the same files and compares the four outputs byte
+// for byte.  Test infrastructure like everything under oracle/: the product never links or loads it.
 #include <omp.h>
 #include <array>
 #include <limits>
@@ -59,7 +67,32 @@
 namespace SLAM {
 GenbankIndex getIndexFromBoostSerial(const std::string serialFileName);
 }
+#ifdef KSLAM_REF_GPU_OPERATOR
+#include "SLAM_minus_alignToDatabase.h"     // the Makefile's slice: src/SLAM.h without lines 59-79
+#include "../k-slam_amd/host/slam_hot_path.hpp"
+namespace SLAM {
+static kslam_host::HotPath *gpuPath = nullptr;   // one per process, like the reference's globals
+// INTEGRATION.md, "The reference-side binding": the replacement a maintainer would write in src/SLAM.h
+template <typename FASTQType>
+inline std::vector<Overlap> alignToDatabase(const std::vector<FASTQType> &reads, const GenbankIndex &genbankIndex) {
+  log("Aligning reads to database using k = " + std::to_string(k));
+  if (!gpuPath) {                       // first batch: upload genomes, build the resident k-mer list
+    gpuPath = new kslam_host::HotPath(match, misMatch, gapOpen, gapExtend, scoreThreshold, reportCigar);
+    gpuPath->setIndex(genbankIndex);    // uses genbankIndex.entries[j].bases
+  }
+  return gpuPath->alignToDatabase<Overlap>(reads);   // same order, same Alignment ownership
+}
+static void dropGpuPath() {   // (the test harness changes index and scoring between runs; a k-SLAM process would not)
+  delete gpuPath;
+  gpuPath = nullptr;
+}
+}  // namespace SLAM
+#else
 #include "SLAM.h"
+namespace SLAM {
+static void dropGpuPath() {}
+}
+#endif
 
 namespace {
 SLAM::GenbankIndex g_index;
@@ -83,7 +116,18 @@ struct ref_slam_params {  // the option globals of src/main.cpp:40-97
   int32_t threads;              // OMP_NUM_THREADS (0 = leave)
 };
 
-void ref_slam_index_reset(void) { g_index.entries.clear(); }
+void ref_slam_index_reset(void) {
+  g_index.entries.clear();
+  SLAM::dropGpuPath();
+}
+// 1 when alignToDatabase is the GPU operator behind the C ABI (libslam_gpu_ref.so), 0 for the reference's own
+int ref_slam_operator_is_gpu(void) {
+#ifdef KSLAM_REF_GPU_OPERATOR
+  return 1;
+#else
+  return 0;
+#endif
+}
 
 // appends a GenbankEntry (fields the archive carries, src/GenbankTools.h:155-163)
 void ref_slam_index_add_entry(const char *bases, uint64_t len, const char *locus_tag,
@@ -131,6 +175,7 @@ int ref_slam_run(const char *r1, const char *r2, const char *db_dir, const char 
   commandLine = command_line;
   if (p->threads > 0) omp_set_num_threads(p->threads);
   int rc = 0;
+  SLAM::dropGpuPath();   // the scoring globals may have changed since the last run
   try {
     SLAM::metagenomicAnalysis_Low_Mem(r1, r2, db_dir, out, sam, p->num_reads_at_once,
                                       p->num_reads);
@@ -138,6 +183,7 @@ int ref_slam_run(const char *r1, const char *r2, const char *db_dir, const char 
     std::cerr << "reference threw: " << e.what() << std::endl;
     rc = 1;
   }
+  SLAM::dropGpuPath();
   if (workdir && chdir(old) != 0) abort();
   return rc;
 }

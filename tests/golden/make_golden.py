@@ -273,10 +273,44 @@ def make_slam_loop():
     np.savez_compressed(os.path.join(HERE, "slam_loop.npz"), **out)
 
 
+def make_c1_golden():
+    """SURVEY 8c golden (5): the C1-size end-to-end run -- 10 k pairs x 150 bp vs 3 x 2 Mb, genome 2 carrying a 20 kb copy of
+    genome 0 -- through the reference's OWN loop (oracle/_ref/libslam_ref.so, one thread: the XML report's order of equal
+    counts depends on the thread count), seeds 1 / 2, with and without pseudo-assembly.  The inputs are regenerated from
+    the seeds wherever the fixture is replayed (kslam_amd.synth, numpy only); their md5s are recorded so that a drifting
+    generator shows up as that, not as a product failure.  Kept of the outputs: md5 + size of the four files, the first /
+    last 200 SAM lines."""
+    import importlib
+    import tempfile
+    import oracle as O
+    import ref_loop_case as R
+    assert O.have_ref_slam(), "needs /root/reference (make -C oracle ref)"
+    load_kslam()
+    synth = importlib.import_module("kslam_amd.synth")
+    D = importlib.import_module("kslam_amd.db")
+    out = {"what": "tests/ref_loop_case.py make_case_c1(seed) through the reference's metagenomicAnalysis_Low_Mem (src/SLAM.h:159-268), "
+                   "command line 'SLAM --db db R1.fq R2.fq', one batch, one thread", "cases": {}}
+    for seed in (1, 2):
+        case = R.make_case_c1(synth, seed)
+        for pseudo in (True, False):
+            with tempfile.TemporaryDirectory() as t:
+                dbdir = R.write_case(case, t, D)
+                ref = R.run_reference(O, case, t, dbdir, 10_000_000, pseudo=pseudo)
+            d = R.digest_of_outputs(ref)
+            d["inputs_md5"] = R.digest_of_inputs(case)
+            out["cases"]["seed%d_%s" % (seed, "pseudo" if pseudo else "nopseudo")] = d
+            print("c1_golden seed %d pseudo %d: %d SAM lines, md5 %s" % (seed, pseudo, d["sam_lines"], d["md5"]["sam"]))
+    json.dump(out, open(os.path.join(HERE, "c1_golden.json"), "w"), indent=0)
+
+
 if __name__ == "__main__":
+    if "--c1" in sys.argv:
+        make_c1_golden()
+        sys.exit(0)
     if "--pins" in sys.argv:           # only the fixtures recorded from libjoin_ref.so / libslam_ref.so
         make_join_and_align_vectors()
         make_slam_loop()
+        make_c1_golden()
         sys.exit(0)
     if "--taxonomy" in sys.argv:
         make_taxonomy_cases()
@@ -287,3 +321,4 @@ if __name__ == "__main__":
     make_taxonomy_cases()
     make_join_and_align_vectors()
     make_slam_loop()
+    make_c1_golden()

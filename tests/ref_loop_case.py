@@ -57,6 +57,45 @@ def make_case(synth, n_pairs=500, seed=4101, read_len=110, genome_len=14000, n_s
     return case
 
 
+def make_case_c1(synth, seed=1, n_pairs=10000):
+    """BASELINE configs[0] / SURVEY 8c golden (5): n_pairs x 2 x 150 bp vs 3 genomes of 2 Mb, genome 2 carrying a 20 kb copy of
+    genome 0 (reads from it hit two entries), fragments ~ N(350, 30), 1 % substitutions, 0.1 % indels, 2 % of the pairs from
+    no genome of the database, qualities constant 'I'.  Same dict layout as make_case."""
+    genomes = synth.make_genomes(seed, 3, 1, 2_000_000, shared_segment=20000)
+    reads, _ = synth.make_paired_reads(seed + 1000, genomes, n_pairs, read_len=150, frag_mean=350, frag_sd=30, sub_rate=0.01,
+                                       indel_rate=0.001, unmapped_frac=0.02)
+    gb = synth.to_bytes(genomes)
+    entries = [{"bases": g, "taxonomyID": 1000 + i, "genbankID": 7000 + i, "locusTag": b"NC_%06d.1" % i, "isPlasmid": False,
+                "genes": [{"geneName": b"gene%d" % k, "proteinID": b"WP_%d.1" % (100 * i + k), "locusTag": b"LT%02d_%02d" % (i, k),
+                           "referenceSequence": b"NC_%06d" % i, "product": b"hypothetical protein %d" % k,
+                           "start": 400 + 130000 * k, "stop": 120000 + 130000 * k, "geneID": k, "complement": bool(k & 1)}
+                          for k in range(15)]}
+               for i, g in enumerate(gb)]
+    rb = synth.to_bytes(reads)
+    quals = [b"I" * len(b) for b in rb]
+    ids = [b"p%d" % i for i in range(n_pairs)]
+    return {"entries": entries, "taxdb": taxdb_text(3, 1), "bases": rb, "quals": quals, "ids": ids, "n_pairs": n_pairs,
+            "r1": fastq_text(rb[:n_pairs], quals[:n_pairs], ids, 1), "r2": fastq_text(rb[n_pairs:], quals[n_pairs:], ids, 2)}
+
+
+def digest_of_outputs(ref, lines=200):
+    """what tests/golden/c1_golden.json keeps of a run's four files: md5 of each, and the first / last `lines` SAM lines"""
+    import hashlib
+    sam = ref["sam"].split(b"\n")
+    if sam and sam[-1] == b"":
+        sam.pop()
+    return {"md5": {k: hashlib.md5(ref[k]).hexdigest() for k in ("sam", "per_read", "xml", "abbreviated")},
+            "bytes": {k: len(ref[k]) for k in ("sam", "per_read", "xml", "abbreviated")},
+            "sam_lines": len(sam), "sam_head": [x.decode() for x in sam[:lines]], "sam_tail": [x.decode() for x in sam[-lines:]]}
+
+
+def digest_of_inputs(case):
+    import hashlib
+    return {"r1": hashlib.md5(case["r1"]).hexdigest(), "r2": hashlib.md5(case["r2"]).hexdigest(),
+            "genomes": hashlib.md5(b"".join(e["bases"] for e in case["entries"])).hexdigest(),
+            "taxdb": hashlib.md5(case["taxdb"]).hexdigest()}
+
+
 def write_case(case, tmp_path, db_module):
     """files the product reads: <tmp>/db/{database,taxDB}, <tmp>/R1.fq, <tmp>/R2.fq"""
     dbdir = os.path.join(str(tmp_path), "db")
@@ -70,23 +109,27 @@ def write_case(case, tmp_path, db_module):
 
 
 def run_reference(oracle, case, tmp_path, dbdir, per_batch, pseudo=True, just_align=False, sam_xa=False,
-                  num_alignments=10, score_threshold=0, command_line=b"SLAM --db db R1.fq R2.fq", threads=1):
-    """The reference's own loop on the files.  -> dict(sam, xml, abbreviated, per_read, log): bytes of the files it wrote"""
+                  num_alignments=10, score_threshold=0, command_line=b"SLAM --db db R1.fq R2.fq", threads=1, gpu_operator=False,
+                  scoring=None):
+    """The reference's own loop on the files.  -> dict(sam, xml, abbreviated, per_read, log): bytes of the files it wrote.
+    gpu_operator: the same loop with alignToDatabase swapped for the GPU operator (oracle/_ref/libslam_gpu_ref.so)."""
     oracle.ref_slam_set_index([{
         "bases": e["bases"], "locus_tag": e["locusTag"], "taxonomy_id": e["taxonomyID"], "genbank_id": e["genbankID"],
         "genes": [{"name": g["geneName"], "locus_tag": g["locusTag"], "protein_id": g["proteinID"], "product": g["product"],
                    "reference": g["referenceSequence"], "gene_id": g["geneID"], "start": g["start"], "stop": g["stop"],
-                   "complement": g["complement"]} for g in e["genes"]]} for e in case["entries"]])
+                   "complement": g["complement"]} for g in e["genes"]]} for e in case["entries"]], gpu=gpu_operator)
     p = oracle.RefSlamParams.default(pseudo_assembly=int(pseudo), just_align=int(just_align), sam_xa=int(sam_xa),
                                      num_reads_at_once=per_batch, num_sam_alignments=num_alignments,
                                      score_threshold=score_threshold, threads=threads)
+    for k, v in (scoring or {}).items():      # match / mismatch / gap_open / gap_extend
+        setattr(p, k, v)
     t = str(tmp_path)
-    wd = os.path.join(t, "refrun")
+    wd = os.path.join(t, "gpurun" if gpu_operator else "refrun")
     os.makedirs(wd, exist_ok=True)
     out = os.path.join(wd, "out")
     sam = os.path.join(wd, "out.sam")
     run = lambda: oracle.ref_slam_run(os.path.join(t, "R1.fq"), os.path.join(t, "R2.fq") if case["r2"] else "",
-                                      dbdir, out, sam, p, command_line, workdir=wd)
+                                      dbdir, out, sam, p, command_line, workdir=wd, gpu=gpu_operator)
     if threads == 1:
         oracle.binding._one_thread(run)
     else:

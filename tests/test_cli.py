@@ -87,6 +87,32 @@ def test_binary_on_files_equals_the_reference_loop(kslam, tmp_path, tag):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("seed,pseudo", [(1, True), (1, False), (2, True), (2, False)])
+def test_binary_at_c1_size_equals_the_golden(kslam, synth, tmp_path, seed, pseudo):
+    """SURVEY 8c golden (5) / BASELINE configs[0] through the executable: 10 k pairs x 150 bp vs 3 x 2 Mb with a shared 20 kb
+    segment, with and without pseudo-assembly.  tests/golden/c1_golden.json holds what the reference's own loop
+    (src/SLAM.h:209-239 inside metagenomicAnalysis_Low_Mem, oracle/_ref/libslam_ref.so) wrote for these inputs: md5 and size
+    of the four files, the first / last 200 SAM lines.  Only the @PG line differs (this run's command line)."""
+    import hashlib
+    import json
+    import ref_loop_case as R
+    D = importlib.import_module("kslam_amd.db")
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "c1_golden.json")))["cases"]["seed%d_%s" % (seed, "pseudo" if pseudo else "nopseudo")]
+    case = R.make_case_c1(synth, seed)
+    assert R.digest_of_inputs(case) == gold["inputs_md5"], "the generator no longer makes the inputs the golden was recorded on"
+    R.write_case(case, tmp_path, D)
+    args = ["--db=db", "--sam-file", "out.sam", "--output-file=out"] + ([] if pseudo else ["--no-pseudo-assembly"]) + ["R1.fq", "R2.fq"]
+    _run(args, tmp_path)
+    cl = (SLAM + " " + " ".join(args)).encode()
+    sam = (tmp_path / "out.sam").read_bytes().replace(b'CL:"' + cl + b'"', b'CL:"SLAM --db db R1.fq R2.fq"')
+    got = {"sam": sam, "xml": (tmp_path / "out").read_bytes(), "abbreviated": (tmp_path / "out_abbreviated").read_bytes(),
+           "per_read": (tmp_path / "out_PerRead").read_bytes()}
+    d = R.digest_of_outputs(got)
+    assert d["sam_head"] == gold["sam_head"] and d["sam_tail"] == gold["sam_tail"] and d["sam_lines"] == gold["sam_lines"]
+    assert d["bytes"] == gold["bytes"] and d["md5"] == gold["md5"]
+
+
+@pytest.mark.gpu
 def test_binary_other_modes_equal_the_oracle_chain(kslam, oracle, synth, tmp_path):
     """--just-align (SAM only), single-end input, XML on stdout without --output-file, --num-reads, --sam-xa,
     --num-alignments, --min-alignment-score: against the oracle chain (itself pinned to the reference's loop)."""

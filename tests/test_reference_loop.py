@@ -164,3 +164,25 @@ def test_oracle_chain_equals_the_golden_slam_loop(kslam, oracle, tag):
     assert orc["sam"] == z[tag + "_sam"].tobytes()
     assert orc["per_read"] == z[tag + "_per_read"].tobytes()
     assert orc["abbreviated"] == z[tag + "_abbreviated"].tobytes()
+
+
+def test_c1_golden_fixture_is_what_the_reference_writes(kslam, oracle, synth, tmp_path):
+    """tests/golden/c1_golden.json regenerated here (seed 1, pseudo-assembly on) must be identical: the fixture is the real
+    reference's output (oracle/_ref/libslam_ref.so), not a self-made file -- and the ORACLE chain writes the same SAM,
+    _PerRead and _abbreviated at this size too (10 k pairs x 150 bp vs 3 x 2 Mb)."""
+    import json
+    import ref_loop_case as R
+    D = importlib.import_module("kslam_amd.db")
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "c1_golden.json")))["cases"]["seed1_pseudo"]
+    case = R.make_case_c1(synth, 1)
+    assert R.digest_of_inputs(case) == gold["inputs_md5"]
+    chain = R.run_oracle_chain(oracle, case, 10_000_000, pseudo=True)
+    import hashlib
+    for k in ("sam", "per_read", "abbreviated"):
+        assert hashlib.md5(chain[k]).hexdigest() == gold["md5"][k], k
+    if oracle.have_ref_slam():
+        dbdir = R.write_case(case, tmp_path, D)
+        ref = R.run_reference(oracle, case, tmp_path, dbdir, 10_000_000, pseudo=True)
+        d = R.digest_of_outputs(ref)
+        assert {k: d[k] for k in ("md5", "bytes", "sam_lines", "sam_head", "sam_tail")} == {k: gold[k] for k in ("md5", "bytes", "sam_lines", "sam_head", "sam_tail")}
+

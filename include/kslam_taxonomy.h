@@ -98,9 +98,12 @@ kslam_status kslam_taxonomy_summary(const kslam_taxdb *db, const uint32_t *tax_i
  * genes of all its read pairs, sorted and merged with counts, reads sorted by name; taxa by
  * (reads descending, id ascending); abundance = reads * 100.0 / num_reads printed with
  * std::to_string (six decimals).  combineTaxonomies' bookkeeping quirk is kept (without an
- * unclassified read pair the first record of the lowest id is dropped, :159-175).  The reference orders
- * records of equal taxonomy id with an unstable PARALLEL sort, so which of several equal genes
- * represents its class there depends on the thread count; here the records keep their input order. */
+ * unclassified read pair the record at the front of the sorted vector is dropped from its group, :159-175).
+ * The reference orders records of equal taxonomy id with an unstable PARALLEL sort, so which record that is --
+ * and which of several equal genes represents its class -- depends on the thread count there.  Here the
+ * records keep their input order, except that the dropped record is the one std::sort leaves in front: what
+ * the reference writes with one thread (and with any number below 1 000 read pairs), the form the golden
+ * files of tests/golden/ are recorded in. */
 typedef struct kslam_taxreport kslam_taxreport;
 typedef struct {
   const char *gene_locus_tag;      /* Gene::locusTag, by gene */

@@ -179,4 +179,36 @@ KSLAM_HD inline void sort(T *first, T *last, Less less) {
   final_insertion_sort(first, last, less);
 }
 
+// WHICH element std::sort(first, last, less) leaves at *first, without sorting the rest: the chain of partitions that
+// leads to the leftmost block, and nothing else.  A partition only moves elements inside its range, and the recursion into
+// the right part [cut, hi) never touches [lo, cut) -- so following only the left parts reproduces the leftmost block
+// exactly (O(n) instead of O(n log n): n + n/2 + ... element visits).  The final insertion sort never lets an element pass
+// an equal one and every element right of the leftmost block compares >= everything in it, so the front element is the first
+// least element of that block.  Destroys the order of [first, last).  Returns a pointer into the range (first == last: last).
+// Used where the reference's output depends on nothing but the front of a std::sort by a partial key
+// (combineTaxonomies, src/MetagenomicResults.h:149-177: host/taxonomy.cpp).
+template <typename T, typename Less>
+KSLAM_HD inline T *front_after_sort(T *first, T *last, Less less) {
+  if (first == last) return last;
+  ptrdiff_t n = last - first;
+  int lg = 0;
+  for (ptrdiff_t k = n; k > 1; k >>= 1) lg++;
+  int depth = 2 * lg;
+  T *lo = first, *hi = last;
+  while (hi - lo > 16) {
+    if (depth == 0) {
+      heap_sort(lo, hi, less);
+      break;
+    }
+    --depth;
+    T *mid = lo + (hi - lo) / 2;
+    move_median_to_first(lo, lo + 1, mid, hi - 1, less);
+    hi = unguarded_partition(lo + 1, hi, lo, less);
+  }
+  T *best = lo;
+  for (T *p = lo + 1; p != hi; ++p)
+    if (less(*p, *best)) best = p;
+  return best;
+}
+
 }  // namespace kslam_gnu

@@ -459,19 +459,7 @@ def abi_path(K, ctx, reads, read_len, steps):
     }
 
 
-def ids_view(T, n_pairs, read_len, first_pair=0):
-    """kslam_reads_view of a fixed-length batch [R1 block | R2 block] without bases / quality columns (the SAM writer
-    gets NM / MD / log-probability from the GPU and never reads them): identifiers p<8 digits>, offsets."""
-    ids = np.empty((2 * n_pairs, 1 + W.ID_DIGITS), dtype=np.uint8)
-    ids[:, 0] = ord("p")
-    idx = np.tile(np.arange(first_pair, first_pair + n_pairs, dtype=np.int64), 2)
-    for d in range(W.ID_DIGITS):
-        ids[:, 1 + d] = (idx // 10 ** (W.ID_DIGITS - 1 - d)) % 10 + ord("0")
-    ids = ids.reshape(-1)
-    ioff = np.arange(2 * n_pairs + 1, dtype=np.uint64) * np.uint64(1 + W.ID_DIGITS)
-    boff = np.arange(2 * n_pairs + 1, dtype=np.uint64) * np.uint64(read_len)
-    rv = T.ReadsView(2 * n_pairs, None, boff.ctypes.data, None, boff.ctypes.data, ids.ctypes.data, ioff.ctypes.data)
-    return type("IdsView", (), {"view": rv, "n_reads": 2 * n_pairs, "_keep": (ids, ioff, boff)})()
+ids_view = W.ids_view      # (k-slam_amd/workload.py: the tests use it too)
 
 
 # ------------------------------------------------------------------------------------------------ main

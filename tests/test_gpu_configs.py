@@ -1,7 +1,12 @@
-"""BASELINE configs[2] and configs[4] at their full size, through the whole chain:
+"""BASELINE configs[2], configs[3] (its one-GPU shape) and configs[4] at their full size, through the whole chain:
 
   configs[2]  10 M x 2 x 150 bp read pairs vs the bacterial + viral database (1 250 genomes of 4 Mb + 10 000 of 5-200 kb,
               SURVEY.md section 8d), full pipeline incl. SAM output, pseudo-assembly on (the reference's default)
+  configs[3]  ONE batch of 10 M x 2 x 150 bp pairs (the reference's --num-reads-at-once default; configs[3] is four of them)
+              split EIGHT ways, every shard aligned on the box's one GPU in a context of its own; shard -> export in batch
+              terms -> the placement of include/kslam_comm.h -> merged arrays; the tail sharded the same way (insert sizes
+              of all shards, pseudo-assembly with the entries partitioned over the shards); everything compared with ONE
+              context that took the whole batch (test_config3_... at the bottom)
   configs[4]  10 M x 2 x 250 bp read pairs vs the bacterial database
 
 FASTQ text in host memory -> k-slam_amd/stream.py (the reference's batch loop, src/SLAM.h:159-268: ONE batch of 10 M
@@ -197,3 +202,157 @@ def test_config2_bacterial_plus_viral_10m_pairs_full_pipeline(kslam, oracle, tmp
 def test_config4_250bp_10m_pairs_full_pipeline(kslam, oracle, tmp_path):
     b0 = _run_config(kslam, oracle, tmp_path, n_viral=0, read_len=250, by_length=False, pseudo=True)
     assert b0["overlaps"] > 2 * PAIRS
+
+
+def test_config3_one_10m_pair_batch_split_eight_ways_on_one_gpu(kslam):
+    """BASELINE configs[3]'s arithmetic at its real size -- 10 M pairs, ~80 M rows, a multi-GB CIGAR pool, 1.25 M pairs per
+    shard -- on the one GPU a box has: eight sibling contexts (they borrow the index) stand for the eight ranks.
+      alignment   every shard's records, exported in batch terms (kslam_export_shard_device) into the places
+                  kslam_comm_gather_plan assigns, ARE the rows and the CIGAR pool of one context that aligned the whole batch
+      rank-0 tail a context that adopts the merged arrays writes the whole batch's SAM text and _PerRead lines
+      sharded     phase A per shard, all shards' insert sizes to every shard, phase B, pseudo-assembly with entry e owned by
+                  shard e mod 8 (kslam_pseudo_route / _owned / _return; the exchanges are concatenations here, RCCL's part
+                  is tests/test_gpu_multi.py's), per-row walk, text: the shards' SAM / _PerRead text in shard order IS
+                  the whole batch's (CRC-32 of 2.4 GB).
+    What this cannot show is time: the eight shards share one GPU."""
+    import torch
+    assert torch.cuda.is_available(), "torch sees no HIP device"
+    W = importlib.import_module("kslam_amd.workload")
+    T = importlib.import_module("kslam_amd.tail")
+    X = importlib.import_module("kslam_amd.taxonomy")
+    ST = importlib.import_module("kslam_amd.samtext")
+    Cm = importlib.import_module("kslam_amd.comm")
+    kd = importlib.import_module("kslam_amd.dist")
+    dev = torch.device("cuda", 0)
+    N, L, n = 8, 150, PAIRS - PAIRS % 8
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1)
+    db, offs = W.make_database(dev, gen, SPECIES, STRAINS, GENOME_LEN)
+    n_entries = len(offs) - 1
+    whole = kslam.Context()
+    torch.cuda.synchronize()
+    whole.set_index_device(n_entries, db.data_ptr(), offs)
+    reads, _ = W.make_batch_in_pieces(dev, gen, db, offs, n, L, pieces=N, with_truth=False)
+    qgen = torch.Generator(device=dev)
+    qgen.manual_seed(4242)
+    qual = torch.randint(33 + 20, 33 + 41, (2 * n * L + 64,), generator=qgen, device=dev, dtype=torch.uint8)
+    torch.cuda.synchronize()
+    tax_text, entry_tax = W.taxonomy(SPECIES, STRAINS, 0)
+    index_view = T.IndexArrays(np.zeros(1, dtype=np.uint8), offs, taxonomy_ids=entry_tax)
+    taxdb = X.TaxDB(tax_text)
+    keep = []
+
+    def load(c, rd, q, n_loc, first_pair):
+        c.load_reads_device(2 * n_loc, rd.data_ptr(), np.arange(2 * n_loc + 1, dtype=np.uint64) * np.uint64(L))
+        c.load_qualities_device(q.data_ptr())
+        rv = W.ids_view(T, n_loc, L, first_pair=first_pair)
+        ST.set_annotations(c, index_view, taxdb)
+        c._chk(ST.lib().kslam_load_read_ids(c._h, rv._keep[0].ctypes.data, rv._keep[1].ctypes.data))
+        keep.append((rd, q, rv))
+
+    def text_of(contexts, tag):
+        """SAM records and per-read lines of the contexts' read pairs, in order, into two files -> their (crc, bytes)"""
+        sam_path = "/dev/shm/kslam_test_c3_%s_%d.sam" % (tag, os.getpid())
+        fd, pfd = os.open(sam_path, os.O_RDWR | os.O_CREAT | os.O_TRUNC), os.open(sam_path + "_PerRead", os.O_RDWR | os.O_CREAT | os.O_TRUNC)
+        wr = T.SamWriter(fd)
+        n_tax = 0
+        try:
+            for c in contexts:
+                c.row_details(of_pairs=True)
+                _, _, tax = ST.sam_text_to_files(c, wr, pfd, paired=True, num_alignments=10, sam_xa=False, want_per_read=True)
+                n_tax += len(tax)
+        finally:
+            wr.close()
+            os.close(fd)
+            os.close(pfd)
+        out = _file_crc(sam_path), _file_crc(sam_path + "_PerRead"), n_tax
+        os.unlink(sam_path)
+        os.unlink(sam_path + "_PerRead")
+        return out
+
+    # ---- ONE context, the whole batch ----
+    load(whole, reads, qual, n, 0)
+    n_out, n_cig = whole.align_resident()
+    ov_w = torch.empty(n_out * 48, dtype=torch.uint8, device=dev)
+    cg_w = torch.empty(max(n_cig, 1) * 4, dtype=torch.uint8, device=dev)
+    whole.copy_results_device(ov_w.data_ptr(), cg_w.data_ptr())
+    st_w = whole.pair_screen(paired=True, stages=7)
+    assert st_w["stages_done"] & 4 and n_out > 7 * n
+    exp = text_of([whole], "whole")
+    print("one context: %d rows, %d CIGAR words, SAM %d bytes, _PerRead %d bytes, limit %d" % (n_out, n_cig, exp[0][1], exp[1][1], st_w["max_insert_size"]))
+    assert exp[0][1] > 200 * n and exp[2] == st_w["n_read_pairs"]
+
+    # ---- the same batch in eight shards, each in its own context ----
+    bounds = kd.shard_bounds(n, N)
+    shards = []
+    for lo, hi in bounds:
+        c = whole.sibling()
+        rd = torch.cat([reads[lo:hi], reads[n + lo:n + hi]]).contiguous()
+        q = torch.cat([qual[lo * L:hi * L], qual[(n + lo) * L:(n + hi) * L], torch.zeros(64, dtype=torch.uint8, device=dev)]).contiguous()
+        torch.cuda.synchronize()
+        load(c, rd, q, hi - lo, lo)
+        c.align_resident()
+        shards.append(c)
+    counts = [c.shard_counts_device(hi - lo) for c, (lo, hi) in zip(shards, bounds)]
+    row1, row2, op1, op2, (tot_rows, tot_ops) = Cm.gather_plan(counts)
+    assert (tot_rows, tot_ops) == (n_out, n_cig)
+    rows = torch.empty(tot_rows * 48, dtype=torch.uint8, device=dev)
+    pool = torch.empty(max(tot_ops, 1) * 4, dtype=torch.uint8, device=dev)
+    for r, (c, (lo, hi)) in enumerate(zip(shards, bounds)):
+        c.export_shard_device(hi - lo, lo, n, op1[r], op2[r], rows.data_ptr() + 48 * row1[r], rows.data_ptr() + 48 * row2[r],
+                              pool.data_ptr() + 4 * op1[r], pool.data_ptr() + 4 * op2[r])
+    torch.cuda.synchronize()
+    assert torch.equal(rows, ov_w) and torch.equal(pool[:tot_ops * 4], cg_w[:n_cig * 4])
+    del ov_w, cg_w
+
+    # ---- rank 0's form: a context adopts the merged arrays and runs the batch-global tail ----
+    tail_ctx = whole.sibling()
+    load(tail_ctx, reads, qual, n, 0)
+    tail_ctx.adopt_results_device(rows.data_ptr(), tot_rows, pool.data_ptr(), tot_ops)
+    st_t = tail_ctx.pair_screen(paired=True, stages=7)
+    assert {k: st_t[k] for k in ("n_read_pairs", "n_pairs", "max_insert_size", "stages_done")} == \
+           {k: st_w[k] for k in ("n_read_pairs", "n_pairs", "max_insert_size", "stages_done")}
+    assert text_of([tail_ctx], "adopted") == exp
+    tail_ctx.close()
+    del rows, pool
+
+    # ---- the tail sharded like the alignment ----
+    ins = [kd.device_bytes(*(lambda p, k: (p, k * 4))(*c.pair_phase_a(True, 0)), dev) for c in shards]
+    all_ins = torch.cat(ins)
+    torch.cuda.synchronize()
+    limits = []
+    for c in shards:
+        stats, _, _ = c.pair_phase_b(all_ins.data_ptr() if all_ins.numel() else None, all_ins.numel() // 4, 0.95, 3)
+        limits.append(stats["max_insert_size"])
+    assert set(limits) == {st_w["max_insert_size"]}
+    routed = []
+    for c in shards:
+        d_heads, cn = c.pseudo_route(N)
+        routed.append((kd.device_bytes(d_heads, sum(cn) * 16, dev), cn))
+    back = [[None] * N for _ in range(N)]
+    for d, c in enumerate(shards):
+        got = torch.cat([h[sum(cn[:d]) * 16:sum(cn[:d + 1]) * 16] for h, cn in routed]).contiguous()
+        torch.cuda.synchronize()
+        k = got.numel() // 16
+        scores = kd.device_bytes(c.pseudo_owned(got.data_ptr() if k else None, k), k * 4, dev)
+        at = 0
+        for src, (_, cn) in enumerate(routed):
+            back[src][d] = scores[at:at + cn[d] * 4]
+            at += cn[d] * 4
+    owned = [sum(cn[d] for _, cn in routed) for d in range(N)]
+    print("alignment pairs per shard:", [sum(cn) for _, cn in routed], "owned after routing:", owned)
+    n_rp = 0
+    for src, c in enumerate(shards):
+        mine = torch.cat(back[src]).contiguous()
+        torch.cuda.synchronize()
+        s2 = c.pseudo_return(mine.data_ptr() if mine.numel() else None, mine.numel() // 4, 0.95)
+        assert s2["stages_done"] & 4
+        n_rp += s2["n_read_pairs"]
+    assert n_rp == st_w["n_read_pairs"]
+    assert max(owned) < 1.5 * sum(owned) / N                    # entry mod N balances the stage
+    assert text_of(shards, "sharded") == exp
+    for c in shards:
+        c.close()
+    whole.close()
+    taxdb.close()
+

@@ -1191,6 +1191,25 @@ def main():
             # sustained on a bench box (tools/copy_peak.hip, profiles/r01h_copy_peak.txt)
             "streaming_copy_ceiling": {"GB/s": 5590.0, "measured": "profiles/r01h_copy_peak.txt"},
         }
+        # the sort north_star calls "giant": the genome k-mer records, sorted ONCE per index here (the reference re-extracts and
+        # re-sorts them with every batch, src/SLAM.h:64-65).  SURVEY 8d's formula with the passes executed; device time from
+        # HIP events inside kslam_set_index (kslam_index_build_stats); PMC bytes of the same phase from a separate profiled run
+        ist = ctx.index_build_stats()
+        isort_bytes = ist["n_genome_kmers"] * 16 * (2 * ist["sort_passes"] + 1)
+        isort_pmc = None
+        if os.path.exists(tpath) and config in (1, 3) and args.species == 250:
+            try:
+                isort_pmc = (json.load(open(tpath)).get("index_sort") or {}).get("bytes")
+            except Exception:
+                isort_pmc = None
+        roofline["index_sort"] = {
+            "what": "one-time radix sort of the genome k-mer records at kslam_set_index (k_tile_hist_setup<4> + k_scatter_setup<4> per pass)",
+            "records": ist["n_genome_kmers"], "passes": ist["sort_passes"], "bytes": int(isort_bytes), "ms": round(ist["ms_sort"], 3),
+            "achieved": round(isort_bytes / (ist["ms_sort"] * 1e-3) / 1e9, 1) if ist["ms_sort"] > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(isort_bytes / (ist["ms_sort"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ist["ms_sort"] > 0 else 0.0,
+            "pmc_bytes": isort_pmc,
+            "pmc_frac": round(isort_pmc / (ist["ms_sort"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if isort_pmc and ist["ms_sort"] > 0 else None,
+            "index_build_ms": {k: round(ist[k], 2) for k in ("ms_encode_extract", "ms_sort", "ms_tables", "ms_total")}}
         hot = {
             "reads_per_s": round(total_reads / elapsed, 1), "ms_per_step": round(elapsed / Ksteps * 1e3, 3),
             "what": ("ONE batch of %d pairs per step, read pairs split over %d GPU(s), timed until rank 0 holds the merged overlap records"

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define KSLAM_ABI_VERSION 9
+#define KSLAM_ABI_VERSION 10
 #define KSLAM_K 32u /* src/Globals.h:25 */
 
 typedef enum {
@@ -112,6 +112,20 @@ typedef struct {
                                 (= n_read_kmers when the filter is off); these are sorted and joined */
 } kslam_timings;
 
+/* Device time of the last kslam_set_index / kslam_set_index_device by phase (HIP events on the context's stream,
+ * milliseconds) and the size of its one-time sort -- the sort of the genome k-mer records north_star calls "giant"
+ * (src/KMer.h:388-398 run on the genomes' records: once per index here, once per BATCH in the reference,
+ * src/SLAM.h:64-65).  Algorithmic HBM bytes of that sort by SURVEY 8d's formula: n_genome_kmers x 16 x (2 x sort_passes + 1). */
+typedef struct {
+  uint64_t n_genome_kmers;
+  uint32_t sort_passes;      /* 8-bit LSD passes executed: 8 over the 64-bit k-mer + those bytes of the meta word that can differ */
+  uint32_t n_entries;
+  float ms_encode_extract;   /* base coding + genome k-mer extraction (gap k / 2) */
+  float ms_sort;             /* the radix sort of the 16-byte records: histograms, scans, scatters */
+  float ms_tables;           /* key and {meta, offset} columns, bucket table, membership filter */
+  float ms_total;
+} kslam_index_stats;
+
 typedef struct kslam_ctx kslam_ctx;
 
 /* ---- lifecycle ------------------------------------------------------- */
@@ -158,6 +172,8 @@ kslam_status kslam_set_index(kslam_ctx *ctx, uint64_t n_entries,
 kslam_status kslam_set_index_device(kslam_ctx *ctx, uint64_t n_entries,
                                     const void *d_bases,
                                     const uint64_t *h_offsets);
+/* phases of the last index build on this context (a sibling / lane reports its primary's); KSLAM_ERR_STATE before one */
+kslam_status kslam_index_build_stats(const kslam_ctx *ctx, kslam_index_stats *out);
 
 /* ---- the operator: alignToDatabase, src/SLAM.h:59-79 -------------------
  * reads[i].bases used verbatim (src/FASTQsequence.h:46).  Output: overlaps

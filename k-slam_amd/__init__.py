@@ -39,7 +39,7 @@ STATUS = {0: "OK", 1: "ERR_ARG", 2: "ERR_NO_DEVICE", 3: "ERR_OOM", 4: "ERR_UNSUP
           5: "ERR_STATE", 6: "ERR_INTERNAL"}
 
 # every symbol include/kslam.h declares
-EXPORTS = ["kslam_abi_version", "kslam_version", "kslam_check_std_sort", "kslam_create", "kslam_destroy", "kslam_last_error", "kslam_reload_tuning", "kslam_ctx_device", "kslam_create_sibling", "kslam_adopt_results_device",
+EXPORTS = ["kslam_abi_version", "kslam_index_build_stats", "kslam_version", "kslam_check_std_sort", "kslam_create", "kslam_destroy", "kslam_last_error", "kslam_reload_tuning", "kslam_ctx_device", "kslam_create_sibling", "kslam_adopt_results_device",
            "kslam_set_index", "kslam_set_index_device", "kslam_align_batch", "kslam_free_batch",
            "kslam_align_batch_async", "kslam_wait_batch", "kslam_load_qualities", "kslam_load_qualities_device",
            "kslam_row_details", "kslam_take_row_details", "kslam_free_pinned", "kslam_submit_batch",
@@ -94,6 +94,12 @@ class Timings(C.Structure):
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class IndexStats(C.Structure):
+    """kslam_index_stats (include/kslam.h)"""
+    _fields_ = [("n_genome_kmers", C.c_uint64), ("sort_passes", C.c_uint32), ("n_entries", C.c_uint32),
+                ("ms_encode_extract", C.c_float), ("ms_sort", C.c_float), ("ms_tables", C.c_float), ("ms_total", C.c_float)]
 
 
 class KslamError(RuntimeError):
@@ -383,6 +389,12 @@ class Context:
         st = PairStats()
         self._chk(self._L.kslam_pair_screen(self._h, int(paired), score_threshold, score_fraction, stages, C.byref(st)))
         return st.as_dict()
+
+    def index_build_stats(self):
+        """kslam_index_build_stats -> dict (device milliseconds by phase, records and passes of the one-time sort)"""
+        st = IndexStats()
+        self._chk(self._L.kslam_index_build_stats(self._h, C.byref(st)))
+        return {k: (float(getattr(st, k)) if k.startswith("ms_") else int(getattr(st, k))) for k, _ in IndexStats._fields_}
 
     def pair_phase_a(self, paired=True, score_threshold=0):
         """kslam_pair_phase_a -> (device address of this shard's insert sizes (int32), their number)"""

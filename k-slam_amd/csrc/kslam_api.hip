@@ -35,6 +35,7 @@ struct kslam_ctx {
 
   // ---- index (const GenbankIndex&) ----
   bool have_index = false;
+  kslam_index_stats index_stats{};   // phases of the last build_index (siblings / lanes: a copy of the primary's)
   uint64_t n_entries = 0;
   uint64_t max_entry_len = 0;
   std::vector<uint64_t> h_goff;  // [n_entries + 1]
@@ -429,6 +430,9 @@ void build_index(kslam_ctx *c) {
   if (c->max_entry_len >= (1ull << 32)) throw StatusError{KSLAM_ERR_UNSUPPORTED, "entry longer than 2^32 bases"};
   c->g_off.ensure((n + 1) * sizeof(uint64_t));
   HIPCHK(hipMemcpyAsync(c->g_off.p, c->h_goff.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+  hipEvent_t ev_begin;
+  HIPCHK(hipEventCreate(&ev_begin));
+  HIPCHK(hipEventRecord(ev_begin, s));
   c->g_codes.ensure(c->h_goff[n] + 64);
   encode_bases(c->g_bases.as<uint8_t>(), c->g_codes.as<uint8_t>(), c->h_goff[n] + 48, s);
   Planned pl = plan_host(c->h_goff.data(), n, KSLAM_K / 2);  // gap k/2, SLAM.h:64
@@ -439,10 +443,23 @@ void build_index(kslam_ctx *c) {
   c->recs_b.ensure((m + 1) * sizeof(uint4));
   run_extract(c, c->g_bases.as<uint8_t>(), c->g_off.as<uint64_t>(), n, KSLAM_K / 2, 1, pl.n_segs,
               c->recs_a.as<uint4>());
+  // sortKMers' order (src/KMer.h:388-398): k-mer ascending, then the meta word DESCENDING.  LSD passes over the meta bytes
+  // first -- but only over bytes that can differ in a list of genome records: id < n (the low bytes its bits reach),
+  // isFromGB = 1 everywhere, revComp in bit 30 (the top byte) -- then the 8 bytes of the k-mer.  A pass over a byte that is
+  // the same in every record is the identity permutation; for 1 250 entries that is one pass of twelve not made.
   std::vector<SortPass> passes;
-  full_key_passes(passes);
+  for (uint32_t b = 0; b < 4; b++) {
+    const bool id_reaches = b < 3 && (b == 0 || ((n - 1) >> (8 * b)) != 0);   // ids 0 .. n - 1 in bits 0-29
+    const bool top = b == 3;                                                   // revComp (bit 30; ids of 2^24 entries and more)
+    if (id_reaches || top) passes.push_back(SortPass{2, 8 * b, 0xFFFFFFFFu});
+  }
+  kmer_passes(passes);
+  hipEvent_t e1, e2, e3;
+  for (hipEvent_t *e : {&e1, &e2, &e3}) HIPCHK(hipEventCreate(e));
+  HIPCHK(hipEventRecord(e1, s));
   void *sorted = radix_sort(c->recs_a.p, c->recs_b.p, m, 4, passes.data(), (int)passes.size(), c->sortws, s,
                             nullptr, nullptr, nullptr, /*setup=*/true);
+  HIPCHK(hipEventRecord(e2, s));
   c->gk_key.ensure((m + 1) * sizeof(uint64_t));
   c->gk_meta.ensure((m + 1) * sizeof(uint2));   // {meta, offset} pairs
   if (m) hipLaunchKernelGGL(k_split_soa, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, (const uint4 *)sorted,
@@ -466,7 +483,20 @@ void build_index(kslam_ctx *c) {
       filter_build(c->gk_key.as<uint64_t>(), (uint32_t)m, fb, c->g_filter.p, s);
     }
   }
+  HIPCHK(hipEventRecord(e3, s));
   HIPCHK(stream_wait(s));
+  {
+    kslam_index_stats &st = c->index_stats;
+    memset(&st, 0, sizeof st);
+    st.n_genome_kmers = m;
+    st.sort_passes = (uint32_t)passes.size();
+    st.n_entries = (uint32_t)n;
+    (void)hipEventElapsedTime(&st.ms_encode_extract, ev_begin, e1);
+    (void)hipEventElapsedTime(&st.ms_sort, e1, e2);
+    (void)hipEventElapsedTime(&st.ms_tables, e2, e3);
+    (void)hipEventElapsedTime(&st.ms_total, ev_begin, e3);
+    for (hipEvent_t e : {ev_begin, e1, e2, e3}) (void)hipEventDestroy(e);
+  }
   c->kept_last = 0;
   c->have_index = true;
   for (auto *l : c->lanes) share_index(l->c, c);   // (no batch may be in flight across kslam_set_index)
@@ -855,6 +885,7 @@ template <typename F> kslam_status multi_for_each(kslam_multi *m, F &&f) {
 void share_index(kslam_ctx *dst, const kslam_ctx *src) {
   dst->borrowed_index = true;
   dst->have_index = src->have_index;
+  dst->index_stats = src->index_stats;
   dst->n_entries = src->n_entries; dst->max_entry_len = src->max_entry_len; dst->h_goff = src->h_goff;
   dst->g_bases = src->g_bases; dst->g_off = src->g_off; dst->g_codes = src->g_codes;
   dst->n_gk = src->n_gk; dst->gk_key = src->gk_key; dst->gk_meta = src->gk_meta; dst->gk_off = src->gk_off;
@@ -1388,6 +1419,13 @@ void kslam_destroy(kslam_ctx *c) {
 }
 
 const char *kslam_last_error(const kslam_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+kslam_status kslam_index_build_stats(const kslam_ctx *c, kslam_index_stats *out) {
+  if (!c || !out) return KSLAM_ERR_ARG;
+  if (!c->have_index) return KSLAM_ERR_STATE;
+  *out = c->index_stats;
+  return KSLAM_OK;
+}
 
 kslam_status kslam_create_sibling(kslam_ctx *primary, kslam_ctx **out) {
   if (!primary || !out) return KSLAM_ERR_ARG;

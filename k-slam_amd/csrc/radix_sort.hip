@@ -67,8 +67,8 @@ __device__ __forceinline__ void tile_hist_body(const typename RecT<RW>::type *__
 // p + 1 at the record's destination (one byte next to the 8 / 16 the record takes), so that pass p + 1's
 // histogram reads 1 byte per record instead of the whole record -- the histogram read had been a third of a
 // pass's traffic.  One workgroup of 256 threads per tile, 16 digits per thread.
-__global__ __launch_bounds__(256) void k_tile_hist_bytes(const uint8_t *__restrict__ dig, uint32_t n,
-                                                         uint32_t *__restrict__ tile_hist) {
+__device__ __forceinline__ void tile_hist_bytes_body(const uint8_t *__restrict__ dig, uint32_t n,
+                                                      uint32_t *__restrict__ tile_hist) {
   __shared__ uint32_t h[256];
   const uint32_t tid = threadIdx.x;
   h[tid] = 0;
@@ -86,6 +86,15 @@ __global__ __launch_bounds__(256) void k_tile_hist_bytes(const uint8_t *__restri
   }
   __syncthreads();
   tile_hist[(uint64_t)blockIdx.x * 256 + tid] = h[tid];
+}
+__global__ __launch_bounds__(256) void k_tile_hist_bytes(const uint8_t *__restrict__ dig, uint32_t n,
+                                                         uint32_t *__restrict__ tile_hist) {
+  tile_hist_bytes_body(dig, n, tile_hist);
+}
+// the same kernel under the one-time sorts' name (see k_tile_hist_setup)
+__global__ __launch_bounds__(256) void k_tile_hist_bytes_setup(const uint8_t *__restrict__ dig, uint32_t n,
+                                                               uint32_t *__restrict__ tile_hist) {
+  tile_hist_bytes_body(dig, n, tile_hist);
 }
 
 // ---- scan of the tile histograms (per digit, over tiles) --------------------------------------
@@ -310,12 +319,14 @@ void sort_impl(void *a, void *b, uint32_t n, const PassList &pl, SortWorkspace &
   uint32_t *chunk_tot = ws.hist.as<uint32_t>();
   uint32_t *digit_tot = ws.tickets.as<uint32_t>();
   T *src = (T *)a, *dst = (T *)b;
-  // digit bytes of the NEXT pass, written by each scatter next to the records (ws.digits: n bytes; the one-time
-  // sorts keep the plain form, their kernel names are the profile's reference for it)
-  uint8_t *digits = (!SETUP && pl.n > 1 && ws.use_digit_bytes) ? ws.digits.as<uint8_t>() : nullptr;
+  // digit bytes of the NEXT pass, written by each scatter next to the records (ws.digits: n bytes): a pass then reads
+  // 1 + 16 bytes per record and writes 16 + 1 instead of reading 16 + 16 (the one-time index sort too, since round 5:
+  // its 312 M records x 11 passes are the largest sort of the path)
+  uint8_t *digits = (pl.n > 1 && ws.use_digit_bytes) ? ws.digits.as<uint8_t>() : nullptr;
   if (ev0) HIPCHK(hipEventRecord(ev0, s));
   for (int p = 0; p < pl.n; p++) {
-    if (SETUP) hipLaunchKernelGGL(k_tile_hist_setup<RW>, dim3(tiles), dim3(RS_BLOCK), 0, s, (const T *)src, n, pl.p[p], tile_hist);
+    if (SETUP && digits && p > 0) hipLaunchKernelGGL(k_tile_hist_bytes_setup, dim3(tiles), dim3(256), 0, s, (const uint8_t *)digits, n, tile_hist);
+    else if (SETUP) hipLaunchKernelGGL(k_tile_hist_setup<RW>, dim3(tiles), dim3(RS_BLOCK), 0, s, (const T *)src, n, pl.p[p], tile_hist);
     else if (digits && (p > 0 || ws.first_digits_ready)) hipLaunchKernelGGL(k_tile_hist_bytes, dim3(tiles), dim3(256), 0, s, (const uint8_t *)digits, n, tile_hist);
     else hipLaunchKernelGGL(k_tile_hist<RW>, dim3(tiles), dim3(RS_BLOCK), 0, s, (const T *)src, n, pl.p[p], tile_hist);
     hipLaunchKernelGGL(k_chunk_scan, dim3(chunks), dim3(256), 0, s, tile_hist, tiles, chunk_tot);
@@ -325,7 +336,7 @@ void sort_impl(void *a, void *b, uint32_t n, const PassList &pl, SortWorkspace &
     uint8_t *nd = (digits && p + 1 < pl.n) ? digits : nullptr;   // (pass p's histogram has read the array by now)
     const SortPass np = pl.p[p + 1 < pl.n ? p + 1 : p];
     if (SETUP) hipLaunchKernelGGL(k_scatter_setup<RW>, dim3(tiles), dim3(RS_BLOCK), 0, s, (const T *)src, dst, n, tile_hist,
-                                  chunk_tot, digit_tot, pl.p[p], (uint8_t *)nullptr, np);
+                                  chunk_tot, digit_tot, pl.p[p], nd, np);
     else hipLaunchKernelGGL(k_scatter<RW>, dim3(tiles), dim3(RS_BLOCK), 0, s, (const T *)src, dst, n, tile_hist,
                             chunk_tot, digit_tot, pl.p[p], nd, np);
     if (ws.ev_sc0) HIPCHK(hipEventRecord(ws.ev_sc1[p], s));
@@ -356,7 +367,7 @@ void *radix_sort(void *a, void *b, uint64_t n, int rec_words, const SortPass *pa
   ws.status.ensure(tiles * 256 * sizeof(uint32_t));   // per-tile digit histograms / prefixes
   ws.hist.ensure(chunks * 256 * sizeof(uint32_t));    // per-chunk totals / bases
   ws.tickets.ensure(256 * sizeof(uint32_t));           // per-digit totals -> bin bases
-  if (!setup && n_passes > 1 && ws.use_digit_bytes) ws.digits.ensure(n + 64);   // next-pass digit of every record
+  if (n_passes > 1 && ws.use_digit_bytes) ws.digits.ensure(n + 64);   // next-pass digit of every record
   void *res = nullptr;
   if (rec_words == 4 && setup) sort_impl<4, true>(a, b, (uint32_t)n, pl, ws, s, ev0, ev1, n_launches, &res);
   else if (rec_words == 4) sort_impl<4, false>(a, b, (uint32_t)n, pl, ws, s, ev0, ev1, n_launches, &res);

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol(kslam):
     for name in declared:
         assert hasattr(L, name), "missing export " + name
     assert sorted(kslam.EXPORTS) == declared
-    assert L.kslam_abi_version() == 9
+    assert L.kslam_abi_version() == 10
 
 
 def test_library_exports_every_tail_symbol(kslam):

@@ -22,8 +22,9 @@
 // sw_origin_pass), which provably selects the same begin as the reference's
 // reverse scan (the test tree holds a scalar CPU statement of it that
 // equals the striped emulation on 80k random + 60k low-complexity trials).  The striped Lazy-F evaluation order
-// is only observable when a gap pair can beat a mismatch or when gapE >= gapO;
-// kslam_create rejects such scoring.
+// is only observable when a gap pair can beat a mismatch or when gapE >= gapO: scoring outside that
+// envelope goes, candidate by candidate, through k_sw_striped below, which plays the reference's SSE
+// lanes literally (kslam_create accepts whatever the reference's flags accept).
 //
 // MI355X design: integer ALU work, no MFMA; the kernels are bound by VALU issue cycles
 // (tools/valu_peak.hip), so the code is written against the instruction
@@ -560,25 +561,92 @@ __global__ __launch_bounds__(256) void k_sw_plan(kslam_overlap *__restrict__ ov,
       nm[k] += (uint32_t)__popc((ne | inv) ^ B7);    // matches
     }
   }
-  int32_t best = 0, full = 0;
+  int32_t best = 0, full = 0, full_x = 0, near_m = 0;   // near_m: most matches on one of the two other diagonals counted
 #pragma unroll
   for (int k = 0; k < 3; k++) {
     uint32_t c = nm[k] | (nx[k] << 16);   // both counts of a diagonal in one register (each < 2^10)
 #pragma unroll
     for (int m = 1; m < GL; m <<= 1) c += (uint32_t)__shfl_xor((int)c, m, GL);
     best = max(best, (int32_t)(c & 0xFFFFu) * p.match - (int32_t)(c >> 16) * p.mismatch);
-    if (k == 0 && !z0.w.rc) full = (int32_t)(c & 0xFFFFu);   // the seed diagonal d0 itself
-    if (k == 2 && z0.w.rc) full = (int32_t)(c & 0xFFFFu);
+    const bool seed = z0.w.rc ? k == 2 : k == 0;   // the seed diagonal d0 itself
+    if (seed) {
+      full = (int32_t)(c & 0xFFFFu);
+      full_x = (int32_t)(c >> 16);
+    } else {
+      near_m = max(near_m, (int32_t)(c & 0xFFFFu));
+    }
   }
   // A read that matches its whole window base for base (seed diagonal, W = L, every column a real
   // match: no N) needs no DP at all: score match x L; any other alignment has fewer matched pairs or
   // pays for a gap, so it is the unique optimum -- end (L-1, L-1), begin (0, 0), CIGAR <L>M -- and
   // the reference's tie rules never come into play.  ~5 % of the candidates of the bench workload.
-  const bool perfect = have && rel >= 0 && W == L && L > 0 && full == L && p.ablate == 0;
-  {
-    PassResult f{p.match * L, L - 1, L - 1, 0, 0};
-    sw_epilogue<GL, 1>(ov, gi, perfect, t, L, f, qc, wc, p, band0);
+  bool perfect = have && rel >= 0 && W == L && L > 0 && full == L && p.ablate == 0;
+  PassResult f{p.match * L, L - 1, L - 1, 0, 0};
+  // ONE mismatch on the seed diagonal, every other column a real match (8.8 % of the bench workload's candidates): no DP
+  // either, when four counts say that nothing else can reach the diagonal's own best score S1.  With x the mismatch's row,
+  // the diagonal offers three maximal runs -- the whole read: match (L - 1) - mismatch; rows [0, x): match x; rows (x, L):
+  // match (L - 1 - x) -- and S1 is the largest, required to be STRICTLY the largest (a tie is left to the DP and the
+  // reference's tie rules).  Everything else is below S1 when
+  //   (a) match (L - 3) < S1               an ungapped alignment on a diagonal 3 or more away has at most L - 3 pairs;
+  //   (b) match (L - 1) - gapO < S1        an alignment with g >= 1 gap bases has I inserted and D deleted bases, at most
+  //                                        L - I pairs by its rows and at most W - D = L - D by its columns, so at most
+  //                                        L - 1, and pays gapO at least: the window is exactly as long as the read
+  //                                        (substr(s, L), src/SmithWaterman.h:204-206), that is what kills the gapped ones;
+  //   (c) match M_k < S1 for k = +-1, +-2  an ungapped alignment on diagonal d0 + k scores at most match x (the matches
+  //                                        M_k on that diagonal): two of the four were counted above, the other two are
+  //                                        counted here, by the lanes of the few candidates that get this far.
+  // Then the run is the unique optimum: its end cell is the only cell holding S1 (ssw.c:316-342 has nothing to choose),
+  // the reverse pass finds its start (:906-923), the spans are equal and the diagonal sums to S1, so the CIGAR is <n>M
+  // (sw_epilogue).  tests: test_one_mismatch_closed_form_equals_the_dp (every mismatch row, tandem repeats that fail (c),
+  // scorings that fail (a) / (b) or tie), and every parity test of the suite, whose batches are full of such candidates.
+  const bool one = have && !perfect && rel >= 0 && W == L && L > 4 && full == L - 1 && full_x == 1 && p.ablate == 0;
+  if (__ballot(one)) {
+    int32_t far_m[2] = {0, 0}, xrow = -1;
+    if (one) {
+      const int32_t dsec = z0.w.rc ? 1 : -2;   // the two diagonals not counted above: d0 - 2, d0 - 1, or d0 + 1, d0 + 2 when flipped
+      for (int32_t i = -qa + 4 * t; i < L; i += 4 * GL) {
+        const uint32_t q = *reinterpret_cast<const uint32_t *>(qc + i);
+        const uint32_t qn = (q << 5) & B7;
+        const uint8_t *wa = wc + (i + dsec);
+        const uint32_t sh = (uint32_t)(reinterpret_cast<uintptr_t>(wa) & 3u);
+        const uint32_t *wb = reinterpret_cast<const uint32_t *>(wa - sh);
+        const uint32_t a0 = __builtin_amdgcn_alignbyte(wb[1], wb[0], sh), a1 = __builtin_amdgcn_alignbyte(wb[2], wb[1], sh);
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+          const uint32_t w = k == 0 ? a0 : __builtin_amdgcn_alignbyte(a1, a0, 1u);
+          const uint32_t ne = ((q ^ w) + LO7) & B7;
+          far_m[k] += (uint32_t)__popc((ne | qn | ((w << 5) & B7)) ^ B7);
+        }
+        // the seed diagonal once more, for the row of its one mismatch
+        const uint8_t *w0p = wc + i;
+        const uint32_t sh0 = (uint32_t)(reinterpret_cast<uintptr_t>(w0p) & 3u);
+        const uint32_t *w0b = reinterpret_cast<const uint32_t *>(w0p - sh0);
+        const uint32_t w0 = __builtin_amdgcn_alignbyte(w0b[1], w0b[0], sh0);
+        const uint32_t mm = ((q ^ w0) + LO7) & B7 & ~(qn | ((w0 << 5) & B7));
+        if (mm) xrow = i + ((int32_t)__builtin_ctz(mm) >> 3);
+      }
+    }
+#pragma unroll
+    for (int m = 1; m < GL; m <<= 1) {
+      far_m[0] += __shfl_xor(far_m[0], m, GL);
+      far_m[1] += __shfl_xor(far_m[1], m, GL);
+      xrow = max(xrow, __shfl_xor(xrow, m, GL));
+    }
+    if (one && xrow >= 0 && xrow < L) {
+      const int32_t ma = p.match, whole = ma * (L - 1) - p.mismatch, left = ma * xrow, right = ma * (L - 1 - xrow);
+      int32_t S1, b, e;
+      if (whole > left && whole > right) { S1 = whole; b = 0; e = L - 1; }
+      else if (left > whole && left > right) { S1 = left; b = 0; e = xrow - 1; }
+      else if (right > whole && right > left) { S1 = right; b = xrow + 1; e = L - 1; }
+      else { S1 = -1; b = e = 0; }
+      const int32_t others = max(max(ma * (L - 3), ma * (L - 1) - p.gap_open), ma * max(near_m, max(far_m[0], far_m[1])));
+      if (S1 > 0 && others < S1) {
+        perfect = true;   // (for the tier list: this candidate is in none)
+        f = PassResult{S1, e, e, b, b};
+      }
+    }
   }
+  sw_epilogue<GL, 1>(ov, gi, perfect, t, L, f, qc, wc, p, band0);
   {
     // every lane of the group has `best`; lane k asks whether tier k's band holds, the narrowest that does is the choice
     // (no diagonal certifies anything -- a gapped alignment: T.unknown, see sw_scores)

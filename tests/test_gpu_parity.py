@@ -761,6 +761,59 @@ def test_equal_best_scores_on_neighbouring_diagonals(kslam, oracle, monkeypatch,
     assert not bad, bad
 
 
+@pytest.mark.parametrize("scoring", [None, (1, 3, 5, 2), (1, 4, 6, 1), (3, 2, 4, 1), (2, 6, 5, 2), (5, 4, 6, 3)])
+def test_one_mismatch_closed_form_equals_the_dp(kslam, oracle, synth, scoring):
+    """k_sw_plan's closed form for candidates with exactly ONE mismatch on the seed diagonal (sw.hip: no DP when the counts on
+    the four neighbouring diagonals, the window length and the gap cost rule everything else out).  Reads that are a genome
+    window with one substitution at EVERY row in turn (rows 0, 1 and L - 2, L - 1 trim the alignment), both strands, lengths
+    40-160; the same inside tandem repeats of period 1 / 2 / 3, where a neighbouring diagonal matches as well and the form
+    must stand back; reads over a genome end (window shorter than the read); a read with its mismatch next to an N.  Scorings
+    where the whole read ties with one side of the mismatch (match 1, mismatch 3: rows L - 4 and 3) or a gap is nearly free.
+    Rows, ends, begins and CIGARs must be the oracle's, which runs the reference's DP."""
+    rng = np.random.default_rng(31 + (scoring[0] * 7 + scoring[1] if scoring else 0))
+    uniq = synth.random_bases(rng, 6000)
+    reps = []
+    for period in (1, 2, 3):
+        unit = synth.random_bases(rng, period)
+        reps.append(np.concatenate([synth.random_bases(rng, 60), np.resize(unit, 400), synth.random_bases(rng, 60)]))
+    genomes = [uniq] + reps
+    comp = {ord("A"): ord("C"), ord("C"): ord("G"), ord("G"): ord("T"), ord("T"): ord("A")}
+    reads = []
+    for L in (40, 97, 150, 160):
+        at = int(rng.integers(100, 5000))
+        for x in list(range(L)) if L in (40, 150) else [0, 1, 2, 3, 4, L // 2, L - 5, L - 4, L - 3, L - 2, L - 1]:
+            r = uniq[at:at + L].copy()
+            r[x] = comp[int(r[x])]
+            reads.append(r if (x + L) % 3 else synth.revcomp(r))
+    for g in reps:                                         # seeds in the unique flank, the mismatch inside the repeat
+        for x in (50, 70, 100, 140):
+            for start in (20, 30, 45):
+                r = g[start:start + 150].copy()
+                r[x] = comp[int(r[x])]
+                reads.append(r if x % 20 else synth.revcomp(r))
+    for cut in (10, 40):                                   # over the genome's ends: the window is shorter than the read
+        r = np.concatenate([uniq[len(uniq) - 150 + cut:], synth.random_bases(rng, cut)])
+        r[70] = comp[int(r[70])]
+        reads.append(r)
+        r = np.concatenate([synth.random_bases(rng, cut), uniq[:150 - cut]])
+        r[90] = comp[int(r[90])]
+        reads.append(synth.revcomp(r))
+    r = uniq[2000:2150].copy()
+    r[60], r[61] = comp[int(r[60])], ord("N")
+    reads.append(r)
+    rb, gb = synth.to_bytes(reads), synth.to_bytes(genomes)
+    kw, p = {}, oracle.Params.default()
+    if scoring:
+        kw = dict(match=scoring[0], mismatch=scoring[1], gap_open=scoring[2], gap_extend=scoring[3])
+        p = oracle.Params.default(**kw)
+    got, gcig = kslam.align_to_database(rb, gb, **kw)
+    exp, ecig, _ = oracle.align_to_database(rb, gb, p)
+    assert len(exp) >= len(reads) - 4
+    one = (exp["entry"] == 0) & (exp["cigar_len"] == 1)
+    assert one.sum() > 300                                  # the form's own territory: ungapped rows of the unique genome
+    _compare_alignments(got, gcig, exp, ecig)
+
+
 def _low_complexity_dataset(synth, seed, n_genomes, n_reads, read_len):
     """Genomes that alternate unique stretches (seeds) with tandem repeats of period 1..6 (where equal
     best scores, equal-cost gap placements and off-diagonal optima are the rule), reads sampled from

@@ -66,6 +66,35 @@ if phase.get('FETCH_SIZE') and phase.get('WRITE_SIZE'):
           'by_kernel_fetch_kib': phase['FETCH_SIZE'][0]['by_kernel'], 'by_kernel_write_kib': phase['WRITE_SIZE'][0]['by_kernel']}
     json.dump(sp, open('gpurun_out/keep/%s_sort_phase_pmc.json' % R, 'w'), indent=1, sort_keys=True)
     print('sort phase:', sp['bytes_per_call'], 'bytes per alignment call over', sp['dispatches_per_call'], 'dispatches')
+# ---- the ONE-TIME sort of the genome k-mer records (kslam_set_index: the *_setup kernels; one index build per run) ----
+ISORT = ('k_tile_hist_setup', 'k_tile_hist_bytes_setup', 'k_scatter_setup')
+isum = {}
+for tag in ('FETCH_SIZE', 'WRITE_SIZE'):
+    tot, disp, by = 0.0, 0, {}
+    for k, cs in pmc.items():
+        if k.startswith(ISORT) and tag in cs:
+            tot += cs[tag][1]; disp += cs[tag][0]; by[k] = cs[tag][1]
+    isum[tag] = (tot, disp, by)
+index_sort = None
+if isum['FETCH_SIZE'][1] and isum['WRITE_SIZE'][1]:
+    f, w = isum['FETCH_SIZE'][0], isum['WRITE_SIZE'][0]
+    index_sort = {'dispatches': isum['FETCH_SIZE'][1], 'fetch_kib_raw': f, 'write_kib_raw': w, 'bytes': int((2 * f + w) * 1024),
+                  'by_kernel_fetch_kib': isum['FETCH_SIZE'][2], 'by_kernel_write_kib': isum['WRITE_SIZE'][2],
+                  'method': 'every dispatch of the one-time sort (k_tile_hist_setup<4>, k_tile_hist_bytes_setup, k_scatter_setup<4>; the three scan '
+                            'kernels between them move < 0.1 % and share their names with the per-batch sort) of the run\'s single kslam_set_index; '
+                            'FETCH_SIZE doubled (gfx950), WRITE_SIZE as is; unit KiB'}
+    json.dump(index_sort, open('gpurun_out/keep/%s_index_sort_pmc.json' % R, 'w'), indent=1, sort_keys=True)
+    print('index sort:', index_sort['bytes'], 'bytes over', index_sort['dispatches'], 'dispatches')
+# ---- profiles/traffic.json as bench.py reads it (this round's numbers on top; copy it over the committed file) ----
+sc = out.get('k_scatter<4>', {})
+if 'FETCH_SIZE' in sc and 'WRITE_SIZE' in sc:
+    tj = {'kernel': 'k_scatter<4>', 'source': 'profiles/%s_pmc_kslam.json (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, bench.py --steps 1 --warmup 0)' % R,
+          'fetch_kb_per_launch_raw': sc['FETCH_SIZE']['mean'], 'write_kb_per_launch_raw': sc['WRITE_SIZE']['mean'],
+          'k_scatter_bytes_per_launch': int((2 * sc['FETCH_SIZE']['mean'] + sc['WRITE_SIZE']['mean']) * 1024),
+          'method': 'mean over the dispatches of k_scatter<4>; FETCH_SIZE doubled (gfx950 reports half of a wide coalesced stream, MI355X_MICROARCH.md section HBM), WRITE_SIZE as is; counter unit KiB',
+          'sort_phase': json.load(open('gpurun_out/keep/%s_sort_phase_pmc.json' % R)) if phase.get('FETCH_SIZE') and phase.get('WRITE_SIZE') else None,
+          'index_sort': index_sort}
+    json.dump(tj, open('gpurun_out/keep/%s_traffic.json' % R, 'w'), indent=1, sort_keys=True)
 for k in sorted(out):
     print(k.ljust(30), {c: (v['dispatches'], '%.4g' % v['mean'], '%.4g' % v['max']) for c, v in out[k].items()})
 PY

@@ -7,9 +7,11 @@ receives into final places, the all-gather of the insert sizes, pseudo-assembly'
 compared with ONE context that aligned the whole batch: rank 0's gathered arrays byte for byte, the ranks' read pairs,
 alignment pairs and SAM text in rank order.
 
-usage: comm_world_n.py WORLD N_PAIRS PSEUDO(0/1) [decline]
-  decline: KSLAM_PSEUDO_CAP is set so low that the device stage declines on the rank that owns the fullest entry: EVERY
+usage: comm_world_n.py WORLD N_PAIRS PSEUDO(0/1) [decline | empty]
+  decline: the caller set KSLAM_PSEUDO_CAP so low that the device stage declines on the ranks that own entries: EVERY
            rank must come back with KSLAM_ERR_UNSUPPORTED, none may hang.
+  empty:   the read pairs of rank 1 come from nowhere: no rows to send, no alignment pairs to route -- zero-length pieces in
+           every exchange.
 Prints one JSON line."""
 import importlib
 import json
@@ -25,6 +27,7 @@ import __graft_entry__ as entry  # noqa: E402
 def main():
     world, n_pairs, pseudo = int(sys.argv[1]), int(sys.argv[2]), bool(int(sys.argv[3]))
     decline = len(sys.argv) > 4 and sys.argv[4] == "decline"
+    empty = len(sys.argv) > 4 and sys.argv[4] == "empty"
     K = entry.load_package()
     synth = importlib.import_module("kslam_amd.synth")
     Cm = importlib.import_module("kslam_amd.comm")
@@ -35,6 +38,10 @@ def main():
     reads, _ = synth.make_paired_reads(812, genomes, n_pairs, sub_rate=0.015, indel_rate=0.004, edge_frac=0.05)
     rb, gb = synth.to_bytes(reads), synth.to_bytes(genomes)
     rng = np.random.default_rng(5)
+    if empty:
+        lo, hi = kd.shard_bounds(n_pairs, world)[1] if world < 3 else (n_pairs // 5, n_pairs // 5 + 1)
+        for i in list(range(lo, hi)) + list(range(n_pairs + lo, n_pairs + hi)):
+            rb[i] = bytes(synth.random_bases(rng, len(rb[i])))
     quals = [bytes(rng.integers(35, 74, len(b), dtype=np.uint8)) for b in rb]
     ids = [b"q%05d" % i for i in range(n_pairs)]
     I = T.Index(gb, taxonomy_ids=list(range(1, len(gb) + 1)))

@@ -199,6 +199,7 @@ def test_strong_line_of_one_rank_through_the_self_launcher_equals_plain_strong()
 @pytest.mark.parametrize("bounds,pseudo", [([(0, 700), (700, 701), (701, 2500)], "routed"), ([(0, 1250), (1250, 2500)], "routed"),
                                            ([(0, 313), (313, 625), (625, 938), (938, 1250), (1250, 1563), (1563, 1875), (1875, 2188), (2188, 2500)], "routed"),
                                            ([(0, 2500)], "routed"),
+                                           ([(0, 1000), (1000, 1006), (1006, 2500)], "routed-empty-shard"),
                                            ([(0, 700), (700, 701), (701, 2500)], True), ([(0, 1250), (1250, 2500)], True),
                                            ([(0, 900), (900, 1800), (1800, 2500)], False), ([(0, 2500)], True)])
 def test_sharded_tail_equals_one_context(kslam, synth, bounds, pseudo):
@@ -214,6 +215,10 @@ def test_sharded_tail_equals_one_context(kslam, synth, bounds, pseudo):
     n_pairs = 2500
     rng = np.random.default_rng(99)
     rb, gb = _data(synth, 720, n_pairs)
+    if pseudo == "routed-empty-shard":       # the middle shard's reads come from nowhere: no rows, no alignment pairs, nothing to route
+        for i in list(range(1000, 1006)) + list(range(n_pairs + 1000, n_pairs + 1006)):
+            rb[i] = bytes(synth.random_bases(rng, len(rb[i])))
+        pseudo = "routed"
     quals = [bytes(rng.integers(35, 74, len(b), dtype=np.uint8)) for b in rb]
     ids = [b"q%05d" % i for i in range(n_pairs)]
     dev = torch.device("cuda", 0)
@@ -397,14 +402,14 @@ def _fake_rccl():
     return so
 
 
-@pytest.mark.parametrize("world,pseudo", [(2, True), (4, True), (8, True), (3, False)])
-def test_comm_behind_the_c_abi_at_world_n_on_one_gpu(world, pseudo):
+@pytest.mark.parametrize("world,pseudo,mode", [(2, True, ""), (4, True, ""), (8, True, ""), (3, False, ""), (3, True, "empty"), (2, True, "empty")])
+def test_comm_behind_the_c_abi_at_world_n_on_one_gpu(world, pseudo, mode):
     """include/kslam_comm.h at world sizes the box has no GPUs for: N threads are the ranks (tests/comm_world_n.py), RCCL's
     entry points are the test double -- the communicator code of the LIBRARY runs as at N GPUs: rank 0's gathered arrays are
     one context's result byte for byte, the ranks' SAM text in rank order is one context's text (insert-size limit from all
     ranks' insert sizes, pseudo-assembly with the entries partitioned over the ranks)."""
     env = dict(os.environ, KSLAM_RCCL_LIB=_fake_rccl())
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "comm_world_n.py"), str(world), "2400", str(int(pseudo))],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "comm_world_n.py"), str(world), "2400", str(int(pseudo))] + ([mode] if mode else []),
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
@@ -413,7 +418,7 @@ def test_comm_behind_the_c_abi_at_world_n_on_one_gpu(world, pseudo):
     assert line["gather_identical"] and line["rows"] > 2400 and line["second_gather_rows"] == line["rows"]
     assert not any(line["tail_errors"]) and line["sam_identical"] and line["counts_identical"] and line["limit_identical"]
     assert all(bool(s & 4) == pseudo for s in line["stages_done"]) and line["sam_bytes"] > 200 * 2400
-    assert all(m > 0 for m in line["moved"])
+    assert all(m > 0 for m in line["moved"])          # (an empty rank still receives the others' insert sizes)
 
 
 def test_comm_ranks_fail_together_when_one_declines():

@@ -417,7 +417,7 @@ def test_comm_behind_the_c_abi_at_world_n_on_one_gpu(world, pseudo, mode):
     assert "fake_rccl" in line["library"] and line["comm_counts"] == [world] * world and line["comm_ranks"] == list(range(world))
     assert line["gather_identical"] and line["rows"] > 2400 and line["second_gather_rows"] == line["rows"]
     assert not any(line["tail_errors"]) and line["sam_identical"] and line["counts_identical"] and line["limit_identical"]
-    assert all(bool(s & 4) == pseudo for s in line["stages_done"]) and line["sam_bytes"] > 200 * 2400
+    assert all(bool(s & 4) == pseudo for s in line["stages_done"]) and line["sam_bytes"] > (100 if mode == "empty" else 200) * 2400
     assert all(m > 0 for m in line["moved"])          # (an empty rank still receives the others' insert sizes)
 
 

@@ -499,6 +499,9 @@ def main():
                     help="who moves the data between the ranks: kslam = the library's own RCCL path behind the C ABI (include/kslam_comm.h, "
                          "what a C++ host links: librccl opened by the library, no PyTorch in the transfers); torch = torch.distributed "
                          "(k-slam_amd/dist.py, the same protocol); auto = kslam when its communicator comes up on every rank, else torch")
+    ap.add_argument("--strong-reference", choices=["auto", "off"], default="auto",
+                    help="N = 1, default workload: also run `--strong` (ONE 10 M-pair batch per step, the workload of the --gpus N > 1 lines) in a "
+                         "child process afterwards and attach its value as `strong_reference`: the N = 1 point of the scaling curve, same box, same run")
     ap.add_argument("--total-pairs", type=int, default=10_000_000,
                     help="pairs per batch in --strong mode (the reference's --num-reads-at-once default, src/main.cpp:56)")
     args = ap.parse_args()
@@ -1250,6 +1253,8 @@ def main():
                            "shared_gpu": bool(share)}
             out["per_rank_align_ms"] = per_rank_align
         if use_dist and strong:
+            out["n1_point_of_this_curve"] = ("the same workload on one GPU: `bench.py --gpus 1 --strong`, which the default N = 1 line runs as a "
+                                             "child process and reports as `strong_reference` (its own `value` is configs[1]: 1 M-pair batches, FASTQ in, files out)")
             out["strong_step_split_ms"] = {
                 "max_over_ranks": {k: round(v / Ksteps * 1e3, 3) for k, v in split_max.items()},
                 "rank0": {k: round(v / Ksteps * 1e3, 3) for k, v in split.items()}}
@@ -1358,9 +1363,40 @@ def main():
         if out["value"] is None:      # --no-e2e / --no-cigar / weak multi-GPU: the hot path is all that was timed
             out["value"], out["ms_per_step"] = hot["reads_per_s"], hot["ms_per_step"]
             out["value_definition"] = "hot path only: alignToDatabase on the resident batch" + (", results gathered to rank 0" if use_dist else "")
+        # ---- the N = 1 point of the scaling curve: the --gpus N > 1 lines run ONE 10 M-pair batch per step, sharded (configs[3]); this
+        # line's `value` is configs[1] (1 M-pair batches, FASTQ text in, files out).  So that the driver's N = 1, 2, 4, 8 records can be
+        # read as one curve, the same strong workload runs here on one GPU, in a child process, after this one has let go of the GPU's memory
+        if (world == 1 and not strong and config == 1 and args.strong_reference == "auto" and not args.no_e2e and not args.no_cigar
+                and pairs == 1_000_000 and args.species == 250 and args.genome_len == 4_000_000):
+            try:
+                ctx.close()
+                ctx = None
+                del db, reads
+                torch.cuda.empty_cache()
+                env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+                t0 = time.time()
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--strong", "--no-cpu-baseline", "--steps", str(max(3, min(Ksteps, 10))),
+                                    "--warmup", str(min(args.warmup, 2))], env=env, capture_output=True, text=True, timeout=900)
+                js = [x for x in r.stdout.splitlines() if x.startswith("{")]
+                if r.returncode == 0 and js:
+                    sr = json.loads(js[-1])
+                    out["strong_reference"] = {
+                        "what": "`bench.py --gpus 1 --strong` run as a child of this process: the workload of the --gpus N > 1 lines (ONE batch of "
+                                "10 M pairs per step, configs[3]'s shape) on ONE GPU -- the N = 1 point to read the scaling curve against",
+                        "value": sr["value"], "unit": sr["unit"], "ms_per_step": sr["ms_per_step"], "steps": sr["steps"],
+                        "hot_path_reads_per_s": sr["hot_path"]["reads_per_s"], "hot_path_ms_per_step": sr["hot_path"]["ms_per_step"],
+                        "classified_sharded_ms_per_step": sr.get("classified_sharded", {}).get("ms_per_step_max_over_ranks"),
+                        "classified_rank0_tail_reads_per_s": sr.get("classified_rank0_tail", {}).get("reads_per_s"),
+                        "verified": {"hot_path_ok": sr["hot_path"]["verified"]["ok"], "verified_classified": sr.get("verified_classified")},
+                        "seconds": round(time.time() - t0, 1)}
+                else:
+                    out["strong_reference"] = {"error": "child exited with %d: %s" % (r.returncode, r.stderr[-400:])}
+            except Exception as e:   # extra evidence only: never lose the bench line over it
+                out["strong_reference"] = {"error": repr(e)}
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
-    ctx.close()
+    if ctx is not None:
+        ctx.close()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

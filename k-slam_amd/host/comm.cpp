@@ -271,6 +271,7 @@ kslam_status kslam_comm_create(kslam_ctx *ctx, const uint8_t id[KSLAM_COMM_ID_BY
 void kslam_comm_destroy(kslam_comm *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
+  if (c->stream && !c->dead) (void)hipStreamSynchronize(c->stream);   // a gather begun and never ended: its buffers go away below
   if (c->nccl) (void)rccl().CommDestroy(c->nccl);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;

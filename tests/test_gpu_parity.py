@@ -761,6 +761,36 @@ def test_equal_best_scores_on_neighbouring_diagonals(kslam, oracle, monkeypatch,
     assert not bad, bad
 
 
+@pytest.mark.parametrize("n_entries,passes", [(9, 10), (300, 11)])
+def test_index_build_stats_and_the_passes_of_the_one_time_sort(kslam, synth, n_entries, passes):
+    """kslam_index_build_stats (roofline.index_sort of the bench line): the one-time sort of the genome k-mer records makes 8
+    passes over the k-mer and one per byte of the meta word that can differ in a list of genome records -- the ids' low byte,
+    their second byte from 257 entries on, the byte that holds revComp (src/KMer.h:65-67, :388-398) -- and the index it
+    leaves behind aligns like before (the rows of a batch against the oracle's)."""
+    rng = np.random.default_rng(n_entries)
+    genomes = [synth.random_bases(rng, int(rng.integers(400, 900))) for _ in range(n_entries)]
+    reads = []
+    for k in range(200):
+        g = genomes[int(rng.integers(0, n_entries))]
+        at = int(rng.integers(0, len(g) - 120))
+        r = synth.mutate(rng, g[at:at + 120], 0.02, 0.003)
+        reads.append(synth.revcomp(r) if k & 1 else r)
+    rb, gb = synth.to_bytes(reads), synth.to_bytes(genomes)
+    c = kslam.Context()
+    with pytest.raises(kslam.KslamError):
+        c.index_build_stats()                                   # no index yet
+    c.set_index(gb)
+    st = c.index_build_stats()
+    assert st["n_entries"] == n_entries and st["sort_passes"] == passes
+    assert st["n_genome_kmers"] == sum((len(g) - 32) // 16 + 1 for g in gb)
+    assert st["ms_sort"] > 0 and st["ms_total"] >= st["ms_sort"]
+    got, gcig = c.align_batch(rb)
+    assert c.timings()["n_genome_kmers"] == st["n_genome_kmers"]
+    c.close()
+    exp, ecig, _ = oracle_align(rb, gb)
+    _compare_alignments(got, gcig, exp, ecig)
+
+
 @pytest.mark.parametrize("scoring", [None, (1, 3, 5, 2), (1, 4, 6, 1), (3, 2, 4, 1), (2, 6, 5, 2), (5, 4, 6, 3)])
 def test_one_mismatch_closed_form_equals_the_dp(kslam, oracle, synth, scoring):
     """k_sw_plan's closed form for candidates with exactly ONE mismatch on the seed diagonal (sw.hip: no DP when the counts on
@@ -812,6 +842,11 @@ def test_one_mismatch_closed_form_equals_the_dp(kslam, oracle, synth, scoring):
     one = (exp["entry"] == 0) & (exp["cigar_len"] == 1)
     assert one.sum() > 150                                  # the form's own territory: ungapped rows of the unique genome
     _compare_alignments(got, gcig, exp, ecig)
+
+
+def oracle_align(rb, gb):
+    import oracle as O
+    return O.align_to_database(rb, gb)
 
 
 def _low_complexity_dataset(synth, seed, n_genomes, n_reads, read_len):

@@ -103,8 +103,8 @@ def test_bench_strong_mode_through_the_rccl_path_at_world_1():
     assert v["planted_missing"] == 0 and v["planted_expected"] > 50000 and v["merged_rows"] == v["overlaps"]
 
 
-@pytest.mark.parametrize("world", [2, 4, 8])
-def test_bench_strong_mode_with_several_ranks_on_one_gpu(world):
+@pytest.mark.parametrize("world,comm", [(2, "torch"), (4, "torch"), (8, "torch"), (2, "kslam"), (8, "kslam")])
+def test_bench_strong_mode_with_several_ranks_on_one_gpu(world, comm):
     """bench.py --gpus N --strong, launched the way the driver launches it (torch.distributed.run, one process
     per rank), with the ranks SHARING the box's one GPU (KSLAM_BENCH_SHARE_GPU=1: gloo with host-staged pieces
     instead of RCCL, which refuses two ranks on a device).  Every rank aligns its pairs of the batch in its own
@@ -112,10 +112,12 @@ def test_bench_strong_mode_with_several_ranks_on_one_gpu(world):
     real N-GPU run.  Rank 0 then aligns the WHOLE batch in one context: the merged result must equal it byte
     for byte."""
     env = dict(os.environ, KSLAM_BENCH_SHARE_GPU="1")
-    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "KSLAM_RCCL_LIB"):
         env.pop(k, None)
+    if comm == "kslam":          # the data through include/kslam_comm.h, RCCL's entry points played by tests/fake_rccl (see below)
+        env["KSLAM_RCCL_LIB"] = _fake_rccl()
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
-                        "--master-addr", "127.0.0.1", "--master-port", str(29580 + world), os.path.join(ROOT, "bench.py"),
+                        "--master-addr", "127.0.0.1", "--master-port", str(29580 + world + (20 if comm == "kslam" else 0)), os.path.join(ROOT, "bench.py"),
                         "--gpus", str(world), "--total-pairs", "48000", "--species", "4", "--strains", "3",
                         "--genome-len", "300000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
                        env=env, capture_output=True, text=True, timeout=600)
@@ -126,6 +128,9 @@ def test_bench_strong_mode_with_several_ranks_on_one_gpu(world):
     assert line["config"]["pairs_per_gpu"] == 48000 // world
     assert v["ok"] and v["merged_equals_single_context"] and v["merged_unsorted_neighbours"] == 0
     assert v["planted_missing"] == 0 and v["planted_expected"] > 60000 and v["merged_rows"] == v["overlaps"]
+    assert line["rccl"]["data_path"].startswith("kslam_comm" if comm == "kslam" else "torch.distributed")
+    assert line["rccl"]["launched_by"].startswith("external launcher") and line["verified_classified"]
+    assert "strong_reference" in line["n1_point_of_this_curve"]
 
 
 @pytest.mark.parametrize("world,comm", [(2, "torch"), (4, "torch"), (8, "torch"), (2, "kslam"), (4, "kslam"), (8, "kslam")])

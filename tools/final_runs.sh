@@ -1,5 +1,5 @@
 # the round's closing measurements, one call: bash tools/final_runs.sh rNNz
-R=${1:-r04z}
+R=${1:-r05z}
 mkdir -p gpurun_out/keep
 python -m pytest tests -m gpu -q > gpurun_out/${R}_gputests.log 2>&1; tail -4 gpurun_out/${R}_gputests.log
 python bench.py > gpurun_out/keep/${R}_bench.json 2> gpurun_out/${R}_bench.err; tail -c 400 gpurun_out/keep/${R}_bench.json

@@ -254,6 +254,41 @@ __global__ void k_dedupe_flags(const uint64_t *__restrict__ keys, uint64_t n, ui
   }
 }
 
+// The radix sort of the overlap keys spends 3 of its 7 passes on the low bytes -- rel and revComp -- which only order the
+// keys INSIDE a (read, entry) group, and such a group is a handful of keys (3.2 on the bench workload: the k-mers a read
+// shares with one locus).  So the keys are radix-sorted by their high bytes only and every key then finds its place inside
+// its group by counting: the group's bounds by walking left and right over the neighbours with equal high bytes, its rank =
+// the members that are smaller, or equal and earlier (equal keys are indistinguishable; the index only makes the ranks a
+// permutation).  A group of more than GROUP_CAP keys -- a read lying in a tandem repeat seeds hundreds of positions on one
+// entry -- is not ranked: the flag tells the host to sort that chunk the long way (and the context to stop trying).
+constexpr uint32_t GROUP_CAP = 64;
+__global__ __launch_bounds__(256) void k_group_order(const uint64_t *__restrict__ keys, uint64_t n, uint32_t shift, uint64_t *__restrict__ out,
+                                                     uint32_t *__restrict__ big) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t k = keys[i], hi = k >> shift, lowmask = (1ull << shift) - 1ull, kl = k & lowmask;
+  uint64_t lo = i, up = i + 1;
+  uint32_t rank = 0;
+  while (lo > 0 && i - lo <= GROUP_CAP) {
+    const uint64_t o = keys[lo - 1];
+    if ((o >> shift) != hi) break;
+    lo--;
+    rank += ((o & lowmask) <= kl) ? 1u : 0u;        // earlier members: smaller or equal come first
+  }
+  while (up < n && up - i <= GROUP_CAP) {
+    const uint64_t o = keys[up];
+    if ((o >> shift) != hi) break;
+    up++;
+    rank += ((o & lowmask) < kl) ? 1u : 0u;         // later members: only the strictly smaller
+  }
+  if (up - lo > GROUP_CAP) {   // (both walks stop one past the cap: a group of exactly GROUP_CAP is still whole)
+    if (i == lo || i - lo == 1) atomicOr(big, 1u);
+    out[i] = k;
+    return;
+  }
+  out[lo + rank] = k;
+}
+
 __global__ __launch_bounds__(256) void k_dedupe_compact(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ flags,
                                                         const uint32_t *__restrict__ pos, uint64_t n, OverlapKeyLayout lay,
                                                         uint32_t read_id_base, kslam_overlap *__restrict__ out) {
@@ -300,6 +335,12 @@ void join_fill_single_pass(const uint4 *d_read_recs, uint32_t n_r, GenomeIndexDe
   unsigned blocks = (n_r + JOIN_TILE - 1) / JOIN_TILE;
   hipLaunchKernelGGL(k_join_fill, dim3(blocks), dim3(JB), 0, s, d_read_recs, n_r, g, d_read_len,
                      reinterpret_cast<unsigned long long *>(d_cursor), cap, lay, d_out);
+  HIPCHK(hipGetLastError());
+}
+
+void group_order(const uint64_t *d_keys, uint64_t n, uint32_t low_bytes, uint64_t *d_out, uint32_t *d_big, hipStream_t s) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(k_group_order, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_keys, n, 8u * low_bytes, d_out, d_big);
   HIPCHK(hipGetLastError());
 }
 

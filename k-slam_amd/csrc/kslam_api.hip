@@ -34,6 +34,7 @@ struct kslam_ctx {
   hipEvent_t evs0[12]{}, evs1[12]{};   // per-pass events around the k-mer scatter kernel
 
   // ---- index (const GenbankIndex&) ----
+  bool long_groups_seen = false;     // a chunk's overlap keys held a (read, entry) group too long for join.hip's group_order
   bool have_index = false;
   kslam_index_stats index_stats{};   // phases of the last build_index (siblings / lanes: a copy of the primary's)
   uint64_t n_entries = 0;
@@ -191,6 +192,7 @@ Tuning read_tuning() {
   t.lane_waits_yield = starts("KSLAM_LANE_WAITS", 'y');
   t.pageable_columns = flag("KSLAM_PAGEABLE_COLUMNS");
   t.pseudo_cap = std::max(0, num("KSLAM_PSEUDO_CAP", 0));
+  t.join_group_order = starts("KSLAM_JOIN_GROUP_ORDER", '0') ? 0 : 1;
   t.details_in_token = !starts("KSLAM_DETAILS_IN_TOKEN", '0');
 #ifdef KSLAM_ABLATE
   t.sw_ablate = (uint32_t)num("KSLAM_SW_ABLATE", 0);
@@ -744,16 +746,38 @@ void align_resident(kslam_ctx *c, bool stop_after_join, uint64_t *n_raw_out, Pai
       c->ovk_b.ensure((raw + 1) * sizeof(uint64_t));
       // ---- a-6: sort by (read, entry, rel[, revcomp]) + unique ----
       const uint32_t key_bits = lay.bits_read + lay.bits_entry + lay.bits_rel + 1;
-      std::vector<SortPass> op;
-      for (uint32_t b = 0; b < (key_bits + 7) / 8; b++) op.push_back(SortPass{b / 4, 8 * (b % 4), 0});
-      const uint64_t *keys = (const uint64_t *)radix_sort(c->ovk_a.p, c->ovk_b.p, raw, 2, op.data(), (int)op.size(),
-                                                          c->sortws, s, nullptr, nullptr, nullptr);
+      const uint32_t key_bytes = (key_bits + 7) / 8;
+      // the low bytes that hold nothing but rel / revComp bits only order the keys inside a (read, entry[, high rel bits]) group of
+      // a few keys: radix passes over the other bytes, then join.hip's group_order -- unless a chunk of this context has
+      // shown groups too long for that (reads in tandem repeats), or the switch is off
+      const uint32_t low_bytes = (lay.bits_rel + 1) / 8;
+      bool grouped = c->tune.join_group_order && !c->long_groups_seen && low_bytes >= 2 && low_bytes < key_bytes;
       c->flags.ensure((raw + 1) * sizeof(uint32_t));
       c->pos.ensure((raw + 1) * sizeof(uint32_t));
       c->scan_tmp.ensure(scan_tmp_bytes(raw));
-      dedupe_flags(keys, raw, lay, c->flags.as<uint32_t>(), s);
-      exclusive_scan_u32(c->flags.as<uint32_t>(), c->pos.as<uint32_t>(), raw, d_tot, c->scan_tmp.p, s);
-      read_back(&m, d_tot, sizeof m, s);
+      const uint64_t *keys = nullptr;
+      for (int attempt = 0; attempt < 2; attempt++) {
+        std::vector<SortPass> op;
+        for (uint32_t b = grouped ? low_bytes : 0; b < key_bytes; b++) op.push_back(SortPass{b / 4, 8 * (b % 4), 0});
+        void *src = attempt == 0 ? c->ovk_a.p : const_cast<uint64_t *>(keys);           // (second attempt: any order of the same keys will do)
+        void *dst = src == c->ovk_a.p ? c->ovk_b.p : c->ovk_a.p;
+        keys = (const uint64_t *)radix_sort(src, dst, raw, 2, op.data(), (int)op.size(), c->sortws, s, nullptr, nullptr, nullptr);
+        uint32_t *d_big = reinterpret_cast<uint32_t *>(d_tot + 3);
+        if (grouped) {
+          uint64_t *other = keys == c->ovk_a.as<uint64_t>() ? c->ovk_b.as<uint64_t>() : c->ovk_a.as<uint64_t>();
+          HIPCHK(hipMemsetAsync(d_big, 0, sizeof(uint64_t), s));
+          group_order(keys, raw, low_bytes, other, d_big, s);
+          keys = other;
+        }
+        dedupe_flags(keys, raw, lay, c->flags.as<uint32_t>(), s);
+        exclusive_scan_u32(c->flags.as<uint32_t>(), c->pos.as<uint32_t>(), raw, d_tot, c->scan_tmp.p, s);
+        uint64_t back[4] = {0, 0, 0, 0};
+        read_back(back, d_tot, sizeof back, s);      // [0] survivors, [3] "a group was too long to rank"
+        m = back[0];
+        if (!grouped || back[3] == 0) break;
+        c->long_groups_seen = true;                     // this chunk again, all passes; later chunks go there directly
+        grouped = false;
+      }
       ensure_keep(c->res_ov, (c->n_res + m + 1) * sizeof(kslam_overlap), c->n_res * sizeof(kslam_overlap), s);
       dedupe_compact(keys, c->flags.as<uint32_t>(), c->pos.as<uint32_t>(), raw, lay, (uint32_t)r0,
                      c->res_ov.as<kslam_overlap>() + c->n_res, s);

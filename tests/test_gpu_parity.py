@@ -657,7 +657,8 @@ def test_every_kernel_variant_gives_the_same_alignments(kslam, synth, monkeypatc
                 {"KSLAM_SW_NO96": "1"},                              # no 96-diagonal tier
                 {"KSLAM_SW_UNKNOWN_ND": "16"},                       # gapped candidates start at the narrowest band
                 {"KSLAM_SW_UNKNOWN_ND": "64"},
-                {"KSLAM_SORT_DIGIT_BYTES": "0"}]                     # radix histograms re-read the records
+                {"KSLAM_SORT_DIGIT_BYTES": "0"},                     # radix histograms re-read the records
+                {"KSLAM_JOIN_GROUP_ORDER": "0"}]                     # overlap keys through all their radix passes (no group ranking)
     for env in variants:
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -759,6 +760,49 @@ def test_equal_best_scores_on_neighbouring_diagonals(kslam, oracle, monkeypatch,
         except AssertionError as e:
             bad.append((k, c["dpl"], str(e)[:120]))
     assert not bad, bad
+
+
+def test_overlap_keys_ordered_by_groups_equal_the_full_sort(kslam, oracle, synth, monkeypatch):
+    """join.hip group_order: the overlap keys are radix-sorted by their high bytes only and ranked inside each (read, entry)
+    group; a group of more than 64 keys sends the chunk -- and the context from then on -- through all the passes.  Reads from
+    a plain genome (groups of a few keys), reads that meet an entry at 3 / 5 / 9 loci (rRNA-like copies: groups of tens),
+    and reads inside tandem repeats (groups of hundreds: the fallback, in the middle of the context's life), against the
+    oracle and against the same context with the switch off; then a plain batch again on the context that has fallen back."""
+    rng = np.random.default_rng(77)
+    seg = synth.random_bases(rng, 400)
+    multi = np.concatenate([np.concatenate([synth.random_bases(rng, 900), synth.mutate(rng, seg, 0.01, 0.0)]) for _ in range(9)])
+    plain = [synth.random_bases(rng, 20000), multi]
+    unit = synth.random_bases(rng, 5)
+    tandem = np.concatenate([synth.random_bases(rng, 300), np.resize(unit, 1200), synth.random_bases(rng, 300)])
+
+    def reads_from(genomes, n, tandem_too=False):
+        out = []
+        for k in range(n):
+            g = genomes[k % len(genomes)]
+            at = int(rng.integers(0, len(g) - 150))
+            r = synth.mutate(rng, g[at:at + 150], 0.02, 0.003)[:150]
+            out.append(synth.revcomp(r) if k % 3 == 0 else r)
+        return out
+    seg_reads = [synth.mutate(rng, seg[i:i + 150], 0.01, 0.002)[:150] for i in range(0, 240, 8)]      # 9 loci each
+    batch1 = synth.to_bytes(reads_from(plain, 600) + seg_reads)
+    batch2 = synth.to_bytes(reads_from([tandem, plain[0]], 400))                                       # tandem repeats: long groups
+    gb = synth.to_bytes(plain + [tandem])
+    c = kslam.Context()
+    c.set_index(gb)
+    for rb in (batch1, batch2, batch1):
+        got, gcig = c.align_batch(rb)
+        exp, ecig, _ = oracle.align_to_database(rb, gb)
+        _compare_alignments(got, gcig, exp, ecig)
+    monkeypatch.setenv("KSLAM_JOIN_GROUP_ORDER", "0")
+    c2 = kslam.Context()
+    c2.set_index(gb)
+    for rb in (batch1, batch2):
+        a, ac = c.align_batch(rb)
+        b, bc = c2.align_batch(rb)
+        _compare_alignments(a, ac, b, bc)
+    monkeypatch.delenv("KSLAM_JOIN_GROUP_ORDER")
+    c.close()
+    c2.close()
 
 
 @pytest.mark.parametrize("n_entries,passes", [(9, 10), (300, 11)])

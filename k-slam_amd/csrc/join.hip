@@ -264,29 +264,41 @@ __global__ void k_dedupe_flags(const uint64_t *__restrict__ keys, uint64_t n, ui
 constexpr uint32_t GROUP_CAP = 64;
 __global__ __launch_bounds__(256) void k_group_order(const uint64_t *__restrict__ keys, uint64_t n, uint32_t shift, uint64_t *__restrict__ out,
                                                      uint32_t *__restrict__ big) {
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // the block's 256 keys and a halo of GROUP_CAP + 1 on either side in LDS: the walks never leave it
+  constexpr uint32_t HALO = GROUP_CAP + 1, TILE = 256 + 2 * HALO;
+  __shared__ uint64_t sk[TILE];
+  const uint64_t base = (uint64_t)blockIdx.x * 256;
+  for (uint32_t x = threadIdx.x; x < TILE; x += 256) {
+    const int64_t g = (int64_t)base - HALO + x;
+    sk[x] = (g >= 0 && (uint64_t)g < n) ? keys[g] : 0;
+  }
+  __syncthreads();
+  const uint64_t i = base + threadIdx.x;
   if (i >= n) return;
-  const uint64_t k = keys[i], hi = k >> shift, lowmask = (1ull << shift) - 1ull, kl = k & lowmask;
-  uint64_t lo = i, up = i + 1;
-  uint32_t rank = 0;
-  while (lo > 0 && i - lo <= GROUP_CAP) {
-    const uint64_t o = keys[lo - 1];
+  const uint32_t me = HALO + threadIdx.x;
+  // how far the halo reaches into real keys on either side of this block
+  const uint32_t first = (uint32_t)(base >= HALO ? 0 : HALO - base);                       // sk[first] = keys[max(base - HALO, 0)]
+  const uint32_t last = (uint32_t)min((uint64_t)TILE, n - base + HALO);                     // sk[last - 1] = the last real key in reach
+  const uint64_t k = sk[me], hi = k >> shift, lowmask = (1ull << shift) - 1ull, kl = k & lowmask;
+  uint32_t lo = me, up = me + 1, rank = 0;
+  while (lo > first && me - lo <= GROUP_CAP) {
+    const uint64_t o = sk[lo - 1];
     if ((o >> shift) != hi) break;
     lo--;
     rank += ((o & lowmask) <= kl) ? 1u : 0u;        // earlier members: smaller or equal come first
   }
-  while (up < n && up - i <= GROUP_CAP) {
-    const uint64_t o = keys[up];
+  while (up < last && up - me <= GROUP_CAP) {
+    const uint64_t o = sk[up];
     if ((o >> shift) != hi) break;
     up++;
     rank += ((o & lowmask) < kl) ? 1u : 0u;         // later members: only the strictly smaller
   }
   if (up - lo > GROUP_CAP) {   // (both walks stop one past the cap: a group of exactly GROUP_CAP is still whole)
-    if (i == lo || i - lo == 1) atomicOr(big, 1u);
+    if (me - lo <= 1) atomicOr(big, 1u);
     out[i] = k;
     return;
   }
-  out[lo + rank] = k;
+  out[i - (me - lo) + rank] = k;
 }
 
 __global__ __launch_bounds__(256) void k_dedupe_compact(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ flags,

@@ -350,9 +350,9 @@ void join_fill_single_pass(const uint4 *d_read_recs, uint32_t n_r, GenomeIndexDe
   HIPCHK(hipGetLastError());
 }
 
-void group_order(const uint64_t *d_keys, uint64_t n, uint32_t low_bytes, uint64_t *d_out, uint32_t *d_big, hipStream_t s) {
+void group_order(const uint64_t *d_keys, uint64_t n, uint32_t low_bits, uint64_t *d_out, uint32_t *d_big, hipStream_t s) {
   if (n == 0) return;
-  hipLaunchKernelGGL(k_group_order, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_keys, n, 8u * low_bytes, d_out, d_big);
+  hipLaunchKernelGGL(k_group_order, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_keys, n, low_bits, d_out, d_big);
   HIPCHK(hipGetLastError());
 }
 

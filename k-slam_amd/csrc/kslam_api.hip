@@ -747,18 +747,21 @@ void align_resident(kslam_ctx *c, bool stop_after_join, uint64_t *n_raw_out, Pai
       // ---- a-6: sort by (read, entry, rel[, revcomp]) + unique ----
       const uint32_t key_bits = lay.bits_read + lay.bits_entry + lay.bits_rel + 1;
       const uint32_t key_bytes = (key_bits + 7) / 8;
-      // the low bytes that hold nothing but rel / revComp bits only order the keys inside a (read, entry[, high rel bits]) group of
-      // a few keys: radix passes over the other bytes, then join.hip's group_order -- unless a chunk of this context has
-      // shown groups too long for that (reads in tandem repeats), or the switch is off
-      const uint32_t low_bytes = (lay.bits_rel + 1) / 8;
-      bool grouped = c->tune.join_group_order && !c->long_groups_seen && low_bytes >= 2 && low_bytes < key_bytes;
+      // the low bits -- rel and revComp -- only order the keys inside a (read, entry) group of a few keys: radix passes over the
+      // bits above them, then join.hip's group_order -- unless a chunk of this context has shown groups too long for that (reads
+      // in tandem repeats), or the switch is off
+      const uint32_t low_bits = lay.bits_rel + 1;
+      bool grouped = c->tune.join_group_order && !c->long_groups_seen && low_bits >= 16 && low_bits < key_bits;
       c->flags.ensure((raw + 1) * sizeof(uint32_t));
       c->pos.ensure((raw + 1) * sizeof(uint32_t));
       c->scan_tmp.ensure(scan_tmp_bytes(raw));
       const uint64_t *keys = nullptr;
       for (int attempt = 0; attempt < 2; attempt++) {
         std::vector<SortPass> op;
-        for (uint32_t b = grouped ? low_bytes : 0; b < key_bytes; b++) op.push_back(SortPass{b / 4, 8 * (b % 4), 0});
+        if (grouped)   // digits of the whole 64-bit key from bit low_bits on (radix_sort.hip: word 2)
+          for (uint32_t sh = low_bits; sh < key_bits; sh += 8) op.push_back(SortPass{2u, sh, 0});
+        else
+          for (uint32_t b = 0; b < key_bytes; b++) op.push_back(SortPass{b / 4, 8 * (b % 4), 0});
         void *src = attempt == 0 ? c->ovk_a.p : const_cast<uint64_t *>(keys);           // (second attempt: any order of the same keys will do)
         void *dst = src == c->ovk_a.p ? c->ovk_b.p : c->ovk_a.p;
         keys = (const uint64_t *)radix_sort(src, dst, raw, 2, op.data(), (int)op.size(), c->sortws, s, nullptr, nullptr, nullptr);
@@ -766,7 +769,7 @@ void align_resident(kslam_ctx *c, bool stop_after_join, uint64_t *n_raw_out, Pai
         if (grouped) {
           uint64_t *other = keys == c->ovk_a.as<uint64_t>() ? c->ovk_b.as<uint64_t>() : c->ovk_a.as<uint64_t>();
           HIPCHK(hipMemsetAsync(d_big, 0, sizeof(uint64_t), s));
-          group_order(keys, raw, low_bytes, other, d_big, s);
+          group_order(keys, raw, low_bits, other, d_big, s);
           keys = other;
         }
         dedupe_flags(keys, raw, lay, c->flags.as<uint32_t>(), s);

@@ -43,6 +43,11 @@ __device__ inline uint32_t rec_word(const uint2 &r, uint32_t w) { return w == 0 
 template <typename T> __device__ inline uint32_t digit_of(const T &r, const SortPass &p) {
   return ((rec_word(r, p.word) ^ p.invert) >> p.shift) & 0xFFu;
 }
+// a two-word record is also a 64-bit key: word 2 = "the digit at bit `shift` of the whole key", whatever words it straddles
+__device__ inline uint32_t digit_of(const uint2 &r, const SortPass &p) {
+  if (p.word == 2u) return (uint32_t)(((((uint64_t)r.y) << 32) | r.x) >> p.shift) & 0xFFu;
+  return ((rec_word(r, p.word) ^ p.invert) >> p.shift) & 0xFFu;
+}
 
 // ---- per-tile digit histogram of one pass ----------------------------------------------------
 // One workgroup per 4096-record tile: 16 B/lane coalesced loads, LDS atomic histogram, 1 KiB out.

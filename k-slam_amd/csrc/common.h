@@ -260,11 +260,11 @@ void build_bucket_table(const uint64_t *d_keys, uint32_t n, uint32_t bits, uint3
 // total number of overlaps; nothing beyond `cap` is written (caller reruns with a larger buffer)
 void join_fill_single_pass(const uint4 *d_read_recs, uint32_t n_r, GenomeIndexDev g, const uint32_t *d_read_len,
                            uint64_t *d_cursor, uint64_t cap, OverlapKeyLayout lay, uint64_t *d_out, hipStream_t s);
-// overlap keys sorted by their HIGH bits only (radix passes over the bits from low_bits on): order the low bits inside every group of
-// equal high bits -- a handful of keys: the overlaps of one read with one entry -- by ranking each key among its group
-// (join.hip).  *d_big is set when a group holds more than 64 keys (a read in a tandem repeat): the caller sorts such a
-// chunk the long way.
-void group_order(const uint64_t *d_keys, uint64_t n, uint32_t low_bits, uint64_t *d_out, uint32_t *d_big, hipStream_t s);
+// overlap keys radix-sorted by the bits above rel / revComp only: finish every (read, entry) group -- order its few keys by the
+// low bits, apply std::unique's "within 3 of the last kept" (Overlap.h:79-85) -- writing ordered keys and flags (join.hip).
+// *d_big is set when a group holds more than 64 keys (a read in a tandem repeat): d_out / d_flags are then incomplete and the
+// caller sorts the chunk the long way from d_keys, which is only read here.
+void group_order(const uint64_t *d_keys, uint64_t n, OverlapKeyLayout lay, uint64_t *d_out, uint32_t *d_flags, uint32_t *d_big, hipStream_t s);
 void dedupe_flags(const uint64_t *d_keys, uint64_t n, OverlapKeyLayout lay, uint32_t *d_flags,
                   hipStream_t s);
 void dedupe_compact(const uint64_t *d_keys, const uint32_t *d_flags, const uint32_t *d_pos,

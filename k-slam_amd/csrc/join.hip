@@ -254,51 +254,62 @@ __global__ void k_dedupe_flags(const uint64_t *__restrict__ keys, uint64_t n, ui
   }
 }
 
-// The radix sort of the overlap keys spends 3 of its 7 passes on the low bytes -- rel and revComp -- which only order the
+// The radix sort of the overlap keys would spend 3 of its 7 passes on the low bits -- rel and revComp -- which only order the
 // keys INSIDE a (read, entry) group, and such a group is a handful of keys (3.2 on the bench workload: the k-mers a read
-// shares with one locus).  So the keys are radix-sorted by their high bytes only and every key then finds its place inside
-// its group by counting: the group's bounds by walking left and right over the neighbours with equal high bytes, its rank =
-// the members that are smaller, or equal and earlier (equal keys are indistinguishable; the index only makes the ranks a
-// permutation).  A group of more than GROUP_CAP keys -- a read lying in a tandem repeat seeds hundreds of positions on one
-// entry -- is not ranked: the flag tells the host to sort that chunk the long way (and the context to stop trying).
+// shares with one locus).  So the keys are radix-sorted by the bits above them only (4 passes), and the groups are finished
+// here.  A group of more than GROUP_CAP keys -- a read lying in a tandem repeat seeds hundreds of positions on one entry --
+// is not: the flag tells the host to sort that chunk the long way (and the context to stop trying).
 constexpr uint32_t GROUP_CAP = 64;
-__global__ __launch_bounds__(256) void k_group_order(const uint64_t *__restrict__ keys, uint64_t n, uint32_t shift, uint64_t *__restrict__ out,
-                                                     uint32_t *__restrict__ big) {
-  // the block's 256 keys and a halo of GROUP_CAP + 1 on either side in LDS: the walks never leave it
-  constexpr uint32_t HALO = GROUP_CAP + 1, TILE = 256 + 2 * HALO;
+// One lane per GROUP: the lane whose key is the first of its group (its left neighbour has other high bits) finds the group's
+// end, orders the group's keys by their low bits where they lie in LDS (insertion sort: 3 keys on average), and then walks the
+// ordered group once for std::unique's rule -- keep a key iff its rel lies 3 or more above the last KEPT one (Overlap.h:79-85,
+// 290; a group is one (read, entry), so the rule never looks across groups) -- writing the ordered keys and their flags.  So
+// the separate flags kernel is not needed on this route.  A block owns the groups that START in its 256 keys; its LDS tile
+// reaches GROUP_CAP + 1 keys further so that such a group is whole.  A longer group raises *big and is left alone: the host
+// redoes the chunk from the radix sort's output, which this kernel only reads.
+__global__ __launch_bounds__(256) void k_group_order(const uint64_t *__restrict__ keys, uint64_t n, uint32_t shift, uint64_t rel_mask,
+                                                     uint64_t *__restrict__ out, uint32_t *__restrict__ flags, uint32_t *__restrict__ big) {
+  constexpr uint32_t HALO = GROUP_CAP + 1, TILE = 1 + 256 + HALO;
   __shared__ uint64_t sk[TILE];
   const uint64_t base = (uint64_t)blockIdx.x * 256;
   for (uint32_t x = threadIdx.x; x < TILE; x += 256) {
-    const int64_t g = (int64_t)base - HALO + x;
+    const int64_t g = (int64_t)base - 1 + x;
     sk[x] = (g >= 0 && (uint64_t)g < n) ? keys[g] : 0;
   }
   __syncthreads();
   const uint64_t i = base + threadIdx.x;
-  if (i >= n) return;
-  const uint32_t me = HALO + threadIdx.x;
-  // how far the halo reaches into real keys on either side of this block
-  const uint32_t first = (uint32_t)(base >= HALO ? 0 : HALO - base);                       // sk[first] = keys[max(base - HALO, 0)]
-  const uint32_t last = (uint32_t)min((uint64_t)TILE, n - base + HALO);                     // sk[last - 1] = the last real key in reach
-  const uint64_t k = sk[me], hi = k >> shift, lowmask = (1ull << shift) - 1ull, kl = k & lowmask;
-  uint32_t lo = me, up = me + 1, rank = 0;
-  while (lo > first && me - lo <= GROUP_CAP) {
-    const uint64_t o = sk[lo - 1];
-    if ((o >> shift) != hi) break;
-    lo--;
-    rank += ((o & lowmask) <= kl) ? 1u : 0u;        // earlier members: smaller or equal come first
-  }
-  while (up < last && up - me <= GROUP_CAP) {
-    const uint64_t o = sk[up];
-    if ((o >> shift) != hi) break;
-    up++;
-    rank += ((o & lowmask) < kl) ? 1u : 0u;         // later members: only the strictly smaller
-  }
-  if (up - lo > GROUP_CAP) {   // (both walks stop one past the cap: a group of exactly GROUP_CAP is still whole)
-    if (me - lo <= 1) atomicOr(big, 1u);
-    out[i] = k;
+  const uint32_t me = 1 + threadIdx.x;
+  const uint64_t hi = sk[me] >> shift;
+  const bool head = i < n && (i == 0 || (sk[me - 1] >> shift) != hi);   // the first key of its group
+  __syncthreads();                                                     // every lane has looked before any group is reordered
+  if (!head) return;
+  const uint32_t last = (uint32_t)min((uint64_t)TILE, n - base + 1);  // sk[last - 1] = the last real key in reach
+  uint32_t up = me + 1;
+  while (up < last && up - me <= GROUP_CAP && (sk[up] >> shift) == hi) up++;
+  const uint32_t g = up - me;
+  if (g > GROUP_CAP) {
+    atomicOr(big, 1u);
     return;
   }
-  out[i - (me - lo) + rank] = k;
+  const uint64_t lowmask = (1ull << shift) - 1ull;
+  for (uint32_t a = me + 1; a < up; a++) {                           // insertion sort by the low bits (ties: any order, the keys are equal)
+    const uint64_t v = sk[a];
+    uint32_t b = a;
+    while (b > me && (sk[b - 1] & lowmask) > (v & lowmask)) {
+      sk[b] = sk[b - 1];
+      b--;
+    }
+    sk[b] = v;
+  }
+  int64_t kept = 0;
+  for (uint32_t a = me; a < up; a++) {
+    const uint64_t v = sk[a];
+    const int64_t rel = (int64_t)((v >> 1) & rel_mask);
+    const bool keep = a == me || rel - kept >= 3;
+    if (keep) kept = rel;
+    out[i + (a - me)] = v;
+    flags[i + (a - me)] = keep ? 1u : 0u;
+  }
 }
 
 __global__ __launch_bounds__(256) void k_dedupe_compact(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ flags,
@@ -350,9 +361,10 @@ void join_fill_single_pass(const uint4 *d_read_recs, uint32_t n_r, GenomeIndexDe
   HIPCHK(hipGetLastError());
 }
 
-void group_order(const uint64_t *d_keys, uint64_t n, uint32_t low_bits, uint64_t *d_out, uint32_t *d_big, hipStream_t s) {
+void group_order(const uint64_t *d_keys, uint64_t n, OverlapKeyLayout lay, uint64_t *d_out, uint32_t *d_flags, uint32_t *d_big, hipStream_t s) {
   if (n == 0) return;
-  hipLaunchKernelGGL(k_group_order, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_keys, n, low_bits, d_out, d_big);
+  hipLaunchKernelGGL(k_group_order, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_keys, n, lay.bits_rel + 1, (1ull << lay.bits_rel) - 1, d_out,
+                     d_flags, d_big);
   HIPCHK(hipGetLastError());
 }
 

@@ -766,20 +766,23 @@ void align_resident(kslam_ctx *c, bool stop_after_join, uint64_t *n_raw_out, Pai
         void *dst = src == c->ovk_a.p ? c->ovk_b.p : c->ovk_a.p;
         keys = (const uint64_t *)radix_sort(src, dst, raw, 2, op.data(), (int)op.size(), c->sortws, s, nullptr, nullptr, nullptr);
         uint32_t *d_big = reinterpret_cast<uint32_t *>(d_tot + 3);
-        if (grouped) {
+        const uint64_t *sorted_by_high = keys;
+        if (grouped) {   // ordered keys AND flags in one kernel, into the other buffer (the sort's output stays intact)
           uint64_t *other = keys == c->ovk_a.as<uint64_t>() ? c->ovk_b.as<uint64_t>() : c->ovk_a.as<uint64_t>();
           HIPCHK(hipMemsetAsync(d_big, 0, sizeof(uint64_t), s));
-          group_order(keys, raw, low_bits, other, d_big, s);
+          group_order(keys, raw, lay, other, c->flags.as<uint32_t>(), d_big, s);
           keys = other;
+        } else {
+          dedupe_flags(keys, raw, lay, c->flags.as<uint32_t>(), s);
         }
-        dedupe_flags(keys, raw, lay, c->flags.as<uint32_t>(), s);
         exclusive_scan_u32(c->flags.as<uint32_t>(), c->pos.as<uint32_t>(), raw, d_tot, c->scan_tmp.p, s);
         uint64_t back[4] = {0, 0, 0, 0};
-        read_back(back, d_tot, sizeof back, s);      // [0] survivors, [3] "a group was too long to rank"
+        read_back(back, d_tot, sizeof back, s);      // [0] survivors, [3] "a group was too long"
         m = back[0];
         if (!grouped || back[3] == 0) break;
         c->long_groups_seen = true;                     // this chunk again, all passes; later chunks go there directly
         grouped = false;
+        keys = sorted_by_high;                          // (a permutation of the chunk's keys, untouched by the attempt)
       }
       ensure_keep(c->res_ov, (c->n_res + m + 1) * sizeof(kslam_overlap), c->n_res * sizeof(kslam_overlap), s);
       dedupe_compact(keys, c->flags.as<uint32_t>(), c->pos.as<uint32_t>(), raw, lay, (uint32_t)r0,

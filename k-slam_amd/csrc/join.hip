@@ -271,58 +271,44 @@ __global__ __launch_bounds__(256) void k_group_order(const uint64_t *__restrict_
                                                      uint64_t *__restrict__ out, uint32_t *__restrict__ flags, uint32_t *__restrict__ big) {
   constexpr uint32_t HALO = GROUP_CAP + 1, TILE = 1 + 256 + HALO;
   __shared__ uint64_t sk[TILE];
-  __shared__ uint8_t sflag[TILE];
-  __shared__ uint32_t s_first;                                        // the first lane of the block that starts a group
   const uint64_t base = (uint64_t)blockIdx.x * 256;
   for (uint32_t x = threadIdx.x; x < TILE; x += 256) {
     const int64_t g = (int64_t)base - 1 + x;
     sk[x] = (g >= 0 && (uint64_t)g < n) ? keys[g] : 0;
   }
-  if (threadIdx.x == 0) s_first = 0xFFFFFFFFu;
   __syncthreads();
   const uint64_t i = base + threadIdx.x;
   const uint32_t me = 1 + threadIdx.x;
   const uint64_t hi = sk[me] >> shift;
   const bool head = i < n && (i == 0 || (sk[me - 1] >> shift) != hi);   // the first key of its group
-  if (head) atomicMin(&s_first, me);
   __syncthreads();                                                     // every lane has looked before any group is reordered
-  if (head) {
-    const uint32_t last = (uint32_t)min((uint64_t)TILE, n - base + 1);  // sk[last - 1] = the last real key in reach
-    uint32_t up = me + 1;
-    while (up < last && up - me <= GROUP_CAP && (sk[up] >> shift) == hi) up++;
-    if (up - me > GROUP_CAP) {
-      atomicOr(big, 1u);
-    } else {
-      const uint64_t lowmask = (1ull << shift) - 1ull;
-      for (uint32_t a = me + 1; a < up; a++) {                         // insertion sort by the low bits (ties: any order, the keys are equal)
-        const uint64_t v = sk[a];
-        uint32_t b = a;
-        while (b > me && (sk[b - 1] & lowmask) > (v & lowmask)) {
-          sk[b] = sk[b - 1];
-          b--;
-        }
-        sk[b] = v;
-      }
-      int64_t kept = 0;
-      for (uint32_t a = me; a < up; a++) {
-        const uint64_t v = sk[a];
-        const int64_t rel = (int64_t)((v >> 1) & rel_mask);
-        const bool keep = a == me || rel - kept >= 3;
-        if (keep) kept = rel;
-        sflag[a] = keep ? 1 : 0;
-        if (a > 256) {                                                 // the part of the block's last group that lies in the next block's range
-          out[base + (a - 1)] = v;
-          flags[base + (a - 1)] = keep ? 1u : 0u;
-        }
-      }
-    }
+  if (!head) return;
+  const uint32_t last = (uint32_t)min((uint64_t)TILE, n - base + 1);  // sk[last - 1] = the last real key in reach
+  uint32_t up = me + 1;
+  while (up < last && up - me <= GROUP_CAP && (sk[up] >> shift) == hi) up++;
+  const uint32_t g = up - me;
+  if (g > GROUP_CAP) {
+    atomicOr(big, 1u);
+    return;
   }
-  __syncthreads();
-  // every lane stores its own slot (coalesced) -- from the block's first group on: what lies before it belongs to a group that
-  // started in the previous block, which writes it
-  if (i < n && me >= s_first) {
-    out[i] = sk[me];
-    flags[i] = sflag[me];
+  const uint64_t lowmask = (1ull << shift) - 1ull;
+  for (uint32_t a = me + 1; a < up; a++) {                           // insertion sort by the low bits (ties: any order, the keys are equal)
+    const uint64_t v = sk[a];
+    uint32_t b = a;
+    while (b > me && (sk[b - 1] & lowmask) > (v & lowmask)) {
+      sk[b] = sk[b - 1];
+      b--;
+    }
+    sk[b] = v;
+  }
+  int64_t kept = 0;
+  for (uint32_t a = me; a < up; a++) {
+    const uint64_t v = sk[a];
+    const int64_t rel = (int64_t)((v >> 1) & rel_mask);
+    const bool keep = a == me || rel - kept >= 3;
+    if (keep) kept = rel;
+    out[i + (a - me)] = v;
+    flags[i + (a - me)] = keep ? 1u : 0u;
   }
 }
 

@@ -70,26 +70,55 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_tile_sums(uint64_t *tile_su
   if (threadIdx.x == 0 && total_out) *total_out = carry;
 }
 
+// Tile-local scan + tile prefix.  A thread takes FOUR consecutive elements per round (one 16-byte load; a wave's loads and
+// stores are then contiguous) over four rounds of 1 024 elements, instead of sixteen consecutive elements of its own
+// (64-byte stride between lanes: every line fetched in four pieces, 1.45 TB/s); the block scan runs once per round with
+// the carry of the rounds before it.
 template <typename OutT>
 __global__ __launch_bounds__(SCAN_BLOCK) void k_tile_scan(const uint32_t *in, OutT *out, uint64_t n,
                                                           const uint64_t *tile_prefix) {
   __shared__ uint64_t sm[8];
-  const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
-  uint32_t v[SCAN_ITEMS];
-  uint64_t acc = 0;
+  constexpr int ROUNDS = SCAN_ITEMS / 4;
+  const uint64_t tile = (uint64_t)blockIdx.x * SCAN_TILE;
+  uint32_t v[ROUNDS][4];
+  const bool in16 = (reinterpret_cast<uintptr_t>(in) & 15u) == 0, out16 = (reinterpret_cast<uintptr_t>(out) & 15u) == 0;
 #pragma unroll
-  for (int i = 0; i < SCAN_ITEMS; i++) {
-    uint64_t idx = base + i;
-    v[i] = idx < n ? in[idx] : 0;
-    acc += v[i];
+  for (int r = 0; r < ROUNDS; r++) {
+    const uint64_t idx = tile + (uint64_t)r * (SCAN_BLOCK * 4) + (uint64_t)threadIdx.x * 4;
+    if (idx + 4 <= n && in16) {
+      const uint4 q = *reinterpret_cast<const uint4 *>(in + idx);   // (tile and thread offsets are multiples of 4 elements)
+      v[r][0] = q.x; v[r][1] = q.y; v[r][2] = q.z; v[r][3] = q.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; j++) v[r][j] = idx + j < n ? in[idx + j] : 0;
+    }
   }
-  uint64_t tot;
-  uint64_t ex = block_excl_scan(acc, &tot, sm) + tile_prefix[blockIdx.x];
+  uint64_t carry = tile_prefix[blockIdx.x];
 #pragma unroll
-  for (int i = 0; i < SCAN_ITEMS; i++) {
-    uint64_t idx = base + i;
-    if (idx < n) out[idx] = (OutT)ex;
-    ex += v[i];
+  for (int r = 0; r < ROUNDS; r++) {
+    const uint64_t mine = (uint64_t)v[r][0] + v[r][1] + v[r][2] + v[r][3];
+    uint64_t tot;
+    uint64_t ex = block_excl_scan(mine, &tot, sm) + carry;
+    carry += tot;
+    const uint64_t idx = tile + (uint64_t)r * (SCAN_BLOCK * 4) + (uint64_t)threadIdx.x * 4;
+    OutT o[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      o[j] = (OutT)ex;
+      ex += v[r][j];
+    }
+    if (idx + 4 <= n && out16) {
+      if (sizeof(OutT) == 4) {
+        *reinterpret_cast<uint4 *>(out + idx) = make_uint4((uint32_t)o[0], (uint32_t)o[1], (uint32_t)o[2], (uint32_t)o[3]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++) out[idx + j] = o[j];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        if (idx + j < n) out[idx + j] = o[j];
+    }
   }
 }
 

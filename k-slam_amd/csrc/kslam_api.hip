@@ -34,7 +34,9 @@ struct kslam_ctx {
   hipEvent_t evs0[12]{}, evs1[12]{};   // per-pass events around the k-mer scatter kernel
 
   // ---- index (const GenbankIndex&) ----
-  bool long_groups_seen = false;     // a chunk's overlap keys held a (read, entry) group too long for join.hip's group_order
+  uint32_t group_route_pause = 0;    // chunks left on the long route after a chunk's overlap keys held a (read, entry) group too
+                                     // long for join.hip's group_order (a read in a tandem repeat): such data comes in stretches,
+                                     // and a chunk that tries the short route in vain pays for 4 radix passes too many
   bool have_index = false;
   kslam_index_stats index_stats{};   // phases of the last build_index (siblings / lanes: a copy of the primary's)
   uint64_t n_entries = 0;
@@ -748,10 +750,11 @@ void align_resident(kslam_ctx *c, bool stop_after_join, uint64_t *n_raw_out, Pai
       const uint32_t key_bits = lay.bits_read + lay.bits_entry + lay.bits_rel + 1;
       const uint32_t key_bytes = (key_bits + 7) / 8;
       // the low bits -- rel and revComp -- only order the keys inside a (read, entry) group of a few keys: radix passes over the
-      // bits above them, then join.hip's group_order -- unless a chunk of this context has shown groups too long for that (reads
-      // in tandem repeats), or the switch is off
+      // bits above them, then join.hip's group_order -- unless a recent chunk of this context has shown groups too long for that
+      // (reads in tandem repeats), or the switch is off
       const uint32_t low_bits = lay.bits_rel + 1;
-      bool grouped = c->tune.join_group_order && !c->long_groups_seen && low_bits >= 16 && low_bits < key_bits;
+      bool grouped = c->tune.join_group_order && c->group_route_pause == 0 && low_bits >= 16 && low_bits < key_bits;
+      if (c->group_route_pause) c->group_route_pause--;
       c->flags.ensure((raw + 1) * sizeof(uint32_t));
       c->pos.ensure((raw + 1) * sizeof(uint32_t));
       c->scan_tmp.ensure(scan_tmp_bytes(raw));
@@ -780,7 +783,7 @@ void align_resident(kslam_ctx *c, bool stop_after_join, uint64_t *n_raw_out, Pai
         read_back(back, d_tot, sizeof back, s);      // [0] survivors, [3] "a group was too long"
         m = back[0];
         if (!grouped || back[3] == 0) break;
-        c->long_groups_seen = true;                     // this chunk again, all passes; later chunks go there directly
+        c->group_route_pause = 32;                      // this chunk again, all passes; the next 32 chunks go there directly
         grouped = false;
         keys = sorted_by_high;                          // (a permutation of the chunk's keys, untouched by the attempt)
       }

@@ -56,7 +56,6 @@ struct Tuning {
   bool pageable_columns = false;      // KSLAM_PAGEABLE_COLUMNS
   bool details_in_token = true;       // KSLAM_DETAILS_IN_TOKEN=0 (A/B): the per-row walk outside the lanes' compute token
   int plan_blocks_per_cu = 64;        // KSLAM_PLAN_BLOCKS: workgroups of k_sw_plan per CU (its waves walk through the candidates)
-  int join_aos = 1;                   // KSLAM_JOIN_AOS=0: the probe reads the key column and the {meta, offset} column instead of the 16-byte records
   int join_group_order = 1;           // KSLAM_JOIN_GROUP_ORDER=0: the overlap keys go through all their radix passes (join.hip: group_order)
   int pseudo_cap = 0;                 // KSLAM_PSEUDO_CAP (tests): alignment pairs of one entry beyond which pseudo-assembly is left to the host; 0 = 262144
 #ifdef KSLAM_ABLATE
@@ -246,8 +245,6 @@ struct GenomeIndexDev {
   const uint64_t *key;   // sorted genome k-mers
   const uint2 *mo;       // {ID_isFromGB_RC, offset} of the key at the same position: ONE 8-byte gather per hit (two 4-byte
                          // columns cost two cache lines per hit; the join is bound by the lines it touches, not by ALU work)
-  const uint4 *rec;      // the same list as 16-byte records {k-mer lo, k-mer hi, meta, offset} (the sorted records as the sort left them);
-                         // when set, the probe reads keys AND payload from it: a hit's {meta, offset} lies in the sector its key came from
   const uint32_t *bucket;  // [2^bits + 1] lower bounds by top `bits` bits of the key
   uint32_t bucket_bits;
   uint32_t n;

@@ -56,18 +56,6 @@ struct Run {
   uint32_t lo, cnt;
 };
 
-__device__ inline uint64_t gkey(const GenomeIndexDev &g, uint32_t i) {
-  if (g.rec) {
-    const uint2 k = *reinterpret_cast<const uint2 *>(g.rec + i);
-    return ((uint64_t)k.y << 32) | k.x;
-  }
-  return g.key[i];
-}
-__device__ inline uint2 gpayload(const GenomeIndexDev &g, uint32_t i) {
-  if (g.rec) return reinterpret_cast<const uint2 *>(g.rec + i)[1];
-  return g.mo[i];
-}
-
 __device__ inline Run find_run(uint64_t key, const GenomeIndexDev &g) {
   Run r{0, 0};
   if (key == 0) return r;  // Overlap.h:236
@@ -84,7 +72,7 @@ __device__ inline Run find_run(uint64_t key, const GenomeIndexDev &g) {
       if (half * 8u < nb) {
         uint64_t k[8];
 #pragma unroll
-        for (uint32_t i = 0; i < 8; i++) k[i] = half * 8u + i < nb ? gkey(g, lo + half * 8u + i) : ~0ull;
+        for (uint32_t i = 0; i < 8; i++) k[i] = half * 8u + i < nb ? g.key[lo + half * 8u + i] : ~0ull;
 #pragma unroll
         for (uint32_t i = 0; i < 8; i++) {
           const bool in = half * 8u + i < nb;
@@ -99,13 +87,13 @@ __device__ inline Run find_run(uint64_t key, const GenomeIndexDev &g) {
   }
   while (lo < hi) {  // lower_bound
     uint32_t mid = lo + ((hi - lo) >> 1);
-    if (gkey(g, mid) < key) lo = mid + 1; else hi = mid;
+    if (g.key[mid] < key) lo = mid + 1; else hi = mid;
   }
-  if (lo >= end || gkey(g, lo) != key) return r;
+  if (lo >= end || g.key[lo] != key) return r;
   uint32_t a = lo + 1, z = end;
   while (a < z) {  // upper_bound
     uint32_t mid = a + ((z - a) >> 1);
-    if (gkey(g, mid) <= key) a = mid + 1; else z = mid;
+    if (g.key[mid] <= key) a = mid + 1; else z = mid;
   }
   r.lo = lo;
   r.cnt = a - lo;
@@ -194,7 +182,7 @@ __global__ __launch_bounds__(JB) void k_join_fill(const uint4 *__restrict__ recs
     for (uint32_t k = threadIdx.x; k < tot; k += JB) {
       const uint4 e = runq[owner[k]];
       const uint32_t gi = e.z + (k - e.w);
-      const uint2 mo = gpayload(g, gi);
+      const uint2 mo = g.mo[gi];
       out[bb + k] = make_overlap(e.x, e.y, mo.x, mo.y, read_len, lay);
     }
     return;
@@ -215,7 +203,7 @@ __global__ __launch_bounds__(JB) void k_join_fill(const uint4 *__restrict__ recs
     if (!queued) {
       for (uint32_t j = 0; j < c; j++) {
         const uint32_t gi = run[it].lo + j;
-        const uint2 mo = gpayload(g, gi);
+        const uint2 mo = g.mo[gi];
         out[bb + ex + j] = make_overlap(r[it].z, r[it].w, mo.x, mo.y, read_len, lay);
       }
     }
@@ -228,7 +216,7 @@ __global__ __launch_bounds__(JB) void k_join_fill(const uint4 *__restrict__ recs
     const uint64_t ob = bb + bigq_out[q];
     for (uint32_t j = threadIdx.x; j < e.w; j += JB) {
       const uint32_t gi = e.z + j;
-      const uint2 mo = gpayload(g, gi);
+      const uint2 mo = g.mo[gi];
       out[ob + j] = make_overlap(e.x, e.y, mo.x, mo.y, read_len, lay);
     }
   }

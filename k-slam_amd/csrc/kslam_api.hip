@@ -44,7 +44,7 @@ struct kslam_ctx {
   std::vector<uint64_t> h_goff;  // [n_entries + 1]
   DevBuf g_bases, g_off, g_codes;   // g_codes: encode_bases(g_bases)
   uint64_t n_gk = 0;
-  DevBuf gk_key, gk_meta, gk_off, g_bucket, gk_rec;   // gk_rec: the sorted genome records as 16-byte records (the join's view, tune.join_aos)
+  DevBuf gk_key, gk_meta, gk_off, g_bucket;
   uint32_t bucket_bits = 8;
   DevBuf g_filter;            // membership filter over the genome k-mers (filter.hip); filter_bits = 0: off
   uint32_t filter_bits = 0;
@@ -195,7 +195,6 @@ Tuning read_tuning() {
   t.pageable_columns = flag("KSLAM_PAGEABLE_COLUMNS");
   t.pseudo_cap = std::max(0, num("KSLAM_PSEUDO_CAP", 0));
   t.join_group_order = starts("KSLAM_JOIN_GROUP_ORDER", '0') ? 0 : 1;
-  t.join_aos = starts("KSLAM_JOIN_AOS", '0') ? 0 : 1;
   t.details_in_token = !starts("KSLAM_DETAILS_IN_TOKEN", '0');
 #ifdef KSLAM_ABLATE
   t.sw_ablate = (uint32_t)num("KSLAM_SW_ABLATE", 0);
@@ -469,12 +468,6 @@ void build_index(kslam_ctx *c) {
   c->gk_meta.ensure((m + 1) * sizeof(uint2));   // {meta, offset} pairs
   if (m) hipLaunchKernelGGL(k_split_soa, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, (const uint4 *)sorted,
                             (uint32_t)m, c->gk_key.as<uint64_t>(), c->gk_meta.as<uint2>());
-  if (c->tune.join_aos) {   // the sort's buffers are per-batch scratch: the records the probe reads get a home of their own
-    c->gk_rec.ensure((m + 1) * sizeof(uint4));
-    if (m) HIPCHK(hipMemcpyAsync(c->gk_rec.p, sorted, m * sizeof(uint4), hipMemcpyDeviceToDevice, s));
-  } else {
-    c->gk_rec.release();
-  }
   uint32_t bits = 8, max_bits = (uint32_t)c->tune.bucket_bits_max;   // 27: ~2.3 genome k-mers per bucket for a 5 Gb database (537 MB table)
   while (bits < max_bits && (m >> (bits + 2)) != 0) bits++;   // 2 to 4 keys per bucket (measured: 3.06 ms at 27 bits, 3.24 at 26, 3.13 at 28)
   if (c->tune.bucket_bits_exact) bits = (uint32_t)c->tune.bucket_bits_exact;   // tuning
@@ -618,7 +611,6 @@ void align_resident(kslam_ctx *c, bool stop_after_join, uint64_t *n_raw_out, Pai
 
   GenomeIndexDev g;
   g.key = c->gk_key.as<uint64_t>(); g.mo = c->gk_meta.as<uint2>();
-  g.rec = (c->tune.join_aos && c->gk_rec.p) ? c->gk_rec.as<uint4>() : nullptr;
   g.bucket = c->g_bucket.as<uint32_t>(); g.bucket_bits = c->bucket_bits; g.n = (uint32_t)c->n_gk;
   SwInputs in;
   in.read_bases = c->r_bases.as<uint8_t>(); in.read_off = c->r_off.as<uint64_t>();
@@ -929,7 +921,7 @@ void share_index(kslam_ctx *dst, const kslam_ctx *src) {
   dst->index_stats = src->index_stats;
   dst->n_entries = src->n_entries; dst->max_entry_len = src->max_entry_len; dst->h_goff = src->h_goff;
   dst->g_bases = src->g_bases; dst->g_off = src->g_off; dst->g_codes = src->g_codes;
-  dst->n_gk = src->n_gk; dst->gk_key = src->gk_key; dst->gk_meta = src->gk_meta; dst->gk_off = src->gk_off; dst->gk_rec = src->gk_rec;
+  dst->n_gk = src->n_gk; dst->gk_key = src->gk_key; dst->gk_meta = src->gk_meta; dst->gk_off = src->gk_off;
   dst->g_bucket = src->g_bucket; dst->bucket_bits = src->bucket_bits;
   dst->g_filter = src->g_filter; dst->filter_bits = src->filter_bits;
   dst->kept_last = 0;
@@ -1425,7 +1417,7 @@ void kslam_destroy(kslam_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->borrowed_index) {   // a lane's view of its primary's index: not ours to free
-      DevBuf *idx[] = {&c->g_codes, &c->g_bases, &c->g_off, &c->gk_key, &c->gk_meta, &c->gk_off, &c->g_bucket, &c->g_filter, &c->gk_rec};
+      DevBuf *idx[] = {&c->g_codes, &c->g_bases, &c->g_off, &c->gk_key, &c->gk_meta, &c->gk_off, &c->g_bucket, &c->g_filter};
       for (DevBuf *b : idx) { b->p = nullptr; b->cap = 0; }
     }
     DevBuf *bufs[] = {&c->g_codes, &c->r_codes, &c->g_bases, &c->g_off, &c->gk_key, &c->gk_meta, &c->gk_off, &c->g_bucket, &c->g_filter, &c->r_bases,

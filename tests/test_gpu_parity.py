@@ -805,6 +805,45 @@ def test_overlap_keys_ordered_by_groups_equal_the_full_sort(kslam, oracle, synth
     c2.close()
 
 
+@pytest.mark.parametrize("copies", [[3, 9, 12, 13], [12, 13, 16, 17]])
+def test_group_route_at_its_cap(kslam, oracle, synth, copies):
+    """Groups of EXACTLY known size around join.hip's cap of 64 keys.  An entry is G copies of a random 48-base unit (copy
+    starts are multiples of 16 = sampled genome k-mer offsets); a read of 95 bases over two units has 4 k-mers at offsets 0 / 16
+    / 32 / 48 that each match G - 1 sampled genome positions, a read of 96 bases has 5: raw (read, entry) groups of about 4 G
+    and 5 G keys (measured with the oracle's pre-dedupe list: 11 ... 59 and EXACTLY 64 in the first list, which stays on the
+    group route; 63, 64, 67, 79, 84 in the second, which sends its chunk the long way).
+    Plain reads ride along so that blocks hold groups of every size; everything against the oracle."""
+    rng = np.random.default_rng(sum(copies))
+    genomes, reads = [synth.random_bases(rng, 6000)], []
+    for g in copies:
+        unit = synth.random_bases(rng, 48)
+        genomes.append(np.concatenate([synth.random_bases(rng, 64), np.tile(unit, g), synth.random_bases(rng, 64)]))
+        for L in (95, 96):
+            for shift in (0, 48):
+                r = np.tile(unit, 3)[shift:shift + L].copy()
+                reads.append(r)
+                reads.append(synth.revcomp(r))
+    for k in range(300):
+        at = int(rng.integers(0, 5800))
+        reads.append(synth.mutate(rng, genomes[0][at:at + 120], 0.02, 0.002)[:120])
+    order = rng.permutation(len(reads))
+    rb, gb = synth.to_bytes([reads[i] for i in order]), synth.to_bytes(genomes)
+    # the raw (read, entry) group sizes, from the oracle's pre-dedupe list: the cap must lie inside their range
+    recs = oracle.sort_kmers(np.concatenate([oracle.extract_kmers(rb, False, 1), oracle.extract_kmers(gb, True, 16)]))
+    pre = oracle.scan_overlaps(recs, [len(r) for r in rb])
+    sizes = np.unique(pre["read"].astype(np.int64) * 64 + pre["entry"], return_counts=True)[1]
+    assert sizes.max() == (64 if max(copies) <= 13 else 84) and (sizes == 64).any()
+    c = kslam.Context()
+    c.set_index(gb)
+    got, gcig = c.align_batch(rb)
+    again, acig = c.align_batch(rb)          # (second list: this one runs inside the pause the first one's long group started)
+    c.close()
+    exp, ecig, _ = oracle.align_to_database(rb, gb)
+    assert len(exp) > 300 + 4 * sum(copies)
+    _compare_alignments(got, gcig, exp, ecig)
+    _compare_alignments(again, acig, exp, ecig)
+
+
 @pytest.mark.parametrize("n_entries,passes", [(9, 10), (300, 11)])
 def test_index_build_stats_and_the_passes_of_the_one_time_sort(kslam, synth, n_entries, passes):
     """kslam_index_build_stats (roofline.index_sort of the bench line): the one-time sort of the genome k-mer records makes 8

@@ -284,38 +284,6 @@ __global__ __launch_bounds__(256) void k_group_order(const uint64_t *__restrict_
   __syncthreads();                                                     // every lane has looked before any group is reordered
   if (!head) return;
   const uint32_t last = (uint32_t)min((uint64_t)TILE, n - base + 1);  // sk[last - 1] = the last real key in reach
-  const uint64_t lowmask = (1ull << shift) - 1ull;
-  {
-    // Most groups hold 1-4 keys: fetch the four slots after the head at once (the halo keeps them inside the tile), and if the
-    // group ends among them finish it in registers -- a 4-key sorting network on the low bits (absent keys sort last), the
-    // unique rule unrolled -- without the loops' dependent LDS round trips.
-    const uint64_t k0 = sk[me], k1 = sk[me + 1], k2 = sk[me + 2], k3 = sk[me + 3], k4 = sk[me + 4];
-    const bool h1 = me + 1 < last && (k1 >> shift) == hi, h2 = h1 && me + 2 < last && (k2 >> shift) == hi,
-               h3 = h2 && me + 3 < last && (k3 >> shift) == hi, h4 = h3 && me + 4 < last && (k4 >> shift) == hi;
-    if (!h4) {
-      const uint32_t gs = 1u + (h1 ? 1u : 0u) + (h2 ? 1u : 0u) + (h3 ? 1u : 0u);
-      const uint64_t INF = ~0ull;
-      uint64_t a0 = k0 & lowmask, a1 = h1 ? (k1 & lowmask) : INF, a2 = h2 ? (k2 & lowmask) : INF, a3 = h3 ? (k3 & lowmask) : INF;
-      uint64_t v0 = k0, v1 = k1, v2 = k2, v3 = k3;
-      auto cswap = [](uint64_t &x, uint64_t &y, uint64_t &vx, uint64_t &vy) {
-        if (y < x) { uint64_t t = x; x = y; y = t; t = vx; vx = vy; vy = t; }
-      };
-      cswap(a0, a1, v0, v1); cswap(a2, a3, v2, v3); cswap(a0, a2, v0, v2); cswap(a1, a3, v1, v3); cswap(a1, a2, v1, v2);
-      const uint64_t vs[4] = {v0, v1, v2, v3};
-      int64_t kept = 0;
-#pragma unroll
-      for (uint32_t j = 0; j < 4; j++) {
-        if (j < gs) {
-          const int64_t rel = (int64_t)((vs[j] >> 1) & rel_mask);
-          const bool keep = j == 0 || rel - kept >= 3;
-          if (keep) kept = rel;
-          out[i + j] = vs[j];
-          flags[i + j] = keep ? 1u : 0u;
-        }
-      }
-      return;
-    }
-  }
   uint32_t up = me + 1;
   while (up < last && up - me <= GROUP_CAP && (sk[up] >> shift) == hi) up++;
   const uint32_t g = up - me;
@@ -323,6 +291,7 @@ __global__ __launch_bounds__(256) void k_group_order(const uint64_t *__restrict_
     atomicOr(big, 1u);
     return;
   }
+  const uint64_t lowmask = (1ull << shift) - 1ull;
   for (uint32_t a = me + 1; a < up; a++) {                           // insertion sort by the low bits (ties: any order, the keys are equal)
     const uint64_t v = sk[a];
     uint32_t b = a;

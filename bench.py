@@ -68,6 +68,20 @@ def kfd_gpu_count():
     return n
 
 
+def device_identity(ordinal):
+    """what tells two GPUs apart across processes: the uuid the runtime reports, else the PCI address, else the ordinal"""
+    try:
+        p = torch.cuda.get_device_properties(ordinal)
+    except Exception:
+        return "ordinal:%d" % ordinal
+    u = getattr(p, "uuid", None)
+    if u is not None and str(u).strip("0-") != "":
+        return "uuid:%s" % u
+    if hasattr(p, "pci_bus_id"):
+        return "pci:%s:%s:%s" % (getattr(p, "pci_domain_id", 0), p.pci_bus_id, getattr(p, "pci_device_id", 0))
+    return "ordinal:%d" % ordinal
+
+
 def self_launch(args, argv):
     """--gpus N without a launcher: start the N rank processes here.  The parent never calls into the HIP runtime (on this
     pool an exec after the GPU was initialised takes the machine down, and Popen is fork + exec): the GPUs are counted from
@@ -114,16 +128,22 @@ def self_launch(args, argv):
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline
-def cpu_baseline(K, db, offs, seed, n_genomes, n_pairs, read_len=READ_LEN, device=0, full=False, same_reads=None, why=None):
-    """The oracle's alignToDatabase timed on the host cores (reported baseline; the oracle is the checker, never the
-    product).  full + same_reads: the WHOLE workload, on the very batch the hot path timed (then n_alignments ==
-    hot_path.counts.candidates and speedup_on_sample is the apples-to-apples ratio); otherwise a bounded sample, with
-    `why`.  The same reads then go through the HIP library: the result sets are compared record by record and the GPU's
-    time on them is reported, so that `speedup_on_sample` is one workload on both sides."""
+def cpu_baseline(K, db, offs, seed, n_genomes, n_pairs, read_len=READ_LEN, device=0, full=False, same_reads=None, why=None,
+                 with_port=True):
+    """The CPU path timed on the host cores (a reported baseline, never the product): `kind` "reference" = the reference's
+    OWN `alignToDatabase` (src/SLAM.h:59-79, the template compiled from the header where it lies into
+    oracle/_ref/libslam_ref.so: KMer.h, Overlap.h, SmithWaterman.h, ssw.c untouched), OpenMP on every CPU the job may use,
+    phase times from its own log.txt stamps (src/sequenceTools.h:171-179); `kind` "port" = oracle/'s restatement, taken when
+    oracle/_ref is absent (and reported beside the reference as `port` when it is there).
+    full + same_reads: the WHOLE workload, on the very batch the hot path timed; otherwise a bounded sample, with `why`.
+    The same reads then go through the HIP library: every row and CIGAR word is compared with the baseline's (modulo the
+    revComp ties a multi-threaded reference run leaves open) and the GPU's time on them is reported,
+    so that `speedup_on_sample` is one workload on both sides."""
     import oracle as O
+    import tempfile
     n_genomes = min(n_genomes, len(offs) - 1)
     sub = db[:int(offs[n_genomes])].cpu()
-    suboffs = offs[:n_genomes + 1]
+    suboffs = np.asarray(offs[:n_genomes + 1])
     if same_reads is not None:
         reads = same_reads.cpu().numpy()
         n_pairs = reads.shape[0] // 2
@@ -131,38 +151,69 @@ def cpu_baseline(K, db, offs, seed, n_genomes, n_pairs, read_len=READ_LEN, devic
         gen = torch.Generator(device="cpu")
         gen.manual_seed(seed)
         reads = make_reads(torch.device("cpu"), gen, sub, suboffs, n_pairs, read_len=read_len).numpy()
-    rl = [reads[i].tobytes() for i in range(reads.shape[0])]
+    reads = np.ascontiguousarray(reads)
+    n_reads = reads.shape[0]
     subn = sub.numpy()
-    gl = [subn[int(suboffs[i]):int(suboffs[i + 1])].tobytes() for i in range(n_genomes)]
-    kind_ssw = "own scalar SSW restatement"
-    if O.use_reference_ssw(True):
-        kind_ssw = "SSW core = the reference's own ssw.c (SSE2) from oracle/_ref"
     cores = O.usable_cpus()        # one OpenMP thread per CPU the job may use (cgroup quota), not per hardware thread
-    O.set_num_threads(cores)
-    al, cg, ph = O.align_to_database(rl, gl)
-    dt = float(ph[5])              # seconds inside the C call (excludes the ctypes marshalling)
-    O.use_reference_ssw(False)
-    out = {
-        "value": round(len(rl) / dt, 1), "unit": "reads/s", "cores": cores, "kind": "port",
-        "pairs": n_pairs, "read_len": read_len, "db_genomes": n_genomes, "db_bases": int(suboffs[-1]),
-        "seconds": round(dt, 2),
-        "phases_s": dict(zip(("extract", "genome_kmers", "sort", "join", "sw"), (round(float(x), 2) for x in ph[:5]))),
-        "same_batch_as_hot_path": same_reads is not None,
-        "sample": ("the WHOLE workload of this run%s: " % (", on the batch the hot path timed" if same_reads is not None else "") if full else "") +
-                  "%d pairs x %d bp vs %s database genomes (%.0f Mb)%s; whole reference batch path incl. genome k-mer "
-                  "re-extraction and the (reads+genomes) sort, alignToDatabase only (no tail), OpenMP on the CPUs the "
-                  "job's cgroup quota allows; %s" % (
-                      n_pairs, read_len, "all %d" % n_genomes if full else "the first %d" % n_genomes, float(suboffs[-1]) / 1e6,
-                      "" if full else " -- NOT the whole database, which the CPU path cannot finish inside the bounded 10-30 s",
-                      kind_ssw),
-        "n_alignments": int(len(al)),
-    }
+    what = ("%d pairs x %d bp vs %s database genomes (%.0f Mb)%s; the whole alignToDatabase batch path incl. genome k-mer "
+            "re-extraction and the (reads+genomes) sort, no tail, OpenMP on the CPUs the job's cgroup quota allows" % (
+                n_pairs, read_len, "all %d" % n_genomes if full else "the first %d" % n_genomes, float(suboffs[-1]) / 1e6,
+                "" if full else " -- NOT the whole database, which the CPU path cannot finish inside the bounded 10-30 s"))
+    if full:
+        what = "the WHOLE workload of this run%s: " % (", on the batch the hot path timed" if same_reads is not None else "") + what
+    out, ref_rows, ref_cig = None, None, None
+    if O.have_ref_slam():
+        try:
+            O.ref_slam_set_index_arrays(subn, suboffs)
+            with tempfile.TemporaryDirectory() as wd:
+                al, cg, dt, phases = O.ref_slam_align_to_database(reads.reshape(-1), np.arange(n_reads + 1, dtype=np.uint64) * np.uint64(read_len),
+                                                                  threads=cores, workdir=wd)
+            O.ref_slam_set_index_arrays(subn[:0], suboffs[:1])        # the reference's copy of the database goes back to the host
+            out = {"value": round(n_reads / dt, 1), "unit": "reads/s", "cores": cores, "kind": "reference",
+                   "what": "the reference's own alignToDatabase (src/SLAM.h:59-79) compiled in place from /root/reference/src "
+                           "(oracle/_ref/libslam_ref.so), timed around the call",
+                   "seconds": round(dt, 2), "phases_s": phases, "phases_from": "the reference's log.txt stamps (10 ms resolution)",
+                   "n_alignments": int(len(al))}
+            ref_rows, ref_cig = al, cg
+        except Exception as e:     # fall back to the port, and say so
+            out = None
+            why = (why + "; " if why else "") + "reference run failed: %r" % (e,)
+    port = None
+    if out is None or with_port:
+        rl = [reads[i].tobytes() for i in range(n_reads)]
+        gl = [subn[int(suboffs[i]):int(suboffs[i + 1])].tobytes() for i in range(n_genomes)]
+        kind_ssw = "own scalar SSW restatement"
+        if O.use_reference_ssw(True):
+            kind_ssw = "SSW core = the reference's own ssw.c (SSE2) from oracle/_ref"
+        O.set_num_threads(cores)
+        pal, pcg, ph = O.align_to_database(rl, gl)
+        pdt = float(ph[5])              # seconds inside the C call (excludes the ctypes marshalling)
+        O.use_reference_ssw(False)
+        del rl, gl
+        port = {"value": round(n_reads / pdt, 1), "unit": "reads/s", "cores": cores, "kind": "port", "what": "oracle/'s restatement; " + kind_ssw,
+                "seconds": round(pdt, 2),
+                "phases_s": dict(zip(("extract", "genome_kmers", "sort", "join", "sw"), (round(float(x), 2) for x in ph[:5]))),
+                "n_alignments": int(len(pal))}
+        if out is None:
+            out, ref_rows, ref_cig = port, pal, pcg
+            port = None
+            if not O.have_ref_slam():
+                out["why_not_the_reference"] = "oracle/_ref/libslam_ref.so is absent (it is built where /root/reference exists and travels with the snapshot)"
+        else:
+            v = O.compare_with_reference_rows(pal, pcg, ref_rows, ref_cig, lambda i: reads[i].tobytes(),
+                                              lambda j: subn[int(suboffs[j]):int(suboffs[j + 1])].tobytes())
+            port["equals_reference"] = v
+            del pal, pcg
+    out.update({"pairs": n_pairs, "read_len": read_len, "db_genomes": n_genomes, "db_bases": int(suboffs[-1]),
+                "same_batch_as_hot_path": same_reads is not None, "sample": what})
+    if port is not None:
+        out["port"] = port
     if why:
         out["why"] = why
     try:   # the same sample through the HIP library: identical records and CIGARs?  and how long does the GPU take for it?
         c = K.Context(device=device)
-        c.set_index(gl)
-        c.load_reads_arrays(np.ascontiguousarray(reads).reshape(-1), np.arange(len(rl) + 1, dtype=np.uint64) * np.uint64(read_len))
+        c.set_index_arrays(subn, suboffs)
+        c.load_reads_arrays(reads.reshape(-1), np.arange(n_reads + 1, dtype=np.uint64) * np.uint64(read_len))
         n_out, n_cig = c.align_resident()
         t0 = time.perf_counter()
         for _ in range(3):
@@ -170,12 +221,13 @@ def cpu_baseline(K, db, offs, seed, n_genomes, n_pairs, read_len=READ_LEN, devic
         gpu_ms = (time.perf_counter() - t0) / 3 * 1e3
         gov, gcg = c.fetch_results(n_out, n_cig)
         c.close()
-        same = len(gov) == len(al) and all((gov[f] == al[f]).all() for f in (
-            "read", "entry", "rel", "revcomp", "score", "ref_begin", "ref_end", "query_begin", "query_end",
-            "cigar_len", "cigar_off")) and np.array_equal(gcg, cg)
-        out["gpu_equals_cpu_on_sample"] = {"identical": bool(same), "alignments": int(len(gov)), "cigar_ops": int(len(gcg))}
+        v = O.compare_with_reference_rows(gov, gcg, ref_rows, ref_cig, lambda i: reads[i].tobytes(),
+                                          lambda j: subn[int(suboffs[j]):int(suboffs[j + 1])].tobytes())
+        out["gpu_equals_reference" if out["kind"] == "reference" else "gpu_equals_cpu_on_sample"] = v
+        if out["kind"] == "reference":
+            out["gpu_equals_cpu_on_sample"] = v      # (the name rounds 1-5 used; the checker is now the reference itself)
         out["gpu_ms_on_sample"] = round(gpu_ms, 3)
-        out["speedup_on_sample"] = round(dt * 1e3 / gpu_ms, 1)
+        out["speedup_on_sample"] = round(out["seconds"] * 1e3 / gpu_ms, 1)
     except Exception as e:   # never lose the bench line over the extra check
         out["gpu_equals_cpu_on_sample"] = {"error": repr(e)}
     return out
@@ -409,6 +461,112 @@ def e2e_leg(K, ctx, files, pairs_per_batch, index_view, taxdb, steps, warmup, ps
                 pass
 
 
+def solo_strong(K, ctx, whole, read_len, total_pairs, index_view, tax_text, steps, warmup, out_dir, tag):
+    """The strong step (ONE batch of `total_pairs` pairs, configs[3]'s shape) on ONE GPU, through the same stages the sharded
+    clock of the --gpus N > 1 lines times on every rank -- alignToDatabase, pairing / insert-size limit / screens /
+    pseudo-assembly, per-row walk, SAM text and per-read LCA written on the GPU, both files written -- with two contexts
+    taking the steps in turn (the second borrows the index).  This is the N = 1 point of the scaling curve measured IN THE
+    SAME RUN: rank 0 runs it alone after the N-rank clocks (the other ranks wait at a barrier), and the default N = 1 line
+    runs it after its own legs.  -> dict(value, ms_per_step, steps, hot_path_ms_per_step, ...)"""
+    T = importlib.import_module("kslam_amd.tail")
+    X = importlib.import_module("kslam_amd.taxonomy")
+    ST = importlib.import_module("kslam_amd.samtext")
+    dev = whole.device
+    n_reads = whole.shape[0]
+    roffs = np.arange(n_reads + 1, dtype=np.uint64) * np.uint64(read_len)
+    qgen = torch.Generator(device=dev)
+    qgen.manual_seed(4242)
+    qual = torch.randint(33 + 20, 33 + 41, (n_reads * read_len + 64,), generator=qgen, device=dev, dtype=torch.uint8)
+    torch.cuda.synchronize()
+    rv = ids_view(T, total_pairs, read_len)
+    taxdb = X.TaxDB(tax_text)
+    ctx_b = ctx.sibling()
+    pair = (ctx, ctx_b)
+    for c in pair:
+        c.load_reads_device(n_reads, whole.data_ptr(), roffs)
+        c.load_qualities_device(qual.data_ptr())
+        ST.set_annotations(c, index_view, taxdb)
+        c._chk(ST.lib().kslam_load_read_ids(c._h, rv._keep[0].ctypes.data, rv._keep[1].ctypes.data))
+    sam_path = os.path.join(out_dir, "kslam_bench_%d_%s.sam" % (os.getpid(), tag))
+    pr_path = sam_path + "_PerRead"
+    ms = {"align": 0.0, "pairing_screens_pseudo": 0.0, "row_details": 0.0, "sam_text_on_gpu": 0.0}
+    seen = {}
+
+    def worker(c, pst, fds, my_turn, next_turn):
+        my_turn.wait()                                # blocks join the writer's queue in step order: one file
+        t1 = time.perf_counter()
+        n_sam, n_pr, tax = ST.sam_text_to_files(c, fds[0], fds[1], paired=True, num_alignments=10, sam_xa=False, want_per_read=True)
+        ms["sam_text_on_gpu"] += time.perf_counter() - t1
+        seen.update(sam_bytes=n_sam, per_read_lines=int(len(tax)), max_insert_size=int(pst["max_insert_size"]),
+                    pseudo_on="gpu" if pst["stages_done"] & 4 else "host")
+        next_turn.set()
+
+    def steps_(k):
+        sam_fd = fresh_file(sam_path)
+        fds = (T.SamWriter(sam_fd), fresh_file(pr_path))
+        turn = threading.Event()
+        turn.set()
+        flights = []
+        for i in range(k):
+            c = pair[i & 1]
+            if i >= 2:
+                flights[i - 2].join()                 # this context's previous step has left its buffers and the host
+            t1 = time.perf_counter()
+            c.align_resident()
+            t2 = time.perf_counter()
+            pst = c.pair_screen(paired=True, stages=7)
+            t3 = time.perf_counter()
+            c.row_details(of_pairs=True)
+            t4 = time.perf_counter()
+            ms["align"] += t2 - t1
+            ms["pairing_screens_pseudo"] += t3 - t2
+            ms["row_details"] += t4 - t3
+            nxt = threading.Event()
+            w = threading.Thread(target=worker, args=(c, pst, fds, turn, nxt))
+            w.start()
+            flights.append(w)
+            turn = nxt
+        for w in flights:
+            w.join()
+        fds[0].close()
+        os.close(sam_fd)
+        os.close(fds[1])
+    try:
+        steps_(max(warmup, 2))                        # both contexts once: their page-locked result buffers exist afterwards
+        for k in ms:
+            ms[k] = 0.0
+        for pth in (sam_path, pr_path):
+            if os.path.exists(pth):
+                os.unlink(pth)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        steps_(steps)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        sizes = (os.path.getsize(sam_path), os.path.getsize(pr_path))
+        # the hot path alone on the whole batch: the N = 1 point of hot_path.reads_per_s
+        ctx.align_resident()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ctx.align_resident()
+        torch.cuda.synchronize()
+        hot = (time.perf_counter() - t0) / steps
+    finally:
+        for pth in (sam_path, pr_path):
+            if os.path.exists(pth):
+                os.unlink(pth)
+        ctx_b.close()
+        taxdb.close()
+    return {"what": "ONE batch of %d pairs per step on ONE GPU, the stages of classified_sharded with nothing to exchange: the N = 1 "
+                    "point of the strong-scaling curve, measured in this run" % total_pairs,
+            "value": round(2 * total_pairs * steps / el, 1), "unit": "reads/s", "ms_per_step": round(el / steps * 1e3, 3), "steps": steps,
+            "stage_ms_per_step": {k: round(v / steps * 1e3, 2) for k, v in ms.items()},
+            "hot_path_ms_per_step": round(hot * 1e3, 3), "hot_path_reads_per_s": round(2 * total_pairs / hot, 1),
+            "sam_file_bytes": sizes[0], "per_read_file_bytes": sizes[1], "sam_mb_per_batch": round(seen["sam_bytes"] / 1e6, 1),
+            "max_insert_size": seen["max_insert_size"], "pseudo_assembly_on": seen["pseudo_on"]}
+
+
 def abi_path(K, ctx, reads, read_len, steps):
     """What a k-SLAM host that only swaps alignToDatabase sees (first sketch): reads[i].bases in host
     memory in (char **, lengths), overlap records + CIGAR pool back in host memory, through kslam_align_batch one
@@ -485,7 +643,11 @@ def main():
                     help="auto: the whole configs[1] workload on the hot path's own batch when the box has >= 16 usable CPUs and the "
                          "memory (about 30 s), else the bounded sample (--cpu-pairs / --cpu-genomes)")
     ap.add_argument("--no-cigar", action="store_true")
-    ap.add_argument("--no-abi-path", action="store_true", help="skip the host-pointers-in / host-results-out leg")
+    ap.add_argument("--legs", default="", help="optional evidence legs of the N = 1 line, comma-separated or `all` (none by default: the "
+                    "driver's run is the contract legs -- hot path, e2e `value`, cpu_baseline, strong_n1): abi_path (host pointers in / host "
+                    "results out), other_sink (the e2e leg on the directory --out-dir auto did not choose), null_sink (SAM text to "
+                    "/dev/null), pseudo (the e2e leg with the reference's default, pseudo-assembly on)")
+    ap.add_argument("--no-abi-path", action="store_true", help=argparse.SUPPRESS)     # rounds 2-5 spelling: the leg is opt-in now
     ap.add_argument("--no-e2e", action="store_true", help="hot path only: `value` is then the resident-input rate and says so")
     ap.add_argument("--out-dir", default="auto", help="where the e2e legs write their SAM / _PerRead files (auto: the faster of "
                     "/dev/shm and the temp directory by a 256 MB write probe, see sink_probe in the line)")
@@ -499,12 +661,20 @@ def main():
                     help="who moves the data between the ranks: kslam = the library's own RCCL path behind the C ABI (include/kslam_comm.h, "
                          "what a C++ host links: librccl opened by the library, no PyTorch in the transfers); torch = torch.distributed "
                          "(k-slam_amd/dist.py, the same protocol); auto = kslam when its communicator comes up on every rank, else torch")
-    ap.add_argument("--strong-reference", choices=["auto", "off"], default="auto",
-                    help="N = 1, default workload: also run `--strong` (ONE 10 M-pair batch per step, the workload of the --gpus N > 1 lines) in a "
-                         "child process afterwards and attach its value as `strong_reference`: the N = 1 point of the scaling curve, same box, same run")
+    ap.add_argument("--strong-n1", choices=["auto", "off"], default="auto",
+                    help="N = 1, configs[1]: after the line's own legs, also time the workload of the --gpus N > 1 lines (ONE batch of "
+                         "--total-pairs pairs per step) on this one GPU, in this process, and attach it as `strong_n1`: the origin of the "
+                         "strong-scaling curve.  Every --gpus N > 1 line measures the same thing itself (`n1_same_workload`)")
+    ap.add_argument("--strong-reference", choices=["auto", "on", "off"], default=None, help=argparse.SUPPRESS)   # round 5 spelling of --strong-n1
     ap.add_argument("--total-pairs", type=int, default=10_000_000,
                     help="pairs per batch in --strong mode (the reference's --num-reads-at-once default, src/main.cpp:56)")
     args = ap.parse_args()
+    if args.strong_reference == "off":
+        args.strong_n1 = "off"
+    legs = set(x for x in args.legs.replace("all", "abi_path,other_sink,null_sink,pseudo").split(",") if x)
+    unknown = legs - {"abi_path", "other_sink", "null_sink", "pseudo"}
+    if unknown:
+        raise SystemExit("--legs: unknown leg(s) %s" % ", ".join(sorted(unknown)))
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(args, sys.argv[1:])       # before this process makes any HIP call
@@ -513,6 +683,36 @@ def main():
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
+    pending_line = [None]          # the graded line once it is complete enough to print, while optional legs still run
+    emitted = [False]
+
+    def emit(obj):
+        """ONE JSON line, once, on the saved stdout"""
+        if emitted[0] or obj is None:
+            return
+        emitted[0] = True
+        try:
+            sys.stdout.flush()
+        except Exception:
+            pass
+        os.write(real_stdout, (json.dumps(obj) + "\n").encode())
+
+    def emit_on_exit():
+        # a line that was complete when an optional leg took the process down (SIGTERM from a launcher's timeout, an exception
+        # escaping to the interpreter's exit) is still written
+        import atexit
+        import signal
+        atexit.register(lambda: emit(pending_line[0]))
+
+        def on_signal(signum, frame):
+            emit(pending_line[0])
+            os._exit(128 + signum)
+        for sig in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+            try:
+                signal.signal(sig, on_signal)
+            except (ValueError, OSError):
+                pass
+    emit_on_exit()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -543,6 +743,19 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world, timeout=limit)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=limit)
+
+    # ---- one rank per GPU, or the run is not a scaling point: every rank's device identity (uuid when the runtime reports one,
+    # else PCI ids, else the ordinal) must be different.  A repeat is a hard failure of every rank -- exit code, not a JSON
+    # field -- unless the tests asked for ranks that share a GPU.
+    device_ids = [device_identity(local_rank)]
+    if use_dist:
+        box = [None] * world
+        dist.all_gather_object(box, device_ids[0])
+        device_ids = box
+        if len(set(device_ids)) != world and not share:
+            print("bench.py: ranks share a device (%s): not one rank per GPU; KSLAM_BENCH_SHARE_GPU=1 allows it for tests" % device_ids,
+                  file=sys.stderr)
+            raise SystemExit(3)
 
     K = entry.load_package()
     kdist = importlib.import_module("kslam_amd.dist")
@@ -642,6 +855,13 @@ def main():
             comm, comm_why = make_comm(ctx)
         if comm is None and args.comm == "kslam":
             raise SystemExit("--comm kslam: %s" % comm_why)
+        if comm is not None:
+            # what RCCL itself says about the communicator the data will move through: a count other than N is a hard failure
+            mine = comm.info()
+            if mine["comm_count"] != world or mine["comm_rank"] != rank:
+                print("bench.py: rank %d: ncclCommCount = %d, ncclCommUserRank = %d in a world of %d" % (rank, mine["comm_count"], mine["comm_rank"], world),
+                      file=sys.stderr)
+                raise SystemExit(4)
 
     pending = []   # the gather of the previous batch, still in flight while this one is aligned
     merged = {}    # rank 0, --strong: the batch-global result of the last finished batch (device tensors)
@@ -784,6 +1004,7 @@ def main():
 
     # ================= strong mode, second clock: through the batch-global tail to SAM text + per-read taxa on rank 0 =================
     classified = None
+    n1_same = None
     if strong and not args.no_e2e and not args.no_cigar:
         taxdb = X.TaxDB(tax_text) if rank == 0 else None
         tail_ctx = rv = None
@@ -1109,6 +1330,15 @@ def main():
         if comm_b is not None:
             comm_b.close()
         ctx_b.close()
+        del qual_loc
+        # ---- the N = 1 point of THIS workload, in THIS run: rank 0 alone repeats the step on the whole batch, the others wait
+        if world > 1:
+            if rank == 0:
+                try:
+                    n1_same = solo_strong(K, ctx, whole, read_len, args.total_pairs, index_view, tax_text, args.steps, args.warmup, args.out_dir, "n1")
+                except Exception as e:
+                    n1_same = {"error": repr(e)}
+            dist.barrier()
 
     # RCCL announces itself on stdout through C stdio ("Librccl path : ..."), buffered when piped and
     # otherwise flushed when each rank exits -- after rank 0's JSON.  Every rank pushes it out now,
@@ -1253,8 +1483,6 @@ def main():
                            "shared_gpu": bool(share)}
             out["per_rank_align_ms"] = per_rank_align
         if use_dist and strong:
-            out["n1_point_of_this_curve"] = ("the same workload on one GPU: `bench.py --gpus 1 --strong`, which the default N = 1 line runs as a "
-                                             "child process and reports as `strong_reference` (its own `value` is configs[1]: 1 M-pair batches, FASTQ in, files out)")
             out["strong_step_split_ms"] = {
                 "max_over_ranks": {k: round(v / Ksteps * 1e3, 3) for k, v in split_max.items()},
                 "rank0": {k: round(v / Ksteps * 1e3, 3) for k, v in split.items()}}
@@ -1278,6 +1506,20 @@ def main():
                 "parts in rank order are the files: verified_classified); max over ranks.  classified_rank0_tail: the same "
                 "result with the overlap records gathered to rank 0 and the whole tail there (the Amdahl form); "
                 "hot_path.reads_per_s: clock stopped when rank 0 holds the merged overlap records")
+            # the curve's origin, same workload, same run (world 1: this line IS that point)
+            if world > 1:
+                out["n1_same_workload"] = n1_same
+                if n1_same and "value" in n1_same:
+                    out["speedup_vs_n1_same_workload"] = round(out["value"] / n1_same["value"], 3)
+                    hot["speedup_vs_n1_same_workload"] = round(hot["reads_per_s"] / n1_same["hot_path_reads_per_s"], 3)
+                else:
+                    out["speedup_vs_n1_same_workload"] = None
+            else:
+                out["n1_same_workload"] = {"what": "this line is the N = 1 point of the strong workload", "value": out["value"], "unit": "reads/s",
+                                           "ms_per_step": out["ms_per_step"], "hot_path_reads_per_s": hot["reads_per_s"]}
+                out["speedup_vs_n1_same_workload"] = 1.0
+            out["scaling_curve_origin"] = ("n1_same_workload.value: the same ONE-batch-of-%d-pairs step on one GPU, measured in this run by rank 0 "
+                                           "alone after the N-rank clocks; speedup_vs_n1_same_workload = value / that" % args.total_pairs)
         else:
             out["value_definition"] = "see e2e" if not args.no_e2e and not strong else "hot path only (--no-e2e): resident-input alignToDatabase"
         torch.cuda.empty_cache()       # what torch's allocator cached while generating the inputs goes back to the device
@@ -1307,7 +1549,7 @@ def main():
                 out["cpu_baseline"]["n_alignments_equals_hot_path_candidates"] = (cands == out["cpu_baseline"]["n_alignments"])
             else:
                 out["cpu_baseline"] = cpu_baseline(K, db, offs, 77, args.cpu_genomes, args.cpu_pairs, read_len, local_rank, why=why)
-        if world == 1 and not strong and not args.no_abi_path and pairs <= 2_000_000:
+        if world == 1 and not strong and "abi_path" in legs and pairs <= 2_000_000:
             try:
                 out["abi_path"] = abi_path(K, ctx, reads, read_len, max(Ksteps, 12))
             except Exception as e:   # extra evidence only: never lose the bench line over it
@@ -1341,19 +1583,20 @@ def main():
                 "sink_probe; e2e_other_sink is the same leg on the other one), per-read LCA inside.  The rate with "
                 "the batch resident in HBM and the results left on the device (alignToDatabase only) is hot_path.reads_per_s"
                 % (3, args.out_dir))
-            if sink_probe and len(sink_probe) > 1:
+            if sink_probe and len(sink_probe) > 1 and "other_sink" in legs:
                 other = [d for d in sink_probe if d != args.out_dir][0]
                 try:
                     d = e2e_leg(K, ctx, files, pairs, index_view, taxdb, Ksteps, args.warmup, pseudo, reps=1, tag="other", out_dir=other)
                     out["e2e_other_sink"] = {k: d[k] for k in ("reads_per_s", "ms_per_step", "host_ms_per_batch", "sink")}
                 except Exception as e:
                     out["e2e_other_sink"] = {"error": repr(e)}
-            try:                  # what the sink costs: the same leg with the SAM text written to /dev/null
-                d = e2e_leg(K, ctx, files, pairs, index_view, taxdb, Ksteps, args.warmup, pseudo, reps=1, tag="null", out_dir="/dev/null")
-                out["e2e_sam_to_dev_null"] = {k: d[k] for k in ("reads_per_s", "ms_per_step", "host_ms_per_batch")}
-            except Exception as e:
-                out["e2e_sam_to_dev_null"] = {"error": repr(e)}
-            if config == 1:       # the same with the reference's default (pseudo-assembly on)
+            if "null_sink" in legs:
+                try:                  # what the sink costs: the same leg with the SAM text written to /dev/null
+                    d = e2e_leg(K, ctx, files, pairs, index_view, taxdb, Ksteps, args.warmup, pseudo, reps=1, tag="null", out_dir="/dev/null")
+                    out["e2e_sam_to_dev_null"] = {k: d[k] for k in ("reads_per_s", "ms_per_step", "host_ms_per_batch")}
+                except Exception as e:
+                    out["e2e_sam_to_dev_null"] = {"error": repr(e)}
+            if config == 1 and "pseudo" in legs:       # the same with the reference's default (pseudo-assembly on)
                 try:
                     out["e2e_with_pseudo_assembly"] = e2e_leg(K, ctx, files, pairs, index_view, taxdb, Ksteps, args.warmup, True, tag="pa", out_dir=args.out_dir)
                 except Exception as e:
@@ -1363,38 +1606,31 @@ def main():
         if out["value"] is None:      # --no-e2e / --no-cigar / weak multi-GPU: the hot path is all that was timed
             out["value"], out["ms_per_step"] = hot["reads_per_s"], hot["ms_per_step"]
             out["value_definition"] = "hot path only: alignToDatabase on the resident batch" + (", results gathered to rank 0" if use_dist else "")
-        # ---- the N = 1 point of the scaling curve: the --gpus N > 1 lines run ONE 10 M-pair batch per step, sharded (configs[3]); this
-        # line's `value` is configs[1] (1 M-pair batches, FASTQ text in, files out).  So that the driver's N = 1, 2, 4, 8 records can be
-        # read as one curve, the same strong workload runs here on one GPU, in a child process, after this one has let go of the GPU's memory
-        if (world == 1 and not strong and config == 1 and args.strong_reference == "auto" and not args.no_e2e and not args.no_cigar
-                and pairs == 1_000_000 and args.species == 250 and args.genome_len == 4_000_000):
+        # ---- the origin of the strong-scaling curve: the --gpus N > 1 lines run ONE batch of --total-pairs pairs per step, sharded
+        # (configs[3]); this line's `value` is configs[1] (1 M-pair batches, FASTQ text in, files out).  The same strong step runs
+        # here on this one GPU, in this process (no child, nothing exec'ed), with this context's index.  Should the leg take the
+        # process down, the line as it stands is written by the handlers installed in emit_on_exit().
+        if world == 1 and not strong and config == 1 and args.strong_n1 == "auto" and not args.no_e2e and not args.no_cigar:
+            n1_pairs = args.total_pairs if pairs == 1_000_000 else max(PIECES, min(args.total_pairs, 8 * pairs) // PIECES * PIECES)
+            out["scaling_curve_origin"] = ("strong_n1.value: the workload of the --gpus N > 1 lines (ONE batch of %d pairs per step) on this one "
+                                           "GPU; `value` itself is configs[1] and is NOT the N = 1 point of their curve.  Every N > 1 line also "
+                                           "measures that point itself (n1_same_workload)" % n1_pairs)
+            pending_line[0] = out
+            t0 = time.time()
             try:
-                ctx.close()
-                ctx = None
-                del db, reads
+                del reads
                 torch.cuda.empty_cache()
-                env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-                t0 = time.time()
-                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--strong", "--no-cpu-baseline", "--steps", str(max(3, min(Ksteps, 10))),
-                                    "--warmup", str(min(args.warmup, 2))], env=env, capture_output=True, text=True, timeout=900)
-                js = [x for x in r.stdout.splitlines() if x.startswith("{")]
-                if r.returncode == 0 and js:
-                    sr = json.loads(js[-1])
-                    out["strong_reference"] = {
-                        "what": "`bench.py --gpus 1 --strong` run as a child of this process: the workload of the --gpus N > 1 lines (ONE batch of "
-                                "10 M pairs per step, configs[3]'s shape) on ONE GPU -- the N = 1 point to read the scaling curve against",
-                        "value": sr["value"], "unit": sr["unit"], "ms_per_step": sr["ms_per_step"], "steps": sr["steps"],
-                        "hot_path_reads_per_s": sr["hot_path"]["reads_per_s"], "hot_path_ms_per_step": sr["hot_path"]["ms_per_step"],
-                        "classified_sharded_ms_per_step": sr.get("classified_sharded", {}).get("ms_per_step_max_over_ranks"),
-                        "classified_rank0_tail_reads_per_s": sr.get("classified_rank0_tail", {}).get("reads_per_s"),
-                        "verified": {"hot_path_ok": sr["hot_path"]["verified"]["ok"], "verified_classified": sr.get("verified_classified")},
-                        "seconds": round(time.time() - t0, 1)}
-                else:
-                    out["strong_reference"] = {"error": "child exited with %d: %s" % (r.returncode, r.stderr[-400:])}
+                whole, _ = W.make_batch_in_pieces(dev, gen, db, offs, n1_pairs, read_len, pieces=PIECES, by_length=by_length, with_truth=False)
+                torch.cuda.synchronize()
+                out["strong_n1"] = solo_strong(K, ctx, whole, read_len, n1_pairs, index_view, tax_text, max(3, min(Ksteps, 10)), min(args.warmup, 2),
+                                               args.out_dir, "n1")
+                out["strong_n1"]["seconds"] = round(time.time() - t0, 1)
+                del whole
             except Exception as e:   # extra evidence only: never lose the bench line over it
-                out["strong_reference"] = {"error": repr(e)}
-        sys.stdout.flush()
-        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+                out["strong_n1"] = {"error": repr(e)}
+        elif world == 1 and not strong:
+            out["scaling_curve_origin"] = None
+        emit(out)
     if ctx is not None:
         ctx.close()
     if use_dist:

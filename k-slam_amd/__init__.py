@@ -277,6 +277,15 @@ class Context:
         off = np.ascontiguousarray(host_offsets, dtype=np.uint64)
         self._chk(self._L.kslam_set_index_device(self._h, n_entries, dev_ptr, off.ctypes.data))
 
+    def set_index_arrays(self, cat_u8, offsets_u64):
+        """kslam_set_index on a database held as ONE host uint8 array + entry offsets (no bytes object per entry)."""
+        off = np.ascontiguousarray(offsets_u64, dtype=np.uint64)
+        n = len(off) - 1
+        base = cat_u8.ctypes.data
+        ptrs = (C.c_void_p * max(n, 1))(*[base + int(off[i]) for i in range(n)])
+        lens = np.ascontiguousarray(np.diff(off), dtype=np.uint64)
+        self._chk(self._L.kslam_set_index(self._h, n, C.cast(ptrs, C.c_void_p), lens.ctypes.data))
+
     # ---- alignToDatabase ----
     def align_batch(self, reads):
         """alignToDatabase(reads, index): returns (overlaps[OVERLAP_DT], cigar_pool[u32])."""

@@ -755,6 +755,83 @@ def ref_sw_on_overlaps(overlaps, reads, entries, params=None):
     return out[:len(ov)].copy(), pool[:int(nc.value)].copy()
 
 
+ROW_FIELDS = ("read", "entry", "rel", "revcomp", "score", "ref_begin", "ref_end", "query_begin", "query_end", "cigar_len")
+
+
+def compare_with_reference_rows(got, gcig, exp, ecig, read_bytes, entry_bytes):
+    """A result set (rows[ALIGN_DT or the ABI's record], CIGAR pool) against a MULTI-THREADED run of the reference, whose
+    only thread-dependent output is documented in DESIGN.md section 2: when the raw overlap list holds one
+    (read, entry, rel) with both revComp values, `overlapSort` has no revComp in its key and `__gnu_parallel::sort` is
+    unstable (src/Overlap.h:87-98, 289), so which flag survives std::unique -- and with it that row's alignment -- depends
+    on the thread count.  Every other row must be identical in every field and CIGAR word.
+    read_bytes(i) / entry_bytes(j) -> bytes: only called for the reads / entries of rows that differ, to rebuild THEIR raw
+    overlap list with the restatement (extract -> sort -> findOverlaps) and check that each differing row is such a tie.
+    -> dict(identical, alignments, cigar_ops, rows_differing, differing_rows_are_revcomp_ties[, why])"""
+    out = {"identical": False, "alignments": int(len(got)), "cigar_ops": int(len(gcig)), "rows_differing": None,
+           "differing_rows_are_revcomp_ties": None}
+    if len(got) != len(exp):
+        out["why"] = "row counts differ: %d vs %d" % (len(got), len(exp))
+        return out
+    for f in ("read", "entry", "rel"):
+        if not (got[f] == exp[f]).all():
+            out["why"] = "the (read, entry, rel) lists differ in `%s`" % f
+            return out
+    bad = np.zeros(len(got), dtype=bool)
+    for f in ROW_FIELDS[3:]:
+        bad |= got[f] != exp[f]
+    # CIGAR words of the rows that agree so far (their lengths are equal): drop the differing rows' words on both sides
+    glen, elen = got["cigar_len"].astype(np.int64), exp["cigar_len"].astype(np.int64)
+    if int(glen.sum()) != len(gcig) or int(elen.sum()) != len(ecig):
+        out["why"] = "a CIGAR pool does not have the length its rows add up to"
+        return out
+    if bad.any():
+        gw = np.repeat(~bad, glen)
+        ew = np.repeat(~bad, elen)
+        ga, ea = np.asarray(gcig)[gw], np.asarray(ecig)[ew]
+    else:
+        ga, ea = np.asarray(gcig), np.asarray(ecig)
+    if len(ga) != len(ea):
+        out["why"] = "CIGAR pools of the agreeing rows differ in length"
+        return out
+    neq = ga != ea
+    if neq.any():
+        # name the rows: word index -> row
+        keep_rows = np.flatnonzero(~bad)
+        row_of_word = np.repeat(keep_rows, glen[keep_rows])
+        bad[np.unique(row_of_word[neq])] = True
+    nbad = int(bad.sum())
+    out["rows_differing"] = nbad
+    if nbad == 0:
+        if not (got["cigar_off"] == exp["cigar_off"]).all():
+            out["why"] = "cigar_off differs"
+            return out
+        out["identical"] = True
+        out["differing_rows_are_revcomp_ties"] = True
+        return out
+    if nbad > 100000:
+        out["why"] = "%d rows differ: not a handful of ties" % nbad
+        return out
+    rows = np.flatnonzero(bad)
+    rids = sorted({int(x) for x in got["read"][rows]})
+    eids = sorted({int(x) for x in got["entry"][rows]})
+    sub_reads = [read_bytes(i) for i in rids]
+    sub_entries = [entry_bytes(j) for j in eids]
+    recs = np.concatenate([extract_kmers(sub_reads, False, 1), extract_kmers(sub_entries, True, 16)])
+    raw = scan_overlaps(sort_kmers(recs), [len(r) for r in sub_reads])
+    seen = {}
+    for r, e, l, c in zip(raw["read"], raw["entry"], raw["rel"], raw["revcomp"]):
+        seen.setdefault((rids[int(r)], eids[int(e)], int(l)), set()).add(int(c))
+    # std::unique compares with the last KEPT element: a kept row stands for the raw rows within < 3 of it, so the flag of
+    # the kept row is ambiguous when the raw list holds both flags AT the kept rel (the first of the equal-key run)
+    ok = all(len(seen.get((int(got["read"][i]), int(got["entry"][i]), int(got["rel"][i])), ())) == 2 and
+             int(got["revcomp"][i]) != int(exp["revcomp"][i]) for i in rows)
+    out["differing_rows_are_revcomp_ties"] = bool(ok)
+    out["identical"] = bool(ok)       # identical modulo the one tie the reference leaves open
+    if not ok:
+        out["why"] = "rows differ that are not revComp ties; first: %s" % [int(x) for x in rows[:5]]
+    return out
+
+
 # ---- the REAL batch loop metagenomicAnalysis_Low_Mem on files (oracle/_ref/libslam_ref.so) ----
 REF_SLAM = os.path.join(_HERE, "_ref", "libslam_ref.so")
 # the same program with ONE function swapped: alignToDatabase = the GPU operator behind the C ABI (ref_slam_driver.cpp built
@@ -799,6 +876,12 @@ def _refs(gpu=False):
         R.ref_slam_index_add_gene.argtypes = [cp, cp, cp, cp, cp, u32, u32, u32, C.c_int32]
         R.ref_slam_run.restype = C.c_int
         R.ref_slam_run.argtypes = [cp, cp, cp, cp, cp, cp, C.POINTER(RefSlamParams), cp]
+        vp = C.c_void_p
+        R.ref_slam_align_to_database.restype = C.c_int
+        R.ref_slam_align_to_database.argtypes = [u64, vp, vp, C.POINTER(RefSlamParams), C.c_int32, C.POINTER(vp),
+                                                 C.POINTER(u64), C.POINTER(vp), C.POINTER(u64),
+                                                 C.POINTER(C.c_double), cp]
+        R.ref_slam_free.argtypes = [vp]
         _refslam[gpu] = R
     return _refslam[gpu]
 
@@ -816,6 +899,99 @@ def ref_slam_set_index(entries, gpu=False):
             R.ref_slam_index_add_gene(g.get("name", b""), g.get("locus_tag", b""), g.get("protein_id", b""),
                                       g.get("product", b""), g.get("reference", b""), g.get("gene_id", 0),
                                       g["start"], g["stop"], int(g.get("complement", 0)))
+
+
+def ref_slam_set_index_arrays(db, offs, gpu=False):
+    """The same injection for a database held as ONE uint8 array + entry offsets (the bench's 5 Gb database: no Python
+    bytes object per entry)."""
+    R = _refs(gpu)
+    R.ref_slam_index_reset()
+    db = np.ascontiguousarray(db, dtype=np.uint8)
+    add = R.ref_slam_index_add_entry
+    old = add.argtypes
+    add.argtypes = [C.c_void_p] + list(old[1:])
+    try:
+        for i in range(len(offs) - 1):
+            lo, hi = int(offs[i]), int(offs[i + 1])
+            add(db.ctypes.data + lo, hi - lo, b"", 0, 0)
+    finally:
+        add.argtypes = old
+
+
+_REF_LOG_PHASES = (("extract", "Getting k-mers from reads"), ("genome_kmers", "Getting k-mers from index"),
+                   ("sort", "Sorting k-mers"), ("join", "Finding overlaps"), ("sw", "Performing pairwise Smith-Waterman"))
+
+
+def _ref_log_phases(path, seconds):
+    """Phase times of the LAST alignToDatabase call from the reference's own log.txt stamps `[t = 1.23s]\t<text>`
+    (src/sequenceTools.h:171-179; 10 ms resolution): each phase runs from its stamp to the next phase's; the last one
+    (Smith-Waterman) to the end of the call, `seconds` after the "Aligning reads to database" stamp.  None when the log is
+    not there (the function-static Log opens ./log.txt at the process's FIRST log() call)."""
+    try:
+        lines = open(path).read().splitlines()
+    except OSError:
+        return None
+    stamps = []
+    for ln in lines:
+        if ln.startswith("[t = ") and "s]\t" in ln:
+            t, _, text = ln[5:].partition("s]\t")
+            try:
+                stamps.append((float(t), text))
+            except ValueError:
+                pass
+    starts = [i for i, (_, text) in enumerate(stamps) if text.startswith("Aligning reads to database")]
+    if not starts:
+        return None
+    blk = stamps[starts[-1]:]
+    t0 = blk[0][0]
+    at = {}
+    for name, text in _REF_LOG_PHASES:
+        hit = [t for t, x in blk if x.startswith(text)]
+        if not hit:
+            return None
+        at[name] = hit[0] - t0
+    order = [n for n, _ in _REF_LOG_PHASES]
+    out = {}
+    for i, n in enumerate(order):
+        end = at[order[i + 1]] if i + 1 < len(order) else seconds
+        out[n] = round(max(end - at[n], 0.0), 2)
+    return out
+
+
+def ref_slam_align_to_database(reads_flat, read_offs, params=None, report_cigar=True, threads=0, gpu=False,
+                               workdir=None):
+    """The reference's OWN alignToDatabase (src/SLAM.h:59-79: the template itself, compiled from the header where it lies
+    into oracle/_ref/libslam_ref.so) on a batch given as one flat uint8 array + offsets, against the index injected with
+    ref_slam_set_index[_arrays].  threads: OpenMP threads (0 = leave; 1 = the deterministic run the goldens use).
+    -> (alignments[ALIGN_DT], cigar_pool[u32], seconds inside alignToDatabase, phases from its log.txt or None)"""
+    R = _refs(gpu)
+    p = params or RefSlamParams.default()
+    p.threads = int(threads)
+    flat = np.ascontiguousarray(reads_flat, dtype=np.uint8)
+    offs = np.ascontiguousarray(read_offs, dtype=np.uint64)
+    out, cig = C.c_void_p(), C.c_void_p()
+    n_out, n_cig, sec = C.c_uint64(), C.c_uint64(), C.c_double()
+    tmp = None
+    if workdir is None:
+        tmp = tempfile.TemporaryDirectory()
+        workdir = tmp.name
+    try:
+        rc = R.ref_slam_align_to_database(len(offs) - 1, flat.ctypes.data, offs.ctypes.data, C.byref(p),
+                                          int(bool(report_cigar)), C.byref(out), C.byref(n_out), C.byref(cig),
+                                          C.byref(n_cig), C.byref(sec), workdir.encode())
+        assert rc == 0, "the reference's alignToDatabase failed (%d)" % rc
+        phases = _ref_log_phases(os.path.join(workdir, "log.txt"), float(sec.value))
+    finally:
+        if tmp is not None:
+            tmp.cleanup()
+    n, nc = int(n_out.value), int(n_cig.value)
+    al = np.frombuffer((C.c_char * (n * ALIGN_DT.itemsize)).from_address(out.value),
+                       dtype=ALIGN_DT).copy() if n else np.zeros(0, dtype=ALIGN_DT)
+    cg = np.frombuffer((C.c_char * (nc * 4)).from_address(cig.value),
+                       dtype=np.uint32).copy() if nc else np.zeros(0, dtype=np.uint32)
+    R.ref_slam_free(out)
+    R.ref_slam_free(cig)
+    return al, cg, float(sec.value), phases
 
 
 def ref_slam_run(r1, r2, db_dir, out, sam, params=None, command_line=b"SLAM", workdir=None, gpu=False):

@@ -54,6 +54,7 @@
 #include <sstream>
 #include <iostream>
 #include <climits>
+#include <chrono>
 #include <unistd.h>
 #include "ssw_cpp_noboost.h"
 #include "Globals.h"
@@ -187,4 +188,87 @@ int ref_slam_run(const char *r1, const char *r2, const char *db_dir, const char 
   if (workdir && chdir(old) != 0) abort();
   return rc;
 }
+
+// THE OPERATOR ALONE: the reference's own `alignToDatabase` (src/SLAM.h:59-79, the template compiled from the header where
+// it lies -- in libslam_ref.so it is the reference's code, in libslam_gpu_ref.so the swapped-in GPU operator) on a batch
+// handed over as arrays: reads = one flat byte buffer + n_reads + 1 offsets (R1 block then R2 block, as
+// getPairedSequencesFromFASTQFiles leaves them, src/FASTQsequence.h:111-123), genomes = the index injected through
+// ref_slam_index_add_entry.  bench.py times this as `cpu_baseline.kind = "reference"` and the -m gpu tests use it as the
+// full-size checker.  Runs in `workdir`: the reference's log() stamps (src/sequenceTools.h:171-179) land in
+// <workdir>/log.txt when this is the process's first log() call.  *seconds = wall clock of the call to alignToDatabase
+// alone (building the std::vector<MetagenomicFASTQSequence> and flattening the result are outside).  Results are
+// malloc'ed (free with ref_slam_free): 56-byte records == oracle/kslam_oracle.h orc_alignment, CIGAR words pooled.
+struct ref_slam_alignment {
+  uint32_t read, entry;
+  int32_t rel;
+  uint8_t revcomp, pad;
+  uint16_t score;
+  int32_t ref_begin, ref_end, query_begin, query_end;
+  uint32_t cigar_len, pad2;
+  uint64_t cigar_off;
+};
+
+int ref_slam_align_to_database(uint64_t n_reads, const char *bases, const uint64_t *offs,
+                               const ref_slam_params *p, int32_t report_cigar, void **out, uint64_t *n_out,
+                               uint32_t **cigar_pool, uint64_t *n_cigar, double *seconds, const char *workdir) {
+  char old[4096];
+  if (!getcwd(old, sizeof old)) return 2;
+  if (workdir && chdir(workdir) != 0) return 3;
+  match = p->match;
+  misMatch = p->mismatch;
+  gapOpen = p->gap_open;
+  gapExtend = p->gap_extend;
+  scoreThreshold = p->score_threshold;
+  reportCigar = report_cigar != 0;
+  pairedData = true;
+  if (p->threads > 0) omp_set_num_threads(p->threads);
+  SLAM::dropGpuPath();
+  int rc = 0;
+  std::vector<SLAM::Overlap> overlaps;
+  try {
+    std::vector<SLAM::MetagenomicFASTQSequence> reads(n_reads);
+    for (uint64_t i = 0; i < n_reads; i++) reads[i].bases.assign(bases + offs[i], offs[i + 1] - offs[i]);
+    const auto t0 = std::chrono::steady_clock::now();
+    overlaps = SLAM::alignToDatabase(reads, g_index);
+    *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  } catch (const std::exception &e) {
+    std::cerr << "reference threw: " << e.what() << std::endl;
+    rc = 1;
+  }
+  SLAM::dropGpuPath();
+  if (workdir && chdir(old) != 0) abort();
+  if (rc) return rc;
+  uint64_t nc = 0;
+  for (auto &o : overlaps)
+    if (o.alignment.cigar) nc += o.alignment.cigarLen;
+  ref_slam_alignment *res = static_cast<ref_slam_alignment *>(std::calloc(overlaps.size() + 1, sizeof(ref_slam_alignment)));
+  uint32_t *pool = static_cast<uint32_t *>(std::malloc(sizeof(uint32_t) * (nc + 1)));
+  if (!res || !pool) return 4;
+  uint64_t off = 0;
+  for (size_t i = 0; i < overlaps.size(); i++) {
+    const SLAM::Overlap &o = overlaps[i];
+    ref_slam_alignment &r = res[i];
+    r.read = o.readPosInArray;
+    r.entry = o.entryPosInArray;
+    r.rel = o.relativePosition;
+    r.revcomp = o.revComp;
+    r.score = o.alignment.sw_score;
+    r.ref_begin = o.alignment.ref_begin;
+    r.ref_end = o.alignment.ref_end;
+    r.query_begin = o.alignment.query_begin;
+    r.query_end = o.alignment.query_end;
+    r.cigar_off = off;
+    r.cigar_len = o.alignment.cigar ? o.alignment.cigarLen : 0;
+    if (r.cigar_len) {
+      std::memcpy(pool + off, o.alignment.cigar, sizeof(uint32_t) * r.cigar_len);
+      off += r.cigar_len;
+    }
+  }
+  *out = res;
+  *n_out = overlaps.size();
+  *cigar_pool = pool;
+  *n_cigar = nc;
+  return 0;
+}
+void ref_slam_free(void *q) { std::free(q); }
 }

@@ -1,7 +1,10 @@
-"""BASELINE configs[1] at its full size against the oracle, record for record: 1 M x 2 x 150 bp read pairs vs the 1 250-genome
-5 Gb bacterial database -- ALL 8.15 M alignments of the batch (read, entry, rel, revComp, score, the four coordinates, CIGAR
-length and offset, every CIGAR word), not a sub-database.  The oracle (pinned to the reference compiled in place,
-tests/test_oracle.py) runs on every CPU the job may use: about 30 s on 16."""
+"""BASELINE configs[1] at its full size against the REFERENCE ITSELF, record for record: 1 M x 2 x 150 bp read pairs vs the
+1 250-genome 5 Gb bacterial database -- ALL 8.15 M alignments of the batch (read, entry, rel, revComp, score, the four
+coordinates, CIGAR length and offset, every CIGAR word), not a sub-database.  The checker is the reference's own
+`alignToDatabase` (src/SLAM.h:59-79: KMer.h, Overlap.h, SmithWaterman.h, ssw.c compiled in place into
+oracle/_ref/libslam_ref.so) on every CPU the job may use; rows may differ only where a multi-threaded run of the reference
+is itself undecided (revComp ties), and each such row is checked to be one.  Without oracle/_ref (no
+/root/reference where the tree was built) the checker is the restatement, which tests/test_oracle.py pins to the reference."""
 import importlib
 import os
 
@@ -12,7 +15,7 @@ pytestmark = pytest.mark.gpu
 PAIRS = int(os.environ.get("KSLAM_TEST_CONFIG1_PAIRS", "1000000"))
 
 
-def test_config1_full_batch_equals_the_oracle(kslam, oracle):
+def test_config1_full_batch_equals_the_reference(kslam, oracle):
     import torch
     assert torch.cuda.is_available(), "torch sees no HIP device"
     W = importlib.import_module("kslam_amd.workload")
@@ -33,19 +36,29 @@ def test_config1_full_batch_equals_the_oracle(kslam, oracle):
     ctx.close()
     # ---- the checker: the whole batch against the whole database on the host ----
     host_db = db.cpu().numpy()
-    gl = [host_db[int(offs[i]):int(offs[i + 1])].tobytes() for i in range(n_entries)]
-    del host_db
-    rn = reads.cpu().numpy()
-    rl = [rn[i].tobytes() for i in range(rn.shape[0])]
+    rn = np.ascontiguousarray(reads.cpu().numpy())
     del db, reads
     torch.cuda.empty_cache()
-    oracle.use_reference_ssw(True)          # the SSW core of the checker = the reference's own ssw.c when oracle/_ref has it
-    oracle.set_num_threads(oracle.usable_cpus())
-    try:
-        exp, ecig, _ = oracle.align_to_database(rl, gl)
-    finally:
-        oracle.use_reference_ssw(False)
+    rb = lambda i: rn[i].tobytes()
+    eb = lambda j: host_db[int(offs[j]):int(offs[j + 1])].tobytes()
+    if oracle.have_ref_slam():
+        oracle.ref_slam_set_index_arrays(host_db, offs)
+        exp, ecig, seconds, phases = oracle.ref_slam_align_to_database(
+            rn.reshape(-1), np.arange(rn.shape[0] + 1, dtype=np.uint64) * np.uint64(150), threads=oracle.usable_cpus())
+        oracle.ref_slam_set_index_arrays(host_db[:0], offs[:1])
+        print("the reference's alignToDatabase: %.1f s on %d CPUs, phases %s" % (seconds, oracle.usable_cpus(), phases))
+    else:
+        gl = [eb(j) for j in range(n_entries)]
+        rl = [rb(i) for i in range(rn.shape[0])]
+        oracle.use_reference_ssw(True)
+        oracle.set_num_threads(oracle.usable_cpus())
+        try:
+            exp, ecig, _ = oracle.align_to_database(rl, gl)
+        finally:
+            oracle.use_reference_ssw(False)
+        del gl, rl
     assert len(exp) == len(got) and len(got) > 7 * PAIRS
-    for f in ("read", "entry", "rel", "revcomp", "score", "ref_begin", "ref_end", "query_begin", "query_end", "cigar_len", "cigar_off"):
-        assert (got[f] == exp[f]).all(), f
-    assert np.array_equal(gcig, ecig)
+    v = oracle.compare_with_reference_rows(got, gcig, exp, ecig, rb, eb)
+    print(v)
+    assert v["identical"] and v["differing_rows_are_revcomp_ties"], v
+    assert v["rows_differing"] <= 1000, v

@@ -130,7 +130,7 @@ def test_bench_strong_mode_with_several_ranks_on_one_gpu(world, comm):
     assert v["planted_missing"] == 0 and v["planted_expected"] > 60000 and v["merged_rows"] == v["overlaps"]
     assert line["rccl"]["data_path"].startswith("kslam_comm" if comm == "kslam" else "torch.distributed")
     assert line["rccl"]["launched_by"].startswith("external launcher") and line["verified_classified"]
-    assert "strong_reference" in line["n1_point_of_this_curve"]
+    _n1_point_is_in_the_line(line)
 
 
 @pytest.mark.parametrize("world,comm", [(2, "torch"), (4, "torch"), (8, "torch"), (2, "kslam"), (4, "kslam"), (8, "kslam")])
@@ -171,6 +171,21 @@ def test_bench_starts_its_own_ranks_when_no_launcher_did(world, comm):
     sh = line["classified_sharded"]
     assert line["verified_classified"] and sh["part_files_in_rank_order_equal_rank0_files"] and sh["pseudo_assembly_on"] == "gpu"
     assert sh["bytes_received_from_other_ranks_per_step"] > 4 * 48000 and sh["max_insert_size"] == c["max_insert_size"]
+    _n1_point_is_in_the_line(line)
+    assert line["n1_same_workload"]["max_insert_size"] == c["max_insert_size"]
+
+
+def _n1_point_is_in_the_line(line):
+    """every --gpus N > 1 line carries the N = 1 point of ITS workload, measured in that run by rank 0 alone, and the ratio"""
+    n1 = line["n1_same_workload"]
+    assert "error" not in n1, n1
+    assert n1["value"] > 0 and n1["steps"] == line["steps"] and n1["hot_path_reads_per_s"] > 0 and n1["pseudo_assembly_on"] == "gpu"
+    assert abs(line["speedup_vs_n1_same_workload"] - line["value"] / n1["value"]) < 2e-3
+    assert abs(line["hot_path"]["speedup_vs_n1_same_workload"] - line["hot_path"]["reads_per_s"] / n1["hot_path_reads_per_s"]) < 2e-3
+    assert line["scaling_curve_origin"].startswith("n1_same_workload.value")
+    # the same batch, the same files: what the one GPU wrote is what the ranks wrote together
+    c = line["classified_rank0_tail"]
+    assert n1["sam_file_bytes"] == c["sam_file_bytes"] and n1["per_read_file_bytes"] == c["per_read_file_bytes"]
 
 
 def test_strong_line_of_one_rank_through_the_self_launcher_equals_plain_strong():
@@ -326,9 +341,9 @@ def test_default_bench_line_keeps_the_contract(tmp_path):
     env = dict(os.environ)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--pairs", "30000", "--species", "4", "--strains", "3",
-                        "--genome-len", "300000", "--steps", "3", "--warmup", "1", "--cpu-pairs", "3000", "--cpu-genomes", "4"],
-                       env=env, capture_output=True, text=True, timeout=900)
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--pairs", "30000", "--species", "4", "--strains", "3",
+            "--genome-len", "300000", "--steps", "3", "--warmup", "1", "--cpu-pairs", "3000", "--cpu-genomes", "4"]
+    r = subprocess.run(base, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     out = r.stdout.strip().splitlines()
     assert len(out) == 1 and out[0].startswith("{"), r.stdout[:500]
@@ -340,15 +355,33 @@ def test_default_bench_line_keeps_the_contract(tmp_path):
     assert line["vs_baseline"] is None and "workload" in line["config"] and line["value"] > 0
     rf, cb = line["roofline"], line["cpu_baseline"]
     assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
-    assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["gpu_equals_cpu_on_sample"]["identical"]
+    have_ref = os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libslam_ref.so"))
+    assert cb["kind"] == ("reference" if have_ref else "port") and cb["cores"] >= 1 and cb["gpu_equals_cpu_on_sample"]["identical"]
+    if have_ref:      # the reference's own alignToDatabase timed, the port beside it, the GPU's rows compared with the reference's
+        assert cb["gpu_equals_reference"]["identical"] and cb["gpu_equals_reference"]["differing_rows_are_revcomp_ties"]
+        assert cb["port"]["kind"] == "port" and cb["port"]["equals_reference"]["identical"] and cb["port"]["n_alignments"] == cb["n_alignments"]
+        assert cb["seconds"] > 0 and (cb["phases_s"] is None or set(cb["phases_s"]) == {"extract", "genome_kmers", "sort", "join", "sw"})
     hp = line["hot_path"]
     assert hp["verified"]["ok"] and hp["verified"]["run_to_run_identical"] and hp["verified"]["planted_missing"] == 0
     e = line["e2e"]
     assert line["value"] == e["reads_per_s"] and len(e["repetitions_ms_per_step"]) == 3 and e["verified"]["repetitions_identical"]
     assert e["verified"]["sam_file_bytes"] > 100 * 30000 and e["driver"].startswith("kslam_stream_classify")
     assert e["sink"] == line["sink_probe"]["chosen"] and isinstance(e["cpu_s_by_thread"], dict) and e["host_cpus_usable"] >= 1
+    # the optional legs are opt-in (--legs): the driver's run is the contract legs and the curve's origin
+    for k in ("e2e_sam_to_dev_null", "e2e_with_pseudo_assembly", "abi_path", "e2e_other_sink", "strong_reference"):
+        assert k not in line, k
+    n1 = line["strong_n1"]
+    assert "error" not in n1, n1
+    assert n1["value"] > 0 and n1["hot_path_reads_per_s"] > 0 and n1["pseudo_assembly_on"] == "gpu" and n1["sam_file_bytes"] > 0
+    assert line["scaling_curve_origin"].startswith("strong_n1.value")
+    # ---- the same with every optional leg switched on
+    r = subprocess.run(base + ["--legs", "all", "--strong-n1", "off", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    out = r.stdout.strip().splitlines()
+    assert len(out) == 1 and out[0].startswith("{"), r.stdout[:500]
+    line = json.loads(out[0])
     assert line["e2e_sam_to_dev_null"]["reads_per_s"] > 0 and line["e2e_with_pseudo_assembly"]["pseudo_assembly_on"] == "gpu"
-    assert line["abi_path"]["equals_resident_result"]
+    assert line["abi_path"]["equals_resident_result"] and "strong_n1" not in line and line["scaling_curve_origin"] is None
 
 
 @pytest.mark.parametrize("pseudo", [True, False])

@@ -328,6 +328,53 @@ def test_against_real_align_to_database_when_present(oracle, seed):
     _same_modulo_revcomp_ties(mt, one, ties, fields)
 
 
+def test_the_real_align_to_database_template_and_the_full_size_comparison(oracle):
+    """oracle/_ref/libslam_ref.so::ref_slam_align_to_database calls the reference's own `alignToDatabase` template
+    (src/SLAM.h:59-79, compiled from the header) -- what bench.py times as cpu_baseline.kind "reference" and what the
+    full-size -m gpu checker runs.  It equals libjoin_ref.so's statement of the same five calls; and
+    compare_with_reference_rows (the comparison both use) accepts exactly the documented revComp ties and nothing else."""
+    if not (oracle.have_ref_slam() and oracle.have_ref_join()):
+        pytest.skip("oracle/_ref not built (no /root/reference)")
+    from join_cases import make_join_case
+    reads, genomes = make_join_case(12, n_reads=160)
+    oracle.ref_slam_set_index([{"bases": g} for g in genomes])
+    flat = np.frombuffer(b"".join(reads), dtype=np.uint8)
+    offs = np.concatenate([[0], np.cumsum([len(r) for r in reads])]).astype(np.uint64)
+    one, ocig, sec, _ = oracle.ref_slam_align_to_database(flat, offs, threads=1)
+    exp, ecig = oracle.ref_align_to_database(reads, genomes)
+    assert len(one) > 400 and (one == exp).all() and np.array_equal(ocig, ecig) and sec > 0
+    rb, eb = (lambda i: reads[i]), (lambda j: genomes[j])
+    # the restatement against a multi-threaded run of the real thing
+    mt, mcig, _, _ = oracle.ref_slam_align_to_database(flat, offs, threads=4)
+    got, gcig, _ = oracle.align_to_database(reads, genomes)
+    v = oracle.compare_with_reference_rows(got, gcig, mt, mcig, rb, eb)
+    assert v["identical"] and v["differing_rows_are_revcomp_ties"], v
+    # a planted tie decided the other way is accepted ...
+    from join_cases import revcomp_tie_rows
+    recs = np.concatenate([oracle.extract_kmers(reads, False, 1), oracle.extract_kmers(genomes, True, 16)])
+    ties = revcomp_tie_rows(oracle.scan_overlaps(oracle.sort_kmers(recs), [len(r) for r in reads]))
+    assert ties
+    flip = got.copy()
+    i = [k for k in range(len(flip)) if (int(flip["read"][k]), int(flip["entry"][k]), int(flip["rel"][k])) in ties][0]
+    flip["revcomp"][i] = one["revcomp"][i] ^ 1
+    v = oracle.compare_with_reference_rows(flip, gcig, one, ocig, rb, eb)
+    assert v["identical"] and v["rows_differing"] >= 1, v
+    base = oracle.compare_with_reference_rows(got, gcig, one, ocig, rb, eb)
+    assert base["identical"], base
+    # ... a flipped flag on a row that is no tie, a changed score, a changed CIGAR word are not
+    j = [k for k in range(len(got)) if (int(got["read"][k]), int(got["entry"][k]), int(got["rel"][k])) not in ties][5]
+    for field, delta in (("revcomp", 1), ("score", 1), ("ref_end", 1)):
+        wrong = got.copy()
+        wrong[field][j] ^= delta
+        v = oracle.compare_with_reference_rows(wrong, gcig, one, ocig, rb, eb)
+        assert not v["identical"] and v["rows_differing"] == base["rows_differing"] + 1, (field, v)
+    wcig = gcig.copy()
+    wcig[0] ^= 16
+    v = oracle.compare_with_reference_rows(got, wcig, one, ocig, rb, eb)
+    assert not v["identical"] and v["rows_differing"] == base["rows_differing"] + 1, v
+    assert not oracle.compare_with_reference_rows(got[:-1], gcig, one, ocig, rb, eb)["identical"]
+
+
 # ---- the committed answers of the real reference (recorded by tests/golden/make_golden.py --pins): these run anywhere ----
 def _cols(z, name):
     flat, off = z[name], z[name + "_off"]

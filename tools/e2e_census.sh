@@ -1,6 +1,6 @@
 # Per-batch GPU time of every kernel inside the e2e legs (the windows between the first and last k_sam_write):  bash tools/e2e_census.sh
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-rm -rf /tmp/prof; rocprofv3 --kernel-trace --output-format csv -d /tmp/prof/kt -o x -- python3 bench.py --steps 8 --warmup 1 --no-cpu-baseline --no-abi-path $BENCH_ARGS > /tmp/o1 2> /tmp/e1
+rm -rf /tmp/prof; rocprofv3 --kernel-trace --output-format csv -d /tmp/prof/kt -o x -- python3 bench.py --steps 8 --warmup 1 --no-cpu-baseline --strong-n1 off $BENCH_ARGS > /tmp/o1 2> /tmp/e1
 python3 - <<'PY'
 import csv, glob, re, collections
 rows = list(csv.DictReader(open(glob.glob('/tmp/prof/kt/**/*kernel_trace.csv', recursive=True)[0])))

@@ -1,6 +1,6 @@
 # e2e kernel profile (one command per gpurun call): bash tools/prof_sam.sh
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-rm -rf /tmp/prof; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof/kt -o x -- python3 bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-abi-path $BENCH_ARGS > /tmp/o1 2> /tmp/e1
+rm -rf /tmp/prof; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof/kt -o x -- python3 bench.py --steps 6 --warmup 1 --no-cpu-baseline --strong-n1 off $BENCH_ARGS > /tmp/o1 2> /tmp/e1
 python3 - <<'PY'
 import csv, glob, re
 rows=list(csv.reader(open(glob.glob('/tmp/prof/kt/**/*kernel_stats.csv', recursive=True)[0])))

@@ -23,7 +23,11 @@
  * (ncclCommAbort): the peers come out with an error, and the communicator is dead -- every later call returns
  * KSLAM_ERR_STATE, kslam_comm_destroy is what is left.
  * The library opens librccl.so at run time (dlopen, the first kslam_comm_* call): a single-GPU host never loads it, and
- * a process that also carries PyTorch's own copy of RCCL keeps the two apart.
+ * a process that also carries PyTorch's own copy of RCCL keeps the two apart.  Which file: the environment variable
+ * KSLAM_RCCL_LIB when it is set (a path or soname; meant for a ROCm installed elsewhere and for the repository's tests, which
+ * name tests/fake_rccl's stand-in there so that several ranks can share one GPU), else librccl.so.1, librccl.so,
+ * /opt/rocm/lib/librccl.so.1 in that order.  The variable decides what code the product loads: a deployment that does
+ * not control its environment should not run with it set.  kslam_comm_info reports the file that was opened.
  *
  * Rendezvous: rank 0 calls kslam_comm_unique_id and hands the 128 bytes to the other ranks by whatever the host has
  * (a file, a socket, MPI, torch.distributed's store); every rank then calls kslam_comm_create.

@@ -57,6 +57,8 @@ struct Tuning {
   bool details_in_token = true;       // KSLAM_DETAILS_IN_TOKEN=0 (A/B): the per-row walk outside the lanes' compute token
   int plan_blocks_per_cu = 64;        // KSLAM_PLAN_BLOCKS: workgroups of k_sw_plan per CU (its waves walk through the candidates)
   int join_group_order = 1;           // KSLAM_JOIN_GROUP_ORDER=0: the overlap keys go through all their radix passes (join.hip: group_order)
+  int join_merge = 0;                 // KSLAM_JOIN=merge: k_join_merge instead of the probe k_join_fill (join.hip)
+  bool filter_build_sorted = true;    // KSLAM_FILTER_BUILD=atomics: the membership filter by scattered atomics instead of block by block (filter.hip)
   int pseudo_cap = 0;                 // KSLAM_PSEUDO_CAP (tests): alignment pairs of one entry beyond which pseudo-assembly is left to the host; 0 = 262144
 #ifdef KSLAM_ABLATE
   uint32_t sw_ablate = 0, cigar_variant = 0, filter_ablate = 0;   // KSLAM_SW_ABLATE / _CIGAR_VARIANT / _FILTER_ABLATE
@@ -64,22 +66,33 @@ struct Tuning {
 };
 Tuning read_tuning();   // kslam_api.hip
 
-// grow-only device buffer
+// grow-only device buffer.  Owns its block unless it was made a VIEW of another buffer with borrow() (a sibling context's
+// index, share_index): a view never frees.  No copy-assignment: `a = b` between owners would free the block twice.
 struct DevBuf {
   void *p = nullptr;
   size_t cap = 0;
+  bool borrowed = false;
   DevBuf() = default;
-  // freed with its owner: a buffer added to a work struct cannot be forgotten by kslam_destroy's list any more.  A
-  // copy-ASSIGNED DevBuf is a borrowed view (share_index): whoever borrows clears p before it goes away (kslam_destroy).
-  ~DevBuf() { if (p) (void)hipFree(p); }
+  ~DevBuf() { if (p && !borrowed) (void)hipFree(p); }
   DevBuf(const DevBuf &) = delete;
-  DevBuf(DevBuf &&o) noexcept : p(o.p), cap(o.cap) { o.p = nullptr; o.cap = 0; }
-  DevBuf &operator=(const DevBuf &o) = default;
+  DevBuf &operator=(const DevBuf &) = delete;
+  DevBuf(DevBuf &&o) noexcept : p(o.p), cap(o.cap), borrowed(o.borrowed) { o.p = nullptr; o.cap = 0; o.borrowed = false; }
+  DevBuf &operator=(DevBuf &&o) noexcept {
+    if (this != &o) {
+      release();
+      p = o.p; cap = o.cap; borrowed = o.borrowed;
+      o.p = nullptr; o.cap = 0; o.borrowed = false;
+    }
+    return *this;
+  }
+  // a non-owning view of `o`'s block (whatever this buffer owned before is freed)
+  void borrow(const DevBuf &o) {
+    release();
+    p = o.p; cap = o.cap; borrowed = true;
+  }
   void ensure(size_t bytes) {
-    if (bytes <= cap) return;
-    if (p) HIPCHK(hipFree(p));
-    p = nullptr;
-    cap = 0;
+    if (bytes <= cap && !borrowed) return;      // (a view is never written into as if it were ours: it becomes an owner)
+    release();
     size_t want = bytes + bytes / 8 + 256;
     hipError_t e = hipMalloc(&p, want);
     if (e != hipSuccess) {
@@ -90,9 +103,10 @@ struct DevBuf {
     cap = want;
   }
   void release() {
-    if (p) (void)hipFree(p);
+    if (p && !borrowed) (void)hipFree(p);
     p = nullptr;
     cap = 0;
+    borrowed = false;
   }
   template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
 };
@@ -148,16 +162,25 @@ void extract_plan(const uint64_t *d_offsets, uint64_t n_seqs, uint32_t gap,
 void extract_fill_segments(const uint32_t *d_nk, const uint64_t *d_rec_start,
                            const uint64_t *d_seg_start, uint64_t n_seqs, uint32_t gap,
                            SegEntry *d_segs, hipStream_t s, uint64_t n_segs = ~0ull);
-// AoS output (reference record layout); id_base is added to the sequence index
+// AoS output (reference record layout); id_base is added to the sequence index.  d_digits != nullptr: also the digit of
+// *first_pass of every record, one byte at the record's index (the first histogram of the sort that follows reads those
+// instead of the records: radix_sort.hip, SortWorkspace::first_digits_ready)
+struct SortPass;
 void extract_kmers_launch(const uint8_t *d_bases, const uint64_t *d_offsets,
                           const SegEntry *d_segs, uint64_t n_segs, uint32_t gap,
-                          int is_gb, uint32_t id_base, uint4 *d_out, hipStream_t s);
+                          int is_gb, uint32_t id_base, uint4 *d_out, hipStream_t s,
+                          uint8_t *d_digits = nullptr, const SortPass *first_pass = nullptr);
 
 // -------------------------------------------------------------- filter.hip
 // Blocked Bloom filter over the genome k-mer set (2^log2_bits bits, 128-byte lines chosen by the
 // k-mer's minimizer) and the read extraction kernel that keeps only the k-mers the filter lets through.
 size_t filter_bytes(uint32_t log2_bits);
 void filter_build(const uint64_t *d_sorted_keys, uint32_t n, uint32_t log2_bits, void *d_filter, hipStream_t s);
+// the same filter, built from the keys' probe words ordered by 32 KB filter block, each block assembled in LDS (filter.hip);
+// d_words_a / _b: n + 1 u64 each; d_block_start: (filter bytes / 32 KB) + 2 u32
+struct SortWorkspace;
+void filter_build_sorted(const uint64_t *d_sorted_keys, uint32_t n, uint32_t log2_bits, void *d_filter, void *d_words_a, void *d_words_b,
+                         uint32_t *d_block_start, SortWorkspace &ws, hipStream_t s);
 // reads d_off[0..n_reads] (gap 1, ids = position in d_off): surviving records appended at *d_cursor
 // (which ends as their number); nothing is written beyond `cap` (the caller reruns with a larger buffer)
 // d_digits != nullptr: also byte digit_word / digit_shift of every record written (the first radix pass's digit), at
@@ -171,7 +194,18 @@ struct SortPass {
   uint32_t word;    // which 32-bit word of the record holds the digit
   uint32_t shift;   // bit shift inside the word
   uint32_t invert;  // XOR mask applied to the word first (descending keys)
+  // a digit made of TWO bit fields of the word (hi_bits > 0): bits [shift, shift + 8 - hi_bits) below bits
+  // [hi_shift, hi_shift + hi_bits) -- the meta word's high id bits and its revComp bit in one pass (kslam_api.hip: build_index)
+  uint32_t hi_shift = 0, hi_bits = 0;
 };
+#ifdef __HIPCC__
+__host__ __device__ inline uint32_t sort_pass_digit(uint32_t word_value, const SortPass &p) {
+  const uint32_t v = word_value ^ p.invert;
+  if (p.hi_bits == 0) return (v >> p.shift) & 0xFFu;
+  const uint32_t lo_bits = 8u - p.hi_bits;
+  return ((v >> p.shift) & ((1u << lo_bits) - 1u)) | (((v >> p.hi_shift) & ((1u << p.hi_bits) - 1u)) << lo_bits);
+}
+#endif
 // Waiting for a stream.  hipStreamSynchronize spins on the completion signal: the fastest wake-up, and what a caller
 // that has nothing else to do wants (kslam_align_batch, the resident bench).  A pipeline lane waits while the host
 // stage of an earlier batch needs every CPU the process may use (a 16-CPU cgroup quota on the bench boxes), and its
@@ -256,10 +290,15 @@ struct OverlapKeyLayout {  // packed u64 overlap: read | entry | rel + bias | re
 constexpr int JOIN_TILE = 1024;
 void build_bucket_table(const uint64_t *d_keys, uint32_t n, uint32_t bits, uint32_t *d_bucket,
                         hipStream_t s);
+// lower bounds of the nb values `key >> shift` takes (keys ordered by it): d_table[0 .. nb]
+void build_offsets_table(const uint64_t *d_keys, uint32_t n, uint32_t shift, uint32_t nb, uint32_t *d_table, hipStream_t s);
 // single-pass join: output ranges reserved with one atomic per workgroup; *d_cursor ends as the
 // total number of overlaps; nothing beyond `cap` is written (caller reruns with a larger buffer)
 void join_fill_single_pass(const uint4 *d_read_recs, uint32_t n_r, GenomeIndexDev g, const uint32_t *d_read_len,
                            uint64_t *d_cursor, uint64_t cap, OverlapKeyLayout lay, uint64_t *d_out, hipStream_t s);
+// the same contract by a merge (join.hip: k_join_merge): the read records must be ordered by their top `sorted_top_bits` key bits
+void join_fill_merge(const uint4 *d_read_recs, uint32_t n_r, GenomeIndexDev g, uint32_t sorted_top_bits, const uint32_t *d_read_len,
+                     uint64_t *d_cursor, uint64_t cap, OverlapKeyLayout lay, uint64_t *d_out, hipStream_t s);
 // overlap keys radix-sorted by the bits above rel / revComp only: finish every (read, entry) group -- order its few keys by the
 // low bits, apply std::unique's "within 3 of the last kept" (Overlap.h:79-85) -- writing ordered keys and flags (join.hip).
 // *d_big is set when a group holds more than 64 keys (a read in a tandem repeat): d_out / d_flags are then incomplete and the

@@ -88,7 +88,8 @@ __global__ __launch_bounds__(256) void k_extract(const uint8_t *__restrict__ bas
                                                  const uint64_t *__restrict__ off,
                                                  const SegEntry *__restrict__ segs, uint64_t n_segs,
                                                  uint32_t gap, uint32_t is_gb, uint32_t id_base,
-                                                 uint32_t words_per_wave, uint4 *__restrict__ out) {
+                                                 uint32_t words_per_wave, uint4 *__restrict__ out,
+                                                 uint8_t *__restrict__ digits, SortPass dp) {
   extern __shared__ uint32_t lds[];
   const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const uint64_t seg_i = (uint64_t)blockIdx.x * 4 + w;
@@ -136,6 +137,10 @@ __global__ __launch_bounds__(256) void k_extract(const uint8_t *__restrict__ bas
       rec.w = is_gb ? (uint32_t)pos : (uint32_t)(len - KSLAM_K - pos);  // KMer.h:176: len-1-i
     }
     out[sg.out + q] = rec;
+    if (digits) {
+      const uint32_t wv = dp.word == 0 ? rec.x : (dp.word == 1 ? rec.y : (dp.word == 2 ? rec.z : rec.w));
+      digits[sg.out + q] = (uint8_t)sort_pass_digit(wv, dp);
+    }
   }
 }
 
@@ -174,14 +179,15 @@ void extract_fill_segments(const uint32_t *d_nk, const uint64_t *d_rec_start, co
 
 void extract_kmers_launch(const uint8_t *d_bases, const uint64_t *d_offsets, const SegEntry *d_segs,
                           uint64_t n_segs, uint32_t gap, int is_gb, uint32_t id_base, uint4 *d_out,
-                          hipStream_t s) {
+                          hipStream_t s, uint8_t *d_digits, const SortPass *first_pass) {
   if (n_segs == 0) return;
   uint32_t span = (SEG_KMERS - 1) * gap + KSLAM_K + 3;
   uint32_t words = (span + 15) / 16 + 3;
   size_t lds = (size_t)4 * words * sizeof(uint32_t);
   unsigned blocks = (unsigned)((n_segs + 3) / 4);
   hipLaunchKernelGGL(k_extract, dim3(blocks), dim3(256), lds, s, d_bases, d_offsets, d_segs, n_segs, gap,
-                     (uint32_t)(is_gb != 0), id_base, words, d_out);
+                     (uint32_t)(is_gb != 0), id_base, words, d_out, first_pass ? d_digits : nullptr,
+                     first_pass ? *first_pass : SortPass{0, 0, 0});
   HIPCHK(hipGetLastError());
 }
 

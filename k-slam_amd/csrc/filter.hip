@@ -94,6 +94,47 @@ __global__ void k_filter_build(const uint64_t *__restrict__ keys, uint32_t n, ui
   atomicOr(w + 3, 1u << p.s3);
 }
 
+// ---- the build since round 6: the keys' probes ordered by filter block, each block assembled in LDS ----------------
+// k_filter_build above is 4 scattered read-modify-writes per key over the whole filter (312 M keys, 512 MB: 45 ms, 58 %
+// of kslam_set_index).  Instead: (1) k_filter_words turns every distinct non-zero key into its probe, one 64-bit word
+// `piece << 20 | s3 s2 s1 s0` (a key that is zero or repeats its left neighbour becomes a word beyond every block);
+// (2) the words go through the radix passes that cover the bits above a BLOCK of FBLK pieces (32 KB of filter: two 8-bit
+// passes for the 5 Gb database); (3) k_filter_fill: one workgroup per block ORs its words into 32 KB of LDS and stores
+// the block with 16-byte coalesced writes -- every filter byte written once, no read-modify-write in HBM.
+constexpr uint32_t FBLK_BITS = 11, FBLK = 1u << FBLK_BITS;     // 2048 pieces of 16 bytes
+__global__ __launch_bounds__(256) void k_filter_words(const uint64_t *__restrict__ keys, uint32_t n, uint32_t line_bits,
+                                                      uint64_t *__restrict__ words) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t k = keys[i];
+  uint64_t w = 1ull << (20 + 3 + line_bits);    // beyond the last piece: sorts behind every block, belongs to none
+  if (k != 0 && !(i > 0 && keys[i - 1] == k)) {  // k-mer 0 never joins (src/Overlap.h:236); one insert per distinct key
+    const Probe p = probe_of(k, revcomp64(k), line_bits);
+    w = ((uint64_t)p.piece << 20) | ((uint64_t)p.s3 << 15) | (p.s2 << 10) | (p.s1 << 5) | p.s0;
+  }
+  words[i] = w;
+}
+// block_start[b] = index of the first word of block b (words ordered by block; join.hip's offsets kernel)
+__global__ __launch_bounds__(256) void k_filter_fill(const uint64_t *__restrict__ words, const uint32_t *__restrict__ block_start,
+                                                     uint4 *__restrict__ filter) {
+  __shared__ uint32_t blk[FBLK * 4];
+  for (uint32_t x = threadIdx.x; x < FBLK * 4; x += 256) blk[x] = 0;
+  __syncthreads();
+  const uint32_t lo = block_start[blockIdx.x], hi = block_start[blockIdx.x + 1];
+  for (uint32_t i = lo + threadIdx.x; i < hi; i += 256) {
+    const uint64_t w = words[i];
+    uint32_t *q = blk + (((uint32_t)(w >> 20)) & (FBLK - 1u)) * 4;
+    const uint32_t g = (uint32_t)w;
+    atomicOr(q + 0, 1u << (g & 31u));
+    atomicOr(q + 1, 1u << ((g >> 5) & 31u));
+    atomicOr(q + 2, 1u << ((g >> 10) & 31u));
+    atomicOr(q + 3, 1u << ((g >> 15) & 31u));
+  }
+  __syncthreads();
+  uint4 *dst = filter + (size_t)blockIdx.x * FBLK;
+  for (uint32_t x = threadIdx.x; x < FBLK; x += 256) dst[x] = reinterpret_cast<const uint4 *>(blk)[x];
+}
+
 constexpr int FW = 8;              // waves per workgroup
 constexpr int STAGE = 2048;        // survivor records staged per workgroup (128 reads x ~12.6 on the bench workload)
 constexpr uint32_t LWORDS = 36;    // packed-base words per wave: reads up to 511 bases + alignment slack
@@ -282,6 +323,28 @@ void filter_build(const uint64_t *d_sorted_keys, uint32_t n, uint32_t log2_bits,
   if (n == 0) return;
   hipLaunchKernelGGL(k_filter_build, dim3((n + 255) / 256), dim3(256), 0, s, d_sorted_keys, n, log2_bits - 10,
                      (uint32_t *)d_filter);
+  HIPCHK(hipGetLastError());
+}
+
+void filter_build_sorted(const uint64_t *d_sorted_keys, uint32_t n, uint32_t log2_bits, void *d_filter, void *d_words_a, void *d_words_b,
+                         uint32_t *d_block_start, SortWorkspace &ws, hipStream_t s) {
+  const uint32_t line_bits = log2_bits - 10, piece_bits = line_bits + 3;
+  if (n == 0 || piece_bits < FBLK_BITS) {         // (a filter smaller than one block: never chosen by kslam_set_index, fb >= 20)
+    filter_build(d_sorted_keys, n, log2_bits, d_filter, s);
+    return;
+  }
+  const uint32_t n_blocks = 1u << (piece_bits - FBLK_BITS);
+  hipLaunchKernelGGL(k_filter_words, dim3((n + 255) / 256), dim3(256), 0, s, d_sorted_keys, n, line_bits, (uint64_t *)d_words_a);
+  // radix passes over the block number and the "belongs to no block" bit above it: key bits [20 + FBLK_BITS, 20 + piece_bits]
+  SortPass passes[8];
+  int np = 0;
+  for (uint32_t sh = 20 + FBLK_BITS; sh <= 20 + piece_bits; sh += 8) passes[np++] = SortPass{2u, sh, 0};
+  const bool keep = ws.use_digit_bytes;
+  ws.use_digit_bytes = true;
+  const uint64_t *words = (const uint64_t *)radix_sort(d_words_a, d_words_b, n, 2, passes, np, ws, s, nullptr, nullptr, nullptr, /*setup=*/true);
+  ws.use_digit_bytes = keep;
+  build_offsets_table(words, n, 20 + FBLK_BITS, n_blocks + 1, d_block_start, s);   // [0, n_blocks]: starts; the words of no block follow
+  hipLaunchKernelGGL(k_filter_fill, dim3(n_blocks), dim3(256), 0, s, words, d_block_start, (uint4 *)d_filter);
   HIPCHK(hipGetLastError());
 }
 

@@ -115,26 +115,110 @@ __device__ inline uint64_t make_overlap(uint32_t rmeta, uint32_t roff, uint32_t 
 // its writes when the range would exceed `cap` (the host then reruns with a larger buffer); the
 // output ORDER depends on scheduling, which is harmless because the overlap keys are totally ordered
 // by the sort that follows (equal keys are indistinguishable).
+//
+// flat emission: the block's runs {rmeta, roff, run.lo, first output slot} and, per output slot,
+// the run it belongs to -- so that every thread then writes ONE overlap (parallel gathers of the
+// genome records, consecutive stores) instead of walking its own runs with the wave idling
+constexpr uint32_t FLAT_MAX = 4096;
+struct JoinSmem {
+  uint32_t wsum[JB / 64];
+  unsigned long long s_base;
+  uint32_t bigq_n;
+  uint4 bigq[BIGQ];          // {rmeta, roff, run.lo, run.cnt}
+  uint32_t bigq_out[BIGQ];   // block-relative output offset
+  uint4 runq[JOIN_TILE];
+  uint16_t owner[FLAT_MAX];
+  uint32_t runq_n;
+};
+
+// what both join kernels do once every thread knows the run of equal genome keys of each of its JI read records
+// (sm.bigq_n and sm.runq_n zeroed by thread 0 before the first barrier the caller passed)
+__device__ __forceinline__ void emit_runs(JoinSmem &sm, const uint4 (&r)[JI], const Run (&run)[JI], uint32_t mine, const GenomeIndexDev &g,
+                                          const uint32_t *__restrict__ read_len, unsigned long long *__restrict__ cursor, uint64_t cap,
+                                          const OverlapKeyLayout &lay, uint64_t *__restrict__ out) {
+  // block exclusive scan of `mine`
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  uint32_t inc = mine;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t t = __shfl_up(inc, d, 64);
+    if (lane >= d) inc += t;
+  }
+  if (lane == 63) sm.wsum[w] = inc;
+  __syncthreads();
+  uint32_t ex = inc - mine;
+  for (int i = 0; i < w; i++) ex += sm.wsum[i];
+  uint64_t bb;
+  uint32_t tot = 0;
+  for (int i = 0; i < JB / 64; i++) tot += sm.wsum[i];
+  if (threadIdx.x == 0) sm.s_base = tot ? atomicAdd(cursor, (unsigned long long)tot) : 0ull;
+  __syncthreads();
+  bb = sm.s_base;
+  if (bb + tot > cap) return;   // does not fit: only the cursor matters now (block-uniform exit)
+  if (tot <= FLAT_MAX) {   // (block-uniform)
+#pragma unroll
+    for (int it = 0; it < JI; it++) {
+      const uint32_t c = run[it].cnt;
+      if (c == 0) continue;
+      const uint32_t slot = atomicAdd(&sm.runq_n, 1u);
+      sm.runq[slot] = make_uint4(r[it].z, r[it].w, run[it].lo, ex);
+      for (uint32_t j = 0; j < c; j++) sm.owner[ex + j] = (uint16_t)slot;
+      ex += c;
+    }
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < tot; k += JB) {
+      const uint4 e = sm.runq[sm.owner[k]];
+      const uint32_t gi = e.z + (k - e.w);
+      const uint2 mo = g.mo[gi];
+      out[bb + k] = make_overlap(e.x, e.y, mo.x, mo.y, read_len, lay);
+    }
+    return;
+  }
+#pragma unroll
+  for (int it = 0; it < JI; it++) {
+    const uint32_t c = run[it].cnt;
+    if (c == 0) continue;
+    bool queued = false;
+    if (c > BIG) {
+      uint32_t slot = atomicAdd(&sm.bigq_n, 1u);
+      if (slot < BIGQ) {
+        sm.bigq[slot] = make_uint4(r[it].z, r[it].w, run[it].lo, c);
+        sm.bigq_out[slot] = ex;
+        queued = true;
+      }
+    }
+    if (!queued) {
+      for (uint32_t j = 0; j < c; j++) {
+        const uint32_t gi = run[it].lo + j;
+        const uint2 mo = g.mo[gi];
+        out[bb + ex + j] = make_overlap(r[it].z, r[it].w, mo.x, mo.y, read_len, lay);
+      }
+    }
+    ex += c;
+  }
+  __syncthreads();
+  const uint32_t nq = min(sm.bigq_n, (uint32_t)BIGQ);
+  for (uint32_t q = 0; q < nq; q++) {
+    const uint4 e = sm.bigq[q];
+    const uint64_t ob = bb + sm.bigq_out[q];
+    for (uint32_t j = threadIdx.x; j < e.w; j += JB) {
+      const uint32_t gi = e.z + j;
+      const uint2 mo = g.mo[gi];
+      out[ob + j] = make_overlap(e.x, e.y, mo.x, mo.y, read_len, lay);
+    }
+  }
+}
+
+// THE PROBE (default): every sorted read record looks its key up through the bucket table
 __global__ __launch_bounds__(JB) void k_join_fill(const uint4 *__restrict__ recs, uint32_t n,
                                                   GenomeIndexDev g, const uint32_t *__restrict__ read_len,
                                                   unsigned long long *__restrict__ cursor, uint64_t cap,
                                                   OverlapKeyLayout lay, uint64_t *__restrict__ out) {
-  __shared__ uint32_t wsum[JB / 64];
-  __shared__ unsigned long long s_base;
-  __shared__ uint32_t bigq_n;
-  __shared__ uint4 bigq[BIGQ];       // {rmeta, roff, run.lo, run.cnt}
-  __shared__ uint32_t bigq_out[BIGQ];  // block-relative output offset
-  // flat emission: the block's runs {rmeta, roff, run.lo, first output slot} and, per output slot,
-  // the run it belongs to -- so that every thread then writes ONE overlap (parallel gathers of the
-  // genome records, consecutive stores) instead of walking its own runs with the wave idling
-  constexpr uint32_t FLAT_MAX = 4096;
-  __shared__ uint4 runq[JOIN_TILE];
-  __shared__ uint16_t owner[FLAT_MAX];
-  __shared__ uint32_t runq_n;
+  __shared__ JoinSmem sm;
   const uint32_t base = blockIdx.x * JOIN_TILE;
   if (threadIdx.x == 0) {
-    bigq_n = 0;
-    runq_n = 0;
+    sm.bigq_n = 0;
+    sm.runq_n = 0;
   }
   uint4 r[JI];
   Run run[JI];
@@ -149,77 +233,130 @@ __global__ __launch_bounds__(JB) void k_join_fill(const uint4 *__restrict__ recs
     }
     mine += run[it].cnt;
   }
-  // block exclusive scan of `mine`
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  uint32_t inc = mine;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    uint32_t t = __shfl_up(inc, d, 64);
-    if (lane >= d) inc += t;
+  emit_runs(sm, r, run, mine, g, read_len, cursor, cap, lay, out);
+}
+
+// THE MERGE (KSLAM_JOIN=merge): the shape of the reference's findOverlaps (src/Overlap.h:230-246) -- two sorted lists walked
+// side by side -- cut into segments of one workgroup each.  The read records are ordered by the top `gb` bits of their key
+// (the radix passes the per-batch sort executes), so a tile of JOIN_TILE consecutive read records meets ONE contiguous range of
+// the sorted genome key column, [bucket(first record's group), bucket(last record's group + 1)) -- two table reads per
+// WORKGROUP instead of two per record.  The workgroup streams that range through LDS in pieces of MP keys with 16-byte
+// coalesced loads (the next piece is in flight in registers while the current one is searched); every thread places each of
+// its JI read keys in the piece by a binary search in LDS (the JI searches in lock step: independent LDS reads), and the run
+// of equal keys is counted where it lies (a run cut by a piece boundary continues in the next piece: the column is sorted, the
+// parts are adjacent).  Key 0 never joins (Overlap.h:236).  Then the same flat emission as the probe: {meta, offset} is
+// gathered only for hits.  HBM: the key column once, sequentially (2.5 GB for the 5 Gb database whatever the batch), against the
+// probe's scattered 64-byte sectors (table rows + keys: ~2 per record); measured side by side in profiles/r06_join_merge.json.
+constexpr uint32_t MP = 4096;                    // keys per piece: 32 KB of LDS
+constexpr uint32_t MPV = MP / 2 / JB;            // 16-byte loads per thread and piece
+__global__ __launch_bounds__(JB) void k_join_merge(const uint4 *__restrict__ recs, uint32_t n, GenomeIndexDev g, uint32_t gb,
+                                                   const uint32_t *__restrict__ read_len, unsigned long long *__restrict__ cursor,
+                                                   uint64_t cap, OverlapKeyLayout lay, uint64_t *__restrict__ out) {
+  // the staged piece and the emission's queues are never live together: one 32 KB block of LDS (5 workgroups per CU)
+  static_assert(sizeof(JoinSmem) <= MP * sizeof(uint64_t), "the emission's LDS must fit under the piece");
+  __shared__ __attribute__((aligned(16))) unsigned char raw[MP * sizeof(uint64_t)];
+  __shared__ uint32_t s_range[2];
+  JoinSmem &sm = *reinterpret_cast<JoinSmem *>(raw);
+  uint64_t *piece = reinterpret_cast<uint64_t *>(raw);
+  const uint32_t base = blockIdx.x * JOIN_TILE;
+  const uint32_t tile_end = min(n, base + (uint32_t)JOIN_TILE);
+  if (threadIdx.x == 0) {
+    const uint4 a = recs[base], z = recs[tile_end - 1];
+    const uint64_t ka = ((uint64_t)a.y << 32) | a.x, kz = ((uint64_t)z.y << 32) | z.x;
+    const uint32_t up = g.bucket_bits - gb;
+    s_range[0] = g.bucket[(uint32_t)(ka >> (64 - gb)) << up] & ~1u;        // (16-byte loads: an even start)
+    s_range[1] = g.bucket[((uint32_t)(kz >> (64 - gb)) + 1u) << up];
   }
-  if (lane == 63) wsum[w] = inc;
-  __syncthreads();
-  uint32_t ex = inc - mine;
-  for (int i = 0; i < w; i++) ex += wsum[i];
-  uint64_t bb;
-  uint32_t tot = 0;
-  for (int i = 0; i < JB / 64; i++) tot += wsum[i];
-  if (threadIdx.x == 0) s_base = tot ? atomicAdd(cursor, (unsigned long long)tot) : 0ull;
-  __syncthreads();
-  bb = s_base;
-  if (bb + tot > cap) return;   // does not fit: only the cursor matters now (block-uniform exit)
-  if (tot <= FLAT_MAX) {   // (block-uniform)
-#pragma unroll
-    for (int it = 0; it < JI; it++) {
-      const uint32_t c = run[it].cnt;
-      if (c == 0) continue;
-      const uint32_t slot = atomicAdd(&runq_n, 1u);
-      runq[slot] = make_uint4(r[it].z, r[it].w, run[it].lo, ex);
-      for (uint32_t j = 0; j < c; j++) owner[ex + j] = (uint16_t)slot;
-      ex += c;
-    }
-    __syncthreads();
-    for (uint32_t k = threadIdx.x; k < tot; k += JB) {
-      const uint4 e = runq[owner[k]];
-      const uint32_t gi = e.z + (k - e.w);
-      const uint2 mo = g.mo[gi];
-      out[bb + k] = make_overlap(e.x, e.y, mo.x, mo.y, read_len, lay);
-    }
-    return;
-  }
+  uint4 r[JI];
+  uint64_t key[JI];
+  Run run[JI];
 #pragma unroll
   for (int it = 0; it < JI; it++) {
-    const uint32_t c = run[it].cnt;
-    if (c == 0) continue;
-    bool queued = false;
-    if (c > BIG) {
-      uint32_t slot = atomicAdd(&bigq_n, 1u);
-      if (slot < BIGQ) {
-        bigq[slot] = make_uint4(r[it].z, r[it].w, run[it].lo, c);
-        bigq_out[slot] = ex;
-        queued = true;
-      }
+    const uint32_t i = base + it * JB + threadIdx.x;
+    run[it] = Run{0, 0};
+    key[it] = 0;
+    if (i < n) {
+      r[it] = recs[i];
+      key[it] = ((uint64_t)r[it].y << 32) | r[it].x;
     }
-    if (!queued) {
-      for (uint32_t j = 0; j < c; j++) {
-        const uint32_t gi = run[it].lo + j;
-        const uint2 mo = g.mo[gi];
-        out[bb + ex + j] = make_overlap(r[it].z, r[it].w, mo.x, mo.y, read_len, lay);
-      }
-    }
-    ex += c;
   }
   __syncthreads();
-  const uint32_t nq = min(bigq_n, (uint32_t)BIGQ);
-  for (uint32_t q = 0; q < nq; q++) {
-    const uint4 e = bigq[q];
-    const uint64_t ob = bb + bigq_out[q];
-    for (uint32_t j = threadIdx.x; j < e.w; j += JB) {
-      const uint32_t gi = e.z + j;
-      const uint2 mo = g.mo[gi];
-      out[ob + j] = make_overlap(e.x, e.y, mo.x, mo.y, read_len, lay);
+  const uint32_t glo = s_range[0], ghi = s_range[1];
+  const ulonglong2 *col = reinterpret_cast<const ulonglong2 *>(g.key);
+  const uint32_t n_even = (g.n + 1u) & ~1u;       // the column's allocation is padded (kslam_api.hip: n_gk + 2 keys)
+  ulonglong2 nxt[MPV];
+  auto fetch = [&](uint32_t p) {
+#pragma unroll
+    for (uint32_t v = 0; v < MPV; v++) {
+      const uint32_t at = p + 2u * (v * JB + threadIdx.x);
+      nxt[v] = at < ghi && at < n_even ? col[at >> 1] : make_ulonglong2(~0ull, ~0ull);
     }
+  };
+  if (glo < ghi) fetch(glo);
+  for (uint32_t p = glo; p < ghi; p += MP) {
+    const uint32_t cnt = min((uint32_t)MP, ghi - p);
+#pragma unroll
+    for (uint32_t v = 0; v < MPV; v++) reinterpret_cast<ulonglong2 *>(piece)[v * JB + threadIdx.x] = nxt[v];
+    __syncthreads();
+    if (p + MP < ghi) fetch(p + MP);                 // in flight while this piece is searched
+    const uint64_t first = piece[0], last = piece[cnt - 1];
+    // lower bounds of the JI keys in piece[0, cnt), in lock step
+    uint32_t lo[JI], hi[JI];
+    bool in[JI];
+    bool any = false;
+#pragma unroll
+    for (int it = 0; it < JI; it++) {
+      in[it] = key[it] != 0 && key[it] >= first && key[it] <= last;
+      lo[it] = 0;
+      hi[it] = in[it] ? cnt : 0;
+      any |= in[it];
+    }
+    if (__any(any)) {
+      for (uint32_t step = 0; step < 13; step++) {   // 2^12 = MP
+        bool more = false;
+#pragma unroll
+        for (int it = 0; it < JI; it++) {
+          if (lo[it] < hi[it]) {
+            const uint32_t mid = lo[it] + ((hi[it] - lo[it]) >> 1);
+            if (piece[mid] < key[it]) lo[it] = mid + 1; else hi[it] = mid;
+            more |= lo[it] < hi[it];
+          }
+        }
+        if (!__any(more)) break;
+      }
+#pragma unroll
+      for (int it = 0; it < JI; it++) {
+        if (!in[it]) continue;
+        uint32_t e = lo[it];
+        // the run's end: a few steps (runs are short), then a second binary search (tandem repeats: thousands)
+        uint32_t c = 0;
+        while (c < 4 && e + c < cnt && piece[e + c] == key[it]) c++;
+        if (c == 4 && e + 4 < cnt && piece[e + 4] == key[it]) {
+          uint32_t a = e + 5, z = cnt;
+          while (a < z) {
+            const uint32_t mid = a + ((z - a) >> 1);
+            if (piece[mid] <= key[it]) a = mid + 1; else z = mid;
+          }
+          c = a - e;
+        }
+        // the padding of an odd start / the column's end reads as ~0 and a real key of ~0 cannot exist below index n
+        if (c && p + e + c > g.n) c = g.n > p + e ? g.n - (p + e) : 0;
+        if (c) {
+          if (run[it].cnt == 0) run[it].lo = p + e;
+          run[it].cnt += c;
+        }
+      }
+    }
+    __syncthreads();
   }
+  if (threadIdx.x == 0) {      // (the loop's last barrier has passed: nobody reads the piece any more)
+    sm.bigq_n = 0;
+    sm.runq_n = 0;
+  }
+  uint32_t mine = 0;
+#pragma unroll
+  for (int it = 0; it < JI; it++) mine += run[it].cnt;
+  emit_runs(sm, r, run, mine, g, read_len, cursor, cap, lay, out);
 }
 
 // std::unique with "same read & entry & |delta rel| < 3 against the LAST KEPT element" (Overlap.h:79-85, 290)
@@ -351,12 +488,30 @@ void build_bucket_table(const uint64_t *d_keys, uint32_t n, uint32_t bits, uint3
   HIPCHK(hipGetLastError());
 }
 
+void build_offsets_table(const uint64_t *d_keys, uint32_t n, uint32_t shift, uint32_t nb, uint32_t *d_table, hipStream_t s) {
+  if (n == 0) hipLaunchKernelGGL(k_bucket_empty, dim3((nb + 256) / 256), dim3(256), 0, s, nb, d_table);
+  else hipLaunchKernelGGL(k_bucket, dim3((n + 255) / 256), dim3(256), 0, s, d_keys, n, shift, nb, d_table);
+  HIPCHK(hipGetLastError());
+}
+
 void join_fill_single_pass(const uint4 *d_read_recs, uint32_t n_r, GenomeIndexDev g, const uint32_t *d_read_len,
                            uint64_t *d_cursor, uint64_t cap, OverlapKeyLayout lay, uint64_t *d_out, hipStream_t s) {
   HIPCHK(hipMemsetAsync(d_cursor, 0, sizeof(uint64_t), s));
   if (n_r == 0) return;
   unsigned blocks = (n_r + JOIN_TILE - 1) / JOIN_TILE;
   hipLaunchKernelGGL(k_join_fill, dim3(blocks), dim3(JB), 0, s, d_read_recs, n_r, g, d_read_len,
+                     reinterpret_cast<unsigned long long *>(d_cursor), cap, lay, d_out);
+  HIPCHK(hipGetLastError());
+}
+
+void join_fill_merge(const uint4 *d_read_recs, uint32_t n_r, GenomeIndexDev g, uint32_t sorted_top_bits, const uint32_t *d_read_len,
+                     uint64_t *d_cursor, uint64_t cap, OverlapKeyLayout lay, uint64_t *d_out, hipStream_t s) {
+  HIPCHK(hipMemsetAsync(d_cursor, 0, sizeof(uint64_t), s));
+  if (n_r == 0) return;
+  const uint32_t gb = std::min(sorted_top_bits, g.bucket_bits);
+  if (gb == 0 || gb > 31) throw StatusError{KSLAM_ERR_STATE, "the merge join needs read records ordered by 1..31 top key bits"};
+  unsigned blocks = (n_r + JOIN_TILE - 1) / JOIN_TILE;
+  hipLaunchKernelGGL(k_join_merge, dim3(blocks), dim3(JB), 0, s, d_read_recs, n_r, g, gb, d_read_len,
                      reinterpret_cast<unsigned long long *>(d_cursor), cap, lay, d_out);
   HIPCHK(hipGetLastError());
 }

@@ -195,6 +195,8 @@ Tuning read_tuning() {
   t.pageable_columns = flag("KSLAM_PAGEABLE_COLUMNS");
   t.pseudo_cap = std::max(0, num("KSLAM_PSEUDO_CAP", 0));
   t.join_group_order = starts("KSLAM_JOIN_GROUP_ORDER", '0') ? 0 : 1;
+  t.join_merge = starts("KSLAM_JOIN", 'm') ? 1 : 0;
+  t.filter_build_sorted = !starts("KSLAM_FILTER_BUILD", 'a');      // =atomics: the scattered read-modify-write build (A/B)
   t.details_in_token = !starts("KSLAM_DETAILS_IN_TOKEN", '0');
 #ifdef KSLAM_ABLATE
   t.sw_ablate = (uint32_t)num("KSLAM_SW_ABLATE", 0);
@@ -248,10 +250,7 @@ void ensure_keep(DevBuf &b, size_t bytes, size_t used, hipStream_t s) {
     HIPCHK(hipMemcpyAsync(nb.p, b.p, used, hipMemcpyDeviceToDevice, s));
     HIPCHK(stream_wait(s));
   }
-  b.release();
-  b = nb;              // (copy-assignment is a borrowed view: common.h)
-  nb.p = nullptr;      // ... so the local gives the block up before its destructor runs
-  nb.cap = 0;
+  b = std::move(nb);   // frees the old block, takes the new one
 }
 
 // Page-locked host memory for the result / staging buffers: a private anonymous mapping advised for
@@ -409,7 +408,7 @@ Planned plan_host(const uint64_t *off, uint64_t n, uint32_t gap) {
 
 // extraction of n sequences d_off[0..n] into d_out (AoS records)
 void run_extract(kslam_ctx *c, const uint8_t *d_bases, const uint64_t *d_off, uint64_t n, uint32_t gap, int is_gb,
-                 uint64_t n_segs, uint4 *d_out) {
+                 uint64_t n_segs, uint4 *d_out, uint8_t *d_digits = nullptr, const SortPass *first_pass = nullptr) {
   hipStream_t s = c->stream;
   c->nk.ensure(n * sizeof(uint32_t) + 4);
   c->nseg.ensure(n * sizeof(uint32_t) + 4);
@@ -422,7 +421,7 @@ void run_extract(kslam_ctx *c, const uint8_t *d_bases, const uint64_t *d_off, ui
                c->seg_start.as<uint64_t>(), c->totals.as<uint64_t>(), c->scan_tmp.p, s);
   extract_fill_segments(c->nk.as<uint32_t>(), c->rec_start.as<uint64_t>(), c->seg_start.as<uint64_t>(), n, gap,
                         c->segs.as<SegEntry>(), s, n_segs);
-  extract_kmers_launch(d_bases, d_off, c->segs.as<SegEntry>(), n_segs, gap, is_gb, 0, d_out, s);
+  extract_kmers_launch(d_bases, d_off, c->segs.as<SegEntry>(), n_segs, gap, is_gb, 0, d_out, s, d_digits, first_pass);
 }
 
 void build_index(kslam_ctx *c) {
@@ -434,8 +433,12 @@ void build_index(kslam_ctx *c) {
   if (c->max_entry_len >= (1ull << 32)) throw StatusError{KSLAM_ERR_UNSUPPORTED, "entry longer than 2^32 bases"};
   c->g_off.ensure((n + 1) * sizeof(uint64_t));
   HIPCHK(hipMemcpyAsync(c->g_off.p, c->h_goff.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s));
-  hipEvent_t ev_begin;
-  HIPCHK(hipEventCreate(&ev_begin));
+  struct Events {       // destroyed on every way out of this function
+    hipEvent_t e[4] = {nullptr, nullptr, nullptr, nullptr};
+    ~Events() { for (hipEvent_t x : e) if (x) (void)hipEventDestroy(x); }
+  } evs;
+  for (hipEvent_t &x : evs.e) HIPCHK(hipEventCreate(&x));
+  hipEvent_t ev_begin = evs.e[0], e1 = evs.e[1], e2 = evs.e[2], e3 = evs.e[3];
   HIPCHK(hipEventRecord(ev_begin, s));
   c->g_codes.ensure(c->h_goff[n] + 64);
   encode_bases(c->g_bases.as<uint8_t>(), c->g_codes.as<uint8_t>(), c->h_goff[n] + 48, s);
@@ -445,24 +448,38 @@ void build_index(kslam_ctx *c) {
   const uint64_t m = pl.n_kmers;
   c->recs_a.ensure((m + 1) * sizeof(uint4));
   c->recs_b.ensure((m + 1) * sizeof(uint4));
-  run_extract(c, c->g_bases.as<uint8_t>(), c->g_off.as<uint64_t>(), n, KSLAM_K / 2, 1, pl.n_segs,
-              c->recs_a.as<uint4>());
-  // sortKMers' order (src/KMer.h:388-398): k-mer ascending, then the meta word DESCENDING.  LSD passes over the meta bytes
-  // first -- but only over bytes that can differ in a list of genome records: id < n (the low bytes its bits reach),
-  // isFromGB = 1 everywhere, revComp in bit 30 (the top byte) -- then the 8 bytes of the k-mer.  A pass over a byte that is
-  // the same in every record is the identity permutation; for 1 250 entries that is one pass of twelve not made.
+  // sortKMers' order (src/KMer.h:388-398): k-mer ascending, then the meta word DESCENDING.  LSD passes over the meta word
+  // first -- but only over what can differ in a list of genome records: the id (n entries: bits 0 .. b - 1), isFromGB = 1
+  // everywhere, revComp in bit 30 -- then the 8 bytes of the k-mer.  The id's bytes below its top one take a pass each; its
+  // top bits (at most 7 of them) share ONE pass with the revComp bit above them (SortPass::hi_bits): ids of 1 250 entries
+  // are 11 bits, so the meta word takes two passes -- id bits 0-7, then {revComp, id bits 8-14} -- and the sort ten.
+  // (Round 5: a pass per byte that can differ, three for this database.)
   std::vector<SortPass> passes;
-  for (uint32_t b = 0; b < 4; b++) {
-    const bool id_reaches = b < 3 && (b == 0 || ((n - 1) >> (8 * b)) != 0);   // ids 0 .. n - 1 in bits 0-29
-    const bool top = b == 3;                                                   // revComp (bit 30; ids of 2^24 entries and more)
-    if (id_reaches || top) passes.push_back(SortPass{2, 8 * b, 0xFFFFFFFFu});
+  {
+    const uint32_t id_bits = (uint32_t)bits_for(n ? n - 1 : 0);     // <= 30
+    uint32_t at = 0;
+    while (id_bits - at > 7) {                                        // whole bytes of the id while more than 7 bits remain
+      passes.push_back(SortPass{2, at, 0xFFFFFFFFu});
+      at += 8;
+    }
+    SortPass top{2, at, 0xFFFFFFFFu};                                 // the rest of the id below the revComp bit
+    top.hi_shift = 30;
+    top.hi_bits = 1;
+    passes.push_back(top);
   }
   kmer_passes(passes);
-  hipEvent_t e1, e2, e3;
-  for (hipEvent_t *e : {&e1, &e2, &e3}) HIPCHK(hipEventCreate(e));
+  // the extraction writes the first pass's digit of every record next to it: the sort's first histogram reads 1 byte per
+  // record instead of 16
+  const bool first_digits = c->tune.sort_digit_bytes && passes.size() > 1;
+  if (first_digits) c->sortws.digits.ensure(m + 64);
+  run_extract(c, c->g_bases.as<uint8_t>(), c->g_off.as<uint64_t>(), n, KSLAM_K / 2, 1, pl.n_segs,
+              c->recs_a.as<uint4>(), first_digits ? c->sortws.digits.as<uint8_t>() : nullptr, first_digits ? &passes[0] : nullptr);
+  c->sortws.use_digit_bytes = c->tune.sort_digit_bytes;
+  c->sortws.first_digits_ready = first_digits;
   HIPCHK(hipEventRecord(e1, s));
   void *sorted = radix_sort(c->recs_a.p, c->recs_b.p, m, 4, passes.data(), (int)passes.size(), c->sortws, s,
                             nullptr, nullptr, nullptr, /*setup=*/true);
+  c->sortws.first_digits_ready = false;
   HIPCHK(hipEventRecord(e2, s));
   c->gk_key.ensure((m + 1) * sizeof(uint64_t));
   c->gk_meta.ensure((m + 1) * sizeof(uint2));   // {meta, offset} pairs
@@ -484,7 +501,13 @@ void build_index(kslam_ctx *c) {
     c->filter_bits = fb;
     if (fb) {
       c->g_filter.ensure(filter_bytes(fb));
-      filter_build(c->gk_key.as<uint64_t>(), (uint32_t)m, fb, c->g_filter.p, s);
+      if (c->tune.filter_build_sorted) {
+        // the probe words take the record buffers of the sort that has just finished (k_split_soa, queued above, was their last reader)
+        c->pos.ensure((filter_bytes(fb) / 32768 + 2) * sizeof(uint32_t));
+        filter_build_sorted(c->gk_key.as<uint64_t>(), (uint32_t)m, fb, c->g_filter.p, c->recs_a.p, c->recs_b.p, c->pos.as<uint32_t>(), c->sortws, s);
+      } else {
+        filter_build(c->gk_key.as<uint64_t>(), (uint32_t)m, fb, c->g_filter.p, s);
+      }
     }
   }
   HIPCHK(hipEventRecord(e3, s));
@@ -499,7 +522,9 @@ void build_index(kslam_ctx *c) {
     (void)hipEventElapsedTime(&st.ms_sort, e1, e2);
     (void)hipEventElapsedTime(&st.ms_tables, e2, e3);
     (void)hipEventElapsedTime(&st.ms_total, ev_begin, e3);
-    for (hipEvent_t e : {ev_begin, e1, e2, e3}) (void)hipEventDestroy(e);
+    // the one-time sorts' digit bytes (one per genome k-mer: 312 MB for the 5 Gb database) are not kept for the context's life:
+    // a batch's sort allocates what its own record count needs
+    c->sortws.digits.release();
   }
   c->kept_last = 0;
   c->have_index = true;
@@ -734,8 +759,12 @@ void align_resident(kslam_ctx *c, bool stop_after_join, uint64_t *n_raw_out, Pai
       uint64_t cap = have_cap > guess ? have_cap - 1 : guess;   // never grows a big-enough buffer
       for (int attempt = 0; attempt < 2; attempt++) {
         c->ovk_a.ensure((cap + 1) * sizeof(uint64_t));
-        join_fill_single_pass(sorted, (uint32_t)nk, g, c->r_len.as<uint32_t>() + r0, d_tot, cap, lay,
-                              c->ovk_a.as<uint64_t>(), s);
+        if (c->tune.join_merge && !kpasses.empty())
+          join_fill_merge(sorted, (uint32_t)nk, g, 8u * (uint32_t)kpasses.size(), c->r_len.as<uint32_t>() + r0, d_tot, cap, lay,
+                          c->ovk_a.as<uint64_t>(), s);
+        else
+          join_fill_single_pass(sorted, (uint32_t)nk, g, c->r_len.as<uint32_t>() + r0, d_tot, cap, lay,
+                                c->ovk_a.as<uint64_t>(), s);
         read_back(&raw, d_tot, sizeof raw, s);
         if (raw <= cap) break;
         cap = raw + raw / 8;
@@ -920,10 +949,11 @@ void share_index(kslam_ctx *dst, const kslam_ctx *src) {
   dst->have_index = src->have_index;
   dst->index_stats = src->index_stats;
   dst->n_entries = src->n_entries; dst->max_entry_len = src->max_entry_len; dst->h_goff = src->h_goff;
-  dst->g_bases = src->g_bases; dst->g_off = src->g_off; dst->g_codes = src->g_codes;
-  dst->n_gk = src->n_gk; dst->gk_key = src->gk_key; dst->gk_meta = src->gk_meta; dst->gk_off = src->gk_off;
-  dst->g_bucket = src->g_bucket; dst->bucket_bits = src->bucket_bits;
-  dst->g_filter = src->g_filter; dst->filter_bits = src->filter_bits;
+  // views, not owners (DevBuf::borrow frees what dst owned before: an index of its own, if it had one)
+  dst->g_bases.borrow(src->g_bases); dst->g_off.borrow(src->g_off); dst->g_codes.borrow(src->g_codes);
+  dst->n_gk = src->n_gk; dst->gk_key.borrow(src->gk_key); dst->gk_meta.borrow(src->gk_meta); dst->gk_off.borrow(src->gk_off);
+  dst->g_bucket.borrow(src->g_bucket); dst->bucket_bits = src->bucket_bits;
+  dst->g_filter.borrow(src->g_filter); dst->filter_bits = src->filter_bits;
   dst->kept_last = 0;
   dst->pairing = src->pairing;
 }
@@ -1416,10 +1446,7 @@ void kslam_destroy(kslam_ctx *c) {
   if (c->device >= 0) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    if (c->borrowed_index) {   // a lane's view of its primary's index: not ours to free
-      DevBuf *idx[] = {&c->g_codes, &c->g_bases, &c->g_off, &c->gk_key, &c->gk_meta, &c->gk_off, &c->g_bucket, &c->g_filter};
-      for (DevBuf *b : idx) { b->p = nullptr; b->cap = 0; }
-    }
+    // (a lane's / sibling's view of its primary's index is not freed: DevBuf::borrowed)
     DevBuf *bufs[] = {&c->g_codes, &c->r_codes, &c->g_bases, &c->g_off, &c->gk_key, &c->gk_meta, &c->gk_off, &c->g_bucket, &c->g_filter, &c->r_bases,
                       &c->r_off, &c->r_len, &c->nk, &c->nseg, &c->rec_start, &c->seg_start, &c->segs, &c->scan_tmp,
                       &c->totals, &c->recs_a, &c->recs_b, &c->block_tot, &c->block_base, &c->ovk_a, &c->ovk_b,

@@ -41,12 +41,12 @@ __device__ inline uint32_t rec_word(const uint4 &r, uint32_t w) {
 __device__ inline uint32_t rec_word(const uint2 &r, uint32_t w) { return w == 0 ? r.x : r.y; }
 
 template <typename T> __device__ inline uint32_t digit_of(const T &r, const SortPass &p) {
-  return ((rec_word(r, p.word) ^ p.invert) >> p.shift) & 0xFFu;
+  return sort_pass_digit(rec_word(r, p.word), p);
 }
 // a two-word record is also a 64-bit key: word 2 = "the digit at bit `shift` of the whole key", whatever words it straddles
 __device__ inline uint32_t digit_of(const uint2 &r, const SortPass &p) {
   if (p.word == 2u) return (uint32_t)(((((uint64_t)r.y) << 32) | r.x) >> p.shift) & 0xFFu;
-  return ((rec_word(r, p.word) ^ p.invert) >> p.shift) & 0xFFu;
+  return sort_pass_digit(rec_word(r, p.word), p);
 }
 
 // ---- per-tile digit histogram of one pass ----------------------------------------------------
@@ -96,10 +96,49 @@ __global__ __launch_bounds__(256) void k_tile_hist_bytes(const uint8_t *__restri
                                                          uint32_t *__restrict__ tile_hist) {
   tile_hist_bytes_body(dig, n, tile_hist);
 }
-// the same kernel under the one-time sorts' name (see k_tile_hist_setup)
-__global__ __launch_bounds__(256) void k_tile_hist_bytes_setup(const uint8_t *__restrict__ dig, uint32_t n,
+// The one-time sorts' byte histogram (312 M digit bytes per pass for the 5 Gb database).  Two things the per-batch kernel
+// above does not need: (1) SKEW: the passes over the meta word see digits that take a handful of values (the high id
+// bits of 1 250 entries, the revComp bit), and 64 lanes adding to two LDS addresses serialise -- those passes' histograms
+// took 1.09 ms against 0.10 for a k-mer byte.  So every tile keeps HC copies of its histogram and lane l adds to copy
+// l mod HC (16 copies: four lanes per address at worst); they are summed when the tile's counts are written.  (2) HT
+// tiles per workgroup, all their 16-byte loads in flight before the first LDS atomic.
+constexpr uint32_t HT = 2, HC = 16;
+__global__ __launch_bounds__(256) void k_tile_hist_bytes_setup(const uint8_t *__restrict__ dig, uint32_t n, uint32_t n_tiles,
                                                                uint32_t *__restrict__ tile_hist) {
-  tile_hist_bytes_body(dig, n, tile_hist);
+  __shared__ uint32_t h[HT][HC][256];
+  const uint32_t tid = threadIdx.x;
+  for (uint32_t x = tid; x < HT * HC * 256; x += 256) (&h[0][0][0])[x] = 0;
+  __syncthreads();
+  const uint32_t tile0 = blockIdx.x * HT, copy = tid & (HC - 1u);
+  uint4 v[HT];
+#pragma unroll
+  for (uint32_t t = 0; t < HT; t++) {
+    const uint32_t base = (tile0 + t) * SORT_TILE + tid * 16;
+    v[t] = (tile0 + t < n_tiles && base + 16 <= n) ? *reinterpret_cast<const uint4 *>(dig + base) : make_uint4(0, 0, 0, 0);
+  }
+#pragma unroll
+  for (uint32_t t = 0; t < HT; t++) {
+    const uint32_t base = (tile0 + t) * SORT_TILE + tid * 16;
+    if (tile0 + t >= n_tiles) break;
+    if (base + 16 <= n) {
+      const uint32_t w[4] = {v[t].x, v[t].y, v[t].z, v[t].w};
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) atomicAdd(&h[t][copy][(w[k] >> (8 * b)) & 0xFFu], 1u);
+    } else {
+      for (uint32_t i = base; i < n && i < base + 16; i++) atomicAdd(&h[t][copy][dig[i]], 1u);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (uint32_t t = 0; t < HT; t++)
+    if (tile0 + t < n_tiles) {
+      uint32_t sum = 0;
+#pragma unroll
+      for (uint32_t c = 0; c < HC; c++) sum += h[t][(c + tid) & (HC - 1u)][tid];   // (rotated: the 64 lanes of a wave spread over the copies' banks)
+      tile_hist[(uint64_t)(tile0 + t) * 256 + tid] = sum;
+    }
 }
 
 // ---- scan of the tile histograms (per digit, over tiles) --------------------------------------
@@ -330,7 +369,7 @@ void sort_impl(void *a, void *b, uint32_t n, const PassList &pl, SortWorkspace &
   uint8_t *digits = (pl.n > 1 && ws.use_digit_bytes) ? ws.digits.as<uint8_t>() : nullptr;
   if (ev0) HIPCHK(hipEventRecord(ev0, s));
   for (int p = 0; p < pl.n; p++) {
-    if (SETUP && digits && p > 0) hipLaunchKernelGGL(k_tile_hist_bytes_setup, dim3(tiles), dim3(256), 0, s, (const uint8_t *)digits, n, tile_hist);
+    if (SETUP && digits && (p > 0 || ws.first_digits_ready)) hipLaunchKernelGGL(k_tile_hist_bytes_setup, dim3((tiles + HT - 1) / HT), dim3(256), 0, s, (const uint8_t *)digits, n, tiles, tile_hist);
     else if (SETUP) hipLaunchKernelGGL(k_tile_hist_setup<RW>, dim3(tiles), dim3(RS_BLOCK), 0, s, (const T *)src, n, pl.p[p], tile_hist);
     else if (digits && (p > 0 || ws.first_digits_ready)) hipLaunchKernelGGL(k_tile_hist_bytes, dim3(tiles), dim3(256), 0, s, (const uint8_t *)digits, n, tile_hist);
     else hipLaunchKernelGGL(k_tile_hist<RW>, dim3(tiles), dim3(RS_BLOCK), 0, s, (const T *)src, n, pl.p[p], tile_hist);
@@ -376,6 +415,7 @@ void *radix_sort(void *a, void *b, uint64_t n, int rec_words, const SortPass *pa
   void *res = nullptr;
   if (rec_words == 4 && setup) sort_impl<4, true>(a, b, (uint32_t)n, pl, ws, s, ev0, ev1, n_launches, &res);
   else if (rec_words == 4) sort_impl<4, false>(a, b, (uint32_t)n, pl, ws, s, ev0, ev1, n_launches, &res);
+  else if (rec_words == 2 && setup) sort_impl<2, true>(a, b, (uint32_t)n, pl, ws, s, ev0, ev1, n_launches, &res);
   else if (rec_words == 2) sort_impl<2, false>(a, b, (uint32_t)n, pl, ws, s, ev0, ev1, n_launches, &res);
   else throw StatusError{KSLAM_ERR_ARG, "unsupported record width"};
   return res;

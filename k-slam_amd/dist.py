@@ -263,10 +263,27 @@ def routed_pseudo_assembly(ctx, dev, score_fraction=0.95, group=None):
     word travels with the scores), none is left waiting.  Returns (stats dict, bytes this rank received)."""
     from . import KslamError
     world = dist.get_world_size(group)
-    d_heads, counts = ctx.pseudo_route(world)
-    n_own = sum(counts)
-    heads = device_bytes(d_heads, n_own * 16, dev)
+    staged = dist.get_backend(group) == "gloo"
+    fdev = torch.device("cpu") if staged else dev
+
+    def agree(status):
+        """the worst status of all ranks, before anybody enters a transfer that depends on the step"""
+        flag = torch.tensor([status], dtype=torch.int64, device=fdev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+        return int(flag.item())
+    # the routing step can fail on one rank alone (out of memory in the route buffers, a world beyond 256): its status is
+    # shared BEFORE the first all-to-all, so that the others do not wait in it for a rank that has left
+    status, counts, n_own, heads = 0, [0] * world, 0, torch.empty(0, dtype=torch.uint8, device=dev)
+    try:
+        d_heads, counts = ctx.pseudo_route(world)
+        n_own = sum(counts)
+        heads = device_bytes(d_heads, n_own * 16, dev)
+    except KslamError as e:
+        status = int(e.status) or 1
     _sync(dev)
+    worst = agree(status)
+    if worst:
+        raise KslamError(worst, "the routing step of the partitioned pseudo-assembly failed on some rank: no rank enters the exchange")
     got, recv = all_to_all_bytes(heads, [c * 16 for c in counts], dev, group)
     _sync(dev)
     n_recv = got.numel() // 16
@@ -278,15 +295,21 @@ def routed_pseudo_assembly(ctx, dev, score_fraction=0.95, group=None):
         status, scores = int(e.status) or 1, torch.zeros(n_recv * 4, dtype=torch.uint8, device=dev)
     _sync(dev)
     # the status of every rank, before anybody depends on the scores
-    staged = dist.get_backend(group) == "gloo"
-    flag = torch.tensor([status], dtype=torch.int64, device=torch.device("cpu") if staged else dev)
-    dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+    worst = agree(status)
     back, _ = all_to_all_bytes(scores, [b // 4 for b in recv], dev, group)
     _sync(dev)
-    if int(flag.item()):
-        raise KslamError(int(flag.item()), "the pseudo-assembly of some rank's entries declined on the device: the batch's stage belongs to the host")
+    if worst:
+        raise KslamError(worst, "the pseudo-assembly of some rank's entries declined on the device: the batch's stage belongs to the host")
     assert back.numel() == n_own * 4
-    stats = ctx.pseudo_return(back.data_ptr() if n_own else None, n_own, score_fraction)
+    # ... and the last step: a rank that fails to commit the scores must not leave the others with a batch it does not have
+    status, stats = 0, None
+    try:
+        stats = ctx.pseudo_return(back.data_ptr() if n_own else None, n_own, score_fraction)
+    except KslamError as e:
+        status = int(e.status) or 1
+    worst = agree(status)
+    if worst:
+        raise KslamError(worst, "kslam_pseudo_return failed on some rank: the batch's pseudo-assembly is void on every rank")
     return stats, got.numel() + back.numel()
 
 
@@ -301,9 +324,9 @@ def sharded_tail(ctx, dev, paired=True, score_threshold=0, score_fraction=0.95, 
     rank = dist.get_rank(group)
     d_ins, n_ins = ctx.pair_phase_a(paired, score_threshold)
     mine = device_bytes(d_ins, n_ins * 4, dev)
-    torch.cuda.synchronize(dev)
+    _sync(dev)
     all_ins, c1 = all_gather_bytes(mine, dev, group)
-    torch.cuda.synchronize(dev)
+    _sync(dev)
     stats, d_pairs, n_pairs = ctx.pair_phase_b(all_ins.data_ptr() if all_ins.numel() else None, all_ins.numel() // 4, score_fraction, 3)
     moved = sum(c1)
     if pseudo_assembly and routed:
@@ -311,9 +334,9 @@ def sharded_tail(ctx, dev, paired=True, score_threshold=0, score_fraction=0.95, 
         moved += m2
     elif pseudo_assembly:
         recs = device_bytes(d_pairs, n_pairs * 32, dev)
-        torch.cuda.synchronize(dev)
+        _sync(dev)
         all_recs, c2 = all_gather_bytes(recs, dev, group)
-        torch.cuda.synchronize(dev)
+        _sync(dev)
         # raises KslamError(KSLAM_ERR_UNSUPPORTED) when the device stage declines (2^28 or more records in the batch):
         # a rank must not fall back to pseudo-assembling its OWN pairs, the stage is batch-global (src/PairedOverlap.h:480-582)
         stats = ctx.pseudo_merged(all_recs.data_ptr() if all_recs.numel() else None, all_recs.numel() // 32, sum(c2[:rank]) // 32,

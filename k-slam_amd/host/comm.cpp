@@ -558,8 +558,12 @@ kslam_status kslam_comm_sharded_tail(kslam_comm *c, int paired, uint32_t score_t
     agree(c, local, "kslam_pseudo_owned");
     all_to_all(c, (const char *)d_scores, scaled(recv_off, SB), scaled(recv_n, SB), back, scaled(send_off, SB), scaled(send_n, SB));
     moved += (n_own - send_n[me]) * SB;
+    // the last step is agreed like the others: a rank that cannot commit the scores must not leave its peers with a batch
+    // whose pseudo-assembly only they hold
+    local = Status();
     if (kslam_pseudo_return(c->ctx, n_own ? (const uint32_t *)back : nullptr, n_own, score_fraction, stats) != KSLAM_OK)
-      fail(KSLAM_ERR_STATE, kslam_last_error(c->ctx));
+      local.set(KSLAM_ERR_STATE, kslam_last_error(c->ctx));
+    agree(c, local, "kslam_pseudo_return");
     if (bytes_received) *bytes_received = moved;
   });
 }
@@ -568,6 +572,7 @@ kslam_status kslam_comm_info(const kslam_comm *c, kslam_comm_facts *out) {
   return guarded([&] {
     if (!c || !out) fail(KSLAM_ERR_ARG, "null argument");
     memset(out, 0, sizeof *out);
+    if (c->dead || !c->nccl) fail(KSLAM_ERR_STATE, "this communicator was aborted by an earlier failure");
     Rccl &R = rccl();
     int v = 0, n = 0, r = -1;
     ncchk(R.GetVersion(&v), "ncclGetVersion");

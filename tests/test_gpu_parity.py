@@ -658,7 +658,10 @@ def test_every_kernel_variant_gives_the_same_alignments(kslam, synth, monkeypatc
                 {"KSLAM_SW_UNKNOWN_ND": "16"},                       # gapped candidates start at the narrowest band
                 {"KSLAM_SW_UNKNOWN_ND": "64"},
                 {"KSLAM_SORT_DIGIT_BYTES": "0"},                     # radix histograms re-read the records
-                {"KSLAM_JOIN_GROUP_ORDER": "0"}]                     # overlap keys through all their radix passes (no group ranking)
+                {"KSLAM_JOIN_GROUP_ORDER": "0"},                     # overlap keys through all their radix passes (no group ranking)
+                {"KSLAM_JOIN": "merge"},                             # the merge join instead of the probe (join.hip: k_join_merge)
+                {"KSLAM_JOIN": "merge", "KSLAM_SORT_BYTES": "1"},    # ... with read records ordered by their top byte only
+                {"KSLAM_JOIN": "merge", "KSLAM_SORT_BYTES": "8"}]    # ... and by the whole key
     for env in variants:
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -805,6 +808,96 @@ def test_overlap_keys_ordered_by_groups_equal_the_full_sort(kslam, oracle, synth
     c2.close()
 
 
+def test_merge_join_equals_the_probe_and_the_oracle(kslam, oracle, synth, monkeypatch):
+    """join.hip k_join_merge (KSLAM_JOIN=merge): a workgroup streams the genome key range its tile of sorted read records
+    meets through LDS in pieces of 4096 keys and places every read key by binary search.  Cases: tiles that span several
+    pieces (2 Mb of genome against a few thousand reads), runs of equal genome keys of hundreds (tandem repeats: runs cut by
+    piece boundaries, the whole-block expansion), an entry met at nine loci, reads that are not from the database, a batch
+    of three reads, the filter switched off (every read k-mer joins: tiles of one piece); against the oracle and the probe."""
+    rng = np.random.default_rng(4242)
+    seg = synth.random_bases(rng, 400)
+    multi = np.concatenate([np.concatenate([synth.random_bases(rng, 900), synth.mutate(rng, seg, 0.01, 0.0)]) for _ in range(9)])
+    unit = synth.random_bases(rng, 5)
+    tandem = np.concatenate([synth.random_bases(rng, 300), np.resize(unit, 3000), synth.random_bases(rng, 300)])
+    big = [synth.random_bases(rng, 700000) for _ in range(3)]
+    genomes = big + [multi, tandem]
+    reads = []
+    for k in range(3000):
+        g = genomes[k % len(genomes)]
+        at = int(rng.integers(0, len(g) - 150))
+        r = synth.mutate(rng, g[at:at + 150], 0.02, 0.003)[:150]
+        reads.append(synth.revcomp(r) if k % 3 == 0 else r)
+    reads += [synth.random_bases(rng, 150) for _ in range(200)]                        # not from the database
+    rb, gb = synth.to_bytes(reads), synth.to_bytes(genomes)
+    exp, ecig, _ = oracle.align_to_database(rb, gb)
+    few = rb[:3]
+    fexp, fecig, _ = oracle.align_to_database(few, gb)
+    probe = kslam.Context()
+    probe.set_index(gb)
+    base, bcig = probe.align_batch(rb)
+    _compare_alignments(base, bcig, exp, ecig)
+    for env in ({}, {"KSLAM_FILTER_BITS": "0"}, {"KSLAM_SORT_BYTES": "8"}, {"KSLAM_BUCKET_BITS_EXACT": "12"}):
+        monkeypatch.setenv("KSLAM_JOIN", "merge")
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        c = kslam.Context()
+        c.set_index(gb)
+        got, gcig = c.align_batch(rb)
+        _compare_alignments(got, gcig, exp, ecig)
+        got, gcig = c.align_batch(few)
+        _compare_alignments(got, gcig, fexp, fecig)
+        assert c.timings()["n_overlaps_raw"] == probe_raw(probe, few)
+        c.close()
+        monkeypatch.delenv("KSLAM_JOIN")
+        for k in env:
+            monkeypatch.delenv(k)
+    probe.close()
+
+
+def probe_raw(ctx, reads):
+    ctx.align_batch(reads)
+    return ctx.timings()["n_overlaps_raw"]
+
+
+def test_filter_built_block_by_block_equals_the_atomic_build(kslam, oracle, synth, monkeypatch):
+    """filter.hip since round 6: the membership filter is assembled 32 KB block by block in LDS from the keys' probe words
+    ordered by block, instead of four scattered atomics per key.  Same bits: the same read k-mers survive (count) and the
+    same alignments come out, for a filter of several blocks, for KSLAM_FILTER_BITS at its smallest, for an index with
+    repeated keys and k-mer 0 (poly-A), and for an index without a single k-mer."""
+    rng = np.random.default_rng(99)
+    genomes = [synth.random_bases(rng, 300000) for _ in range(3)] + [np.frombuffer(b"A" * 500, dtype=np.uint8).copy()]
+    genomes.append(np.concatenate([genomes[0][1000:3000], genomes[1][500:900]]))             # repeated keys
+    reads = []
+    for k in range(2500):
+        g = genomes[k % 3]
+        at = int(rng.integers(0, len(g) - 150))
+        reads.append(synth.mutate(rng, g[at:at + 150], 0.02, 0.003)[:150])
+    reads += [synth.random_bases(rng, 150) for _ in range(500)] + [np.frombuffer(b"A" * 150, dtype=np.uint8).copy()]
+    rb, gb = synth.to_bytes(reads), synth.to_bytes(genomes)
+    exp, ecig, _ = oracle.align_to_database(rb, gb)
+    for bits in (None, "20", "26"):
+        kept = {}
+        for how in ("blocks", "atomics"):
+            if how == "atomics":
+                monkeypatch.setenv("KSLAM_FILTER_BUILD", "atomics")
+            if bits:
+                monkeypatch.setenv("KSLAM_FILTER_BITS", bits)
+            c = kslam.Context()
+            c.set_index(gb)
+            got, gcig = c.align_batch(rb)
+            _compare_alignments(got, gcig, exp, ecig)
+            kept[how] = c.timings()["n_kmers_kept"]
+            c.close()
+            monkeypatch.delenv("KSLAM_FILTER_BUILD", raising=False)
+            monkeypatch.delenv("KSLAM_FILTER_BITS", raising=False)
+        assert kept["blocks"] == kept["atomics"] and 0 < kept["blocks"] < 0.5 * len(rb) * 119, (bits, kept)
+    c = kslam.Context()
+    c.set_index([b"ACGT" * 5, b""])                   # no entry reaches 32 bases: no k-mer, an empty filter
+    got, gcig = c.align_batch(rb[:50])
+    assert len(got) == 0 and len(gcig) == 0
+    c.close()
+
+
 @pytest.mark.parametrize("copies", [[3, 9, 12, 13], [12, 13, 16, 17]])
 def test_group_route_at_its_cap(kslam, oracle, synth, copies):
     """Groups of EXACTLY known size around join.hip's cap of 64 keys.  An entry is G copies of a random 48-base unit (copy
@@ -844,14 +937,15 @@ def test_group_route_at_its_cap(kslam, oracle, synth, copies):
     _compare_alignments(again, acig, exp, ecig)
 
 
-@pytest.mark.parametrize("n_entries,passes", [(9, 10), (300, 11)])
+@pytest.mark.parametrize("n_entries,passes", [(1, 9), (9, 9), (128, 9), (129, 10), (300, 10), (40000, 11)])
 def test_index_build_stats_and_the_passes_of_the_one_time_sort(kslam, synth, n_entries, passes):
     """kslam_index_build_stats (roofline.index_sort of the bench line): the one-time sort of the genome k-mer records makes 8
-    passes over the k-mer and one per byte of the meta word that can differ in a list of genome records -- the ids' low byte,
-    their second byte from 257 entries on, the byte that holds revComp (src/KMer.h:65-67, :388-398) -- and the index it
-    leaves behind aligns like before (the rows of a batch against the oracle's)."""
+    passes over the k-mer and, over the meta word, what can differ in a list of genome records (src/KMer.h:65-67, :388-398):
+    a pass per whole byte of the ids while more than 7 id bits remain, then ONE pass over the remaining id bits with the
+    revComp bit on top (round 6; a pass per byte until then) -- 9 passes up to 128 entries, 10 up to 32 768, 11 beyond -- and
+    the index it leaves behind aligns like before (the rows of a batch against the oracle's)."""
     rng = np.random.default_rng(n_entries)
-    genomes = [synth.random_bases(rng, int(rng.integers(400, 900))) for _ in range(n_entries)]
+    genomes = [synth.random_bases(rng, int(rng.integers(400, 900)) if n_entries < 1000 else int(rng.integers(150, 300))) for _ in range(n_entries)]
     reads = []
     for k in range(200):
         g = genomes[int(rng.integers(0, n_entries))]

@@ -89,7 +89,9 @@ struct CigJob {
   int32_t *bmax;
   uint8_t *needbig;
   const uint32_t *list;
-  uint32_t m;           // list entries in this launch
+  uint32_t m;           // list entries in this launch (with m_dev: the launch's CAPACITY)
+  const uint32_t *m_dev = nullptr;   // the list's length on the device, read when the kernel runs: this launch covers entries
+                                     // [list_base, min(list_base + m, *m_dev)) -- a bin's list is still growing when the host sizes its launch
   uint32_t list_base;   // first list entry of this launch
   uint32_t slot_bw;     // band width the scratch slab is sized for
   uint32_t lmax;        // max read length (row count bound)
@@ -113,6 +115,13 @@ struct CigJob {
   // group's lane 0 walks the traceback itself, at the end of the DP kernel)
   uint8_t *tb_flag = nullptr;   // [m], zeroed: 1 = this list position's attempt reached the score
 };
+
+// list entries this launch really has (CigJob::m_dev)
+__device__ inline uint32_t live_entries(const CigJob &J) {
+  if (!J.m_dev) return J.m;
+  const uint32_t tot = *J.m_dev;
+  return min(J.m, tot > J.list_base ? tot - J.list_base : 0u);
+}
 
 // wave-aggregated append of candidate ci to a list (one atomic per wave)
 __device__ inline void append_candidate(bool want, uint32_t ci, uint32_t *list, uint32_t *count) {
@@ -320,7 +329,7 @@ __global__ __launch_bounds__(64) void k_banded_lds(CigJob J, SwInputs in, SwPara
   const uint32_t lane = threadIdx.x;
   const uint32_t NL = Y.nl;
   const uint32_t li = blockIdx.x * NL + lane;
-  const bool have = lane < NL && li < J.m;
+  const bool have = lane < NL && li < live_entries(J);
   const uint32_t half = Y.nch * NL * 8u;   // bytes per packed sequence buffer
   uint8_t *SQ = lds_raw;
   uint8_t *SR = SQ + half;
@@ -545,7 +554,7 @@ __global__ __launch_bounds__(BS) void k_cigar_systolic(CigJob J, SwInputs in, Sw
   const int32_t t = lane & (GL - 1);
   const int32_t grp = threadIdx.x / GL;
   const uint32_t li = blockIdx.x * NG + grp;
-  bool have = li < J.m, special = false;
+  bool have = li < live_entries(J), special = false;
   uint32_t ci = 0;
   kslam_overlap o;
   memset(&o, 0, sizeof o);
@@ -713,7 +722,7 @@ __global__ __launch_bounds__(BS) void k_cigar_systolic(CigJob J, SwInputs in, Sw
 template <int GL, int DPL>
 __global__ __launch_bounds__(256) void k_systolic_traceback(CigJob J) {
   const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
-  if (x >= J.m || !J.tb_flag[x]) return;
+  if (x >= live_entries(J) || !J.tb_flag[x]) return;
   const uint32_t li = x;
   const uint32_t ci = J.list[J.list_base + li];
   kslam_overlap o = J.ov[ci];
@@ -889,6 +898,8 @@ void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, u
       const uint32_t *list = nullptr;
       uint32_t *const *bin_list = nullptr;   // [8]: where a candidate goes whose band doubled (nullptr: the host re-lists by flags)
       uint32_t *bin_count = nullptr, *special_list = nullptr, *special_count = nullptr, *big_count = nullptr;
+      const uint32_t *count_dev = nullptr;   // the list's length where the kernels read it (CigJob::m_dev); then `m` is a capacity
+      uint32_t first = 0;                    // the launch starts at this entry of the list
     };
     auto launch_systolic = [&](uint64_t m, uint32_t slot_bw, uint32_t bin, const Route &R) -> bool {
       const uint32_t need = 2 * slot_bw + 1;
@@ -913,7 +924,8 @@ void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, u
         if (R.bin_list) for (int k = 0; k < 8; k++) J.bin_list[k] = R.bin_list[k];
         J.bin_count = R.bin_list ? R.bin_count : nullptr;
         J.special_list = R.special_list; J.special_count = R.special_count; J.big_count = R.big_count;
-        J.list_base = (uint32_t)g0;
+        J.list_base = R.first + (uint32_t)g0;
+        J.m_dev = R.count_dev;
         J.m = (uint32_t)std::min<uint64_t>(groups_per_launch, m - g0);
         J.slot_bw = slot_bw; J.lmax = lmax;
         J.cap = CIG_CAP;
@@ -996,7 +1008,8 @@ void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, u
         J.bin_count = R.bin_list ? R.bin_count : nullptr;
         J.big_count = R.big_count;
         const uint64_t nb_here = std::min<uint64_t>(blocks_per_launch, n_blocks - b0);
-        J.list_base = (uint32_t)(b0 * nl);
+        J.list_base = R.first + (uint32_t)(b0 * nl);
+        J.m_dev = R.count_dev;
         J.m = (uint32_t)std::min<uint64_t>(nb_here * nl, m - b0 * nl);
         J.slot_bw = slot_bw; J.lmax = lmax;
         J.cap = big ? cap_big : CIG_CAP;
@@ -1029,38 +1042,79 @@ void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, u
     uint32_t *lists[8];
     for (int k = 0; k < 8; k++) lists[k] = W.cls_list[k].as<uint32_t>();
     partition_bins(W.cls.as<uint8_t>(), n, lists, cnt, W.pos, s);
+    // ONE sweep over the bins without a read-back in front of each (round 6; the GPU used to idle 25-60 us at each of ~11 of
+    // them per chunk).  A bin's list grows while the earlier bins run (a failed attempt appends the candidate whose band
+    // doubled), so the host cannot know its length when it queues the bin's launch -- but the kernels can: a launch is
+    // sized for a CAPACITY, what the partition put into the bin plus room for an eighth of everything in the bins before
+    // it (all of it while that is little), and its workgroups read the list's real length when they run (CigJob::m_dev; failures are rare, the spare
+    // workgroups leave at once).  Then one read-back.  What did not fit a capacity, what the systolic launches handed to
+    // the one-lane kernel (spans the band covers completely; laid out for the widest band among the bins that handed over)
+    // and whatever THOSE append is left to rounds: each launches the part of every list nobody has run yet, then reads
+    // the counters again, until nothing is new.
     uint32_t hc[10];
-    for (uint32_t bin = 0; bin < 7; bin++) {
-      read_back(hc, cnt, sizeof hc, s);
-      if (debug && bin == 0)
-        fprintf(stderr, "[kslam] cigar bins as the SW stage asked for them: %u %u %u %u %u %u %u %u\n", hc[0], hc[1], hc[2], hc[3], hc[4], hc[5], hc[6], hc[7]);
-      const uint64_t m = hc[bin];
-      if (m == 0) continue;
-      const uint32_t slot_bw = CIG_BIN_MAX_BW[bin];
-      if (debug) fprintf(stderr, "[kslam] cigar bin %u (band <= %u): %llu candidates\n", bin, slot_bw, (unsigned long long)m);
-      Route R;
-      R.list = lists[bin];
-      R.bin_list = lists;
-      R.bin_count = cnt;
-      R.special_list = W.special.as<uint32_t>();
-      R.special_count = cnt + 8;
-      R.big_count = cnt + 9;
-      if (launch_systolic(m, slot_bw, bin, R)) {
-        read_back(hc, cnt, sizeof hc, s);
-        if (hc[8]) {   // the few it hands back (spans the band covers completely)
-          if (debug) fprintf(stderr, "[kslam]   handed to the one-lane kernel: %u\n", hc[8]);
-          Route R2 = R;
-          R2.list = W.special.as<uint32_t>();
-          R2.special_list = nullptr;
-          launch(hc[8], slot_bw, false, R2);
-          HIPCHK(hipMemsetAsync(cnt + 8, 0, sizeof(uint32_t), s));
-        }
-      } else {
-        launch(m, slot_bw, false, R);
+    uint32_t done[7] = {0, 0, 0, 0, 0, 0, 0};
+    read_back(hc, cnt, sizeof hc, s);
+    if (debug) fprintf(stderr, "[kslam] cigar bins as the SW stage asked for them: %u %u %u %u %u %u %u %u\n", hc[0], hc[1], hc[2], hc[3], hc[4], hc[5], hc[6], hc[7]);
+    uint32_t special_bw = 0;
+    {
+      uint64_t before = 0;
+      for (uint32_t bin = 0; bin < 7; bin++) {
+        const uint64_t room = before <= 65536 ? before : std::max<uint64_t>(65536, before / 8);   // (spare workgroups cost ~1 ns each)
+        const uint64_t cap = hc[bin] + room;
+        before += hc[bin];
+        if (cap == 0) continue;
+        const uint32_t slot_bw = CIG_BIN_MAX_BW[bin];
+        Route R;
+        R.list = lists[bin];
+        R.bin_list = lists;
+        R.bin_count = cnt;
+        R.special_list = W.special.as<uint32_t>();
+        R.special_count = cnt + 8;
+        R.big_count = cnt + 9;
+        R.count_dev = cnt + bin;
+        if (launch_systolic(cap, slot_bw, bin, R)) special_bw = std::max(special_bw, slot_bw);
+        else launch(cap, slot_bw, false, R);
+        done[bin] = (uint32_t)cap;       // (clamped to the list's length below)
       }
     }
+    for (int round = 0;; round++) {
+      read_back(hc, cnt, sizeof hc, s);
+      for (uint32_t bin = 0; bin < 7; bin++) done[bin] = std::min(done[bin], hc[bin]);
+      bool progressed = false;
+      if (hc[8]) {   // the few the systolic launches handed back
+        if (debug) fprintf(stderr, "[kslam]   handed to the one-lane kernel: %u\n", hc[8]);
+        Route R2;
+        R2.list = W.special.as<uint32_t>();
+        R2.bin_list = lists;
+        R2.bin_count = cnt;
+        R2.big_count = cnt + 9;
+        launch(hc[8], special_bw, false, R2);
+        HIPCHK(hipMemsetAsync(cnt + 8, 0, sizeof(uint32_t), s));
+        special_bw = 0;
+        progressed = true;
+      }
+      for (uint32_t bin = 0; bin < 7; bin++) {
+        if (hc[bin] <= done[bin]) continue;
+        const uint64_t m = hc[bin] - done[bin];
+        const uint32_t slot_bw = CIG_BIN_MAX_BW[bin];
+        if (debug) fprintf(stderr, "[kslam] cigar round %d bin %u (band <= %u): %llu candidates left over\n", round, bin, slot_bw, (unsigned long long)m);
+        Route R;
+        R.list = lists[bin];
+        R.first = done[bin];
+        R.bin_list = lists;
+        R.bin_count = cnt;
+        R.special_list = W.special.as<uint32_t>();
+        R.special_count = cnt + 8;
+        R.big_count = cnt + 9;
+        if (launch_systolic(m, slot_bw, bin, R)) special_bw = std::max(special_bw, slot_bw);
+        else launch(m, slot_bw, false, R);
+        done[bin] = hc[bin];
+        progressed = true;
+      }
+      if (!progressed) break;
+    }
     // 64 and wider (never seen on real reads): the flag / scan / scatter loop, class c = floor(log2 bw) after class
-    read_back(hc, cnt, sizeof hc, s);
+    // (hc is current: the loop above ends on a round that found nothing new after its last read-back)
     if (hc[7]) {
       HIPCHK(hipMemsetAsync(cnt + 11, 0, sizeof(uint32_t), s));
       hipLaunchKernelGGL(k_class_mask, dim3(nb), dim3(256), 0, s, d_bw, W.needbig.as<uint8_t>(), n, cnt + 11);

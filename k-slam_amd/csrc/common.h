@@ -57,6 +57,7 @@ struct Tuning {
   bool details_in_token = true;       // KSLAM_DETAILS_IN_TOKEN=0 (A/B): the per-row walk outside the lanes' compute token
   int plan_blocks_per_cu = 64;        // KSLAM_PLAN_BLOCKS: workgroups of k_sw_plan per CU (its waves walk through the candidates)
   int join_group_order = 1;           // KSLAM_JOIN_GROUP_ORDER=0: the overlap keys go through all their radix passes (join.hip: group_order)
+  bool sw_sweep = true;               // KSLAM_SW_SWEEP=0: a read-back in front of every SW tier (as until round 5)
   int join_merge = 0;                 // KSLAM_JOIN=merge: k_join_merge instead of the probe k_join_fill (join.hip)
   bool filter_build_sorted = true;    // KSLAM_FILTER_BUILD=atomics: the membership filter by scattered atomics instead of block by block (filter.hip)
   int pseudo_cap = 0;                 // KSLAM_PSEUDO_CAP (tests): alignment pairs of one entry beyond which pseudo-assembly is left to the host; 0 = 262144
@@ -433,6 +434,10 @@ void encode_bases(const uint8_t *d_src, uint8_t *d_dst, uint64_t n, hipStream_t 
 // (0 = no cigar wanted, ssw.c:924-927)
 struct SwWork {
   DevBuf flags, pos, list, list2, scan_tmp, totals, tier_list[6];
+  // what the last chunk's tiers received from the tiers before them (sw.hip: the one sweep over the tiers is sized from it)
+  uint64_t last_n = 0;
+  uint32_t last_inflow[6] = {0, 0, 0, 0, 0, 0};
+  int last_tiers = 0, last_lm = -1;
 };
 // *n_full_out: candidates that needed the full-matrix kernel (the rest ran in a proven band)
 void sw_scores(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, uint32_t max_read_len,

@@ -196,6 +196,7 @@ Tuning read_tuning() {
   t.pseudo_cap = std::max(0, num("KSLAM_PSEUDO_CAP", 0));
   t.join_group_order = starts("KSLAM_JOIN_GROUP_ORDER", '0') ? 0 : 1;
   t.join_merge = starts("KSLAM_JOIN", 'm') ? 1 : 0;
+  t.sw_sweep = !starts("KSLAM_SW_SWEEP", '0');
   t.filter_build_sorted = !starts("KSLAM_FILTER_BUILD", 'a');      // =atomics: the scattered read-modify-write build (A/B)
   t.details_in_token = !starts("KSLAM_DETAILS_IN_TOKEN", '0');
 #ifdef KSLAM_ABLATE

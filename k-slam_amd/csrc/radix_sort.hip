@@ -96,18 +96,21 @@ __global__ __launch_bounds__(256) void k_tile_hist_bytes(const uint8_t *__restri
                                                          uint32_t *__restrict__ tile_hist) {
   tile_hist_bytes_body(dig, n, tile_hist);
 }
-// The one-time sorts' byte histogram (312 M digit bytes per pass for the 5 Gb database).  Two things the per-batch kernel
-// above does not need: (1) SKEW: the passes over the meta word see digits that take a handful of values (the high id
-// bits of 1 250 entries, the revComp bit), and 64 lanes adding to two LDS addresses serialise -- those passes' histograms
-// took 1.09 ms against 0.10 for a k-mer byte.  So every tile keeps HC copies of its histogram and lane l adds to copy
-// l mod HC (16 copies: four lanes per address at worst); they are summed when the tile's counts are written.  (2) HT
-// tiles per workgroup, all their 16-byte loads in flight before the first LDS atomic.
-constexpr uint32_t HT = 2, HC = 16;
+// The one-time sorts' byte histogram (312 M digit bytes per pass for the 5 Gb database), in two shapes the host picks per
+// pass.  Digits of the K-MER bytes are spread over the 256 values: HT = 4 tiles per workgroup, their 16-byte loads all in
+// flight before the first LDS atomic, one histogram per tile (0.10 ms per pass).  Digits of the META word take a handful of
+// values (the high id bits of 1 250 entries, the revComp bit): 64 lanes adding to two or ten LDS addresses serialise -- such a
+// pass's histogram took 1.09 ms in round 5.  For those: one tile per workgroup and a private copy of the histogram per LANE
+// position (HC = 64 copies, 64 KB of LDS: no two lanes of a wave ever meet on an address), summed when the counts are written.
+template <uint32_t HT, uint32_t HC>
 __global__ __launch_bounds__(256) void k_tile_hist_bytes_setup(const uint8_t *__restrict__ dig, uint32_t n, uint32_t n_tiles,
                                                                uint32_t *__restrict__ tile_hist) {
   __shared__ uint32_t h[HT][HC][256];
   const uint32_t tid = threadIdx.x;
-  for (uint32_t x = tid; x < HT * HC * 256; x += 256) (&h[0][0][0])[x] = 0;
+  {
+    uint4 *z = reinterpret_cast<uint4 *>(&h[0][0][0]);
+    for (uint32_t x = tid; x < HT * HC * 64; x += 256) z[x] = make_uint4(0, 0, 0, 0);
+  }
   __syncthreads();
   const uint32_t tile0 = blockIdx.x * HT, copy = tid & (HC - 1u);
   uint4 v[HT];
@@ -135,8 +138,8 @@ __global__ __launch_bounds__(256) void k_tile_hist_bytes_setup(const uint8_t *__
   for (uint32_t t = 0; t < HT; t++)
     if (tile0 + t < n_tiles) {
       uint32_t sum = 0;
-#pragma unroll
-      for (uint32_t c = 0; c < HC; c++) sum += h[t][(c + tid) & (HC - 1u)][tid];   // (rotated: the 64 lanes of a wave spread over the copies' banks)
+#pragma unroll 16
+      for (uint32_t c = 0; c < HC; c++) sum += h[t][c][tid];
       tile_hist[(uint64_t)(tile0 + t) * 256 + tid] = sum;
     }
 }
@@ -369,7 +372,11 @@ void sort_impl(void *a, void *b, uint32_t n, const PassList &pl, SortWorkspace &
   uint8_t *digits = (pl.n > 1 && ws.use_digit_bytes) ? ws.digits.as<uint8_t>() : nullptr;
   if (ev0) HIPCHK(hipEventRecord(ev0, s));
   for (int p = 0; p < pl.n; p++) {
-    if (SETUP && digits && (p > 0 || ws.first_digits_ready)) hipLaunchKernelGGL(k_tile_hist_bytes_setup, dim3((tiles + HT - 1) / HT), dim3(256), 0, s, (const uint8_t *)digits, n, tiles, tile_hist);
+    if (SETUP && digits && (p > 0 || ws.first_digits_ready)) {
+      // a digit of few values (a pass over the meta word of k-mer records): the conflict-free shape
+      if (RW == 4 && pl.p[p].word == 2) hipLaunchKernelGGL((k_tile_hist_bytes_setup<1, 64>), dim3(tiles), dim3(256), 0, s, (const uint8_t *)digits, n, tiles, tile_hist);
+      else hipLaunchKernelGGL((k_tile_hist_bytes_setup<4, 1>), dim3((tiles + 3) / 4), dim3(256), 0, s, (const uint8_t *)digits, n, tiles, tile_hist);
+    }
     else if (SETUP) hipLaunchKernelGGL(k_tile_hist_setup<RW>, dim3(tiles), dim3(RS_BLOCK), 0, s, (const T *)src, n, pl.p[p], tile_hist);
     else if (digits && (p > 0 || ws.first_digits_ready)) hipLaunchKernelGGL(k_tile_hist_bytes, dim3(tiles), dim3(256), 0, s, (const uint8_t *)digits, n, tile_hist);
     else hipLaunchKernelGGL(k_tile_hist<RW>, dim3(tiles), dim3(RS_BLOCK), 0, s, (const T *)src, n, pl.p[p], tile_hist);

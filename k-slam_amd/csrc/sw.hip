@@ -772,9 +772,18 @@ __global__ __launch_bounds__(256) void k_tier_scatter(const uint8_t *__restrict_
 // GL = lanes per candidate: 8 (32 diagonals, 8 candidates per wave) or 16 (64 diagonals, 4 per wave).
 // `list` (optional) maps work items to candidates; todo[] is indexed by work item.
 template <int LMAX, int GL, int DPL, int BS = 256>
-__global__ __launch_bounds__(BS) void k_sw_band(kslam_overlap *__restrict__ ov, uint64_t n, SwInputs in, SwParams p,
+__global__ __launch_bounds__(BS) void k_sw_band(kslam_overlap *__restrict__ ov, uint64_t n_cap, SwInputs in, SwParams p,
                                                  uint32_t *__restrict__ band0, const uint32_t *__restrict__ list,
-                                                 Tiers T, int self) {
+                                                 Tiers T, int self, const uint32_t *__restrict__ n_dev, uint32_t first) {
+  // n_dev: the list's length on the device, read now (the list was still growing when the host sized this launch for n_cap
+  // entries from `first` on); a workgroup beyond it leaves at once
+  uint64_t n = n_cap;
+  if (n_dev) {
+    const uint32_t tot = *n_dev;
+    n = min(n_cap, (uint64_t)(tot > first ? tot - first : 0u));
+  }
+  if ((uint64_t)blockIdx.x * (BS / GL) >= n) return;   // (block-uniform)
+  list += first;
   constexpr int NG = BS / GL;           // candidates per block
   constexpr int ND = DPL * GL;          // diagonals swept (DPL adjacent diagonals per lane)
   // The sweep also computes cells that lie outside the matrix near its corners (no per-cell range
@@ -1431,17 +1440,18 @@ void sw_scores(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, uint32_
       read_back(h, counts, sizeof h, s);
       fprintf(stderr, "[kslam] SW planned: %u / %u / %u / %u / %u / %u\n", h[0], h[1], h[2], h[3], h[4], h[5]);
     }
-    for (int k = 0; k < T.n; k++) {
-      // the size of tier k: planned + sent on by the tiers before it (both in counts[k] by now)
-      read_back(h, counts, sizeof h, s);
-      const uint64_t m = h[k];
+    // One sweep over the tiers without a read-back in front of each (round 6; ~25 us of idle GPU at each of them).  Tier k's
+    // list = what k_sw_plan put there + what the tiers before it send on -- unknown to the host when it queues tier k, known
+    // to the kernel when it runs (n_dev).  The launch is sized for planned + 1.2 x the inflow the LAST chunk of this context
+    // saw at that tier (scaled by the chunks' sizes) + 4096: chunks of one run are statistically alike.  What did not fit,
+    // and what that sends on, is left to rounds after the one read-back: each launches the part of every list nobody has
+    // run yet.  A context's first chunk (no history) and a changed tier set go tier by tier as before.
+    auto launch_tier = [&](int k, uint64_t m, const uint32_t *n_dev, uint32_t first) {
       const int nd = T.nd[k];
-      if (debug) fprintf(stderr, "[kslam] SW tier %d (%d diagonals): %llu candidates\n", k, nd, (unsigned long long)m);
-      if (!m) continue;
       const uint32_t *list = T.list[k];
 #define KSLAM_BAND(LM, GLV, DPLV, BSV) \
   hipLaunchKernelGGL((k_sw_band<LM, GLV, DPLV, BSV>), dim3((unsigned)((m + (BSV / GLV) - 1) / (BSV / GLV))), dim3(BSV), 0, s, \
-                     d_ov, m, in, p, d_band0, list, T, k)
+                     d_ov, m, in, p, d_band0, list, T, k, n_dev, first)
 #define KSLAM_BAND_LM(GLV, DPLV, BSV) \
   do { if (lm == 0) KSLAM_BAND(160, GLV, DPLV, BSV); else if (lm == 1) KSLAM_BAND(256, GLV, DPLV, BSV); \
        else KSLAM_BAND(512, GLV, DPLV, BSV); } while (0)
@@ -1455,8 +1465,43 @@ void sw_scores(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, uint32_
       else KSLAM_BAND_LM(16, 8, 256);
 #undef KSLAM_BAND_LM
 #undef KSLAM_BAND
-    }
+    };
+    uint32_t planned[NT_MAX] = {0, 0, 0, 0, 0, 0}, done[NT_MAX] = {0, 0, 0, 0, 0, 0};
     read_back(h, counts, sizeof h, s);
+    for (int k = 0; k < T.n; k++) planned[k] = h[k];
+    const bool history = W.last_n && W.last_tiers == T.n && W.last_lm == lm && tune.sw_sweep;
+    if (history) {
+      const double scale = (double)n / (double)W.last_n;
+      for (int k = 0; k < T.n; k++) {
+        const uint64_t room = k ? (uint64_t)(1.2 * scale * W.last_inflow[k]) + 4096 : 0;
+        const uint64_t cap = std::min<uint64_t>(n, planned[k] + room);
+        if (debug) fprintf(stderr, "[kslam] SW tier %d (%d diagonals): %u planned, sized for %llu\n", k, T.nd[k], planned[k], (unsigned long long)cap);
+        if (cap) launch_tier(k, cap, counts + k, 0);
+        done[k] = (uint32_t)cap;
+      }
+    }
+    for (int round = 0;; round++) {
+      if (round || history) read_back(h, counts, sizeof h, s);
+      bool progressed = false;
+      for (int k = 0; k < T.n; k++) {
+        done[k] = std::min(done[k], h[k]);
+        if (h[k] <= done[k]) continue;
+        const uint64_t m = h[k] - done[k];
+        if (debug) fprintf(stderr, "[kslam] SW round %d tier %d (%d diagonals): %llu candidates%s\n", round, k, T.nd[k], (unsigned long long)m, history ? " left over" : "");
+        launch_tier(k, m, nullptr, done[k]);
+        done[k] = h[k];
+        progressed = true;
+        if (!history) {    // tier by tier: the next tier's size is known once this one has run
+          read_back(h, counts, sizeof h, s);
+        }
+      }
+      if (!progressed) break;
+    }
+    W.last_n = n;
+    W.last_tiers = T.n;
+    W.last_lm = lm;
+    for (int k = 0; k < T.n; k++) W.last_inflow[k] = h[k] - planned[k];
+    read_back(h, counts, sizeof h, s);      // (the full-matrix list's length: the last round's launches may have added to it)
     n_full = h[NT_FULL];
     full_list = W.list.as<uint32_t>();
     if (debug) fprintf(stderr, "[kslam] SW full matrix: %llu candidates\n", (unsigned long long)n_full);

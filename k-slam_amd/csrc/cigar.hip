@@ -92,6 +92,7 @@ struct CigJob {
   uint32_t m;           // list entries in this launch (with m_dev: the launch's CAPACITY)
   const uint32_t *m_dev = nullptr;   // the list's length on the device, read when the kernel runs: this launch covers entries
                                      // [list_base, min(list_base + m, *m_dev)) -- a bin's list is still growing when the host sizes its launch
+  uint32_t m_sure = 0;               // entries of this launch the host KNEW to exist: a workgroup inside them does not wait for *m_dev
   uint32_t list_base;   // first list entry of this launch
   uint32_t slot_bw;     // band width the scratch slab is sized for
   uint32_t lmax;        // max read length (row count bound)
@@ -117,8 +118,9 @@ struct CigJob {
 };
 
 // list entries this launch really has (CigJob::m_dev)
-__device__ inline uint32_t live_entries(const CigJob &J) {
-  if (!J.m_dev) return J.m;
+// (hi: one past the last entry the calling workgroup looks at)
+__device__ inline uint32_t live_entries(const CigJob &J, uint32_t hi) {
+  if (!J.m_dev || hi <= J.m_sure) return J.m;
   const uint32_t tot = *J.m_dev;
   return min(J.m, tot > J.list_base ? tot - J.list_base : 0u);
 }
@@ -329,7 +331,7 @@ __global__ __launch_bounds__(64) void k_banded_lds(CigJob J, SwInputs in, SwPara
   const uint32_t lane = threadIdx.x;
   const uint32_t NL = Y.nl;
   const uint32_t li = blockIdx.x * NL + lane;
-  const bool have = lane < NL && li < live_entries(J);
+  const bool have = lane < NL && li < live_entries(J, (blockIdx.x + 1) * NL);
   const uint32_t half = Y.nch * NL * 8u;   // bytes per packed sequence buffer
   uint8_t *SQ = lds_raw;
   uint8_t *SR = SQ + half;
@@ -554,7 +556,7 @@ __global__ __launch_bounds__(BS) void k_cigar_systolic(CigJob J, SwInputs in, Sw
   const int32_t t = lane & (GL - 1);
   const int32_t grp = threadIdx.x / GL;
   const uint32_t li = blockIdx.x * NG + grp;
-  bool have = li < live_entries(J), special = false;
+  bool have = li < live_entries(J, (blockIdx.x + 1) * NG), special = false;
   uint32_t ci = 0;
   kslam_overlap o;
   memset(&o, 0, sizeof o);
@@ -722,7 +724,7 @@ __global__ __launch_bounds__(BS) void k_cigar_systolic(CigJob J, SwInputs in, Sw
 template <int GL, int DPL>
 __global__ __launch_bounds__(256) void k_systolic_traceback(CigJob J) {
   const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
-  if (x >= live_entries(J) || !J.tb_flag[x]) return;
+  if (x >= live_entries(J, (blockIdx.x + 1) * blockDim.x) || !J.tb_flag[x]) return;
   const uint32_t li = x;
   const uint32_t ci = J.list[J.list_base + li];
   kslam_overlap o = J.ov[ci];
@@ -899,6 +901,7 @@ void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, u
       uint32_t *const *bin_list = nullptr;   // [8]: where a candidate goes whose band doubled (nullptr: the host re-lists by flags)
       uint32_t *bin_count = nullptr, *special_list = nullptr, *special_count = nullptr, *big_count = nullptr;
       const uint32_t *count_dev = nullptr;   // the list's length where the kernels read it (CigJob::m_dev); then `m` is a capacity
+      uint32_t sure = 0;                     // ... and this many entries of the list are known to exist
       uint32_t first = 0;                    // the launch starts at this entry of the list
     };
     auto launch_systolic = [&](uint64_t m, uint32_t slot_bw, uint32_t bin, const Route &R) -> bool {
@@ -926,6 +929,7 @@ void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, u
         J.special_list = R.special_list; J.special_count = R.special_count; J.big_count = R.big_count;
         J.list_base = R.first + (uint32_t)g0;
         J.m_dev = R.count_dev;
+        J.m_sure = R.sure > J.list_base ? R.sure - J.list_base : 0;
         J.m = (uint32_t)std::min<uint64_t>(groups_per_launch, m - g0);
         J.slot_bw = slot_bw; J.lmax = lmax;
         J.cap = CIG_CAP;
@@ -1010,6 +1014,7 @@ void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, u
         const uint64_t nb_here = std::min<uint64_t>(blocks_per_launch, n_blocks - b0);
         J.list_base = R.first + (uint32_t)(b0 * nl);
         J.m_dev = R.count_dev;
+        J.m_sure = R.sure > J.list_base ? R.sure - J.list_base : 0;
         J.m = (uint32_t)std::min<uint64_t>(nb_here * nl, m - b0 * nl);
         J.slot_bw = slot_bw; J.lmax = lmax;
         J.cap = big ? cap_big : CIG_CAP;
@@ -1072,6 +1077,7 @@ void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, u
         R.special_count = cnt + 8;
         R.big_count = cnt + 9;
         R.count_dev = cnt + bin;
+        R.sure = hc[bin];
         if (launch_systolic(cap, slot_bw, bin, R)) special_bw = std::max(special_bw, slot_bw);
         else launch(cap, slot_bw, false, R);
         done[bin] = (uint32_t)cap;       // (clamped to the list's length below)

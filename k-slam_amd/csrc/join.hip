@@ -17,15 +17,29 @@
 // MI355X design: the reference re-sorts reads + genomes together every batch;
 // here the genome list is sorted once and stays in HBM (a key column and a
 // {meta, offset} column) with a 2^b-entry bucket table over the top key bits.
-// The read side is NOT merged against it: after the membership filter only one
-// read k-mer in ten is left (25 M against 312 M genome keys per batch), so each
-// sorted survivor PROBES -- two table reads, the bucket's handful of keys in one
-// round trip, one 8-byte gather per hit -- in a region its neighbours in the
-// wavefront are touching too.  A merge would stream the whole 2.5 GB key column
-// per batch to use a tenth of it; the probe touches ~1.5 GB of cache lines (the
-// kernel is bound by lines touched: VALU 0.07 of peak).  Output is a packed u64
-// per overlap (read | entry | rel + bias | revcomp) so that the overlap sort is
-// a keys-only radix sort over just the populated bytes.
+// After the membership filter one read k-mer in ten is left (25.3 M against
+// 312 M genome keys per configs[1] batch).  Two ways to meet the two lists, both
+// built, both measured on that batch (profiles/r06_join_merge.json):
+//   * THE PROBE (k_join_fill, the default): every sorted survivor reads its two
+//     table bounds, the bucket's handful of keys in one round trip, and one
+//     8-byte {meta, offset} per hit.  0.98 ms; 46.8 M 64-byte requests = 2.92 GB
+//     by FETCH_SIZE -- MORE than the 2.5 GB key column it declines to stream: the
+//     kernel is bound by scattered sectors (3.0 TB/s of them), VALU 0.07.
+//   * THE MERGE (k_join_merge, KSLAM_JOIN=merge): the shape of the reference's
+//     findOverlaps (src/Overlap.h:230-246), cut into one segment per workgroup: the
+//     key range a tile of read records meets is streamed through LDS once, 16 bytes
+//     per lane.  0.93 ms on configs[1], 1.04 against 1.00 on the repeat-rich
+//     database, 1.71 against 1.69 per chunk on configs[2]: the stream is cheap
+//     (2.5 GB sequential) but the {meta, offset} gathers of 23 M hits remain, and
+//     they are half of the probe's sectors.  A wash within 5 % either way, and the
+//     probe does not care how sparse a batch is (the merge streams the column even
+//     for a handful of reads): the probe stays the default.
+// An AoS index ({key, meta, offset} in 16 bytes, one gather instead of two) was
+// priced and not built: keys and payloads of neighbouring buckets share sectors in
+// the two columns more often than a 16-byte record shares its sector with the next
+// probe's (42 M against 46.8 M requests expected: -10 %).
+// Output is a packed u64 per overlap (read | entry | rel + bias | revcomp) so that
+// the overlap sort is a keys-only radix sort over just the populated bytes.
 #include "common.h"
 
 namespace kslam {

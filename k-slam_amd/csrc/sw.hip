@@ -774,11 +774,13 @@ __global__ __launch_bounds__(256) void k_tier_scatter(const uint8_t *__restrict_
 template <int LMAX, int GL, int DPL, int BS = 256>
 __global__ __launch_bounds__(BS) void k_sw_band(kslam_overlap *__restrict__ ov, uint64_t n_cap, SwInputs in, SwParams p,
                                                  uint32_t *__restrict__ band0, const uint32_t *__restrict__ list,
-                                                 Tiers T, int self, const uint32_t *__restrict__ n_dev, uint32_t first) {
+                                                 Tiers T, int self, const uint32_t *__restrict__ n_dev, uint32_t first,
+                                                 uint32_t n_sure) {
   // n_dev: the list's length on the device, read now (the list was still growing when the host sized this launch for n_cap
-  // entries from `first` on); a workgroup beyond it leaves at once
+  // entries from `first` on); a workgroup beyond it leaves at once.  n_sure entries were there when the host looked: a
+  // workgroup inside them does not wait for the load
   uint64_t n = n_cap;
-  if (n_dev) {
+  if (n_dev && (uint64_t)(blockIdx.x + 1) * (BS / GL) > n_sure) {
     const uint32_t tot = *n_dev;
     n = min(n_cap, (uint64_t)(tot > first ? tot - first : 0u));
   }
@@ -1446,12 +1448,12 @@ void sw_scores(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, uint32_
     // saw at that tier (scaled by the chunks' sizes) + 4096: chunks of one run are statistically alike.  What did not fit,
     // and what that sends on, is left to rounds after the one read-back: each launches the part of every list nobody has
     // run yet.  A context's first chunk (no history) and a changed tier set go tier by tier as before.
-    auto launch_tier = [&](int k, uint64_t m, const uint32_t *n_dev, uint32_t first) {
+    auto launch_tier = [&](int k, uint64_t m, const uint32_t *n_dev, uint32_t first, uint32_t n_sure = 0) {
       const int nd = T.nd[k];
       const uint32_t *list = T.list[k];
 #define KSLAM_BAND(LM, GLV, DPLV, BSV) \
   hipLaunchKernelGGL((k_sw_band<LM, GLV, DPLV, BSV>), dim3((unsigned)((m + (BSV / GLV) - 1) / (BSV / GLV))), dim3(BSV), 0, s, \
-                     d_ov, m, in, p, d_band0, list, T, k, n_dev, first)
+                     d_ov, m, in, p, d_band0, list, T, k, n_dev, first, n_sure)
 #define KSLAM_BAND_LM(GLV, DPLV, BSV) \
   do { if (lm == 0) KSLAM_BAND(160, GLV, DPLV, BSV); else if (lm == 1) KSLAM_BAND(256, GLV, DPLV, BSV); \
        else KSLAM_BAND(512, GLV, DPLV, BSV); } while (0)
@@ -1476,7 +1478,7 @@ void sw_scores(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, uint32_
         const uint64_t room = k ? (uint64_t)(1.2 * scale * W.last_inflow[k]) + 4096 : 0;
         const uint64_t cap = std::min<uint64_t>(n, planned[k] + room);
         if (debug) fprintf(stderr, "[kslam] SW tier %d (%d diagonals): %u planned, sized for %llu\n", k, T.nd[k], planned[k], (unsigned long long)cap);
-        if (cap) launch_tier(k, cap, counts + k, 0);
+        if (cap) launch_tier(k, cap, counts + k, 0, planned[k]);
         done[k] = (uint32_t)cap;
       }
     }

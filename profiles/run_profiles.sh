@@ -3,9 +3,9 @@
 # (kernel-trace/stats and the two PMC passes are separate runs, as the pool requires)
 R=${1:-r01}
 REPO="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"; cd /tmp && export TMPDIR=/tmp; cd "$REPO" || exit 1; rm -rf /tmp/prof; mkdir -p /tmp/prof gpurun_out/keep
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof/kt -o x -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-abi-path --no-sam-pipeline --no-full-pipeline > gpurun_out/keep/${R}_bench_under_rocprof.json 2> /tmp/e1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/prof/pf -o x -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-abi-path --no-sam-pipeline --no-full-pipeline > /tmp/o2 2> /tmp/e2
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/prof/pw -o x -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-abi-path --no-sam-pipeline --no-full-pipeline > /tmp/o3 2> /tmp/e3
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof/kt -o x -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-full-pipeline > gpurun_out/keep/${R}_bench_under_rocprof.json 2> /tmp/e1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/prof/pf -o x -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-full-pipeline > /tmp/o2 2> /tmp/e2
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/prof/pw -o x -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-full-pipeline > /tmp/o3 2> /tmp/e3
 python3 - "$R" <<'PY'
 import csv, glob, json, sys
 R = sys.argv[1]
@@ -69,18 +69,27 @@ if phase.get('FETCH_SIZE') and phase.get('WRITE_SIZE'):
 # ---- the ONE-TIME sort of the genome k-mer records (kslam_set_index: the *_setup kernels; one index build per run) ----
 ISORT = ('k_tile_hist_setup', 'k_tile_hist_bytes_setup', 'k_scatter_setup')
 isum = {}
-for tag in ('FETCH_SIZE', 'WRITE_SIZE'):
+for tag, d in (('FETCH_SIZE', 'pf'), ('WRITE_SIZE', 'pw')):
+    rows = []
+    for f in glob.glob('/tmp/prof/%s/**/*counter_collection.csv' % d, recursive=True):
+        rows += [r for r in csv.DictReader(open(f)) if 'kslam' in r['Kernel_Name'] and r['Counter_Name'] == tag]
+    rows.sort(key=lambda r: int(r['Dispatch_Id']))
+    # the record sort ends where k_split_soa starts (since round 6 the membership filter's probe words go through the same
+    # *_setup kernels afterwards: not part of this sum)
+    ends = [int(r['Dispatch_Id']) for r in rows if clean(r['Kernel_Name']).startswith('k_split_soa')]
+    end = ends[0] if ends else 1 << 62
     tot, disp, by = 0.0, 0, {}
-    for k, cs in pmc.items():
-        if k.startswith(ISORT) and tag in cs:
-            tot += cs[tag][1]; disp += cs[tag][0]; by[k] = cs[tag][1]
+    for r in rows:
+        k = clean(r['Kernel_Name'])
+        if int(r['Dispatch_Id']) < end and k.startswith(ISORT):
+            v = float(r['Counter_Value']); tot += v; disp += 1; by[k] = by.get(k, 0.0) + v
     isum[tag] = (tot, disp, by)
 index_sort = None
 if isum['FETCH_SIZE'][1] and isum['WRITE_SIZE'][1]:
     f, w = isum['FETCH_SIZE'][0], isum['WRITE_SIZE'][0]
     index_sort = {'dispatches': isum['FETCH_SIZE'][1], 'fetch_kib_raw': f, 'write_kib_raw': w, 'bytes': int((2 * f + w) * 1024),
                   'by_kernel_fetch_kib': isum['FETCH_SIZE'][2], 'by_kernel_write_kib': isum['WRITE_SIZE'][2],
-                  'method': 'every dispatch of the one-time sort (k_tile_hist_setup<4>, k_tile_hist_bytes_setup, k_scatter_setup<4>; the three scan '
+                  'method': 'every dispatch of the one-time sort of the genome k-mer records, i.e. before k_split_soa (k_tile_hist_bytes_setup<...>, k_scatter_setup<4>; the three scan '
                             'kernels between them move < 0.1 % and share their names with the per-batch sort) of the run\'s single kslam_set_index; '
                             'FETCH_SIZE doubled (gfx950), WRITE_SIZE as is; unit KiB'}
     json.dump(index_sort, open('gpurun_out/keep/%s_index_sort_pmc.json' % R, 'w'), indent=1, sort_keys=True)

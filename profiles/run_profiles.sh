@@ -10,7 +10,7 @@ python3 - "$R" <<'PY'
 import csv, glob, json, sys
 R = sys.argv[1]
 def clean(n):
-    return n.replace('(anonymous namespace)::', '').replace('kslam::', '').replace('void ', '').split('(')[0]
+    return n.replace('(anonymous namespace)::', '').replace('kslam_api::', '').replace('kslam::', '').replace('void ', '').split('(')[0]
 rows = list(csv.reader(open(glob.glob('/tmp/prof/kt/**/*kernel_stats.csv', recursive=True)[0])))
 with open('gpurun_out/keep/%s_kernel_stats_kslam.csv' % R, 'w') as fh:
     w = csv.writer(fh); w.writerow(rows[0])

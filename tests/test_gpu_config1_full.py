@@ -15,22 +15,26 @@ pytestmark = pytest.mark.gpu
 PAIRS = int(os.environ.get("KSLAM_TEST_CONFIG1_PAIRS", "1000000"))
 
 
-def test_config1_full_batch_equals_the_reference(kslam, oracle):
+# configs[1] itself; configs[4]'s read length and configs[2]'s database (bacterial + 10 k viral genomes of 5-200 kb: short
+# entries, 11 250 ids) at half a batch each -- every one against the reference's own alignToDatabase on the 5 Gb database
+@pytest.mark.parametrize("read_len,pairs,n_viral", [(150, PAIRS, 0), (250, PAIRS // 2, 0), (150, PAIRS // 2, 10000)],
+                         ids=["configs1", "250bp", "bacterial+viral"])
+def test_config1_full_batch_equals_the_reference(kslam, oracle, read_len, pairs, n_viral):
     import torch
     assert torch.cuda.is_available(), "torch sees no HIP device"
     W = importlib.import_module("kslam_amd.workload")
     dev = torch.device("cuda", 0)
     gen = torch.Generator(device=dev)
     gen.manual_seed(1)
-    db, offs = W.make_database(dev, gen, 250, 5, 4_000_000)
+    db, offs = W.make_database(dev, gen, 250, 5, 4_000_000, n_viral=n_viral)
     n_entries = len(offs) - 1
     gen.manual_seed(2)
-    reads = W.make_reads(dev, gen, db, offs, PAIRS, read_len=150)
+    reads = W.make_reads(dev, gen, db, offs, pairs, read_len=read_len, by_length=n_viral > 0)
     ctx = kslam.Context()
     torch.cuda.synchronize()   # torch wrote the database on its own stream
     ctx.set_index_device(n_entries, db.data_ptr(), offs)
     flat = reads.reshape(-1)
-    ctx.load_reads_device(reads.shape[0], flat.data_ptr(), np.arange(reads.shape[0] + 1, dtype=np.uint64) * np.uint64(150))
+    ctx.load_reads_device(reads.shape[0], flat.data_ptr(), np.arange(reads.shape[0] + 1, dtype=np.uint64) * np.uint64(read_len))
     n_out, n_cig = ctx.align_resident()
     got, gcig = ctx.fetch_results(n_out, n_cig)
     ctx.close()
@@ -44,7 +48,7 @@ def test_config1_full_batch_equals_the_reference(kslam, oracle):
     if oracle.have_ref_slam():
         oracle.ref_slam_set_index_arrays(host_db, offs)
         exp, ecig, seconds, phases = oracle.ref_slam_align_to_database(
-            rn.reshape(-1), np.arange(rn.shape[0] + 1, dtype=np.uint64) * np.uint64(150), threads=oracle.usable_cpus())
+            rn.reshape(-1), np.arange(rn.shape[0] + 1, dtype=np.uint64) * np.uint64(read_len), threads=oracle.usable_cpus())
         oracle.ref_slam_set_index_arrays(host_db[:0], offs[:1])
         print("the reference's alignToDatabase: %.1f s on %d CPUs, phases %s" % (seconds, oracle.usable_cpus(), phases))
     else:
@@ -57,7 +61,7 @@ def test_config1_full_batch_equals_the_reference(kslam, oracle):
         finally:
             oracle.use_reference_ssw(False)
         del gl, rl
-    assert len(exp) == len(got) and len(got) > 7 * PAIRS
+    assert len(exp) == len(got) and len(got) > 5 * pairs
     v = oracle.compare_with_reference_rows(got, gcig, exp, ecig, rb, eb)
     print(v)
     assert v["identical"] and v["differing_rows_are_revcomp_ties"], v

@@ -8,7 +8,7 @@ import csv, glob, sys
 R = sys.argv[1]
 rows = list(csv.reader(open(glob.glob('/tmp/prof_fp/**/*kernel_stats.csv', recursive=True)[0])))
 def clean(n):
-    return n.replace('(anonymous namespace)::', '').replace('kslam::', '').replace('void ', '').split('(')[0]
+    return n.replace('(anonymous namespace)::', '').replace('kslam_api::', '').replace('kslam::', '').replace('void ', '').split('(')[0]
 with open('gpurun_out/keep/%s_full_pipeline_kernels.txt' % R, 'w') as fh:
     for r in rows[1:]:
         if 'kslam' in r[0]:

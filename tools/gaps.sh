@@ -4,7 +4,7 @@ rocprofv3 --kernel-trace --output-format csv -d /tmp/gp -o x -- python3 bench.py
 python3 - <<'PY'
 import csv, glob
 rows = list(csv.DictReader(open(glob.glob('/tmp/gp/**/*kernel_trace.csv', recursive=True)[0])))
-def clean(n): return n.replace('(anonymous namespace)::', '').replace('kslam::', '').replace('void ', '').split('(')[0]
+def clean(n): return n.replace('(anonymous namespace)::', '').replace('kslam_api::', '').replace('kslam::', '').replace('void ', '').split('(')[0]
 ks = sorted(((int(r['Start_Timestamp']), int(r['End_Timestamp']), clean(r['Kernel_Name'])) for r in rows if 'kslam' in r['Kernel_Name']))
 # last alignment call = from the last k_extract_filter (first kernel of a call) to the end
 starts = [i for i, k in enumerate(ks) if k[2].startswith('k_extract_filter')]

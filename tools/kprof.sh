@@ -4,7 +4,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kprof -o x -- pytho
 python3 - <<'PY'
 import csv, glob, json
 rows = list(csv.DictReader(open(glob.glob('/tmp/kprof/**/*kernel_stats.csv', recursive=True)[0])))
-def clean(n): return n.replace('(anonymous namespace)::', '').replace('kslam::', '').replace('void ', '').split('(')[0]
+def clean(n): return n.replace('(anonymous namespace)::', '').replace('kslam_api::', '').replace('kslam::', '').replace('void ', '').split('(')[0]
 for r in rows:
     if 'kslam' in r['Name'] and float(r['TotalDurationNs']) > 3e5:
         print("%-34s calls %4s  avg %9.3f ms  total/step %8.3f ms" % (clean(r['Name'])[:34], r['Calls'], float(r['AverageNs']) / 1e6, float(r['TotalDurationNs']) / 1e6 / 4))

@@ -7,7 +7,7 @@ import csv, glob
 f = glob.glob('/tmp/prof_ov/**/*kernel_trace.csv', recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 def clean(n):
-    return n.replace('(anonymous namespace)::', '').replace('kslam::', '').replace('void ', '').split('(')[0]
+    return n.replace('(anonymous namespace)::', '').replace('kslam_api::', '').replace('kslam::', '').replace('void ', '').split('(')[0]
 ev = [(int(r['Start_Timestamp']), int(r['End_Timestamp']), clean(r['Kernel_Name']), r.get('Queue_Id', ''), r.get('Stream_Id', '')) for r in rows if 'kslam' in r['Kernel_Name']]
 ev.sort()
 t0 = ev[0][0]

@@ -1,12 +1,12 @@
 # SQ instruction counters of the SW kernels for one bench step -> gpurun_out/keep/<tag>_valu.json
 TAG=${1:-r01f}
 REPO="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"; cd /tmp && export TMPDIR=/tmp; cd "$REPO" || exit 1; rm -rf /tmp/prof4; mkdir -p /tmp/prof4 gpurun_out/keep
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS --output-format csv -d /tmp/prof4 -o x -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-abi-path --no-sam-pipeline --no-full-pipeline > /tmp/o4 2> /tmp/e4
-rm -rf /tmp/prof5; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof5 -o x -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-abi-path --no-sam-pipeline --no-full-pipeline > /tmp/o5 2> /tmp/e5
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS --output-format csv -d /tmp/prof4 -o x -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-full-pipeline > /tmp/o4 2> /tmp/e4
+rm -rf /tmp/prof5; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof5 -o x -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-full-pipeline > /tmp/o5 2> /tmp/e5
 python3 - "$TAG" <<'PY'
 import csv, glob, json, sys
 tag = sys.argv[1]
-def clean(n): return n.replace('(anonymous namespace)::', '').replace('kslam::', '').replace('void ', '').split('(')[0]
+def clean(n): return n.replace('(anonymous namespace)::', '').replace('kslam_api::', '').replace('kslam::', '').replace('void ', '').split('(')[0]
 agg = {}
 ndisp = {}
 for f in glob.glob('/tmp/prof4/**/*counter_collection.csv', recursive=True):

@@ -12,7 +12,7 @@ for f in glob.glob('/tmp/kp/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
         n = r['Kernel_Name']
         if any(k in n for k in ('k_banded_lds', 'k_cigar_systolic', 'k_systolic_traceback', 'k_sw_band', 'k_join_fill', 'k_extract_filter')):
-            short = n.replace('(anonymous namespace)::', '').replace('kslam::', '').replace('void ', '').split('(')[0]
+            short = n.replace('(anonymous namespace)::', '').replace('kslam_api::', '').replace('kslam::', '').replace('void ', '').split('(')[0]
             a = agg[(short, r['Counter_Name'])]; a[0] += 1; a[1] += float(r['Counter_Value'])
 for (k, c), (n, v) in sorted(agg.items()):
     print(k, c, n, v / n)

@@ -21,7 +21,7 @@ agg = collections.defaultdict(lambda: [0, 0.0])
 for f in glob.glob('/tmp/kp/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
         if 'k_join' in r['Kernel_Name']:
-            name = r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('kslam::', '').replace('void ', '').split('(')[0]
+            name = r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('kslam_api::', '').replace('kslam::', '').replace('void ', '').split('(')[0]
             a = agg[(name, r['Counter_Name'])]; a[0] += 1; a[1] += float(r['Counter_Value'])
 for (k, c), (n, v) in sorted(agg.items()):
     print(sys.argv[1], k, c, 'dispatches', n, 'mean', v / n)
@@ -40,6 +40,6 @@ for mode in ('probe', 'merge'):
         except Exception as e:
             print(mode, wl, 'missing', e); continue
         k = [r for r in rows if 'k_join' in r['Name']]
-        print(mode, wl, [(r['Name'].replace('(anonymous namespace)::', '').replace('kslam::', '').replace('void ', '').split('(')[0], r['Calls'], round(float(r['AverageNs']) / 1e6, 4)) for r in k],
+        print(mode, wl, [(r['Name'].replace('(anonymous namespace)::', '').replace('kslam_api::', '').replace('kslam::', '').replace('void ', '').split('(')[0], r['Calls'], round(float(r['AverageNs']) / 1e6, 4)) for r in k],
               j['hot_path']['phases_ms']['ms_join'], j['hot_path']['ms_per_step'], j['hot_path']['verified']['ok'], j['hot_path']['counts']['overlaps_raw'])
 PY

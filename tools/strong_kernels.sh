@@ -3,7 +3,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/sprof -o x -- pytho
 python3 - <<'PY'
 import csv, glob
 rows = list(csv.DictReader(open(glob.glob('/tmp/sprof/**/*kernel_stats.csv', recursive=True)[0])))
-def clean(n): return n.replace('(anonymous namespace)::', '').replace('kslam::', '').replace('void ', '').split('(')[0]
+def clean(n): return n.replace('(anonymous namespace)::', '').replace('kslam_api::', '').replace('kslam::', '').replace('void ', '').split('(')[0]
 tot=0
 for r in sorted(rows, key=lambda r: -float(r['TotalDurationNs'])):
     if 'kslam' in r['Name'] and float(r['TotalDurationNs']) > 2e6:

@@ -10,7 +10,7 @@ import csv, glob, sys
 R = sys.argv[1]
 rows = list(csv.reader(open(glob.glob('/tmp/prof_250/**/*kernel_stats.csv', recursive=True)[0])))
 def clean(n):
-    return n.replace('(anonymous namespace)::', '').replace('kslam::', '').replace('void ', '').split('(')[0]
+    return n.replace('(anonymous namespace)::', '').replace('kslam_api::', '').replace('kslam::', '').replace('void ', '').split('(')[0]
 with open('gpurun_out/keep/%s_kernel_stats_250bp.txt' % R, 'w') as fh:
     fh.write('# rocprofv3 --kernel-trace --stats of: bench.py --read-len 250 --steps 3 --warmup 1 (6 timed-or-warm steps + verification runs)\n')
     for r in rows[1:]:

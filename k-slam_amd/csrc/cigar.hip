@@ -372,6 +372,14 @@ __global__ __launch_bounds__(64) void k_banded_lds(CigJob J, SwInputs in, SwPara
       rsrc = in.genome_codes + go + s0 + (o.revcomp ? (wlen - 1 - o.ref_end) : (int64_t)o.ref_begin);
     }
   }
+  if constexpr (REG_BW > 0) {
+    // a window no longer than its band does not fit the register sweep (banded_attempt_reg wants refLen > 2 bw + 1), and this
+    // instantiation keeps no row arrays: to the one-lane kernel (the whole wave takes part in the append)
+    const bool hand = !skip && !(band_width <= REG_BW && refLen > 2 * band_width + 1);
+    if (hand) J.needbig[ci] = 3;
+    append_candidate(hand, ci, J.special_list, J.special_count);
+    skip = skip || hand;
+  }
   if (J.variant == 4) return;   // ablation: candidate header loads only
   // stage the two spans as SSW codes (ssw_cpp.cpp:11-23): the wave together, eight lanes per candidate
   const int32_t oq = stage_codes_wave(qsrc, skip ? 0 : readLen, false, SQ, NL, lane);
@@ -435,9 +443,7 @@ __global__ __launch_bounds__(64) void k_banded_lds(CigJob J, SwInputs in, SwPara
   } A{S, SQ, SR, D, NL, lane, Y.W1, (uint32_t)(band_width * 2 + 1), oq, orf, DW, Y.wpr, 0u};
   (void)score;
   int32_t mx;
-  bool in_regs = false;
-  if constexpr (REG_BW > 0) in_regs = band_width <= REG_BW && refLen > 2 * band_width + 1;
-  if (in_regs) {
+  if constexpr (REG_BW > 0) {
     // direction words in the global slab, [row * WPR + word][lane]; slot x of row i
     constexpr uint32_t WPR = (2 * (REG_BW > 0 ? REG_BW : 1) + 1 + 5) / 6;
     mx = banded_attempt_reg<(REG_BW > 0 ? REG_BW : 1)>(A, reinterpret_cast<uint32_t *>(D), NL, lane, refLen,
@@ -902,6 +908,7 @@ void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, u
       uint32_t *bin_count = nullptr, *special_list = nullptr, *special_count = nullptr, *big_count = nullptr;
       const uint32_t *count_dev = nullptr;   // the list's length where the kernels read it (CigJob::m_dev); then `m` is a capacity
       uint32_t sure = 0;                     // ... and this many entries of the list are known to exist
+      bool no_reg = false;                   // the one-lane kernel whatever the band (the candidates the others handed over)
       uint32_t first = 0;                    // the launch starts at this entry of the list
     };
     auto launch_systolic = [&](uint64_t m, uint32_t slot_bw, uint32_t bin, const Route &R) -> bool {
@@ -973,11 +980,22 @@ void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, u
       // LDS-instruction bound, not bound by the traceback's loads, and the extra 38 KB per block cost
       // more occupancy than the traceback gained (class 1: 7.9 ms against 2.8 ms).
       Y.nch = ((lmax + 30) >> 4) + 1;   // 15 bytes of misalignment in front, up to 15 behind
-      const size_t base_lane = (size_t)2 * Y.nch * 8 + (size_t)3 * Y.W1 * sizeof(int16_t);
       const uint32_t wpr_fit = (Y.wd + 5) / 6;
       const bool dir_in_lds = tune.cigar_dirs_lds &&
-                              (base_lane + (size_t)lmax * wpr_fit * 4) * 16 + 64 <= 64 * 1024;
+                              ((size_t)2 * Y.nch * 8 + (size_t)3 * Y.W1 * sizeof(int16_t) + (size_t)lmax * wpr_fit * 4) * 16 + 64 <= 64 * 1024;
       Y.wpr = dir_in_lds ? wpr_fit : 0;
+      // narrow bands: the band in registers (KSLAM_CIGAR_REG=0 turns it off)
+      const bool use_reg = tune.cigar_reg && !R.no_reg;
+      // (a class-0 candidate has band 1: three slots, not the five of the band-2 instantiation it used to share)
+      const uint32_t reg_bw = (!use_reg || big || Y.wpr) ? 0u : (slot_bw <= 1 ? 1u : (slot_bw <= 2 ? 2u : (slot_bw <= 4 ? 4u : (slot_bw <= 8 ? 8u : (slot_bw <= 16 ? 16u : 0u)))));
+      // The register kernels keep no row arrays in LDS (round 6): a candidate they cannot hold -- a window no longer than its
+      // band -- goes to the one-lane kernel through the same list the systolic kernels hand theirs over on.  3-5 KB less per
+      // workgroup: 13 instead of 10 workgroups per CU for band 2.
+      if (reg_bw) {
+        if (!R.special_list) throw StatusError{KSLAM_ERR_STATE, "a register-band launch needs a hand-over list"};
+        Y.W1 = 0;
+      }
+      const size_t base_lane = (size_t)2 * Y.nch * 8 + (size_t)3 * Y.W1 * sizeof(int16_t);
       const size_t per_lane = base_lane + (size_t)lmax * Y.wpr * 4;
       uint32_t nl = 64;
       while (nl > 1 && per_lane * nl + 64 > 64 * 1024) nl >>= 1;   // <= 64 KB: at least two blocks per CU
@@ -994,10 +1012,6 @@ void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, u
                               reinterpret_cast<const void *>(&k_banded_lds<8>),
                               reinterpret_cast<const void *>(&k_banded_lds<16>)})
           HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      // narrow bands: the band in registers (KSLAM_CIGAR_REG=0 turns it off)
-      const bool use_reg = tune.cigar_reg;
-      // (a class-0 candidate has band 1: three slots, not the five of the band-2 instantiation it used to share)
-      const uint32_t reg_bw = (!use_reg || big || Y.wpr) ? 0u : (slot_bw <= 1 ? 1u : (slot_bw <= 2 ? 2u : (slot_bw <= 4 ? 4u : (slot_bw <= 8 ? 8u : (slot_bw <= 16 ? 16u : 0u)))));
       uint64_t slab = Y.wpr ? 256 : (uint64_t)lmax * std::max<uint32_t>(Y.wd, reg_bw ? 8u : 0u) * nl;   // direction
       slab = (slab + 255) & ~255ull;   // bytes per block; the register variant stores <= 8 bytes per row and lane
       const uint64_t SCRATCH_BUDGET = 3ull << 30;
@@ -1011,6 +1025,8 @@ void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, u
         if (R.bin_list) for (int k = 0; k < 8; k++) J.bin_list[k] = R.bin_list[k];
         J.bin_count = R.bin_list ? R.bin_count : nullptr;
         J.big_count = R.big_count;
+        J.special_list = reg_bw ? R.special_list : nullptr;
+        J.special_count = reg_bw ? R.special_count : nullptr;
         const uint64_t nb_here = std::min<uint64_t>(blocks_per_launch, n_blocks - b0);
         J.list_base = R.first + (uint32_t)(b0 * nl);
         J.m_dev = R.count_dev;
@@ -1078,8 +1094,8 @@ void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, u
         R.big_count = cnt + 9;
         R.count_dev = cnt + bin;
         R.sure = hc[bin];
-        if (launch_systolic(cap, slot_bw, bin, R)) special_bw = std::max(special_bw, slot_bw);
-        else launch(cap, slot_bw, false, R);
+        if (!launch_systolic(cap, slot_bw, bin, R)) launch(cap, slot_bw, false, R);
+        special_bw = std::max(special_bw, slot_bw);    // (register bins hand over too: windows no longer than their band)
         done[bin] = (uint32_t)cap;       // (clamped to the list's length below)
       }
     }
@@ -1094,6 +1110,7 @@ void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, u
         R2.bin_list = lists;
         R2.bin_count = cnt;
         R2.big_count = cnt + 9;
+        R2.no_reg = true;
         launch(hc[8], special_bw, false, R2);
         HIPCHK(hipMemsetAsync(cnt + 8, 0, sizeof(uint32_t), s));
         special_bw = 0;
@@ -1112,8 +1129,8 @@ void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, u
         R.special_list = W.special.as<uint32_t>();
         R.special_count = cnt + 8;
         R.big_count = cnt + 9;
-        if (launch_systolic(m, slot_bw, bin, R)) special_bw = std::max(special_bw, slot_bw);
-        else launch(m, slot_bw, false, R);
+        if (!launch_systolic(m, slot_bw, bin, R)) launch(m, slot_bw, false, R);
+        special_bw = std::max(special_bw, slot_bw);
         done[bin] = hc[bin];
         progressed = true;
       }
@@ -1143,6 +1160,7 @@ void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, u
             Route R2 = R;
             R2.list = W.special.as<uint32_t>();
             R2.special_list = nullptr;
+            R2.no_reg = true;
             launch(hc[8], slot_bw, false, R2);
             HIPCHK(hipMemsetAsync(cnt + 8, 0, sizeof(uint32_t), s));
           }

@@ -137,10 +137,12 @@ void build_index(kslam_ctx *c) {
               c->recs_a.as<uint4>(), first_digits ? c->sortws.digits.as<uint8_t>() : nullptr, first_digits ? &passes[0] : nullptr);
   c->sortws.use_digit_bytes = c->tune.sort_digit_bytes;
   c->sortws.first_digits_ready = first_digits;
+  c->sortws.meta_digits_in_runs = n && m / n >= 64;     // (a database of many tiny entries has as many ids as records in a tile)
   HIPCHK(hipEventRecord(e1, s));
   void *sorted = radix_sort(c->recs_a.p, c->recs_b.p, m, 4, passes.data(), (int)passes.size(), c->sortws, s,
                             nullptr, nullptr, nullptr, /*setup=*/true);
   c->sortws.first_digits_ready = false;
+  c->sortws.meta_digits_in_runs = false;
   HIPCHK(hipEventRecord(e2, s));
   c->gk_key.ensure((m + 1) * sizeof(uint64_t));
   c->gk_meta.ensure((m + 1) * sizeof(uint2));   // {meta, offset} pairs

@@ -264,6 +264,8 @@ struct SortWorkspace {
   bool use_digit_bytes = true;   // KSLAM_SORT_DIGIT_BYTES=0: every histogram re-reads the records (A/B)
   bool first_digits_ready = false;   // `digits` already holds the FIRST pass's digit of every record (the producer of the
                                      // records wrote them: extract_filtered); the caller sets and clears it around one sort
+  bool meta_digits_in_runs = false;  // set around the one-time sort of genome records when entries hold many k-mers each: the meta word's
+                                     // digits then come in long runs of few values, and their histograms take the kernel made for that
   hipEvent_t *ev_sc0 = nullptr, *ev_sc1 = nullptr;   // optional per-pass events around k_scatter
   uint32_t epoch = 0;
 };

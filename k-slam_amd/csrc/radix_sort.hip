@@ -96,23 +96,18 @@ __global__ __launch_bounds__(256) void k_tile_hist_bytes(const uint8_t *__restri
                                                          uint32_t *__restrict__ tile_hist) {
   tile_hist_bytes_body(dig, n, tile_hist);
 }
-// The one-time sorts' byte histogram (312 M digit bytes per pass for the 5 Gb database), in two shapes the host picks per
-// pass.  Digits of the K-MER bytes are spread over the 256 values: HT = 4 tiles per workgroup, their 16-byte loads all in
-// flight before the first LDS atomic, one histogram per tile (0.10 ms per pass).  Digits of the META word take a handful of
-// values (the high id bits of 1 250 entries, the revComp bit): 64 lanes adding to two or ten LDS addresses serialise -- such a
-// pass's histogram took 1.09 ms in round 5.  For those: one tile per workgroup and a private copy of the histogram per LANE
-// position (HC = 64 copies, 64 KB of LDS: no two lanes of a wave ever meet on an address), summed when the counts are written.
-template <uint32_t HT, uint32_t HC>
+// The one-time sorts' byte histograms (312 M digit bytes per pass for the 5 Gb database), two kernels the host picks from per
+// pass.  Both: HT = 4 tiles per workgroup, their 16-byte loads all in flight before the first LDS operation, a histogram per tile.
+constexpr uint32_t HT = 4;
+// (1) digits of the K-MER bytes are spread over the 256 values: an LDS atomic per digit (0.10 ms per pass).
 __global__ __launch_bounds__(256) void k_tile_hist_bytes_setup(const uint8_t *__restrict__ dig, uint32_t n, uint32_t n_tiles,
                                                                uint32_t *__restrict__ tile_hist) {
-  __shared__ uint32_t h[HT][HC][256];
+  __shared__ uint32_t h[HT][256];
   const uint32_t tid = threadIdx.x;
-  {
-    uint4 *z = reinterpret_cast<uint4 *>(&h[0][0][0]);
-    for (uint32_t x = tid; x < HT * HC * 64; x += 256) z[x] = make_uint4(0, 0, 0, 0);
-  }
+#pragma unroll
+  for (uint32_t t = 0; t < HT; t++) h[t][tid] = 0;
   __syncthreads();
-  const uint32_t tile0 = blockIdx.x * HT, copy = tid & (HC - 1u);
+  const uint32_t tile0 = blockIdx.x * HT;
   uint4 v[HT];
 #pragma unroll
   for (uint32_t t = 0; t < HT; t++) {
@@ -128,20 +123,85 @@ __global__ __launch_bounds__(256) void k_tile_hist_bytes_setup(const uint8_t *__
 #pragma unroll
       for (int k = 0; k < 4; k++)
 #pragma unroll
-        for (int b = 0; b < 4; b++) atomicAdd(&h[t][copy][(w[k] >> (8 * b)) & 0xFFu], 1u);
+        for (int b = 0; b < 4; b++) atomicAdd(&h[t][(w[k] >> (8 * b)) & 0xFFu], 1u);
     } else {
-      for (uint32_t i = base; i < n && i < base + 16; i++) atomicAdd(&h[t][copy][dig[i]], 1u);
+      for (uint32_t i = base; i < n && i < base + 16; i++) atomicAdd(&h[t][dig[i]], 1u);
     }
   }
   __syncthreads();
 #pragma unroll
   for (uint32_t t = 0; t < HT; t++)
-    if (tile0 + t < n_tiles) {
-      uint32_t sum = 0;
-#pragma unroll 16
-      for (uint32_t c = 0; c < HC; c++) sum += h[t][c][tid];
-      tile_hist[(uint64_t)(tile0 + t) * 256 + tid] = sum;
+    if (tile0 + t < n_tiles) tile_hist[(uint64_t)(tile0 + t) * 256 + tid] = h[t][tid];
+}
+// (2) digits of the META word take a handful of values -- the low id byte is ONE value over a whole tile of records in
+// extraction order, the {revComp, high id bits} digit two to ten -- and 64 lanes adding to one or two LDS addresses serialise
+// (1.09 ms per such pass with kernel (1); 0.8 with 64 private copies of the histogram, whose zeroing and summing cost more
+// than the atomics they spared).  Here a thread first counts its OWN 16 bytes per distinct value (byte-parallel compare
+// against the first byte not yet counted: one or two rounds), the wave then adds up the counts of the lanes that hold
+// the same value (ballot + butterfly), and ONE lane per value and wave touches the histogram.  Only right for such digits:
+// 16 distinct bytes in a thread would be 16 rounds.
+__global__ __launch_bounds__(256) void k_tile_hist_bytes_skew_setup(const uint8_t *__restrict__ dig, uint32_t n, uint32_t n_tiles,
+                                                                    uint32_t *__restrict__ tile_hist) {
+  __shared__ uint32_t h[HT][256];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
+#pragma unroll
+  for (uint32_t t = 0; t < HT; t++) h[t][tid] = 0;
+  __syncthreads();
+  const uint32_t tile0 = blockIdx.x * HT;
+  uint4 v[HT];
+#pragma unroll
+  for (uint32_t t = 0; t < HT; t++) {
+    const uint32_t base = (tile0 + t) * SORT_TILE + tid * 16;
+    v[t] = (tile0 + t < n_tiles && base + 16 <= n) ? *reinterpret_cast<const uint4 *>(dig + base) : make_uint4(0, 0, 0, 0);
+  }
+#pragma unroll
+  for (uint32_t t = 0; t < HT; t++) {
+    const uint32_t base = (tile0 + t) * SORT_TILE + tid * 16;
+    if (tile0 + t >= n_tiles) break;
+    const bool whole = base + 16 <= n;
+    if (!whole)    // (the list's last, partial 16 bytes: one thread of the whole launch)
+      for (uint32_t i = base; i < n && i < base + 16; i++) atomicAdd(&h[t][dig[i]], 1u);
+    const uint32_t w[4] = {v[t].x, v[t].y, v[t].z, v[t].w};
+    uint32_t done[4] = {0, 0, 0, 0};   // 0x80 in every byte already counted
+    bool more = whole;
+    while (__any(more)) {
+      uint32_t val = 0, cnt = 0;
+      if (more) {
+        // the first byte not yet counted
+        const uint32_t r0 = ~done[0] & 0x80808080u, r1 = ~done[1] & 0x80808080u, r2 = ~done[2] & 0x80808080u, r3 = ~done[3] & 0x80808080u;
+        const uint32_t k = r0 ? 0u : (r1 ? 1u : (r2 ? 2u : 3u));
+        const uint32_t rk = r0 ? r0 : (r1 ? r1 : (r2 ? r2 : r3)), wk = k == 0 ? w[0] : (k == 1 ? w[1] : (k == 2 ? w[2] : w[3]));
+        val = (wk >> (((uint32_t)__builtin_ctz(rk)) & 24u)) & 0xFFu;
+        const uint32_t pat = val * 0x01010101u;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const uint32_t x = w[q] ^ pat;
+          uint32_t eq = (x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;
+          eq = ~(eq | x | 0x7F7F7F7Fu);                 // 0x80 exactly in the bytes of w[q] that equal val
+          cnt += (uint32_t)__builtin_popcount(eq);
+          done[q] |= eq;
+        }
+        more = (done[0] & done[1] & done[2] & done[3]) != 0x80808080u;
+      }
+      // the wave's lanes that hold the same value add up; one lane per value touches LDS
+      uint64_t todo = __ballot(cnt != 0);
+      while (todo) {
+        const int leader = (int)__builtin_ctzll(todo);
+        const uint32_t vl = (uint32_t)__shfl((int)val, leader, 64);
+        const bool mine = cnt != 0 && val == vl;
+        const uint64_t m = __ballot(mine);
+        uint32_t part = mine ? cnt : 0u;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) part += (uint32_t)__shfl_xor((int)part, d, 64);
+        if ((int)lane == leader) atomicAdd(&h[t][vl], part);
+        todo &= ~m;
+      }
     }
+  }
+  __syncthreads();
+#pragma unroll
+  for (uint32_t t = 0; t < HT; t++)
+    if (tile0 + t < n_tiles) tile_hist[(uint64_t)(tile0 + t) * 256 + tid] = h[t][tid];
 }
 
 // ---- scan of the tile histograms (per digit, over tiles) --------------------------------------
@@ -374,8 +434,8 @@ void sort_impl(void *a, void *b, uint32_t n, const PassList &pl, SortWorkspace &
   for (int p = 0; p < pl.n; p++) {
     if (SETUP && digits && (p > 0 || ws.first_digits_ready)) {
       // a digit of few values (a pass over the meta word of k-mer records): the conflict-free shape
-      if (RW == 4 && pl.p[p].word == 2) hipLaunchKernelGGL((k_tile_hist_bytes_setup<1, 64>), dim3(tiles), dim3(256), 0, s, (const uint8_t *)digits, n, tiles, tile_hist);
-      else hipLaunchKernelGGL((k_tile_hist_bytes_setup<4, 1>), dim3((tiles + 3) / 4), dim3(256), 0, s, (const uint8_t *)digits, n, tiles, tile_hist);
+      if (RW == 4 && pl.p[p].word == 2 && ws.meta_digits_in_runs) hipLaunchKernelGGL(k_tile_hist_bytes_skew_setup, dim3((tiles + HT - 1) / HT), dim3(256), 0, s, (const uint8_t *)digits, n, tiles, tile_hist);
+      else hipLaunchKernelGGL(k_tile_hist_bytes_setup, dim3((tiles + HT - 1) / HT), dim3(256), 0, s, (const uint8_t *)digits, n, tiles, tile_hist);
     }
     else if (SETUP) hipLaunchKernelGGL(k_tile_hist_setup<RW>, dim3(tiles), dim3(RS_BLOCK), 0, s, (const T *)src, n, pl.p[p], tile_hist);
     else if (digits && (p > 0 || ws.first_digits_ready)) hipLaunchKernelGGL(k_tile_hist_bytes, dim3(tiles), dim3(256), 0, s, (const uint8_t *)digits, n, tile_hist);

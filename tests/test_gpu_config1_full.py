@@ -16,17 +16,20 @@ PAIRS = int(os.environ.get("KSLAM_TEST_CONFIG1_PAIRS", "1000000"))
 
 
 # configs[1] itself; configs[4]'s read length and configs[2]'s database (bacterial + 10 k viral genomes of 5-200 kb: short
-# entries, 11 250 ids) at half a batch each -- every one against the reference's own alignToDatabase on the 5 Gb database
-@pytest.mark.parametrize("read_len,pairs,n_viral", [(150, PAIRS, 0), (250, PAIRS // 2, 0), (150, PAIRS // 2, 10000)],
-                         ids=["configs1", "250bp", "bacterial+viral"])
-def test_config1_full_batch_equals_the_reference(kslam, oracle, read_len, pairs, n_viral):
+# entries, 11 250 ids) at half a batch each; a quarter batch against the repeat-rich database (rRNA-like segments and insertion
+# elements shared by hundreds of entries: the join's long pile-ups, (read, entry) groups of tens of keys, 6.7 candidates per read
+# instead of 4) -- every one against the reference's own alignToDatabase on the 5 Gb database
+@pytest.mark.parametrize("read_len,pairs,n_viral,repeats", [(150, PAIRS, 0, False), (250, PAIRS // 2, 0, False), (150, PAIRS // 2, 10000, False),
+                                                            (150, PAIRS // 4, 0, True)],
+                         ids=["configs1", "250bp", "bacterial+viral", "repeat-rich"])
+def test_config1_full_batch_equals_the_reference(kslam, oracle, read_len, pairs, n_viral, repeats):
     import torch
     assert torch.cuda.is_available(), "torch sees no HIP device"
     W = importlib.import_module("kslam_amd.workload")
     dev = torch.device("cuda", 0)
     gen = torch.Generator(device=dev)
     gen.manual_seed(1)
-    db, offs = W.make_database(dev, gen, 250, 5, 4_000_000, n_viral=n_viral)
+    db, offs = W.make_database(dev, gen, 250, 5, 4_000_000, n_viral=n_viral, repeats=repeats)
     n_entries = len(offs) - 1
     gen.manual_seed(2)
     reads = W.make_reads(dev, gen, db, offs, pairs, read_len=read_len, by_length=n_viral > 0)
@@ -61,7 +64,7 @@ def test_config1_full_batch_equals_the_reference(kslam, oracle, read_len, pairs,
         finally:
             oracle.use_reference_ssw(False)
         del gl, rl
-    assert len(exp) == len(got) and len(got) > 5 * pairs
+    assert len(exp) == len(got) and len(got) > 5 * pairs, (len(exp), len(got))
     v = oracle.compare_with_reference_rows(got, gcig, exp, ecig, rb, eb)
     print(v)
     assert v["identical"] and v["differing_rows_are_revcomp_ties"], v

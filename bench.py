@@ -13,9 +13,16 @@ resident in HBM (what `value` was in rounds 1-2), with the `roofline` objects at
                                --no-pseudo-assembly
   --config 2                   configs[2]: 10 M pairs per batch vs bacterial + 10 k viral genomes, pseudo-assembly on
   --config 4                   configs[4]: 10 M x 2 x 250 bp pairs per batch vs the bacterial database
-  --gpus N > 1 (config 3)      ONE batch of --total-pairs pairs per step, read pairs sharded over the N GPUs, gathered to
-                               rank 0 (RCCL over xGMI), batch-global tail and SAM text on rank 0.  Without a launcher
-                               (WORLD_SIZE unset) bench.py starts the N rank processes itself.
+  --gpus N > 1 (config 3)      ONE batch of --total-pairs pairs per step, read pairs sharded over the N GPUs: `value` = every
+                               rank classifies its own read pairs (insert sizes all-gathered, pseudo-assembly by entry over
+                               RCCL, its part of the SAM file written); `hot_path` = the merged records gathered to rank 0.
+                               The line carries the N = 1 point of this workload measured in the same run
+                               (`n1_same_workload`).  Without a launcher (WORLD_SIZE unset) bench.py starts the ranks itself.
+
+The N = 1 line's legs: the hot path + its verification, the e2e leg (`value`), `cpu_baseline` (the reference's own
+alignToDatabase compiled in place, timed on the host cores; oracle/ is used by this leg only) and `strong_n1` (the N > 1
+lines' workload on this one GPU).  More evidence on request: --legs abi_path,other_sink,null_sink,pseudo | all.
+The legs themselves: bench_legs.py.
 
 Prints ONE JSON line on rank 0 (the driver contract of the task statement).
 """

@@ -1,7 +1,8 @@
 // api_core.hip -- the C ABI (include/kslam.h), part 1: context life cycle, tuning switches, page-locked pools, loading reads,
 // fetching results and the operator entry point.  The hot path is alignToDatabase (reference src/SLAM.h:59-79) as
-//   extract read k-mers -> radix sort -> merge-join against the resident sorted
-//   genome k-mer list -> overlap sort + dedupe -> SW scores -> banded CIGAR.
+//   extract read k-mers -> radix sort -> join against the resident sorted genome
+//   k-mer list (a probe; a merge behind KSLAM_JOIN=merge) -> overlap sort + dedupe -> SW scores -> banded CIGAR
+// (api_align.hip).
 // All device work runs on the context's own HIP stream; phases are bracketed
 // with HIP events.  No CPU fallback exists: without a HIP device every entry
 // point fails with KSLAM_ERR_NO_DEVICE.

@@ -42,6 +42,7 @@ Tuning read_tuning() {
   t.join_group_order = starts("KSLAM_JOIN_GROUP_ORDER", '0') ? 0 : 1;
   t.join_merge = starts("KSLAM_JOIN", 'm') ? 1 : 0;
   t.sw_sweep = !starts("KSLAM_SW_SWEEP", '0');
+  t.sweep_room = !starts("KSLAM_SWEEP_ROOM", '0');
   t.filter_build_sorted = !starts("KSLAM_FILTER_BUILD", 'a');      // =atomics: the scattered read-modify-write build (A/B)
   t.details_in_token = !starts("KSLAM_DETAILS_IN_TOKEN", '0');
 #ifdef KSLAM_ABLATE

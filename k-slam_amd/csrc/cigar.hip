@@ -1080,7 +1080,7 @@ void cigar_traceback(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, u
     {
       uint64_t before = 0;
       for (uint32_t bin = 0; bin < 7; bin++) {
-        const uint64_t room = before <= 65536 ? before : std::max<uint64_t>(65536, before / 8);   // (spare workgroups cost ~1 ns each)
+        const uint64_t room = !tune.sweep_room ? 0 : (before <= 65536 ? before : std::max<uint64_t>(65536, before / 8));   // (spare workgroups cost ~1 ns each)
         const uint64_t cap = hc[bin] + room;
         before += hc[bin];
         if (cap == 0) continue;

@@ -58,6 +58,8 @@ struct Tuning {
   int plan_blocks_per_cu = 64;        // KSLAM_PLAN_BLOCKS: workgroups of k_sw_plan per CU (its waves walk through the candidates)
   int join_group_order = 1;           // KSLAM_JOIN_GROUP_ORDER=0: the overlap keys go through all their radix passes (join.hip: group_order)
   bool sw_sweep = true;               // KSLAM_SW_SWEEP=0: a read-back in front of every SW tier (as until round 5)
+  bool sweep_room = true;             // KSLAM_SWEEP_ROOM=0 (tests): the CIGAR bins' and SW tiers' launches get NO room for what earlier ones send
+                                      // on, so that every such candidate takes the left-over rounds
   int join_merge = 0;                 // KSLAM_JOIN=merge: k_join_merge instead of the probe k_join_fill (join.hip)
   bool filter_build_sorted = true;    // KSLAM_FILTER_BUILD=atomics: the membership filter by scattered atomics instead of block by block (filter.hip)
   int pseudo_cap = 0;                 // KSLAM_PSEUDO_CAP (tests): alignment pairs of one entry beyond which pseudo-assembly is left to the host; 0 = 262144

@@ -66,9 +66,9 @@ struct Probe {
   uint32_t s0, s1, s2, s3; // bit number inside each dword of the piece
 };
 
-// `kmer` and `rc` are the two strands of one 32-mer (either order): the result is the same for both
-__device__ inline Probe probe_of(uint64_t kmer, uint64_t rc, uint32_t line_bits) {
-  const uint32_t mini = min(min_window16(kmer), min_window16(rc));
+// `kmer` and `rc` are the two strands of one 32-mer (either order): the result is the same for both.  `mini`: the k-mer's
+// canonical minimizer = the smallest 16-mer over both strands = min(min_window16(kmer), min_window16(rc))
+__device__ inline Probe probe_with_minimizer(uint64_t kmer, uint64_t rc, uint32_t mini, uint32_t line_bits) {
   const uint64_t canon = kmer < rc ? kmer : rc;
   const uint32_t h = ((uint32_t)canon * 0x9E3779B1u) ^ ((uint32_t)(canon >> 32) * 0x85EBCA77u);
   const uint32_t g = h ^ (h >> 15);
@@ -77,6 +77,29 @@ __device__ inline Probe probe_of(uint64_t kmer, uint64_t rc, uint32_t line_bits)
   p.piece = (line << 3) | (g >> 29);
   p.s0 = g & 31u; p.s1 = (g >> 5) & 31u; p.s2 = (g >> 10) & 31u; p.s3 = (g >> 15) & 31u;
   return p;
+}
+__device__ inline Probe probe_of(uint64_t kmer, uint64_t rc, uint32_t line_bits) {
+  return probe_with_minimizer(kmer, rc, min(min_window16(kmer), min_window16(rc)), line_bits);
+}
+// reverse complement of a 16-mer held as 32 bits (the 64-bit form: revcomp64)
+__device__ inline uint32_t revcomp32(uint32_t f) {
+  uint32_t x = __brev(f ^ 0xAAAAAAAAu);
+  return ((x & 0x55555555u) << 1) | ((x >> 1) & 0x55555555u);
+}
+// min over the lanes of the 16-lane row at and below / at and above this one (DPP row shifts; a lane without a source keeps its own)
+__device__ inline uint32_t row_prefix_min(uint32_t v) {
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x111, 0xF, 0xF, false));   // row_shr:1
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x112, 0xF, 0xF, false));
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x114, 0xF, 0xF, false));
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x118, 0xF, 0xF, false));
+  return v;
+}
+__device__ inline uint32_t row_suffix_min(uint32_t v) {
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x101, 0xF, 0xF, false));   // row_shl:1
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x102, 0xF, 0xF, false));
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x104, 0xF, 0xF, false));
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x108, 0xF, 0xF, false));
+  return v;
 }
 
 __global__ void k_filter_build(const uint64_t *__restrict__ keys, uint32_t n, uint32_t line_bits,
@@ -289,15 +312,38 @@ __global__ __launch_bounds__(FW * 64) void k_extract_filter(const uint8_t *__res
         }
       }
     };
+    // The minimizers of a chunk of 128 k-mers from the read's 16-MERS (round 6).  A k-mer's canonical minimizer is the smallest of
+    // its 17 windows over both strands, and window j of k-mer q is the 16-mer at read position q + j whichever k-mer looks at
+    // it: so c(p) = min(16-mer at p, its reverse complement) is computed ONCE per position (a lane takes positions q0 + lane,
+    // + 64, and the first 16 lanes + 128), and k-mer q's minimizer is the minimum of c over [q, q + 16] -- by van Herk's
+    // blocks: positions fall into the wave's rows of 16 lanes, and 17 consecutive ones are the suffix of one row from q on
+    // plus the prefix of the next row up to q + 16 (the same lane of the next row).  Row prefix / suffix minima are four
+    // DPP shifts each.  (probe_of computes the same value from the two 64-bit strands, 17 windows each: 66 operations per
+    // k-mer, of which this keeps about 35 per PAIR of k-mers.)
+    auto canon16 = [&](uint32_t pos) -> uint32_t {
+      if (pos + 16u > len) return 0xFFFFFFFFu;              // beyond the read's last 16-mer: no k-mer's window
+      const uint32_t sidx = m + pos, wi = sidx >> 4, sh = (sidx & 15u) * 2u;
+      const uint32_t f = (uint32_t)((((((uint64_t)my[wi]) << 32) | my[wi + 1]) << sh) >> 32);
+      return min(f, revcomp32(f));
+    };
     for (uint32_t q0 = 0; q0 < nk; q0 += 128) {
       const uint32_t qa = q0 + lane, qb = q0 + 64 + lane;
       const Cut ca = cut(qa), cb = cut(qb);
+      uint32_t mini_a, mini_b;
+      {
+        const uint32_t c0 = canon16(qa), c1 = canon16(qb), c2 = lane < 16u ? canon16(q0 + 128u + lane) : 0xFFFFFFFFu;
+        const uint32_t p0 = row_prefix_min(c0), p1 = row_prefix_min(c1), p2 = row_prefix_min(c2);
+        const int up = (int)((lane + 16u) & 63u);             // the same lane of the next row (of the next register for the last row)
+        const uint32_t a0 = (uint32_t)__shfl((int)p0, up, 64), a1 = (uint32_t)__shfl((int)p1, up, 64), a2 = (uint32_t)__shfl((int)p2, up, 64);
+        mini_a = min(row_suffix_min(c0), lane < 48u ? a0 : a1);
+        mini_b = min(row_suffix_min(c1), lane < 48u ? a1 : a2);
+      }
       Probe pa, pb;
       if (KSLAM_FILTER_ABLATED(2u)) {   // measurement only: no minimizer (a pseudo-random line per k-mer)
         pa.piece = (uint32_t)((ca.fwd * 0x9E3779B97F4A7C15ull) >> (64 - line_bits - 3)); pa.s0 = pa.s1 = pa.s2 = pa.s3 = (uint32_t)ca.rc & 31u;
         pb.piece = (uint32_t)((cb.fwd * 0x9E3779B97F4A7C15ull) >> (64 - line_bits - 3)); pb.s0 = pb.s1 = pb.s2 = pb.s3 = (uint32_t)cb.rc & 31u;
       } else {
-        pa = probe_of(ca.fwd, ca.rc, line_bits); pb = probe_of(cb.fwd, cb.rc, line_bits);
+        pa = probe_with_minimizer(ca.fwd, ca.rc, mini_a, line_bits); pb = probe_with_minimizer(cb.fwd, cb.rc, mini_b, line_bits);
       }
       uint4 fa, fb;
       if (KSLAM_FILTER_ABLATED(1u)) {   // measurement only: no probe load

@@ -1475,7 +1475,7 @@ void sw_scores(kslam_overlap *d_ov, uint64_t n, SwInputs in, SwParams p, uint32_
     if (history) {
       const double scale = (double)n / (double)W.last_n;
       for (int k = 0; k < T.n; k++) {
-        const uint64_t room = k ? (uint64_t)(1.2 * scale * W.last_inflow[k]) + 4096 : 0;
+        const uint64_t room = k && tune.sweep_room ? (uint64_t)(1.2 * scale * W.last_inflow[k]) + 4096 : 0;
         const uint64_t cap = std::min<uint64_t>(n, planned[k] + room);
         if (debug) fprintf(stderr, "[kslam] SW tier %d (%d diagonals): %u planned, sized for %llu\n", k, T.nd[k], planned[k], (unsigned long long)cap);
         if (cap) launch_tier(k, cap, counts + k, 0, planned[k]);

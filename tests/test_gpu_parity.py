@@ -659,6 +659,8 @@ def test_every_kernel_variant_gives_the_same_alignments(kslam, synth, monkeypatc
                 {"KSLAM_SW_UNKNOWN_ND": "64"},
                 {"KSLAM_SORT_DIGIT_BYTES": "0"},                     # radix histograms re-read the records
                 {"KSLAM_JOIN_GROUP_ORDER": "0"},                     # overlap keys through all their radix passes (no group ranking)
+                {"KSLAM_SWEEP_ROOM": "0"},                           # CIGAR bins / SW tiers sized without room: every candidate sent on takes the left-over rounds
+                {"KSLAM_SW_SWEEP": "0"},                             # a read-back in front of every SW tier
                 {"KSLAM_JOIN": "merge"},                             # the merge join instead of the probe (join.hip: k_join_merge)
                 {"KSLAM_JOIN": "merge", "KSLAM_SORT_BYTES": "1"},    # ... with read records ordered by their top byte only
                 {"KSLAM_JOIN": "merge", "KSLAM_SORT_BYTES": "8"}]    # ... and by the whole key
@@ -667,6 +669,8 @@ def test_every_kernel_variant_gives_the_same_alignments(kslam, synth, monkeypatc
             monkeypatch.setenv(k, v)
         c.reload_tuning()                 # the switches are read at kslam_create, not per batch
         got, gcig = c.align_batch(rb)
+        if "KSLAM_SWEEP_ROOM" in env:     # (the SW tiers' sweep is sized from the context's previous chunk: once more)
+            got, gcig = c.align_batch(rb)
         for k in env:
             monkeypatch.delenv(k)
         _compare_alignments(got, gcig, base, bcig)

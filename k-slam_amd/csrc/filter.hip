@@ -270,17 +270,6 @@ __global__ __launch_bounds__(FW * 64) void k_extract_filter(const uint8_t *__res
     const uint32_t nk = len - KSLAM_K + 1; // gap 1 (src/KMer.h:378)
     const uint32_t idbits = (r_begin + i) & 0x3FFFFFFFu;
 
-    auto cut = [&](uint32_t q) -> Cut {
-      Cut c;
-      c.valid = q < nk;
-      const uint32_t sidx = m + (c.valid ? q : 0u);
-      const uint32_t wi = sidx >> 4, sh = (sidx & 15u) * 2u;
-      const uint32_t W0 = my[wi], W1 = my[wi + 1], W2 = my[wi + 2];
-      const uint64_t a = ((uint64_t)W0 << 32) | W1, b = ((uint64_t)W1 << 32) | W2;
-      c.fwd = ((a << sh) & 0xFFFFFFFF00000000ull) | ((b << sh) >> 32);
-      c.rc = revcomp64(c.fwd);
-      return c;
-    };
     auto keep_record = [&](const Cut &c, uint32_t q, bool pass) {
       const bool is_fwd = c.fwd < c.rc;    // src/KMer.h:173 (palindromes take the rc branch)
       const uint64_t kmer = is_fwd ? c.fwd : c.rc;
@@ -320,23 +309,36 @@ __global__ __launch_bounds__(FW * 64) void k_extract_filter(const uint8_t *__res
     // plus the prefix of the next row up to q + 16 (the same lane of the next row).  Row prefix / suffix minima are four
     // DPP shifts each.  (probe_of computes the same value from the two 64-bit strands, 17 windows each: 66 operations per
     // k-mer, of which this keeps about 35 per PAIR of k-mers.)
-    auto canon16 = [&](uint32_t pos) -> uint32_t {
-      if (pos + 16u > len) return 0xFFFFFFFFu;              // beyond the read's last 16-mer: no k-mer's window
+    // ... and the k-mers themselves are two such 16-mers: fwd(q) = F(q) : F(q + 16), its reverse complement
+    // R(q + 16) : R(q) with R = the 16-mer's own reverse complement -- the values c() was made of, one row up.
+    struct Mer16 { uint32_t f, r, c; };
+    auto mer16 = [&](uint32_t pos) -> Mer16 {
+      Mer16 x{0u, 0u, 0xFFFFFFFFu};
+      if (pos + 16u > len) return x;                        // beyond the read's last 16-mer: no k-mer's window
       const uint32_t sidx = m + pos, wi = sidx >> 4, sh = (sidx & 15u) * 2u;
-      const uint32_t f = (uint32_t)((((((uint64_t)my[wi]) << 32) | my[wi + 1]) << sh) >> 32);
-      return min(f, revcomp32(f));
+      x.f = (uint32_t)((((((uint64_t)my[wi]) << 32) | my[wi + 1]) << sh) >> 32);
+      x.r = revcomp32(x.f);
+      x.c = min(x.f, x.r);
+      return x;
     };
     for (uint32_t q0 = 0; q0 < nk; q0 += 128) {
       const uint32_t qa = q0 + lane, qb = q0 + 64 + lane;
-      const Cut ca = cut(qa), cb = cut(qb);
+      Cut ca, cb;
       uint32_t mini_a, mini_b;
       {
-        const uint32_t c0 = canon16(qa), c1 = canon16(qb), c2 = lane < 16u ? canon16(q0 + 128u + lane) : 0xFFFFFFFFu;
-        const uint32_t p0 = row_prefix_min(c0), p1 = row_prefix_min(c1), p2 = row_prefix_min(c2);
+        const Mer16 x0 = mer16(qa), x1 = mer16(qb), x2 = lane < 16u ? mer16(q0 + 128u + lane) : Mer16{0u, 0u, 0xFFFFFFFFu};
+        const uint32_t p0 = row_prefix_min(x0.c), p1 = row_prefix_min(x1.c), p2 = row_prefix_min(x2.c);
         const int up = (int)((lane + 16u) & 63u);             // the same lane of the next row (of the next register for the last row)
-        const uint32_t a0 = (uint32_t)__shfl((int)p0, up, 64), a1 = (uint32_t)__shfl((int)p1, up, 64), a2 = (uint32_t)__shfl((int)p2, up, 64);
-        mini_a = min(row_suffix_min(c0), lane < 48u ? a0 : a1);
-        mini_b = min(row_suffix_min(c1), lane < 48u ? a1 : a2);
+        const bool same = lane < 48u;
+        auto up_a = [&](uint32_t v0, uint32_t v1) { const uint32_t a = (uint32_t)__shfl((int)v0, up, 64), b = (uint32_t)__shfl((int)v1, up, 64); return same ? a : b; };
+        mini_a = min(row_suffix_min(x0.c), up_a(p0, p1));
+        mini_b = min(row_suffix_min(x1.c), up_a(p1, p2));
+        ca.valid = qa < nk;
+        cb.valid = qb < nk;
+        ca.fwd = ((uint64_t)x0.f << 32) | up_a(x0.f, x1.f);
+        ca.rc = ((uint64_t)up_a(x0.r, x1.r) << 32) | x0.r;
+        cb.fwd = ((uint64_t)x1.f << 32) | up_a(x1.f, x2.f);
+        cb.rc = ((uint64_t)up_a(x1.r, x2.r) << 32) | x1.r;
       }
       Probe pa, pb;
       if (KSLAM_FILTER_ABLATED(2u)) {   // measurement only: no minimizer (a pseudo-random line per k-mer)

@@ -67,7 +67,7 @@ if phase.get('FETCH_SIZE') and phase.get('WRITE_SIZE'):
     json.dump(sp, open('gpurun_out/keep/%s_sort_phase_pmc.json' % R, 'w'), indent=1, sort_keys=True)
     print('sort phase:', sp['bytes_per_call'], 'bytes per alignment call over', sp['dispatches_per_call'], 'dispatches')
 # ---- the ONE-TIME sort of the genome k-mer records (kslam_set_index: the *_setup kernels; one index build per run) ----
-ISORT = ('k_tile_hist_setup', 'k_tile_hist_bytes_setup', 'k_scatter_setup')
+ISORT = ('k_tile_hist_setup', 'k_tile_hist_bytes_setup', 'k_tile_hist_bytes_skew_setup', 'k_scatter_setup')
 isum = {}
 for tag, d in (('FETCH_SIZE', 'pf'), ('WRITE_SIZE', 'pw')):
     rows = []

@@ -1,5 +1,8 @@
 #!/bin/bash
-# round 6 against round 5 on ONE box: the hot path (resident batch) with each round's library, alternating
+# round 6 against round 5 on ONE box: the hot path (resident batch) with each round's library, alternating.
+# The round-5 library is not in the tree; build it first (in the container, the .so travels with the snapshot):
+#   mkdir -p /tmp/r05src && git archive c1833de k-slam_amd include | tar -x -C /tmp/r05src && make -C /tmp/r05src/k-slam_amd/csrc -j8 ../libkslam_hip.so
+#   cp /tmp/r05src/k-slam_amd/libkslam_hip.so k-slam_amd/libkslam_hip_r05.so      (git-ignored; same C ABI, loaded through KSLAM_LIB)
 REPO="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"; cd /tmp && export TMPDIR=/tmp; cd "$REPO" || exit 1
 O=gpurun_out/r06; mkdir -p $O
 BA="--steps 10 --warmup 3 --no-cpu-baseline --no-full-pipeline"

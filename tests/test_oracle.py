@@ -375,6 +375,26 @@ def test_the_real_align_to_database_template_and_the_full_size_comparison(oracle
     assert not oracle.compare_with_reference_rows(got[:-1], gcig, one, ocig, rb, eb)["identical"]
 
 
+def test_reference_log_stamps_become_phase_times(oracle, tmp_path):
+    """bench.py's cpu_baseline.phases_s: the reference's own log.txt stamps (src/sequenceTools.h:171-179, `[t = 1.23s]\t<text>`) of
+    the LAST alignToDatabase call, each phase from its stamp to the next phase's, Smith-Waterman to the end of the call."""
+    from oracle.binding import _ref_log_phases
+    log = tmp_path / "log.txt"
+    log.write_text("[t = 0.00s]\tBuilding taxonomy index\n"
+                   "[t = 1.00s]\tAligning reads to database using k = 32\n[t = 1.00s]\tGetting k-mers from reads\n"
+                   "[t = 1.50s]\tObtained 5 k-mers\n[t = 1.50s]\tGetting k-mers from index\n[t = 2.00s]\tSorting k-mers\n"
+                   "[t = 2.10s]\tFinding overlaps\n[t = 2.20s]\tPerforming pairwise Smith-Waterman\n"
+                   "[t = 10.00s]\tAligning reads to database using k = 32\n[t = 10.01s]\tGetting k-mers from reads\n"
+                   "[t = 10.35s]\tObtained 238000000 k-mers\n[t = 10.35s]\tGetting k-mers from index\n[t = 12.30s]\tObtained 312498224 k-mers\n"
+                   "[t = 12.31s]\tSorting k-mers\n[t = 15.90s]\tFinding overlaps\n[t = 17.10s]\tFound 8153847 k-mer overlaps\n"
+                   "[t = 17.15s]\tPerforming pairwise Smith-Waterman\n")
+    ph = _ref_log_phases(str(log), 19.5)
+    assert ph == {"extract": 0.34, "genome_kmers": 1.96, "sort": 3.59, "join": 1.25, "sw": 12.35}
+    assert _ref_log_phases(str(tmp_path / "missing.txt"), 1.0) is None
+    (tmp_path / "other.txt").write_text("[t = 0.00s]\tBuilding taxonomy index\n")
+    assert _ref_log_phases(str(tmp_path / "other.txt"), 1.0) is None
+
+
 # ---- the committed answers of the real reference (recorded by tests/golden/make_golden.py --pins): these run anywhere ----
 def _cols(z, name):
     flat, off = z[name], z[name + "_off"]

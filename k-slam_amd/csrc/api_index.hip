@@ -146,31 +146,36 @@ void build_index(kslam_ctx *c) {
   HIPCHK(hipEventRecord(e2, s));
   c->gk_key.ensure((m + 1) * sizeof(uint64_t));
   c->gk_meta.ensure((m + 1) * sizeof(uint2));   // {meta, offset} pairs
-  if (m) hipLaunchKernelGGL(k_split_soa, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, (const uint4 *)sorted,
-                            (uint32_t)m, c->gk_key.as<uint64_t>(), c->gk_meta.as<uint2>());
   uint32_t bits = 8, max_bits = (uint32_t)c->tune.bucket_bits_max;   // 27: ~2.3 genome k-mers per bucket for a 5 Gb database (537 MB table)
   while (bits < max_bits && (m >> (bits + 2)) != 0) bits++;   // 2 to 4 keys per bucket (measured: 3.06 ms at 27 bits, 3.24 at 26, 3.13 at 28)
   if (c->tune.bucket_bits_exact) bits = (uint32_t)c->tune.bucket_bits_exact;   // tuning
   c->bucket_bits = bits;
   c->g_bucket.ensure(((1ull << bits) + 2) * sizeof(uint32_t));
-  build_bucket_table(c->gk_key.as<uint64_t>(), (uint32_t)m, bits, c->g_bucket.as<uint32_t>(), s);
   // membership filter for the read extraction: ~14 bits per genome k-mer (9.3 keys per 128-bit piece),
   // 2^32 bits = 512 MiB for the 312 M k-mers of a 5 Gb database.  KSLAM_FILTER_BITS: log2 of the size
   // in bits, 0 = extract, sort and look up every read k-mer as the reference does.
-  {
-    uint32_t fb = 20;
-    while (fb < 35 && ((uint64_t)1 << fb) < m * 12) fb++;
-    if (c->tune.filter_bits >= 0) fb = (uint32_t)c->tune.filter_bits;
-    c->filter_bits = fb;
-    if (fb) {
-      c->g_filter.ensure(filter_bytes(fb));
-      if (c->tune.filter_build_sorted) {
-        // the probe words take the record buffers of the sort that has just finished (k_split_soa, queued above, was their last reader)
-        c->pos.ensure((filter_bytes(fb) / 32768 + 2) * sizeof(uint32_t));
-        filter_build_sorted(c->gk_key.as<uint64_t>(), (uint32_t)m, fb, c->g_filter.p, c->recs_a.p, c->recs_b.p, c->pos.as<uint32_t>(), c->sortws, s);
-      } else {
-        filter_build(c->gk_key.as<uint64_t>(), (uint32_t)m, fb, c->g_filter.p, s);
-      }
+  uint32_t fb = 20;
+  while (fb < 35 && ((uint64_t)1 << fb) < m * 12) fb++;
+  if (c->tune.filter_bits >= 0) fb = (uint32_t)c->tune.filter_bits;
+  c->filter_bits = fb;
+  if (fb) c->g_filter.ensure(filter_bytes(fb));
+  // the probe words of the filter's build go through the record buffers of the sort that has just finished: the one that does not
+  // hold the sorted list takes them first
+  void *other = sorted == c->recs_a.p ? c->recs_b.p : c->recs_a.p;
+  bool fused = false;
+  if (fb && c->tune.filter_build_sorted)
+    fused = split_columns_and_tables(sorted, (uint32_t)m, c->gk_key.as<uint64_t>(), c->gk_meta.p, bits, c->g_bucket.as<uint32_t>(), fb, other, c->sortws, s);
+  if (!fused) {
+    if (m) hipLaunchKernelGGL(k_split_soa, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, (const uint4 *)sorted,
+                              (uint32_t)m, c->gk_key.as<uint64_t>(), c->gk_meta.as<uint2>());
+    build_bucket_table(c->gk_key.as<uint64_t>(), (uint32_t)m, bits, c->g_bucket.as<uint32_t>(), s);
+  }
+  if (fb) {
+    if (c->tune.filter_build_sorted) {
+      c->pos.ensure((filter_bytes(fb) / 32768 + 2) * sizeof(uint32_t));
+      filter_build_sorted(c->gk_key.as<uint64_t>(), (uint32_t)m, fb, c->g_filter.p, other, sorted, c->pos.as<uint32_t>(), c->sortws, s, fused);
+    } else {
+      filter_build(c->gk_key.as<uint64_t>(), (uint32_t)m, fb, c->g_filter.p, s);
     }
   }
   HIPCHK(hipEventRecord(e3, s));

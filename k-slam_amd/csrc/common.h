@@ -183,7 +183,12 @@ void filter_build(const uint64_t *d_sorted_keys, uint32_t n, uint32_t log2_bits,
 // d_words_a / _b: n + 1 u64 each; d_block_start: (filter bytes / 32 KB) + 2 u32
 struct SortWorkspace;
 void filter_build_sorted(const uint64_t *d_sorted_keys, uint32_t n, uint32_t log2_bits, void *d_filter, void *d_words_a, void *d_words_b,
-                         uint32_t *d_block_start, SortWorkspace &ws, hipStream_t s);
+                         uint32_t *d_block_start, SortWorkspace &ws, hipStream_t s, bool words_ready = false);
+// One pass over the sorted genome records for all of: the key column, the {meta, offset} column, the bucket table (2^bucket_bits + 1
+// lower bounds) and the filter's probe words in d_words (+ their first sort digit in ws.digits) -- then filter_build_sorted(...,
+// words_ready = true).  false: not applicable (empty list, filter smaller than a block), nothing was done.
+bool split_columns_and_tables(const void *d_sorted_recs, uint32_t n, uint64_t *d_key, void *d_meta_off, uint32_t bucket_bits, uint32_t *d_bucket,
+                              uint32_t log2_bits, void *d_words, SortWorkspace &ws, hipStream_t s);
 // reads d_off[0..n_reads] (gap 1, ids = position in d_off): surviving records appended at *d_cursor
 // (which ends as their number); nothing is written beyond `cap` (the caller reruns with a larger buffer)
 // d_digits != nullptr: also byte digit_word / digit_shift of every record written (the first radix pass's digit), at

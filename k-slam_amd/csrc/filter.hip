@@ -137,6 +137,42 @@ __global__ __launch_bounds__(256) void k_filter_words(const uint64_t *__restrict
   }
   words[i] = w;
 }
+// The three tables of the index from ONE pass over the sorted genome records (round 6, second half): the key column and the
+// {meta, offset} column (what k_split_soa wrote), the bucket table over the top key bits (what join.hip's k_bucket computed from
+// the key column: lower bounds, written where the bucket number changes), the key's probe word (k_filter_words) and the first
+// digit byte of the probe words' sort.  The three kernels each streamed the 312 M keys again.
+__global__ __launch_bounds__(256) void k_split_tables(const uint4 *__restrict__ recs, uint32_t n, uint64_t *__restrict__ key,
+                                                      uint2 *__restrict__ mo, uint32_t bucket_shift, uint32_t nb,
+                                                      uint32_t *__restrict__ bucket, uint32_t line_bits, uint64_t *__restrict__ words,
+                                                      uint8_t *__restrict__ digits, uint32_t digit_shift) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint4 r = recs[i];
+  const uint64_t k = ((uint64_t)r.y << 32) | r.x;
+  bool have_prev = i > 0;
+  uint64_t kp = 0;
+  if (have_prev) {
+    const uint2 p = *reinterpret_cast<const uint2 *>(recs + (i - 1));   // the left neighbour's key (same cache line three times in four)
+    kp = ((uint64_t)p.y << 32) | p.x;
+  }
+  key[i] = k;
+  mo[i] = make_uint2(r.z, r.w);
+  {   // bucket[x] = first index whose key's top bits are >= x
+    const uint32_t b = (uint32_t)(k >> bucket_shift);
+    const int64_t bp = have_prev ? (int64_t)(kp >> bucket_shift) : -1;
+    for (int64_t x = bp + 1; x <= (int64_t)b; x++) bucket[x] = i;
+    if (i == n - 1)
+      for (uint32_t x = b + 1; x <= nb; x++) bucket[x] = n;
+  }
+  uint64_t w = 1ull << (20 + 3 + line_bits);
+  if (k != 0 && !(have_prev && kp == k)) {
+    const Probe p = probe_of(k, revcomp64(k), line_bits);
+    w = ((uint64_t)p.piece << 20) | ((uint64_t)p.s3 << 15) | (p.s2 << 10) | (p.s1 << 5) | p.s0;
+  }
+  words[i] = w;
+  digits[i] = (uint8_t)((w >> digit_shift) & 0xFFu);
+}
+
 // block_start[b] = index of the first word of block b (words ordered by block; join.hip's offsets kernel)
 __global__ __launch_bounds__(256) void k_filter_fill(const uint64_t *__restrict__ words, const uint32_t *__restrict__ block_start,
                                                      uint4 *__restrict__ filter) {
@@ -374,22 +410,35 @@ void filter_build(const uint64_t *d_sorted_keys, uint32_t n, uint32_t log2_bits,
   HIPCHK(hipGetLastError());
 }
 
+bool split_columns_and_tables(const void *d_sorted_recs, uint32_t n, uint64_t *d_key, void *d_meta_off, uint32_t bucket_bits, uint32_t *d_bucket,
+                              uint32_t log2_bits, void *d_words, SortWorkspace &ws, hipStream_t s) {
+  const uint32_t line_bits = log2_bits - 10, piece_bits = line_bits + 3;
+  if (n == 0 || log2_bits < 20 || piece_bits < FBLK_BITS) return false;     // the caller takes the separate kernels
+  ws.digits.ensure((size_t)n + 64);
+  hipLaunchKernelGGL(k_split_tables, dim3((n + 255) / 256), dim3(256), 0, s, (const uint4 *)d_sorted_recs, n, d_key, (uint2 *)d_meta_off,
+                     64 - bucket_bits, 1u << bucket_bits, d_bucket, line_bits, (uint64_t *)d_words, ws.digits.as<uint8_t>(), 20 + FBLK_BITS);
+  HIPCHK(hipGetLastError());
+  return true;
+}
+
 void filter_build_sorted(const uint64_t *d_sorted_keys, uint32_t n, uint32_t log2_bits, void *d_filter, void *d_words_a, void *d_words_b,
-                         uint32_t *d_block_start, SortWorkspace &ws, hipStream_t s) {
+                         uint32_t *d_block_start, SortWorkspace &ws, hipStream_t s, bool words_ready) {
   const uint32_t line_bits = log2_bits - 10, piece_bits = line_bits + 3;
   if (n == 0 || piece_bits < FBLK_BITS) {         // (a filter smaller than one block: never chosen by kslam_set_index, fb >= 20)
     filter_build(d_sorted_keys, n, log2_bits, d_filter, s);
     return;
   }
   const uint32_t n_blocks = 1u << (piece_bits - FBLK_BITS);
-  hipLaunchKernelGGL(k_filter_words, dim3((n + 255) / 256), dim3(256), 0, s, d_sorted_keys, n, line_bits, (uint64_t *)d_words_a);
+  if (!words_ready) hipLaunchKernelGGL(k_filter_words, dim3((n + 255) / 256), dim3(256), 0, s, d_sorted_keys, n, line_bits, (uint64_t *)d_words_a);
   // radix passes over the block number and the "belongs to no block" bit above it: key bits [20 + FBLK_BITS, 20 + piece_bits]
   SortPass passes[8];
   int np = 0;
   for (uint32_t sh = 20 + FBLK_BITS; sh <= 20 + piece_bits; sh += 8) passes[np++] = SortPass{2u, sh, 0};
   const bool keep = ws.use_digit_bytes;
   ws.use_digit_bytes = true;
+  ws.first_digits_ready = words_ready;      // (k_split_tables wrote the first pass's digit of every word)
   const uint64_t *words = (const uint64_t *)radix_sort(d_words_a, d_words_b, n, 2, passes, np, ws, s, nullptr, nullptr, nullptr, /*setup=*/true);
+  ws.first_digits_ready = false;
   ws.use_digit_bytes = keep;
   build_offsets_table(words, n, 20 + FBLK_BITS, n_blocks + 1, d_block_start, s);   // [0, n_blocks]: starts; the words of no block follow
   hipLaunchKernelGGL(k_filter_fill, dim3(n_blocks), dim3(256), 0, s, words, d_block_start, (uint4 *)d_filter);

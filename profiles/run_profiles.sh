@@ -76,7 +76,7 @@ for tag, d in (('FETCH_SIZE', 'pf'), ('WRITE_SIZE', 'pw')):
     rows.sort(key=lambda r: int(r['Dispatch_Id']))
     # the record sort ends where k_split_soa starts (since round 6 the membership filter's probe words go through the same
     # *_setup kernels afterwards: not part of this sum)
-    ends = [int(r['Dispatch_Id']) for r in rows if clean(r['Kernel_Name']).startswith('k_split_soa')]
+    ends = [int(r['Dispatch_Id']) for r in rows if clean(r['Kernel_Name']).startswith(('k_split_soa', 'k_split_tables'))]
     end = ends[0] if ends else 1 << 62
     tot, disp, by = 0.0, 0, {}
     for r in rows:

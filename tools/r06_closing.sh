@@ -7,5 +7,5 @@ mkdir -p gpurun_out/keep gpurun_out/r06
 bash profiles/run_profiles.sh $R 2>&1 | tail -8
 bash tools/pmc_valu.sh $R 2>&1 | tail -4
 bash tools/final_runs.sh ${R}z 2>&1 | tail -9
-timeout 900 python tools/soak.py 300 61000 > gpurun_out/keep/${R}_soak.txt 2>&1; tail -1 gpurun_out/keep/${R}_soak.txt
+if [ -z "$NO_SOAK" ]; then timeout 900 python tools/soak.py 300 61000 > gpurun_out/keep/${R}_soak.txt 2>&1; tail -1 gpurun_out/keep/${R}_soak.txt; fi
 ls gpurun_out/keep | grep "^$R" | head -40

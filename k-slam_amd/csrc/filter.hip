@@ -86,19 +86,20 @@ __device__ inline uint32_t revcomp32(uint32_t f) {
   uint32_t x = __brev(f ^ 0xAAAAAAAAu);
   return ((x & 0x55555555u) << 1) | ((x >> 1) & 0x55555555u);
 }
-// min over the lanes of the 16-lane row at and below / at and above this one (DPP row shifts; a lane without a source keeps its own)
+// min over the lanes of the 16-lane row at and below / at and above this one (DPP row shifts; a lane without a source takes the identity)
+// (`old` = the identity of min, so that the compiler can fold the shift into the v_min_u32 itself)
 __device__ inline uint32_t row_prefix_min(uint32_t v) {
-  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x111, 0xF, 0xF, false));   // row_shr:1
-  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x112, 0xF, 0xF, false));
-  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x114, 0xF, 0xF, false));
-  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x118, 0xF, 0xF, false));
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x111, 0xF, 0xF, false));   // row_shr:1
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x112, 0xF, 0xF, false));
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x114, 0xF, 0xF, false));
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x118, 0xF, 0xF, false));
   return v;
 }
 __device__ inline uint32_t row_suffix_min(uint32_t v) {
-  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x101, 0xF, 0xF, false));   // row_shl:1
-  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x102, 0xF, 0xF, false));
-  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x104, 0xF, 0xF, false));
-  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x108, 0xF, 0xF, false));
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x101, 0xF, 0xF, false));   // row_shl:1
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x102, 0xF, 0xF, false));
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x104, 0xF, 0xF, false));
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x108, 0xF, 0xF, false));
   return v;
 }
 
